@@ -1,0 +1,836 @@
+/*
+ * rq_oracle.c -- CPU ORACLE for the RaptorQ precode-solve + symbol-generation path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (nanorq_amd/, include/) links, loads or
+ * calls this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * What it is: a from-scratch C restatement of the algorithm of sleepybishop/nanorq
+ * (reference tree mounted read-only at /root/reference; citations below are file:line in
+ * that tree).  It follows the reference step for step -- same constraint-matrix layout, same
+ * row/column selection order in the symbolic stage, same operation list, same 4-pass replay --
+ * so that (a) outputs are what the reference produces and (b) the operation counts n1/nB/n0
+ * that define the "algorithmic bytes" of SURVEY.md section 8(d) can be read off a run.
+ * Data structures are this file's own (flat CSR-ish arrays, a dense byte work matrix) --
+ * the reference's kvec/spmat/wrkmat containers are not reproduced.
+ *
+ * Third-party dependency that is ABSENT from /root/reference: deps/oblas
+ * (github.com/sleepybishop/oblas, submodule, pinned commit unknown, directory empty:
+ * .gitmodules:1-3).  nanorq uses it for GF(256) row kernels (oaxpy/oscal/oswaprow/
+ * oaxpy_b32), the octmat/gf2mat containers and the OCT_EXP/OCT_LOG/OCT_INV tables.  Its
+ * published algorithm is restated here: GF(256) is RFC 6330 section 5.7 (polynomial
+ * x^8+x^4+x^3+x^2+1 = 0x11D, generator alpha = 2); oaxpy(a,b,i,j,k,beta) is
+ * a[i][0..k) ^= beta*b[j][0..k); oscal(a,i,k,beta) is a[i][0..k) *= beta.
+ * Because that dependency is missing the reference is UNBUILDABLE in this image and no
+ * oracle/_ref binary exists.
+ *
+ * PARITY PIN: the known-answer vectors of SURVEY.md section 8(c) (repair symbols / SHA-256 for
+ * K=10/100/1024/8192, produced during the survey by the reference's own lib/*.c) are
+ * checked in tests/test_oracle_kat.py, together with RFC 6330's systematic property.
+ * The reference itself ships no golden vectors, so beyond those KATs
+ * parity is pinned by uniqueness of the solution of A*C = D, not by reference fixtures.
+ */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+#include "../nanorq_amd/csrc/rfc6330_tables.h" /* RFC 6330 constants (data only) */
+
+/* ------------------------------------------------------------------------------------------
+ * RFC 6330 constants
+ * ---------------------------------------------------------------------------------------- */
+static const struct { uint16_t kp, j, s, h, w; } T2[RQ_TABLE2_COUNT] = {RQ_TABLE2_ROWS};
+static const uint32_t VT[4][256] = {RQ_V_WORDS};
+
+/* degree distribution, RFC 6330 section 5.3.5.2 (reference tuple.c:4-8) */
+static const uint32_t DEG_F[31] = {
+    0,       5243,    529531,  704294,  791675,  844104,  879057,  904023,  922747,  937311, 948962,
+    958494,  966438,  973160,  978921,  983914,  988283,  992138,  995565,  998631,  1001391,
+    1003887, 1006157, 1008229, 1010129, 1011876, 1013490, 1014983, 1016370, 1017662, 1048576};
+
+typedef struct {
+  uint32_t Kp, J, S, H, W, L, P, P1, U, B;
+} orc_params_t;
+
+static int is_prime_u32(uint32_t n) {
+  if (n < 2) return 0;
+  for (uint32_t f = 2; f * f <= n; f++)
+    if (n % f == 0) return 0;
+  return 1;
+}
+
+/* reference params.c:21-45 */
+static int derive_params(uint32_t K, orc_params_t *p) {
+  int found = -1;
+  for (int r = 0; r < RQ_TABLE2_COUNT; r++)
+    if (K <= T2[r].kp) { found = r; break; }
+  if (found < 0 || K == 0) return 0;
+  p->Kp = T2[found].kp; p->J = T2[found].j; p->S = T2[found].s; p->H = T2[found].h; p->W = T2[found].w;
+  p->L = p->Kp + p->S + p->H;
+  p->P = p->L - p->W;
+  p->U = p->P - p->H;
+  p->B = p->W - p->S;
+  p->P1 = p->P;
+  while (!is_prime_u32(p->P1)) p->P1++;
+  return 1;
+}
+
+/* RFC 6330 section 5.3.5.1 Rand[y,i,m] (reference rand.c:183-190) */
+static uint32_t rq_rand(uint32_t y, uint32_t i, uint32_t m) {
+  uint32_t a = VT[0][(y + i) & 255], b = VT[1][((y >> 8) + i) & 255];
+  uint32_t c = VT[2][((y >> 16) + i) & 255], d = VT[3][((y >> 24) + i) & 255];
+  return (a ^ b ^ c ^ d) % m;
+}
+
+typedef struct { uint32_t d, a, b, d1, a1, b1; } orc_tuple_t;
+
+/* RFC 6330 section 5.3.5.4 Tuple[K',X] (reference tuple.c:13-43) */
+static orc_tuple_t make_tuple(const orc_params_t *p, uint32_t X) {
+  orc_tuple_t t;
+  uint64_t A = 53591u + (uint64_t)p->J * 997u;
+  if ((A & 1) == 0) A++;
+  uint64_t B1 = 10267u * ((uint64_t)p->J + 1);
+  uint32_t y = (uint32_t)(B1 + (uint64_t)X * A);
+  uint32_t v = rq_rand(y, 0, 1u << 20);
+  uint32_t dg = 0;
+  for (uint32_t k = 0; k < 31; k++)
+    if (v < DEG_F[k]) { dg = k; break; }
+  if (dg > p->W - 2) dg = p->W - 2; /* Deg[v] = min(d, W-2) */
+  t.d = dg;
+  t.a = 1 + rq_rand(y, 1, p->W - 1);
+  t.b = rq_rand(y, 2, p->W);
+  t.d1 = (t.d < 4) ? 2 + rq_rand(X, 3, 2) : 2;
+  t.a1 = 1 + rq_rand(X, 4, p->P1 - 1);
+  t.b1 = rq_rand(X, 5, p->P1);
+  return t;
+}
+
+/* columns of the LT row of internal symbol id X (reference params.c:47-65); returns count */
+static uint32_t lt_columns(const orc_params_t *p, uint32_t X, uint32_t *out) {
+  orc_tuple_t t = make_tuple(p, X);
+  uint32_t n = 0, b = t.b, b1 = t.b1;
+  out[n++] = b;
+  for (uint32_t k = 1; k < t.d; k++) { b = (b + t.a) % p->W; out[n++] = b; }
+  while (b1 >= p->P) b1 = (b1 + t.a1) % p->P1;
+  out[n++] = p->W + b1;
+  for (uint32_t k = 1; k < t.d1; k++) {
+    b1 = (b1 + t.a1) % p->P1;
+    while (b1 >= p->P) b1 = (b1 + t.a1) % p->P1;
+    out[n++] = p->W + b1;
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * GF(256) field + row kernels (the oblas contract, restated; see header)
+ * ---------------------------------------------------------------------------------------- */
+static uint8_t GF_EXP[510], GF_LOG[256], GF_INV[256];
+static uint8_t GF_LO[256][16], GF_HI[256][16]; /* split-nibble product tables for the SIMD path */
+static int gf_ready = 0;
+static int simd_mode = 1; /* 1: use AVX2 when the CPU has it */
+
+static void gf_init(void) {
+  if (gf_ready) return;
+  uint32_t x = 1;
+  for (int e = 0; e < 255; e++) {
+    GF_EXP[e] = (uint8_t)x;
+    GF_LOG[x] = (uint8_t)e;
+    x <<= 1;
+    if (x & 0x100) x ^= 0x11D;
+  }
+  for (int e = 255; e < 510; e++) GF_EXP[e] = GF_EXP[e - 255];
+  GF_LOG[0] = 0;
+  GF_INV[0] = 0;
+  for (int v = 1; v < 256; v++) GF_INV[v] = GF_EXP[255 - GF_LOG[v]];
+  for (int c = 0; c < 256; c++)
+    for (int n = 0; n < 16; n++) {
+      uint8_t lo = (uint8_t)n, hi = (uint8_t)(n << 4);
+      GF_LO[c][n] = (c && lo) ? GF_EXP[GF_LOG[c] + GF_LOG[lo]] : 0;
+      GF_HI[c][n] = (c && hi) ? GF_EXP[GF_LOG[c] + GF_LOG[hi]] : 0;
+    }
+  gf_ready = 1;
+}
+
+static inline uint8_t gf_mul(uint8_t a, uint8_t b) {
+  return (a && b) ? GF_EXP[GF_LOG[a] + GF_LOG[b]] : 0;
+}
+
+static void row_xor_scalar(uint8_t *dst, const uint8_t *src, size_t n) {
+  size_t k = 0;
+  for (; k + 8 <= n; k += 8) {
+    uint64_t a, b;
+    memcpy(&a, dst + k, 8); memcpy(&b, src + k, 8);
+    a ^= b;
+    memcpy(dst + k, &a, 8);
+  }
+  for (; k < n; k++) dst[k] ^= src[k];
+}
+
+static void row_axpy_scalar(uint8_t *dst, const uint8_t *src, size_t n, uint8_t beta) {
+  const uint8_t lb = GF_LOG[beta];
+  for (size_t k = 0; k < n; k++)
+    if (src[k]) dst[k] ^= GF_EXP[lb + GF_LOG[src[k]]];
+}
+
+static void row_scal_scalar(uint8_t *dst, size_t n, uint8_t beta) {
+  const uint8_t lb = GF_LOG[beta];
+  for (size_t k = 0; k < n; k++)
+    if (dst[k]) dst[k] = GF_EXP[lb + GF_LOG[dst[k]]];
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void row_xor_avx2(uint8_t *dst, const uint8_t *src, size_t n) {
+  size_t k = 0;
+  for (; k + 32 <= n; k += 32) {
+    __m256i a = _mm256_loadu_si256((const __m256i *)(dst + k));
+    __m256i b = _mm256_loadu_si256((const __m256i *)(src + k));
+    _mm256_storeu_si256((__m256i *)(dst + k), _mm256_xor_si256(a, b));
+  }
+  for (; k < n; k++) dst[k] ^= src[k];
+}
+
+__attribute__((target("avx2"))) static void row_axpy_avx2(uint8_t *dst, const uint8_t *src, size_t n,
+                                                           uint8_t beta) {
+  const __m256i lo = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)GF_LO[beta]));
+  const __m256i hi = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)GF_HI[beta]));
+  const __m256i m4 = _mm256_set1_epi8(0x0f);
+  size_t k = 0;
+  for (; k + 32 <= n; k += 32) {
+    __m256i s = _mm256_loadu_si256((const __m256i *)(src + k));
+    __m256i pl = _mm256_shuffle_epi8(lo, _mm256_and_si256(s, m4));
+    __m256i ph = _mm256_shuffle_epi8(hi, _mm256_and_si256(_mm256_srli_epi64(s, 4), m4));
+    __m256i d = _mm256_loadu_si256((const __m256i *)(dst + k));
+    _mm256_storeu_si256((__m256i *)(dst + k), _mm256_xor_si256(d, _mm256_xor_si256(pl, ph)));
+  }
+  for (; k < n; k++) dst[k] ^= gf_mul(beta, src[k]);
+}
+
+__attribute__((target("avx2"))) static void row_scal_avx2(uint8_t *dst, size_t n, uint8_t beta) {
+  const __m256i lo = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)GF_LO[beta]));
+  const __m256i hi = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)GF_HI[beta]));
+  const __m256i m4 = _mm256_set1_epi8(0x0f);
+  size_t k = 0;
+  for (; k + 32 <= n; k += 32) {
+    __m256i s = _mm256_loadu_si256((const __m256i *)(dst + k));
+    __m256i pl = _mm256_shuffle_epi8(lo, _mm256_and_si256(s, m4));
+    __m256i ph = _mm256_shuffle_epi8(hi, _mm256_and_si256(_mm256_srli_epi64(s, 4), m4));
+    _mm256_storeu_si256((__m256i *)(dst + k), _mm256_xor_si256(pl, ph));
+  }
+  for (; k < n; k++) dst[k] = gf_mul(beta, dst[k]);
+}
+static int have_avx2(void) { return __builtin_cpu_supports("avx2"); }
+#else
+static int have_avx2(void) { return 0; }
+#endif
+
+/* dst ^= beta * src  (oaxpy contract) */
+static void row_axpy(uint8_t *dst, const uint8_t *src, size_t n, uint8_t beta) {
+  if (beta == 0) return;
+#if defined(__x86_64__)
+  if (simd_mode && have_avx2()) {
+    if (beta == 1) row_xor_avx2(dst, src, n); else row_axpy_avx2(dst, src, n, beta);
+    return;
+  }
+#endif
+  if (beta == 1) row_xor_scalar(dst, src, n); else row_axpy_scalar(dst, src, n, beta);
+}
+
+/* dst *= beta  (oscal contract) */
+static void row_scal(uint8_t *dst, size_t n, uint8_t beta) {
+  if (beta == 1) return;
+#if defined(__x86_64__)
+  if (simd_mode && have_avx2()) { row_scal_avx2(dst, n, beta); return; }
+#endif
+  row_scal_scalar(dst, n, beta);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse binary constraint matrix: one growable column list per row, plus its transpose
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint32_t *v; uint32_t n, cap; } ivec;
+
+static void iv_push(ivec *a, uint32_t x) {
+  if (a->n == a->cap) {
+    a->cap = a->cap ? a->cap * 2 : 12;
+    a->v = (uint32_t *)realloc(a->v, (size_t)a->cap * sizeof(uint32_t));
+  }
+  a->v[a->n++] = x;
+}
+
+typedef struct { uint32_t rows, cols; ivec *r; } smat;
+
+static smat *sm_new(uint32_t rows, uint32_t cols) {
+  smat *m = (smat *)calloc(1, sizeof(smat));
+  m->rows = rows; m->cols = cols;
+  m->r = (ivec *)calloc(rows, sizeof(ivec));
+  return m;
+}
+static void sm_free(smat *m) {
+  if (!m) return;
+  for (uint32_t i = 0; i < m->rows; i++) free(m->r[i].v);
+  free(m->r); free(m);
+}
+static smat *sm_transpose(const smat *m) { /* reference spmat.c:36-45: row-major scan order */
+  smat *t = sm_new(m->cols, m->rows);
+  for (uint32_t i = 0; i < m->rows; i++)
+    for (uint32_t k = 0; k < m->r[i].n; k++) iv_push(&t->r[m->r[i].v[k]], i);
+  return t;
+}
+
+/* Constraint matrix A, (L+overhead) x L, HDPC rows left empty (reference precode.c:34-58,85-97).
+ * Row layout: [0,S) LDPC, [S,S+H) HDPC, [S+H,L) LT rows of ISI 0..K'-1, [L,L+overhead) extra LT rows. */
+static smat *build_constraints(const orc_params_t *p, uint32_t overhead) {
+  smat *A = sm_new(p->L + overhead, p->L);
+  for (uint32_t col = 0; col < p->B; col++) { /* LDPC part 1: three ones per column */
+    uint32_t blk = col / p->S;
+    iv_push(&A->r[col % p->S], col);
+    iv_push(&A->r[(col + blk + 1) % p->S], col);
+    iv_push(&A->r[(col + 2 * (blk + 1)) % p->S], col);
+  }
+  for (uint32_t k = 0; k < p->S; k++) iv_push(&A->r[k], p->B + k); /* I_S */
+  for (uint32_t k = 0; k < p->S; k++) {                            /* LDPC part 2 */
+    iv_push(&A->r[k], p->W + k % p->P);
+    iv_push(&A->r[k], p->W + (k + 1) % p->P);
+  }
+  uint32_t tmp[64];
+  for (uint32_t row = p->S + p->H; row < p->L; row++) { /* G_ENC */
+    uint32_t n = lt_columns(p, row - p->S - p->H, tmp);
+    for (uint32_t k = 0; k < n; k++) iv_push(&A->r[row], tmp[k]);
+  }
+  return A;
+}
+
+static void replace_row_with_lt(smat *A, const orc_params_t *p, uint32_t row, uint32_t isi) {
+  uint32_t tmp[64];
+  uint32_t n = lt_columns(p, isi, tmp);
+  A->r[row].n = 0;
+  for (uint32_t k = 0; k < n; k++) iv_push(&A->r[row], tmp[k]);
+}
+
+/* H x (K'+S) HDPC block, RFC 6330 section 5.3.3.3 as MT*GAMMA evaluated right-to-left
+ * (reference precode.c:60-83) */
+static uint8_t *build_hdpc(const orc_params_t *p) {
+  uint32_t m = p->H, n = p->Kp + p->S;
+  uint8_t *G = (uint8_t *)calloc((size_t)m * n, 1);
+  for (uint32_t h = 0; h < m; h++) G[(size_t)h * n + n - 1] = GF_EXP[h];
+  for (int64_t col = (int64_t)n - 2; col >= 0; col--) {
+    for (uint32_t h = 0; h < m; h++) {
+      uint8_t right = G[(size_t)h * n + col + 1];
+      G[(size_t)h * n + col] = right ? GF_EXP[GF_LOG[right] + 1] : 0;
+    }
+    uint32_t b1 = rq_rand((uint32_t)col + 1, 6, m);
+    uint32_t b2 = (b1 + rq_rand((uint32_t)col + 1, 7, m - 1) + 1) % m;
+    G[(size_t)b1 * n + col] ^= 1;
+    G[(size_t)b2 * n + col] ^= 1;
+  }
+  return G;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The schedule ("plan") of the reference: an operation list over ORIGINAL row indices plus
+ * the row/column permutations (reference sched.h:6-27)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint32_t dst, src; uint8_t beta; } rowop; /* beta==0: row dst *= (uint8_t)src */
+
+typedef struct {
+  uint32_t rows, cols;
+  int32_t *c, *ci, *d, *di;
+  uint32_t *nz;
+  rowop *ops; size_t nops, cap;
+  uint32_t i, u;
+  int64_t mark0, mark1;
+} plan_t;
+
+static plan_t *plan_new(uint32_t rows, uint32_t cols) {
+  plan_t *s = (plan_t *)calloc(1, sizeof(plan_t));
+  s->rows = rows; s->cols = cols;
+  s->c = (int32_t *)malloc(sizeof(int32_t) * cols); s->ci = (int32_t *)malloc(sizeof(int32_t) * cols);
+  s->d = (int32_t *)malloc(sizeof(int32_t) * rows); s->di = (int32_t *)malloc(sizeof(int32_t) * rows);
+  s->nz = (uint32_t *)calloc(rows, sizeof(uint32_t));
+  for (uint32_t k = 0; k < cols; k++) s->c[k] = s->ci[k] = (int32_t)k;
+  for (uint32_t k = 0; k < rows; k++) s->d[k] = s->di[k] = (int32_t)k;
+  return s;
+}
+static void plan_free(plan_t *s) {
+  if (!s) return;
+  free(s->c); free(s->ci); free(s->d); free(s->di); free(s->nz); free(s->ops); free(s);
+}
+static void plan_push(plan_t *s, uint32_t dst, uint32_t src, uint8_t beta) {
+  if (s->nops == s->cap) {
+    s->cap = s->cap ? s->cap * 2 : 4096;
+    s->ops = (rowop *)realloc(s->ops, s->cap * sizeof(rowop));
+  }
+  s->ops[s->nops].dst = dst; s->ops[s->nops].src = src; s->ops[s->nops].beta = beta;
+  s->nops++;
+}
+static inline void swap_i32(int32_t *a, int32_t *b) { int32_t t = *a; *a = *b; *b = t; }
+
+/* dense byte work matrix U (rows x u): the reference keeps a bit-packed/byte hybrid
+ * (wrkmat.c:76-118); every entry is a GF(256) element either way, so one byte per entry
+ * gives identical arithmetic without the promotion bookkeeping. */
+typedef struct { uint8_t *a; uint32_t rows, cols; size_t ld; } dmat;
+static inline uint8_t *dm_row(dmat *m, uint32_t r) { return m->a + (size_t)r * m->ld; }
+
+/* initial row order and V-degree of every row (reference precode.c:99-109) */
+static void stage_sort(const orc_params_t *p, const smat *A, plan_t *s) {
+  for (uint32_t pos = 0; pos < A->rows; pos++) s->d[pos] = (int32_t)((pos + p->S + p->H) % A->rows);
+  for (uint32_t pos = 0; pos < A->rows; pos++) s->di[s->d[pos]] = (int32_t)pos;
+  uint32_t vend = A->cols - p->P;
+  for (uint32_t r = 0; r < A->rows; r++) {
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < A->r[r].n; k++) cnt += (A->r[r].v[k] < vend);
+    s->nz[r] = cnt ? cnt : A->cols;
+  }
+}
+
+/* phase 1 of inactivation decoding with the reference's simplified choice rule: only rows with
+ * one or two ones left in V are ever chosen, taken LIFO from two stacks
+ * (reference precode.c:115-203) */
+static void stage_precondition(const orc_params_t *p, const smat *A, const smat *AT, plan_t *s) {
+  uint32_t rows = A->rows, cols = A->cols, srows = rows - p->H;
+  uint32_t i = 0, u = p->P;
+  ivec stack[3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (uint32_t pos = 0; pos < srows; pos++) {
+    uint32_t r = (uint32_t)s->d[pos];
+    if (s->nz[r] < 3) iv_push(&stack[s->nz[r]], r);
+  }
+  while (i + u < p->L) {
+    uint32_t vcols = cols - i - u, v0 = i, vlast = v0 + vcols - 1;
+    /* choose */
+    int64_t pos = -1;
+    for (uint32_t b = 1; b < 3 && pos < 0; b++) {
+      while (stack[b].n > 0) {
+        uint32_t cand = stack[b].v[--stack[b].n];
+        if ((uint32_t)s->di[cand] >= v0 && s->nz[cand] == b) { pos = s->di[cand]; break; }
+      }
+    }
+    if (pos < 0) break;
+    if ((uint32_t)pos != v0) {
+      swap_i32(&s->d[v0], &s->d[pos]);
+      swap_i32(&s->di[s->d[v0]], &s->di[s->d[pos]]);
+    }
+    /* locate this row's ones inside V (at most nz of them), smallest position first */
+    const ivec *rl = &A->r[s->d[v0]];
+    uint32_t limit = s->nz[s->d[v0]], r = 0;
+    int32_t at[2] = {(int32_t)(v0 + vcols), (int32_t)(v0 + vcols)};
+    for (uint32_t k = 0; k < rl->n && r < limit; k++) {
+      int32_t cp = s->ci[rl->v[k]];
+      if (cp >= (int32_t)v0 && cp < (int32_t)(v0 + vcols)) at[r++] = cp;
+    }
+    if (at[0] > at[1]) swap_i32(&at[0], &at[1]);
+    if (at[0] != (int32_t)v0) {
+      swap_i32(&s->c[v0], &s->c[at[0]]);
+      swap_i32(&s->ci[s->c[v0]], &s->ci[s->c[at[0]]]);
+    }
+    if (r == 2 && at[1] != (int32_t)vlast) {
+      swap_i32(&s->c[vlast], &s->c[at[1]]);
+      swap_i32(&s->ci[s->c[vlast]], &s->ci[s->c[at[1]]]);
+    }
+    /* the pivot column, then (r==2) the column that just left V for U */
+    for (uint32_t leave = 0; leave < r; leave++) {
+      const ivec *cl = &AT->r[s->c[leave == 0 ? v0 : vlast]];
+      for (uint32_t k = 0; k < cl->n; k++) {
+        uint32_t row = cl->v[k];
+        uint32_t left = --s->nz[row];
+        if (left > 0 && left < 3) iv_push(&stack[left], row);
+      }
+    }
+    i++;
+    u += r - 1;
+  }
+  for (int b = 0; b < 3; b++) free(stack[b].v);
+  s->i = i;
+  s->u = p->L - i;
+}
+
+/* eliminate column `pos` (for every pos < i) from the rows whose position h satisfies
+ * max(from,pos) < h < to, using the pivot row at position pos (reference precode.c:205-219) */
+static void stage_forward(dmat *U, plan_t *s, const smat *AT, uint32_t from, uint32_t to) {
+  for (uint32_t pos = 0; pos < s->i; pos++) {
+    uint32_t floor_ = from < pos ? pos : from;
+    const ivec *cl = &AT->r[s->c[pos]];
+    for (uint32_t k = 0; k < cl->n; k++) {
+      uint32_t target = cl->v[k], h = (uint32_t)s->di[target];
+      if (h > floor_ && h < to) {
+        row_axpy(dm_row(U, target), dm_row(U, (uint32_t)s->d[pos]), U->cols, 1);
+        plan_push(s, target, (uint32_t)s->d[pos], 1);
+      }
+    }
+  }
+}
+
+/* reference precode.c:221-230, 254-262 */
+static dmat *stage_make_U(const orc_params_t *p, const smat *A, const smat *AT, plan_t *s) {
+  dmat *U = (dmat *)calloc(1, sizeof(dmat));
+  U->rows = A->rows; U->cols = s->u; U->ld = (s->u + 31u) & ~31u;
+  if (U->ld == 0) U->ld = 32;
+  U->a = (uint8_t *)calloc((size_t)U->rows * U->ld, 1);
+  for (uint32_t r = 0; r < A->rows; r++)
+    for (uint32_t k = 0; k < A->r[r].n; k++) {
+      int32_t cp = s->ci[A->r[r].v[k]];
+      if (cp >= (int32_t)s->i) dm_row(U, r)[cp - s->i] = 1;
+    }
+  stage_forward(U, s, AT, 0, s->i);
+  s->mark0 = (int64_t)s->nops - 1;
+  stage_forward(U, s, AT, s->i - 1, A->rows - p->H);
+  return U;
+}
+
+/* dense GF(2) elimination on the non-HDPC rows (reference precode.c:264-285) */
+static uint32_t stage_solve_binary(const orc_params_t *p, dmat *U, plan_t *s) {
+  uint32_t lim = U->rows - p->H, pos;
+  for (pos = s->i; pos < p->L; pos++) {
+    uint32_t col = pos - s->i, hit;
+    for (hit = pos; hit < lim; hit++)
+      if (dm_row(U, (uint32_t)s->d[hit])[col]) break;
+    if (hit == lim) break;
+    if (hit != pos) {
+      swap_i32(&s->d[pos], &s->d[hit]);
+      swap_i32(&s->di[s->d[pos]], &s->di[s->d[hit]]);
+    }
+    for (uint32_t below = pos + 1; below < lim; below++) {
+      if (dm_row(U, (uint32_t)s->d[below])[col] == 0) continue;
+      row_axpy(dm_row(U, (uint32_t)s->d[below]), dm_row(U, (uint32_t)s->d[pos]), U->cols, 1);
+      plan_push(s, (uint32_t)s->d[below], (uint32_t)s->d[pos], 1);
+    }
+  }
+  return pos;
+}
+
+/* overlay [HDPC(:, c[i..]) | I_H] on the H HDPC rows of U, then clear their first i columns
+ * (reference precode.c:232-252) */
+static void stage_hdpc(const orc_params_t *p, dmat *U, plan_t *s) {
+  uint8_t *G = build_hdpc(p);
+  uint32_t n = p->Kp + p->S, inner = s->u - p->H;
+  for (uint32_t h = 0; h < p->H; h++) {
+    uint8_t *ur = dm_row(U, p->S + h);
+    memset(ur, 0, U->cols);
+    for (uint32_t k = 0; k < inner; k++) ur[k] = G[(size_t)h * n + (uint32_t)s->c[n - inner + k]];
+    ur[inner + h] = 1;
+  }
+  for (uint32_t pos = 0; pos < s->i; pos++)
+    for (uint32_t h = 0; h < p->H; h++) {
+      uint8_t beta = G[(size_t)h * n + (uint32_t)s->c[pos]];
+      if (!beta) continue;
+      uint32_t target = (uint32_t)s->d[U->rows - p->H + h];
+      row_axpy(dm_row(U, target), dm_row(U, (uint32_t)s->d[pos]), U->cols, beta);
+      plan_push(s, target, (uint32_t)s->d[pos], beta);
+    }
+  free(G);
+}
+
+/* dense GF(256) elimination over all rows (reference precode.c:287-315) */
+static uint32_t stage_solve_gf256(const orc_params_t *p, dmat *U, plan_t *s) {
+  uint32_t lim = U->rows, pos;
+  for (pos = s->i; pos < p->L; pos++) {
+    uint32_t col = pos - s->i, hit;
+    uint8_t beta = 0;
+    for (hit = pos; hit < lim; hit++) {
+      beta = dm_row(U, (uint32_t)s->d[hit])[col];
+      if (beta) break;
+    }
+    if (hit == lim) break;
+    if (hit != pos) {
+      swap_i32(&s->d[pos], &s->d[hit]);
+      swap_i32(&s->di[s->d[pos]], &s->di[s->d[hit]]);
+    }
+    if (beta > 1) {
+      row_scal(dm_row(U, (uint32_t)s->d[pos]), U->cols, GF_INV[beta]);
+      plan_push(s, (uint32_t)s->d[pos], GF_INV[beta], 0);
+    }
+    for (uint32_t below = pos + 1; below < lim; below++) {
+      beta = dm_row(U, (uint32_t)s->d[below])[col];
+      if (!beta) continue;
+      row_axpy(dm_row(U, (uint32_t)s->d[below]), dm_row(U, (uint32_t)s->d[pos]), U->cols, beta);
+      plan_push(s, (uint32_t)s->d[below], (uint32_t)s->d[pos], beta);
+    }
+  }
+  return pos;
+}
+
+/* record (do not execute) the back substitution (reference precode.c:317-334) */
+static void stage_backsolve(const orc_params_t *p, const smat *AT, dmat *U, plan_t *s) {
+  for (int64_t pos = (int64_t)p->L - 1; pos >= (int64_t)s->i; pos--) {
+    const ivec *cl = &AT->r[s->c[pos]];
+    for (uint32_t k = 0; k < cl->n; k++) {
+      uint32_t h = (uint32_t)s->di[cl->v[k]];
+      if (h < s->i) plan_push(s, (uint32_t)s->d[h], (uint32_t)s->d[pos], 1);
+    }
+    for (uint32_t h = s->i; h < (uint32_t)pos; h++) {
+      uint8_t beta = dm_row(U, (uint32_t)s->d[h])[pos - s->i];
+      if (beta) plan_push(s, (uint32_t)s->d[h], (uint32_t)s->d[pos], beta);
+    }
+  }
+}
+
+/* symbolic stage; consumes A; NULL when rank(A) < L (reference precode.c:347-377) */
+static plan_t *make_plan(const orc_params_t *p, smat *A) {
+  plan_t *s = plan_new(A->rows, A->cols);
+  stage_sort(p, A, s);
+  smat *AT = sm_transpose(A);
+  stage_precondition(p, A, AT, s);
+  dmat *U = stage_make_U(p, A, AT, s);
+  uint32_t rank = 0;
+  if (A->rows - p->H >= p->L) rank = stage_solve_binary(p, U, s);
+  if (rank < p->L) {
+    stage_hdpc(p, U, s);
+    rank = stage_solve_gf256(p, U, s);
+  }
+  if (rank < p->L) {
+    plan_free(s);
+    s = NULL;
+  } else {
+    s->mark1 = (int64_t)s->nops - 1;
+    stage_backsolve(p, AT, U, s);
+  }
+  free(U->a); free(U);
+  sm_free(AT); sm_free(A);
+  return s;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Replay on the symbol matrix D (reference precode.c:15-32, 379-389)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t i, u;
+  uint64_t recorded_ops;
+  uint64_t n1, nB, n0;       /* replay counts: beta==1 axpy, beta>1 axpy, scal */
+  uint64_t gaps, overhead;
+  uint64_t gen_rows;         /* sum over generated symbols of (d + d1 + 1) */
+  uint64_t ns_plan, ns_replay, ns_gen;
+} orc_stats;
+
+static uint64_t now_ns(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+static inline void replay_one(uint8_t *D, size_t ld, size_t T, const rowop *op, orc_stats *st) {
+  if (op->beta) {
+    row_axpy(D + (size_t)op->dst * ld, D + (size_t)op->src * ld, T, op->beta);
+    if (st) { if (op->beta == 1) st->n1++; else st->nB++; }
+  } else {
+    row_scal(D + (size_t)op->dst * ld, T, (uint8_t)op->src);
+    if (st) st->n0++;
+  }
+}
+
+/* D (rows x ld) -> C (L x ldc); C[c[k]] = D[d[k]] is the net effect of the reference's two
+ * in-place cycle permutations (precode.c:3-13 with P=di, then P=c) */
+static void replay_plan(const orc_params_t *p, const plan_t *s, uint8_t *D, size_t ld, size_t T, uint8_t *C,
+                        size_t ldc, orc_stats *st) {
+  int64_t n = (int64_t)s->nops, k;
+  for (k = 0; k < s->mark1; k++) replay_one(D, ld, T, &s->ops[k], st);
+  for (k = s->mark0; k >= 0; k--) replay_one(D, ld, T, &s->ops[k], st);
+  for (k = s->mark1 < 0 ? 0 : s->mark1; k < n; k++) replay_one(D, ld, T, &s->ops[k], st);
+  for (k = 0; k <= s->mark0; k++) replay_one(D, ld, T, &s->ops[k], st);
+  for (uint32_t q = 0; q < p->L; q++) memcpy(C + (size_t)s->c[q] * ldc, D + (size_t)s->d[q] * ld, T);
+}
+
+/* one encoding symbol from the intermediate symbols (reference nanorq.c:184-204) */
+static uint32_t lt_symbol(const orc_params_t *p, const uint8_t *C, size_t ldc, size_t T, uint32_t isi, uint8_t *out) {
+  uint32_t cols[64];
+  uint32_t n = lt_columns(p, isi, cols);
+  memset(out, 0, T);
+  for (uint32_t k = 0; k < n; k++) row_xor_scalar(out, C + (size_t)cols[k] * ldc, T);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Exported entry points (ctypes)
+ * ---------------------------------------------------------------------------------------- */
+void orc_set_simd(int on) { simd_mode = on; }
+int orc_has_avx2(void) { return have_avx2(); }
+
+int orc_params(uint32_t K, uint32_t out[10]) {
+  orc_params_t p;
+  if (!derive_params(K, &p)) return 0;
+  out[0] = p.Kp; out[1] = p.J; out[2] = p.S; out[3] = p.H; out[4] = p.W;
+  out[5] = p.L; out[6] = p.P; out[7] = p.P1; out[8] = p.U; out[9] = p.B;
+  return 1;
+}
+
+int orc_tuple(uint32_t K, uint32_t isi, uint32_t out[6]) {
+  orc_params_t p;
+  if (!derive_params(K, &p)) return 0;
+  orc_tuple_t t = make_tuple(&p, isi);
+  out[0] = t.d; out[1] = t.a; out[2] = t.b; out[3] = t.d1; out[4] = t.a1; out[5] = t.b1;
+  return 1;
+}
+
+int orc_lt_columns(uint32_t K, uint32_t isi, uint32_t *out /* >= 64 */) {
+  orc_params_t p;
+  if (!derive_params(K, &p)) return -1;
+  return (int)lt_columns(&p, isi, out);
+}
+
+void orc_gf_tables(uint8_t *exp510, uint8_t *log256, uint8_t *inv256) {
+  gf_init();
+  memcpy(exp510, GF_EXP, 510); memcpy(log256, GF_LOG, 256); memcpy(inv256, GF_INV, 256);
+}
+
+int orc_hdpc(uint32_t K, uint8_t *out /* H*(K'+S) */) {
+  orc_params_t p;
+  gf_init();
+  if (!derive_params(K, &p)) return 0;
+  uint8_t *G = build_hdpc(&p);
+  memcpy(out, G, (size_t)p.H * (p.Kp + p.S));
+  free(G);
+  return 1;
+}
+
+/* row kernels exposed for the SIMD-vs-scalar self check */
+void orc_row_axpy(uint8_t *dst, const uint8_t *src, size_t n, uint8_t beta) { gf_init(); row_axpy(dst, src, n, beta); }
+void orc_row_scal(uint8_t *dst, size_t n, uint8_t beta) { gf_init(); row_scal(dst, n, beta); }
+
+/* Encode one source block (reference nanorq.c:206-232 + :403-435).
+ *   src: K*T bytes; inter (nullable): L*T bytes out; rep: nrep*T bytes out for ESIs esis[] (>= K)
+ * returns 1 on success */
+int orc_encode_block(uint32_t K, uint32_t T, const uint8_t *src, uint8_t *inter, uint32_t nrep,
+                     const uint32_t *esis, uint8_t *rep, orc_stats *st) {
+  orc_params_t p;
+  gf_init();
+  if (st) memset(st, 0, sizeof(*st));
+  if (!derive_params(K, &p) || T == 0) return 0;
+  size_t ld = ((size_t)T + 31u) & ~(size_t)31u;
+  uint8_t *D = (uint8_t *)aligned_alloc(64, (size_t)p.L * ld);
+  uint8_t *C = (uint8_t *)aligned_alloc(64, (size_t)p.L * ld);
+  memset(D, 0, (size_t)p.L * ld);
+  for (uint32_t e = 0; e < K; e++) memcpy(D + (size_t)(p.S + p.H + e) * ld, src + (size_t)e * T, T);
+  uint64_t t0 = now_ns();
+  plan_t *s = make_plan(&p, build_constraints(&p, 0));
+  uint64_t t1 = now_ns();
+  if (!s) { free(D); free(C); return 0; }
+  replay_plan(&p, s, D, ld, T, C, ld, st);
+  uint64_t t2 = now_ns();
+  for (uint32_t k = 0; k < nrep; k++) {
+    uint32_t n = lt_symbol(&p, C, ld, T, esis[k] + (p.Kp - K), rep + (size_t)k * T);
+    if (st) st->gen_rows += n + 1;
+  }
+  uint64_t t3 = now_ns();
+  if (inter)
+    for (uint32_t q = 0; q < p.L; q++) memcpy(inter + (size_t)q * T, C + (size_t)q * ld, T);
+  if (st) {
+    st->i = s->i; st->u = s->u; st->recorded_ops = s->nops;
+    st->ns_plan = t1 - t0; st->ns_replay = t2 - t1; st->ns_gen = t3 - t2;
+  }
+  plan_free(s); free(D); free(C);
+  return 1;
+}
+
+/* Decode one source block from received symbols in ARRIVAL order
+ * (reference nanorq.c:478-509 add_symbol, :527-631 repair_block).
+ *   esis[n], syms[n*T]; out: K*T bytes (received source symbols are written through, recovered
+ *   ones after the solve).  returns 1 = block complete, 0 = not decodable (too few symbols or
+ *   rank(A) < L). */
+int orc_decode_block(uint32_t K, uint32_t T, uint32_t n, const uint32_t *esis, const uint8_t *syms, uint8_t *out,
+                     orc_stats *st) {
+  orc_params_t p;
+  gf_init();
+  if (st) memset(st, 0, sizeof(*st));
+  if (!derive_params(K, &p) || T == 0) return 0;
+  uint32_t max_esi = 2 * p.Kp; /* reference nanorq.c:374 */
+  uint8_t *seen = (uint8_t *)calloc((size_t)max_esi + 1, 1);
+  uint32_t *rep_idx = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+  uint32_t nrep = 0, have_src = 0;
+  size_t ld = ((size_t)T + 31u) & ~(size_t)31u;
+  size_t drows = (size_t)p.L + (max_esi - K);
+  uint8_t *D = (uint8_t *)aligned_alloc(64, drows * ld);
+  memset(D, 0, drows * ld);
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t e = esis[k];
+    if (e > max_esi) continue;       /* NANORQ_SYM_ERR */
+    if (have_src == K) continue;     /* NANORQ_SYM_IGN: nothing missing */
+    if (seen[e]) continue;           /* NANORQ_SYM_DUP */
+    seen[e] = 1;
+    if (e < K) {
+      memcpy(D + (size_t)(p.S + p.H + e) * ld, syms + (size_t)k * T, T);
+      memcpy(out + (size_t)e * T, syms + (size_t)k * T, T);
+      have_src++;
+    } else {
+      rep_idx[nrep++] = k;
+    }
+  }
+  uint32_t gaps = K - have_src;
+  int ok = 0;
+  if (st) { st->gaps = gaps; }
+  if (gaps == 0) { ok = 1; goto done; }
+  if (nrep < gaps) goto done;
+  {
+    uint32_t overhead = nrep - gaps, pad = p.Kp - K, used = 0;
+    if (st) st->overhead = overhead;
+    if (drows < (size_t)p.L + overhead) goto done;
+    smat *A = build_constraints(&p, overhead);
+    for (uint32_t e = 0; e < K && used < nrep; e++) { /* gaps take repair symbols in arrival order */
+      if (seen[e]) continue;
+      uint32_t k = rep_idx[used++];
+      memcpy(D + (size_t)(p.S + p.H + e) * ld, syms + (size_t)k * T, T);
+      replace_row_with_lt(A, &p, p.S + p.H + e, esis[k] + pad);
+    }
+    for (uint32_t row = p.L; used < nrep; row++) { /* surplus symbols become extra rows */
+      uint32_t k = rep_idx[used++];
+      memcpy(D + (size_t)row * ld, syms + (size_t)k * T, T);
+      replace_row_with_lt(A, &p, row, esis[k] + pad);
+    }
+    uint64_t t0 = now_ns();
+    plan_t *s = make_plan(&p, A);
+    uint64_t t1 = now_ns();
+    if (!s) goto done;
+    uint8_t *C = (uint8_t *)aligned_alloc(64, (size_t)p.L * ld);
+    replay_plan(&p, s, D, ld, T, C, ld, st);
+    uint64_t t2 = now_ns();
+    uint8_t *tmp = (uint8_t *)malloc(T);
+    for (uint32_t e = 0; e < K; e++) {
+      if (seen[e]) continue;
+      uint32_t nn = lt_symbol(&p, C, ld, T, e, tmp);
+      memcpy(out + (size_t)e * T, tmp, T);
+      if (st) st->gen_rows += nn + 1;
+    }
+    uint64_t t3 = now_ns();
+    if (st) {
+      st->i = s->i; st->u = s->u; st->recorded_ops = s->nops;
+      st->ns_plan = t1 - t0; st->ns_replay = t2 - t1; st->ns_gen = t3 - t2;
+    }
+    free(tmp); free(C); plan_free(s);
+    ok = 1;
+  }
+done:
+  free(D); free(seen); free(rep_idx);
+  return ok;
+}
+
+/* plan-only probe: rank verdict + schedule statistics for an arbitrary LT row set.
+ * isis[nrows] are the ISIs of rows S+H.. (first K' entries) and L.. (the rest). */
+int orc_plan_probe(uint32_t K, uint32_t nrows, const uint32_t *isis, orc_stats *st) {
+  orc_params_t p;
+  gf_init();
+  if (st) memset(st, 0, sizeof(*st));
+  if (!derive_params(K, &p) || nrows < p.Kp) return -1;
+  uint32_t overhead = nrows - p.Kp;
+  smat *A = build_constraints(&p, overhead);
+  for (uint32_t k = 0; k < nrows; k++) replace_row_with_lt(A, &p, p.S + p.H + k, isis[k]);
+  uint64_t t0 = now_ns();
+  plan_t *s = make_plan(&p, A);
+  uint64_t t1 = now_ns();
+  if (!s) return 0;
+  if (st) {
+    st->i = s->i; st->u = s->u; st->recorded_ops = s->nops; st->ns_plan = t1 - t0;
+    /* replay counts in 4-pass order without touching data */
+    int64_t nn = (int64_t)s->nops, k;
+    uint64_t c1 = 0, cB = 0, c0 = 0;
+#define COUNT(op) do { if ((op).beta == 1) c1++; else if ((op).beta) cB++; else c0++; } while (0)
+    for (k = 0; k < s->mark1; k++) COUNT(s->ops[k]);
+    for (k = s->mark0; k >= 0; k--) COUNT(s->ops[k]);
+    for (k = s->mark1 < 0 ? 0 : s->mark1; k < nn; k++) COUNT(s->ops[k]);
+    for (k = 0; k <= s->mark0; k++) COUNT(s->ops[k]);
+#undef COUNT
+    st->n1 = c1; st->nB = cB; st->n0 = c0;
+  }
+  plan_free(s);
+  return 1;
+}
