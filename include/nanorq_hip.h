@@ -1,0 +1,109 @@
+/*
+ * nanorq_hip.h -- thin C ABI into the gfx950 (MI355X) RaptorQ precode-solve / symbol-generation
+ * path.  Plain C types only: device and host pointers as void*, sizes, int status returns
+ * (0 = ok, negative = error, text via nrq_ctx_error()); no C++ exceptions cross this line.
+ *
+ * This is the seam the drop-in library (include/nanorq.h, include/io.h) sits on, and the
+ * entry points a binding of the reference would call instead of its CPU solver.  Reference
+ * interfaces replaced (file:line in sleepybishop/nanorq):
+ *   precode_matrix_gen / precode_matrix_invert / precode_matrix_intermediate   include/precode.h:10-12
+ *   nanorq_generate_symbols  (load + plan + replay)                            lib/nanorq.c:206-232
+ *   nanorq_repair_block      (patch + plan + replay + regenerate gaps)         lib/nanorq.c:591-631
+ *   decode_row / nanorq_encode (LT symbol generation)                          lib/nanorq.c:184-204, :403-435
+ *   oblas oaxpy/oscal/oswaprow row kernels (absent submodule deps/oblas)       precode.c:7,18,20
+ * The unit of work is a batch of independent source blocks of equal (K, T) that stay resident in
+ * HBM; one 256-thread workgroup solves one 16/8/4/2-byte column strip of one block out of LDS.
+ */
+#ifndef NANORQ_HIP_H
+#define NANORQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nrq_ctx nrq_ctx;
+
+/* statistics of the last encode/decode call (host side, for benchmarks and tests) */
+typedef struct nrq_call_stats {
+  double plan_ms;      /* symbolic stage wall time (all blocks) */
+  double host_ms;      /* whole host side of the call before the launch returns */
+  uint32_t strip_bytes;/* column-strip width chosen (16/8/4/2) */
+  uint32_t lds_bytes;  /* dynamic LDS per workgroup */
+  uint32_t grid;       /* workgroups launched */
+  uint32_t planner;    /* 0 = host planner, 1 = device planner */
+  uint64_t plan_bytes; /* plan bytes resident on the device for this call */
+  uint64_t xor_ops;    /* row XOR ops in the forward passes, summed over blocks */
+  uint32_t npiv, u, nlev, nfree; /* of block 0 */
+} nrq_call_stats;
+
+/* One context per GPU (one process per GPU: no cross-device state).  `stream` is a hipStream_t the
+ * caller owns (NULL = the default stream); all work of later calls is enqueued on it. */
+int nrq_ctx_create(int device, void *stream, nrq_ctx **out);
+void nrq_ctx_destroy(nrq_ctx *ctx);
+int nrq_ctx_set_stream(nrq_ctx *ctx, void *stream);
+const char *nrq_ctx_error(nrq_ctx *ctx);
+int nrq_ctx_sync(nrq_ctx *ctx);
+void nrq_ctx_last_stats(nrq_ctx *ctx, nrq_call_stats *out);
+/* threads used for host-side planning (0 = hardware concurrency) */
+int nrq_ctx_set_threads(nrq_ctx *ctx, int n);
+
+/* Parameters of RFC 6330 section 5.3.1.2 for K source symbols: out = {K',J,S,H,W,L,P,P1,U,B}. */
+int nrq_params(uint32_t K, uint32_t out[10]);
+
+/* Build (or fetch the cached) plan for encoding blocks of K symbols: the counterpart of
+ * nanorq_precalculate (lib/nanorq.c:393-401).  Implied by nrq_encode_blocks. */
+int nrq_precalculate(nrq_ctx *ctx, uint32_t K);
+/* drop cached encode plans (so that a benchmark can time plan generation) */
+void nrq_plan_cache_clear(nrq_ctx *ctx);
+
+/* Encode nblk source blocks (asynchronous on the context's stream).
+ *   d_src    device: block b at d_src + b*src_stride, source symbol j at + j*T        (K*T bytes)
+ *   d_inter  device or NULL: block b's L intermediate symbols at d_inter + b*inter_stride
+ *   h_esis   host: nrep repair ESIs (each K <= esi < 2^24), the same list for every block
+ *   d_rep    device: block b's repair symbol q at d_rep + b*rep_stride + q*T
+ * Bit-exact with nanorq_generate_symbols + nanorq_encode(esi) of the reference. */
+int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,
+                      void *d_inter, size_t inter_stride, uint32_t nrep, const uint32_t *h_esis, void *d_rep,
+                      size_t rep_stride);
+
+/* Decode nblk source blocks (asynchronous on the context's stream; h_status is final on return).
+ *   d_src    device, in/out: block b at d_src + b*src_stride; received source symbols are in place at
+ *            row esi, rows of missing symbols are overwritten with the recovered symbols
+ *   h_lost   host: missing source ESIs of block b, ascending, at h_lost[b*lost_cap .. + h_nlost[b])
+ *   h_rep_esi host: ESIs (>= K) of block b's received repair symbols in ARRIVAL order at
+ *            h_rep_esi[b*rep_cap .. + h_nrep[b]); symbol q at d_rep + b*rep_stride + q*T
+ *   d_inter  device or NULL: intermediate symbols out
+ *   h_status host out: 1 = block recovered, 0 = not decodable (fewer repair symbols than gaps, or
+ *            rank deficient: the caller may add symbols and retry, as with nanorq_repair_block)
+ * The i-th missing ESI takes the i-th repair symbol, surplus symbols become extra constraint rows
+ * (lib/nanorq.c:527-565). */
+int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                      const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                      const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
+                      size_t inter_stride, int *h_status);
+
+/* Generate encoding symbols from intermediate symbols already in HBM (after encode/decode with
+ * d_inter != NULL): symbol q of block b = LT(C_b, isi[q]) -> d_out + b*out_stride + q*T.
+ * h_isi are INTERNAL symbol ids (esi for esi < K, esi + K' - K for repair symbols). */
+int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,
+                    uint32_t n, const uint32_t *h_isi, void *d_out, size_t out_stride);
+
+/* Raw device memory helpers for hosts without a HIP binding of their own (the drop-in C library and
+ * the ctypes tests use them; PyTorch callers pass tensor data pointers instead). */
+int nrq_dev_alloc(nrq_ctx *ctx, size_t bytes, void **out);
+int nrq_dev_free(nrq_ctx *ctx, void *p);
+int nrq_dev_upload(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* synchronous */
+int nrq_dev_download(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* synchronous */
+int nrq_dev_memset(nrq_ctx *ctx, void *d_dst, int value, size_t bytes);
+
+/* Kernel timing on the context's stream with HIP events (bench.py's roofline leg). */
+int nrq_timer_start(nrq_ctx *ctx);
+int nrq_timer_stop_ms(nrq_ctx *ctx, float *ms); /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANORQ_HIP_H */

@@ -1,0 +1,12 @@
+"""nanorq_amd -- MI355X-native RaptorQ precode solve / symbol generation (nanorq-compatible).
+
+The product is the native library nanorq_amd/libnanorq_hip.so (gfx950 HIP kernels behind the C ABI
+of include/nanorq_hip.h, plus the drop-in nanorq.h / io.h layer).  This package only loads it and
+offers a thin ctypes mirror for tests and bench.py; there is no Python or CPU implementation of
+the hot path, and every entry point raises when the HIP library or a GPU is missing.
+"""
+from .binding import (NrqError, Context, lib, lib_path, params, host_plan, host_kconst, PLAN_FIELDS,
+                      plan_header)
+
+__all__ = ["NrqError", "Context", "lib", "lib_path", "params", "host_plan", "host_kconst", "PLAN_FIELDS",
+           "plan_header"]

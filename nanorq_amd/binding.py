@@ -1,0 +1,220 @@
+"""ctypes binding of libnanorq_hip.so (include/nanorq_hip.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class NrqError(RuntimeError):
+    pass
+
+
+class CallStats(C.Structure):
+    _fields_ = [("plan_ms", C.c_double), ("host_ms", C.c_double), ("strip_bytes", C.c_uint32),
+                ("lds_bytes", C.c_uint32), ("grid", C.c_uint32), ("planner", C.c_uint32),
+                ("plan_bytes", C.c_uint64), ("xor_ops", C.c_uint64), ("npiv", C.c_uint32), ("u", C.c_uint32),
+                ("nlev", C.c_uint32), ("nfree", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def lib_path():
+    return os.path.join(_HERE, "libnanorq_hip.so")
+
+
+def lib():
+    """Load the native library (building it first if the sources are newer). No fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    from . import build
+    path = build.build_lib()
+    L = C.CDLL(path)
+    vp, u32p, ip = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)
+    sz = C.c_size_t
+    L.nrq_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.nrq_ctx_destroy.argtypes = [vp]
+    L.nrq_ctx_destroy.restype = None
+    L.nrq_ctx_set_stream.argtypes = [vp, vp]
+    L.nrq_ctx_error.argtypes = [vp]
+    L.nrq_ctx_error.restype = C.c_char_p
+    L.nrq_ctx_sync.argtypes = [vp]
+    L.nrq_ctx_last_stats.argtypes = [vp, C.POINTER(CallStats)]
+    L.nrq_ctx_last_stats.restype = None
+    L.nrq_ctx_set_threads.argtypes = [vp, C.c_int]
+    L.nrq_params.argtypes = [C.c_uint32, u32p]
+    L.nrq_precalculate.argtypes = [vp, C.c_uint32]
+    L.nrq_plan_cache_clear.argtypes = [vp]
+    L.nrq_plan_cache_clear.restype = None
+    L.nrq_encode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, vp, sz, C.c_uint32, u32p, vp, sz]
+    L.nrq_decode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, u32p, u32p, C.c_uint32, u32p,
+                                    u32p, C.c_uint32, vp, sz, vp, sz, ip]
+    L.nrq_gen_symbols.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, C.c_uint32, u32p, vp, sz]
+    L.nrq_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.nrq_dev_free.argtypes = [vp, vp]
+    L.nrq_dev_upload.argtypes = [vp, vp, vp, sz]
+    L.nrq_dev_download.argtypes = [vp, vp, vp, sz]
+    L.nrq_dev_memset.argtypes = [vp, vp, C.c_int, sz]
+    L.nrq_timer_start.argtypes = [vp]
+    L.nrq_timer_stop_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    u8pp = C.POINTER(C.POINTER(C.c_uint8))
+    L.nrq_host_kconst_build.argtypes = [C.c_uint32, u8pp, u32p]
+    L.nrq_host_plan_build.argtypes = [C.c_uint32, C.c_uint32, u32p, C.POINTER(C.c_uint8), u8pp, u32p]
+    L.nrq_host_free.argtypes = [vp]
+    L.nrq_host_free.restype = None
+    _LIB = L
+    return L
+
+
+PARAM_NAMES = ("Kp", "J", "S", "H", "W", "L", "P", "P1", "U", "B")
+PLAN_FIELDS = ("magic status K Kp J S H W L P P1 B M npiv u nlow r2 nfree nlev nchunk1 nchunk2 wpr lpr "
+               "npiv_pad n_xor_ops").split()
+
+
+def params(K):
+    out = (C.c_uint32 * 10)()
+    if lib().nrq_params(K, out) != 0:
+        raise ValueError("K out of range: %r" % (K,))
+    return dict(zip(PARAM_NAMES, (int(x) for x in out)))
+
+
+def _u32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def host_kconst(K):
+    """Per-K' HDPC constants arena (bytes)."""
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_uint32()
+    if lib().nrq_host_kconst_build(K, C.byref(out), C.byref(n)) != 0:
+        raise NrqError("kconst build failed")
+    buf = bytes(C.string_at(out, n.value))
+    lib().nrq_host_free(out)
+    return buf
+
+
+def host_plan(K, isis, kconst):
+    """Host planner: returns the plan arena as bytes (header status tells solvable/singular)."""
+    isis = np.ascontiguousarray(isis, dtype=np.uint32)
+    kc = (C.c_uint8 * len(kconst)).from_buffer_copy(kconst)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_uint32()
+    rc = lib().nrq_host_plan_build(K, len(isis), _u32(isis), kc, C.byref(out), C.byref(n))
+    if rc != 0:
+        raise NrqError("plan build failed: %d" % rc)
+    buf = bytes(C.string_at(out, n.value))
+    lib().nrq_host_free(out)
+    return buf
+
+
+def plan_header(plan):
+    h = np.frombuffer(plan, dtype=np.uint32, count=len(PLAN_FIELDS))
+    return dict(zip(PLAN_FIELDS, (int(x) for x in h)))
+
+
+class Context:
+    """One per GPU.  Device buffers are plain integers (device addresses): pass torch tensor
+    data_ptr()s, or use alloc()/upload()/download()."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.nrq_ctx_create(device, C.c_void_p(stream or 0), C.byref(h))
+        if rc != 0:
+            raise NrqError("nrq_ctx_create failed (%d): no usable HIP device -- the HIP path has no CPU fallback" % rc)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nrq_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NrqError("%s (rc=%d)" % (self._L.nrq_ctx_error(self._h).decode(), rc))
+
+    def set_stream(self, stream):
+        self._chk(self._L.nrq_ctx_set_stream(self._h, C.c_void_p(stream or 0)))
+
+    def set_threads(self, n):
+        self._chk(self._L.nrq_ctx_set_threads(self._h, n))
+
+    def sync(self):
+        self._chk(self._L.nrq_ctx_sync(self._h))
+
+    def stats(self):
+        s = CallStats()
+        self._L.nrq_ctx_last_stats(self._h, C.byref(s))
+        return s.as_dict()
+
+    def precalculate(self, K):
+        self._chk(self._L.nrq_precalculate(self._h, K))
+
+    def clear_plan_cache(self):
+        self._L.nrq_plan_cache_clear(self._h)
+
+    # -- raw device memory -------------------------------------------------------------------
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self._L.nrq_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        self._chk(self._L.nrq_dev_free(self._h, C.c_void_p(ptr)))
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self._L.nrq_dev_upload(self._h, C.c_void_p(dptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def download(self, dptr, nbytes):
+        out = np.empty(nbytes, np.uint8)
+        self._chk(self._L.nrq_dev_download(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), nbytes))
+        return out
+
+    def memset(self, dptr, value, nbytes):
+        self._chk(self._L.nrq_dev_memset(self._h, C.c_void_p(dptr), value, nbytes))
+
+    # -- hot path ----------------------------------------------------------------------------
+    def encode_blocks(self, K, T, nblk, d_src, src_stride, d_rep, rep_stride, esis, d_inter=0, inter_stride=0):
+        esis = np.ascontiguousarray(esis, dtype=np.uint32)
+        self._chk(self._L.nrq_encode_blocks(self._h, K, T, nblk, C.c_void_p(d_src), src_stride,
+                                            C.c_void_p(d_inter or 0), inter_stride, len(esis),
+                                            _u32(esis) if len(esis) else None, C.c_void_p(d_rep or 0), rep_stride))
+
+    def decode_blocks(self, K, T, nblk, d_src, src_stride, lost, nlost, rep_esi, nrep, d_rep, rep_stride,
+                      d_inter=0, inter_stride=0):
+        """lost: [nblk, lost_cap] uint32, rep_esi: [nblk, rep_cap] uint32. Returns status int array."""
+        lost = np.ascontiguousarray(lost, dtype=np.uint32).reshape(nblk, -1)
+        rep_esi = np.ascontiguousarray(rep_esi, dtype=np.uint32).reshape(nblk, -1)
+        nlost = np.ascontiguousarray(nlost, dtype=np.uint32)
+        nrep = np.ascontiguousarray(nrep, dtype=np.uint32)
+        status = np.zeros(nblk, dtype=np.int32)
+        self._chk(self._L.nrq_decode_blocks(self._h, K, T, nblk, C.c_void_p(d_src), src_stride, _u32(lost),
+                                            _u32(nlost), lost.shape[1], _u32(rep_esi), _u32(nrep), rep_esi.shape[1],
+                                            C.c_void_p(d_rep or 0), rep_stride, C.c_void_p(d_inter or 0),
+                                            inter_stride, status.ctypes.data_as(C.POINTER(C.c_int))))
+        return status
+
+    def gen_symbols(self, K, T, nblk, d_inter, inter_stride, isis, d_out, out_stride):
+        isis = np.ascontiguousarray(isis, dtype=np.uint32)
+        self._chk(self._L.nrq_gen_symbols(self._h, K, T, nblk, C.c_void_p(d_inter), inter_stride, len(isis),
+                                          _u32(isis), C.c_void_p(d_out), out_stride))
+
+    def timer_start(self):
+        self._chk(self._L.nrq_timer_start(self._h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._chk(self._L.nrq_timer_stop_ms(self._h, C.byref(ms)))
+        return float(ms.value)

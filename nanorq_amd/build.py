@@ -1,0 +1,87 @@
+"""Builds the in-tree native libraries.
+
+  libnanorq_hip.so   product: gfx950 kernels + C ABI (include/nanorq_hip.h) + drop-in nanorq.h/io.h
+                     layer, compiled with hipcc --offload-arch=gfx950 (cross-compiles without a GPU)
+  tests/emu/libsolve_emu.so   test support: CPU emulation of the solve workgroup (g++)
+
+The .so files are git-ignored but travel to the GPU box with the working tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libnanorq_hip.so")
+EMU = os.path.join(ROOT, "tests", "emu", "libsolve_emu.so")
+
+HIP_SOURCES = ["nrq_device.hip"]
+CXX_SOURCES = ["planner_host.cpp"]
+C_SOURCES = ["nanorq_api.c", "io.c"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (no CPU fallback exists)")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _deps():
+    out = []
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        for f in os.listdir(d):
+            out.append(os.path.join(d, f))
+    return out
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not _newer(LIB, _deps()):
+        return LIB
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    common = ["-O3", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    for s in HIP_SOURCES:
+        o = os.path.join(objdir, s + ".o")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", *common, "-c", os.path.join(CSRC, s), "-o", o],
+                       check=True)
+        objs.append(o)
+    for s in CXX_SOURCES:
+        o = os.path.join(objdir, s + ".o")
+        subprocess.run(["g++", "-std=c++17", "-Wall", *common, "-c", os.path.join(CSRC, s), "-o", o], check=True)
+        objs.append(o)
+    for s in C_SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        o = os.path.join(objdir, s + ".o")
+        subprocess.run(["gcc", "-std=gnu11", "-Wall", "-D_FILE_OFFSET_BITS=64", *common, "-c", src, "-o", o], check=True)
+        objs.append(o)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-lpthread"], check=True)
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+def build_emu(force=False):
+    src = os.path.join(ROOT, "tests", "emu", "solve_emu.cpp")
+    deps = [src, os.path.join(CSRC, "solve_body.h"), os.path.join(CSRC, "plan.h")]
+    if force or _newer(EMU, deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", EMU, src], check=True)
+    return EMU
+
+
+if __name__ == "__main__":
+    build_lib(force="-f" in sys.argv, verbose=True)
+    build_emu(force="-f" in sys.argv)

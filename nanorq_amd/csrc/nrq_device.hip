@@ -1,0 +1,731 @@
+/*
+ * nrq_device.hip -- gfx950 kernels and the C ABI of include/nanorq_hip.h.
+ *
+ * Kernels
+ *   nrq_solve_kernel<WB>   the whole data stage of the precode solve for one WB-byte column strip
+ *                          of one source block, LDS-resident (phases in solve_body.h)
+ *   nrq_gen_kernel         LT symbol generation from intermediate symbols in HBM
+ *                          (reference decode_row, nanorq.c:184-204)
+ * Host side: context, per-K' caches, plan staging, batching, launch geometry.
+ * MI355X only: wave64, 160 KiB LDS per workgroup, XCD-aware workgroup->strip mapping.
+ */
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/nanorq_hip.h"
+#include "plan.h"
+#include "planner_host.h"
+#include "rq_math.h"
+#include "solve_body.h"
+
+#define NRQ_LDS_MAX 163840u /* 160 KiB per workgroup on gfx950 */
+#define NRQ_WG 256
+
+/* ============================================================================================
+ * Kernels
+ * ========================================================================================== */
+
+/* Workgroup -> (block, strip).  Workgroup n is dispatched to XCD n%8 (observed; speed only).  The
+ * strips that share one 128-byte line of every symbol row are given consecutive slots on ONE XCD so
+ * that the line is fetched into (and write-combined in) a single L2. */
+__device__ __forceinline__ bool nrq_map_strip(uint32_t wb, uint32_t nblk, uint32_t nstrips, uint32_t *blk,
+                                              uint32_t *strip) {
+  const uint32_t n = blockIdx.x, xcd = n & 7u, m = n >> 3;
+  const uint32_t spl = 128u / wb;                       /* strips per 128-byte line */
+  const uint32_t gpb = (nstrips + spl - 1u) / spl;      /* line groups per block */
+  const uint32_t q = (m / spl) * 8u + xcd, sidx = m % spl;
+  if (q >= nblk * gpb) return false;
+  *blk = q / gpb;
+  *strip = (q % gpb) * spl + sidx;
+  return *strip < nstrips;
+}
+
+template <int WB>
+__global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
+                                                           uint32_t T, uint32_t nstrips,
+                                                           const uint8_t *__restrict__ kc) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t blk, strip;
+  if (!nrq_map_strip(WB, nblk, nstrips, &blk, &strip)) return;
+  StripCtx<WB> c;
+  c.job = jobs[blk];
+  c.plan = reinterpret_cast<const uint8_t *>(c.job.plan);
+  c.h = reinterpret_cast<const nrq_plan_hdr *>(c.plan);
+  if (c.h->status) return; /* rank deficient: nothing is written for this block */
+  c.kc = kc;
+  c.lds = smem;
+  c.lay = nrq_lds_plan(c.h, WB);
+  c.T = T;
+  c.strip = strip;
+  const uint32_t rem = T - strip * WB;
+  c.valid = rem < (uint32_t)WB ? rem : (uint32_t)WB;
+  const uint32_t tid = threadIdx.x;
+
+  ph_load<WB>(c, tid, NRQ_WG);
+  __syncthreads();
+
+  /* forward passes: chunks of 256 independent-up-to-accumulation XOR ops; op words are
+   * prefetched four chunks ahead so that their L2 latency never sits on the dependency chain */
+  {
+    const uint32_t *ops = c.template arr<uint32_t>(c.h->off_ops);
+    const uint32_t nch = c.h->nchunk1 + c.h->nchunk2;
+    uint32_t q0 = nch > 0 ? ops[tid] : NRQ_NOP;
+    uint32_t q1 = nch > 1 ? ops[NRQ_WG + tid] : NRQ_NOP;
+    uint32_t q2 = nch > 2 ? ops[2 * NRQ_WG + tid] : NRQ_NOP;
+    uint32_t q3 = nch > 3 ? ops[3 * NRQ_WG + tid] : NRQ_NOP;
+    const uint32_t *sy = c.syncw();
+    for (uint32_t ch = 0; ch < nch; ch++) {
+      const uint32_t cur = q0;
+      q0 = q1; q1 = q2; q2 = q3;
+      q3 = (ch + 4 < nch) ? ops[(size_t)(ch + 4) * NRQ_WG + tid] : NRQ_NOP;
+      ph_op<WB>(c, cur);
+      if ((sy[ch >> 5] >> (ch & 31u)) & 1u) __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  ph_hdpc<WB>(c, tid, NRQ_WG);
+  ph_dense_bin<WB>(c, tid, NRQ_WG);
+  __syncthreads();
+  ph_dense_fold<WB>(c, tid, NRQ_WG);
+  __syncthreads();
+  ph_dense_free<WB>(c, tid, NRQ_WG);
+  __syncthreads();
+  ph_dense_cu<WB>(c, tid, NRQ_WG);
+  __syncthreads();
+  ph_tables<WB>(c, tid, NRQ_WG);
+  __syncthreads();
+  ph_backsub<WB>(c, tid, NRQ_WG);
+  ph_park<WB>(c, tid, NRQ_WG);
+  __syncthreads();
+  ph_store<WB>(c, tid, NRQ_WG);
+}
+
+/* One workgroup per (symbol, block): out = XOR of the LT neighbours of `isi` among the L
+ * intermediate symbols in HBM (coalesced 16-byte lanes along the symbol). */
+__global__ __launch_bounds__(NRQ_WG) void nrq_gen_kernel(rq_params p, uint32_t T, const uint8_t *__restrict__ inter,
+                                                         size_t inter_stride, const uint32_t *__restrict__ isis,
+                                                         uint8_t *__restrict__ out, size_t out_stride) {
+  __shared__ uint32_t cols[RQ_MAX_LT_COLS];
+  __shared__ uint32_t ncols;
+  const uint32_t q = blockIdx.x, b = blockIdx.y;
+  if (threadIdx.x == 0) {
+    uint32_t tmp[RQ_MAX_LT_COLS];
+    uint32_t n = rq_lt_columns(&p, isis[q], tmp);
+    for (uint32_t k = 0; k < n; k++) cols[k] = tmp[k];
+    ncols = n;
+  }
+  __syncthreads();
+  const uint8_t *C = inter + (size_t)b * inter_stride;
+  uint8_t *dst = out + (size_t)b * out_stride + (size_t)q * T;
+  const uint32_t n = ncols;
+  const bool vec = ((T & 15u) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+  if (vec) {
+    for (uint32_t off = threadIdx.x * 16u; off < T; off += NRQ_WG * 16u) {
+      uint4 acc = make_uint4(0, 0, 0, 0);
+      for (uint32_t k = 0; k < n; k++) {
+        uint4 v = *reinterpret_cast<const uint4 *>(C + (size_t)cols[k] * T + off);
+        acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+      }
+      *reinterpret_cast<uint4 *>(dst + off) = acc;
+    }
+  } else {
+    for (uint32_t off = threadIdx.x; off < T; off += NRQ_WG) {
+      uint8_t acc = 0;
+      for (uint32_t k = 0; k < n; k++) acc ^= C[(size_t)cols[k] * T + off];
+      dst[off] = acc;
+    }
+  }
+}
+
+/* ============================================================================================
+ * Host side
+ * ========================================================================================== */
+namespace {
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct DevBuf {
+  uint8_t *p = nullptr;
+  size_t cap = 0;
+};
+struct PinBuf {
+  uint8_t *p = nullptr;
+  size_t cap = 0;
+};
+
+struct KConst {
+  uint8_t *host = nullptr;
+  uint8_t *dev = nullptr;
+  uint32_t bytes = 0;
+};
+
+struct EncPlan {
+  uint8_t *dev = nullptr; /* plan arena followed by rowsrc */
+  uint32_t plan_bytes = 0;
+  uint32_t rowsrc_off = 0;
+  nrq_plan_hdr hdr;
+  double build_ms = 0;
+};
+
+inline size_t r16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+} // namespace
+
+struct nrq_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::map<uint32_t, KConst> kconst;    /* by K' */
+  std::map<uint32_t, EncPlan> encplans; /* by K */
+  DevBuf scratch[2];                    /* per-call device arrays (double-buffered across calls) */
+  PinBuf staging[2];
+  hipEvent_t staged[2] = {nullptr, nullptr};
+  int flip = 0;
+  int threads = 0;
+  nrq_call_stats stats;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool attr_set[4] = {false, false, false, false};
+};
+
+namespace {
+
+int fail(nrq_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                                   \
+  do {                                                                                                      \
+    hipError_t e_ = (call);                                                                                 \
+    if (e_ != hipSuccess) return fail(ctx, -10, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                                      __FILE__, __LINE__);                                                  \
+  } while (0)
+
+int ensure_dev(nrq_ctx *ctx, DevBuf &b, size_t bytes) {
+  if (b.cap >= bytes) return 0;
+  if (b.p) HIPCHK(ctx, hipFree(b.p));
+  b.p = nullptr; b.cap = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  HIPCHK(ctx, hipMalloc((void **)&b.p, want));
+  b.cap = want;
+  return 0;
+}
+int ensure_pin(nrq_ctx *ctx, PinBuf &b, size_t bytes) {
+  if (b.cap >= bytes) return 0;
+  if (b.p) HIPCHK(ctx, hipHostFree(b.p));
+  b.p = nullptr; b.cap = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  HIPCHK(ctx, hipHostMalloc((void **)&b.p, want, hipHostMallocDefault));
+  b.cap = want;
+  return 0;
+}
+
+int get_kconst(nrq_ctx *ctx, uint32_t K, KConst **out) {
+  rq_params p;
+  if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
+  auto it = ctx->kconst.find(p.Kp);
+  if (it == ctx->kconst.end()) {
+    KConst kc;
+    if (nrq_host_kconst_build(K, &kc.host, &kc.bytes) != 0) return fail(ctx, -2, "kconst build failed");
+    HIPCHK(ctx, hipMalloc((void **)&kc.dev, kc.bytes));
+    HIPCHK(ctx, hipMemcpy(kc.dev, kc.host, kc.bytes, hipMemcpyHostToDevice));
+    it = ctx->kconst.emplace(p.Kp, kc).first;
+  }
+  *out = &it->second;
+  return 0;
+}
+
+int get_encplan(nrq_ctx *ctx, uint32_t K, EncPlan **out) {
+  auto it = ctx->encplans.find(K);
+  if (it != ctx->encplans.end()) { *out = &it->second; return 0; }
+  rq_params p;
+  if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
+  KConst *kc;
+  int rc = get_kconst(ctx, K, &kc);
+  if (rc) return rc;
+  double t0 = now_ms();
+  std::vector<uint32_t> isis(p.Kp);
+  for (uint32_t j = 0; j < p.Kp; j++) isis[j] = j;
+  uint8_t *arena = nullptr;
+  uint32_t bytes = 0;
+  if (nrq_host_plan_build(K, p.Kp, isis.data(), kc->host, &arena, &bytes) != 0)
+    return fail(ctx, -2, "encode plan build failed for K=%u", K);
+  EncPlan ep;
+  memcpy(&ep.hdr, arena, sizeof(ep.hdr));
+  if (ep.hdr.status) { nrq_host_free(arena); return fail(ctx, -3, "encode matrix singular for K=%u (cannot happen)", K); }
+  ep.plan_bytes = bytes;
+  ep.rowsrc_off = (uint32_t)r16(bytes);
+  std::vector<uint32_t> rowsrc(p.L, NRQ_ROW_ZERO);
+  for (uint32_t j = 0; j < K; j++) rowsrc[p.S + p.H + j] = j;
+  size_t total = ep.rowsrc_off + (size_t)p.L * 4;
+  HIPCHK(ctx, hipMalloc((void **)&ep.dev, total));
+  HIPCHK(ctx, hipMemcpy(ep.dev, arena, bytes, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ep.dev + ep.rowsrc_off, rowsrc.data(), (size_t)p.L * 4, hipMemcpyHostToDevice));
+  nrq_host_free(arena);
+  ep.build_ms = now_ms() - t0;
+  it = ctx->encplans.emplace(K, ep).first;
+  *out = &it->second;
+  return 0;
+}
+
+/* LT neighbour lists of the symbols to generate, in the layout ph_store() reads */
+void build_out_lists(const rq_params &p, uint32_t n, const uint32_t *isis, std::vector<uint32_t> &cptr,
+                     std::vector<uint16_t> &cols) {
+  cptr.resize(n + 1);
+  cols.clear();
+  cols.reserve((size_t)n * 9);
+  uint32_t tmp[RQ_MAX_LT_COLS];
+  for (uint32_t q = 0; q < n; q++) {
+    cptr[q] = (uint32_t)cols.size();
+    uint32_t m = rq_lt_columns(&p, isis[q], tmp);
+    for (uint32_t k = 0; k < m; k++) cols.push_back((uint16_t)tmp[k]);
+  }
+  cptr[n] = (uint32_t)cols.size();
+}
+
+template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, uint32_t nblk, uint32_t T,
+                                const uint8_t *d_kc, uint32_t lds_bytes) {
+  const uint32_t nstrips = (T + WB - 1) / WB, spl = 128u / WB;
+  const uint32_t gpb = (nstrips + spl - 1) / spl;
+  const uint64_t groups = (uint64_t)nblk * gpb;
+  const uint64_t grid = ((groups + 7) / 8) * 8 * spl;
+  if (grid > 0x7FFFFFFFull) return fail(ctx, -4, "grid too large");
+  if (!ctx->attr_set[slot]) {
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    ctx->attr_set[slot] = true;
+  }
+  hipLaunchKernelGGL(nrq_solve_kernel<WB>, dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T,
+                     nstrips, d_kc);
+  HIPCHK(ctx, hipGetLastError());
+  ctx->stats.strip_bytes = WB;
+  ctx->stats.lds_bytes = lds_bytes;
+  ctx->stats.grid = (uint32_t)grid;
+  return 0;
+}
+
+/* widest strip whose LDS image fits for every plan header in hdrs */
+int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs, const nrq_job *d_jobs, uint32_t nblk,
+                    uint32_t T, const uint8_t *d_kc) {
+  static const uint32_t widths[4] = {16, 8, 4, 2};
+  for (int s = 0; s < 4; s++) {
+    uint32_t need = 0;
+    for (const nrq_plan_hdr *h : hdrs) {
+      if (h->status) continue;
+      uint32_t t = nrq_lds_plan(h, widths[s]).total;
+      if (t > need) need = t;
+    }
+    if (need == 0) return 0; /* nothing solvable in this batch */
+    if (need > NRQ_LDS_MAX) continue;
+    switch (widths[s]) {
+      case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need);
+      case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need);
+      case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need);
+      default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need);
+    }
+  }
+  return fail(ctx, -5, "block too large for the LDS-resident solver");
+}
+
+} // namespace
+
+/* ============================================================================================
+ * C ABI
+ * ========================================================================================== */
+extern "C" {
+
+int nrq_params(uint32_t K, uint32_t out[10]) {
+  rq_params p;
+  if (!rq_params_init(K, &p)) return -1;
+  out[0] = p.Kp; out[1] = p.J; out[2] = p.S; out[3] = p.H; out[4] = p.W;
+  out[5] = p.L; out[6] = p.P; out[7] = p.P1; out[8] = p.U; out[9] = p.B;
+  return 0;
+}
+
+int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
+  if (!out) return -1;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -20; /* no HIP device: fail loudly, no fallback */
+  if (device < 0 || device >= ndev) return -21;
+  if (hipSetDevice(device) != hipSuccess) return -22;
+  nrq_ctx *ctx = new nrq_ctx();
+  ctx->device = device;
+  ctx->stream = (hipStream_t)stream;
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  if (hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->staged[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->staged[1], hipEventDisableTiming) != hipSuccess) {
+    delete ctx;
+    return -23;
+  }
+  *out = ctx;
+  return 0;
+}
+
+void nrq_plan_cache_clear(nrq_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->encplans)
+    if (kv.second.dev) (void)hipFree(kv.second.dev);
+  ctx->encplans.clear();
+}
+
+void nrq_ctx_destroy(nrq_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  nrq_plan_cache_clear(ctx);
+  for (auto &kv : ctx->kconst) {
+    if (kv.second.dev) (void)hipFree(kv.second.dev);
+    nrq_host_free(kv.second.host);
+  }
+  for (int i = 0; i < 2; i++) {
+    if (ctx->scratch[i].p) (void)hipFree(ctx->scratch[i].p);
+    if (ctx->staging[i].p) (void)hipHostFree(ctx->staging[i].p);
+    if (ctx->staged[i]) (void)hipEventDestroy(ctx->staged[i]);
+  }
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  delete ctx;
+}
+
+int nrq_ctx_set_stream(nrq_ctx *ctx, void *stream) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = (hipStream_t)stream;
+  return 0;
+}
+
+const char *nrq_ctx_error(nrq_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+int nrq_ctx_sync(nrq_ctx *ctx) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+void nrq_ctx_last_stats(nrq_ctx *ctx, nrq_call_stats *out) {
+  if (ctx && out) *out = ctx->stats;
+}
+
+int nrq_ctx_set_threads(nrq_ctx *ctx, int n) {
+  if (!ctx || n < 0) return -1;
+  ctx->threads = n;
+  return 0;
+}
+
+int nrq_precalculate(nrq_ctx *ctx, uint32_t K) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  EncPlan *ep;
+  return get_encplan(ctx, K, &ep);
+}
+
+int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,
+                      void *d_inter, size_t inter_stride, uint32_t nrep, const uint32_t *h_esis, void *d_rep,
+                      size_t rep_stride) {
+  if (!ctx) return -1;
+  if (!d_src || T == 0 || nblk == 0 || (nrep && (!h_esis || !d_rep))) return fail(ctx, -1, "bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const double t_begin = now_ms();
+  rq_params p;
+  if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
+  for (uint32_t q = 0; q < nrep; q++)
+    if (h_esis[q] < K || h_esis[q] >= (1u << 24)) return fail(ctx, -1, "repair ESI %u out of range", h_esis[q]);
+  KConst *kc;
+  int rc = get_kconst(ctx, K, &kc);
+  if (rc) return rc;
+  const bool cached = ctx->encplans.count(K) != 0;
+  EncPlan *ep;
+  rc = get_encplan(ctx, K, &ep);
+  if (rc) return rc;
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  ctx->stats.plan_ms = cached ? 0.0 : ep->build_ms;
+  ctx->stats.plan_bytes = ep->plan_bytes;
+  ctx->stats.xor_ops = (uint64_t)ep->hdr.n_xor_ops * nblk;
+  ctx->stats.npiv = ep->hdr.npiv; ctx->stats.u = ep->hdr.u; ctx->stats.nlev = ep->hdr.nlev;
+  ctx->stats.nfree = ep->hdr.nfree;
+
+  /* per-call arrays: [jobs][isi->(cptr, cols, row)] */
+  std::vector<uint32_t> isis(nrep), cptr;
+  std::vector<uint16_t> cols;
+  for (uint32_t q = 0; q < nrep; q++) isis[q] = h_esis[q] + (p.Kp - K);
+  build_out_lists(p, nrep, isis.data(), cptr, cols);
+  const size_t off_jobs = 0;
+  const size_t off_cptr = r16(off_jobs + (size_t)nblk * sizeof(nrq_job));
+  const size_t off_row = r16(off_cptr + (size_t)(nrep + 1) * 4);
+  const size_t off_cols = r16(off_row + (size_t)(nrep ? nrep : 1) * 4);
+  const size_t total = r16(off_cols + cols.size() * 2 + 16);
+  const int f = ctx->flip;
+  ctx->flip ^= 1;
+  HIPCHK(ctx, hipEventSynchronize(ctx->staged[f]));
+  if ((rc = ensure_pin(ctx, ctx->staging[f], total))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->scratch[f], total))) return rc;
+  uint8_t *hs = ctx->staging[f].p, *ds = ctx->scratch[f].p;
+  memcpy(hs + off_cptr, cptr.data(), (size_t)(nrep + 1) * 4);
+  for (uint32_t q = 0; q < nrep; q++) reinterpret_cast<uint32_t *>(hs + off_row)[q] = q;
+  if (!cols.empty()) memcpy(hs + off_cols, cols.data(), cols.size() * 2);
+  nrq_job *jobs = reinterpret_cast<nrq_job *>(hs + off_jobs);
+  for (uint32_t b = 0; b < nblk; b++) {
+    nrq_job &j = jobs[b];
+    memset(&j, 0, sizeof(j));
+    j.plan = (uint64_t)(uintptr_t)ep->dev;
+    j.rowsrc = (uint64_t)(uintptr_t)(ep->dev + ep->rowsrc_off);
+    j.src = (uint64_t)(uintptr_t)((const uint8_t *)d_src + (size_t)b * src_stride);
+    j.rep = 0;
+    j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
+    j.out = nrep ? (uint64_t)(uintptr_t)((uint8_t *)d_rep + (size_t)b * rep_stride) : 0;
+    j.out_cptr = (uint64_t)(uintptr_t)(ds + off_cptr);
+    j.out_cols = (uint64_t)(uintptr_t)(ds + off_cols);
+    j.out_row = (uint64_t)(uintptr_t)(ds + off_row);
+    j.nout = nrep;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->staged[f], ctx->stream));
+  std::vector<const nrq_plan_hdr *> hdrs(1, &ep->hdr);
+  rc = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds + off_jobs), nblk, T, kc->dev);
+  ctx->stats.host_ms = now_ms() - t_begin;
+  return rc;
+}
+
+int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                      const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                      const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
+                      size_t inter_stride, int *h_status) {
+  if (!ctx) return -1;
+  if (!d_src || T == 0 || nblk == 0 || !h_nlost || !h_nrep || !h_status) return fail(ctx, -1, "bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const double t_begin = now_ms();
+  rq_params p;
+  if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
+  KConst *kc;
+  int rc = get_kconst(ctx, K, &kc);
+  if (rc) return rc;
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+
+  struct Prep {
+    uint8_t *plan = nullptr;
+    uint32_t plan_bytes = 0;
+    std::vector<uint32_t> rowsrc, cptr, orow;
+    std::vector<uint16_t> cols;
+    int state = 0; /* 0 = nothing to do, 1 = solve, -1 = cannot */
+    size_t off_plan = 0, off_rowsrc = 0, off_cptr = 0, off_row = 0, off_cols = 0;
+  };
+  std::vector<Prep> prep(nblk);
+  const uint32_t pad = p.Kp - K;
+
+  auto prepare = [&](uint32_t b) {
+    Prep &pr = prep[b];
+    const uint32_t nl = h_nlost[b], nr = h_nrep[b];
+    if (nl == 0) { pr.state = 0; return; }             /* nothing missing (nanorq.c:605-606) */
+    if (nr < nl || nl > lost_cap || nr > rep_cap) { pr.state = -1; return; } /* nanorq.c:607-608 */
+    const uint32_t *lost = h_lost + (size_t)b * lost_cap;
+    const uint32_t *resi = h_rep_esi + (size_t)b * rep_cap;
+    const uint32_t overhead = nr - nl;
+    const uint32_t M = p.L + overhead;
+    if (M > 65535u) { pr.state = -1; return; }
+    std::vector<uint32_t> isis(p.Kp + overhead);
+    for (uint32_t j = 0; j < p.Kp; j++) isis[j] = j;
+    pr.rowsrc.assign(M, NRQ_ROW_ZERO);
+    for (uint32_t j = 0; j < K; j++) pr.rowsrc[p.S + p.H + j] = j;
+    for (uint32_t g = 0; g < nl; g++) {
+      if (lost[g] >= K || (g && lost[g] <= lost[g - 1]) || resi[g] < K || resi[g] >= (1u << 24)) { pr.state = -1; return; }
+      isis[lost[g]] = resi[g] + pad;
+      pr.rowsrc[p.S + p.H + lost[g]] = NRQ_ROW_REP | g;
+    }
+    for (uint32_t e = 0; e < overhead; e++) {
+      if (resi[nl + e] < K || resi[nl + e] >= (1u << 24)) { pr.state = -1; return; }
+      isis[p.Kp + e] = resi[nl + e] + pad;
+      pr.rowsrc[p.L + e] = NRQ_ROW_REP | (nl + e);
+    }
+    if (nrq_host_plan_build(K, p.Kp + overhead, isis.data(), kc->host, &pr.plan, &pr.plan_bytes) != 0) {
+      pr.state = -1;
+      return;
+    }
+    if (reinterpret_cast<const nrq_plan_hdr *>(pr.plan)->status) { pr.state = -1; return; } /* rank(A) < L */
+    build_out_lists(p, nl, lost, pr.cptr, pr.cols); /* ISI of a source symbol is its ESI */
+    pr.orow.assign(lost, lost + nl);
+    pr.state = 1;
+  };
+
+  const double t_plan0 = now_ms();
+  {
+    uint32_t nth = ctx->threads > 0 ? (uint32_t)ctx->threads : std::thread::hardware_concurrency();
+    if (nth == 0) nth = 1;
+    if (nth > nblk) nth = nblk;
+    std::atomic<uint32_t> next(0);
+    auto worker = [&]() {
+      for (;;) {
+        uint32_t b = next.fetch_add(1);
+        if (b >= nblk) break;
+        prepare(b);
+      }
+    };
+    if (nth <= 1) worker();
+    else {
+      std::vector<std::thread> pool;
+      for (uint32_t t = 0; t < nth; t++) pool.emplace_back(worker);
+      for (auto &t : pool) t.join();
+    }
+  }
+  ctx->stats.plan_ms = now_ms() - t_plan0;
+
+  /* pack everything the kernel reads into one staging image */
+  size_t off = r16((size_t)nblk * sizeof(nrq_job));
+  /* a shared dummy header (status=1) for blocks that need no launch work */
+  const size_t off_dummy = off;
+  off = r16(off + sizeof(nrq_plan_hdr));
+  uint32_t nsolve = 0;
+  for (uint32_t b = 0; b < nblk; b++) {
+    Prep &pr = prep[b];
+    h_status[b] = pr.state >= 0 ? 1 : 0;
+    if (pr.state != 1) continue;
+    nsolve++;
+    pr.off_plan = off;   off = r16(off + pr.plan_bytes);
+    pr.off_rowsrc = off; off = r16(off + pr.rowsrc.size() * 4);
+    pr.off_cptr = off;   off = r16(off + pr.cptr.size() * 4);
+    pr.off_row = off;    off = r16(off + pr.orow.size() * 4);
+    pr.off_cols = off;   off = r16(off + pr.cols.size() * 2 + 16);
+  }
+  const size_t total = off;
+  int result = 0;
+  if (nsolve) {
+    const int f = ctx->flip;
+    ctx->flip ^= 1;
+    HIPCHK(ctx, hipEventSynchronize(ctx->staged[f]));
+    if ((rc = ensure_pin(ctx, ctx->staging[f], total))) return rc;
+    if ((rc = ensure_dev(ctx, ctx->scratch[f], total))) return rc;
+    uint8_t *hs = ctx->staging[f].p, *ds = ctx->scratch[f].p;
+    nrq_plan_hdr dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    dummy.magic = NRQ_PLAN_MAGIC;
+    dummy.status = 1;
+    memcpy(hs + off_dummy, &dummy, sizeof(dummy));
+    nrq_job *jobs = reinterpret_cast<nrq_job *>(hs);
+    std::vector<const nrq_plan_hdr *> hdrs;
+    for (uint32_t b = 0; b < nblk; b++) {
+      Prep &pr = prep[b];
+      nrq_job &j = jobs[b];
+      memset(&j, 0, sizeof(j));
+      if (pr.state != 1) { j.plan = (uint64_t)(uintptr_t)(ds + off_dummy); continue; }
+      memcpy(hs + pr.off_plan, pr.plan, pr.plan_bytes);
+      memcpy(hs + pr.off_rowsrc, pr.rowsrc.data(), pr.rowsrc.size() * 4);
+      memcpy(hs + pr.off_cptr, pr.cptr.data(), pr.cptr.size() * 4);
+      memcpy(hs + pr.off_row, pr.orow.data(), pr.orow.size() * 4);
+      if (!pr.cols.empty()) memcpy(hs + pr.off_cols, pr.cols.data(), pr.cols.size() * 2);
+      const nrq_plan_hdr *h = reinterpret_cast<const nrq_plan_hdr *>(hs + pr.off_plan);
+      hdrs.push_back(h);
+      if (ctx->stats.npiv == 0) {
+        ctx->stats.npiv = h->npiv; ctx->stats.u = h->u; ctx->stats.nlev = h->nlev; ctx->stats.nfree = h->nfree;
+      }
+      ctx->stats.xor_ops += h->n_xor_ops;
+      ctx->stats.plan_bytes += pr.plan_bytes;
+      j.plan = (uint64_t)(uintptr_t)(ds + pr.off_plan);
+      j.rowsrc = (uint64_t)(uintptr_t)(ds + pr.off_rowsrc);
+      j.src = (uint64_t)(uintptr_t)((uint8_t *)d_src + (size_t)b * src_stride);
+      j.rep = (uint64_t)(uintptr_t)((const uint8_t *)d_rep + (size_t)b * rep_stride);
+      j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
+      j.out = j.src; /* recovered symbols go back into the block's own rows */
+      j.out_cptr = (uint64_t)(uintptr_t)(ds + pr.off_cptr);
+      j.out_cols = (uint64_t)(uintptr_t)(ds + pr.off_cols);
+      j.out_row = (uint64_t)(uintptr_t)(ds + pr.off_row);
+      j.nout = (uint32_t)pr.orow.size();
+    }
+    hipError_t e = hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->staged[f], ctx->stream);
+    if (e != hipSuccess) result = fail(ctx, -10, "staging copy failed: %s", hipGetErrorString(e));
+    else result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds), nblk, T, kc->dev);
+  }
+  for (auto &pr : prep)
+    if (pr.plan) nrq_host_free(pr.plan);
+  ctx->stats.host_ms = now_ms() - t_begin;
+  return result;
+}
+
+int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,
+                    uint32_t n, const uint32_t *h_isi, void *d_out, size_t out_stride) {
+  if (!ctx) return -1;
+  if (!d_inter || !d_out || !h_isi || T == 0 || nblk == 0) return fail(ctx, -1, "bad arguments");
+  if (n == 0) return 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  rq_params p;
+  if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
+  const int f = ctx->flip;
+  ctx->flip ^= 1;
+  int rc;
+  HIPCHK(ctx, hipEventSynchronize(ctx->staged[f]));
+  if ((rc = ensure_pin(ctx, ctx->staging[f], (size_t)n * 4))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->scratch[f], (size_t)n * 4))) return rc;
+  memcpy(ctx->staging[f].p, h_isi, (size_t)n * 4);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->scratch[f].p, ctx->staging[f].p, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->staged[f], ctx->stream));
+  hipLaunchKernelGGL(nrq_gen_kernel, dim3(n, nblk), dim3(NRQ_WG), 0, ctx->stream, p, T, (const uint8_t *)d_inter,
+                     inter_stride, (const uint32_t *)ctx->scratch[f].p, (uint8_t *)d_out, out_stride);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+int nrq_dev_alloc(nrq_ctx *ctx, size_t bytes, void **out) {
+  if (!ctx || !out) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc(out, bytes ? bytes : 16));
+  return 0;
+}
+int nrq_dev_free(nrq_ctx *ctx, void *p) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipFree(p));
+  return 0;
+}
+int nrq_dev_upload(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int nrq_dev_download(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int nrq_dev_memset(nrq_ctx *ctx, void *d_dst, int value, size_t bytes) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+  return 0;
+}
+
+int nrq_timer_start(nrq_ctx *ctx) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream));
+  return 0;
+}
+int nrq_timer_stop_ms(nrq_ctx *ctx, float *ms) {
+  if (!ctx || !ms) return -1;
+  HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(ctx->t1));
+  HIPCHK(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+  return 0;
+}
+
+} /* extern "C" */

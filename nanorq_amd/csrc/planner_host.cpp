@@ -1,0 +1,508 @@
+/*
+ * planner_host.cpp -- symbolic stage on the host: constraint structure -> device plan (plan.h).
+ *
+ * Stands where the reference's precode_matrix_gen / patch_precode_matrix /
+ * precode_matrix_invert stand (precode.c:90-97, :347-377; nanorq.c:527-547), but it is a
+ * different algorithm with the same mathematical result (the solution C of A*C = D is
+ * unique when rank(A) = L, SURVEY.md headline fact 5):
+ *   1. breadth-first peeling: every row with exactly one unresolved column in V claims it in
+ *      the same round (rounds = dependency levels, ~400 at K=8192 instead of the ~1900 of the
+ *      reference's LIFO order); when no such row exists the sparsest remaining row is taken and all
+ *      but one of its columns are inactivated (RFC 6330 section 5.4.2.2 phase 1; the reference only
+ *      ever takes rows of weight <= 2, precode.c:115-126);
+ *   2. W = X^-1 * A_top,U as a bit matrix (replaces the reference's undo/redo passes over X,
+ *      precode.c:23-32 passes B and D);
+ *   3. the u inactive columns: GF(2) Gauss-Jordan on the leftover binary rows first, the H HDPC
+ *      rows (GF(256)) only for the columns the binary rows cannot resolve (reference:
+ *      solve_gf2 / fill_HDPC / solve_gf256, precode.c:232-315).
+ * The GPU planner (planner.hip) produces the same format; this one is the portable twin used
+ * for plans that are built once per K' (encode) and as its cross-check.
+ */
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "plan.h"
+#include "planner_host.h"
+#include "rq_math.h"
+
+namespace {
+
+/* ---- GF(256), RFC 6330 section 5.7 ---- */
+struct GF {
+  uint8_t exp[510], log[256], inv[256];
+  GF() {
+    uint32_t x = 1;
+    for (int e = 0; e < 255; e++) {
+      exp[e] = (uint8_t)x;
+      log[x] = (uint8_t)e;
+      x <<= 1;
+      if (x & 0x100) x ^= 0x11D;
+    }
+    for (int e = 255; e < 510; e++) exp[e] = exp[e - 255];
+    log[0] = 0; inv[0] = 0;
+    for (int v = 1; v < 256; v++) inv[v] = exp[255 - log[v]];
+  }
+  uint8_t mul(uint8_t a, uint8_t b) const { return (a && b) ? exp[log[a] + log[b]] : 0; }
+};
+const GF gf;
+
+inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+
+struct Arena {
+  std::vector<uint8_t> buf;
+  uint32_t reserve(uint32_t bytes) {
+    uint32_t off = align16((uint32_t)buf.size());
+    buf.resize((size_t)off + bytes, 0);
+    return off;
+  }
+  template <class T> T *at(uint32_t off) { return reinterpret_cast<T *>(buf.data() + off); }
+};
+
+inline bool bit(const uint32_t *row, uint32_t x) { return (row[x >> 5] >> (x & 31)) & 1u; }
+inline void flip(uint32_t *row, uint32_t x) { row[x >> 5] ^= 1u << (x & 31); }
+
+} // namespace
+
+/* ------------------------------------------------------------------------------------------ */
+extern "C" int nrq_host_kconst_build(uint32_t K, uint8_t **out, uint32_t *out_bytes) {
+  rq_params p;
+  if (!rq_params_init(K, &p)) return -1;
+  const uint32_t n = p.Kp + p.S, H = p.H;
+  nrq_kconst_hdr h;
+  memset(&h, 0, sizeof(h));
+  h.Kp = p.Kp; h.S = p.S; h.H = H; h.n = n;
+  uint32_t off = align16((uint32_t)sizeof(h));
+  h.off_g = off; off = align16(off + H * n);
+  h.off_b12 = off; off = align16(off + n);
+  h.total_bytes = off;
+  uint8_t *buf = (uint8_t *)calloc(off, 1);
+  if (!buf) return -2;
+  uint8_t *G = buf + h.off_g, *b12 = buf + h.off_b12;
+  /* HDPC = MT * GAMMA evaluated right to left: column c = alpha * column c+1, plus the two unit
+   * entries of MT's column c; the last column is alpha^row (RFC 6330 section 5.3.3.3). */
+  for (uint32_t r = 0; r < H; r++) G[(size_t)r * n + n - 1] = gf.exp[r];
+  for (int64_t c = (int64_t)n - 2; c >= 0; c--) {
+    for (uint32_t r = 0; r < H; r++) {
+      uint8_t right = G[(size_t)r * n + c + 1];
+      G[(size_t)r * n + c] = right ? gf.exp[gf.log[right] + 1] : 0;
+    }
+    uint32_t b1 = rq_rand((uint32_t)c + 1, 6, H);
+    uint32_t b2 = (b1 + rq_rand((uint32_t)c + 1, 7, H - 1) + 1) % H;
+    G[(size_t)b1 * n + c] ^= 1;
+    G[(size_t)b2 * n + c] ^= 1;
+    b12[c] = (uint8_t)(b1 | (b2 << 4));
+  }
+  memcpy(buf, &h, sizeof(h));
+  *out = buf;
+  *out_bytes = off;
+  return 0;
+}
+
+extern "C" void nrq_host_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------ */
+extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *isis, const uint8_t *kconst,
+                                   uint8_t **out, uint32_t *out_bytes) {
+  rq_params p;
+  if (!rq_params_init(K, &p)) return -1;
+  if (nrows < p.Kp) return -1;
+  const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(kconst);
+  if (!kh || kh->Kp != p.Kp) return -1;
+  const uint8_t *G = kconst + kh->off_g;
+  const uint32_t S = p.S, H = p.H, W = p.W, L = p.L, n_hd = p.Kp + p.S;
+  const uint32_t M = S + H + nrows;
+  if (M > 65535u) return -3; /* slots are 16-bit */
+
+  /* ---- A: binary constraint rows as CSR (HDPC rows stay empty) ---- */
+  std::vector<uint32_t> rptr(M + 1, 0);
+  std::vector<uint16_t> cidx;
+  {
+    std::vector<std::vector<uint16_t>> ldpc(S);
+    for (uint32_t c = 0; c < p.B; c++) {
+      uint32_t blk = c / S;
+      ldpc[c % S].push_back((uint16_t)c);
+      ldpc[(c + blk + 1) % S].push_back((uint16_t)c);
+      ldpc[(c + 2 * (blk + 1)) % S].push_back((uint16_t)c);
+    }
+    for (uint32_t r = 0; r < S; r++) {
+      ldpc[r].push_back((uint16_t)(p.B + r));
+      ldpc[r].push_back((uint16_t)(W + r % p.P));
+      ldpc[r].push_back((uint16_t)(W + (r + 1) % p.P));
+    }
+    cidx.reserve((size_t)nrows * 8 + (size_t)p.B * 3 + 3 * S);
+    for (uint32_t r = 0; r < S; r++) {
+      rptr[r] = (uint32_t)cidx.size();
+      /* LDPC part 2 can name the same column twice when P == 1; XOR semantics */
+      cidx.insert(cidx.end(), ldpc[r].begin(), ldpc[r].end());
+    }
+    for (uint32_t r = S; r < S + H; r++) rptr[r] = (uint32_t)cidx.size();
+    uint32_t tmp[RQ_MAX_LT_COLS];
+    for (uint32_t k = 0; k < nrows; k++) {
+      rptr[S + H + k] = (uint32_t)cidx.size();
+      uint32_t n = rq_lt_columns(&p, isis[k], tmp);
+      for (uint32_t q = 0; q < n; q++) cidx.push_back((uint16_t)tmp[q]);
+    }
+    rptr[M] = (uint32_t)cidx.size();
+  }
+  const uint32_t nnz = (uint32_t)cidx.size();
+  /* column lists are sets by construction (W, P1 prime; S > B/S + 1), as in the reference */
+  (void)nnz;
+  /* CSC */
+  std::vector<uint32_t> cptr(L + 1, 0);
+  std::vector<uint16_t> ridx(cidx.size());
+  for (uint16_t c : cidx) cptr[c + 1]++;
+  for (uint32_t c = 0; c < L; c++) cptr[c + 1] += cptr[c];
+  {
+    std::vector<uint32_t> fill(cptr.begin(), cptr.end() - 1);
+    for (uint32_t r = 0; r < M; r++)
+      for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++) ridx[fill[cidx[e]]++] = (uint16_t)r;
+  }
+
+  /* ---- phase 1: breadth-first peeling with inactivation ---- */
+  enum : uint8_t { IN_V = 0, PIVOT = 1, INACTIVE = 2 };
+  std::vector<uint8_t> cstate(L, IN_V);
+  for (uint32_t c = W; c < L; c++) cstate[c] = INACTIVE; /* PI columns start inactive */
+  std::vector<uint32_t> cnt(M, 0), xs(M, 0);
+  for (uint32_t r = 0; r < M; r++)
+    for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++)
+      if (cidx[e] < W) { cnt[r]++; xs[r] ^= cidx[e]; }
+  std::vector<uint8_t> assigned(M, 0);
+  std::vector<uint16_t> owner(L, NRQ_NOSLOT); /* pivot row of a column */
+  std::vector<uint32_t> kof(L, 0);            /* pivot index of a column */
+  std::vector<uint32_t> level(M, 0);
+  std::vector<uint16_t> pivslot, pivcol;
+  std::vector<uint32_t> inact_order; /* V columns in the order they were inactivated */
+  pivslot.reserve(L); pivcol.reserve(L);
+  uint32_t nV = W, nlev = 0;
+  std::vector<uint32_t> frontier, next;
+  for (uint32_t r = 0; r < M; r++)
+    if (cnt[r] == 1) frontier.push_back(r);
+
+  auto drop_column = [&](uint32_t c) { /* c leaves V */
+    for (uint32_t e = cptr[c]; e < cptr[c + 1]; e++) {
+      uint32_t r = ridx[e];
+      cnt[r]--; xs[r] ^= c;
+      if (cnt[r] == 1 && !assigned[r]) next.push_back(r);
+    }
+  };
+
+  std::vector<uint32_t> claimed;
+  while (nV > 0) {
+    if (!frontier.empty()) {
+      claimed.clear();
+      for (uint32_t r : frontier) {
+        if (assigned[r] || cnt[r] != 1) continue;
+        uint32_t c = xs[r];
+        if (owner[c] != NRQ_NOSLOT) continue; /* another row of this round got it first */
+        owner[c] = (uint16_t)r;
+        assigned[r] = 1;
+        claimed.push_back(c);
+      }
+      next.clear();
+      for (uint32_t c : claimed) {
+        uint32_t r = owner[c], lv = 0;
+        for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++) {
+          uint32_t c2 = cidx[e];
+          if (c2 != c && cstate[c2] == PIVOT) lv = std::max(lv, level[owner[c2]] + 1);
+        }
+        level[r] = lv;
+        nlev = std::max(nlev, lv + 1);
+        kof[c] = (uint32_t)pivslot.size();
+        pivslot.push_back((uint16_t)r);
+        pivcol.push_back((uint16_t)c);
+      }
+      for (uint32_t c : claimed) { cstate[c] = PIVOT; nV--; }
+      for (uint32_t c : claimed) drop_column(c);
+      frontier.swap(next);
+      continue;
+    }
+    /* no weight-1 row: take the sparsest unassigned row and inactivate all but one of its columns */
+    uint32_t best = M, bestc = 0xFFFFFFFFu;
+    for (uint32_t r = 0; r < M; r++)
+      if (!assigned[r] && cnt[r] >= 2 && cnt[r] < bestc) {
+        best = r; bestc = cnt[r];
+        if (bestc == 2) break;
+      }
+    next.clear();
+    if (best == M) { /* nothing left that touches V: every remaining V column is inactivated */
+      for (uint32_t c = 0; c < W; c++)
+        if (cstate[c] == IN_V) { cstate[c] = INACTIVE; inact_order.push_back(c); nV--; }
+      break;
+    }
+    uint32_t keep = 0xFFFFFFFFu, keepdeg = 0xFFFFFFFFu;
+    for (uint32_t e = rptr[best]; e < rptr[best + 1]; e++) {
+      uint32_t c = cidx[e];
+      if (cstate[c] != IN_V) continue;
+      uint32_t dg = cptr[c + 1] - cptr[c];
+      if (dg < keepdeg) { keepdeg = dg; keep = c; }
+    }
+    for (uint32_t e = rptr[best]; e < rptr[best + 1]; e++) {
+      uint32_t c = cidx[e];
+      if (cstate[c] != IN_V || c == keep) continue;
+      cstate[c] = INACTIVE; inact_order.push_back(c); nV--;
+      drop_column(c);
+    }
+    frontier.swap(next);
+  }
+  const uint32_t npiv = (uint32_t)pivslot.size();
+  const uint32_t u = L - npiv;
+
+  /* inactive-column numbering: the P permanently inactive columns first, then by inactivation time */
+  std::vector<uint32_t> xof(L, 0xFFFFFFFFu);
+  std::vector<uint16_t> ucol;
+  ucol.reserve(u);
+  for (uint32_t c = W; c < L; c++) { xof[c] = (uint32_t)ucol.size(); ucol.push_back((uint16_t)c); }
+  for (uint32_t c : inact_order) { xof[c] = (uint32_t)ucol.size(); ucol.push_back((uint16_t)c); }
+  if (ucol.size() != u) return -4;
+
+  /* ---- W = X^-1 * A_top,U (bit rows, pivot order is a topological order) ---- */
+  const uint32_t wpr = std::max(1u, (u + 31u) / 32u);
+  std::vector<uint32_t> Wm((size_t)npiv * wpr, 0);
+  for (uint32_t k = 0; k < npiv; k++) {
+    uint32_t r = pivslot[k];
+    uint32_t *wk = &Wm[(size_t)k * wpr];
+    for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++) {
+      uint32_t c = cidx[e];
+      if (cstate[c] == INACTIVE) flip(wk, xof[c]);
+      else if (c != pivcol[k]) {
+        const uint32_t *wj = &Wm[(size_t)kof[c] * wpr];
+        for (uint32_t w = 0; w < wpr; w++) wk[w] ^= wj[w];
+      }
+    }
+  }
+
+  /* ---- leftover binary rows and their reduced coefficient rows over the inactive columns ---- */
+  std::vector<uint16_t> lowslot;
+  for (uint32_t r = 0; r < M; r++)
+    if (!assigned[r] && !(r >= S && r < S + H)) lowslot.push_back((uint16_t)r);
+  const uint32_t nlow = (uint32_t)lowslot.size();
+  const uint32_t lpr = std::max(1u, (nlow + 31u) / 32u);
+  const uint32_t rowlen = wpr + lpr;
+  std::vector<uint32_t> Mb((size_t)nlow * rowlen, 0);
+  for (uint32_t j = 0; j < nlow; j++) {
+    uint32_t r = lowslot[j];
+    uint32_t *mj = &Mb[(size_t)j * rowlen];
+    for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++) {
+      uint32_t c = cidx[e];
+      if (cstate[c] == INACTIVE) flip(mj, xof[c]);
+      else {
+        const uint32_t *wj = &Wm[(size_t)kof[c] * wpr];
+        for (uint32_t w = 0; w < wpr; w++) mj[w] ^= wj[w];
+      }
+    }
+    flip(mj + wpr, j); /* augmented identity: which original low rows are summed into this one */
+  }
+
+  /* ---- XOR op stream: pivot pass by level, then the low-row pass ---- */
+  std::vector<uint32_t> ops, sync_bits;
+  uint32_t n_real_ops = 0, nchunk1 = 0, nchunk2 = 0;
+  {
+    std::vector<uint32_t> lev_cnt(nlev + 1, 0);
+    for (uint32_t k = 0; k < npiv; k++) lev_cnt[level[pivslot[k]] + 1]++;
+    for (uint32_t l = 0; l < nlev; l++) lev_cnt[l + 1] += lev_cnt[l];
+    std::vector<uint32_t> by_level(npiv), fill(lev_cnt.begin(), lev_cnt.end() - 1);
+    for (uint32_t k = 0; k < npiv; k++) by_level[fill[level[pivslot[k]]]++] = k;
+    auto emit_group = [&](const uint32_t *rows, uint32_t nr, bool pivots) {
+      /* round-robin over the rows of the group so that neighbouring ops rarely share a target */
+      size_t start = ops.size();
+      std::vector<uint32_t> cur(nr);
+      for (uint32_t q = 0; q < nr; q++) cur[q] = rptr[pivots ? pivslot[rows[q]] : lowslot[rows[q]]];
+      bool any = true;
+      while (any) {
+        any = false;
+        for (uint32_t q = 0; q < nr; q++) {
+          uint32_t r = pivots ? pivslot[rows[q]] : lowslot[rows[q]];
+          uint32_t own = pivots ? pivcol[rows[q]] : 0xFFFFFFFFu;
+          uint32_t &e = cur[q];
+          while (e < rptr[r + 1] && (cstate[cidx[e]] != PIVOT || cidx[e] == own)) e++;
+          if (e < rptr[r + 1]) {
+            ops.push_back((uint32_t)r | ((uint32_t)owner[cidx[e]] << 16));
+            e++; any = true;
+          }
+        }
+      }
+      n_real_ops += (uint32_t)(ops.size() - start);
+      while ((ops.size() - start) % NRQ_CHUNK) ops.push_back(NRQ_NOP);
+      if (ops.size() > start) { /* ops of one group only accumulate: one barrier after its last chunk */
+        uint32_t last = (uint32_t)(ops.size() / NRQ_CHUNK) - 1;
+        if (sync_bits.size() <= last / 32) sync_bits.resize(last / 32 + 1, 0);
+        sync_bits[last / 32] |= 1u << (last % 32);
+      }
+    };
+    for (uint32_t l = 1; l < nlev; l++) /* level 0 rows have nothing to gather */
+      emit_group(&by_level[lev_cnt[l]], lev_cnt[l + 1] - lev_cnt[l], true);
+    nchunk1 = (uint32_t)(ops.size() / NRQ_CHUNK);
+    std::vector<uint32_t> all_low(nlow);
+    for (uint32_t j = 0; j < nlow; j++) all_low[j] = j;
+    emit_group(all_low.data(), nlow, false);
+    nchunk2 = (uint32_t)(ops.size() / NRQ_CHUNK) - nchunk1;
+  }
+
+  /* ---- HDPC rows over the inactive columns: Mh = G_U ^ G_left * W ---- */
+  std::vector<uint8_t> Mh((size_t)H * u, 0);
+  for (uint32_t x = 0; x < u; x++) {
+    uint32_t c = ucol[x];
+    for (uint32_t h = 0; h < H; h++)
+      Mh[(size_t)h * u + x] = (c < n_hd) ? G[(size_t)h * n_hd + c] : (uint8_t)(c - n_hd == h);
+  }
+  for (uint32_t k = 0; k < npiv; k++) {
+    const uint32_t *wk = &Wm[(size_t)k * wpr];
+    uint32_t c = pivcol[k];
+    for (uint32_t w = 0; w < wpr; w++) {
+      uint32_t bits = wk[w];
+      while (bits) {
+        uint32_t x = w * 32 + (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1;
+        for (uint32_t h = 0; h < H; h++) Mh[(size_t)h * u + x] ^= G[(size_t)h * n_hd + c];
+      }
+    }
+  }
+
+  /* ---- GF(2) Gauss-Jordan on the leftover binary rows ---- */
+  std::vector<uint8_t> used(nlow, 0);
+  std::vector<uint32_t> red_row, red_x, freex;
+  for (uint32_t x = 0; x < u; x++) {
+    uint32_t pr = nlow;
+    for (uint32_t j = 0; j < nlow; j++)
+      if (!used[j] && bit(&Mb[(size_t)j * rowlen], x)) { pr = j; break; }
+    if (pr == nlow) { freex.push_back(x); continue; }
+    used[pr] = 1;
+    const uint32_t *src = &Mb[(size_t)pr * rowlen];
+    for (uint32_t j = 0; j < nlow; j++) {
+      if (j == pr) continue;
+      uint32_t *dst = &Mb[(size_t)j * rowlen];
+      if (!bit(dst, x)) continue;
+      for (uint32_t w = 0; w < rowlen; w++) dst[w] ^= src[w];
+    }
+    red_row.push_back(pr);
+    red_x.push_back(x);
+  }
+  const uint32_t r2 = (uint32_t)red_row.size(), nfree = (uint32_t)freex.size();
+  uint32_t status = 0;
+  if (nfree > H || nfree > NRQ_MAX_FREE) status = 1;
+
+  /* ---- the free columns: H x nfree system over GF(256) from the HDPC rows ---- */
+  std::vector<uint8_t> mh((size_t)H * std::max(1u, r2), 0), hinv((size_t)std::max(1u, nfree) * H, 0);
+  std::vector<uint32_t> fbits(std::max(1u, r2), 0);
+  if (!status) {
+    for (uint32_t q = 0; q < r2; q++) {
+      const uint32_t *row = &Mb[(size_t)red_row[q] * rowlen];
+      uint32_t fb = 0;
+      for (uint32_t f = 0; f < nfree; f++)
+        if (bit(row, freex[f])) fb |= 1u << f;
+      fbits[q] = fb;
+      for (uint32_t h = 0; h < H; h++) mh[(size_t)h * r2 + q] = Mh[(size_t)h * u + red_x[q]];
+    }
+    /* aug = [ Mh restricted to free columns, with the pivot columns folded in | I_H ] */
+    const uint32_t aw = nfree + H;
+    std::vector<uint8_t> aug((size_t)H * aw, 0);
+    for (uint32_t h = 0; h < H; h++) {
+      for (uint32_t f = 0; f < nfree; f++) {
+        uint8_t v = Mh[(size_t)h * u + freex[f]];
+        for (uint32_t q = 0; q < r2; q++)
+          if ((fbits[q] >> f) & 1u) v ^= mh[(size_t)h * r2 + q];
+        aug[(size_t)h * aw + f] = v;
+      }
+      aug[(size_t)h * aw + nfree + h] = 1;
+    }
+    std::vector<uint8_t> taken(H, 0), solver(std::max(1u, nfree), 0);
+    for (uint32_t f = 0; f < nfree && !status; f++) {
+      uint32_t pr = H;
+      for (uint32_t h = 0; h < H; h++)
+        if (!taken[h] && aug[(size_t)h * aw + f]) { pr = h; break; }
+      if (pr == H) { status = 1; break; }
+      taken[pr] = 1;
+      solver[f] = (uint8_t)pr;
+      uint8_t iv = gf.inv[aug[(size_t)pr * aw + f]];
+      for (uint32_t w = 0; w < aw; w++) aug[(size_t)pr * aw + w] = gf.mul(aug[(size_t)pr * aw + w], iv);
+      for (uint32_t h = 0; h < H; h++) {
+        if (h == pr) continue;
+        uint8_t b = aug[(size_t)h * aw + f];
+        if (!b) continue;
+        for (uint32_t w = 0; w < aw; w++) aug[(size_t)h * aw + w] ^= gf.mul(b, aug[(size_t)pr * aw + w]);
+      }
+    }
+    if (!status)
+      for (uint32_t f = 0; f < nfree; f++)
+        for (uint32_t h = 0; h < H; h++) hinv[(size_t)f * H + h] = aug[(size_t)solver[f] * aw + nfree + h];
+  }
+
+  /* ---- homes of the intermediate symbols ---- */
+  std::vector<uint16_t> colslot(L, NRQ_NOSLOT), pivof(n_hd, NRQ_NOSLOT), uslot(u, NRQ_NOSLOT);
+  for (uint32_t k = 0; k < npiv; k++) {
+    colslot[pivcol[k]] = pivslot[k];
+    pivof[pivcol[k]] = pivslot[k];
+  }
+  {
+    uint32_t x = 0;
+    for (uint32_t r = 0; r < M && x < u; r++)
+      if (!assigned[r]) { uslot[x] = (uint16_t)r; colslot[ucol[x]] = (uint16_t)r; x++; }
+    if (x != u) return -5;
+  }
+
+  /* ---- serialise ---- */
+  Arena A;
+  nrq_plan_hdr hd;
+  memset(&hd, 0, sizeof(hd));
+  A.reserve((uint32_t)sizeof(hd));
+  hd.magic = NRQ_PLAN_MAGIC; hd.status = status;
+  hd.K = K; hd.Kp = p.Kp; hd.J = p.J; hd.S = S; hd.H = H; hd.W = W; hd.L = L; hd.P = p.P; hd.P1 = p.P1; hd.B = p.B;
+  hd.M = M; hd.npiv = npiv; hd.u = u; hd.nlow = nlow; hd.r2 = r2; hd.nfree = nfree; hd.nlev = nlev;
+  hd.nchunk1 = nchunk1; hd.nchunk2 = nchunk2; hd.wpr = wpr; hd.lpr = lpr;
+  hd.npiv_pad = (npiv + 63u) & ~63u;
+  hd.n_xor_ops = n_real_ops;
+  hd.off_ops = A.reserve((uint32_t)(ops.size() * 4));
+  if (!ops.empty()) memcpy(A.at<uint8_t>(hd.off_ops), ops.data(), ops.size() * 4);
+  hd.off_pivslot = A.reserve(npiv * 2);
+  memcpy(A.at<uint8_t>(hd.off_pivslot), pivslot.data(), (size_t)npiv * 2);
+  hd.off_pivcol = A.reserve(npiv * 2);
+  memcpy(A.at<uint8_t>(hd.off_pivcol), pivcol.data(), (size_t)npiv * 2);
+  hd.off_wt = A.reserve(wpr * hd.npiv_pad * 4);
+  {
+    uint32_t *wt = A.at<uint32_t>(hd.off_wt);
+    for (uint32_t k = 0; k < npiv; k++)
+      for (uint32_t w = 0; w < wpr; w++) wt[(size_t)w * hd.npiv_pad + k] = Wm[(size_t)k * wpr + w];
+  }
+  hd.off_lowslot = A.reserve(std::max(1u, nlow) * 2);
+  if (nlow) memcpy(A.at<uint8_t>(hd.off_lowslot), lowslot.data(), (size_t)nlow * 2);
+  hd.off_g2 = A.reserve(std::max(1u, r2) * lpr * 4);
+  {
+    uint32_t *g2 = A.at<uint32_t>(hd.off_g2);
+    for (uint32_t q = 0; q < r2; q++)
+      memcpy(&g2[(size_t)q * lpr], &Mb[(size_t)red_row[q] * rowlen + wpr], (size_t)lpr * 4);
+  }
+  hd.off_pivx = A.reserve(std::max(1u, r2) * 2);
+  for (uint32_t q = 0; q < r2; q++) A.at<uint16_t>(hd.off_pivx)[q] = (uint16_t)red_x[q];
+  hd.off_fbits = A.reserve(std::max(1u, r2) * 4);
+  memcpy(A.at<uint8_t>(hd.off_fbits), fbits.data(), (size_t)std::max(1u, r2) * 4);
+  hd.off_mh = A.reserve(H * std::max(1u, r2));
+  memcpy(A.at<uint8_t>(hd.off_mh), mh.data(), (size_t)H * std::max(1u, r2));
+  hd.off_freex = A.reserve(std::max(1u, nfree) * 2);
+  for (uint32_t f = 0; f < nfree; f++) A.at<uint16_t>(hd.off_freex)[f] = (uint16_t)freex[f];
+  hd.off_hinv = A.reserve(std::max(1u, nfree) * H);
+  memcpy(A.at<uint8_t>(hd.off_hinv), hinv.data(), (size_t)std::max(1u, nfree) * H);
+  hd.off_colslot = A.reserve(L * 2);
+  memcpy(A.at<uint8_t>(hd.off_colslot), colslot.data(), (size_t)L * 2);
+  hd.off_pivof = A.reserve(n_hd * 2);
+  memcpy(A.at<uint8_t>(hd.off_pivof), pivof.data(), (size_t)n_hd * 2);
+  hd.off_uslot = A.reserve(std::max(1u, u) * 2);
+  if (u) memcpy(A.at<uint8_t>(hd.off_uslot), uslot.data(), (size_t)u * 2);
+  {
+    uint32_t nw = std::max(1u, (nchunk1 + nchunk2 + 31u) / 32u);
+    sync_bits.resize(nw, 0);
+    hd.off_sync = A.reserve(nw * 4);
+    memcpy(A.at<uint8_t>(hd.off_sync), sync_bits.data(), (size_t)nw * 4);
+  }
+  hd.total_bytes = align16((uint32_t)A.buf.size());
+  A.buf.resize(hd.total_bytes, 0);
+  memcpy(A.buf.data(), &hd, sizeof(hd));
+
+  uint8_t *res = (uint8_t *)malloc(hd.total_bytes);
+  if (!res) return -2;
+  memcpy(res, A.buf.data(), hd.total_bytes);
+  *out = res;
+  *out_bytes = hd.total_bytes;
+  return 0;
+}

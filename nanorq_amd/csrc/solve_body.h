@@ -1,0 +1,457 @@
+/*
+ * solve_body.h -- the data stage of the precode solve for ONE column strip of ONE source block,
+ * written as per-thread phase functions.  solve.hip instantiates them inside the gfx950 kernel
+ * (one 256-thread workgroup per strip, `__syncthreads()` between phases); tests/emu compiles the
+ * same functions with g++ and runs the 256 "threads" of a phase in a loop, so the indexing, the
+ * GF(256) bit tricks and the strip handling are exercised on the CPU build machine as well.
+ *
+ * What it replaces in the reference: precode_matrix_intermediate (precode.c:379-389 =
+ * apply_sched :23-32 + permute :3-13), decode_row / APPLYROW (nanorq.c:8-13,:184-204) and the
+ * oblas row kernels underneath (oaxpy/oscal), for every byte column of a block at once.
+ *
+ * Data layout: the strip's WB bytes of every constraint row ("slot") live in
+ * LDS for the whole solve: M slots x WB bytes (8416 x 16 B = 131.5 KiB at K=8192), plus small
+ * scratch regions.  All row operations of the solve are LDS<->register traffic; HBM is touched
+ * once to load the received symbols and once to store results.
+ *
+ * GF(256) = RFC 6330 section 5.7 (x^8+x^4+x^3+x^2+1).  Arithmetic is carried out on 4 packed
+ * bytes per dword: multiply-by-alpha is a shift/mask/xor ("xtime"), a general multiply is 8
+ * conditional xtime-accumulates, and the HDPC block (reference precode.c:60-83, :232-252) is
+ * applied through its MT*GAMMA factorisation as a Horner recurrence, not by table lookups.
+ */
+#ifndef NRQ_SOLVE_BODY_H
+#define NRQ_SOLVE_BODY_H
+
+#include <stdint.h>
+#include <string.h>
+
+#include "plan.h"
+
+#if defined(__HIPCC__)
+#define SB_HD __host__ __device__ __forceinline__
+#define SB_MEM __host__ __device__ __forceinline__
+#else
+#define SB_HD static inline
+#define SB_MEM inline
+struct uint2 { uint32_t x, y; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+#endif
+
+/* device-visible description of one block's work (filled by the host API) */
+typedef struct nrq_job {
+  uint64_t plan;     /* plan arena (plan.h) */
+  uint64_t rowsrc;   /* u32[M]: slot -> NRQ_ROW_ZERO | j (row of src) | 0x80000000|q (row of rep) */
+  uint64_t src;      /* source-symbol rows, pitch T */
+  uint64_t rep;      /* repair-symbol rows, pitch T */
+  uint64_t inter;    /* nullable: L x T intermediate symbols out */
+  uint64_t out;      /* generated symbols out, pitch T */
+  uint64_t out_cptr; /* u32[nout+1] */
+  uint64_t out_cols; /* u16[]: intermediate-symbol indices XORed into each generated symbol */
+  uint64_t out_row;  /* u32[nout]: destination row in `out` */
+  uint32_t nout;
+  uint32_t pad;
+} nrq_job;
+
+#define NRQ_ROW_ZERO 0xFFFFFFFFu
+#define NRQ_ROW_REP 0x80000000u
+
+/* ---- strip vector: WB bytes as packed dwords ---- */
+template <int WB> struct SV {
+  static constexpr int ND = (WB + 3) / 4;
+  uint32_t w[ND];
+};
+
+template <int WB> SB_HD SV<WB> sv_zero() {
+  SV<WB> r;
+#pragma unroll
+  for (int i = 0; i < SV<WB>::ND; i++) r.w[i] = 0;
+  return r;
+}
+template <int WB> SB_HD void sv_xor(SV<WB> &a, const SV<WB> &b) {
+#pragma unroll
+  for (int i = 0; i < SV<WB>::ND; i++) a.w[i] ^= b.w[i];
+}
+template <int WB> SB_HD void sv_xor_masked(SV<WB> &a, const SV<WB> &b, uint32_t mask) {
+#pragma unroll
+  for (int i = 0; i < SV<WB>::ND; i++) a.w[i] ^= b.w[i] & mask;
+}
+/* multiply every byte by alpha (= 2) */
+SB_HD uint32_t xtime32(uint32_t x) {
+  uint32_t hi = (x >> 7) & 0x01010101u;
+  return ((x & 0x7f7f7f7fu) << 1) ^ (hi * 0x1du);
+}
+template <int WB> SB_HD SV<WB> sv_xtime(const SV<WB> &a) {
+  SV<WB> r;
+#pragma unroll
+  for (int i = 0; i < SV<WB>::ND; i++) r.w[i] = xtime32(a.w[i]);
+  return r;
+}
+/* every byte times coef (coef may differ per thread) */
+template <int WB> SB_HD SV<WB> sv_mul(SV<WB> v, uint32_t coef) {
+  SV<WB> acc = sv_zero<WB>();
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    uint32_t m = 0u - ((coef >> b) & 1u);
+    sv_xor_masked<WB>(acc, v, m);
+    v = sv_xtime<WB>(v);
+  }
+  return acc;
+}
+
+/* ---- LDS access (plain memory in the emulator) ---- */
+template <int WB> SB_HD SV<WB> lds_get(const uint8_t *lds, uint32_t idx) {
+  SV<WB> r;
+  if constexpr (WB == 16) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(lds) + idx;
+    uint4 v = *p;
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  } else if constexpr (WB == 8) {
+    const uint2 *p = reinterpret_cast<const uint2 *>(lds) + idx;
+    uint2 v = *p;
+    r.w[0] = v.x; r.w[1] = v.y;
+  } else if constexpr (WB == 4) {
+    r.w[0] = reinterpret_cast<const uint32_t *>(lds)[idx];
+  } else {
+    r.w[0] = reinterpret_cast<const uint16_t *>(lds)[idx];
+  }
+  return r;
+}
+template <int WB> SB_HD void lds_put(uint8_t *lds, uint32_t idx, const SV<WB> &v) {
+  if constexpr (WB == 16) {
+    uint4 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2]; t.w = v.w[3];
+    reinterpret_cast<uint4 *>(lds)[idx] = t;
+  } else if constexpr (WB == 8) {
+    uint2 t; t.x = v.w[0]; t.y = v.w[1];
+    reinterpret_cast<uint2 *>(lds)[idx] = t;
+  } else if constexpr (WB == 4) {
+    reinterpret_cast<uint32_t *>(lds)[idx] = v.w[0];
+  } else {
+    reinterpret_cast<uint16_t *>(lds)[idx] = (uint16_t)v.w[0];
+  }
+}
+/* slot ^= v, safe against other threads of the workgroup doing the same to the same slot */
+template <int WB> SB_HD void lds_xor(uint8_t *lds, uint32_t idx, const SV<WB> &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (WB == 16) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(lds) + 2 * (size_t)idx;
+    atomicXor(p, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32));
+    atomicXor(p + 1, (unsigned long long)v.w[2] | ((unsigned long long)v.w[3] << 32));
+  } else if constexpr (WB == 8) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(lds) + idx;
+    atomicXor(p, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32));
+  } else if constexpr (WB == 4) {
+    atomicXor(reinterpret_cast<unsigned int *>(lds) + idx, v.w[0]);
+  } else {
+    atomicXor(reinterpret_cast<unsigned int *>(lds) + (idx >> 1), v.w[0] << ((idx & 1u) * 16u));
+  }
+#else
+  SV<WB> t = lds_get<WB>(lds, idx);
+  sv_xor<WB>(t, v);
+  lds_put<WB>(lds, idx, t);
+#endif
+}
+
+/* ---- global strip access: `valid` bytes (<= WB) at p ---- */
+template <int WB> SB_HD SV<WB> g_get(const uint8_t *p, uint32_t valid) {
+  SV<WB> r = sv_zero<WB>();
+  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
+    if constexpr (WB == 16) {
+      uint4 v = *reinterpret_cast<const uint4 *>(p);
+      r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    } else if constexpr (WB == 8) {
+      uint2 v = *reinterpret_cast<const uint2 *>(p);
+      r.w[0] = v.x; r.w[1] = v.y;
+    } else if constexpr (WB == 4) {
+      r.w[0] = *reinterpret_cast<const uint32_t *>(p);
+    } else {
+      r.w[0] = *reinterpret_cast<const uint16_t *>(p);
+    }
+  } else {
+    for (uint32_t k = 0; k < valid; k++) r.w[k >> 2] |= (uint32_t)p[k] << ((k & 3u) * 8u);
+  }
+  return r;
+}
+template <int WB> SB_HD void g_put(uint8_t *p, uint32_t valid, const SV<WB> &v) {
+  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
+    if constexpr (WB == 16) {
+      uint4 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2]; t.w = v.w[3];
+      *reinterpret_cast<uint4 *>(p) = t;
+    } else if constexpr (WB == 8) {
+      uint2 t; t.x = v.w[0]; t.y = v.w[1];
+      *reinterpret_cast<uint2 *>(p) = t;
+    } else if constexpr (WB == 4) {
+      *reinterpret_cast<uint32_t *>(p) = v.w[0];
+    } else {
+      *reinterpret_cast<uint16_t *>(p) = (uint16_t)v.w[0];
+    }
+  } else {
+    for (uint32_t k = 0; k < valid; k++) p[k] = (uint8_t)(v.w[k >> 2] >> ((k & 3u) * 8u));
+  }
+}
+
+/* ---- LDS carve-up, identical on host (launch sizing) and device ---- */
+typedef struct nrq_lds_layout {
+  uint32_t off_slots, off_cu, off_low, off_sync, off_x, off_cf, total;
+} nrq_lds_layout;
+
+SB_HD uint32_t nrq_r16(uint32_t x) { return (x + 15u) & ~15u; }
+
+SB_HD nrq_lds_layout nrq_lds_plan(const nrq_plan_hdr *h, uint32_t WB) {
+  nrq_lds_layout l;
+  uint32_t o = 0;
+  l.off_slots = o; o = nrq_r16(o + h->M * WB);
+  l.off_cu = o;    o = nrq_r16(o + (h->u ? h->u : 1u) * WB);
+  l.off_low = o;   o = nrq_r16(o + (h->nlow ? h->nlow : 1u) * 2u);
+  l.off_sync = o;  o = nrq_r16(o + ((h->nchunk1 + h->nchunk2 + 31u) / 32u + 1u) * 4u);
+  /* region X: {E[r2], Cf[NRQ_MAX_FREE]} during the dense stage, then the 4-bit combination tables */
+  uint32_t e_bytes = nrq_r16((h->r2 ? h->r2 : 1u) * WB);
+  uint32_t dense = e_bytes + NRQ_MAX_FREE * WB;
+  uint32_t t4 = h->wpr * 8u * 16u * WB;
+  l.off_x = o;
+  l.off_cf = o + e_bytes;
+  o = nrq_r16(o + (dense > t4 ? dense : t4));
+  l.total = o;
+  return l;
+}
+
+/* ---- per-workgroup context (uniform across the threads of a strip) ---- */
+template <int WB> struct StripCtx {
+  const uint8_t *plan;
+  const nrq_plan_hdr *h;
+  const uint8_t *kc; /* nrq_kconst_hdr arena of this K' */
+  nrq_job job;
+  uint8_t *lds;
+  nrq_lds_layout lay;
+  uint32_t T, strip, valid; /* valid = bytes of this strip inside T */
+  SB_MEM uint8_t *slots() const { return lds + lay.off_slots; }
+  SB_MEM uint8_t *cu() const { return lds + lay.off_cu; }
+  SB_MEM uint16_t *low() const { return reinterpret_cast<uint16_t *>(lds + lay.off_low); }
+  SB_MEM uint32_t *syncw() const { return reinterpret_cast<uint32_t *>(lds + lay.off_sync); }
+  SB_MEM uint8_t *ebuf() const { return lds + lay.off_x; }
+  SB_MEM uint8_t *cf() const { return lds + lay.off_cf; }
+  SB_MEM uint8_t *t4() const { return lds + lay.off_x; }
+  template <class X> SB_MEM const X *arr(uint32_t off) const { return reinterpret_cast<const X *>(plan + off); }
+};
+
+/* phase 0: bring the strip of every slot into LDS; stage small index arrays */
+template <int WB> SB_HD void ph_load(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint32_t *rowsrc = reinterpret_cast<const uint32_t *>(c.job.rowsrc);
+  const uint8_t *src = reinterpret_cast<const uint8_t *>(c.job.src);
+  const uint8_t *rep = reinterpret_cast<const uint8_t *>(c.job.rep);
+  const size_t boff = (size_t)c.strip * WB;
+  for (uint32_t r = tid; r < c.h->M; r += nt) {
+    uint32_t s = rowsrc[r];
+    SV<WB> v = sv_zero<WB>();
+    if (s != NRQ_ROW_ZERO) {
+      const uint8_t *base = (s & NRQ_ROW_REP) ? rep + (size_t)(s & 0x7FFFFFFFu) * c.T : src + (size_t)s * c.T;
+      v = g_get<WB>(base + boff, c.valid);
+    }
+    lds_put<WB>(c.slots(), r, v);
+  }
+  const uint16_t *lowslot = c.template arr<uint16_t>(c.h->off_lowslot);
+  for (uint32_t j = tid; j < c.h->nlow; j += nt) c.low()[j] = lowslot[j];
+  const uint32_t *sy = c.template arr<uint32_t>(c.h->off_sync);
+  uint32_t nsw = (c.h->nchunk1 + c.h->nchunk2 + 31u) / 32u;
+  for (uint32_t j = tid; j < nsw; j += nt) c.syncw()[j] = sy[j];
+}
+
+/* phases 1+2: one XOR op of the forward pass (X^-1 on the peeled rows, then the leftover rows) */
+template <int WB> SB_HD void ph_op(const StripCtx<WB> &c, uint32_t op) {
+  if (op == NRQ_NOP) return;
+  SV<WB> v = lds_get<WB>(c.slots(), op >> 16);
+  lds_xor<WB>(c.slots(), op & 0xFFFFu, v);
+}
+
+/* phase 3: HDPC right-hand sides R_h = SUM_c HDPC[h][c] * Y(c) over the peeled columns, through
+ * HDPC = MT*GAMMA (RFC 6330 section 5.3.3.3): thread t owns columns [a,b); g follows the GAMMA
+ * recurrence g = alpha*g + Y(c); the two unit entries of MT's column c add g to two of the H
+ * accumulators; whatever the chunk owes to columns beyond b is G[.][b] * alpha*g_end. */
+template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(c.kc);
+  const uint8_t *G = c.kc + kh->off_g;
+  const uint8_t *b12 = c.kc + kh->off_b12;
+  const uint16_t *pivof = c.template arr<uint16_t>(c.h->off_pivof);
+  const uint32_t n = kh->n, H = c.h->H;
+  uint32_t len = (n + nt - 1) / nt;
+  len = (len + 7u) & ~7u;
+  const uint32_t a = tid * len;
+  if (a >= n) return;
+  const uint32_t b = (a + len < n) ? a + len : n;
+  SV<WB> acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) acc[q] = sv_zero<WB>();
+  SV<WB> g = sv_zero<WB>();
+  for (uint32_t col = a; col < b; col++) {
+    uint32_t s = pivof[col];
+    g = sv_xtime<WB>(g);
+    if (s != NRQ_NOSLOT) {
+      SV<WB> y = lds_get<WB>(c.slots(), s);
+      sv_xor<WB>(g, y);
+    }
+    if (col + 1 < n) {
+      uint32_t bb = b12[col], b1 = bb & 15u, b2 = bb >> 4;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        uint32_t m = ((uint32_t)q == b1 || (uint32_t)q == b2) ? 0xFFFFFFFFu : 0u;
+        sv_xor_masked<WB>(acc[q], g, m);
+      }
+    } else { /* last column of MT is alpha^h */
+      SV<WB> v = g;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        if ((uint32_t)q < H) sv_xor<WB>(acc[q], v);
+        v = sv_xtime<WB>(v);
+      }
+    }
+  }
+  if (b < n) {
+    SV<WB> carry = sv_xtime<WB>(g);
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+      if ((uint32_t)q < H) {
+        SV<WB> t = sv_mul<WB>(carry, G[(size_t)q * n + b]);
+        sv_xor<WB>(acc[q], t);
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; q++)
+    if ((uint32_t)q < H) lds_xor<WB>(c.slots(), c.h->S + q, acc[q]);
+}
+
+/* phase 4a: E_p = GF(2) combination of leftover rows; also clears the free-column accumulators */
+template <int WB> SB_HD void ph_dense_bin(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint32_t *g2 = c.template arr<uint32_t>(c.h->off_g2);
+  const uint32_t lpr = c.h->lpr;
+  for (uint32_t p = tid; p < c.h->r2; p += nt) {
+    SV<WB> acc = sv_zero<WB>();
+    for (uint32_t wj = 0; wj < lpr; wj++) {
+      uint32_t bits = g2[(size_t)p * lpr + wj];
+      while (bits) {
+        uint32_t j = wj * 32u + (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1u;
+        SV<WB> v = lds_get<WB>(c.slots(), c.low()[j]);
+        sv_xor<WB>(acc, v);
+      }
+    }
+    lds_put<WB>(c.ebuf(), p, acc);
+  }
+  for (uint32_t f = tid; f < NRQ_MAX_FREE; f += nt) lds_put<WB>(c.cf(), f, sv_zero<WB>());
+}
+
+/* phase 4b: fold the columns resolved by binary rows out of the HDPC rows: R_h ^= mh[h][p]*E_p */
+template <int WB> SB_HD void ph_dense_fold(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint8_t *mh = c.plan + c.h->off_mh;
+  const uint32_t H = c.h->H, r2 = c.h->r2;
+  const uint32_t hq = tid & 15u, part = tid >> 4, nparts = nt >> 4;
+  if (hq >= H) return;
+  SV<WB> acc = sv_zero<WB>();
+  for (uint32_t p = part; p < r2; p += nparts) {
+    uint32_t coef = mh[(size_t)hq * r2 + p];
+    if (!coef) continue;
+    SV<WB> t = sv_mul<WB>(lds_get<WB>(c.ebuf(), p), coef);
+    sv_xor<WB>(acc, t);
+  }
+  lds_xor<WB>(c.slots(), c.h->S + hq, acc);
+}
+
+/* phase 4c: free columns C_f = SUM_h hinv[f][h] * R_h */
+template <int WB> SB_HD void ph_dense_free(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint8_t *hinv = c.plan + c.h->off_hinv;
+  const uint32_t H = c.h->H, nfree = c.h->nfree;
+  const uint32_t hq = tid & 15u;
+  if (hq >= H) return;
+  for (uint32_t f = tid >> 4; f < nfree; f += nt >> 4) {
+    uint32_t coef = hinv[(size_t)f * H + hq];
+    if (!coef) continue;
+    SV<WB> t = sv_mul<WB>(lds_get<WB>(c.slots(), c.h->S + hq), coef);
+    lds_xor<WB>(c.cf(), f, t);
+  }
+}
+
+/* phase 4d: values of all u inactive columns */
+template <int WB> SB_HD void ph_dense_cu(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint16_t *pivx = c.template arr<uint16_t>(c.h->off_pivx);
+  const uint32_t *fbits = c.template arr<uint32_t>(c.h->off_fbits);
+  const uint16_t *freex = c.template arr<uint16_t>(c.h->off_freex);
+  for (uint32_t p = tid; p < c.h->r2; p += nt) {
+    SV<WB> v = lds_get<WB>(c.ebuf(), p);
+    uint32_t fb = fbits[p];
+    while (fb) {
+      uint32_t f = (uint32_t)__builtin_ctz(fb);
+      fb &= fb - 1u;
+      SV<WB> t = lds_get<WB>(c.cf(), f);
+      sv_xor<WB>(v, t);
+    }
+    lds_put<WB>(c.cu(), pivx[p], v);
+  }
+  for (uint32_t f = tid; f < c.h->nfree; f += nt) lds_put<WB>(c.cu(), freex[f], lds_get<WB>(c.cf(), f));
+}
+
+/* phase 5a: 16-entry XOR tables over groups of 4 inactive columns (region X is reused) */
+template <int WB> SB_HD void ph_tables(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint32_t ngroups = c.h->wpr * 8u, u = c.h->u;
+  for (uint32_t e = tid; e < ngroups * 16u; e += nt) {
+    uint32_t grp = e >> 4, nib = e & 15u;
+    SV<WB> v = sv_zero<WB>();
+#pragma unroll
+    for (uint32_t bq = 0; bq < 4; bq++) {
+      uint32_t x = grp * 4u + bq;
+      if (((nib >> bq) & 1u) && x < u) {
+        SV<WB> t = lds_get<WB>(c.cu(), x);
+        sv_xor<WB>(v, t);
+      }
+    }
+    lds_put<WB>(c.t4(), e, v);
+  }
+}
+
+/* phase 5b: back substitution C(pivot k) = Y_k ^ W_k * C_u */
+template <int WB> SB_HD void ph_backsub(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint16_t *pivslot = c.template arr<uint16_t>(c.h->off_pivslot);
+  const uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
+  const uint32_t wpr = c.h->wpr, stride = c.h->npiv_pad;
+  for (uint32_t k = tid; k < c.h->npiv; k += nt) {
+    uint32_t s = pivslot[k];
+    SV<WB> acc = lds_get<WB>(c.slots(), s);
+    for (uint32_t w = 0; w < wpr; w++) {
+      uint32_t bits = wt[(size_t)w * stride + k];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) {
+        uint32_t nib = (bits >> (4u * q)) & 15u;
+        SV<WB> t = lds_get<WB>(c.t4(), (w * 8u + q) * 16u + nib);
+        sv_xor<WB>(acc, t);
+      }
+    }
+    lds_put<WB>(c.slots(), s, acc);
+  }
+}
+
+/* phase 6a: park the inactive columns in the slots the plan reserved for them */
+template <int WB> SB_HD void ph_park(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint16_t *uslot = c.template arr<uint16_t>(c.h->off_uslot);
+  for (uint32_t x = tid; x < c.h->u; x += nt) lds_put<WB>(c.slots(), uslot[x], lds_get<WB>(c.cu(), x));
+}
+
+/* phase 6b: results to HBM: intermediate symbols (optional) and generated symbols */
+template <int WB> SB_HD void ph_store(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint16_t *colslot = c.template arr<uint16_t>(c.h->off_colslot);
+  const size_t boff = (size_t)c.strip * WB;
+  uint8_t *inter = reinterpret_cast<uint8_t *>(c.job.inter);
+  if (inter)
+    for (uint32_t col = tid; col < c.h->L; col += nt)
+      g_put<WB>(inter + (size_t)col * c.T + boff, c.valid, lds_get<WB>(c.slots(), colslot[col]));
+  const uint32_t *cptr = reinterpret_cast<const uint32_t *>(c.job.out_cptr);
+  const uint16_t *cols = reinterpret_cast<const uint16_t *>(c.job.out_cols);
+  const uint32_t *orow = reinterpret_cast<const uint32_t *>(c.job.out_row);
+  uint8_t *out = reinterpret_cast<uint8_t *>(c.job.out);
+  for (uint32_t q = tid; q < c.job.nout; q += nt) {
+    SV<WB> acc = sv_zero<WB>();
+    for (uint32_t e = cptr[q]; e < cptr[q + 1]; e++) {
+      SV<WB> t = lds_get<WB>(c.slots(), colslot[cols[e]]);
+      sv_xor<WB>(acc, t);
+    }
+    g_put<WB>(out + (size_t)orow[q] * c.T + boff, c.valid, acc);
+  }
+}
+
+#endif /* NRQ_SOLVE_BODY_H */

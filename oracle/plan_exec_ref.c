@@ -1,3 +1,91 @@
-/* placeholder translation unit; the CPU reference executor for device plans is added with the
- * planner (test infrastructure only). */
-int orc_plan_exec_abi(void) { return 0; }
+/*
+ * plan_exec_ref.c -- CPU reference executor for device plans (nanorq_amd/csrc/plan.h).
+ *
+ * TEST INFRASTRUCTURE ONLY (part of the oracle library).  It applies a plan to whole symbol
+ * rows with straightforward loops and table-based GF(256) arithmetic, independently of the HIP
+ * kernels' strip layout, xtime/Horner tricks and chunk scheduling.  tests/ use it to check a
+ * planner on the CPU against the reference-equivalent oracle (rq_oracle.c) and as the executable
+ * specification of what solve.hip must compute from the same plan.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../nanorq_amd/csrc/plan.h"
+
+void orc_gf_tables(uint8_t *exp510, uint8_t *log256, uint8_t *inv256);
+int orc_hdpc(uint32_t K, uint8_t *out);
+
+static uint8_t E_[510], L_[256], I_[256];
+
+static void xor_row(uint8_t *d, const uint8_t *s, size_t n) { for (size_t k = 0; k < n; k++) d[k] ^= s[k]; }
+static void fma_row(uint8_t *d, const uint8_t *s, size_t n, uint8_t b) {
+  if (!b) return;
+  for (size_t k = 0; k < n; k++)
+    if (s[k]) d[k] ^= E_[L_[b] + L_[s[k]]];
+}
+
+/* D: M x T (pitch T) with the received/source symbols already placed in their rows, zero
+ * elsewhere.  C out: L x T.  returns 1 ok, 0 if the plan is marked singular, <0 on a bad plan. */
+int orc_plan_exec(const uint8_t *plan, uint8_t *D, uint32_t T, uint8_t *C) {
+  const nrq_plan_hdr *h = (const nrq_plan_hdr *)plan;
+  if (h->magic != NRQ_PLAN_MAGIC) return -1;
+  if (h->status) return 0;
+  orc_gf_tables(E_, L_, I_);
+  const uint32_t *ops = (const uint32_t *)(plan + h->off_ops);
+  const uint16_t *pivslot = (const uint16_t *)(plan + h->off_pivslot);
+  const uint16_t *pivcol = (const uint16_t *)(plan + h->off_pivcol);
+  const uint32_t *wt = (const uint32_t *)(plan + h->off_wt);
+  const uint16_t *lowslot = (const uint16_t *)(plan + h->off_lowslot);
+  const uint32_t *g2 = (const uint32_t *)(plan + h->off_g2);
+  const uint16_t *pivx = (const uint16_t *)(plan + h->off_pivx);
+  const uint32_t *fbits = (const uint32_t *)(plan + h->off_fbits);
+  const uint8_t *mh = plan + h->off_mh;
+  const uint16_t *freex = (const uint16_t *)(plan + h->off_freex);
+  const uint8_t *hinv = plan + h->off_hinv;
+  const uint16_t *colslot = (const uint16_t *)(plan + h->off_colslot);
+  const uint16_t *uslot = (const uint16_t *)(plan + h->off_uslot);
+  const uint32_t H = h->H, n_hd = h->Kp + h->S;
+#define ROW(r) (D + (size_t)(r) * T)
+  /* 1+2: forward substitution through X, then the leftover rows */
+  size_t nops = (size_t)(h->nchunk1 + h->nchunk2) * NRQ_CHUNK;
+  for (size_t e = 0; e < nops; e++) {
+    if (ops[e] == NRQ_NOP) continue;
+    xor_row(ROW(ops[e] & 0xFFFFu), ROW(ops[e] >> 16), T);
+  }
+  /* 3: HDPC right-hand sides */
+  uint8_t *G = (uint8_t *)malloc((size_t)H * n_hd);
+  orc_hdpc(h->K, G);
+  for (uint32_t k = 0; k < h->npiv; k++)
+    for (uint32_t q = 0; q < H; q++) fma_row(ROW(h->S + q), ROW(pivslot[k]), T, G[(size_t)q * n_hd + pivcol[k]]);
+  free(G);
+  /* 4: binary combination of the leftover rows */
+  uint8_t *E = (uint8_t *)calloc((size_t)(h->r2 ? h->r2 : 1) * T, 1);
+  for (uint32_t p = 0; p < h->r2; p++)
+    for (uint32_t j = 0; j < h->nlow; j++)
+      if ((g2[(size_t)p * h->lpr + (j >> 5)] >> (j & 31)) & 1u) xor_row(E + (size_t)p * T, ROW(lowslot[j]), T);
+  /* 5: fold the resolved columns out of the HDPC rows */
+  for (uint32_t q = 0; q < H; q++)
+    for (uint32_t p = 0; p < h->r2; p++) fma_row(ROW(h->S + q), E + (size_t)p * T, T, mh[(size_t)q * h->r2 + p]);
+  /* 6: free columns */
+  uint8_t *Cu = (uint8_t *)calloc((size_t)(h->u ? h->u : 1) * T, 1);
+  for (uint32_t f = 0; f < h->nfree; f++)
+    for (uint32_t q = 0; q < H; q++) fma_row(Cu + (size_t)freex[f] * T, ROW(h->S + q), T, hinv[(size_t)f * H + q]);
+  /* 7: columns resolved by binary rows */
+  for (uint32_t p = 0; p < h->r2; p++) {
+    uint8_t *dst = Cu + (size_t)pivx[p] * T;
+    memcpy(dst, E + (size_t)p * T, T);
+    for (uint32_t f = 0; f < h->nfree; f++)
+      if ((fbits[p] >> f) & 1u) xor_row(dst, Cu + (size_t)freex[f] * T, T);
+  }
+  /* 8: back substitution with the fill-in matrix W */
+  for (uint32_t k = 0; k < h->npiv; k++)
+    for (uint32_t x = 0; x < h->u; x++)
+      if ((wt[(size_t)(x >> 5) * h->npiv_pad + k] >> (x & 31)) & 1u) xor_row(ROW(pivslot[k]), Cu + (size_t)x * T, T);
+  /* 9+10: homes, gather */
+  for (uint32_t x = 0; x < h->u; x++) memcpy(ROW(uslot[x]), Cu + (size_t)x * T, T);
+  for (uint32_t c = 0; c < h->L; c++) memcpy(C + (size_t)c * T, ROW(colslot[c]), T);
+  free(E); free(Cu);
+#undef ROW
+  return 1;
+}

@@ -1,0 +1,81 @@
+"""Test support: drive the CPU emulation of the solve workgroup (tests/emu/solve_emu.cpp) and the
+oracle's reference plan executor with host-built plans."""
+import ctypes as C
+
+import numpy as np
+
+import nanorq_amd
+from nanorq_amd import build as nbuild
+
+
+class Job(C.Structure):
+    _fields_ = [("plan", C.c_uint64), ("rowsrc", C.c_uint64), ("src", C.c_uint64), ("rep", C.c_uint64),
+                ("inter", C.c_uint64), ("out", C.c_uint64), ("out_cptr", C.c_uint64), ("out_cols", C.c_uint64),
+                ("out_row", C.c_uint64), ("nout", C.c_uint32), ("pad", C.c_uint32)]
+
+
+_EMU = None
+ROW_ZERO = 0xFFFFFFFF
+ROW_REP = 0x80000000
+
+
+def emu():
+    global _EMU
+    if _EMU is None:
+        L = C.CDLL(nbuild.build_emu())
+        L.emu_solve.argtypes = [C.POINTER(Job), C.c_uint32, C.c_uint32, C.c_void_p]
+        L.emu_lds_bytes.argtypes = [C.c_void_p, C.c_uint32]
+        L.emu_lds_bytes.restype = C.c_uint32
+        _EMU = L
+    return _EMU
+
+
+def decode_setup(orc, K, lost, rep_esis):
+    """Row/ISI layout of a decode (reference nanorq.c:527-565): returns (isis, rowsrc)."""
+    p = orc.params(K)
+    pad = p["Kp"] - K
+    nl = len(lost)
+    overhead = len(rep_esis) - nl
+    isis = list(range(p["Kp"]))
+    rowsrc = np.full(p["L"] + overhead, ROW_ZERO, np.uint32)
+    rowsrc[p["S"] + p["H"]: p["S"] + p["H"] + K] = np.arange(K, dtype=np.uint32)
+    for g, e in enumerate(lost):
+        isis[int(e)] = int(rep_esis[g]) + pad
+        rowsrc[p["S"] + p["H"] + int(e)] = ROW_REP | g
+    for x in range(overhead):
+        isis.append(int(rep_esis[nl + x]) + pad)
+        rowsrc[p["L"] + x] = ROW_REP | (nl + x)
+    return np.array(isis, np.uint32), rowsrc
+
+
+def lt_lists(orc, K, isis):
+    cptr = [0]
+    cols = []
+    for x in isis:
+        cols += orc.lt_columns(K, int(x))
+        cptr.append(len(cols))
+    return np.array(cptr, np.uint32), np.array(cols if cols else [0], np.uint16)
+
+
+def emu_solve(plan, kconst, rowsrc, src, rep, T, L, out_isis_lists, out_rows, out_buf, wb):
+    """Runs all strips. Returns (status, inter[L,T]); out_buf is modified in place."""
+    L_ = emu()
+    planb = (C.c_uint8 * len(plan)).from_buffer_copy(plan)
+    kcb = (C.c_uint8 * len(kconst)).from_buffer_copy(kconst)
+    inter = np.zeros((L, T), np.uint8)
+    cptr, cols = out_isis_lists
+    out_rows = np.ascontiguousarray(out_rows, np.uint32)
+    rep = np.ascontiguousarray(rep if rep is not None and len(rep) else np.zeros((1, T), np.uint8))
+    j = Job()
+    j.plan = C.addressof(planb)
+    j.rowsrc = rowsrc.ctypes.data
+    j.src = src.ctypes.data
+    j.rep = rep.ctypes.data
+    j.inter = inter.ctypes.data
+    j.out = out_buf.ctypes.data
+    j.out_cptr = cptr.ctypes.data
+    j.out_cols = cols.ctypes.data
+    j.out_row = out_rows.ctypes.data if len(out_rows) else 0
+    j.nout = len(out_rows)
+    r = L_.emu_solve(C.byref(j), T, wb, C.addressof(kcb))
+    return r, inter

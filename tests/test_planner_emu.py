@@ -1,0 +1,100 @@
+"""CPU tier: host planner + CPU emulation of the HIP solve workgroup versus the oracle.
+
+These run the SAME per-thread phase code the gfx950 kernel runs (nanorq_amd/csrc/solve_body.h),
+sequentially on the CPU (tests/emu/solve_emu.cpp), so plan format, strip indexing and the packed
+GF(256) arithmetic are verified without a GPU.  The -m gpu tests then repeat the comparisons on
+the real kernel through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import nanorq_amd
+from emu_support import ROW_ZERO, decode_setup, emu, emu_solve, lt_lists
+from util import loss_pattern, payload, received_set
+
+
+def _encode_case(orc, K, T, wb, nrep=7):
+    p = orc.params(K)
+    src = payload(K * T, seed=11).reshape(K, T)
+    kc = nanorq_amd.host_kconst(K)
+    plan = nanorq_amd.host_plan(K, np.arange(p["Kp"], dtype=np.uint32), kc)
+    hdr = nanorq_amd.plan_header(plan)
+    assert hdr["status"] == 0 and hdr["npiv"] + hdr["u"] == p["L"]
+    rowsrc = np.full(p["L"], ROW_ZERO, np.uint32)
+    rowsrc[p["S"] + p["H"]: p["S"] + p["H"] + K] = np.arange(K, dtype=np.uint32)
+    esis = np.arange(K, K + nrep, dtype=np.uint32)
+    lists = lt_lists(orc, K, esis + (p["Kp"] - K))
+    out = np.zeros((nrep, T), np.uint8)
+    r, inter = emu_solve(plan, kc, rowsrc, src, None, T, p["L"], lists, np.arange(nrep), out, wb)
+    ref_rep, ref_inter, _ = orc.encode_block(src, K, T, esis, want_inter=True)
+    assert r == 1
+    assert np.array_equal(inter, ref_inter)
+    assert np.array_equal(out, ref_rep)
+
+
+@pytest.mark.parametrize("K,T,wb", [(10, 8, 16), (10, 8, 4), (10, 24, 16), (100, 64, 16), (100, 36, 8), (100, 10, 4),
+                                    (100, 6, 2), (1024, 32, 16), (1024, 20, 8), (8192, 16, 16)])
+def test_encode_emulated_matches_oracle(orc, K, T, wb):
+    _encode_case(orc, K, T, wb)
+
+
+@pytest.mark.parametrize("K,T,wb,p,oh", [(10, 16, 16, 0.3, 0), (100, 32, 16, 0.06, 0), (100, 32, 8, 0.06, 2),
+                                         (100, 8, 2, 0.5, 30), (1024, 16, 16, 0.05, 0), (1024, 16, 4, 0.06, 52),
+                                         (8192, 16, 16, 0.1, 0), (8192, 16, 16, 0.1, 2)])
+def test_decode_emulated_matches_oracle(orc, K, T, wb, p, oh):
+    prm = orc.params(K)
+    src = payload(K * T, seed=5).reshape(K, T)
+    kc = nanorq_amd.host_kconst(K)
+    done = 0
+    for seed in range(1, 4):
+        lost = loss_pattern(K, p, seed)
+        esis = received_set(K, lost, oh)
+        rep_esis = esis[esis >= K]
+        rep, _, _ = orc.encode_block(src, K, T, rep_esis)
+        syms = np.concatenate([src[esis[esis < K]], rep])
+        ok, ref_out, _ = orc.decode_block(esis, syms, K, T)
+        isis, rowsrc = decode_setup(orc, K, lost, rep_esis)
+        plan = nanorq_amd.host_plan(K, isis, kc)
+        hdr = nanorq_amd.plan_header(plan)
+        assert (hdr["status"] == 0) == ok  # failure parity: decodable iff rank(A) == L
+        if not ok:
+            continue
+        work = src.copy()
+        work[lost] = 0xEE  # missing rows hold garbage
+        lists = lt_lists(orc, K, lost)
+        r, inter = emu_solve(plan, kc, rowsrc, work, rep, T, prm["L"], lists, lost, work, wb)
+        assert r == 1
+        assert np.array_equal(work, src)
+        done += 1
+    assert done >= 1
+
+
+def test_failure_parity_small_blocks(orc):
+    """rank(A) < L verdicts must agree with the reference algorithm (~1 % at +0)."""
+    K = 12
+    kc = nanorq_amd.host_kconst(K)
+    nfail = 0
+    rng = np.random.default_rng(7)
+    for trial in range(400):
+        nl = int(rng.integers(1, 7))
+        lost = np.sort(rng.choice(K, nl, replace=False)).astype(np.uint32)
+        rep_esis = (K + rng.choice(60, nl, replace=False)).astype(np.uint32)
+        isis, _ = decode_setup(orc, K, lost, rep_esis)
+        r, st = orc.plan_probe(K, isis)
+        hdr = nanorq_amd.plan_header(nanorq_amd.host_plan(K, isis, kc))
+        assert (hdr["status"] == 0) == (r == 1), (trial, lost, rep_esis)
+        nfail += (r == 0)
+    assert nfail > 0  # the sweep really contains singular systems
+
+
+def test_lds_budget_of_headline_config(orc):
+    """K=8192: the 16-byte strip image must fit the 160 KiB LDS of one gfx950 workgroup."""
+    K = 8192
+    p = orc.params(K)
+    kc = nanorq_amd.host_kconst(K)
+    plan = nanorq_amd.host_plan(K, np.arange(p["Kp"], dtype=np.uint32), kc)
+    buf = (C.c_uint8 * len(plan)).from_buffer_copy(plan)
+    assert emu().emu_lds_bytes(C.addressof(buf), 16) <= 163840
+    hdr = nanorq_amd.plan_header(plan)
+    assert hdr["nlev"] < 600  # breadth-first peeling keeps the dependency depth low
