@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py -- RaptorQ encode+decode throughput of the MI355X path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (config.workload "cfg3"): BASELINE.json configs[2] -- K=8192 source symbols of T=1280 bytes per
+source block, 10 % independent random loss per block, decode with exactly K received symbols
+(overhead 0: the GF(256)/HDPC path; a block whose matrix is rank deficient is retried with one more
+repair symbol inside the timed region and counted).  One STEP = one batch of `--blocks` independent
+source blocks per GPU: encode (source -> intermediate symbols in HBM + R repair symbols; the encode
+plan is rebuilt every step, i.e. once per 256-block object like nanorq_precalculate) followed by
+decode (per-block plan from the loss pattern + solve + regeneration of the missing symbols).
+Payloads are synthetic and already resident in HBM when the timed region starts.  Blocks shard
+across GPUs with no data-path collective (weak scaling); rank 0 prints ONE JSON line.
+
+`value` = 8 * (payload bytes encoded and decoded) / wall time, whole job.
+`roofline`: the solve kernel (nrq_solve_kernel) against the HBM roofline using the ALGORITHMIC
+bytes of SURVEY.md section 8(d) -- the row traffic the reference CPU path performs for the same blocks,
+counted live by the oracle on the sampled blocks -- divided by the kernel's average launch
+duration measured with HIP events on the launch stream.
+`cpu_baseline`: the oracle (C restatement of the reference algorithm with AVX2 GF(256) row kernels;
+upstream oblas is absent so this is a "port") timed on this host, one core, on a bounded sample of the
+same workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--K", type=int, default=8192)
+    ap.add_argument("--T", type=int, default=1280)
+    ap.add_argument("--blocks", type=int, default=256, help="source blocks per GPU per step")
+    ap.add_argument("--loss", type=float, default=0.10)
+    ap.add_argument("--overhead", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0, help="host planner threads per rank (0 = cores / ranks)")
+    ap.add_argument("--cpu-sample", type=int, default=6, help="blocks timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-replan", action="store_true", help="keep the encode plan cached across steps")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(st, K, T, L, nsym_loaded, nsym_generated_rows):
+    """B_alg = B_load + T*(3*(n1+nB)+2*n0) + 2*L*T + B_gen."""
+    return T * (nsym_loaded + 3 * (st["n1"] + st["nB"]) + 2 * st["n0"] + 2 * L + nsym_generated_rows)
+
+
+def cpu_baseline(args, src_np, lost_np, nrep_enc):
+    """Oracle on one host core over a bounded sample; also yields the algorithmic byte counts."""
+    import oracle
+    K, T = args.K, args.T
+    prm = oracle.params(K)
+    n = min(args.cpu_sample, len(src_np))
+    esis = np.arange(K, K + nrep_enc, dtype=np.uint32)
+    t_enc = t_dec = 0.0
+    balg_enc = balg_dec = 0.0
+    for b in range(n):
+        t0 = time.perf_counter()
+        rep, _, st_e = oracle.encode_block(src_np[b], K, T, esis)
+        t1 = time.perf_counter()
+        lost = lost_np[b]
+        keep = np.setdiff1d(np.arange(K, dtype=np.uint32), lost)
+        nr = len(lost) + args.overhead
+        ok = False
+        while not ok:
+            recv = np.concatenate([keep, esis[:nr]])
+            syms = np.concatenate([src_np[b][keep], rep[:nr]])
+            t2 = time.perf_counter()
+            ok, out, st_d = oracle.decode_block(recv, syms, K, T)
+            t3 = time.perf_counter()
+            t_dec += t3 - t2
+            nr += 1
+        assert np.array_equal(out, src_np[b])
+        t_enc += t1 - t0
+        balg_enc += algorithmic_bytes(st_e, K, T, prm["L"], K, st_e["gen_rows"])
+        balg_dec += algorithmic_bytes(st_d, K, T, prm["L"], K + st_d["overhead"], st_d["gen_rows"])
+    payload = n * K * T
+    return {
+        "value": 8.0 * payload / (t_enc + t_dec) / 1e9, "unit": "Gbit/s", "cores": 1, "kind": "port",
+        "sample": "%d blocks of K=%d T=%d, encode (+%d repair) and decode (%.0f%% loss, +%d), oracle/rq_oracle.c "
+                  "AVX2=%s, 1 thread" % (n, K, T, nrep_enc, args.loss * 100, args.overhead, oracle.has_avx2()),
+        "encode_gbps": 8.0 * payload / t_enc / 1e9, "decode_gbps": 8.0 * payload / t_dec / 1e9,
+        "host_cpu": _cpu_model(), "host_threads": os.cpu_count(),
+    }, balg_enc / n, balg_dec / n
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse()
+    import torch
+    import nanorq_amd
+    from util import loss_pattern
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    stream = torch.cuda.current_stream(dev)
+    ctx = nanorq_amd.Context(local, stream.cuda_stream)
+    threads = args.threads or max(1, (os.cpu_count() or 1) // max(1, world))
+    ctx.set_threads(threads)
+
+    K, T, NB = args.K, args.T, args.blocks
+    prm = nanorq_amd.params(K)
+    L = prm["L"]
+    # synthetic payload, resident in HBM (seeded per rank so that every GPU works on different blocks)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1 + rank)
+    src = torch.randint(0, 256, (NB, K, T), dtype=torch.uint8, device=dev, generator=g)
+    lost = [loss_pattern(K, args.loss, seed=1000 + rank, block=b) for b in range(NB)]
+    max_lost = max(len(x) for x in lost)
+    nrep = max_lost + args.overhead + 2  # repair symbols generated per block by the encoder
+    esis = np.arange(K, K + nrep, dtype=np.uint32)
+    rep = torch.empty((NB, nrep, T), dtype=torch.uint8, device=dev)
+    inter = torch.empty((NB, L, T), dtype=torch.uint8, device=dev)
+    work = src.clone()  # what the receiver holds: source block with the lost rows destroyed
+    for b in range(NB):
+        work[b, torch.from_numpy(lost[b].astype(np.int64)).to(dev)] = 0xEE
+    lost_arr = np.zeros((NB, max_lost + 1), np.uint32)
+    for b in range(NB):
+        lost_arr[b, :len(lost[b])] = lost[b]
+    nlost = np.array([len(x) for x in lost], np.uint32)
+    resi = np.tile(esis, (NB, 1))
+    retries = 0
+
+    def step():
+        nonlocal retries
+        if not args.no_replan:
+            ctx.clear_plan_cache()
+        ctx.encode_blocks(K, T, NB, src.data_ptr(), K * T, rep.data_ptr(), nrep * T, esis, inter.data_ptr(), L * T)
+        enc_stats = ctx.stats()
+        extra = np.full(NB, args.overhead, np.uint32)
+        pending = np.arange(NB)
+        dec_stats = None
+        while len(pending):
+            nr = (nlost[pending] + extra[pending]).astype(np.uint32)
+            if len(pending) == NB:
+                st = ctx.decode_blocks(K, T, NB, work.data_ptr(), K * T, lost_arr, nlost, resi, nr, rep.data_ptr(),
+                                       nrep * T)
+                if dec_stats is None:
+                    dec_stats = ctx.stats()
+            else:  # rank-deficient blocks: one more repair symbol each (nanorq_repair_block is retryable)
+                st = np.zeros(len(pending), np.int32)
+                for i, b in enumerate(pending):
+                    s1 = ctx.decode_blocks(K, T, 1, work.data_ptr() + int(b) * K * T, K * T, lost_arr[b:b + 1],
+                                           nlost[b:b + 1], resi[b:b + 1], nr[i:i + 1],
+                                           rep.data_ptr() + int(b) * nrep * T, nrep * T)
+                    st[i] = s1[0]
+            failed = pending[st == 0]
+            retries += len(failed)
+            extra[failed] += 1
+            if len(failed) and int(extra[failed].max()) > 2 + args.overhead:
+                raise RuntimeError("decode keeps failing")
+            pending = failed
+        return enc_stats, dec_stats
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    retries = 0
+    ctx.ktime_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc_stats, dec_stats = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = ctx.ktime_read()
+    ctx.ktime_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # correctness of what was timed: every block decoded back to its source
+    assert torch.equal(work, src), "decoded blocks differ from the source blocks"
+
+    if rank == 0:
+        payload_step = world * NB * K * T
+        value = 8.0 * payload_step * args.steps / elapsed / 1e9
+        cpu, balg_enc, balg_dec = (None, None, None)
+        if args.cpu_sample > 0:
+            src_np = src[:args.cpu_sample].cpu().numpy()
+            cpu, balg_enc, balg_dec = cpu_baseline(args, src_np, lost, nrep)
+        # solve-kernel launches in the timed region: [encode, decode(, retries...)] per step
+        roof = None
+        if balg_enc is not None and ktimes:
+            # two full-batch launches per step (encode, decode); retry launches are a few single blocks
+            full = sorted(ktimes, reverse=True)[:2 * args.steps]
+            avg_ms = sum(full) / len(full)
+            alg_per_launch = 0.5 * (balg_enc + balg_dec) * NB
+            achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "nrq_solve_kernel<%d>" %
+                    enc_stats["strip_bytes"], "avg_launch_ms": avg_ms, "launches_timed": len(ktimes),
+                    "algorithmic_bytes_per_launch": alg_per_launch,
+                    "algorithmic_bytes_per_block": {"encode": balg_enc, "decode": balg_dec},
+                    "note": "algorithmic bytes = reference-equivalent row traffic (SURVEY 8d), not physical HBM "
+                            "bytes: the strip solver keeps rows in LDS"}
+        out = {
+            "metric": "Gbit/s encode+decode, K=%d T=%d" % (K, T), "value": value, "unit": "Gbit/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "cfg3: K=%d T=%d, %d blocks/GPU/step, %.0f%% loss, overhead %d, encode(+%d repair)"
+                                   "+decode" % (K, T, NB, args.loss * 100, args.overhead, nrep),
+                       "K": K, "T": T, "blocks_per_gpu": NB, "loss": args.loss, "overhead": args.overhead,
+                       "repair_per_block": nrep, "sharding": "blocks over GPUs, no collective",
+                       "encode_plan": "cached" if args.no_replan else "rebuilt every step",
+                       "planner": "host, %d threads/rank" % threads, "decode_retries": retries},
+            "roofline": roof, "cpu_baseline": cpu,
+            "detail": {"solve_kernel_ms_sum_per_step": sum(ktimes) / args.steps,
+                       "encode": {k: enc_stats[k] for k in ("plan_ms", "host_ms", "strip_bytes", "lds_bytes", "grid",
+                                                            "npiv", "u", "nlev")},
+                       "decode": {k: dec_stats[k] for k in ("plan_ms", "host_ms", "strip_bytes", "lds_bytes", "grid",
+                                                            "npiv", "u", "nlev")}},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

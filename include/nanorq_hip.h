@@ -99,7 +99,13 @@ int nrq_dev_upload(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); 
 int nrq_dev_download(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* synchronous */
 int nrq_dev_memset(nrq_ctx *ctx, void *d_dst, int value, size_t bytes);
 
-/* Kernel timing on the context's stream with HIP events (bench.py's roofline leg). */
+/* Per-launch duration of the solve kernel, measured with HIP events recorded on the launch stream
+ * immediately around each launch (bench.py's roofline leg).  enable(1) starts collecting; read()
+ * synchronises, returns the durations of the launches since the last read/enable in launch order. */
+int nrq_ktime_enable(nrq_ctx *ctx, int on);
+int nrq_ktime_read(nrq_ctx *ctx, float *ms_out, uint32_t cap, uint32_t *count);
+
+/* Generic stream timer (HIP events on the context's stream). */
 int nrq_timer_start(nrq_ctx *ctx);
 int nrq_timer_stop_ms(nrq_ctx *ctx, float *ms); /* synchronises */
 

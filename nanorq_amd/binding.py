@@ -59,6 +59,8 @@ def lib():
     L.nrq_dev_upload.argtypes = [vp, vp, vp, sz]
     L.nrq_dev_download.argtypes = [vp, vp, vp, sz]
     L.nrq_dev_memset.argtypes = [vp, vp, C.c_int, sz]
+    L.nrq_ktime_enable.argtypes = [vp, C.c_int]
+    L.nrq_ktime_read.argtypes = [vp, C.POINTER(C.c_float), C.c_uint32, u32p]
     L.nrq_timer_start.argtypes = [vp]
     L.nrq_timer_stop_ms.argtypes = [vp, C.POINTER(C.c_float)]
     u8pp = C.POINTER(C.POINTER(C.c_uint8))
@@ -210,6 +212,15 @@ class Context:
         isis = np.ascontiguousarray(isis, dtype=np.uint32)
         self._chk(self._L.nrq_gen_symbols(self._h, K, T, nblk, C.c_void_p(d_inter), inter_stride, len(isis),
                                           _u32(isis), C.c_void_p(d_out), out_stride))
+
+    def ktime_enable(self, on=True):
+        self._chk(self._L.nrq_ktime_enable(self._h, int(on)))
+
+    def ktime_read(self, cap=65536):
+        buf = (C.c_float * cap)()
+        n = C.c_uint32()
+        self._chk(self._L.nrq_ktime_read(self._h, buf, cap, C.byref(n)))
+        return [float(buf[k]) for k in range(min(cap, n.value))]
 
     def timer_start(self):
         self._chk(self._L.nrq_timer_start(self._h))

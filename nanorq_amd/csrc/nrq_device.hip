@@ -199,6 +199,10 @@ struct nrq_ctx {
   nrq_call_stats stats;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool attr_set[4] = {false, false, false, false};
+  /* optional per-launch timing of the solve kernel (HIP events on the launch stream) */
+  bool ktime_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ktime_pool;
+  size_t ktime_used = 0;
 };
 
 namespace {
@@ -314,9 +318,23 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     ctx->attr_set[slot] = true;
   }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (ctx->ktime_on) {
+    if (ctx->ktime_used == ctx->ktime_pool.size()) {
+      hipEvent_t a, b;
+      HIPCHK(ctx, hipEventCreate(&a));
+      HIPCHK(ctx, hipEventCreate(&b));
+      ctx->ktime_pool.emplace_back(a, b);
+    }
+    ev0 = ctx->ktime_pool[ctx->ktime_used].first;
+    ev1 = ctx->ktime_pool[ctx->ktime_used].second;
+    ctx->ktime_used++;
+    HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
+  }
   hipLaunchKernelGGL(nrq_solve_kernel<WB>, dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T,
                      nstrips, d_kc);
   HIPCHK(ctx, hipGetLastError());
+  if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
   ctx->stats.strip_bytes = WB;
   ctx->stats.lds_bytes = lds_bytes;
   ctx->stats.grid = (uint32_t)grid;
@@ -404,6 +422,7 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
     if (ctx->staging[i].p) (void)hipHostFree(ctx->staging[i].p);
     if (ctx->staged[i]) (void)hipEventDestroy(ctx->staged[i]);
   }
+  for (auto &pr : ctx->ktime_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   delete ctx;
@@ -712,6 +731,24 @@ int nrq_dev_download(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 int nrq_dev_memset(nrq_ctx *ctx, void *d_dst, int value, size_t bytes) {
   if (!ctx) return -1;
   HIPCHK(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+  return 0;
+}
+
+int nrq_ktime_enable(nrq_ctx *ctx, int on) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->ktime_on = on != 0;
+  ctx->ktime_used = 0;
+  return 0;
+}
+int nrq_ktime_read(nrq_ctx *ctx, float *ms_out, uint32_t cap, uint32_t *count) {
+  if (!ctx || !count) return -1;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  uint32_t n = (uint32_t)ctx->ktime_used;
+  for (uint32_t k = 0; k < n && k < cap; k++)
+    HIPCHK(ctx, hipEventElapsedTime(&ms_out[k], ctx->ktime_pool[k].first, ctx->ktime_pool[k].second));
+  *count = n;
+  ctx->ktime_used = 0;
   return 0;
 }
 

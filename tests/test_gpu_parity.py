@@ -1,0 +1,178 @@
+"""-m gpu tier: the HIP path (through the C ABI of include/nanorq_hip.h) against the CPU oracle,
+the SURVEY section 8(c) known answers and, at BASELINE.json's full sizes, size-independent properties
+(encode -> erase -> decode round trips, the systematic property).  Bit-exact everywhere."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import nanorq_amd
+from test_oracle_kat import KAT_SHA, KAT_SMALL
+from util import kat_payload, loss_pattern, payload, received_set
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_support
+    gpu_support.ctx()
+    return gpu_support
+
+
+def test_kat_small(G):
+    rep, _ = G.gpu_encode(kat_payload(80).reshape(1, 10, 8), 10, 8, [10, 11, 12])
+    assert {10 + k: rep[0, k].tobytes().hex() for k in range(3)} == KAT_SMALL
+
+
+@pytest.mark.parametrize("K,T,lo,hi,sha", KAT_SHA)
+def test_kat_sha(G, K, T, lo, hi, sha):
+    rep, _ = G.gpu_encode(kat_payload(K * T).reshape(1, K, T), K, T, list(range(lo, hi)))
+    assert hashlib.sha256(rep[0].tobytes()).hexdigest() == sha
+
+
+@pytest.mark.parametrize("K,T", [(10, 8), (10, 40), (55, 4), (100, 1024), (101, 20), (500, 72), (1024, 1280),
+                                 (1033, 16), (4000, 48)])
+def test_encode_matches_oracle(G, orc, K, T):
+    nblk = 3
+    src = np.stack([payload(K * T, seed=3, block=b).reshape(K, T) for b in range(nblk)])
+    esis = np.array([K, K + 1, K + 5, K + 1000, (1 << 24) - 1], np.uint32)
+    rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+    for b in range(nblk):
+        r_rep, r_int, _ = orc.encode_block(src[b], K, T, esis, want_inter=True)
+        assert np.array_equal(inter[b], r_int), "intermediate symbols differ (block %d)" % b
+        assert np.array_equal(rep[b], r_rep)
+
+
+@pytest.mark.parametrize("K,T,p,oh", [(10, 16, 0.3, 0), (100, 1024, 0.06, 0), (100, 64, 0.06, 3), (100, 8, 0.5, 40),
+                                      (1024, 1280, 0.05, 0), (1024, 1280, 0.06, 52), (1024, 24, 0.3, 1),
+                                      (8192, 32, 0.1, 0), (8192, 32, 0.1, 2), (8192, 32, 0.1, 11)])
+def test_decode_matches_oracle(G, orc, K, T, p, oh):
+    nblk = 4
+    src = np.stack([payload(K * T, seed=9, block=b).reshape(K, T) for b in range(nblk)])
+    lost = [loss_pattern(K, p, seed=21, block=b) for b in range(nblk)]
+    lost[0] = lost[0][:0] if K > 10 else lost[0]  # one block with nothing missing
+    rep_esis = [np.arange(K, K + len(l) + (oh if len(l) else 0), dtype=np.uint32) for l in lost]
+    reps, work, exp_ok = [], src.copy(), []
+    for b in range(nblk):
+        r, _, _ = orc.encode_block(src[b], K, T, rep_esis[b])
+        reps.append(r)
+        work[b][lost[b]] = 0x5A
+        esis = received_set(K, lost[b], oh if len(lost[b]) else 0)
+        syms = np.concatenate([src[b][esis[esis < K]], r]) if len(r) else src[b][esis[esis < K]]
+        ok, out, _ = orc.decode_block(esis, syms, K, T)
+        exp_ok.append(ok)
+    st, out, _ = G.gpu_decode(work, K, T, lost, rep_esis, reps)
+    for b in range(nblk):
+        assert bool(st[b]) == exp_ok[b]
+        if exp_ok[b]:
+            assert np.array_equal(out[b], src[b]), "block %d" % b
+        else:
+            assert np.array_equal(out[b], work[b])  # an undecodable block is left untouched
+
+
+def test_decode_too_few_symbols_and_retry(G, orc):
+    K, T = 100, 32
+    src = payload(K * T, seed=2).reshape(1, K, T)
+    lost = [np.array([3, 50, 77], np.uint32)]
+    rep, _ = G.gpu_encode(src, K, T, [100, 101, 102])
+    work = src.copy(); work[0][lost[0]] = 0
+    st, out, _ = G.gpu_decode(work, K, T, lost, [np.array([100, 101], np.uint32)], [rep[0][:2]])
+    assert st[0] == 0
+    st, out, _ = G.gpu_decode(work, K, T, lost, [np.array([100, 101, 102], np.uint32)], [rep[0]])
+    assert st[0] == 1 and np.array_equal(out[0], src[0])
+
+
+def test_failure_parity_sweep(G, orc):
+    """rank-deficient systems must be reported exactly where the reference algorithm reports them."""
+    from emu_support import decode_setup
+    K, T = 12, 8
+    src = payload(K * T, seed=4).reshape(K, T)
+    rng = np.random.default_rng(7)
+    lost_l, resi_l, reps_l, expect = [], [], [], []
+    all_rep, _ = G.gpu_encode(src.reshape(1, K, T), K, T, np.arange(K, K + 60, dtype=np.uint32))
+    for trial in range(200):
+        nl = int(rng.integers(1, 7))
+        lost = np.sort(rng.choice(K, nl, replace=False)).astype(np.uint32)
+        resi = (K + rng.choice(60, nl, replace=False)).astype(np.uint32)
+        isis, _ = decode_setup(orc, K, lost, resi)
+        r, _ = orc.plan_probe(K, isis)
+        lost_l.append(lost); resi_l.append(resi); reps_l.append(all_rep[0][resi - K]); expect.append(r == 1)
+    work = np.repeat(src.reshape(1, K, T), 200, axis=0).copy()
+    for b in range(200):
+        work[b][lost_l[b]] = 0xFF
+    st, out, _ = G.gpu_decode(work, K, T, lost_l, resi_l, reps_l)
+    assert [bool(x) for x in st] == expect and not all(expect)
+    for b in range(200):
+        if expect[b]:
+            assert np.array_equal(out[b], src)
+
+
+def test_gen_symbols_from_hbm(G, orc):
+    K, T, nblk = 300, 96, 2
+    p = orc.params(K)
+    src = np.stack([payload(K * T, seed=6, block=b).reshape(K, T) for b in range(nblk)])
+    c = G.ctx()
+    L = p["L"]
+    d_src = c.alloc(nblk * K * T); d_int = c.alloc(nblk * L * T)
+    isis = np.array([0, 5, K - 1, p["Kp"], p["Kp"] + 7, p["Kp"] + 100000], np.uint32)
+    d_out = c.alloc(nblk * len(isis) * T)
+    c.upload(d_src, src)
+    c.encode_blocks(K, T, nblk, d_src, K * T, 0, 0, [], d_int, L * T)
+    c.gen_symbols(K, T, nblk, d_int, L * T, isis, d_out, len(isis) * T)
+    got = c.download(d_out, nblk * len(isis) * T).reshape(nblk, len(isis), T)
+    for b in range(nblk):
+        assert np.array_equal(got[b, 0], src[b, 0]) and np.array_equal(got[b, 2], src[b, K - 1])  # systematic
+        rep, _, _ = orc.encode_block(src[b], K, T, isis[3:] - (p["Kp"] - K))
+        assert np.array_equal(got[b, 3:], rep)
+    for d in (d_src, d_int, d_out):
+        c.free(d)
+
+
+def _roundtrip(G, K, T, nblk, p, oh, seed):
+    src = np.stack([payload(K * T, seed=seed, block=b).reshape(K, T) for b in range(nblk)])
+    lost = [loss_pattern(K, p, seed=seed + 1, block=b) for b in range(nblk)]
+    nrep = max(len(l) for l in lost) + oh
+    esis = np.arange(K, K + nrep, dtype=np.uint32)
+    rep, _ = G.gpu_encode(src, K, T, esis)
+    work = src.copy()
+    for b in range(nblk):
+        work[b][lost[b]] = 0
+    st, out, _ = G.gpu_decode(work, K, T, lost, [esis[:len(l) + oh] for l in lost],
+                              [rep[b][:len(lost[b]) + oh] for b in range(nblk)])
+    return st, out, src
+
+
+def test_roundtrip_headline_config(G):
+    """BASELINE configs[1]/[2] at full size: K=8192, T=1280, 10 % loss, +2 overhead, 8 blocks."""
+    st, out, src = _roundtrip(G, 8192, 1280, 8, 0.10, 2, seed=31)
+    assert st.sum() >= 7
+    for b in range(8):
+        if st[b]:
+            assert np.array_equal(out[b], src[b])
+
+
+def test_headline_block_vs_oracle_checksum(G, orc):
+    """One full-size K=8192/T=1280 block: repair symbols and recovered data equal the oracle's."""
+    K, T = 8192, 1280
+    src = payload(K * T, seed=77).reshape(K, T)
+    lost = loss_pattern(K, 0.10, seed=78)
+    esis = np.arange(K, K + len(lost) + 2, dtype=np.uint32)
+    rep, _ = G.gpu_encode(src.reshape(1, K, T), K, T, esis)
+    r_rep, _, _ = orc.encode_block(src, K, T, esis)
+    assert hashlib.sha256(rep[0].tobytes()).hexdigest() == hashlib.sha256(r_rep.tobytes()).hexdigest()
+    work = src.copy(); work[lost] = 0
+    st, out, _ = G.gpu_decode(work.reshape(1, K, T), K, T, [lost], [esis], [rep[0]])
+    assert st[0] == 1 and np.array_equal(out[0], src)
+
+
+def test_roundtrip_max_k(G):
+    """BASELINE configs[4] shape: K'=56403 (RFC 6330 maximum), T=1280, 20 % loss, +16 (2-byte strips)."""
+    st, out, src = _roundtrip(G, 56403, 1280, 1, 0.20, 16, seed=41)
+    assert st[0] == 1 and np.array_equal(out[0], src[0])
+
+
+def test_roundtrip_large_symbols(G):
+    """BASELINE configs[3] shape: K=27000 with large symbols (T reduced to 4096 to bound host memory)."""
+    st, out, src = _roundtrip(G, 27000, 4096, 1, 0.10, 2, seed=51)
+    assert st[0] == 1 and np.array_equal(out[0], src[0])
