@@ -53,8 +53,14 @@ __device__ __forceinline__ bool nrq_map_strip(uint32_t wb, uint32_t nblk, uint32
 template <int WB>
 __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
                                                            uint32_t T, uint32_t nstrips,
-                                                           const uint8_t *__restrict__ kc) {
+                                                           const uint8_t *__restrict__ kc,
+                                                           unsigned long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  /* NRQ_PROF=1 debugging aid: shader-clock stamps at phase boundaries of every 1024th workgroup */
+  unsigned long long *stamp = nullptr;
+  if (prof && (blockIdx.x & 1023u) == 0 && threadIdx.x == 0) stamp = prof + (size_t)(blockIdx.x >> 10) * 16;
+#define NRQ_STAMP(i) do { if (stamp) stamp[i] = (unsigned long long)clock64(); } while (0)
+  NRQ_STAMP(0);
   uint32_t blk, strip;
   if (!nrq_map_strip(WB, nblk, nstrips, &blk, &strip)) return;
   StripCtx<WB> c;
@@ -73,42 +79,63 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
 
   ph_load<WB>(c, tid, NRQ_WG);
   __syncthreads();
+  NRQ_STAMP(1);
 
-  /* forward passes: chunks of 256 independent-up-to-accumulation XOR ops; op words are
-   * prefetched four chunks ahead so that their L2 latency never sits on the dependency chain */
+  /* forward passes: chunks of 256 independent-up-to-accumulation XOR ops.  Op words are fetched
+   * four chunks ahead into four fixed registers (no hand-over between them, so the loads stay
+   * outstanding across the LDS work and the barriers); the barrier schedule is one bit per chunk. */
   {
-    const uint32_t *ops = c.template arr<uint32_t>(c.h->off_ops);
+    const NRQ_GAS uint32_t *ops = c.template arr<uint32_t>(c.h->off_ops);
+    const NRQ_GAS uint32_t *sy = c.template arr<uint32_t>(c.h->off_sync);
     const uint32_t nch = c.h->nchunk1 + c.h->nchunk2;
-    uint32_t q0 = nch > 0 ? ops[tid] : NRQ_NOP;
-    uint32_t q1 = nch > 1 ? ops[NRQ_WG + tid] : NRQ_NOP;
-    uint32_t q2 = nch > 2 ? ops[2 * NRQ_WG + tid] : NRQ_NOP;
-    uint32_t q3 = nch > 3 ? ops[3 * NRQ_WG + tid] : NRQ_NOP;
-    const uint32_t *sy = c.syncw();
-    for (uint32_t ch = 0; ch < nch; ch++) {
-      const uint32_t cur = q0;
-      q0 = q1; q1 = q2; q2 = q3;
-      q3 = (ch + 4 < nch) ? ops[(size_t)(ch + 4) * NRQ_WG + tid] : NRQ_NOP;
+    /* the plan pads the stream with 4 all-NOP chunks and the sync words with 2 words, so every
+     * read-ahead below is in bounds and needs no branch */
+    uint32_t q0 = ops[tid], q1 = ops[NRQ_WG + tid], q2 = ops[2 * NRQ_WG + tid], q3 = ops[3 * NRQ_WG + tid];
+    uint32_t swv = sy[0];
+    const NRQ_GAS uint32_t *nxt = ops + 4 * NRQ_WG + tid;
+    for (uint32_t base = 0; base < nch; base += 4, nxt += 4 * NRQ_WG) {
+      uint32_t sw = __builtin_amdgcn_readfirstlane(swv) >> (base & 31u);
+      if ((base & 31u) == 28u) swv = sy[(base >> 5) + 1];
+      uint32_t cur;
+      cur = q0; q0 = nxt[0];
       ph_op<WB>(c, cur);
-      if ((sy[ch >> 5] >> (ch & 31u)) & 1u) __syncthreads();
+      if (sw & 1u) __syncthreads();
+      cur = q1; q1 = nxt[NRQ_WG];
+      ph_op<WB>(c, cur);
+      if (sw & 2u) __syncthreads();
+      cur = q2; q2 = nxt[2 * NRQ_WG];
+      ph_op<WB>(c, cur);
+      if (sw & 4u) __syncthreads();
+      cur = q3; q3 = nxt[3 * NRQ_WG];
+      ph_op<WB>(c, cur);
+      if (sw & 8u) __syncthreads();
     }
   }
   __syncthreads();
+  NRQ_STAMP(2);
 
   ph_hdpc<WB>(c, tid, NRQ_WG);
-  ph_dense_bin<WB>(c, tid, NRQ_WG);
   __syncthreads();
+  NRQ_STAMP(3);
+  NRQ_STAMP(4);
   ph_dense_fold<WB>(c, tid, NRQ_WG);
   __syncthreads();
   ph_dense_free<WB>(c, tid, NRQ_WG);
   __syncthreads();
   ph_dense_cu<WB>(c, tid, NRQ_WG);
   __syncthreads();
+  NRQ_STAMP(5);
   ph_tables<WB>(c, tid, NRQ_WG);
   __syncthreads();
+  NRQ_STAMP(6);
   ph_backsub<WB>(c, tid, NRQ_WG);
   ph_park<WB>(c, tid, NRQ_WG);
   __syncthreads();
+  NRQ_STAMP(7);
   ph_store<WB>(c, tid, NRQ_WG);
+  __syncthreads();
+  NRQ_STAMP(8);
+#undef NRQ_STAMP
 }
 
 /* One workgroup per (symbol, block): out = XOR of the LT neighbours of `isi` among the L
@@ -178,6 +205,7 @@ struct EncPlan {
   uint32_t plan_bytes = 0;
   uint32_t rowsrc_off = 0;
   nrq_plan_hdr hdr;
+  std::vector<uint16_t> colslot; /* host copy, to translate LT neighbour lists into slots */
   double build_ms = 0;
 };
 
@@ -203,6 +231,7 @@ struct nrq_ctx {
   bool ktime_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ktime_pool;
   size_t ktime_used = 0;
+  unsigned long long *prof = nullptr; /* NRQ_PROF=1 */
 };
 
 namespace {
@@ -277,6 +306,8 @@ int get_encplan(nrq_ctx *ctx, uint32_t K, EncPlan **out) {
   memcpy(&ep.hdr, arena, sizeof(ep.hdr));
   if (ep.hdr.status) { nrq_host_free(arena); return fail(ctx, -3, "encode matrix singular for K=%u (cannot happen)", K); }
   ep.plan_bytes = bytes;
+  ep.colslot.assign(reinterpret_cast<const uint16_t *>(arena + ep.hdr.off_colslot),
+                    reinterpret_cast<const uint16_t *>(arena + ep.hdr.off_colslot) + p.L);
   ep.rowsrc_off = (uint32_t)r16(bytes);
   std::vector<uint32_t> rowsrc(p.L, NRQ_ROW_ZERO);
   for (uint32_t j = 0; j < K; j++) rowsrc[p.S + p.H + j] = j;
@@ -291,9 +322,10 @@ int get_encplan(nrq_ctx *ctx, uint32_t K, EncPlan **out) {
   return 0;
 }
 
-/* LT neighbour lists of the symbols to generate, in the layout ph_store() reads */
-void build_out_lists(const rq_params &p, uint32_t n, const uint32_t *isis, std::vector<uint32_t> &cptr,
-                     std::vector<uint16_t> &cols) {
+/* LT neighbour lists of the symbols to generate, already translated to LDS slots through the plan's
+ * colslot[], in the layout ph_store() reads */
+void build_out_lists(const rq_params &p, const uint16_t *colslot, uint32_t n, const uint32_t *isis,
+                     std::vector<uint32_t> &cptr, std::vector<uint16_t> &cols) {
   cptr.resize(n + 1);
   cols.clear();
   cols.reserve((size_t)n * 9);
@@ -301,7 +333,7 @@ void build_out_lists(const rq_params &p, uint32_t n, const uint32_t *isis, std::
   for (uint32_t q = 0; q < n; q++) {
     cptr[q] = (uint32_t)cols.size();
     uint32_t m = rq_lt_columns(&p, isis[q], tmp);
-    for (uint32_t k = 0; k < m; k++) cols.push_back((uint16_t)tmp[k]);
+    for (uint32_t k = 0; k < m; k++) cols.push_back(colslot[tmp[k]]); /* slot that holds C[col] */
   }
   cptr[n] = (uint32_t)cols.size();
 }
@@ -331,10 +363,37 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     ctx->ktime_used++;
     HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
   }
+  const uint32_t nprof = (uint32_t)((grid + 1023) / 1024);
+  if (getenv("NRQ_PROF")) {
+    if (ctx->prof) { (void)hipFree(ctx->prof); ctx->prof = nullptr; }
+    HIPCHK(ctx, hipMalloc((void **)&ctx->prof, (size_t)nprof * 16 * 8));
+    HIPCHK(ctx, hipMemsetAsync(ctx->prof, 0, (size_t)nprof * 16 * 8, ctx->stream));
+  }
   hipLaunchKernelGGL(nrq_solve_kernel<WB>, dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T,
-                     nstrips, d_kc);
+                     nstrips, d_kc, ctx->prof);
   HIPCHK(ctx, hipGetLastError());
   if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
+  if (ctx->prof) {
+    std::vector<unsigned long long> hp((size_t)nprof * 16);
+    HIPCHK(ctx, hipMemcpyAsync(hp.data(), ctx->prof, hp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    static const char *names[8] = {"load", "fwd", "hdpc", "bin", "dense", "tables", "backsub", "store"};
+    double sum[8] = {0}, tot = 0;
+    uint32_t cnt = 0;
+    for (uint32_t w = 0; w < nprof; w++) {
+      const unsigned long long *q = &hp[(size_t)w * 16];
+      if (!q[8]) continue;
+      for (int k = 0; k < 8; k++) sum[k] += (double)(q[k + 1] - q[k]);
+      tot += (double)(q[8] - q[0]);
+      cnt++;
+    }
+    fprintf(stderr, "[NRQ_PROF] WB=%d grid=%llu sampled=%u total=%.0f clk:", WB, (unsigned long long)grid, cnt,
+            cnt ? tot / cnt : 0.0);
+    for (int k = 0; k < 8; k++) fprintf(stderr, " %s=%.0f", names[k], cnt ? sum[k] / cnt : 0.0);
+    fprintf(stderr, "\n");
+    (void)hipFree(ctx->prof);
+    ctx->prof = nullptr;
+  }
   ctx->stats.strip_bytes = WB;
   ctx->stats.lds_bytes = lds_bytes;
   ctx->stats.grid = (uint32_t)grid;
@@ -489,7 +548,7 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const
   std::vector<uint32_t> isis(nrep), cptr;
   std::vector<uint16_t> cols;
   for (uint32_t q = 0; q < nrep; q++) isis[q] = h_esis[q] + (p.Kp - K);
-  build_out_lists(p, nrep, isis.data(), cptr, cols);
+  build_out_lists(p, ep->colslot.data(), nrep, isis.data(), cptr, cols);
   const size_t off_jobs = 0;
   const size_t off_cptr = r16(off_jobs + (size_t)nblk * sizeof(nrq_job));
   const size_t off_row = r16(off_cptr + (size_t)(nrep + 1) * 4);
@@ -515,7 +574,7 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const
     j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
     j.out = nrep ? (uint64_t)(uintptr_t)((uint8_t *)d_rep + (size_t)b * rep_stride) : 0;
     j.out_cptr = (uint64_t)(uintptr_t)(ds + off_cptr);
-    j.out_cols = (uint64_t)(uintptr_t)(ds + off_cols);
+    j.out_slots = (uint64_t)(uintptr_t)(ds + off_cols);
     j.out_row = (uint64_t)(uintptr_t)(ds + off_row);
     j.nout = nrep;
   }
@@ -582,7 +641,8 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void 
       return;
     }
     if (reinterpret_cast<const nrq_plan_hdr *>(pr.plan)->status) { pr.state = -1; return; } /* rank(A) < L */
-    build_out_lists(p, nl, lost, pr.cptr, pr.cols); /* ISI of a source symbol is its ESI */
+    build_out_lists(p, reinterpret_cast<const uint16_t *>(pr.plan + reinterpret_cast<const nrq_plan_hdr *>(pr.plan)->off_colslot),
+                    nl, lost, pr.cptr, pr.cols); /* ISI of a source symbol is its ESI */
     pr.orow.assign(lost, lost + nl);
     pr.state = 1;
   };
@@ -666,7 +726,7 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void 
       j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
       j.out = j.src; /* recovered symbols go back into the block's own rows */
       j.out_cptr = (uint64_t)(uintptr_t)(ds + pr.off_cptr);
-      j.out_cols = (uint64_t)(uintptr_t)(ds + pr.off_cols);
+      j.out_slots = (uint64_t)(uintptr_t)(ds + pr.off_cols);
       j.out_row = (uint64_t)(uintptr_t)(ds + pr.off_row);
       j.nout = (uint32_t)pr.orow.size();
     }

@@ -39,18 +39,20 @@ typedef struct nrq_plan_hdr {
   uint32_t nfree;   /* u - r2: columns that need the HDPC rows */
   uint32_t nlev;    /* dependency depth of the peeled block */
   uint32_t nchunk1; /* chunks of the pivot forward pass */
-  uint32_t nchunk2; /* chunks of the low-row pass */
+  uint32_t nchunk2; /* chunks of the low-row pass and of the GF(2) combination pass (E rows) */
   uint32_t wpr;     /* 32-bit words per W row: ceil(u/32) */
-  uint32_t lpr;     /* 32-bit words per G2 row: ceil(nlow/32) */
+  uint32_t lpr;     /* reserved (was: words per G2 row) */
   uint32_t npiv_pad;/* stride (in pivots) of the transposed W image, multiple of 64 */
   uint32_t n_xor_ops; /* real (non-padding) ops in both passes, for statistics */
 
-  uint32_t off_ops;     /* u32[(nchunk1+nchunk2)*NRQ_CHUNK]: dst | src<<16, NRQ_NOP = padding */
+  uint32_t off_ops;     /* u32[(nchunk1+nchunk2)*NRQ_CHUNK]: dst | src<<16, NRQ_NOP = padding
+                         * (4 more all-NOP chunks follow the last one: prefetch slack).  Slots >= M are the
+                         * r2 scratch rows E_p (slot M+p) of the dense stage: E_p = XOR of leftover rows */
   uint32_t off_pivslot; /* u16[npiv]: slot of pivot k */
   uint32_t off_pivcol;  /* u16[npiv]: column of pivot k */
   uint32_t off_wt;      /* u32[wpr*npiv_pad]: word w of W row k at [w*npiv_pad + k] */
   uint32_t off_lowslot; /* u16[nlow] */
-  uint32_t off_g2;      /* u32[r2*lpr]: E_p = XOR_{j in bits} slot[lowslot[j]] */
+  uint32_t off_g2;      /* reserved (the GF(2) combinations are part of the op stream) */
   uint32_t off_pivx;    /* u16[r2]: inactive-column index solved by reduced row p */
   uint32_t off_fbits;   /* u32[r2]: bit f set -> C_u[pivx[p]] ^= C_free[f] */
   uint32_t off_mh;      /* u8[H*r2], [h][p]: R_h ^= mh * E_p */
@@ -59,7 +61,7 @@ typedef struct nrq_plan_hdr {
   uint32_t off_colslot; /* u16[L]: slot that finally holds intermediate symbol C[c] */
   uint32_t off_pivof;   /* u16[Kp+S]: slot of the pivot row of column c, NRQ_NOSLOT if inactive */
   uint32_t off_uslot;   /* u16[u]: slot that receives inactive column x */
-  uint32_t off_sync;    /* u32[ceil(nchunk/32)]: bit c set -> workgroup barrier after chunk c */
+  uint32_t off_sync;    /* u32[ceil(nchunk/32)+2]: bit c set -> workgroup barrier after chunk c */
   uint32_t total_bytes;
   uint32_t reserved[2];
 } nrq_plan_hdr;

@@ -380,6 +380,35 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
     red_x.push_back(x);
   }
   const uint32_t r2 = (uint32_t)red_row.size(), nfree = (uint32_t)freex.size();
+  /* GF(2) combinations E_p (slot M+p) = XOR of the leftover rows named by the augmented part of
+   * reduced row p: appended to the op stream as one more accumulate-only group */
+  {
+    size_t start = ops.size();
+    if (M + r2 > 65535u) return -3;
+    /* round-robin over p so that neighbouring ops hit different targets */
+    std::vector<uint32_t> curj(r2, 0);
+    bool any = r2 > 0;
+    while (any) {
+      any = false;
+      for (uint32_t q = 0; q < r2; q++) {
+        const uint32_t *aug = &Mb[(size_t)red_row[q] * rowlen + wpr];
+        uint32_t &j = curj[q];
+        while (j < nlow && !bit(aug, j)) j++;
+        if (j < nlow) {
+          ops.push_back((uint32_t)(M + q) | ((uint32_t)lowslot[j] << 16));
+          j++; any = true;
+        }
+      }
+    }
+    n_real_ops += (uint32_t)(ops.size() - start);
+    while ((ops.size() - start) % NRQ_CHUNK) ops.push_back(NRQ_NOP);
+    if (ops.size() > start) {
+      uint32_t last = (uint32_t)(ops.size() / NRQ_CHUNK) - 1;
+      if (sync_bits.size() <= last / 32) sync_bits.resize(last / 32 + 1, 0);
+      sync_bits[last / 32] |= 1u << (last % 32);
+    }
+    nchunk2 = (uint32_t)(ops.size() / NRQ_CHUNK) - nchunk1;
+  }
   uint32_t status = 0;
   if (nfree > H || nfree > NRQ_MAX_FREE) status = 1;
 
@@ -453,7 +482,9 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   hd.nchunk1 = nchunk1; hd.nchunk2 = nchunk2; hd.wpr = wpr; hd.lpr = lpr;
   hd.npiv_pad = (npiv + 63u) & ~63u;
   hd.n_xor_ops = n_real_ops;
-  hd.off_ops = A.reserve((uint32_t)(ops.size() * 4));
+  /* 4 chunks of padding: the kernel prefetches op words 4 chunks ahead without bounds checks */
+  hd.off_ops = A.reserve((uint32_t)((ops.size() + 4 * NRQ_CHUNK) * 4));
+  memset(A.at<uint8_t>(hd.off_ops), 0xFF, (ops.size() + 4 * NRQ_CHUNK) * 4);
   if (!ops.empty()) memcpy(A.at<uint8_t>(hd.off_ops), ops.data(), ops.size() * 4);
   hd.off_pivslot = A.reserve(npiv * 2);
   memcpy(A.at<uint8_t>(hd.off_pivslot), pivslot.data(), (size_t)npiv * 2);
@@ -467,12 +498,7 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   }
   hd.off_lowslot = A.reserve(std::max(1u, nlow) * 2);
   if (nlow) memcpy(A.at<uint8_t>(hd.off_lowslot), lowslot.data(), (size_t)nlow * 2);
-  hd.off_g2 = A.reserve(std::max(1u, r2) * lpr * 4);
-  {
-    uint32_t *g2 = A.at<uint32_t>(hd.off_g2);
-    for (uint32_t q = 0; q < r2; q++)
-      memcpy(&g2[(size_t)q * lpr], &Mb[(size_t)red_row[q] * rowlen + wpr], (size_t)lpr * 4);
-  }
+  hd.off_g2 = 0;
   hd.off_pivx = A.reserve(std::max(1u, r2) * 2);
   for (uint32_t q = 0; q < r2; q++) A.at<uint16_t>(hd.off_pivx)[q] = (uint16_t)red_x[q];
   hd.off_fbits = A.reserve(std::max(1u, r2) * 4);
@@ -490,7 +516,7 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   hd.off_uslot = A.reserve(std::max(1u, u) * 2);
   if (u) memcpy(A.at<uint8_t>(hd.off_uslot), uslot.data(), (size_t)u * 2);
   {
-    uint32_t nw = std::max(1u, (nchunk1 + nchunk2 + 31u) / 32u);
+    uint32_t nw = (nchunk1 + nchunk2 + 31u) / 32u + 2u; /* +2: read-ahead padding */
     sync_bits.resize(nw, 0);
     hd.off_sync = A.reserve(nw * 4);
     memcpy(A.at<uint8_t>(hd.off_sync), sync_bits.data(), (size_t)nw * 4);

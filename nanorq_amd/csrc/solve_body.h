@@ -34,8 +34,20 @@
 #define SB_HD static inline
 #define SB_MEM inline
 struct uint2 { uint32_t x, y; };
-struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct uint4 { uint32_t x, y, z, w; };
 #endif
+
+/* Pointers that come out of the job descriptor are generic as far as the compiler can tell, which
+ * would turn every access into flat_load/flat_store (counted on BOTH vmcnt and lgkmcnt, so each LDS
+ * wait would also drain them).  They all point to HBM: say so. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NRQ_GAS __attribute__((address_space(1)))
+#else
+#define NRQ_GAS
+#endif
+template <class X> SB_HD const NRQ_GAS X *gptr(const void *p) { return (const NRQ_GAS X *)p; }
+template <class X> SB_HD const NRQ_GAS X *gptr(uint64_t p) { return (const NRQ_GAS X *)(uintptr_t)p; }
+template <class X> SB_HD NRQ_GAS X *gptr_w(uint64_t p) { return (NRQ_GAS X *)(uintptr_t)p; }
 
 /* device-visible description of one block's work (filled by the host API) */
 typedef struct nrq_job {
@@ -46,7 +58,7 @@ typedef struct nrq_job {
   uint64_t inter;    /* nullable: L x T intermediate symbols out */
   uint64_t out;      /* generated symbols out, pitch T */
   uint64_t out_cptr; /* u32[nout+1] */
-  uint64_t out_cols; /* u16[]: intermediate-symbol indices XORed into each generated symbol */
+  uint64_t out_slots;/* u16[]: slots (plan colslot[] of the LT neighbours) XORed into each generated symbol */
   uint64_t out_row;  /* u32[nout]: destination row in `out` */
   uint32_t nout;
   uint32_t pad;
@@ -152,37 +164,37 @@ template <int WB> SB_HD void lds_xor(uint8_t *lds, uint32_t idx, const SV<WB> &v
 }
 
 /* ---- global strip access: `valid` bytes (<= WB) at p ---- */
-template <int WB> SB_HD SV<WB> g_get(const uint8_t *p, uint32_t valid) {
+template <int WB> SB_HD SV<WB> g_get(const NRQ_GAS uint8_t *p, uint32_t valid) {
   SV<WB> r = sv_zero<WB>();
   if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
     if constexpr (WB == 16) {
-      uint4 v = *reinterpret_cast<const uint4 *>(p);
+      uint4 v = *reinterpret_cast<const NRQ_GAS uint4 *>(p);
       r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
     } else if constexpr (WB == 8) {
-      uint2 v = *reinterpret_cast<const uint2 *>(p);
+      uint2 v = *reinterpret_cast<const NRQ_GAS uint2 *>(p);
       r.w[0] = v.x; r.w[1] = v.y;
     } else if constexpr (WB == 4) {
-      r.w[0] = *reinterpret_cast<const uint32_t *>(p);
+      r.w[0] = *reinterpret_cast<const NRQ_GAS uint32_t *>(p);
     } else {
-      r.w[0] = *reinterpret_cast<const uint16_t *>(p);
+      r.w[0] = *reinterpret_cast<const NRQ_GAS uint16_t *>(p);
     }
   } else {
     for (uint32_t k = 0; k < valid; k++) r.w[k >> 2] |= (uint32_t)p[k] << ((k & 3u) * 8u);
   }
   return r;
 }
-template <int WB> SB_HD void g_put(uint8_t *p, uint32_t valid, const SV<WB> &v) {
+template <int WB> SB_HD void g_put(NRQ_GAS uint8_t *p, uint32_t valid, const SV<WB> &v) {
   if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
     if constexpr (WB == 16) {
       uint4 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2]; t.w = v.w[3];
-      *reinterpret_cast<uint4 *>(p) = t;
+      *reinterpret_cast<NRQ_GAS uint4 *>(p) = t;
     } else if constexpr (WB == 8) {
       uint2 t; t.x = v.w[0]; t.y = v.w[1];
-      *reinterpret_cast<uint2 *>(p) = t;
+      *reinterpret_cast<NRQ_GAS uint2 *>(p) = t;
     } else if constexpr (WB == 4) {
-      *reinterpret_cast<uint32_t *>(p) = v.w[0];
+      *reinterpret_cast<NRQ_GAS uint32_t *>(p) = v.w[0];
     } else {
-      *reinterpret_cast<uint16_t *>(p) = (uint16_t)v.w[0];
+      *reinterpret_cast<NRQ_GAS uint16_t *>(p) = (uint16_t)v.w[0];
     }
   } else {
     for (uint32_t k = 0; k < valid; k++) p[k] = (uint8_t)(v.w[k >> 2] >> ((k & 3u) * 8u));
@@ -191,7 +203,7 @@ template <int WB> SB_HD void g_put(uint8_t *p, uint32_t valid, const SV<WB> &v) 
 
 /* ---- LDS carve-up, identical on host (launch sizing) and device ---- */
 typedef struct nrq_lds_layout {
-  uint32_t off_slots, off_cu, off_low, off_sync, off_x, off_cf, total;
+  uint32_t off_slots, off_cu, off_x, total;
 } nrq_lds_layout;
 
 SB_HD uint32_t nrq_r16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -199,17 +211,13 @@ SB_HD uint32_t nrq_r16(uint32_t x) { return (x + 15u) & ~15u; }
 SB_HD nrq_lds_layout nrq_lds_plan(const nrq_plan_hdr *h, uint32_t WB) {
   nrq_lds_layout l;
   uint32_t o = 0;
-  l.off_slots = o; o = nrq_r16(o + h->M * WB);
+  l.off_slots = o; o = nrq_r16(o + (h->M + h->r2) * WB); /* M slots, then the r2 scratch rows E_p */
   l.off_cu = o;    o = nrq_r16(o + (h->u ? h->u : 1u) * WB);
-  l.off_low = o;   o = nrq_r16(o + (h->nlow ? h->nlow : 1u) * 2u);
-  l.off_sync = o;  o = nrq_r16(o + ((h->nchunk1 + h->nchunk2 + 31u) / 32u + 1u) * 4u);
-  /* region X: {E[r2], Cf[NRQ_MAX_FREE]} during the dense stage, then the 4-bit combination tables */
-  uint32_t e_bytes = nrq_r16((h->r2 ? h->r2 : 1u) * WB);
-  uint32_t dense = e_bytes + NRQ_MAX_FREE * WB;
+  /* region X: the free-column accumulators Cf during the dense stage, then the 4-bit XOR tables */
+  uint32_t cf = NRQ_MAX_FREE * WB;
   uint32_t t4 = h->wpr * 8u * 16u * WB;
   l.off_x = o;
-  l.off_cf = o + e_bytes;
-  o = nrq_r16(o + (dense > t4 ? dense : t4));
+  o = nrq_r16(o + (cf > t4 ? cf : t4));
   l.total = o;
   return l;
 }
@@ -225,37 +233,48 @@ template <int WB> struct StripCtx {
   uint32_t T, strip, valid; /* valid = bytes of this strip inside T */
   SB_MEM uint8_t *slots() const { return lds + lay.off_slots; }
   SB_MEM uint8_t *cu() const { return lds + lay.off_cu; }
-  SB_MEM uint16_t *low() const { return reinterpret_cast<uint16_t *>(lds + lay.off_low); }
-  SB_MEM uint32_t *syncw() const { return reinterpret_cast<uint32_t *>(lds + lay.off_sync); }
-  SB_MEM uint8_t *ebuf() const { return lds + lay.off_x; }
-  SB_MEM uint8_t *cf() const { return lds + lay.off_cf; }
+  SB_MEM uint8_t *cf() const { return lds + lay.off_x; }
   SB_MEM uint8_t *t4() const { return lds + lay.off_x; }
-  template <class X> SB_MEM const X *arr(uint32_t off) const { return reinterpret_cast<const X *>(plan + off); }
+  template <class X> SB_MEM const NRQ_GAS X *arr(uint32_t off) const { return gptr<X>(plan + off); }
 };
 
-/* phase 0: bring the strip of every slot into LDS; stage small index arrays */
+/* phase 0: bring the strip of every slot into LDS (loads are issued LDB at a time so that their
+ * HBM/L2 latencies overlap); clear the scratch rows and the free-column accumulators */
 template <int WB> SB_HD void ph_load(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  const uint32_t *rowsrc = reinterpret_cast<const uint32_t *>(c.job.rowsrc);
-  const uint8_t *src = reinterpret_cast<const uint8_t *>(c.job.src);
-  const uint8_t *rep = reinterpret_cast<const uint8_t *>(c.job.rep);
+  constexpr int LDB = 16;
+  const NRQ_GAS uint32_t *rowsrc = gptr<uint32_t>(c.job.rowsrc);
+  const NRQ_GAS uint8_t *src = gptr<uint8_t>(c.job.src);
+  const NRQ_GAS uint8_t *rep = gptr<uint8_t>(c.job.rep);
   const size_t boff = (size_t)c.strip * WB;
-  for (uint32_t r = tid; r < c.h->M; r += nt) {
-    uint32_t s = rowsrc[r];
-    SV<WB> v = sv_zero<WB>();
-    if (s != NRQ_ROW_ZERO) {
-      const uint8_t *base = (s & NRQ_ROW_REP) ? rep + (size_t)(s & 0x7FFFFFFFu) * c.T : src + (size_t)s * c.T;
-      v = g_get<WB>(base + boff, c.valid);
+  const uint32_t M = c.h->M;
+  for (uint32_t base = tid; base < M; base += LDB * nt) {
+    uint32_t s[LDB];
+    SV<WB> v[LDB];
+#pragma unroll
+    for (int q = 0; q < LDB; q++) {
+      uint32_t r = base + (uint32_t)q * nt;
+      s[q] = r < M ? rowsrc[r] : NRQ_ROW_ZERO;
     }
-    lds_put<WB>(c.slots(), r, v);
+#pragma unroll
+    for (int q = 0; q < LDB; q++) {
+      v[q] = sv_zero<WB>();
+      if (s[q] != NRQ_ROW_ZERO) {
+        const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? rep + (size_t)(s[q] & 0x7FFFFFFFu) * c.T : src + (size_t)s[q] * c.T;
+        v[q] = g_get<WB>(b + boff, c.valid);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < LDB; q++) {
+      uint32_t r = base + (uint32_t)q * nt;
+      if (r < M) lds_put<WB>(c.slots(), r, v[q]);
+    }
   }
-  const uint16_t *lowslot = c.template arr<uint16_t>(c.h->off_lowslot);
-  for (uint32_t j = tid; j < c.h->nlow; j += nt) c.low()[j] = lowslot[j];
-  const uint32_t *sy = c.template arr<uint32_t>(c.h->off_sync);
-  uint32_t nsw = (c.h->nchunk1 + c.h->nchunk2 + 31u) / 32u;
-  for (uint32_t j = tid; j < nsw; j += nt) c.syncw()[j] = sy[j];
+  for (uint32_t p = tid; p < c.h->r2; p += nt) lds_put<WB>(c.slots(), M + p, sv_zero<WB>());
+  for (uint32_t f = tid; f < NRQ_MAX_FREE; f += nt) lds_put<WB>(c.cf(), f, sv_zero<WB>());
 }
 
-/* phases 1+2: one XOR op of the forward pass (X^-1 on the peeled rows, then the leftover rows) */
+/* phases 1+2: one XOR op of the forward passes (X^-1 on the peeled rows, the leftover rows, the
+ * GF(2) combinations of the dense stage) */
 template <int WB> SB_HD void ph_op(const StripCtx<WB> &c, uint32_t op) {
   if (op == NRQ_NOP) return;
   SV<WB> v = lds_get<WB>(c.slots(), op >> 16);
@@ -265,90 +284,70 @@ template <int WB> SB_HD void ph_op(const StripCtx<WB> &c, uint32_t op) {
 /* phase 3: HDPC right-hand sides R_h = SUM_c HDPC[h][c] * Y(c) over the peeled columns, through
  * HDPC = MT*GAMMA (RFC 6330 section 5.3.3.3): thread t owns columns [a,b); g follows the GAMMA
  * recurrence g = alpha*g + Y(c); the two unit entries of MT's column c add g to two of the H
- * accumulators; whatever the chunk owes to columns beyond b is G[.][b] * alpha*g_end. */
+ * accumulators (LDS atomics on the HDPC slots); whatever the chunk owes to the columns beyond b is
+ * G[.][b] * alpha*g_end. */
 template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
   const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(c.kc);
-  const uint8_t *G = c.kc + kh->off_g;
-  const uint8_t *b12 = c.kc + kh->off_b12;
-  const uint16_t *pivof = c.template arr<uint16_t>(c.h->off_pivof);
-  const uint32_t n = kh->n, H = c.h->H;
+  const NRQ_GAS uint8_t *G = gptr<uint8_t>(c.kc + kh->off_g);
+  const NRQ_GAS uint8_t *b12 = gptr<uint8_t>(c.kc + kh->off_b12);
+  const NRQ_GAS uint16_t *pivof = c.template arr<uint16_t>(c.h->off_pivof);
+  const uint32_t n = kh->n, H = c.h->H, S = c.h->S;
   uint32_t len = (n + nt - 1) / nt;
   len = (len + 7u) & ~7u;
   const uint32_t a = tid * len;
   if (a >= n) return;
   const uint32_t b = (a + len < n) ? a + len : n;
-  SV<WB> acc[16];
-#pragma unroll
-  for (int q = 0; q < 16; q++) acc[q] = sv_zero<WB>();
   SV<WB> g = sv_zero<WB>();
-  for (uint32_t col = a; col < b; col++) {
-    uint32_t s = pivof[col];
-    g = sv_xtime<WB>(g);
-    if (s != NRQ_NOSLOT) {
-      SV<WB> y = lds_get<WB>(c.slots(), s);
-      sv_xor<WB>(g, y);
-    }
-    if (col + 1 < n) {
-      uint32_t bb = b12[col], b1 = bb & 15u, b2 = bb >> 4;
+  /* 8 columns per step: their slot indices and MT rows come in two vector loads (the arrays are
+   * 16-byte aligned and padded, a is a multiple of 8) */
+  for (uint32_t c0 = a; c0 < b; c0 += 8) {
+    const uint4 sl = *reinterpret_cast<const NRQ_GAS uint4 *>(pivof + c0);
+    const uint2 bb = *reinterpret_cast<const NRQ_GAS uint2 *>(b12 + c0);
+    const uint32_t slw[4] = {sl.x, sl.y, sl.z, sl.w};
+    const uint32_t bbw[2] = {bb.x, bb.y};
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        uint32_t m = ((uint32_t)q == b1 || (uint32_t)q == b2) ? 0xFFFFFFFFu : 0u;
-        sv_xor_masked<WB>(acc[q], g, m);
+    for (uint32_t q = 0; q < 8; q++) {
+      const uint32_t col = c0 + q;
+      if (col >= b) break;
+      const uint32_t s = (slw[q >> 1] >> ((q & 1u) * 16u)) & 0xFFFFu;
+      g = sv_xtime<WB>(g);
+      if (s != NRQ_NOSLOT) {
+        SV<WB> y = lds_get<WB>(c.slots(), s);
+        sv_xor<WB>(g, y);
       }
-    } else { /* last column of MT is alpha^h */
-      SV<WB> v = g;
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        if ((uint32_t)q < H) sv_xor<WB>(acc[q], v);
-        v = sv_xtime<WB>(v);
+      if (col + 1 < n) {
+        const uint32_t e = (bbw[q >> 2] >> ((q & 3u) * 8u)) & 0xFFu;
+        lds_xor<WB>(c.slots(), S + (e & 15u), g);
+        lds_xor<WB>(c.slots(), S + (e >> 4), g);
+      } else { /* last column of MT is alpha^h */
+        SV<WB> v = g;
+        for (uint32_t h = 0; h < H; h++) {
+          lds_xor<WB>(c.slots(), S + h, v);
+          v = sv_xtime<WB>(v);
+        }
       }
     }
   }
   if (b < n) {
     SV<WB> carry = sv_xtime<WB>(g);
-#pragma unroll
-    for (int q = 0; q < 16; q++)
-      if ((uint32_t)q < H) {
-        SV<WB> t = sv_mul<WB>(carry, G[(size_t)q * n + b]);
-        sv_xor<WB>(acc[q], t);
-      }
-  }
-#pragma unroll
-  for (int q = 0; q < 16; q++)
-    if ((uint32_t)q < H) lds_xor<WB>(c.slots(), c.h->S + q, acc[q]);
-}
-
-/* phase 4a: E_p = GF(2) combination of leftover rows; also clears the free-column accumulators */
-template <int WB> SB_HD void ph_dense_bin(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  const uint32_t *g2 = c.template arr<uint32_t>(c.h->off_g2);
-  const uint32_t lpr = c.h->lpr;
-  for (uint32_t p = tid; p < c.h->r2; p += nt) {
-    SV<WB> acc = sv_zero<WB>();
-    for (uint32_t wj = 0; wj < lpr; wj++) {
-      uint32_t bits = g2[(size_t)p * lpr + wj];
-      while (bits) {
-        uint32_t j = wj * 32u + (uint32_t)__builtin_ctz(bits);
-        bits &= bits - 1u;
-        SV<WB> v = lds_get<WB>(c.slots(), c.low()[j]);
-        sv_xor<WB>(acc, v);
-      }
+    for (uint32_t h = 0; h < H; h++) {
+      SV<WB> t = sv_mul<WB>(carry, G[(size_t)h * n + b]);
+      lds_xor<WB>(c.slots(), S + h, t);
     }
-    lds_put<WB>(c.ebuf(), p, acc);
   }
-  for (uint32_t f = tid; f < NRQ_MAX_FREE; f += nt) lds_put<WB>(c.cf(), f, sv_zero<WB>());
 }
 
 /* phase 4b: fold the columns resolved by binary rows out of the HDPC rows: R_h ^= mh[h][p]*E_p */
 template <int WB> SB_HD void ph_dense_fold(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  const uint8_t *mh = c.plan + c.h->off_mh;
-  const uint32_t H = c.h->H, r2 = c.h->r2;
+  const NRQ_GAS uint8_t *mh = c.template arr<uint8_t>(c.h->off_mh);
+  const uint32_t H = c.h->H, r2 = c.h->r2, M = c.h->M;
   const uint32_t hq = tid & 15u, part = tid >> 4, nparts = nt >> 4;
   if (hq >= H) return;
   SV<WB> acc = sv_zero<WB>();
   for (uint32_t p = part; p < r2; p += nparts) {
     uint32_t coef = mh[(size_t)hq * r2 + p];
     if (!coef) continue;
-    SV<WB> t = sv_mul<WB>(lds_get<WB>(c.ebuf(), p), coef);
+    SV<WB> t = sv_mul<WB>(lds_get<WB>(c.slots(), M + p), coef);
     sv_xor<WB>(acc, t);
   }
   lds_xor<WB>(c.slots(), c.h->S + hq, acc);
@@ -356,7 +355,7 @@ template <int WB> SB_HD void ph_dense_fold(const StripCtx<WB> &c, uint32_t tid, 
 
 /* phase 4c: free columns C_f = SUM_h hinv[f][h] * R_h */
 template <int WB> SB_HD void ph_dense_free(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  const uint8_t *hinv = c.plan + c.h->off_hinv;
+  const NRQ_GAS uint8_t *hinv = c.template arr<uint8_t>(c.h->off_hinv);
   const uint32_t H = c.h->H, nfree = c.h->nfree;
   const uint32_t hq = tid & 15u;
   if (hq >= H) return;
@@ -370,11 +369,11 @@ template <int WB> SB_HD void ph_dense_free(const StripCtx<WB> &c, uint32_t tid, 
 
 /* phase 4d: values of all u inactive columns */
 template <int WB> SB_HD void ph_dense_cu(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  const uint16_t *pivx = c.template arr<uint16_t>(c.h->off_pivx);
-  const uint32_t *fbits = c.template arr<uint32_t>(c.h->off_fbits);
-  const uint16_t *freex = c.template arr<uint16_t>(c.h->off_freex);
+  const NRQ_GAS uint16_t *pivx = c.template arr<uint16_t>(c.h->off_pivx);
+  const NRQ_GAS uint32_t *fbits = c.template arr<uint32_t>(c.h->off_fbits);
+  const NRQ_GAS uint16_t *freex = c.template arr<uint16_t>(c.h->off_freex);
   for (uint32_t p = tid; p < c.h->r2; p += nt) {
-    SV<WB> v = lds_get<WB>(c.ebuf(), p);
+    SV<WB> v = lds_get<WB>(c.slots(), c.h->M + p);
     uint32_t fb = fbits[p];
     while (fb) {
       uint32_t f = (uint32_t)__builtin_ctz(fb);
@@ -405,52 +404,114 @@ template <int WB> SB_HD void ph_tables(const StripCtx<WB> &c, uint32_t tid, uint
   }
 }
 
-/* phase 5b: back substitution C(pivot k) = Y_k ^ W_k * C_u */
-template <int WB> SB_HD void ph_backsub(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  const uint16_t *pivslot = c.template arr<uint16_t>(c.h->off_pivslot);
-  const uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
-  const uint32_t wpr = c.h->wpr, stride = c.h->npiv_pad;
-  for (uint32_t k = tid; k < c.h->npiv; k += nt) {
-    uint32_t s = pivslot[k];
-    SV<WB> acc = lds_get<WB>(c.slots(), s);
-    for (uint32_t w = 0; w < wpr; w++) {
-      uint32_t bits = wt[(size_t)w * stride + k];
+/* phase 5b: back substitution C(pivot k) = Y_k ^ W_k * C_u.  Two pivots per trip with separate
+ * register sets: the W words of the second are in flight while the first does its table lookups
+ * (no register hand-over between trips, so the compiler can leave the loads outstanding). */
+template <int WB, int NW>
+SB_HD void backsub_one(const StripCtx<WB> &c, const uint8_t *t4, uint32_t slot, const uint32_t (&bitsw)[NW],
+                       uint32_t wpr) {
+  SV<WB> acc = lds_get<WB>(c.slots(), slot);
 #pragma unroll
-      for (uint32_t q = 0; q < 8; q++) {
-        uint32_t nib = (bits >> (4u * q)) & 15u;
-        SV<WB> t = lds_get<WB>(c.t4(), (w * 8u + q) * 16u + nib);
-        sv_xor<WB>(acc, t);
-      }
+  for (uint32_t w = 0; w < (uint32_t)NW; w++) {
+    if (w >= wpr) break; /* tables exist for wpr*8 groups only */
+    const uint32_t bits = bitsw[w];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+      const uint32_t nib = (bits >> (4u * q)) & 15u;
+      SV<WB> t = lds_get<WB>(t4, (w * 8u + q) * 16u + nib);
+      sv_xor<WB>(acc, t);
     }
-    lds_put<WB>(c.slots(), s, acc);
+  }
+  lds_put<WB>(c.slots(), slot, acc);
+}
+
+template <int WB, int NW> SB_HD void backsub_fixed(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const NRQ_GAS uint16_t *pivslot = c.template arr<uint16_t>(c.h->off_pivslot);
+  const NRQ_GAS uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
+  const uint32_t wpr = c.h->wpr, stride = c.h->npiv_pad, npiv = c.h->npiv;
+  const uint8_t *t4 = c.t4();
+  for (uint32_t k = tid; k < npiv; k += 2 * nt) {
+    const uint32_t k2 = k + nt;
+    uint32_t a[NW], b[NW];
+    const uint32_t sa = pivslot[k];
+    const uint32_t sb = k2 < npiv ? pivslot[k2] : 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)NW; w++) a[w] = w < wpr ? wt[(size_t)w * stride + k] : 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)NW; w++) b[w] = (w < wpr && k2 < npiv) ? wt[(size_t)w * stride + k2] : 0u;
+    backsub_one<WB, NW>(c, t4, sa, a, wpr);
+    if (k2 < npiv) backsub_one<WB, NW>(c, t4, sb, b, wpr);
+  }
+}
+
+template <int WB> SB_HD void ph_backsub(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint32_t wpr = c.h->wpr;
+  if (wpr <= 4) backsub_fixed<WB, 4>(c, tid, nt);
+  else if (wpr <= 8) backsub_fixed<WB, 8>(c, tid, nt);
+  else if (wpr <= 12) backsub_fixed<WB, 12>(c, tid, nt);
+  else if (wpr <= 24) backsub_fixed<WB, 24>(c, tid, nt);
+  else {
+    const NRQ_GAS uint16_t *pivslot = c.template arr<uint16_t>(c.h->off_pivslot);
+    const NRQ_GAS uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
+    const uint32_t stride = c.h->npiv_pad, npiv = c.h->npiv;
+    const uint8_t *t4 = c.t4();
+    for (uint32_t k = tid; k < npiv; k += nt) {
+      uint32_t s = pivslot[k];
+      SV<WB> acc = lds_get<WB>(c.slots(), s);
+      for (uint32_t w = 0; w < wpr; w++) {
+        uint32_t bits = wt[(size_t)w * stride + k];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+          uint32_t nib = (bits >> (4u * q)) & 15u;
+          SV<WB> t = lds_get<WB>(t4, (w * 8u + q) * 16u + nib);
+          sv_xor<WB>(acc, t);
+        }
+      }
+      lds_put<WB>(c.slots(), s, acc);
+    }
   }
 }
 
 /* phase 6a: park the inactive columns in the slots the plan reserved for them */
 template <int WB> SB_HD void ph_park(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  const uint16_t *uslot = c.template arr<uint16_t>(c.h->off_uslot);
+  const NRQ_GAS uint16_t *uslot = c.template arr<uint16_t>(c.h->off_uslot);
   for (uint32_t x = tid; x < c.h->u; x += nt) lds_put<WB>(c.slots(), uslot[x], lds_get<WB>(c.cu(), x));
 }
 
 /* phase 6b: results to HBM: intermediate symbols (optional) and generated symbols */
 template <int WB> SB_HD void ph_store(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  const uint16_t *colslot = c.template arr<uint16_t>(c.h->off_colslot);
+  constexpr int STB = 8;
+  const NRQ_GAS uint16_t *colslot = c.template arr<uint16_t>(c.h->off_colslot);
   const size_t boff = (size_t)c.strip * WB;
-  uint8_t *inter = reinterpret_cast<uint8_t *>(c.job.inter);
-  if (inter)
-    for (uint32_t col = tid; col < c.h->L; col += nt)
-      g_put<WB>(inter + (size_t)col * c.T + boff, c.valid, lds_get<WB>(c.slots(), colslot[col]));
-  const uint32_t *cptr = reinterpret_cast<const uint32_t *>(c.job.out_cptr);
-  const uint16_t *cols = reinterpret_cast<const uint16_t *>(c.job.out_cols);
-  const uint32_t *orow = reinterpret_cast<const uint32_t *>(c.job.out_row);
-  uint8_t *out = reinterpret_cast<uint8_t *>(c.job.out);
+  NRQ_GAS uint8_t *inter = gptr_w<uint8_t>(c.job.inter);
+  const uint32_t L = c.h->L;
+  if (inter) {
+    for (uint32_t base = tid; base < L; base += STB * nt) {
+      uint32_t sl[STB];
+#pragma unroll
+      for (int q = 0; q < STB; q++) {
+        uint32_t col = base + (uint32_t)q * nt;
+        sl[q] = col < L ? colslot[col] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < STB; q++) {
+        uint32_t col = base + (uint32_t)q * nt;
+        if (col < L) g_put<WB>(inter + (size_t)col * c.T + boff, c.valid, lds_get<WB>(c.slots(), sl[q]));
+      }
+    }
+  }
+  const NRQ_GAS uint32_t *cptr = gptr<uint32_t>(c.job.out_cptr);
+  const NRQ_GAS uint16_t *osl = gptr<uint16_t>(c.job.out_slots);
+  const NRQ_GAS uint32_t *orow = gptr<uint32_t>(c.job.out_row);
+  NRQ_GAS uint8_t *out = gptr_w<uint8_t>(c.job.out);
   for (uint32_t q = tid; q < c.job.nout; q += nt) {
     SV<WB> acc = sv_zero<WB>();
-    for (uint32_t e = cptr[q]; e < cptr[q + 1]; e++) {
-      SV<WB> t = lds_get<WB>(c.slots(), colslot[cols[e]]);
+    const uint32_t e0 = cptr[q], e1 = cptr[q + 1], row = orow[q];
+    for (uint32_t e = e0; e < e1; e++) {
+      SV<WB> t = lds_get<WB>(c.slots(), osl[e]);
       sv_xor<WB>(acc, t);
     }
-    g_put<WB>(out + (size_t)orow[q] * c.T + boff, c.valid, acc);
+    g_put<WB>(out + (size_t)row * c.T + boff, c.valid, acc);
   }
 }
 

@@ -25,19 +25,20 @@ static void fma_row(uint8_t *d, const uint8_t *s, size_t n, uint8_t b) {
     if (s[k]) d[k] ^= E_[L_[b] + L_[s[k]]];
 }
 
-/* D: M x T (pitch T) with the received/source symbols already placed in their rows, zero
+/* Din: M x T (pitch T) with the received/source symbols already placed in their rows, zero
  * elsewhere.  C out: L x T.  returns 1 ok, 0 if the plan is marked singular, <0 on a bad plan. */
-int orc_plan_exec(const uint8_t *plan, uint8_t *D, uint32_t T, uint8_t *C) {
+int orc_plan_exec(const uint8_t *plan, uint8_t *Din, uint32_t T, uint8_t *C) {
   const nrq_plan_hdr *h = (const nrq_plan_hdr *)plan;
   if (h->magic != NRQ_PLAN_MAGIC) return -1;
   if (h->status) return 0;
   orc_gf_tables(E_, L_, I_);
+  /* work matrix: the M slots plus the r2 scratch rows E_p the op stream accumulates into */
+  uint8_t *D = (uint8_t *)calloc((size_t)(h->M + h->r2 + 1) * T, 1);
+  memcpy(D, Din, (size_t)h->M * T);
   const uint32_t *ops = (const uint32_t *)(plan + h->off_ops);
   const uint16_t *pivslot = (const uint16_t *)(plan + h->off_pivslot);
   const uint16_t *pivcol = (const uint16_t *)(plan + h->off_pivcol);
   const uint32_t *wt = (const uint32_t *)(plan + h->off_wt);
-  const uint16_t *lowslot = (const uint16_t *)(plan + h->off_lowslot);
-  const uint32_t *g2 = (const uint32_t *)(plan + h->off_g2);
   const uint16_t *pivx = (const uint16_t *)(plan + h->off_pivx);
   const uint32_t *fbits = (const uint32_t *)(plan + h->off_fbits);
   const uint8_t *mh = plan + h->off_mh;
@@ -59,11 +60,8 @@ int orc_plan_exec(const uint8_t *plan, uint8_t *D, uint32_t T, uint8_t *C) {
   for (uint32_t k = 0; k < h->npiv; k++)
     for (uint32_t q = 0; q < H; q++) fma_row(ROW(h->S + q), ROW(pivslot[k]), T, G[(size_t)q * n_hd + pivcol[k]]);
   free(G);
-  /* 4: binary combination of the leftover rows */
-  uint8_t *E = (uint8_t *)calloc((size_t)(h->r2 ? h->r2 : 1) * T, 1);
-  for (uint32_t p = 0; p < h->r2; p++)
-    for (uint32_t j = 0; j < h->nlow; j++)
-      if ((g2[(size_t)p * h->lpr + (j >> 5)] >> (j & 31)) & 1u) xor_row(E + (size_t)p * T, ROW(lowslot[j]), T);
+  /* 4: the binary combinations E_p were accumulated by the op stream into rows M+p */
+  uint8_t *E = D + (size_t)h->M * T;
   /* 5: fold the resolved columns out of the HDPC rows */
   for (uint32_t q = 0; q < H; q++)
     for (uint32_t p = 0; p < h->r2; p++) fma_row(ROW(h->S + q), E + (size_t)p * T, T, mh[(size_t)q * h->r2 + p]);
@@ -85,7 +83,7 @@ int orc_plan_exec(const uint8_t *plan, uint8_t *D, uint32_t T, uint8_t *C) {
   /* 9+10: homes, gather */
   for (uint32_t x = 0; x < h->u; x++) memcpy(ROW(uslot[x]), Cu + (size_t)x * T, T);
   for (uint32_t c = 0; c < h->L; c++) memcpy(C + (size_t)c * T, ROW(colslot[c]), T);
-  free(E); free(Cu);
+  free(Cu); free(D);
 #undef ROW
   return 1;
 }

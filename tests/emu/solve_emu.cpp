@@ -37,7 +37,6 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
   for (uint32_t ch = 0; ch < nch; ch++)
     for (uint32_t t = 0; t < NT; t++) ph_op<WB>(c, ops[(size_t)ch * NT + t]);
   PHASE(ph_hdpc);
-  PHASE(ph_dense_bin);
   PHASE(ph_dense_fold);
   PHASE(ph_dense_free);
   PHASE(ph_dense_cu);

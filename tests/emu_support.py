@@ -10,7 +10,7 @@ from nanorq_amd import build as nbuild
 
 class Job(C.Structure):
     _fields_ = [("plan", C.c_uint64), ("rowsrc", C.c_uint64), ("src", C.c_uint64), ("rep", C.c_uint64),
-                ("inter", C.c_uint64), ("out", C.c_uint64), ("out_cptr", C.c_uint64), ("out_cols", C.c_uint64),
+                ("inter", C.c_uint64), ("out", C.c_uint64), ("out_cptr", C.c_uint64), ("out_slots", C.c_uint64),
                 ("out_row", C.c_uint64), ("nout", C.c_uint32), ("pad", C.c_uint32)]
 
 
@@ -48,11 +48,14 @@ def decode_setup(orc, K, lost, rep_esis):
     return np.array(isis, np.uint32), rowsrc
 
 
-def lt_lists(orc, K, isis):
+def lt_lists(orc, K, isis, plan):
+    """LT neighbour lists translated to slots through the plan's colslot[] (what ph_store reads)."""
+    hdr = nanorq_amd.plan_header(plan)
+    colslot = np.frombuffer(plan, np.uint16, count=hdr["L"], offset=hdr["off_colslot"])
     cptr = [0]
     cols = []
     for x in isis:
-        cols += orc.lt_columns(K, int(x))
+        cols += [int(colslot[c]) for c in orc.lt_columns(K, int(x))]
         cptr.append(len(cols))
     return np.array(cptr, np.uint32), np.array(cols if cols else [0], np.uint16)
 
@@ -74,7 +77,7 @@ def emu_solve(plan, kconst, rowsrc, src, rep, T, L, out_isis_lists, out_rows, ou
     j.inter = inter.ctypes.data
     j.out = out_buf.ctypes.data
     j.out_cptr = cptr.ctypes.data
-    j.out_cols = cols.ctypes.data
+    j.out_slots = cols.ctypes.data
     j.out_row = out_rows.ctypes.data if len(out_rows) else 0
     j.nout = len(out_rows)
     r = L_.emu_solve(C.byref(j), T, wb, C.addressof(kcb))

@@ -24,7 +24,7 @@ def _encode_case(orc, K, T, wb, nrep=7):
     rowsrc = np.full(p["L"], ROW_ZERO, np.uint32)
     rowsrc[p["S"] + p["H"]: p["S"] + p["H"] + K] = np.arange(K, dtype=np.uint32)
     esis = np.arange(K, K + nrep, dtype=np.uint32)
-    lists = lt_lists(orc, K, esis + (p["Kp"] - K))
+    lists = lt_lists(orc, K, esis + (p["Kp"] - K), plan)
     out = np.zeros((nrep, T), np.uint8)
     r, inter = emu_solve(plan, kc, rowsrc, src, None, T, p["L"], lists, np.arange(nrep), out, wb)
     ref_rep, ref_inter, _ = orc.encode_block(src, K, T, esis, want_inter=True)
@@ -62,7 +62,7 @@ def test_decode_emulated_matches_oracle(orc, K, T, wb, p, oh):
             continue
         work = src.copy()
         work[lost] = 0xEE  # missing rows hold garbage
-        lists = lt_lists(orc, K, lost)
+        lists = lt_lists(orc, K, lost, plan)
         r, inter = emu_solve(plan, kc, rowsrc, work, rep, T, prm["L"], lists, lost, work, wb)
         assert r == 1
         assert np.array_equal(work, src)
