@@ -53,9 +53,13 @@ int nrq_ctx_set_threads(nrq_ctx *ctx, int n);
 /* Parameters of RFC 6330 section 5.3.1.2 for K source symbols: out = {K',J,S,H,W,L,P,P1,U,B}. */
 int nrq_params(uint32_t K, uint32_t out[10]);
 
-/* Build (or fetch the cached) plan for encoding blocks of K symbols: the counterpart of
+/* In every call below K is the number of source symbols of a block and Kp the RFC 6330 Table 2 row (K')
+ * it is coded with: 0 = the row the RFC assigns to K; nanorq passes block 0's K' for every block of an
+ * object (lib/nanorq.c:289, :372), which can exceed a short block's own row.
+ *
+ * Build (or fetch the cached) plan for encoding blocks of K symbols: the counterpart of
  * nanorq_precalculate (lib/nanorq.c:393-401).  Implied by nrq_encode_blocks. */
-int nrq_precalculate(nrq_ctx *ctx, uint32_t K);
+int nrq_precalculate(nrq_ctx *ctx, uint32_t K, uint32_t Kp);
 /* drop cached encode plans (so that a benchmark can time plan generation) */
 void nrq_plan_cache_clear(nrq_ctx *ctx);
 
@@ -65,7 +69,7 @@ void nrq_plan_cache_clear(nrq_ctx *ctx);
  *   h_esis   host: nrep repair ESIs (each K <= esi < 2^24), the same list for every block
  *   d_rep    device: block b's repair symbol q at d_rep + b*rep_stride + q*T
  * Bit-exact with nanorq_generate_symbols + nanorq_encode(esi) of the reference. */
-int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,
+int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,
                       void *d_inter, size_t inter_stride, uint32_t nrep, const uint32_t *h_esis, void *d_rep,
                       size_t rep_stride);
 
@@ -80,7 +84,7 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const
  *            rank deficient: the caller may add symbols and retry, as with nanorq_repair_block)
  * The i-th missing ESI takes the i-th repair symbol, surplus symbols become extra constraint rows
  * (lib/nanorq.c:527-565). */
-int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
                       const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
                       const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
                       size_t inter_stride, int *h_status);
@@ -88,7 +92,7 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void 
 /* Generate encoding symbols from intermediate symbols already in HBM (after encode/decode with
  * d_inter != NULL): symbol q of block b = LT(C_b, isi[q]) -> d_out + b*out_stride + q*T.
  * h_isi are INTERNAL symbol ids (esi for esi < K, esi + K' - K for repair symbols). */
-int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,
+int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,
                     uint32_t n, const uint32_t *h_isi, void *d_out, size_t out_stride);
 
 /* Raw device memory helpers for hosts without a HIP binding of their own (the drop-in C library and

@@ -47,13 +47,13 @@ def lib():
     L.nrq_ctx_last_stats.restype = None
     L.nrq_ctx_set_threads.argtypes = [vp, C.c_int]
     L.nrq_params.argtypes = [C.c_uint32, u32p]
-    L.nrq_precalculate.argtypes = [vp, C.c_uint32]
+    L.nrq_precalculate.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.nrq_plan_cache_clear.argtypes = [vp]
     L.nrq_plan_cache_clear.restype = None
-    L.nrq_encode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, vp, sz, C.c_uint32, u32p, vp, sz]
-    L.nrq_decode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, u32p, u32p, C.c_uint32, u32p,
+    L.nrq_encode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, vp, sz, C.c_uint32, u32p, vp, sz]
+    L.nrq_decode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, u32p, u32p, C.c_uint32, u32p,
                                     u32p, C.c_uint32, vp, sz, vp, sz, ip]
-    L.nrq_gen_symbols.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, C.c_uint32, u32p, vp, sz]
+    L.nrq_gen_symbols.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, C.c_uint32, u32p, vp, sz]
     L.nrq_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.nrq_dev_free.argtypes = [vp, vp]
     L.nrq_dev_upload.argtypes = [vp, vp, vp, sz]
@@ -161,8 +161,8 @@ class Context:
         self._L.nrq_ctx_last_stats(self._h, C.byref(s))
         return s.as_dict()
 
-    def precalculate(self, K):
-        self._chk(self._L.nrq_precalculate(self._h, K))
+    def precalculate(self, K, Kp=0):
+        self._chk(self._L.nrq_precalculate(self._h, K, Kp))
 
     def clear_plan_cache(self):
         self._L.nrq_plan_cache_clear(self._h)
@@ -189,29 +189,29 @@ class Context:
         self._chk(self._L.nrq_dev_memset(self._h, C.c_void_p(dptr), value, nbytes))
 
     # -- hot path ----------------------------------------------------------------------------
-    def encode_blocks(self, K, T, nblk, d_src, src_stride, d_rep, rep_stride, esis, d_inter=0, inter_stride=0):
+    def encode_blocks(self, K, T, nblk, d_src, src_stride, d_rep, rep_stride, esis, d_inter=0, inter_stride=0, Kp=0):
         esis = np.ascontiguousarray(esis, dtype=np.uint32)
-        self._chk(self._L.nrq_encode_blocks(self._h, K, T, nblk, C.c_void_p(d_src), src_stride,
+        self._chk(self._L.nrq_encode_blocks(self._h, K, Kp, T, nblk, C.c_void_p(d_src), src_stride,
                                             C.c_void_p(d_inter or 0), inter_stride, len(esis),
                                             _u32(esis) if len(esis) else None, C.c_void_p(d_rep or 0), rep_stride))
 
     def decode_blocks(self, K, T, nblk, d_src, src_stride, lost, nlost, rep_esi, nrep, d_rep, rep_stride,
-                      d_inter=0, inter_stride=0):
+                      d_inter=0, inter_stride=0, Kp=0):
         """lost: [nblk, lost_cap] uint32, rep_esi: [nblk, rep_cap] uint32. Returns status int array."""
         lost = np.ascontiguousarray(lost, dtype=np.uint32).reshape(nblk, -1)
         rep_esi = np.ascontiguousarray(rep_esi, dtype=np.uint32).reshape(nblk, -1)
         nlost = np.ascontiguousarray(nlost, dtype=np.uint32)
         nrep = np.ascontiguousarray(nrep, dtype=np.uint32)
         status = np.zeros(nblk, dtype=np.int32)
-        self._chk(self._L.nrq_decode_blocks(self._h, K, T, nblk, C.c_void_p(d_src), src_stride, _u32(lost),
+        self._chk(self._L.nrq_decode_blocks(self._h, K, Kp, T, nblk, C.c_void_p(d_src), src_stride, _u32(lost),
                                             _u32(nlost), lost.shape[1], _u32(rep_esi), _u32(nrep), rep_esi.shape[1],
                                             C.c_void_p(d_rep or 0), rep_stride, C.c_void_p(d_inter or 0),
                                             inter_stride, status.ctypes.data_as(C.POINTER(C.c_int))))
         return status
 
-    def gen_symbols(self, K, T, nblk, d_inter, inter_stride, isis, d_out, out_stride):
+    def gen_symbols(self, K, T, nblk, d_inter, inter_stride, isis, d_out, out_stride, Kp=0):
         isis = np.ascontiguousarray(isis, dtype=np.uint32)
-        self._chk(self._L.nrq_gen_symbols(self._h, K, T, nblk, C.c_void_p(d_inter), inter_stride, len(isis),
+        self._chk(self._L.nrq_gen_symbols(self._h, K, Kp, T, nblk, C.c_void_p(d_inter), inter_stride, len(isis),
                                           _u32(isis), C.c_void_p(d_out), out_stride))
 
     def ktime_enable(self, on=True):

@@ -218,7 +218,7 @@ struct nrq_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   std::map<uint32_t, KConst> kconst;    /* by K' */
-  std::map<uint32_t, EncPlan> encplans; /* by K */
+  std::map<uint64_t, EncPlan> encplans; /* by (K', K) */
   DevBuf scratch[2];                    /* per-call device arrays (double-buffered across calls) */
   PinBuf staging[2];
   hipEvent_t staged[2] = {nullptr, nullptr};
@@ -272,6 +272,16 @@ int ensure_pin(nrq_ctx *ctx, PinBuf &b, size_t bytes) {
   return 0;
 }
 
+/* parameters for a block of K symbols coded with the table row K' = Kp (0: the row RFC 6330 assigns to
+ * K).  nanorq codes every block of an object with block 0's row (lib/nanorq.c:289, :372), so a short
+ * last block can carry a K' larger than its own. */
+int block_params(nrq_ctx *ctx, uint32_t K, uint32_t Kp, rq_params *p) {
+  if (!rq_params_init(Kp ? Kp : K, p)) return fail(ctx, -1, "K=%u K'=%u out of range", K, Kp);
+  if (K == 0 || K > p->Kp || (Kp && p->Kp != Kp)) return fail(ctx, -1, "K=%u does not fit table row K'=%u", K, Kp);
+  p->K = K;
+  return 0;
+}
+
 int get_kconst(nrq_ctx *ctx, uint32_t K, KConst **out) {
   rq_params p;
   if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
@@ -287,20 +297,22 @@ int get_kconst(nrq_ctx *ctx, uint32_t K, KConst **out) {
   return 0;
 }
 
-int get_encplan(nrq_ctx *ctx, uint32_t K, EncPlan **out) {
-  auto it = ctx->encplans.find(K);
-  if (it != ctx->encplans.end()) { *out = &it->second; return 0; }
+int get_encplan(nrq_ctx *ctx, uint32_t K, uint32_t Kp, EncPlan **out) {
   rq_params p;
-  if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
+  int rc = block_params(ctx, K, Kp, &p);
+  if (rc) return rc;
+  const uint64_t key = ((uint64_t)p.Kp << 32) | K;
+  auto it = ctx->encplans.find(key);
+  if (it != ctx->encplans.end()) { *out = &it->second; return 0; }
   KConst *kc;
-  int rc = get_kconst(ctx, K, &kc);
+  rc = get_kconst(ctx, p.Kp, &kc);
   if (rc) return rc;
   double t0 = now_ms();
   std::vector<uint32_t> isis(p.Kp);
   for (uint32_t j = 0; j < p.Kp; j++) isis[j] = j;
   uint8_t *arena = nullptr;
   uint32_t bytes = 0;
-  if (nrq_host_plan_build(K, p.Kp, isis.data(), kc->host, &arena, &bytes) != 0)
+  if (nrq_host_plan_build(p.Kp, p.Kp, isis.data(), kc->host, &arena, &bytes) != 0)
     return fail(ctx, -2, "encode plan build failed for K=%u", K);
   EncPlan ep;
   memcpy(&ep.hdr, arena, sizeof(ep.hdr));
@@ -317,7 +329,7 @@ int get_encplan(nrq_ctx *ctx, uint32_t K, EncPlan **out) {
   HIPCHK(ctx, hipMemcpy(ep.dev + ep.rowsrc_off, rowsrc.data(), (size_t)p.L * 4, hipMemcpyHostToDevice));
   nrq_host_free(arena);
   ep.build_ms = now_ms() - t0;
-  it = ctx->encplans.emplace(K, ep).first;
+  it = ctx->encplans.emplace(key, ep).first;
   *out = &it->second;
   return 0;
 }
@@ -512,14 +524,14 @@ int nrq_ctx_set_threads(nrq_ctx *ctx, int n) {
   return 0;
 }
 
-int nrq_precalculate(nrq_ctx *ctx, uint32_t K) {
+int nrq_precalculate(nrq_ctx *ctx, uint32_t K, uint32_t Kp) {
   if (!ctx) return -1;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   EncPlan *ep;
-  return get_encplan(ctx, K, &ep);
+  return get_encplan(ctx, K, Kp, &ep);
 }
 
-int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,
+int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,
                       void *d_inter, size_t inter_stride, uint32_t nrep, const uint32_t *h_esis, void *d_rep,
                       size_t rep_stride) {
   if (!ctx) return -1;
@@ -527,15 +539,16 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
   rq_params p;
-  if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
+  int rc = block_params(ctx, K, Kp, &p);
+  if (rc) return rc;
   for (uint32_t q = 0; q < nrep; q++)
     if (h_esis[q] < K || h_esis[q] >= (1u << 24)) return fail(ctx, -1, "repair ESI %u out of range", h_esis[q]);
   KConst *kc;
-  int rc = get_kconst(ctx, K, &kc);
+  rc = get_kconst(ctx, p.Kp, &kc);
   if (rc) return rc;
-  const bool cached = ctx->encplans.count(K) != 0;
+  const bool cached = ctx->encplans.count(((uint64_t)p.Kp << 32) | K) != 0;
   EncPlan *ep;
-  rc = get_encplan(ctx, K, &ep);
+  rc = get_encplan(ctx, K, p.Kp, &ep);
   if (rc) return rc;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->stats.plan_ms = cached ? 0.0 : ep->build_ms;
@@ -586,7 +599,7 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const
   return rc;
 }
 
-int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
                       const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
                       const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
                       size_t inter_stride, int *h_status) {
@@ -595,9 +608,10 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void 
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
   rq_params p;
-  if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
+  int rc = block_params(ctx, K, Kp, &p);
+  if (rc) return rc;
   KConst *kc;
-  int rc = get_kconst(ctx, K, &kc);
+  rc = get_kconst(ctx, p.Kp, &kc);
   if (rc) return rc;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
 
@@ -636,7 +650,7 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void 
       isis[p.Kp + e] = resi[nl + e] + pad;
       pr.rowsrc[p.L + e] = NRQ_ROW_REP | (nl + e);
     }
-    if (nrq_host_plan_build(K, p.Kp + overhead, isis.data(), kc->host, &pr.plan, &pr.plan_bytes) != 0) {
+    if (nrq_host_plan_build(p.Kp, p.Kp + overhead, isis.data(), kc->host, &pr.plan, &pr.plan_bytes) != 0) {
       pr.state = -1;
       return;
     }
@@ -741,17 +755,17 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, void 
   return result;
 }
 
-int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,
+int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,
                     uint32_t n, const uint32_t *h_isi, void *d_out, size_t out_stride) {
   if (!ctx) return -1;
   if (!d_inter || !d_out || !h_isi || T == 0 || nblk == 0) return fail(ctx, -1, "bad arguments");
   if (n == 0) return 0;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   rq_params p;
-  if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
+  int rc = block_params(ctx, K, Kp, &p);
+  if (rc) return rc;
   const int f = ctx->flip;
   ctx->flip ^= 1;
-  int rc;
   HIPCHK(ctx, hipEventSynchronize(ctx->staged[f]));
   if ((rc = ensure_pin(ctx, ctx->staging[f], (size_t)n * 4))) return rc;
   if ((rc = ensure_dev(ctx, ctx->scratch[f], (size_t)n * 4))) return rc;

@@ -1,0 +1,135 @@
+"""ctypes view of the drop-in C API (include/nanorq.h, include/io.h) for tests: the same calls the
+reference's encode.c / decode.c / benchmark.c make."""
+import ctypes as C
+
+import numpy as np
+
+import nanorq_amd
+
+SYM_DUP, SYM_IGN, SYM_ADDED, SYM_ERR = 2, 1, 0, -1
+
+
+class IoCtx(C.Structure):
+    pass
+
+
+IoCtx._fields_ = [("read", C.CFUNCTYPE(C.c_size_t, C.POINTER(IoCtx), C.POINTER(C.c_uint8), C.c_size_t)),
+                  ("write", C.CFUNCTYPE(C.c_size_t, C.POINTER(IoCtx), C.POINTER(C.c_uint8), C.c_size_t)),
+                  ("seek", C.CFUNCTYPE(C.c_bool, C.POINTER(IoCtx), C.c_size_t)),
+                  ("size", C.CFUNCTYPE(C.c_size_t, C.POINTER(IoCtx))),
+                  ("tell", C.CFUNCTYPE(C.c_long, C.POINTER(IoCtx))),
+                  ("destroy", C.CFUNCTYPE(None, C.POINTER(IoCtx))),
+                  ("seekable", C.c_bool), ("writable", C.c_bool)]
+
+_L = None
+
+
+def api():
+    global _L
+    if _L is None:
+        L = nanorq_amd.lib()
+        vp, iop = C.c_void_p, C.POINTER(IoCtx)
+        L.nanorq_encoder_new.restype = vp
+        L.nanorq_encoder_new.argtypes = [C.c_size_t, C.c_uint16, C.c_uint8]
+        L.nanorq_encoder_new_ex.restype = vp
+        L.nanorq_encoder_new_ex.argtypes = [C.c_size_t, C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint8]
+        L.nanorq_decoder_new.restype = vp
+        L.nanorq_decoder_new.argtypes = [C.c_uint64, C.c_uint32]
+        L.nanorq_free.argtypes = [vp]
+        L.nanorq_free.restype = None
+        L.nanorq_oti_common.restype = C.c_uint64
+        L.nanorq_oti_common.argtypes = [vp]
+        L.nanorq_oti_scheme_specific.restype = C.c_uint32
+        L.nanorq_oti_scheme_specific.argtypes = [vp]
+        for f in ("nanorq_transfer_length", "nanorq_symbol_size", "nanorq_blocks", "nanorq_max_blocks"):
+            getattr(L, f).restype = C.c_size_t
+            getattr(L, f).argtypes = [vp]
+        L.nanorq_block_symbols.restype = C.c_size_t
+        L.nanorq_block_symbols.argtypes = [vp, C.c_uint8]
+        L.nanorq_tag.restype = C.c_uint32
+        L.nanorq_tag.argtypes = [C.c_uint8, C.c_uint32]
+        L.nanorq_precalculate.restype = C.c_bool
+        L.nanorq_precalculate.argtypes = [vp]
+        L.nanorq_generate_symbols.restype = C.c_bool
+        L.nanorq_generate_symbols.argtypes = [vp, C.c_uint8, iop]
+        L.nanorq_encode.restype = C.c_size_t
+        L.nanorq_encode.argtypes = [vp, vp, C.c_uint32, C.c_uint8, iop]
+        L.nanorq_encoder_cleanup.argtypes = [vp, C.c_uint8]
+        L.nanorq_encoder_cleanup.restype = None
+        L.nanorq_encoder_reset.argtypes = [vp, C.c_uint8]
+        L.nanorq_encoder_reset.restype = None
+        L.nanorq_set_max_esi.restype = C.c_bool
+        L.nanorq_set_max_esi.argtypes = [vp, C.c_uint32]
+        L.nanorq_decoder_add_symbol.restype = C.c_int
+        L.nanorq_decoder_add_symbol.argtypes = [vp, vp, C.c_uint32, iop]
+        L.nanorq_num_missing.restype = C.c_size_t
+        L.nanorq_num_missing.argtypes = [vp, C.c_uint8]
+        L.nanorq_num_repair.restype = C.c_size_t
+        L.nanorq_num_repair.argtypes = [vp, C.c_uint8]
+        L.nanorq_repair_block.restype = C.c_bool
+        L.nanorq_repair_block.argtypes = [vp, iop, C.c_uint8]
+        L.ioctx_from_mem.restype = iop
+        L.ioctx_from_mem.argtypes = [vp, C.c_size_t]
+        L.ioctx_from_file.restype = iop
+        L.ioctx_from_file.argtypes = [C.c_char_p, C.c_int]
+        L.ioctx_mmap_file.restype = iop
+        L.ioctx_mmap_file.argtypes = [C.c_char_p, C.c_int]
+        _L = L
+    return _L
+
+
+def mem_io(arr):
+    return api().ioctx_from_mem(arr.ctypes.data_as(C.c_void_p), arr.nbytes)
+
+
+def encode_object(data, T, K=0, Z=0, Al=8, loss=0.06, overhead=0, seed=1, precalc=False):
+    """The shape of reference benchmark.c:52-116 / encode.c: returns (oti_common, oti_scheme, packets)
+    where packets = [(tag, bytes)], each source ESI dropped with probability `loss` and replaced by a
+    repair symbol, plus `overhead` extra repair symbols per block."""
+    L = api()
+    data = np.ascontiguousarray(data, np.uint8)
+    rq = L.nanorq_encoder_new_ex(data.nbytes, T, K, Z, Al)
+    assert rq, "encoder_new_ex failed"
+    io = mem_io(data)
+    if precalc:
+        assert L.nanorq_precalculate(rq)
+    rng = np.random.default_rng(seed)
+    Tsz = L.nanorq_symbol_size(rq)
+    packets = []
+    buf = (C.c_uint8 * Tsz)()
+    for sbn in range(L.nanorq_blocks(rq)):
+        assert L.nanorq_generate_symbols(rq, sbn, io)
+        nk = L.nanorq_block_symbols(rq, sbn)
+        dropped = 0
+        for esi in range(nk):
+            if rng.random() < loss:
+                dropped += 1
+                continue
+            assert L.nanorq_encode(rq, buf, esi, sbn, io) == Tsz
+            packets.append((L.nanorq_tag(sbn, esi), bytes(buf)))
+        for esi in range(nk, nk + dropped + overhead):
+            assert L.nanorq_encode(rq, buf, esi, sbn, io) == Tsz
+            packets.append((L.nanorq_tag(sbn, esi), bytes(buf)))
+        L.nanorq_encoder_cleanup(rq, sbn)
+    oti = (L.nanorq_oti_common(rq), L.nanorq_oti_scheme_specific(rq))
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+    return oti[0], oti[1], packets
+
+
+def decode_object(oti_common, oti_scheme, packets, nbytes):
+    """reference benchmark.c:118-160 / decode.c: returns (ok, data)."""
+    L = api()
+    rq = L.nanorq_decoder_new(oti_common, oti_scheme)
+    assert rq
+    out = np.zeros(nbytes, np.uint8)
+    io = mem_io(out)
+    for tag, payload in packets:
+        b = (C.c_uint8 * len(payload)).from_buffer_copy(payload)
+        assert L.nanorq_decoder_add_symbol(rq, b, tag, io) != SYM_ERR
+    ok = True
+    for sbn in range(L.nanorq_blocks(rq)):
+        ok = L.nanorq_repair_block(rq, io, sbn) and ok
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+    return ok, out

@@ -1,0 +1,96 @@
+"""-m gpu tier for the drop-in object API (include/nanorq.h): what the reference's encode.c /
+decode.c / benchmark.c do, through the same calls, with the solve on the GPU."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from capi import api, decode_object, encode_object, mem_io
+from test_oracle_kat import KAT_SHA, KAT_SMALL
+from util import kat_payload, payload
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kat_through_object_api():
+    L = api()
+    data = kat_payload(80)
+    rq = L.nanorq_encoder_new_ex(80, 8, 10, 0, 8)
+    io = mem_io(data)
+    buf = (C.c_uint8 * 8)()
+    got = {}
+    for esi in (10, 11, 12):
+        assert L.nanorq_encode(rq, buf, esi, 0, io) == 8  # solves the block on first repair request
+        got[esi] = bytes(buf).hex()
+    assert got == KAT_SMALL
+    assert L.nanorq_encode(rq, buf, 1 << 24, 0, io) == 0  # ESI out of range
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+
+
+@pytest.mark.parametrize("K,T,lo,hi,sha", KAT_SHA[:2])
+def test_kat_sha_through_object_api(K, T, lo, hi, sha):
+    L = api()
+    data = kat_payload(K * T)
+    rq = L.nanorq_encoder_new_ex(K * T, T, K, 0, 8)
+    io = mem_io(data)
+    assert L.nanorq_precalculate(rq) and L.nanorq_generate_symbols(rq, 0, io)
+    buf = (C.c_uint8 * T)()
+    h = hashlib.sha256()
+    for esi in range(lo, hi):
+        assert L.nanorq_encode(rq, buf, esi, 0, io) == T
+        h.update(bytes(buf))
+    assert h.hexdigest() == sha
+    # systematic symbols after the solve are the source symbols
+    assert L.nanorq_encode(rq, buf, 5, 0, io) == T and bytes(buf) == data[5 * T:6 * T].tobytes()
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+
+
+@pytest.mark.parametrize("K,T,overhead", [(100, 1024, 0), (100, 1024, 5), (1000, 1280, 50), (500, 64, 2)])
+def test_benchmark_shaped_roundtrip(K, T, overhead):
+    """reference benchmark.c: one block, 6 % loss, `overhead` extra repair symbols, assert(in == out)"""
+    data = payload(K * T, seed=K)
+    done = False
+    for seed in range(1, 5):  # ~1 % of exactly-K receptions are rank deficient: then the harness retries
+        c, s, packets = encode_object(data, T, K=K, loss=0.06, overhead=overhead, seed=seed)
+        ok, out = decode_object(c, s, packets, len(data))
+        if ok:
+            assert np.array_equal(out, data)
+            done = True
+            break
+    assert done
+
+
+def test_multi_block_object_with_ragged_tail():
+    """several source blocks of unequal size, object length not a multiple of T (example.make shape)"""
+    T = 64
+    F = 103 * T - 17
+    data = payload(F, seed=3)
+    c, s, packets = encode_object(data, T, K=25, loss=0.1, overhead=3, seed=2)
+    ok, out = decode_object(c, s, packets, F)
+    assert ok and np.array_equal(out, data)
+
+
+def test_decode_retry_after_more_symbols():
+    L = api()
+    K, T = 60, 32
+    data = payload(K * T, seed=8)
+    c, s, packets = encode_object(data, T, K=K, loss=0.0, overhead=6, seed=1)
+    src = [p for p in packets if (p[0] & 0xffffff) < K]
+    rep = [p for p in packets if (p[0] & 0xffffff) >= K]
+    rq = L.nanorq_decoder_new(c, s)
+    out = np.zeros(K * T, np.uint8)
+    io = mem_io(out)
+    for tag, pl in src[4:]:
+        L.nanorq_decoder_add_symbol(rq, (C.c_uint8 * T).from_buffer_copy(pl), tag, io)
+    for tag, pl in rep[:3]:
+        L.nanorq_decoder_add_symbol(rq, (C.c_uint8 * T).from_buffer_copy(pl), tag, io)
+    assert L.nanorq_num_missing(rq, 0) == 4 and not L.nanorq_repair_block(rq, io, 0)
+    for tag, pl in rep[3:]:
+        L.nanorq_decoder_add_symbol(rq, (C.c_uint8 * T).from_buffer_copy(pl), tag, io)
+    assert L.nanorq_repair_block(rq, io, 0) and L.nanorq_num_missing(rq, 0) == 0
+    assert np.array_equal(out, data)
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
