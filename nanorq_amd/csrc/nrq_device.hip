@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
     const NRQ_GAS uint32_t *ops = c.template arr<uint32_t>(c.h->off_ops);
     const NRQ_GAS uint32_t *sy = c.template arr<uint32_t>(c.h->off_sync);
     const uint32_t nch = c.h->nchunk1 + c.h->nchunk2;
-    /* the plan pads the stream with 4 all-NOP chunks and the sync words with 2 words, so every
+    /* the plan pads the stream with 8 all-NOP chunks and the sync words with 2 words, so every
      * read-ahead below is in bounds and needs no branch */
     uint32_t q0 = ops[tid], q1 = ops[NRQ_WG + tid], q2 = ops[2 * NRQ_WG + tid], q3 = ops[3 * NRQ_WG + tid];
     uint32_t swv = sy[0];

@@ -46,7 +46,7 @@ typedef struct nrq_plan_hdr {
   uint32_t n_xor_ops; /* real (non-padding) ops in both passes, for statistics */
 
   uint32_t off_ops;     /* u32[(nchunk1+nchunk2)*NRQ_CHUNK]: dst | src<<16, NRQ_NOP = padding
-                         * (4 more all-NOP chunks follow the last one: prefetch slack).  Slots >= M are the
+                         * (8 more all-NOP chunks follow the last one: prefetch slack).  Slots >= M are the
                          * r2 scratch rows E_p (slot M+p) of the dense stage: E_p = XOR of leftover rows */
   uint32_t off_pivslot; /* u16[npiv]: slot of pivot k */
   uint32_t off_pivcol;  /* u16[npiv]: column of pivot k */

@@ -482,9 +482,10 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   hd.nchunk1 = nchunk1; hd.nchunk2 = nchunk2; hd.wpr = wpr; hd.lpr = lpr;
   hd.npiv_pad = (npiv + 63u) & ~63u;
   hd.n_xor_ops = n_real_ops;
-  /* 4 chunks of padding: the kernel prefetches op words 4 chunks ahead without bounds checks */
-  hd.off_ops = A.reserve((uint32_t)((ops.size() + 4 * NRQ_CHUNK) * 4));
-  memset(A.at<uint8_t>(hd.off_ops), 0xFF, (ops.size() + 4 * NRQ_CHUNK) * 4);
+  /* 8 chunks of padding: the kernel walks the stream 4 chunks at a time and prefetches op words 4 chunks
+   * ahead without bounds checks, so it can touch up to chunk nchunk+6 */
+  hd.off_ops = A.reserve((uint32_t)((ops.size() + 8 * NRQ_CHUNK) * 4));
+  memset(A.at<uint8_t>(hd.off_ops), 0xFF, (ops.size() + 8 * NRQ_CHUNK) * 4);
   if (!ops.empty()) memcpy(A.at<uint8_t>(hd.off_ops), ops.data(), ops.size() * 4);
   hd.off_pivslot = A.reserve(npiv * 2);
   memcpy(A.at<uint8_t>(hd.off_pivslot), pivslot.data(), (size_t)npiv * 2);
