@@ -47,6 +47,9 @@ int nrq_ctx_set_stream(nrq_ctx *ctx, void *stream);
 const char *nrq_ctx_error(nrq_ctx *ctx);
 int nrq_ctx_sync(nrq_ctx *ctx);
 void nrq_ctx_last_stats(nrq_ctx *ctx, nrq_call_stats *out);
+/* where decode plans are built: 1 = on the GPU (default; planner kernel, one workgroup per block),
+ * 0 = on the host (thread pool).  The environment variable NRQ_HOST_PLANNER=1 selects 0 at creation. */
+int nrq_ctx_set_planner(nrq_ctx *ctx, int device_planner);
 /* threads used for host-side planning (0 = hardware concurrency) */
 int nrq_ctx_set_threads(nrq_ctx *ctx, int n);
 

@@ -46,6 +46,7 @@ def lib():
     L.nrq_ctx_last_stats.argtypes = [vp, C.POINTER(CallStats)]
     L.nrq_ctx_last_stats.restype = None
     L.nrq_ctx_set_threads.argtypes = [vp, C.c_int]
+    L.nrq_ctx_set_planner.argtypes = [vp, C.c_int]
     L.nrq_params.argtypes = [C.c_uint32, u32p]
     L.nrq_precalculate.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.nrq_plan_cache_clear.argtypes = [vp]
@@ -149,6 +150,9 @@ class Context:
 
     def set_stream(self, stream):
         self._chk(self._L.nrq_ctx_set_stream(self._h, C.c_void_p(stream or 0)))
+
+    def set_planner(self, device=True):
+        self._chk(self._L.nrq_ctx_set_planner(self._h, int(bool(device))))
 
     def set_threads(self, n):
         self._chk(self._L.nrq_ctx_set_threads(self._h, n))

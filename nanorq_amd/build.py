@@ -16,6 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnanorq_hip.so")
 EMU = os.path.join(ROOT, "tests", "emu", "libsolve_emu.so")
+PEMU = os.path.join(ROOT, "tests", "emu", "libplanner_emu.so")
 
 HIP_SOURCES = ["nrq_device.hip"]
 CXX_SOURCES = ["planner_host.cpp"]
@@ -82,6 +83,15 @@ def build_emu(force=False):
     return EMU
 
 
+def build_planner_emu(force=False):
+    src = os.path.join(ROOT, "tests", "emu", "planner_emu.cpp")
+    deps = [src] + [os.path.join(CSRC, f) for f in ("planner_body.h", "planner_seq.h", "solve_body.h", "plan.h", "rq_math.h")]
+    if force or _newer(PEMU, deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", PEMU, src], check=True)
+    return PEMU
+
+
 if __name__ == "__main__":
     build_lib(force="-f" in sys.argv, verbose=True)
     build_emu(force="-f" in sys.argv)
+    build_planner_emu(force="-f" in sys.argv)

@@ -27,6 +27,7 @@
 #include "planner_host.h"
 #include "rq_math.h"
 #include "solve_body.h"
+#include "planner_body.h"
 
 #define NRQ_LDS_MAX 163840u /* 160 KiB per workgroup on gfx950 */
 #define NRQ_WG 256
@@ -138,6 +139,26 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
 #undef NRQ_STAMP
 }
 
+/* The symbolic stage of one decode block per workgroup (phases in planner_body.h, order in
+ * planner_seq.h): reception pattern -> device plan + the block's solve job. */
+__global__ __launch_bounds__(PL_NT) void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
+                                                         const nrq_planjob *__restrict__ pjobs,
+                                                         nrq_job *__restrict__ jobs_out, uint32_t nblk, uint32_t Mcap,
+                                                         uint32_t npcap, uint32_t ucap, uint32_t lds_dyn_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  if (b >= nblk) return;
+  pl_shared *sh = reinterpret_cast<pl_shared *>(smem);
+  uint8_t *dyn = smem + ((sizeof(pl_shared) + 15u) & ~(size_t)15u);
+  PlanCtx c;
+  pl_ctx_setup(c, p, kc, pjobs[b], sh, dyn, lds_dyn_bytes, Mcap, npcap, ucap, jobs_out + b);
+#define PL_PHASE(fn) do { fn<0>(c, tid, PL_NT); __syncthreads(); } while (0)
+#define PL_PHASE1(fn, a) do { fn<0>(c, (a), tid, PL_NT); __syncthreads(); } while (0)
+#include "planner_seq.h"
+#undef PL_PHASE
+#undef PL_PHASE1
+}
+
 /* One workgroup per (symbol, block): out = XOR of the LT neighbours of `isi` among the L
  * intermediate symbols in HBM (coalesced 16-byte lanes along the symbol). */
 __global__ __launch_bounds__(NRQ_WG) void nrq_gen_kernel(rq_params p, uint32_t T, const uint8_t *__restrict__ inter,
@@ -232,6 +253,10 @@ struct nrq_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ktime_pool;
   size_t ktime_used = 0;
   unsigned long long *prof = nullptr; /* NRQ_PROF=1 */
+  /* device planner */
+  int planner = 1; /* 1 = device planner for decode (default), 0 = host planner */
+  DevBuf plan_work, plan_arena, plan_jobs;
+  bool plan_attr = false;
 };
 
 namespace {
@@ -460,6 +485,7 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
   nrq_ctx *ctx = new nrq_ctx();
   ctx->device = device;
   ctx->stream = (hipStream_t)stream;
+  if (getenv("NRQ_HOST_PLANNER")) ctx->planner = 0;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->staged[0], hipEventDisableTiming) != hipSuccess ||
@@ -488,6 +514,9 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
     if (kv.second.dev) (void)hipFree(kv.second.dev);
     nrq_host_free(kv.second.host);
   }
+  if (ctx->plan_work.p) (void)hipFree(ctx->plan_work.p);
+  if (ctx->plan_arena.p) (void)hipFree(ctx->plan_arena.p);
+  if (ctx->plan_jobs.p) (void)hipFree(ctx->plan_jobs.p);
   for (int i = 0; i < 2; i++) {
     if (ctx->scratch[i].p) (void)hipFree(ctx->scratch[i].p);
     if (ctx->staging[i].p) (void)hipHostFree(ctx->staging[i].p);
@@ -516,6 +545,12 @@ int nrq_ctx_sync(nrq_ctx *ctx) {
 
 void nrq_ctx_last_stats(nrq_ctx *ctx, nrq_call_stats *out) {
   if (ctx && out) *out = ctx->stats;
+}
+
+int nrq_ctx_set_planner(nrq_ctx *ctx, int device_planner) {
+  if (!ctx) return -1;
+  ctx->planner = device_planner ? 1 : 0;
+  return 0;
 }
 
 int nrq_ctx_set_threads(nrq_ctx *ctx, int n) {
@@ -599,13 +634,10 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   return rc;
 }
 
-int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
                       const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
                       const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
                       size_t inter_stride, int *h_status) {
-  if (!ctx) return -1;
-  if (!d_src || T == 0 || nblk == 0 || !h_nlost || !h_nrep || !h_status) return fail(ctx, -1, "bad arguments");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const double t_begin = now_ms();
   rq_params p;
   int rc = block_params(ctx, K, Kp, &p);
@@ -613,7 +645,7 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   KConst *kc;
   rc = get_kconst(ctx, p.Kp, &kc);
   if (rc) return rc;
-  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  if (!select) memset(&ctx->stats, 0, sizeof(ctx->stats));
 
   struct Prep {
     uint8_t *plan = nullptr;
@@ -629,6 +661,7 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   auto prepare = [&](uint32_t b) {
     Prep &pr = prep[b];
     const uint32_t nl = h_nlost[b], nr = h_nrep[b];
+    if (select && !select[b]) { pr.state = 2; return; } /* not ours: leave its status alone */
     if (nl == 0) { pr.state = 0; return; }             /* nothing missing (nanorq.c:605-606) */
     if (nr < nl || nl > lost_cap || nr > rep_cap) { pr.state = -1; return; } /* nanorq.c:607-608 */
     const uint32_t *lost = h_lost + (size_t)b * lost_cap;
@@ -681,7 +714,7 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
       for (auto &t : pool) t.join();
     }
   }
-  ctx->stats.plan_ms = now_ms() - t_plan0;
+  ctx->stats.plan_ms += now_ms() - t_plan0;
 
   /* pack everything the kernel reads into one staging image */
   size_t off = r16((size_t)nblk * sizeof(nrq_job));
@@ -691,7 +724,7 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   uint32_t nsolve = 0;
   for (uint32_t b = 0; b < nblk; b++) {
     Prep &pr = prep[b];
-    h_status[b] = pr.state >= 0 ? 1 : 0;
+    if (pr.state != 2) h_status[b] = pr.state >= 0 ? 1 : 0;
     if (pr.state != 1) continue;
     nsolve++;
     pr.off_plan = off;   off = r16(off + pr.plan_bytes);
@@ -751,8 +784,139 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   }
   for (auto &pr : prep)
     if (pr.plan) nrq_host_free(pr.plan);
-  ctx->stats.host_ms = now_ms() - t_begin;
+  ctx->stats.host_ms += now_ms() - t_begin;
   return result;
+}
+
+
+/* decode with the symbolic stage on the GPU: one planner workgroup per block, then the solve */
+static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                         const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                         const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
+                         size_t inter_stride, int *h_status, std::vector<uint8_t> *fallback) {
+  const double t_begin = now_ms();
+  rq_params p;
+  int rc = block_params(ctx, K, Kp, &p);
+  if (rc) return rc;
+  KConst *kc;
+  rc = get_kconst(ctx, p.Kp, &kc);
+  if (rc) return rc;
+  const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(kc->host);
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  ctx->stats.planner = 1;
+  uint32_t max_oh = 0, max_nrep = 0, max_nl = 0;
+  for (uint32_t b = 0; b < nblk; b++) {
+    const uint32_t nl = h_nlost[b], nr = h_nrep[b];
+    if (nl == 0 || nr < nl || nl > lost_cap || nr > rep_cap) continue;
+    if (nr - nl > max_oh) max_oh = nr - nl;
+    if (nr > max_nrep) max_nrep = nr;
+    if (nl > max_nl) max_nl = nl;
+  }
+  uint32_t ucap = p.P + 768u;
+  if (ucap > 1280u) ucap = 1280u; /* 40 words per W row at most */
+  if (ucap < p.P + 32u) return fail(ctx, -5, "K'=%u has too many permanently inactive columns for the device planner", p.Kp);
+  const uint32_t Mcap = p.L + max_oh + 8u, npcap = max_nrep + 8u;
+  const pl_work_layout wl = pl_work_plan(p.L, Mcap, npcap, ucap);
+  const uint32_t arena_cap = pl_arena_bound(p.L, Mcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE, max_nl + 8u);
+  if ((rc = ensure_dev(ctx, ctx->plan_work, (size_t)nblk * wl.total))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->plan_arena, (size_t)nblk * arena_cap))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->plan_jobs, (size_t)nblk * sizeof(nrq_job)))) return rc;
+
+  /* inputs of the planner: [planjobs][lost lists][repair ESI lists]; headers come back after them */
+  const size_t off_pj = 0;
+  const size_t off_lost = r16(off_pj + (size_t)nblk * sizeof(nrq_planjob));
+  const size_t off_resi = r16(off_lost + (size_t)nblk * lost_cap * 4);
+  const size_t in_bytes = r16(off_resi + (size_t)nblk * rep_cap * 4);
+  const size_t off_hdrs = in_bytes;
+  const size_t total = r16(off_hdrs + (size_t)nblk * sizeof(nrq_plan_hdr));
+  const int f = ctx->flip;
+  ctx->flip ^= 1;
+  HIPCHK(ctx, hipEventSynchronize(ctx->staged[f]));
+  if ((rc = ensure_pin(ctx, ctx->staging[f], total))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->scratch[f], in_bytes))) return rc;
+  uint8_t *hs = ctx->staging[f].p, *ds = ctx->scratch[f].p;
+  memcpy(hs + off_lost, h_lost, (size_t)nblk * lost_cap * 4);
+  memcpy(hs + off_resi, h_rep_esi, (size_t)nblk * rep_cap * 4);
+  nrq_planjob *pj = reinterpret_cast<nrq_planjob *>(hs + off_pj);
+  for (uint32_t b = 0; b < nblk; b++) {
+    nrq_planjob &j = pj[b];
+    memset(&j, 0, sizeof(j));
+    const bool sane = h_nlost[b] <= lost_cap && h_nrep[b] <= rep_cap;
+    j.lost = (uint64_t)(uintptr_t)(ds + off_lost + (size_t)b * lost_cap * 4);
+    j.rep_esi = (uint64_t)(uintptr_t)(ds + off_resi + (size_t)b * rep_cap * 4);
+    j.work = (uint64_t)(uintptr_t)(ctx->plan_work.p + (size_t)b * wl.total);
+    j.arena = (uint64_t)(uintptr_t)(ctx->plan_arena.p + (size_t)b * arena_cap);
+    j.src = (uint64_t)(uintptr_t)((uint8_t *)d_src + (size_t)b * src_stride);
+    j.rep = (uint64_t)(uintptr_t)((const uint8_t *)d_rep + (size_t)b * rep_stride);
+    j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
+    j.nlost = sane ? h_nlost[b] : 0;
+    j.nrep = sane ? h_nrep[b] : 0;
+    j.arena_cap = arena_cap;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared));
+  const uint32_t dyn_bytes = NRQ_LDS_MAX - sh_bytes;
+  if (!ctx->plan_attr) {
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    ctx->plan_attr = true;
+  }
+  hipLaunchKernelGGL(nrq_plan_kernel, dim3(nblk), dim3(PL_NT), NRQ_LDS_MAX, ctx->stream, p, (const uint8_t *)kc->dev,
+                     reinterpret_cast<const nrq_planjob *>(ds + off_pj), reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk,
+                     Mcap, npcap, ucap, dyn_bytes);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpy2DAsync(hs + off_hdrs, sizeof(nrq_plan_hdr), ctx->plan_arena.p, arena_cap, sizeof(nrq_plan_hdr), nblk,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->staged[f], ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stats.plan_ms = now_ms() - t_begin;
+  const nrq_plan_hdr *hd = reinterpret_cast<const nrq_plan_hdr *>(hs + off_hdrs);
+  std::vector<const nrq_plan_hdr *> hdrs;
+  bool need_fallback = false;
+  for (uint32_t b = 0; b < nblk; b++) {
+    if (h_nlost[b] == 0) { h_status[b] = 1; continue; } /* nothing missing (nanorq.c:605-606) */
+    if (hd[b].magic != NRQ_PLAN_MAGIC) return fail(ctx, -11, "device planner produced no header for block %u", b);
+    if (hd[b].status == 0) {
+      h_status[b] = 1;
+      hdrs.push_back(&hd[b]);
+      if (ctx->stats.npiv == 0) {
+        ctx->stats.npiv = hd[b].npiv; ctx->stats.u = hd[b].u; ctx->stats.nlev = hd[b].nlev; ctx->stats.nfree = hd[b].nfree;
+      }
+      ctx->stats.xor_ops += hd[b].n_xor_ops;
+      ctx->stats.plan_bytes += hd[b].total_bytes;
+    } else if (hd[b].reserved[0] == PL_FAIL_CAPACITY) {
+      (*fallback)[b] = 1;
+      need_fallback = true;
+      h_status[b] = 0;
+    } else {
+      h_status[b] = 0;
+    }
+  }
+  int result = 0;
+  if (!hdrs.empty())
+    result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ctx->plan_jobs.p), nblk, T, kc->dev);
+  ctx->stats.host_ms = now_ms() - t_begin;
+  if (result) return result;
+  return need_fallback ? 1 : 0;
+}
+
+int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                      const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                      const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
+                      size_t inter_stride, int *h_status) {
+  if (!ctx) return -1;
+  if (!d_src || T == 0 || nblk == 0 || !h_nlost || !h_nrep || !h_status) return fail(ctx, -1, "bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->planner)
+    return decode_host(ctx, nullptr, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap,
+                       d_rep, rep_stride, d_inter, inter_stride, h_status);
+  std::vector<uint8_t> fallback(nblk, 0);
+  int rc = decode_device(ctx, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap, d_rep,
+                         rep_stride, d_inter, inter_stride, h_status, &fallback);
+  if (rc <= 0) return rc;
+  /* blocks that exceeded a device-planner capacity are planned on the host (rare) */
+  return decode_host(ctx, fallback.data(), K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
+                     rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);
 }
 
 int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,

@@ -66,13 +66,22 @@ typedef struct nrq_plan_hdr {
   uint32_t reserved[2];
 } nrq_plan_hdr;
 
-/* Per-K' constants of the HDPC block (RFC 6330 section 5.3.3.3), shared by every plan of that K'. */
+/* Per-K' constants shared by every plan of that K': the HDPC block (RFC 6330 section 5.3.3.3) and the
+ * "base" constraint structure -- the S LDPC rows and the LT rows of ISI 0..K'-1 (reference
+ * precode_matrix_gen, precode.c:90-97) in CSR and CSC form -- which a decode only patches in the rows
+ * whose source symbol was replaced by a repair symbol (reference patch_precode_matrix, nanorq.c:527-547). */
 typedef struct nrq_kconst_hdr {
   uint32_t Kp, S, H, n; /* n = Kp + S */
   uint32_t off_g;       /* u8[H*n] row-major: the HDPC block (reference precode.c:60-83) */
   uint32_t off_b12;     /* u8[n]: b1 | b2<<4 of column c (two unit entries of MT), c < n-1 */
   uint32_t total_bytes;
-  uint32_t reserved;
+  uint32_t L, W, P, nnz;
+  uint32_t off_rptr;    /* u32[L+1]: base CSR row pointers (rows [S,S+H) are empty) */
+  uint32_t off_cidx;    /* u16[nnz]: base CSR column indices */
+  uint32_t off_cptr;    /* u32[L+1]: base CSC column pointers */
+  uint32_t off_ridx;    /* u16[nnz]: base CSC row indices, ascending per column */
+  uint32_t off_state;   /* u32[L]: per base row, (count << 24 | sum) of its column ids below W */
+  uint32_t reserved[3];
 } nrq_kconst_hdr;
 
 #endif

@@ -1,0 +1,1100 @@
+/*
+ * planner_body.h -- the symbolic stage ON THE GPU: one 256-thread workgroup turns one source
+ * block's reception pattern into a device plan (plan.h), the same format planner_host.cpp emits.
+ * Written, like solve_body.h, as per-thread phase functions: planner kernel (nrq_device.hip) =
+ * phases + `__syncthreads()`; tests/emu runs the 256 threads of a phase in a loop on the CPU.
+ *
+ * Replaces the reference's patch_precode_matrix + precode_matrix_invert for decoding
+ * (nanorq.c:527-547, precode.c:99-377) -- sort/precond/choose/swap_cols/update_nnz, make_U,
+ * fwd_GE, fill_HDPC, solve_gf2/solve_gf256, backsolve -- by a parallel formulation:
+ *   peeling   breadth-first rounds: every row with ONE unresolved V column claims it with an atomic
+ *             compare-and-swap; a column leaving V updates its rows' (count, id-sum) word with one
+ *             atomic subtract; when a round has no claimant the sparsest open row is found by a
+ *             workgroup-wide atomic min and all but one of its columns are inactivated;
+ *   W         fill-in bit rows by level (groups of 8 lanes per row);
+ *   dense     GF(2) Gauss-Jordan in LDS on the leftover rows (pivot row = atomic min over the
+ *             candidates of a column), then the H HDPC rows over GF(256) for what is left, with
+ *             log/antilog tables staged in LDS;
+ *   emission  XOR op stream by dependency level (scattered inside a level so that neighbouring
+ *             lanes rarely share a target), slot maps, the block's job descriptor.
+ * Any valid elimination order yields the same intermediate symbols (unique solution of A*C = D),
+ * so plans differ from the host planner's while results are bit-identical.
+ */
+#ifndef NRQ_PLANNER_BODY_H
+#define NRQ_PLANNER_BODY_H
+
+#include <stdint.h>
+#include <string.h>
+
+#include "plan.h"
+#include "rq_math.h"
+#include "solve_body.h"
+
+#define PL_NT 256u
+#define PL_QCAP 2048u          /* frontier / claim queue capacity */
+#define PL_UNASSIGNED 0x80000000u
+#define PL_ST_V 0u
+#define PL_ST_PIVOT 1u
+#define PL_ST_INACT 2u
+#define PL_ST_CLAIM 3u
+#define PL_NONE 0xFFFFFFFFu
+#define PL_MAXH 16u
+#define PL_PATCH_STRIDE RQ_MAX_LT_COLS
+#define PL_DENSE_RESERVE (36u * 1024u) /* LDS kept for the dense stage when the peeling state is in LDS too */
+
+/* what the host hands the planner for one block */
+typedef struct nrq_planjob {
+  uint64_t lost;     /* u32[nlost]: missing source ESIs, ascending */
+  uint64_t rep_esi;  /* u32[nrep]: ESIs of the received repair symbols, arrival order */
+  uint64_t work;     /* this block's workspace (nrq_planwork_bytes) */
+  uint64_t arena;    /* plan arena out (capacity arena_cap bytes) */
+  uint64_t src, rep, inter; /* forwarded into the solve job: symbol buffers of the block */
+  uint32_t nlost, nrep;
+  uint32_t arena_cap;
+  uint32_t pad;
+} nrq_planjob;
+
+/* ---- atomics: device intrinsics / plain memory in the emulator ---- */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PL_ATOM_ADD(p, v) atomicAdd((p), (v))
+#define PL_ATOM_SUB(p, v) atomicSub((p), (v))
+#define PL_ATOM_MAX(p, v) atomicMax((p), (v))
+#define PL_ATOM_MIN(p, v) atomicMin((p), (v))
+#define PL_ATOM_OR(p, v) atomicOr((p), (v))
+#define PL_ATOM_CAS(p, c, v) atomicCAS((p), (c), (v))
+#else
+static inline uint32_t pl_add_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+static inline uint32_t pl_sub_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o - v; return o; }
+static inline uint32_t pl_max_(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
+static inline uint32_t pl_min_(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+static inline uint32_t pl_or_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+static inline uint32_t pl_cas_(uint32_t *p, uint32_t c, uint32_t v) { uint32_t o = *p; if (o == c) *p = v; return o; }
+#define PL_ATOM_ADD(p, v) pl_add_((p), (v))
+#define PL_ATOM_SUB(p, v) pl_sub_((p), (v))
+#define PL_ATOM_MAX(p, v) pl_max_((p), (v))
+#define PL_ATOM_MIN(p, v) pl_min_((p), (v))
+#define PL_ATOM_OR(p, v) pl_or_((p), (v))
+#define PL_ATOM_CAS(p, c, v) pl_cas_((p), (c), (v))
+#endif
+
+SB_HD uint32_t pl_r16(uint32_t x) { return (x + 15u) & ~15u; }
+
+/* ---- workgroup-shared scalars and small arrays (LDS) ---- */
+/* status: 0 ok, 1 = not decodable (too few symbols / rank deficient), 2 = a planner capacity was
+ * exceeded (queues, inactive-column cap, arena, LDS): the caller re-plans that block on the host */
+#define PL_FAIL_SINGULAR 1u
+#define PL_FAIL_CAPACITY 2u
+
+typedef struct pl_shared {
+  uint32_t status;
+  uint32_t M, overhead, npatch, wpr, lpr, rowlen;
+  uint32_t nV, npiv, ninact, nlev;
+  uint32_t nfront, nnext, nclaim, cur; /* cur: which of the two queues is the frontier */
+  uint32_t best;
+  uint32_t nlow, r2, nfree, cand[2];
+  uint32_t arena_top, nchunk1, nchunk2, nops_real, opbase;
+  uint32_t uslot_fill, tmp0, tmp1;
+  uint32_t off_ops, off_sync, nsyncw;
+  uint16_t queue[2][PL_QCAP];
+  uint16_t claim_r[PL_QCAP], claim_c[PL_QCAP];
+  uint32_t partial[PL_NT];
+  uint32_t freex[NRQ_MAX_FREE];
+  uint8_t gf_exp[512], gf_log[256];
+  uint8_t aug[PL_MAXH * (NRQ_MAX_FREE + PL_MAXH)];
+  uint8_t solver[NRQ_MAX_FREE];
+  uint8_t taken[PL_MAXH];
+  uint8_t colf[PL_MAXH];
+} pl_shared;
+
+/* ---- per-block workspace in HBM (offsets from job.work) ---- */
+typedef struct pl_work_layout {
+  uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, ucol, wrows,
+      by_level, lev_cnt, lev_ops, lev_base, lev_fill, pivdeg, lowdeg, red_row, red_x, used, flag, total;
+} pl_work_layout;
+
+SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uint32_t ucap) {
+  pl_work_layout w;
+  uint32_t o = 0;
+  const uint32_t wprcap = (ucap + 31u) / 32u;
+  w.rowstate = o;   o = pl_r16(o + Mcap * 4u);
+  w.rowinfo = o;    o = pl_r16(o + Mcap * 4u);
+  w.colinfo = o;    o = pl_r16(o + L * 4u);
+  w.patch_of = o;   o = pl_r16(o + Mcap * 2u);
+  w.patch_cols = o; o = pl_r16(o + npcap * PL_PATCH_STRIDE * 2u);
+  w.patch_len = o;  o = pl_r16(o + npcap);
+  w.pc_ptr = o;     o = pl_r16(o + (L + 1u) * 4u);
+  w.pc_fill = o;    o = pl_r16(o + (L + 1u) * 4u);
+  w.pc_rows = o;    o = pl_r16(o + npcap * PL_PATCH_STRIDE * 2u);
+  w.ucol = o;       o = pl_r16(o + ucap * 2u);
+  w.wrows = o;      o = pl_r16(o + L * wprcap * 4u);
+  w.by_level = o;   o = pl_r16(o + L * 4u);
+  w.lev_cnt = o;    o = pl_r16(o + (L + 2u) * 4u);
+  w.lev_ops = o;    o = pl_r16(o + (L + 2u) * 4u);
+  w.lev_base = o;   o = pl_r16(o + (L + 2u) * 4u);
+  w.lev_fill = o;   o = pl_r16(o + (L + 2u) * 4u);
+  w.pivdeg = o;     o = pl_r16(o + L * 4u);
+  w.lowdeg = o;     o = pl_r16(o + Mcap * 4u);
+  w.red_row = o;    o = pl_r16(o + ucap * 4u);
+  w.red_x = o;      o = pl_r16(o + ucap * 4u);
+  w.used = o;       o = pl_r16(o + Mcap);
+  w.flag = o;       o = pl_r16(o + Mcap);
+  w.total = o;
+  return w;
+}
+
+/* upper bound of a plan arena (header + arrays + rowsrc + output lists) for a block of this size */
+SB_HD uint32_t pl_arena_bound(uint32_t L, uint32_t Mcap, uint32_t ucap, uint32_t nnz, uint32_t nlost_cap) {
+  const uint32_t wprcap = (ucap + 31u) / 32u, npad = (L + 63u) & ~63u;
+  uint32_t ops = (2u * nnz + 2u * ucap * 64u) + NRQ_CHUNK * (L / 4u + 64u);
+  uint32_t b = 256u + L * 2u * 3u + (L + 16u) * 2u + ucap * 2u * 4u + ucap * 4u * 2u + PL_MAXH * ucap +
+               NRQ_MAX_FREE * PL_MAXH + wprcap * npad * 4u + ops * 4u + (ops / NRQ_CHUNK / 32u + 4u) * 4u +
+               Mcap * 4u + (nlost_cap + 1u) * 8u + nlost_cap * PL_PATCH_STRIDE * 2u + 1024u;
+  return pl_r16(b);
+}
+
+/* ---- context ---- */
+struct PlanCtx {
+  /* inputs */
+  rq_params p;
+  const uint8_t *kc;
+  const nrq_kconst_hdr *kh;
+  const uint32_t *b_rptr, *b_cptr, *b_state;
+  const uint16_t *b_cidx, *b_ridx;
+  const uint8_t *G;
+  nrq_planjob job;
+  const uint32_t *lost, *rep_esi;
+  pl_shared *sh;
+  uint8_t *lds_dyn; /* dynamic LDS region: peeling state (if it fits) and the dense stage (Mb, Mh) */
+  uint32_t lds_dyn_bytes;
+  uint8_t *dense_lds;
+  uint32_t dense_bytes;
+  uint32_t Mcap, npcap, ucap;
+  /* workspace views */
+  pl_work_layout wl;
+  uint8_t *work;
+  uint32_t *rowstate, *rowinfo, *colinfo;
+  uint16_t *patch_of, *patch_cols, *pc_rows, *ucol;
+  uint8_t *patch_len, *used, *flag;
+  uint32_t *pc_ptr, *pc_fill, *wrows, *by_level, *lev_cnt, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *red_row,
+      *red_x;
+  /* arena views (fixed part laid out up front) */
+  uint8_t *arena;
+  nrq_plan_hdr *hdr;
+  uint16_t *pivslot, *pivcol, *colslot, *pivof, *uslot, *lowslot, *pivx, *freex_out;
+  uint32_t *fbits;
+  uint8_t *mh, *hinv;
+  uint32_t off_pivslot, off_pivcol, off_colslot, off_pivof, off_uslot, off_lowslot, off_pivx, off_fbits, off_mh,
+      off_freex, off_hinv, fixed_end;
+  nrq_job *jobout;
+};
+
+SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, const nrq_planjob &job, pl_shared *sh,
+                        uint8_t *lds_dyn, uint32_t lds_dyn_bytes, uint32_t Mcap, uint32_t npcap, uint32_t ucap,
+                        nrq_job *jobout) {
+  c.kc = kc;
+  c.kh = reinterpret_cast<const nrq_kconst_hdr *>(kc);
+  c.p = prm;
+  c.b_rptr = reinterpret_cast<const uint32_t *>(kc + c.kh->off_rptr);
+  c.b_cidx = reinterpret_cast<const uint16_t *>(kc + c.kh->off_cidx);
+  c.b_cptr = reinterpret_cast<const uint32_t *>(kc + c.kh->off_cptr);
+  c.b_ridx = reinterpret_cast<const uint16_t *>(kc + c.kh->off_ridx);
+  c.b_state = reinterpret_cast<const uint32_t *>(kc + c.kh->off_state);
+  c.G = kc + c.kh->off_g;
+  c.job = job;
+  c.lost = reinterpret_cast<const uint32_t *>(job.lost);
+  c.rep_esi = reinterpret_cast<const uint32_t *>(job.rep_esi);
+  c.sh = sh;
+  c.lds_dyn = lds_dyn;
+  c.lds_dyn_bytes = lds_dyn_bytes;
+  c.Mcap = Mcap; c.npcap = npcap; c.ucap = ucap;
+  c.wl = pl_work_plan(c.p.L, Mcap, npcap, ucap);
+  c.work = reinterpret_cast<uint8_t *>(job.work);
+  uint8_t *w = c.work;
+  c.rowstate = reinterpret_cast<uint32_t *>(w + c.wl.rowstate);
+  c.rowinfo = reinterpret_cast<uint32_t *>(w + c.wl.rowinfo);
+  c.colinfo = reinterpret_cast<uint32_t *>(w + c.wl.colinfo);
+  /* the three hot peeling arrays live in LDS when they fit next to the dense-stage reserve; the
+   * dense stage (Mb, Mh) uses what is left of the dynamic region */
+  c.dense_lds = lds_dyn;
+  c.dense_bytes = lds_dyn_bytes;
+  {
+    uint32_t need = pl_r16(Mcap * 4u) * 2u + pl_r16(c.p.L * 4u);
+    if (lds_dyn && need + PL_DENSE_RESERVE <= lds_dyn_bytes) {
+      c.rowstate = reinterpret_cast<uint32_t *>(lds_dyn);
+      c.rowinfo = reinterpret_cast<uint32_t *>(lds_dyn + pl_r16(Mcap * 4u));
+      c.colinfo = reinterpret_cast<uint32_t *>(lds_dyn + 2u * pl_r16(Mcap * 4u));
+      c.dense_lds = lds_dyn + need;
+      c.dense_bytes = lds_dyn_bytes - need;
+    }
+  }
+  c.patch_of = reinterpret_cast<uint16_t *>(w + c.wl.patch_of);
+  c.patch_cols = reinterpret_cast<uint16_t *>(w + c.wl.patch_cols);
+  c.patch_len = w + c.wl.patch_len;
+  c.pc_ptr = reinterpret_cast<uint32_t *>(w + c.wl.pc_ptr);
+  c.pc_fill = reinterpret_cast<uint32_t *>(w + c.wl.pc_fill);
+  c.pc_rows = reinterpret_cast<uint16_t *>(w + c.wl.pc_rows);
+  c.ucol = reinterpret_cast<uint16_t *>(w + c.wl.ucol);
+  c.wrows = reinterpret_cast<uint32_t *>(w + c.wl.wrows);
+  c.by_level = reinterpret_cast<uint32_t *>(w + c.wl.by_level);
+  c.lev_cnt = reinterpret_cast<uint32_t *>(w + c.wl.lev_cnt);
+  c.lev_ops = reinterpret_cast<uint32_t *>(w + c.wl.lev_ops);
+  c.lev_base = reinterpret_cast<uint32_t *>(w + c.wl.lev_base);
+  c.lev_fill = reinterpret_cast<uint32_t *>(w + c.wl.lev_fill);
+  c.pivdeg = reinterpret_cast<uint32_t *>(w + c.wl.pivdeg);
+  c.lowdeg = reinterpret_cast<uint32_t *>(w + c.wl.lowdeg);
+  c.red_row = reinterpret_cast<uint32_t *>(w + c.wl.red_row);
+  c.red_x = reinterpret_cast<uint32_t *>(w + c.wl.red_x);
+  c.used = w + c.wl.used;
+  c.flag = w + c.wl.flag;
+  /* arena: header, then the arrays whose size is bounded by (L, ucap) */
+  c.arena = reinterpret_cast<uint8_t *>(job.arena);
+  c.hdr = reinterpret_cast<nrq_plan_hdr *>(c.arena);
+  uint32_t o = pl_r16((uint32_t)sizeof(nrq_plan_hdr));
+  const uint32_t L = c.p.L, n_hd = c.p.Kp + c.p.S;
+  c.off_pivslot = o; o = pl_r16(o + L * 2u);
+  c.off_pivcol = o;  o = pl_r16(o + L * 2u);
+  c.off_colslot = o; o = pl_r16(o + L * 2u);
+  c.off_pivof = o;   o = pl_r16(o + ((n_hd + 7u) & ~7u) * 2u);
+  c.off_uslot = o;   o = pl_r16(o + ucap * 2u);
+  c.off_lowslot = o; o = pl_r16(o + ucap * 2u + 64u);
+  c.off_pivx = o;    o = pl_r16(o + ucap * 2u);
+  c.off_fbits = o;   o = pl_r16(o + ucap * 4u);
+  c.off_mh = o;      o = pl_r16(o + PL_MAXH * ucap);
+  c.off_freex = o;   o = pl_r16(o + NRQ_MAX_FREE * 2u);
+  c.off_hinv = o;    o = pl_r16(o + NRQ_MAX_FREE * PL_MAXH);
+  c.fixed_end = o;
+  c.pivslot = reinterpret_cast<uint16_t *>(c.arena + c.off_pivslot);
+  c.pivcol = reinterpret_cast<uint16_t *>(c.arena + c.off_pivcol);
+  c.colslot = reinterpret_cast<uint16_t *>(c.arena + c.off_colslot);
+  c.pivof = reinterpret_cast<uint16_t *>(c.arena + c.off_pivof);
+  c.uslot = reinterpret_cast<uint16_t *>(c.arena + c.off_uslot);
+  c.lowslot = reinterpret_cast<uint16_t *>(c.arena + c.off_lowslot);
+  c.pivx = reinterpret_cast<uint16_t *>(c.arena + c.off_pivx);
+  c.fbits = reinterpret_cast<uint32_t *>(c.arena + c.off_fbits);
+  c.mh = c.arena + c.off_mh;
+  c.freex_out = reinterpret_cast<uint16_t *>(c.arena + c.off_freex);
+  c.hinv = c.arena + c.off_hinv;
+  c.jobout = jobout;
+}
+
+/* columns of constraint row r: base structure unless this block patched the row */
+SB_HD uint32_t pl_row(const PlanCtx &c, uint32_t r, const uint16_t **cols) {
+  uint32_t pi = c.patch_of[r];
+  if (pi != 0xFFFFu) {
+    *cols = c.patch_cols + (size_t)pi * PL_PATCH_STRIDE;
+    return c.patch_len[pi];
+  }
+  if (r >= c.p.L) { *cols = c.patch_cols; return 0; }
+  uint32_t a = c.b_rptr[r];
+  *cols = c.b_cidx + a;
+  return c.b_rptr[r + 1] - a;
+}
+
+SB_HD uint8_t pl_gfmul(const pl_shared *sh, uint8_t a, uint8_t b) {
+  return (a && b) ? sh->gf_exp[(uint32_t)sh->gf_log[a] + sh->gf_log[b]] : 0;
+}
+
+/* =============================== phase 0: inputs, patch rows, state ========================== */
+template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const rq_params &p = c.p;
+  if (tid == 0) {
+    uint32_t st = 0;
+    const uint32_t nl = c.job.nlost, nr = c.job.nrep;
+    if (nl == 0 || nr < nl) st = PL_FAIL_SINGULAR;
+    uint32_t oh = st ? 0 : nr - nl;
+    if (!st && (p.L + oh > c.Mcap || nr > c.npcap || p.L + oh > 65534u)) st = PL_FAIL_CAPACITY;
+    sh->status = st;
+    sh->overhead = oh;
+    sh->M = p.L + oh;
+    sh->npatch = st ? 0 : nr;
+    sh->nV = p.W; sh->npiv = 0; sh->ninact = 0; sh->nlev = 0;
+    sh->nfront = 0; sh->nnext = 0; sh->nclaim = 0; sh->cur = 0; sh->best = PL_NONE;
+    sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = PL_NONE;
+    sh->nchunk1 = sh->nchunk2 = 0; sh->nops_real = 0; sh->uslot_fill = 0;
+  }
+  /* GF(256) tables into LDS (RFC 6330 section 5.7): generated by one thread, 255 steps */
+  if (tid == 1 % nt) {
+    uint32_t x = 1;
+    for (uint32_t e = 0; e < 255; e++) {
+      sh->gf_exp[e] = (uint8_t)x;
+      sh->gf_log[x] = (uint8_t)e;
+      x <<= 1;
+      if (x & 0x100u) x ^= 0x11Du;
+    }
+    for (uint32_t e = 255; e < 512; e++) sh->gf_exp[e] = sh->gf_exp[e - 255];
+    sh->gf_log[0] = 0;
+  }
+  const uint32_t L = p.L;
+  for (uint32_t r = tid; r < c.Mcap; r += nt) {
+    c.rowstate[r] = r < L ? c.b_state[r] : 0u;
+    c.rowinfo[r] = PL_UNASSIGNED;
+    c.patch_of[r] = 0xFFFFu;
+    c.used[r] = 0;
+  }
+  for (uint32_t col = tid; col < L; col += nt) {
+    c.colinfo[col] = col < p.W ? 0u : ((PL_ST_INACT << 30) | (col - p.W));
+    c.pc_fill[col] = 0;
+  }
+  for (uint32_t x = tid; x < p.P; x += nt) c.ucol[x] = (uint16_t)(p.W + x);
+}
+
+/* validate the inputs and expand the patched rows (thread per received repair symbol) */
+template <int Z> SB_HD void pl_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const rq_params &p = c.p;
+  const uint32_t nl = c.job.nlost, pad = p.Kp - p.K;
+  for (uint32_t i = tid; i < sh->npatch; i += nt) {
+    uint32_t esi = c.rep_esi[i], row;
+    bool bad = esi < p.K || esi >= (1u << 24);
+    if (i < nl) {
+      uint32_t e = c.lost[i];
+      if (e >= p.K || (i && e <= c.lost[i - 1])) bad = true;
+      row = p.S + p.H + (bad ? 0u : e);
+    } else {
+      row = p.L + (i - nl);
+    }
+    if (bad) { sh->status = PL_FAIL_SINGULAR; continue; }
+    uint32_t cols[RQ_MAX_LT_COLS];
+    uint32_t n = rq_lt_columns(&p, esi + pad, cols);
+    uint16_t *dst = c.patch_cols + (size_t)i * PL_PATCH_STRIDE;
+    uint32_t cnt = 0, sum = 0;
+    for (uint32_t k = 0; k < n; k++) {
+      dst[k] = (uint16_t)cols[k];
+      if (cols[k] < p.W) { cnt++; sum += cols[k]; }
+      PL_ATOM_ADD(&c.pc_fill[cols[k]], 1u);
+    }
+    c.patch_len[i] = (uint8_t)n;
+    c.patch_of[row] = (uint16_t)i;
+    c.rowstate[row] = (cnt << 24) | sum;
+  }
+}
+
+/* exclusive scan of pc_fill[0..L) into pc_ptr[0..L]; three steps */
+template <int Z> SB_HD void pl_scan_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  const uint32_t L = c.p.L, per = (L + nt - 1) / nt;
+  uint32_t a = tid * per, b = a + per < L ? a + per : L, s = 0;
+  for (uint32_t k = a; k < b; k++) s += c.pc_fill[k];
+  c.sh->partial[tid] = s;
+}
+template <int Z> SB_HD void pl_scan_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  if (tid != 0) return;
+  uint32_t run = 0;
+  for (uint32_t t = 0; t < nt; t++) { uint32_t v = c.sh->partial[t]; c.sh->partial[t] = run; run += v; }
+  c.pc_ptr[c.p.L] = run;
+}
+template <int Z> SB_HD void pl_scan_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  const uint32_t L = c.p.L, per = (L + nt - 1) / nt;
+  uint32_t a = tid * per, b = a + per < L ? a + per : L, run = c.sh->partial[tid];
+  for (uint32_t k = a; k < b; k++) { uint32_t v = c.pc_fill[k]; c.pc_ptr[k] = run; run += v; c.pc_fill[k] = 0; }
+}
+/* fill the patch CSC; seed the first frontier with the rows that already have one V column */
+template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const rq_params &p = c.p;
+  const uint32_t nl = c.job.nlost;
+  for (uint32_t i = tid; i < sh->npatch; i += nt) {
+    uint32_t row = i < nl ? p.S + p.H + c.lost[i] : p.L + (i - nl);
+    const uint16_t *cols = c.patch_cols + (size_t)i * PL_PATCH_STRIDE;
+    for (uint32_t k = 0; k < c.patch_len[i]; k++) {
+      uint32_t col = cols[k];
+      uint32_t pos = PL_ATOM_ADD(&c.pc_fill[col], 1u);
+      c.pc_rows[c.pc_ptr[col] + pos] = (uint16_t)row;
+    }
+  }
+  for (uint32_t r = tid; r < sh->M; r += nt) {
+    if ((c.rowstate[r] >> 24) == 1u) {
+      uint32_t j = PL_ATOM_ADD(&sh->nfront, 1u);
+      if (j < PL_QCAP) sh->queue[0][j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
+    }
+  }
+}
+
+/* column `col` leaves V: one atomic subtract per row that contains it; rows that drop to a single V
+ * column join the next frontier.  `lvl1` (pivot level + 1) is folded into the rows' level-so-far; 0
+ * for an inactivated column.  Called by one thread per column (`lane0`/`lanes` = 0/1) or by a group of
+ * lanes striding over the column's row list. */
+SB_HD void pl_drop_column(PlanCtx &c, uint32_t col, uint32_t lvl1, uint32_t lane0, uint32_t lanes) {
+  pl_shared *sh = c.sh;
+  const uint32_t dec = (1u << 24) | col;
+  uint16_t *nextq = sh->queue[sh->cur ^ 1u];
+  const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a;
+  const uint32_t pa = c.pc_ptr[col], np = c.pc_ptr[col + 1] - pa;
+  for (uint32_t e = lane0; e < nb + np; e += lanes) {
+    uint32_t r;
+    if (e < nb) {
+      r = c.b_ridx[a + e];
+      if (c.patch_of[r] != 0xFFFFu) continue; /* base entry of a row this block replaced */
+    } else {
+      r = c.pc_rows[pa + (e - nb)];
+    }
+    const uint32_t info = c.rowinfo[r]; /* assignments happen in another phase: stable here */
+    if (lvl1 && (info & PL_UNASSIGNED)) PL_ATOM_MAX(&c.rowinfo[r], PL_UNASSIGNED | lvl1);
+    uint32_t old = PL_ATOM_SUB(&c.rowstate[r], dec);
+    if ((old >> 24) == 2u && (info & PL_UNASSIGNED)) {
+      uint32_t j = PL_ATOM_ADD(&sh->nnext, 1u);
+      if (j < PL_QCAP) nextq[j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
+    }
+  }
+}
+
+/* =============================== phase 1: peeling rounds ==================================== */
+/* A: every frontier row that still has exactly one V column tries to claim it */
+template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const uint16_t *fq = sh->queue[sh->cur];
+  for (uint32_t t = tid; t < sh->nfront; t += nt) {
+    uint32_t r = fq[t];
+    uint32_t st = c.rowstate[r];
+    if ((st >> 24) != 1u || !(c.rowinfo[r] & PL_UNASSIGNED)) continue;
+    uint32_t col = st & 0xFFFFFFu;
+    if (PL_ATOM_CAS(&c.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) == 0u) {
+      uint32_t i = PL_ATOM_ADD(&sh->nclaim, 1u);
+      if (i < PL_QCAP) { sh->claim_r[i] = (uint16_t)r; sh->claim_c[i] = (uint16_t)col; } else sh->status = PL_FAIL_CAPACITY;
+    }
+  }
+}
+/* B: winners become pivots; their level is the level-so-far accumulated by earlier column drops */
+template <int Z> SB_HD void pl_round_pivot(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  for (uint32_t i = tid; i < sh->nclaim; i += nt) {
+    uint32_t r = sh->claim_r[i], col = sh->claim_c[i];
+    uint32_t lv = c.rowinfo[r] & 0x7FFFFFFFu;
+    uint32_t k = PL_ATOM_ADD(&sh->npiv, 1u);
+    c.pivslot[k] = (uint16_t)r;
+    c.pivcol[k] = (uint16_t)col;
+    c.rowinfo[r] = lv; /* assigned: bit 31 cleared, level kept */
+    c.colinfo[col] = (PL_ST_PIVOT << 30) | k;
+    PL_ATOM_MAX(&sh->nlev, lv + 1u);
+  }
+}
+/* C: the claimed columns leave V (8 lanes per column) */
+template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const uint32_t grp = tid >> 3, lane = tid & 7u, ngrp = nt >> 3;
+  for (uint32_t i = grp; i < sh->nclaim; i += ngrp) {
+    uint32_t r = sh->claim_r[i], col = sh->claim_c[i];
+    pl_drop_column(c, col, (c.rowinfo[r] & 0x7FFFFFFFu) + 1u, lane, 8u);
+  }
+}
+/* D: bookkeeping by one thread */
+template <int Z> SB_HD void pl_round_swap(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (tid != 0) return;
+  if (sh->nclaim > PL_QCAP) sh->nclaim = PL_QCAP;
+  sh->nV -= sh->nclaim;
+  sh->nclaim = 0;
+  sh->cur ^= 1u;
+  sh->nfront = sh->nnext < PL_QCAP ? sh->nnext : PL_QCAP;
+  sh->nnext = 0;
+  sh->best = PL_NONE;
+}
+/* E: no claimant: find the open row with the fewest V columns (workgroup-wide atomic min) */
+template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  uint32_t best = PL_NONE;
+  for (uint32_t r = tid; r < sh->M; r += nt) {
+    if (!(c.rowinfo[r] & PL_UNASSIGNED)) continue;
+    uint32_t cnt = c.rowstate[r] >> 24;
+    if (cnt >= 2u) {
+      uint32_t key = (cnt << 16) | r;
+      if (key < best) best = key;
+    }
+  }
+  if (best != PL_NONE) PL_ATOM_MIN(&sh->best, best);
+}
+/* F: inactivate all but one V column of that row (or every remaining V column if no row is left) */
+template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const rq_params &p = c.p;
+  if (sh->best == PL_NONE) {
+    for (uint32_t col = tid; col < p.W; col += nt) {
+      if (c.colinfo[col] == 0u) {
+        uint32_t x = p.P + PL_ATOM_ADD(&sh->ninact, 1u);
+        if (x < c.ucap) { c.colinfo[col] = (PL_ST_INACT << 30) | x; c.ucol[x] = (uint16_t)col; }
+        else sh->status = PL_FAIL_CAPACITY;
+      }
+    }
+    return;
+  }
+  if (tid != 0) return;
+  /* list the row's V columns; keep the one with the fewest entries (heuristic), inactivate the others */
+  const uint32_t r = sh->best & 0xFFFFu;
+  const uint16_t *cols;
+  const uint32_t n = pl_row(c, r, &cols);
+  uint32_t keep = PL_NONE, keepdeg = PL_NONE, m = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t col = cols[k];
+    if (c.colinfo[col] != 0u) continue;
+    uint32_t dg = (c.b_cptr[col + 1] - c.b_cptr[col]) + (c.pc_ptr[col + 1] - c.pc_ptr[col]);
+    if (dg < keepdeg) { keepdeg = dg; keep = col; }
+  }
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t col = cols[k];
+    if (c.colinfo[col] != 0u || col == keep) continue;
+    uint32_t x = p.P + sh->ninact;
+    if (x >= c.ucap || m >= PL_QCAP) { sh->status = PL_FAIL_CAPACITY; break; }
+    sh->ninact++;
+    c.colinfo[col] = (PL_ST_INACT << 30) | x;
+    c.ucol[x] = (uint16_t)col;
+    sh->claim_c[m++] = (uint16_t)col;
+  }
+  sh->nclaim = m; /* reused as "columns to drop" */
+}
+template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->best == PL_NONE) return;
+  const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
+  for (uint32_t i = grp; i < sh->nclaim; i += ngrp) pl_drop_column(c, sh->claim_c[i], 0u, lane, 32u);
+}
+template <int Z> SB_HD void pl_inact_apply_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (tid != 0) return;
+  if (sh->best == PL_NONE) sh->nV = 0;
+  else sh->nV -= sh->nclaim;
+  sh->nclaim = 0;
+  sh->cur ^= 1u;
+  sh->nfront = sh->nnext < PL_QCAP ? sh->nnext : PL_QCAP;
+  sh->nnext = 0;
+  sh->best = PL_NONE;
+}
+
+/* =============================== phase 2: levels, W ========================================== */
+template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (tid == 0) {
+    const uint32_t u = c.p.L - sh->npiv;
+    sh->wpr = u ? (u + 31u) / 32u : 1u;
+    if (c.p.P + sh->ninact != u) sh->status = PL_FAIL_CAPACITY; /* cannot happen: every column is pivot or inactive */
+  }
+  for (uint32_t l = tid; l < sh->nlev + 2u; l += nt) { c.lev_cnt[l] = 0; c.lev_ops[l] = 0; c.lev_fill[l] = 0; }
+}
+template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  for (uint32_t k = tid; k < sh->npiv; k += nt) PL_ATOM_ADD(&c.lev_cnt[c.rowinfo[c.pivslot[k]] + 1u], 1u);
+}
+template <int Z> SB_HD void pl_lev_c(PlanCtx &c, uint32_t tid, uint32_t nt) { /* serial prefix over levels */
+  pl_shared *sh = c.sh;
+  if (tid != 0) return;
+  uint32_t run = 0;
+  for (uint32_t l = 0; l <= sh->nlev; l++) { run += c.lev_cnt[l]; c.lev_cnt[l] = run; }
+}
+template <int Z> SB_HD void pl_lev_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  for (uint32_t k = tid; k < sh->npiv; k += nt) {
+    uint32_t l = c.rowinfo[c.pivslot[k]];
+    uint32_t pos = PL_ATOM_ADD(&c.lev_fill[l], 1u);
+    c.by_level[c.lev_cnt[l] + pos] = k;
+  }
+}
+
+/* bit row over the inactive columns for constraint row r: its own inactive entries plus the W rows of
+ * its pivot columns (except `own`).  8 lanes cooperate, lane w8 owns words w8, w8+8, ... (<= 5 of them) */
+SB_HD void pl_bitrow(const PlanCtx &c, uint32_t r, uint32_t own, uint32_t w8, uint32_t wpr, uint32_t (&acc)[5],
+                     uint32_t *deg) {
+#pragma unroll
+  for (int q = 0; q < 5; q++) acc[q] = 0;
+  const uint16_t *cols;
+  const uint32_t n = pl_row(c, r, &cols);
+  uint32_t d = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t col = cols[k];
+    const uint32_t info = c.colinfo[col], st = info >> 30, idx = info & 0x3FFFFFFFu;
+    if (st == PL_ST_INACT) {
+      const uint32_t wd = idx >> 5;
+      if ((wd & 7u) == w8) acc[(wd >> 3) % 5u] ^= 1u << (idx & 31u);
+    } else if (col != own) { /* pivot column */
+      d++;
+      const uint32_t *src = c.wrows + (size_t)idx * wpr;
+#pragma unroll
+      for (uint32_t q = 0; q < 5; q++) {
+        const uint32_t wd = w8 + 8u * q;
+        if (wd < wpr) acc[q] ^= src[wd];
+      }
+    }
+  }
+  *deg = d;
+}
+
+/* one dependency level of W (8 lanes per pivot row) */
+template <int Z> SB_HD void pl_w_level(PlanCtx &c, uint32_t level, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr;
+  const uint32_t a = c.lev_cnt[level], b = c.lev_cnt[level + 1];
+  for (uint32_t j = a + grp; j < b; j += ngrp) {
+    const uint32_t k = c.by_level[j];
+    uint32_t acc[5], deg;
+    pl_bitrow(c, c.pivslot[k], c.pivcol[k], w8, wpr, acc, &deg);
+    uint32_t *dst = c.wrows + (size_t)k * wpr;
+#pragma unroll
+    for (uint32_t q = 0; q < 5; q++) {
+      const uint32_t wd = w8 + 8u * q;
+      if (wd < wpr) dst[wd] = acc[q];
+    }
+    if (w8 == 0) {
+      c.pivdeg[k] = deg;
+      PL_ATOM_ADD(&c.lev_ops[level], deg);
+    }
+  }
+}
+
+/* =============================== phase 3: leftover rows ====================================== */
+template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /* list them */
+  pl_shared *sh = c.sh;
+  const rq_params &p = c.p;
+  for (uint32_t r = tid; r < sh->M; r += nt) {
+    if (!(c.rowinfo[r] & PL_UNASSIGNED) || (r >= p.S && r < p.S + p.H)) continue;
+    uint32_t j = PL_ATOM_ADD(&sh->nlow, 1u);
+    if (j < c.ucap + 32u) c.lowslot[j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
+  }
+}
+template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (tid != 0) return;
+  sh->lpr = sh->nlow ? (sh->nlow + 31u) / 32u : 1u;
+  sh->rowlen = sh->wpr + sh->lpr;
+  /* Mb (nlow x rowlen words) and Mh (H x u bytes) share the dynamic LDS region from here on */
+  uint32_t need = pl_r16(sh->nlow * sh->rowlen * 4u) + pl_r16(PL_MAXH * (c.p.L - sh->npiv));
+  if (need > c.dense_bytes || sh->wpr > 40u) sh->status = PL_FAIL_CAPACITY;
+}
+SB_HD uint32_t *pl_mb(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(c.dense_lds); }
+SB_HD uint8_t *pl_mhm(const PlanCtx &c) { return c.dense_lds + pl_r16(c.sh->nlow * c.sh->rowlen * 4u); }
+
+/* reduced coefficient rows of the leftover rows over the inactive columns, with the augmented identity */
+template <int Z> SB_HD void pl_low_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr, rowlen = sh->rowlen;
+  uint32_t *Mb = pl_mb(c);
+  for (uint32_t j = grp; j < sh->nlow; j += ngrp) {
+    uint32_t acc[5], deg;
+    pl_bitrow(c, c.lowslot[j], PL_NONE, w8, wpr, acc, &deg);
+    uint32_t *dst = Mb + (size_t)j * rowlen;
+#pragma unroll
+    for (uint32_t q = 0; q < 5; q++) {
+      const uint32_t wd = w8 + 8u * q;
+      if (wd < wpr) dst[wd] = acc[q];
+    }
+    for (uint32_t wd = w8; wd < sh->lpr; wd += 8u) dst[wpr + wd] = (wd == (j >> 5)) ? (1u << (j & 31u)) : 0u;
+    if (w8 == 0) {
+      c.lowdeg[j] = deg;
+      PL_ATOM_ADD(&c.lev_ops[sh->nlev], deg); /* the leftover rows form one more accumulate-only group */
+    }
+  }
+}
+
+/* =============================== phase 4: op stream layout =================================== */
+template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (tid != 0) return;
+  /* chunk base of every level group (levels 1..nlev-1 are pivot groups, index nlev = leftover rows) */
+  uint32_t chunks = 0;
+  for (uint32_t l = 0; l <= sh->nlev; l++) {
+    c.lev_base[l] = chunks;
+    chunks += (c.lev_ops[l] + NRQ_CHUNK - 1u) / NRQ_CHUNK;
+    if (l + 1 == sh->nlev) sh->nchunk1 = chunks;
+    c.lev_fill[l] = 0;
+  }
+  if (sh->nlev == 0) sh->nchunk1 = 0;
+  sh->tmp0 = chunks; /* chunks so far; the GF(2) combination group follows after the elimination */
+  /* ops region: generous bound for the combination group (nlow ones per reduced row at most) */
+  uint32_t bin_bound = (sh->nlow * sh->nlow + NRQ_CHUNK - 1u) / NRQ_CHUNK + 1u;
+  uint32_t total_chunks = chunks + bin_bound + 8u;
+  sh->off_ops = pl_r16(c.fixed_end);
+  sh->nsyncw = (total_chunks + 31u) / 32u + 2u;
+  sh->off_sync = pl_r16(sh->off_ops + total_chunks * NRQ_CHUNK * 4u);
+  sh->arena_top = pl_r16(sh->off_sync + sh->nsyncw * 4u);
+  sh->opbase = total_chunks;
+  if (sh->arena_top > c.job.arena_cap) sh->status = PL_FAIL_CAPACITY;
+}
+template <int Z> SB_HD void pl_ops_clear(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
+  const uint32_t nw = sh->opbase * NRQ_CHUNK;
+  for (uint32_t k = tid; k < nw; k += nt) ops[k] = NRQ_NOP;
+  uint32_t *sy = reinterpret_cast<uint32_t *>(c.arena + sh->off_sync);
+  for (uint32_t k = tid; k < sh->nsyncw; k += nt) sy[k] = 0;
+}
+/* position of the i-th op of a run starting at `pos` inside a group of n ops: a multiplicative shuffle
+ * keeps the ops of one row apart so that the lanes of a wave rarely hit the same target slot */
+SB_HD uint32_t pl_spread(uint32_t pos, uint32_t n) {
+  static const uint32_t mult[6] = {61u, 67u, 71u, 73u, 79u, 83u};
+  if (n < 128u) return pos;
+  uint32_t m = 1u;
+#pragma unroll
+  for (int q = 5; q >= 0; q--)
+    if (n % mult[q]) m = mult[q];
+  return (uint32_t)(((uint64_t)pos * m) % n);
+}
+SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t group, uint32_t start, uint32_t dst) {
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + c.sh->off_ops) + (size_t)c.lev_base[group] * NRQ_CHUNK;
+  const uint32_t n = c.lev_ops[group];
+  const uint16_t *cols;
+  const uint32_t m = pl_row(c, r, &cols);
+  uint32_t i = start;
+  for (uint32_t k = 0; k < m; k++) {
+    const uint32_t col = cols[k], info = c.colinfo[col];
+    if ((info >> 30) != PL_ST_PIVOT || col == own) continue;
+    ops[pl_spread(i, n)] = dst | ((uint32_t)c.pivslot[info & 0x3FFFFFFFu] << 16);
+    i++;
+  }
+}
+template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  for (uint32_t k = tid; k < sh->npiv; k += nt) {
+    const uint32_t deg = c.pivdeg[k];
+    if (!deg) continue;
+    const uint32_t r = c.pivslot[k], l = c.rowinfo[r];
+    const uint32_t start = PL_ATOM_ADD(&c.lev_fill[l], deg);
+    pl_emit_row(c, r, c.pivcol[k], l, start, r);
+  }
+  for (uint32_t j = tid; j < sh->nlow; j += nt) {
+    const uint32_t deg = c.lowdeg[j];
+    if (!deg) continue;
+    const uint32_t start = PL_ATOM_ADD(&c.lev_fill[sh->nlev], deg);
+    pl_emit_row(c, c.lowslot[j], PL_NONE, sh->nlev, start, c.lowslot[j]);
+  }
+  /* barrier bits: after the last chunk of every non-empty group */
+  uint32_t *sy = reinterpret_cast<uint32_t *>(c.arena + sh->off_sync);
+  for (uint32_t l = tid; l <= sh->nlev; l += nt) {
+    const uint32_t nc = (c.lev_ops[l] + NRQ_CHUNK - 1u) / NRQ_CHUNK;
+    if (!nc) continue;
+    const uint32_t last = c.lev_base[l] + nc - 1u;
+    PL_ATOM_OR(&sy[last >> 5], 1u << (last & 31u));
+  }
+}
+
+/* =============================== phase 5: HDPC rows over the inactive columns ================= */
+template <int Z> SB_HD void pl_mh(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const rq_params &p = c.p;
+  const uint32_t u = p.L - sh->npiv, H = p.H, n_hd = p.Kp + p.S, wpr = sh->wpr;
+  uint8_t *Mh = pl_mhm(c);
+  for (uint32_t x = tid; x < u; x += nt) {
+    uint8_t acc[PL_MAXH];
+    const uint32_t col = c.ucol[x];
+#pragma unroll
+    for (uint32_t h = 0; h < PL_MAXH; h++)
+      acc[h] = h < H ? (col < n_hd ? c.G[(size_t)h * n_hd + col] : (uint8_t)(col - n_hd == h)) : 0;
+    const uint32_t wd = x >> 5, bt = x & 31u;
+    for (uint32_t k = 0; k < sh->npiv; k++) {
+      if ((c.wrows[(size_t)k * wpr + wd] >> bt) & 1u) {
+        const uint32_t pc = c.pivcol[k];
+#pragma unroll
+        for (uint32_t h = 0; h < PL_MAXH; h++)
+          if (h < H) acc[h] ^= c.G[(size_t)h * n_hd + pc];
+      }
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < PL_MAXH; h++)
+      if (h < H) Mh[(size_t)h * u + x] = acc[h];
+  }
+}
+
+/* =============================== phase 6: GF(2) Gauss-Jordan in LDS =========================== */
+/* step A of column x: every leftover row publishes its bit; unused rows with the bit set bid */
+template <int Z> SB_HD void pl_gj_a(PlanCtx &c, uint32_t x, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const uint32_t *Mb = pl_mb(c);
+  const uint32_t rowlen = sh->rowlen;
+  for (uint32_t j = tid; j < sh->nlow; j += nt) {
+    const uint32_t f = (Mb[(size_t)j * rowlen + (x >> 5)] >> (x & 31u)) & 1u;
+    c.flag[j] = (uint8_t)f;
+    if (f && !c.used[j]) PL_ATOM_MIN(&sh->cand[x & 1u], j);
+  }
+  if (tid == 0) sh->cand[(x & 1u) ^ 1u] = PL_NONE;
+}
+/* step B: eliminate the column from every other row that has it (or record a free column) */
+template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t x, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const uint32_t pr = sh->cand[x & 1u];
+  if (pr == PL_NONE) {
+    if (tid == 0) {
+      if (sh->nfree < NRQ_MAX_FREE) sh->freex[sh->nfree] = x;
+      sh->nfree++;
+    }
+    return;
+  }
+  uint32_t *Mb = pl_mb(c);
+  const uint32_t rowlen = sh->rowlen, total = sh->nlow * rowlen;
+  const uint32_t *src = Mb + (size_t)pr * rowlen;
+  for (uint32_t e = tid; e < total; e += nt) {
+    const uint32_t j = e / rowlen, wd = e - j * rowlen;
+    if (j != pr && c.flag[j]) Mb[e] ^= src[wd];
+  }
+  if (tid == 0) {
+    c.used[pr] = 1;
+    c.red_row[sh->r2] = pr;
+    c.red_x[sh->r2] = x;
+    sh->r2++;
+  }
+}
+
+/* the GF(2) combinations E_q (slot M+q) as one more accumulate-only group of XOR ops */
+template <int Z> SB_HD void pl_bin_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (tid == 0) {
+    if (sh->status == 0 && (sh->nfree > c.p.H || sh->nfree > NRQ_MAX_FREE)) sh->status = PL_FAIL_SINGULAR;
+    sh->tmp1 = 0;
+  }
+  const uint32_t *Mb = pl_mb(c);
+  for (uint32_t q = tid; q < sh->r2; q += nt) {
+    const uint32_t *aug = Mb + (size_t)c.red_row[q] * sh->rowlen + sh->wpr;
+    uint32_t n = 0;
+    for (uint32_t w = 0; w < sh->lpr; w++) n += (uint32_t)__builtin_popcount(aug[w]);
+    c.pivdeg[q] = n; /* reuse */
+  }
+}
+template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (tid != 0) return;
+  uint32_t run = 0;
+  for (uint32_t q = 0; q < sh->r2; q++) { uint32_t n = c.pivdeg[q]; c.pivdeg[q] = run; run += n; }
+  const uint32_t g = sh->nlev + 1u;
+  c.lev_ops[g] = run;
+  c.lev_base[g] = sh->tmp0;
+  const uint32_t nc = (run + NRQ_CHUNK - 1u) / NRQ_CHUNK;
+  sh->nchunk2 = sh->tmp0 + nc - sh->nchunk1;
+  if (sh->tmp0 + nc + 8u > sh->opbase && sh->status == 0) sh->status = PL_FAIL_CAPACITY;
+  if (nc) {
+    uint32_t *sy = reinterpret_cast<uint32_t *>(c.arena + sh->off_sync);
+    const uint32_t last = sh->tmp0 + nc - 1u;
+    sy[last >> 5] |= 1u << (last & 31u);
+  }
+}
+template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t g = sh->nlev + 1u, n = c.lev_ops[g];
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops) + (size_t)c.lev_base[g] * NRQ_CHUNK;
+  const uint32_t *Mb = pl_mb(c);
+  for (uint32_t q = tid; q < sh->r2; q += nt) {
+    const uint32_t *aug = Mb + (size_t)c.red_row[q] * sh->rowlen + sh->wpr;
+    uint32_t i = c.pivdeg[q];
+    for (uint32_t w = 0; w < sh->lpr; w++) {
+      uint32_t bits = aug[w];
+      while (bits) {
+        const uint32_t j = w * 32u + (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1u;
+        ops[pl_spread(i, n)] = (sh->M + q) | ((uint32_t)c.lowslot[j] << 16);
+        i++;
+      }
+    }
+  }
+}
+
+/* =============================== phase 7: the free columns over GF(256) ====================== */
+/* coefficient columns mh[h][q], free-column masks fbits[q], and the H x (nfree+H) augmented system */
+template <int Z> SB_HD void pl_dense_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t H = c.p.H, u = c.p.L - sh->npiv, r2 = sh->r2, nfree = sh->nfree;
+  const uint32_t *Mb = pl_mb(c);
+  const uint8_t *Mh = pl_mhm(c);
+  for (uint32_t q = tid; q < r2; q += nt) {
+    const uint32_t *row = Mb + (size_t)c.red_row[q] * sh->rowlen;
+    uint32_t fb = 0;
+    for (uint32_t f = 0; f < nfree; f++) {
+      const uint32_t x = sh->freex[f];
+      if ((row[x >> 5] >> (x & 31u)) & 1u) fb |= 1u << f;
+    }
+    c.fbits[q] = fb;
+    c.pivx[q] = (uint16_t)c.red_x[q];
+    for (uint32_t h = 0; h < H; h++) c.mh[(size_t)h * r2 + q] = Mh[(size_t)h * u + c.red_x[q]];
+  }
+  for (uint32_t f = tid; f < nfree; f += nt) c.freex_out[f] = (uint16_t)sh->freex[f];
+  for (uint32_t h = tid; h < PL_MAXH; h += nt) sh->taken[h] = 0;
+}
+template <int Z> SB_HD void pl_dense_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t H = c.p.H, u = c.p.L - sh->npiv, r2 = sh->r2, nfree = sh->nfree, aw = nfree + H;
+  const uint8_t *Mh = pl_mhm(c);
+  for (uint32_t e = tid; e < H * aw; e += nt) {
+    const uint32_t h = e / aw, w = e - h * aw;
+    uint8_t v;
+    if (w < nfree) {
+      v = Mh[(size_t)h * u + sh->freex[w]];
+      for (uint32_t q = 0; q < r2; q++)
+        if ((c.fbits[q] >> w) & 1u) v ^= c.mh[(size_t)h * r2 + q];
+    } else {
+      v = (uint8_t)((w - nfree) == h);
+    }
+    sh->aug[e] = v;
+  }
+}
+/* one elimination step on the augmented system: column f.  Thread w owns augmented column w. */
+template <int Z> SB_HD void pl_dense_step_a(PlanCtx &c, uint32_t f, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status || tid != 0) return;
+  const uint32_t H = c.p.H, aw = sh->nfree + H;
+  uint32_t pr = PL_NONE;
+  for (uint32_t h = 0; h < H; h++)
+    if (!sh->taken[h] && sh->aug[h * aw + f]) { pr = h; break; }
+  if (pr == PL_NONE) { sh->status = PL_FAIL_SINGULAR; return; }
+  sh->taken[pr] = 1;
+  sh->solver[f] = (uint8_t)pr;
+  sh->tmp1 = pr;
+  for (uint32_t h = 0; h < H; h++) sh->colf[h] = sh->aug[h * aw + f]; /* snapshot of the pivot column */
+}
+template <int Z> SB_HD void pl_dense_step_b(PlanCtx &c, uint32_t f, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t H = c.p.H, aw = sh->nfree + H, pr = sh->tmp1;
+  if (tid >= aw) return;
+  /* thread = augmented column; the pivot column is read from the snapshot step A took */
+  const uint8_t *colf = sh->colf;
+  (void)f;
+  const uint8_t piv = colf[pr];
+  const uint8_t inv = sh->gf_exp[255u - sh->gf_log[piv]];
+  const uint8_t scaled = pl_gfmul(sh, sh->aug[pr * aw + tid], inv);
+  for (uint32_t h = 0; h < H; h++) {
+    if (h == pr) continue;
+    if (colf[h]) sh->aug[h * aw + tid] ^= pl_gfmul(sh, colf[h], scaled);
+  }
+  sh->aug[pr * aw + tid] = scaled;
+}
+template <int Z> SB_HD void pl_dense_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t H = c.p.H, nfree = sh->nfree, aw = nfree + H;
+  for (uint32_t e = tid; e < nfree * H; e += nt) {
+    const uint32_t f = e / H, h = e - f * H;
+    c.hinv[e] = sh->aug[sh->solver[f] * aw + nfree + h];
+  }
+}
+
+template <int Z> SB_HD void pl_mark_failed(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  if (tid == 0) c.sh->status = PL_FAIL_CAPACITY;
+}
+
+/* =============================== phase 8: maps, W image, job ================================= */
+template <int Z> SB_HD void pl_final_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const rq_params &p = c.p;
+  const uint32_t n_hd = p.Kp + p.S, u = p.L - sh->npiv;
+  for (uint32_t col = tid; col < ((n_hd + 7u) & ~7u); col += nt) c.pivof[col] = NRQ_NOSLOT;
+  if (tid == 0) {
+    /* W image and the per-block tail (rowsrc, output lists) go after the op stream */
+    sh->tmp0 = (sh->npiv + 63u) & ~63u; /* npiv_pad */
+  }
+  /* homes of the inactive columns: the rows that did not become pivots, any one-to-one assignment */
+  for (uint32_t r = tid; r < sh->M; r += nt) {
+    if (!(c.rowinfo[r] & PL_UNASSIGNED)) continue;
+    uint32_t x = PL_ATOM_ADD(&sh->uslot_fill, 1u);
+    if (x < u) { c.uslot[x] = (uint16_t)r; c.colslot[c.ucol[x]] = (uint16_t)r; }
+  }
+}
+template <int Z> SB_HD void pl_final_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  for (uint32_t k = tid; k < sh->npiv; k += nt) {
+    c.colslot[c.pivcol[k]] = c.pivslot[k];
+    c.pivof[c.pivcol[k]] = c.pivslot[k];
+  }
+  if (tid == 0) {
+    const rq_params &p = c.p;
+    const uint32_t nl = c.job.nlost;
+    uint32_t o = sh->arena_top;
+    sh->partial[0] = o; o = pl_r16(o + sh->wpr * sh->tmp0 * 4u);          /* wt */
+    sh->partial[1] = o; o = pl_r16(o + sh->M * 4u);                       /* rowsrc */
+    sh->partial[2] = o; o = pl_r16(o + (nl + 1u) * 4u);                   /* out_cptr */
+    sh->partial[3] = o; o = pl_r16(o + nl * 4u + 4u);                     /* out_row */
+    sh->partial[4] = o; o = pl_r16(o + nl * PL_PATCH_STRIDE * 2u + 16u);  /* out_slots */
+    sh->arena_top = o;
+    if (o > c.job.arena_cap) sh->status = PL_FAIL_CAPACITY;
+    (void)p;
+  }
+}
+template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const rq_params &p = c.p;
+  const uint32_t wpr = sh->wpr, stride = sh->tmp0, nl = c.job.nlost;
+  uint32_t *wt = reinterpret_cast<uint32_t *>(c.arena + sh->partial[0]);
+  for (uint32_t e = tid; e < wpr * stride; e += nt) {
+    const uint32_t w = e / stride, k = e - w * stride;
+    wt[e] = k < sh->npiv ? c.wrows[(size_t)k * wpr + w] : 0u;
+  }
+  uint32_t *rowsrc = reinterpret_cast<uint32_t *>(c.arena + sh->partial[1]);
+  for (uint32_t r = tid; r < sh->M; r += nt) {
+    uint32_t v = NRQ_ROW_ZERO;
+    const uint32_t pi = c.patch_of[r];
+    if (pi != 0xFFFFu) v = NRQ_ROW_REP | pi;
+    else if (r >= p.S + p.H && r < p.S + p.H + p.K) v = r - p.S - p.H;
+    rowsrc[r] = v;
+  }
+  /* the missing source symbols as LT combinations of slots (ISI of a source symbol = its ESI) */
+  uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + sh->partial[2]);
+  uint32_t *orow = reinterpret_cast<uint32_t *>(c.arena + sh->partial[3]);
+  uint16_t *osl = reinterpret_cast<uint16_t *>(c.arena + sh->partial[4]);
+  for (uint32_t g = tid; g < nl; g += nt) {
+    const uint32_t e = c.lost[g];
+    c.pivdeg[g] = c.b_rptr[p.S + p.H + e + 1] - c.b_rptr[p.S + p.H + e];
+    orow[g] = e;
+  }
+  (void)cptr; (void)osl;
+}
+template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const rq_params &p = c.p;
+  if (tid != 0) return;
+  nrq_plan_hdr h;
+  memset(&h, 0, sizeof(h));
+  h.magic = NRQ_PLAN_MAGIC;
+  h.status = sh->status ? 1u : 0u;
+  h.reserved[0] = sh->status; /* PL_FAIL_* reason */
+  h.K = p.Kp; h.Kp = p.Kp; h.S = p.S; h.H = p.H; h.W = p.W; h.L = p.L; h.P = p.P; h.B = p.B;
+  h.M = sh->M; h.npiv = sh->npiv; h.u = p.L - sh->npiv; h.nlow = sh->nlow; h.r2 = sh->r2; h.nfree = sh->nfree;
+  h.nlev = sh->nlev; h.nchunk1 = sh->nchunk1; h.nchunk2 = sh->nchunk2; h.wpr = sh->wpr; h.lpr = sh->lpr;
+  h.npiv_pad = sh->tmp0;
+  h.off_ops = sh->off_ops; h.off_pivslot = c.off_pivslot; h.off_pivcol = c.off_pivcol; h.off_wt = sh->partial[0];
+  h.off_lowslot = c.off_lowslot; h.off_g2 = 0; h.off_pivx = c.off_pivx; h.off_fbits = c.off_fbits; h.off_mh = c.off_mh;
+  h.off_freex = c.off_freex; h.off_hinv = c.off_hinv; h.off_colslot = c.off_colslot; h.off_pivof = c.off_pivof;
+  h.off_uslot = c.off_uslot; h.off_sync = sh->off_sync; h.total_bytes = sh->arena_top;
+  if (!sh->status) {
+    const uint32_t nl = c.job.nlost;
+    uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + sh->partial[2]);
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < nl; g++) { cptr[g] = run; run += c.pivdeg[g]; }
+    cptr[nl] = run;
+    h.n_xor_ops = c.lev_ops[sh->nlev + 1u] + run;
+    for (uint32_t l = 0; l <= sh->nlev; l++) h.n_xor_ops += c.lev_ops[l];
+  }
+  *c.hdr = h;
+  if (c.jobout) {
+    nrq_job j;
+    memset(&j, 0, sizeof(j));
+    j.plan = (uint64_t)(uintptr_t)c.arena;
+    if (!sh->status) {
+      j.rowsrc = (uint64_t)(uintptr_t)(c.arena + sh->partial[1]);
+      j.src = c.job.src; j.rep = c.job.rep; j.inter = c.job.inter; j.out = c.job.src;
+      j.out_cptr = (uint64_t)(uintptr_t)(c.arena + sh->partial[2]);
+      j.out_row = (uint64_t)(uintptr_t)(c.arena + sh->partial[3]);
+      j.out_slots = (uint64_t)(uintptr_t)(c.arena + sh->partial[4]);
+      j.nout = c.job.nlost;
+    }
+    *c.jobout = j;
+  }
+}
+
+/* the missing source symbols' LT neighbour lists, translated to slots (uses cptr from the step before) */
+template <int Z> SB_HD void pl_final_e(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const rq_params &p = c.p;
+  const uint32_t nl = c.job.nlost;
+  const uint32_t *cptr = reinterpret_cast<const uint32_t *>(c.arena + sh->partial[2]);
+  uint16_t *osl = reinterpret_cast<uint16_t *>(c.arena + sh->partial[4]);
+  for (uint32_t g = tid; g < nl; g += nt) {
+    const uint32_t e = c.lost[g], a = c.b_rptr[p.S + p.H + e], n = c.b_rptr[p.S + p.H + e + 1] - a;
+    for (uint32_t k = 0; k < n; k++) osl[cptr[g] + k] = c.colslot[c.b_cidx[a + k]];
+  }
+}
+
+#endif /* NRQ_PLANNER_BODY_H */

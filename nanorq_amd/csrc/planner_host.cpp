@@ -69,13 +69,62 @@ inline void flip(uint32_t *row, uint32_t x) { row[x >> 5] ^= 1u << (x & 31); }
 extern "C" int nrq_host_kconst_build(uint32_t K, uint8_t **out, uint32_t *out_bytes) {
   rq_params p;
   if (!rq_params_init(K, &p)) return -1;
-  const uint32_t n = p.Kp + p.S, H = p.H;
+  const uint32_t n = p.Kp + p.S, H = p.H, S = p.S, L = p.L, W = p.W;
+  /* base structure: LDPC rows, empty HDPC rows, LT rows of ISI 0..K'-1 */
+  std::vector<uint32_t> rptr(L + 1, 0);
+  std::vector<uint16_t> cidx;
+  {
+    std::vector<std::vector<uint16_t>> ldpc(S);
+    for (uint32_t c = 0; c < p.B; c++) {
+      uint32_t blk = c / S;
+      ldpc[c % S].push_back((uint16_t)c);
+      ldpc[(c + blk + 1) % S].push_back((uint16_t)c);
+      ldpc[(c + 2 * (blk + 1)) % S].push_back((uint16_t)c);
+    }
+    for (uint32_t r = 0; r < S; r++) {
+      ldpc[r].push_back((uint16_t)(p.B + r));
+      ldpc[r].push_back((uint16_t)(W + r % p.P));
+      ldpc[r].push_back((uint16_t)(W + (r + 1) % p.P));
+      rptr[r] = (uint32_t)cidx.size();
+      cidx.insert(cidx.end(), ldpc[r].begin(), ldpc[r].end());
+    }
+    for (uint32_t r = S; r < S + H; r++) rptr[r] = (uint32_t)cidx.size();
+    uint32_t tmp[RQ_MAX_LT_COLS];
+    for (uint32_t j = 0; j < p.Kp; j++) {
+      rptr[S + H + j] = (uint32_t)cidx.size();
+      uint32_t m = rq_lt_columns(&p, j, tmp);
+      for (uint32_t q = 0; q < m; q++) cidx.push_back((uint16_t)tmp[q]);
+    }
+    rptr[L] = (uint32_t)cidx.size();
+  }
+  const uint32_t nnz = (uint32_t)cidx.size();
+  std::vector<uint32_t> cptr(L + 1, 0), state(L, 0);
+  std::vector<uint16_t> ridx(nnz);
+  for (uint16_t c : cidx) cptr[c + 1]++;
+  for (uint32_t c = 0; c < L; c++) cptr[c + 1] += cptr[c];
+  {
+    std::vector<uint32_t> fill(cptr.begin(), cptr.end() - 1);
+    for (uint32_t r = 0; r < L; r++) {
+      uint32_t cnt = 0, sum = 0;
+      for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++) {
+        ridx[fill[cidx[e]]++] = (uint16_t)r;
+        if (cidx[e] < W) { cnt++; sum += cidx[e]; }
+      }
+      if (cnt > 255 || sum >= (1u << 24)) return -6; /* does not happen for RFC 6330 parameters */
+      state[r] = (cnt << 24) | sum;
+    }
+  }
   nrq_kconst_hdr h;
   memset(&h, 0, sizeof(h));
-  h.Kp = p.Kp; h.S = p.S; h.H = H; h.n = n;
+  h.Kp = p.Kp; h.S = S; h.H = H; h.n = n; h.L = L; h.W = W; h.P = p.P; h.nnz = nnz;
   uint32_t off = align16((uint32_t)sizeof(h));
   h.off_g = off; off = align16(off + H * n);
   h.off_b12 = off; off = align16(off + n);
+  h.off_rptr = off; off = align16(off + (L + 1) * 4);
+  h.off_cidx = off; off = align16(off + nnz * 2);
+  h.off_cptr = off; off = align16(off + (L + 1) * 4);
+  h.off_ridx = off; off = align16(off + nnz * 2);
+  h.off_state = off; off = align16(off + L * 4);
   h.total_bytes = off;
   uint8_t *buf = (uint8_t *)calloc(off, 1);
   if (!buf) return -2;
@@ -94,6 +143,11 @@ extern "C" int nrq_host_kconst_build(uint32_t K, uint8_t **out, uint32_t *out_by
     G[(size_t)b2 * n + c] ^= 1;
     b12[c] = (uint8_t)(b1 | (b2 << 4));
   }
+  memcpy(buf + h.off_rptr, rptr.data(), (size_t)(L + 1) * 4);
+  memcpy(buf + h.off_cidx, cidx.data(), (size_t)nnz * 2);
+  memcpy(buf + h.off_cptr, cptr.data(), (size_t)(L + 1) * 4);
+  memcpy(buf + h.off_ridx, ridx.data(), (size_t)nnz * 2);
+  memcpy(buf + h.off_state, state.data(), (size_t)L * 4);
   memcpy(buf, &h, sizeof(h));
   *out = buf;
   *out_bytes = off;

@@ -1,0 +1,78 @@
+/*
+ * planner_seq.h -- the phase sequence of the GPU planner, shared verbatim by the HIP kernel and the
+ * CPU emulator.  The includer defines
+ *     PL_PHASE(fn)        run phase fn(c, tid, PL_NT) on every thread of the workgroup, then barrier
+ *     PL_PHASE1(fn, a)    same with one extra leading argument
+ * and provides `PlanCtx c`.  Every value that steers control flow is read from workgroup-shared state
+ * right after a barrier, so all threads take the same path.
+ */
+{
+  pl_shared *sh_ = c.sh;
+  PL_PHASE(pl_init_a);
+  PL_PHASE(pl_init_b);
+  PL_PHASE(pl_scan_a);
+  PL_PHASE(pl_scan_b);
+  PL_PHASE(pl_scan_c);
+  PL_PHASE(pl_pcsc_fill);
+  /* ---- peeling ---- */
+  {
+    const uint32_t guard_max = 4u * c.p.L + 64u;
+    uint32_t guard = 0;
+    while (sh_->status == 0 && sh_->nV > 0 && guard++ < guard_max) {
+      if (sh_->nfront > 0) {
+        PL_PHASE(pl_round_claim);
+        PL_PHASE(pl_round_pivot);
+        PL_PHASE(pl_round_drop);
+        PL_PHASE(pl_round_swap);
+      } else {
+        PL_PHASE(pl_inact_find);
+        PL_PHASE(pl_inact_apply_a);
+        PL_PHASE(pl_inact_apply_b);
+        PL_PHASE(pl_inact_apply_c);
+      }
+    }
+  }
+  PL_PHASE(pl_lev_a);
+  if (sh_->status == 0 && sh_->nV == 0) {
+    PL_PHASE(pl_lev_b);
+    PL_PHASE(pl_lev_c);
+    PL_PHASE(pl_lev_d);
+    for (uint32_t lv_ = 0; lv_ < sh_->nlev; lv_++) PL_PHASE1(pl_w_level, lv_);
+    PL_PHASE(pl_low_a);
+    PL_PHASE(pl_low_b);
+  }
+  if (sh_->status == 0 && sh_->nV == 0) {
+    PL_PHASE(pl_low_c);
+    PL_PHASE(pl_ops_layout);
+    PL_PHASE(pl_ops_clear);
+    PL_PHASE(pl_ops_emit);
+    PL_PHASE(pl_mh);
+    {
+      const uint32_t u_ = c.p.L - sh_->npiv;
+      for (uint32_t x_ = 0; x_ < u_; x_++) {
+        PL_PHASE1(pl_gj_a, x_);
+        PL_PHASE1(pl_gj_b, x_);
+      }
+    }
+    PL_PHASE(pl_bin_a);
+    PL_PHASE(pl_bin_b);
+    PL_PHASE(pl_bin_c);
+    PL_PHASE(pl_dense_a);
+    PL_PHASE(pl_dense_b);
+    if (sh_->status == 0) {
+      const uint32_t nf_ = sh_->nfree;
+      for (uint32_t f_ = 0; f_ < nf_; f_++) {
+        PL_PHASE1(pl_dense_step_a, f_);
+        PL_PHASE1(pl_dense_step_b, f_);
+      }
+    }
+    PL_PHASE(pl_dense_c);
+    PL_PHASE(pl_final_a);
+    PL_PHASE(pl_final_b);
+    PL_PHASE(pl_final_c);
+  } else if (sh_->status == 0) {
+    PL_PHASE(pl_mark_failed); /* peeling did not terminate: report the block as undecodable */
+  }
+  PL_PHASE(pl_final_d);
+  PL_PHASE(pl_final_e);
+}

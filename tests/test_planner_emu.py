@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import nanorq_amd
-from emu_support import ROW_ZERO, decode_setup, emu, emu_solve, lt_lists
+from emu_support import ROW_ZERO, decode_setup, emu, emu_device_plan, emu_solve, lt_lists
 from util import loss_pattern, payload, received_set
 
 
@@ -98,3 +98,63 @@ def test_lds_budget_of_headline_config(orc):
     assert emu().emu_lds_bytes(C.addressof(buf), 16) <= 163840
     hdr = nanorq_amd.plan_header(plan)
     assert hdr["nlev"] < 600  # breadth-first peeling keeps the dependency depth low
+
+
+@pytest.mark.parametrize("K,T,wb,p,oh,lds", [(10, 16, 16, 0.3, 0, 140), (10, 16, 16, 0.3, 4, 140), (100, 32, 16, 0.06, 0, 140),
+                                             (100, 8, 8, 0.4, 25, 140), (1024, 16, 16, 0.05, 0, 140),
+                                             (1024, 16, 16, 0.06, 52, 24), (8192, 16, 16, 0.1, 0, 140),
+                                             (8192, 16, 16, 0.1, 2, 60)])
+def test_device_planner_emulated_matches_oracle(orc, K, T, wb, p, oh, lds):
+    """The GPU planner's phase code (planner_body.h), emulated, then the emulated solve: decoded data must be
+    the oracle's; `lds` (KiB) small enough forces the peeling state out of LDS into the HBM workspace."""
+    prm = orc.params(K)
+    src = payload(K * T, seed=15).reshape(K, T)
+    kc = nanorq_amd.host_kconst(K)
+    done = 0
+    for seed in range(1, 4):
+        lost = loss_pattern(K, p, seed)
+        if len(lost) == 0:
+            continue
+        esis = received_set(K, lost, oh)
+        rep_esis = esis[esis >= K]
+        rep, _, _ = orc.encode_block(src, K, T, rep_esis)
+        syms = np.concatenate([src[esis[esis < K]], rep])
+        ok, ref_out, _ = orc.decode_block(esis, syms, K, T)
+        plan, hdr = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=lds * 1024)
+        assert (hdr["status"] == 0) == ok
+        if not ok:
+            continue
+        _, rowsrc = decode_setup(orc, K, lost, rep_esis)
+        work = src.copy()
+        work[lost] = 0x77
+        lists = lt_lists(orc, K, lost, plan)
+        r, inter = emu_solve(plan, kc, rowsrc, work, rep, T, prm["L"], lists, lost, work, wb)
+        assert r == 1 and np.array_equal(work, src)
+        done += 1
+    assert done >= 1
+
+
+def test_device_planner_failure_parity(orc):
+    K = 12
+    kc = nanorq_amd.host_kconst(K)
+    rng = np.random.default_rng(11)
+    nfail = 0
+    for trial in range(300):
+        nl = int(rng.integers(1, 7))
+        lost = np.sort(rng.choice(K, nl, replace=False)).astype(np.uint32)
+        rep_esis = (K + rng.choice(60, nl, replace=False)).astype(np.uint32)
+        isis, _ = decode_setup(orc, K, lost, rep_esis)
+        r, _ = orc.plan_probe(K, isis)
+        _, hdr = emu_device_plan(K, kc, lost, rep_esis)
+        assert (hdr["status"] == 0) == (r == 1), (trial, lost, rep_esis)
+        nfail += (r == 0)
+    assert nfail > 0
+
+
+def test_device_planner_rejects_bad_input(orc):
+    K = 100
+    kc = nanorq_amd.host_kconst(K)
+    assert emu_device_plan(K, kc, [5, 3], [100, 101])[1]["status"] == 1      # not ascending
+    assert emu_device_plan(K, kc, [5, 7], [100])[1]["status"] == 1           # fewer repair symbols than gaps
+    assert emu_device_plan(K, kc, [5, 200], [100, 101])[1]["status"] == 1    # ESI outside the block
+    assert emu_device_plan(K, kc, [5, 7], [100, 50])[1]["status"] == 1       # repair ESI below K
