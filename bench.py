@@ -161,28 +161,24 @@ def main():
         ctx.encode_blocks(K, T, NB, src.data_ptr(), K * T, rep.data_ptr(), nrep * T, esis, inter.data_ptr(), L * T)
         enc_stats = ctx.stats()
         extra = np.full(NB, args.overhead, np.uint32)
-        pending = np.arange(NB)
+        todo = nlost.copy()   # blocks still to decode keep their loss count, finished ones are masked to 0
         dec_stats = None
-        while len(pending):
-            nr = (nlost[pending] + extra[pending]).astype(np.uint32)
-            if len(pending) == NB:
-                st = ctx.decode_blocks(K, T, NB, work.data_ptr(), K * T, lost_arr, nlost, resi, nr, rep.data_ptr(),
-                                       nrep * T)
-                if dec_stats is None:
-                    dec_stats = ctx.stats()
-            else:  # rank-deficient blocks: one more repair symbol each (nanorq_repair_block is retryable)
-                st = np.zeros(len(pending), np.int32)
-                for i, b in enumerate(pending):
-                    s1 = ctx.decode_blocks(K, T, 1, work.data_ptr() + int(b) * K * T, K * T, lost_arr[b:b + 1],
-                                           nlost[b:b + 1], resi[b:b + 1], nr[i:i + 1],
-                                           rep.data_ptr() + int(b) * nrep * T, nrep * T)
-                    st[i] = s1[0]
-            failed = pending[st == 0]
+        while True:
+            nr = (nlost + extra).astype(np.uint32)
+            st = ctx.decode_blocks(K, T, NB, work.data_ptr(), K * T, lost_arr, todo, resi, nr, rep.data_ptr(), nrep * T)
+            if dec_stats is None:
+                dec_stats = ctx.stats()
+            failed = np.nonzero((st == 0) & (todo > 0))[0]
+            if len(failed) == 0:
+                break
+            # rank-deficient blocks: one more repair symbol each, retried as ONE batch (nanorq_repair_block is
+            # retryable after more symbols arrive)
             retries += len(failed)
             extra[failed] += 1
-            if len(failed) and int(extra[failed].max()) > 2 + args.overhead:
+            if int(extra[failed].max()) > 3 + args.overhead:
                 raise RuntimeError("decode keeps failing")
-            pending = failed
+            todo = np.zeros_like(nlost)
+            todo[failed] = nlost[failed]
         return enc_stats, dec_stats
 
     def barrier():

@@ -139,12 +139,58 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
 #undef NRQ_STAMP
 }
 
+enum {
+  pl_tag_pl_init_a = 0,
+  pl_tag_pl_init_b = 0,
+  pl_tag_pl_scan_a = 0,
+  pl_tag_pl_scan_b = 0,
+  pl_tag_pl_scan_c = 0,
+  pl_tag_pl_pcsc_fill = 0,
+  pl_tag_pl_round_claim = 1,
+  pl_tag_pl_round_drop = 3,
+  pl_tag_pl_inact_find = 5,
+  pl_tag_pl_inact_apply_a = 6,
+  pl_tag_pl_inact_apply_b = 6,
+  pl_tag_pl_lev_a = 7,
+  pl_tag_pl_lev_b = 7,
+  pl_tag_pl_lev_c = 7,
+  pl_tag_pl_lev_d = 7,
+  pl_tag_pl_w_init = 8,
+  pl_tag_pl_w_group = 8,
+  pl_tag_pl_low_a = 9,
+  pl_tag_pl_low_b = 9,
+  pl_tag_pl_low_c = 9,
+  pl_tag_pl_ops_layout = 10,
+  pl_tag_pl_ops_clear = 10,
+  pl_tag_pl_ops_emit = 10,
+  pl_tag_pl_mh_init = 11,
+  pl_tag_pl_mh_load = 11,
+  pl_tag_pl_mh_acc = 11,
+  pl_tag_pl_gj_a = 12,
+  pl_tag_pl_gj_b = 12,
+  pl_tag_pl_bin_a = 13,
+  pl_tag_pl_bin_b = 13,
+  pl_tag_pl_bin_c = 13,
+  pl_tag_pl_dense_a = 14,
+  pl_tag_pl_dense_b = 14,
+  pl_tag_pl_dense_step_a = 14,
+  pl_tag_pl_dense_step_b = 14,
+  pl_tag_pl_dense_c = 14,
+  pl_tag_pl_final_a = 15,
+  pl_tag_pl_final_b = 15,
+  pl_tag_pl_final_c = 15,
+  pl_tag_pl_final_d = 15,
+  pl_tag_pl_final_e = 15,
+  pl_tag_pl_mark_failed = 15,
+};
+
 /* The symbolic stage of one decode block per workgroup (phases in planner_body.h, order in
  * planner_seq.h): reception pattern -> device plan + the block's solve job. */
 __global__ __launch_bounds__(PL_NT) void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
                                                          const nrq_planjob *__restrict__ pjobs,
                                                          nrq_job *__restrict__ jobs_out, uint32_t nblk, uint32_t Mcap,
-                                                         uint32_t npcap, uint32_t ucap, uint32_t lds_dyn_bytes) {
+                                                         uint32_t npcap, uint32_t ucap, uint32_t lds_dyn_bytes,
+                                                         unsigned long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= nblk) return;
@@ -152,11 +198,16 @@ __global__ __launch_bounds__(PL_NT) void nrq_plan_kernel(rq_params p, const uint
   uint8_t *dyn = smem + ((sizeof(pl_shared) + 15u) & ~(size_t)15u);
   PlanCtx c;
   pl_ctx_setup(c, p, kc, pjobs[b], sh, dyn, lds_dyn_bytes, Mcap, npcap, ucap, jobs_out + b);
-#define PL_PHASE(fn) do { fn<0>(c, tid, PL_NT); __syncthreads(); } while (0)
-#define PL_PHASE1(fn, a) do { fn<0>(c, (a), tid, PL_NT); __syncthreads(); } while (0)
+  /* NRQ_PROF=1: thread 0 of block 0 accumulates shader clocks per phase family (index = PL_TAG) */
+  unsigned long long t_prev = prof ? (unsigned long long)clock64() : 0ull;
+#define PL_ACC(tag) do { if (prof && b == 0 && tid == 0) { unsigned long long t_ = (unsigned long long)clock64(); \
+                                                          prof[tag] += t_ - t_prev; prof[16 + tag] += 1; t_prev = t_; } } while (0)
+#define PL_PHASE(fn) do { fn<0>(c, tid, PL_NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
+#define PL_PHASE1(fn, a) do { fn<0>(c, (a), tid, PL_NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
 #include "planner_seq.h"
 #undef PL_PHASE
 #undef PL_PHASE1
+#undef PL_ACC
 }
 
 /* One workgroup per (symbol, block): out = XOR of the LT neighbours of `isi` among the L
@@ -861,10 +912,28 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     ctx->plan_attr = true;
   }
+  unsigned long long *pprof = nullptr;
+  if (getenv("NRQ_PROF")) {
+    HIPCHK(ctx, hipMalloc((void **)&pprof, 32 * 8));
+    HIPCHK(ctx, hipMemsetAsync(pprof, 0, 32 * 8, ctx->stream));
+  }
   hipLaunchKernelGGL(nrq_plan_kernel, dim3(nblk), dim3(PL_NT), NRQ_LDS_MAX, ctx->stream, p, (const uint8_t *)kc->dev,
                      reinterpret_cast<const nrq_planjob *>(ds + off_pj), reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk,
-                     Mcap, npcap, ucap, dyn_bytes);
+                     Mcap, npcap, ucap, dyn_bytes, pprof);
   HIPCHK(ctx, hipGetLastError());
+  if (pprof) {
+    unsigned long long hp[32];
+    HIPCHK(ctx, hipMemcpyAsync(hp, pprof, sizeof(hp), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    static const char *nm[16] = {"init", "claim", "pivot", "drop", "swap", "ifind", "iapply", "lev", "W", "low", "ops", "mh",
+                                 "gj", "bin", "dense", "final"};
+    unsigned long long tot = 0;
+    for (int k = 0; k < 16; k++) tot += hp[k];
+    fprintf(stderr, "[NRQ_PROF] planner nblk=%u total=%llu clk:", nblk, tot);
+    for (int k = 0; k < 16; k++) fprintf(stderr, " %s=%llu(%llu)", nm[k], hp[k], hp[16 + k]);
+    fprintf(stderr, "\n");
+    (void)hipFree(pprof);
+  }
   HIPCHK(ctx, hipMemcpy2DAsync(hs + off_hdrs, sizeof(nrq_plan_hdr), ctx->plan_arena.p, arena_cap, sizeof(nrq_plan_hdr), nblk,
                                hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->staged[f], ctx->stream));

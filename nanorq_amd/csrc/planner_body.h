@@ -32,7 +32,9 @@
 
 #define PL_NT 256u
 #define PL_QCAP 2048u          /* frontier / claim queue capacity */
-#define PL_UNASSIGNED 0x80000000u
+#define PL_UNASSIGNED 0x80000000u /* rowinfo bit 31: row has no pivot column (yet) */
+#define PL_PATCHED 0x40000000u    /* rowinfo bit 30: this block replaced the base row (its base CSC entries are void) */
+#define PL_LEVEL_MASK 0x3FFFFFFFu /* rowinfo bits 0..29: dependency level (so far) */
 #define PL_ST_V 0u
 #define PL_ST_PIVOT 1u
 #define PL_ST_INACT 2u
@@ -40,6 +42,8 @@
 #define PL_NONE 0xFFFFFFFFu
 #define PL_MAXH 16u
 #define PL_PATCH_STRIDE RQ_MAX_LT_COLS
+#define PL_MH_TILE 128u
+#define PL_LOWCAP 1344u /* leftover rows the dense stage can take (>= inactive-column cap 1280 + 32) */
 #define PL_DENSE_RESERVE (36u * 1024u) /* LDS kept for the dense stage when the peeling state is in LDS too */
 
 /* what the host hands the planner for one block */
@@ -61,6 +65,7 @@ typedef struct nrq_planjob {
 #define PL_ATOM_MAX(p, v) atomicMax((p), (v))
 #define PL_ATOM_MIN(p, v) atomicMin((p), (v))
 #define PL_ATOM_OR(p, v) atomicOr((p), (v))
+#define PL_ATOM_XOR(p, v) atomicXor((p), (v))
 #define PL_ATOM_CAS(p, c, v) atomicCAS((p), (c), (v))
 #else
 static inline uint32_t pl_add_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -68,12 +73,14 @@ static inline uint32_t pl_sub_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = 
 static inline uint32_t pl_max_(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 static inline uint32_t pl_min_(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 static inline uint32_t pl_or_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+static inline uint32_t pl_xor_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o ^ v; return o; }
 static inline uint32_t pl_cas_(uint32_t *p, uint32_t c, uint32_t v) { uint32_t o = *p; if (o == c) *p = v; return o; }
 #define PL_ATOM_ADD(p, v) pl_add_((p), (v))
 #define PL_ATOM_SUB(p, v) pl_sub_((p), (v))
 #define PL_ATOM_MAX(p, v) pl_max_((p), (v))
 #define PL_ATOM_MIN(p, v) pl_min_((p), (v))
 #define PL_ATOM_OR(p, v) pl_or_((p), (v))
+#define PL_ATOM_XOR(p, v) pl_xor_((p), (v))
 #define PL_ATOM_CAS(p, c, v) pl_cas_((p), (c), (v))
 #endif
 
@@ -89,7 +96,7 @@ typedef struct pl_shared {
   uint32_t status;
   uint32_t M, overhead, npatch, wpr, lpr, rowlen;
   uint32_t nV, npiv, ninact, nlev;
-  uint32_t nfront, nnext, nclaim, cur; /* cur: which of the two queues is the frontier */
+  uint32_t nq[2], nclaim[2]; /* frontier / claim counts, indexed by round parity */
   uint32_t best;
   uint32_t nlow, r2, nfree, cand[2];
   uint32_t arena_top, nchunk1, nchunk2, nops_real, opbase;
@@ -104,6 +111,7 @@ typedef struct pl_shared {
   uint8_t solver[NRQ_MAX_FREE];
   uint8_t taken[PL_MAXH];
   uint8_t colf[PL_MAXH];
+  uint8_t gj_flag[PL_LOWCAP], gj_used[PL_LOWCAP]; /* Gauss-Jordan: bit of the current column / row already a pivot */
 } pl_shared;
 
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
@@ -126,7 +134,7 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.pc_fill = o;    o = pl_r16(o + (L + 1u) * 4u);
   w.pc_rows = o;    o = pl_r16(o + npcap * PL_PATCH_STRIDE * 2u);
   w.ucol = o;       o = pl_r16(o + ucap * 2u);
-  w.wrows = o;      o = pl_r16(o + L * wprcap * 4u);
+  w.wrows = o;      o = pl_r16(o + Mcap * wprcap * 4u); /* W rows by SLOT (pivot rows and leftover rows) */
   w.by_level = o;   o = pl_r16(o + L * 4u);
   w.lev_cnt = o;    o = pl_r16(o + (L + 2u) * 4u);
   w.lev_ops = o;    o = pl_r16(o + (L + 2u) * 4u);
@@ -160,7 +168,7 @@ struct PlanCtx {
   const nrq_kconst_hdr *kh;
   const uint32_t *b_rptr, *b_cptr, *b_state;
   const uint16_t *b_cidx, *b_ridx;
-  const uint8_t *G;
+  const uint8_t *G, *GT;
   nrq_planjob job;
   const uint32_t *lost, *rep_esi;
   pl_shared *sh;
@@ -200,6 +208,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.b_ridx = reinterpret_cast<const uint16_t *>(kc + c.kh->off_ridx);
   c.b_state = reinterpret_cast<const uint32_t *>(kc + c.kh->off_state);
   c.G = kc + c.kh->off_g;
+  c.GT = kc + c.kh->off_gt;
   c.job = job;
   c.lost = reinterpret_cast<const uint32_t *>(job.lost);
   c.rep_esi = reinterpret_cast<const uint32_t *>(job.rep_esi);
@@ -309,7 +318,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->M = p.L + oh;
     sh->npatch = st ? 0 : nr;
     sh->nV = p.W; sh->npiv = 0; sh->ninact = 0; sh->nlev = 0;
-    sh->nfront = 0; sh->nnext = 0; sh->nclaim = 0; sh->cur = 0; sh->best = PL_NONE;
+    sh->nq[0] = sh->nq[1] = 0; sh->nclaim[0] = sh->nclaim[1] = 0; sh->best = PL_NONE;
     sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = PL_NONE;
     sh->nchunk1 = sh->nchunk2 = 0; sh->nops_real = 0; sh->uslot_fill = 0;
   }
@@ -330,13 +339,13 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     c.rowstate[r] = r < L ? c.b_state[r] : 0u;
     c.rowinfo[r] = PL_UNASSIGNED;
     c.patch_of[r] = 0xFFFFu;
-    c.used[r] = 0;
   }
   for (uint32_t col = tid; col < L; col += nt) {
     c.colinfo[col] = col < p.W ? 0u : ((PL_ST_INACT << 30) | (col - p.W));
     c.pc_fill[col] = 0;
   }
   for (uint32_t x = tid; x < p.P; x += nt) c.ucol[x] = (uint16_t)(p.W + x);
+  for (uint32_t j = tid; j < PL_LOWCAP; j += nt) sh->gj_used[j] = 0;
 }
 
 /* validate the inputs and expand the patched rows (thread per received repair symbol) */
@@ -368,6 +377,7 @@ template <int Z> SB_HD void pl_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
     c.patch_len[i] = (uint8_t)n;
     c.patch_of[row] = (uint16_t)i;
     c.rowstate[row] = (cnt << 24) | sum;
+    c.rowinfo[row] = PL_UNASSIGNED | PL_PATCHED;
   }
 }
 
@@ -406,113 +416,98 @@ template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) 
   }
   for (uint32_t r = tid; r < sh->M; r += nt) {
     if ((c.rowstate[r] >> 24) == 1u) {
-      uint32_t j = PL_ATOM_ADD(&sh->nfront, 1u);
+      uint32_t j = PL_ATOM_ADD(&sh->nq[0], 1u);
       if (j < PL_QCAP) sh->queue[0][j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
     }
   }
 }
 
 /* column `col` leaves V: one atomic subtract per row that contains it; rows that drop to a single V
- * column join the next frontier.  `lvl1` (pivot level + 1) is folded into the rows' level-so-far; 0
- * for an inactivated column.  Called by one thread per column (`lane0`/`lanes` = 0/1) or by a group of
- * lanes striding over the column's row list. */
-SB_HD void pl_drop_column(PlanCtx &c, uint32_t col, uint32_t lvl1, uint32_t lane0, uint32_t lanes) {
+ * column join the next frontier (queue of parity `np`).  `lvl1` (pivot level + 1) is folded into the
+ * rows' level-so-far; 0 for an inactivated column.  A group of `lanes` lanes strides over the row list. */
+SB_HD void pl_drop_column(PlanCtx &c, uint32_t col, uint32_t lvl1, uint32_t np, uint32_t lane0, uint32_t lanes) {
   pl_shared *sh = c.sh;
   const uint32_t dec = (1u << 24) | col;
-  uint16_t *nextq = sh->queue[sh->cur ^ 1u];
+  uint16_t *nextq = sh->queue[np];
   const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a;
-  const uint32_t pa = c.pc_ptr[col], np = c.pc_ptr[col + 1] - pa;
-  for (uint32_t e = lane0; e < nb + np; e += lanes) {
-    uint32_t r;
-    if (e < nb) {
-      r = c.b_ridx[a + e];
-      if (c.patch_of[r] != 0xFFFFu) continue; /* base entry of a row this block replaced */
-    } else {
-      r = c.pc_rows[pa + (e - nb)];
-    }
-    const uint32_t info = c.rowinfo[r]; /* assignments happen in another phase: stable here */
-    if (lvl1 && (info & PL_UNASSIGNED)) PL_ATOM_MAX(&c.rowinfo[r], PL_UNASSIGNED | lvl1);
-    uint32_t old = PL_ATOM_SUB(&c.rowstate[r], dec);
+  const uint32_t pa = c.pc_ptr[col], npc = c.pc_ptr[col + 1] - pa;
+  for (uint32_t e = lane0; e < nb + npc; e += lanes) {
+    const bool base = e < nb;
+    const uint32_t r = base ? c.b_ridx[a + e] : c.pc_rows[pa + (e - nb)];
+    const uint32_t info = c.rowinfo[r]; /* flags change in other phases only: stable here */
+    if (base && (info & PL_PATCHED)) continue; /* base entry of a row this block replaced */
+    if (lvl1 && (info & PL_UNASSIGNED)) PL_ATOM_MAX(&c.rowinfo[r], (info & ~PL_LEVEL_MASK) | lvl1);
+    const uint32_t old = PL_ATOM_SUB(&c.rowstate[r], dec);
     if ((old >> 24) == 2u && (info & PL_UNASSIGNED)) {
-      uint32_t j = PL_ATOM_ADD(&sh->nnext, 1u);
+      const uint32_t j = PL_ATOM_ADD(&sh->nq[np], 1u);
       if (j < PL_QCAP) nextq[j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
     }
   }
 }
 
 /* =============================== phase 1: peeling rounds ==================================== */
-/* A: every frontier row that still has exactly one V column tries to claim it */
-template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t tid, uint32_t nt) {
+/* Round `rd`: frontier = queue[rd&1], next frontier = queue[(rd+1)&1].
+ * A: every frontier row that still has exactly one V column tries to claim it (compare-and-swap on the
+ *    column); the winner becomes a pivot at the level its earlier column drops accumulated. */
+template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  const uint16_t *fq = sh->queue[sh->cur];
-  for (uint32_t t = tid; t < sh->nfront; t += nt) {
-    uint32_t r = fq[t];
-    uint32_t st = c.rowstate[r];
-    if ((st >> 24) != 1u || !(c.rowinfo[r] & PL_UNASSIGNED)) continue;
-    uint32_t col = st & 0xFFFFFFu;
-    if (PL_ATOM_CAS(&c.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) == 0u) {
-      uint32_t i = PL_ATOM_ADD(&sh->nclaim, 1u);
-      if (i < PL_QCAP) { sh->claim_r[i] = (uint16_t)r; sh->claim_c[i] = (uint16_t)col; } else sh->status = PL_FAIL_CAPACITY;
-    }
-  }
-}
-/* B: winners become pivots; their level is the level-so-far accumulated by earlier column drops */
-template <int Z> SB_HD void pl_round_pivot(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
-  for (uint32_t i = tid; i < sh->nclaim; i += nt) {
-    uint32_t r = sh->claim_r[i], col = sh->claim_c[i];
-    uint32_t lv = c.rowinfo[r] & 0x7FFFFFFFu;
-    uint32_t k = PL_ATOM_ADD(&sh->npiv, 1u);
+  const uint32_t pq = rd & 1u;
+  const uint16_t *fq = sh->queue[pq];
+  const uint32_t nf = sh->nq[pq] < PL_QCAP ? sh->nq[pq] : PL_QCAP;
+  for (uint32_t t = tid; t < nf; t += nt) {
+    const uint32_t r = fq[t];
+    const uint32_t st = c.rowstate[r], info = c.rowinfo[r];
+    if ((st >> 24) != 1u || !(info & PL_UNASSIGNED)) continue;
+    const uint32_t col = st & 0xFFFFFFu;
+    if (PL_ATOM_CAS(&c.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue;
+    const uint32_t lv = info & PL_LEVEL_MASK;
+    const uint32_t k = PL_ATOM_ADD(&sh->npiv, 1u);
     c.pivslot[k] = (uint16_t)r;
     c.pivcol[k] = (uint16_t)col;
-    c.rowinfo[r] = lv; /* assigned: bit 31 cleared, level kept */
+    c.rowinfo[r] = (info & PL_PATCHED) | lv; /* assigned: bit 31 cleared */
     c.colinfo[col] = (PL_ST_PIVOT << 30) | k;
     PL_ATOM_MAX(&sh->nlev, lv + 1u);
+    PL_ATOM_SUB(&sh->nV, 1u);
+    const uint32_t i = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
+    if (i < PL_QCAP) { sh->claim_r[i] = (uint16_t)r; sh->claim_c[i] = (uint16_t)col; } else sh->status = PL_FAIL_CAPACITY;
   }
+  if (tid == 0) { sh->nq[pq ^ 1u] = 0; sh->best = PL_NONE; }
 }
-/* C: the claimed columns leave V (8 lanes per column) */
-template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t tid, uint32_t nt) {
+/* B: the claimed columns leave V (8 lanes per column) */
+template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
+  const uint32_t pq = rd & 1u;
   const uint32_t grp = tid >> 3, lane = tid & 7u, ngrp = nt >> 3;
-  for (uint32_t i = grp; i < sh->nclaim; i += ngrp) {
-    uint32_t r = sh->claim_r[i], col = sh->claim_c[i];
-    pl_drop_column(c, col, (c.rowinfo[r] & 0x7FFFFFFFu) + 1u, lane, 8u);
+  const uint32_t nc = sh->nclaim[pq] < PL_QCAP ? sh->nclaim[pq] : PL_QCAP;
+  for (uint32_t i = grp; i < nc; i += ngrp) {
+    const uint32_t r = sh->claim_r[i], col = sh->claim_c[i];
+    pl_drop_column(c, col, (c.rowinfo[r] & PL_LEVEL_MASK) + 1u, pq ^ 1u, lane, 8u);
   }
+  if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
 }
-/* D: bookkeeping by one thread */
-template <int Z> SB_HD void pl_round_swap(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
-  if (tid != 0) return;
-  if (sh->nclaim > PL_QCAP) sh->nclaim = PL_QCAP;
-  sh->nV -= sh->nclaim;
-  sh->nclaim = 0;
-  sh->cur ^= 1u;
-  sh->nfront = sh->nnext < PL_QCAP ? sh->nnext : PL_QCAP;
-  sh->nnext = 0;
-  sh->best = PL_NONE;
-}
-/* E: no claimant: find the open row with the fewest V columns (workgroup-wide atomic min) */
-template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t tid, uint32_t nt) {
+/* No claimant in the frontier: find the open row with the fewest V columns (workgroup-wide atomic min) */
+template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   uint32_t best = PL_NONE;
   for (uint32_t r = tid; r < sh->M; r += nt) {
     if (!(c.rowinfo[r] & PL_UNASSIGNED)) continue;
-    uint32_t cnt = c.rowstate[r] >> 24;
+    const uint32_t cnt = c.rowstate[r] >> 24;
     if (cnt >= 2u) {
-      uint32_t key = (cnt << 16) | r;
+      const uint32_t key = (cnt << 16) | r;
       if (key < best) best = key;
     }
   }
   if (best != PL_NONE) PL_ATOM_MIN(&sh->best, best);
+  if (tid == 0) { sh->nq[(rd & 1u) ^ 1u] = 0; sh->nclaim[rd & 1u] = 0; }
 }
-/* F: inactivate all but one V column of that row (or every remaining V column if no row is left) */
-template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+/* inactivate all but one V column of that row (or every remaining V column if no row is left) */
+template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   const rq_params &p = c.p;
   if (sh->best == PL_NONE) {
     for (uint32_t col = tid; col < p.W; col += nt) {
       if (c.colinfo[col] == 0u) {
-        uint32_t x = p.P + PL_ATOM_ADD(&sh->ninact, 1u);
+        const uint32_t x = p.P + PL_ATOM_ADD(&sh->ninact, 1u);
         if (x < c.ucap) { c.colinfo[col] = (PL_ST_INACT << 30) | x; c.ucol[x] = (uint16_t)col; }
         else sh->status = PL_FAIL_CAPACITY;
       }
@@ -526,39 +521,34 @@ template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t tid, uint32_t 
   const uint32_t n = pl_row(c, r, &cols);
   uint32_t keep = PL_NONE, keepdeg = PL_NONE, m = 0;
   for (uint32_t k = 0; k < n; k++) {
-    uint32_t col = cols[k];
+    const uint32_t col = cols[k];
     if (c.colinfo[col] != 0u) continue;
-    uint32_t dg = (c.b_cptr[col + 1] - c.b_cptr[col]) + (c.pc_ptr[col + 1] - c.pc_ptr[col]);
+    const uint32_t dg = (c.b_cptr[col + 1] - c.b_cptr[col]) + (c.pc_ptr[col + 1] - c.pc_ptr[col]);
     if (dg < keepdeg) { keepdeg = dg; keep = col; }
   }
   for (uint32_t k = 0; k < n; k++) {
-    uint32_t col = cols[k];
+    const uint32_t col = cols[k];
     if (c.colinfo[col] != 0u || col == keep) continue;
-    uint32_t x = p.P + sh->ninact;
+    const uint32_t x = p.P + sh->ninact;
     if (x >= c.ucap || m >= PL_QCAP) { sh->status = PL_FAIL_CAPACITY; break; }
     sh->ninact++;
     c.colinfo[col] = (PL_ST_INACT << 30) | x;
     c.ucol[x] = (uint16_t)col;
     sh->claim_c[m++] = (uint16_t)col;
   }
-  sh->nclaim = m; /* reused as "columns to drop" */
+  sh->nclaim[rd & 1u] = m; /* "columns to drop" */
+  sh->nV -= m;
 }
-template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  if (sh->best == PL_NONE) return;
+  const uint32_t pq = rd & 1u;
+  if (sh->best == PL_NONE) {
+    if (tid == 0) sh->nV = 0;
+    return;
+  }
   const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
-  for (uint32_t i = grp; i < sh->nclaim; i += ngrp) pl_drop_column(c, sh->claim_c[i], 0u, lane, 32u);
-}
-template <int Z> SB_HD void pl_inact_apply_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
-  if (tid != 0) return;
-  if (sh->best == PL_NONE) sh->nV = 0;
-  else sh->nV -= sh->nclaim;
-  sh->nclaim = 0;
-  sh->cur ^= 1u;
-  sh->nfront = sh->nnext < PL_QCAP ? sh->nnext : PL_QCAP;
-  sh->nnext = 0;
-  sh->best = PL_NONE;
+  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column(c, sh->claim_c[i], 0u, pq ^ 1u, lane, 32u);
+  if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
 }
 
 /* =============================== phase 2: levels, W ========================================== */
@@ -573,7 +563,11 @@ template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  for (uint32_t k = tid; k < sh->npiv; k += nt) PL_ATOM_ADD(&c.lev_cnt[c.rowinfo[c.pivslot[k]] + 1u], 1u);
+  for (uint32_t k = tid; k < sh->npiv; k += nt) PL_ATOM_ADD(&c.lev_cnt[(c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK) + 1u], 1u);
+  /* W rows are accumulated with XORs: start from zero */
+  for (uint32_t e = tid; e < sh->M * sh->wpr; e += nt) c.wrows[e] = 0;
+  for (uint32_t k = tid; k < sh->npiv; k += nt) c.pivdeg[k] = 0;
+  for (uint32_t k = tid; k < sh->M; k += nt) c.lowdeg[k] = 0;
 }
 template <int Z> SB_HD void pl_lev_c(PlanCtx &c, uint32_t tid, uint32_t nt) { /* serial prefix over levels */
   pl_shared *sh = c.sh;
@@ -584,58 +578,119 @@ template <int Z> SB_HD void pl_lev_c(PlanCtx &c, uint32_t tid, uint32_t nt) { /*
 template <int Z> SB_HD void pl_lev_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   for (uint32_t k = tid; k < sh->npiv; k += nt) {
-    uint32_t l = c.rowinfo[c.pivslot[k]];
+    uint32_t l = c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK;
     uint32_t pos = PL_ATOM_ADD(&c.lev_fill[l], 1u);
     c.by_level[c.lev_cnt[l] + pos] = k;
   }
 }
 
-/* bit row over the inactive columns for constraint row r: its own inactive entries plus the W rows of
- * its pivot columns (except `own`).  8 lanes cooperate, lane w8 owns words w8, w8+8, ... (<= 5 of them) */
-SB_HD void pl_bitrow(const PlanCtx &c, uint32_t r, uint32_t own, uint32_t w8, uint32_t wpr, uint32_t (&acc)[5],
-                     uint32_t *deg) {
+/* Own part of the bit row of constraint row r over the inactive columns (the entries of the row that sit in
+ * inactive columns) plus the number of its pivot-column entries other than `own` = XOR ops the row needs.
+ * 8 lanes cooperate, lane w8 owns words w8, w8+8, ...; `sub`/`stride` select a slice of the entries. */
+SB_HD void pl_scan_row(const PlanCtx &c, uint32_t r, uint32_t own, uint32_t w8, uint32_t sub, uint32_t stride,
+                       uint32_t (&acc)[5], uint32_t *deg) {
 #pragma unroll
   for (int q = 0; q < 5; q++) acc[q] = 0;
   const uint16_t *cols;
   const uint32_t n = pl_row(c, r, &cols);
   uint32_t d = 0;
-  for (uint32_t k = 0; k < n; k++) {
+  for (uint32_t k = sub; k < n; k += stride) {
     const uint32_t col = cols[k];
     const uint32_t info = c.colinfo[col], st = info >> 30, idx = info & 0x3FFFFFFFu;
     if (st == PL_ST_INACT) {
       const uint32_t wd = idx >> 5;
       if ((wd & 7u) == w8) acc[(wd >> 3) % 5u] ^= 1u << (idx & 31u);
-    } else if (col != own) { /* pivot column */
+    } else if (col != own) {
       d++;
-      const uint32_t *src = c.wrows + (size_t)idx * wpr;
-#pragma unroll
-      for (uint32_t q = 0; q < 5; q++) {
-        const uint32_t wd = w8 + 8u * q;
-        if (wd < wpr) acc[q] ^= src[wd];
-      }
     }
   }
   *deg = d;
 }
 
-/* one dependency level of W (8 lanes per pivot row) */
-template <int Z> SB_HD void pl_w_level(PlanCtx &c, uint32_t level, uint32_t tid, uint32_t nt) {
+/* W starts as A restricted to the inactive columns, row by slot; op counts per row and per level group.
+ * Ordinary rows: 8 lanes per row.  The long LDPC rows (r < S): 8 slices of 8 lanes, merged with atomics. */
+template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr;
-  const uint32_t a = c.lev_cnt[level], b = c.lev_cnt[level + 1];
-  for (uint32_t j = a + grp; j < b; j += ngrp) {
-    const uint32_t k = c.by_level[j];
+  if (sh->status) return;
+  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr, S = c.p.S, H = c.p.H;
+  const uint32_t total = sh->npiv + sh->nlow;
+  /* item i < npiv: pivot i; otherwise leftover row i - npiv (group nlev) */
+  for (uint32_t i = grp; i < total; i += ngrp) {
+    const bool piv = i < sh->npiv;
+    const uint32_t r = piv ? c.pivslot[i] : c.lowslot[i - sh->npiv];
+    if (r < S) continue;
     uint32_t acc[5], deg;
-    pl_bitrow(c, c.pivslot[k], c.pivcol[k], w8, wpr, acc, &deg);
-    uint32_t *dst = c.wrows + (size_t)k * wpr;
+    pl_scan_row(c, r, piv ? c.pivcol[i] : PL_NONE, w8, 0u, 1u, acc, &deg);
+    uint32_t *dst = c.wrows + (size_t)r * wpr;
 #pragma unroll
     for (uint32_t q = 0; q < 5; q++) {
       const uint32_t wd = w8 + 8u * q;
       if (wd < wpr) dst[wd] = acc[q];
     }
     if (w8 == 0) {
-      c.pivdeg[k] = deg;
-      PL_ATOM_ADD(&c.lev_ops[level], deg);
+      if (piv) { c.pivdeg[i] = deg; PL_ATOM_ADD(&c.lev_ops[c.rowinfo[r] & PL_LEVEL_MASK], deg); }
+      else { c.lowdeg[i - sh->npiv] = deg; PL_ATOM_ADD(&c.lev_ops[sh->nlev], deg); }
+    }
+  }
+  /* long rows: slots [0,S); the destination words were zeroed in pl_lev_b */
+  for (uint32_t i = grp >> 3; i < total; i += ngrp >> 3) {
+    const bool piv = i < sh->npiv;
+    const uint32_t r = piv ? c.pivslot[i] : c.lowslot[i - sh->npiv];
+    if (r >= S) continue;
+    uint32_t acc[5], deg;
+    pl_scan_row(c, r, piv ? c.pivcol[i] : PL_NONE, w8, grp & 7u, 8u, acc, &deg);
+    uint32_t *dst = c.wrows + (size_t)r * wpr;
+#pragma unroll
+    for (uint32_t q = 0; q < 5; q++) {
+      const uint32_t wd = w8 + 8u * q;
+      if (wd < wpr && acc[q]) PL_ATOM_XOR(&dst[wd], acc[q]);
+    }
+    if (w8 == 0 && deg) {
+      if (piv) { PL_ATOM_ADD(&c.pivdeg[i], deg); PL_ATOM_ADD(&c.lev_ops[c.rowinfo[r] & PL_LEVEL_MASK], deg); }
+      else { PL_ATOM_ADD(&c.lowdeg[i - sh->npiv], deg); PL_ATOM_ADD(&c.lev_ops[sh->nlev], deg); }
+    }
+  }
+  (void)H;
+}
+
+/* One level group of the op stream applied to W: W[dst] ^= W[src] for every op of the group -- the same
+ * forward substitution the solve kernel performs on symbols, here on the bit rows (8 lanes per op; for
+ * wpr > 8 each lane takes several words). */
+template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr;
+  const uint32_t nops = ((c.lev_ops[group] + NRQ_CHUNK - 1u) / NRQ_CHUNK) * NRQ_CHUNK;
+  const uint32_t *ops = reinterpret_cast<const uint32_t *>(c.arena + sh->off_ops) + (size_t)c.lev_base[group] * NRQ_CHUNK;
+  if (wpr <= 8u) {
+    /* one word per lane; 8 ops per lane group in flight: all op words first, then all source words */
+    const uint32_t wsel = w8 < wpr ? w8 : 0u;
+    for (uint32_t e0 = grp; e0 < nops; e0 += 8u * ngrp) {
+      uint32_t op[8], v[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) {
+        const uint32_t e = e0 + q * ngrp;
+        op[q] = e < nops ? ops[e] : NRQ_NOP;
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) {
+        const uint32_t srow = op[q] == NRQ_NOP ? 0u : (op[q] >> 16);
+        v[q] = c.wrows[(size_t)srow * wpr + wsel];
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++)
+        if (op[q] != NRQ_NOP && w8 < wpr && v[q]) PL_ATOM_XOR(&c.wrows[(size_t)(op[q] & 0xFFFFu) * wpr + w8], v[q]);
+    }
+    return;
+  }
+  for (uint32_t e = grp; e < nops; e += ngrp) {
+    const uint32_t op = ops[e];
+    if (op == NRQ_NOP) continue;
+    const uint32_t *src = c.wrows + (size_t)(op >> 16) * wpr;
+    uint32_t *dst = c.wrows + (size_t)(op & 0xFFFFu) * wpr;
+    for (uint32_t wd = w8; wd < wpr; wd += 8u) {
+      const uint32_t v = src[wd];
+      if (v) PL_ATOM_XOR(&dst[wd], v);
     }
   }
 }
@@ -647,7 +702,7 @@ template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /*
   for (uint32_t r = tid; r < sh->M; r += nt) {
     if (!(c.rowinfo[r] & PL_UNASSIGNED) || (r >= p.S && r < p.S + p.H)) continue;
     uint32_t j = PL_ATOM_ADD(&sh->nlow, 1u);
-    if (j < c.ucap + 32u) c.lowslot[j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
+    if (j < c.ucap + 32u && j < PL_LOWCAP) c.lowslot[j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
   }
 }
 template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
@@ -656,31 +711,26 @@ template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   sh->lpr = sh->nlow ? (sh->nlow + 31u) / 32u : 1u;
   sh->rowlen = sh->wpr + sh->lpr;
   /* Mb (nlow x rowlen words) and Mh (H x u bytes) share the dynamic LDS region from here on */
-  uint32_t need = pl_r16(sh->nlow * sh->rowlen * 4u) + pl_r16(PL_MAXH * (c.p.L - sh->npiv));
+  uint32_t need = pl_r16(sh->nlow * sh->rowlen * 4u) + pl_r16(PL_MAXH * (c.p.L - sh->npiv)) + PL_MH_TILE * 16u +
+                  PL_MH_TILE * sh->wpr * 4u;
   if (need > c.dense_bytes || sh->wpr > 40u) sh->status = PL_FAIL_CAPACITY;
 }
 SB_HD uint32_t *pl_mb(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(c.dense_lds); }
+/* HDPC rows over the inactive columns, transposed: 16 bytes (one per HDPC row) per inactive column */
 SB_HD uint8_t *pl_mhm(const PlanCtx &c) { return c.dense_lds + pl_r16(c.sh->nlow * c.sh->rowlen * 4u); }
+SB_HD uint8_t *pl_gtile(const PlanCtx &c) { return pl_mhm(c) + pl_r16(PL_MAXH * (c.p.L - c.sh->npiv)); }
+SB_HD uint32_t *pl_wtile(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(pl_gtile(c) + PL_MH_TILE * 16u); }
 
-/* reduced coefficient rows of the leftover rows over the inactive columns, with the augmented identity */
+/* reduced coefficient rows of the leftover rows over the inactive columns (their W rows after the op
+ * stream has run), with the augmented identity, into LDS */
 template <int Z> SB_HD void pl_low_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr, rowlen = sh->rowlen;
+  if (sh->status) return;
+  const uint32_t wpr = sh->wpr, rowlen = sh->rowlen;
   uint32_t *Mb = pl_mb(c);
-  for (uint32_t j = grp; j < sh->nlow; j += ngrp) {
-    uint32_t acc[5], deg;
-    pl_bitrow(c, c.lowslot[j], PL_NONE, w8, wpr, acc, &deg);
-    uint32_t *dst = Mb + (size_t)j * rowlen;
-#pragma unroll
-    for (uint32_t q = 0; q < 5; q++) {
-      const uint32_t wd = w8 + 8u * q;
-      if (wd < wpr) dst[wd] = acc[q];
-    }
-    for (uint32_t wd = w8; wd < sh->lpr; wd += 8u) dst[wpr + wd] = (wd == (j >> 5)) ? (1u << (j & 31u)) : 0u;
-    if (w8 == 0) {
-      c.lowdeg[j] = deg;
-      PL_ATOM_ADD(&c.lev_ops[sh->nlev], deg); /* the leftover rows form one more accumulate-only group */
-    }
+  for (uint32_t e = tid; e < sh->nlow * rowlen; e += nt) {
+    const uint32_t j = e / rowlen, wd = e - j * rowlen;
+    Mb[e] = wd < wpr ? c.wrows[(size_t)c.lowslot[j] * wpr + wd] : ((wd - wpr) == (j >> 5) ? (1u << (j & 31u)) : 0u);
   }
 }
 
@@ -747,7 +797,7 @@ template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
   for (uint32_t k = tid; k < sh->npiv; k += nt) {
     const uint32_t deg = c.pivdeg[k];
     if (!deg) continue;
-    const uint32_t r = c.pivslot[k], l = c.rowinfo[r];
+    const uint32_t r = c.pivslot[k], l = c.rowinfo[r] & PL_LEVEL_MASK;
     const uint32_t start = PL_ATOM_ADD(&c.lev_fill[l], deg);
     pl_emit_row(c, r, c.pivcol[k], l, start, r);
   }
@@ -768,30 +818,56 @@ template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 
 /* =============================== phase 5: HDPC rows over the inactive columns ================= */
-template <int Z> SB_HD void pl_mh(PlanCtx &c, uint32_t tid, uint32_t nt) {
+/* MhT[x] = G_U[:,x] ^ SUM_k W[k][x] * G[:, pivcol k]  (16 bytes per inactive column x, in LDS).  The pivots
+ * are streamed through LDS in tiles: their HDPC columns (16 bytes each, kconst GT) and their W rows. */
+template <int Z> SB_HD void pl_mh_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
   const rq_params &p = c.p;
-  const uint32_t u = p.L - sh->npiv, H = p.H, n_hd = p.Kp + p.S, wpr = sh->wpr;
-  uint8_t *Mh = pl_mhm(c);
+  const uint32_t u = p.L - sh->npiv, n_hd = p.Kp + p.S;
+  uint4 *MhT = reinterpret_cast<uint4 *>(pl_mhm(c));
   for (uint32_t x = tid; x < u; x += nt) {
-    uint8_t acc[PL_MAXH];
     const uint32_t col = c.ucol[x];
-#pragma unroll
-    for (uint32_t h = 0; h < PL_MAXH; h++)
-      acc[h] = h < H ? (col < n_hd ? c.G[(size_t)h * n_hd + col] : (uint8_t)(col - n_hd == h)) : 0;
-    const uint32_t wd = x >> 5, bt = x & 31u;
-    for (uint32_t k = 0; k < sh->npiv; k++) {
-      if ((c.wrows[(size_t)k * wpr + wd] >> bt) & 1u) {
-        const uint32_t pc = c.pivcol[k];
-#pragma unroll
-        for (uint32_t h = 0; h < PL_MAXH; h++)
-          if (h < H) acc[h] ^= c.G[(size_t)h * n_hd + pc];
-      }
+    uint4 v;
+    if (col < n_hd) v = *reinterpret_cast<const uint4 *>(c.GT + (size_t)col * 16u);
+    else {
+      const uint32_t h = col - n_hd; /* identity part of the HDPC rows */
+      v.x = h < 4 ? 1u << (8u * h) : 0u; v.y = (h >= 4 && h < 8) ? 1u << (8u * (h - 4)) : 0u;
+      v.z = (h >= 8 && h < 12) ? 1u << (8u * (h - 8)) : 0u; v.w = (h >= 12 && h < 16) ? 1u << (8u * (h - 12)) : 0u;
     }
-#pragma unroll
-    for (uint32_t h = 0; h < PL_MAXH; h++)
-      if (h < H) Mh[(size_t)h * u + x] = acc[h];
+    MhT[x] = v;
+  }
+}
+template <int Z> SB_HD void pl_mh_load(PlanCtx &c, uint32_t tile, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t k0 = tile * PL_MH_TILE, wpr = sh->wpr;
+  const uint32_t cnt = (sh->npiv - k0) < PL_MH_TILE ? (sh->npiv - k0) : PL_MH_TILE;
+  uint4 *Gt = reinterpret_cast<uint4 *>(pl_gtile(c));
+  uint32_t *Wt = pl_wtile(c);
+  for (uint32_t i = tid; i < cnt; i += nt) Gt[i] = *reinterpret_cast<const uint4 *>(c.GT + (size_t)c.pivcol[k0 + i] * 16u);
+  for (uint32_t e = tid; e < cnt * wpr; e += nt) {
+    const uint32_t i = e / wpr, wd = e - i * wpr;
+    Wt[e] = c.wrows[(size_t)c.pivslot[k0 + i] * wpr + wd];
+  }
+}
+template <int Z> SB_HD void pl_mh_acc(PlanCtx &c, uint32_t tile, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t k0 = tile * PL_MH_TILE, wpr = sh->wpr, u = c.p.L - sh->npiv;
+  const uint32_t cnt = (sh->npiv - k0) < PL_MH_TILE ? (sh->npiv - k0) : PL_MH_TILE;
+  uint4 *MhT = reinterpret_cast<uint4 *>(pl_mhm(c));
+  const uint4 *Gt = reinterpret_cast<const uint4 *>(pl_gtile(c));
+  const uint32_t *Wt = pl_wtile(c);
+  for (uint32_t x = tid; x < u; x += nt) {
+    uint4 acc = MhT[x];
+    const uint32_t wd = x >> 5, bt = x & 31u;
+    for (uint32_t i = 0; i < cnt; i++) {
+      const uint32_t m = 0u - ((Wt[i * wpr + wd] >> bt) & 1u);
+      const uint4 g = Gt[i];
+      acc.x ^= g.x & m; acc.y ^= g.y & m; acc.z ^= g.z & m; acc.w ^= g.w & m;
+    }
+    MhT[x] = acc;
   }
 }
 
@@ -803,8 +879,8 @@ template <int Z> SB_HD void pl_gj_a(PlanCtx &c, uint32_t x, uint32_t tid, uint32
   const uint32_t rowlen = sh->rowlen;
   for (uint32_t j = tid; j < sh->nlow; j += nt) {
     const uint32_t f = (Mb[(size_t)j * rowlen + (x >> 5)] >> (x & 31u)) & 1u;
-    c.flag[j] = (uint8_t)f;
-    if (f && !c.used[j]) PL_ATOM_MIN(&sh->cand[x & 1u], j);
+    sh->gj_flag[j] = (uint8_t)f;
+    if (f && !sh->gj_used[j]) PL_ATOM_MIN(&sh->cand[x & 1u], j);
   }
   if (tid == 0) sh->cand[(x & 1u) ^ 1u] = PL_NONE;
 }
@@ -824,10 +900,10 @@ template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t x, uint32_t tid, uint32
   const uint32_t *src = Mb + (size_t)pr * rowlen;
   for (uint32_t e = tid; e < total; e += nt) {
     const uint32_t j = e / rowlen, wd = e - j * rowlen;
-    if (j != pr && c.flag[j]) Mb[e] ^= src[wd];
+    if (j != pr && sh->gj_flag[j]) Mb[e] ^= src[wd];
   }
   if (tid == 0) {
-    c.used[pr] = 1;
+    sh->gj_used[pr] = 1;
     c.red_row[sh->r2] = pr;
     c.red_x[sh->r2] = x;
     sh->r2++;
@@ -892,7 +968,7 @@ template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 template <int Z> SB_HD void pl_dense_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
-  const uint32_t H = c.p.H, u = c.p.L - sh->npiv, r2 = sh->r2, nfree = sh->nfree;
+  const uint32_t H = c.p.H, r2 = sh->r2, nfree = sh->nfree;
   const uint32_t *Mb = pl_mb(c);
   const uint8_t *Mh = pl_mhm(c);
   for (uint32_t q = tid; q < r2; q += nt) {
@@ -904,7 +980,7 @@ template <int Z> SB_HD void pl_dense_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     }
     c.fbits[q] = fb;
     c.pivx[q] = (uint16_t)c.red_x[q];
-    for (uint32_t h = 0; h < H; h++) c.mh[(size_t)h * r2 + q] = Mh[(size_t)h * u + c.red_x[q]];
+    for (uint32_t h = 0; h < H; h++) c.mh[(size_t)h * r2 + q] = Mh[(size_t)c.red_x[q] * 16u + h];
   }
   for (uint32_t f = tid; f < nfree; f += nt) c.freex_out[f] = (uint16_t)sh->freex[f];
   for (uint32_t h = tid; h < PL_MAXH; h += nt) sh->taken[h] = 0;
@@ -912,13 +988,13 @@ template <int Z> SB_HD void pl_dense_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 template <int Z> SB_HD void pl_dense_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
-  const uint32_t H = c.p.H, u = c.p.L - sh->npiv, r2 = sh->r2, nfree = sh->nfree, aw = nfree + H;
+  const uint32_t H = c.p.H, r2 = sh->r2, nfree = sh->nfree, aw = nfree + H;
   const uint8_t *Mh = pl_mhm(c);
   for (uint32_t e = tid; e < H * aw; e += nt) {
     const uint32_t h = e / aw, w = e - h * aw;
     uint8_t v;
     if (w < nfree) {
-      v = Mh[(size_t)h * u + sh->freex[w]];
+      v = Mh[(size_t)sh->freex[w] * 16u + h];
       for (uint32_t q = 0; q < r2; q++)
         if ((c.fbits[q] >> w) & 1u) v ^= c.mh[(size_t)h * r2 + q];
     } else {
@@ -1019,7 +1095,7 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   uint32_t *wt = reinterpret_cast<uint32_t *>(c.arena + sh->partial[0]);
   for (uint32_t e = tid; e < wpr * stride; e += nt) {
     const uint32_t w = e / stride, k = e - w * stride;
-    wt[e] = k < sh->npiv ? c.wrows[(size_t)k * wpr + w] : 0u;
+    wt[e] = k < sh->npiv ? c.wrows[(size_t)c.pivslot[k] * wpr + w] : 0u;
   }
   uint32_t *rowsrc = reinterpret_cast<uint32_t *>(c.arena + sh->partial[1]);
   for (uint32_t r = tid; r < sh->M; r += nt) {

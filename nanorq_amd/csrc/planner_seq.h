@@ -17,19 +17,17 @@
   /* ---- peeling ---- */
   {
     const uint32_t guard_max = 4u * c.p.L + 64u;
-    uint32_t guard = 0;
-    while (sh_->status == 0 && sh_->nV > 0 && guard++ < guard_max) {
-      if (sh_->nfront > 0) {
-        PL_PHASE(pl_round_claim);
-        PL_PHASE(pl_round_pivot);
-        PL_PHASE(pl_round_drop);
-        PL_PHASE(pl_round_swap);
+    uint32_t rd_ = 0;
+    while (sh_->status == 0 && sh_->nV > 0 && rd_ < guard_max) {
+      if (sh_->nq[rd_ & 1u] > 0) {
+        PL_PHASE1(pl_round_claim, rd_);
+        PL_PHASE1(pl_round_drop, rd_);
       } else {
-        PL_PHASE(pl_inact_find);
-        PL_PHASE(pl_inact_apply_a);
-        PL_PHASE(pl_inact_apply_b);
-        PL_PHASE(pl_inact_apply_c);
+        PL_PHASE1(pl_inact_find, rd_);
+        PL_PHASE1(pl_inact_apply_a, rd_);
+        PL_PHASE1(pl_inact_apply_b, rd_);
       }
+      rd_++;
     }
   }
   PL_PHASE(pl_lev_a);
@@ -37,16 +35,22 @@
     PL_PHASE(pl_lev_b);
     PL_PHASE(pl_lev_c);
     PL_PHASE(pl_lev_d);
-    for (uint32_t lv_ = 0; lv_ < sh_->nlev; lv_++) PL_PHASE1(pl_w_level, lv_);
     PL_PHASE(pl_low_a);
     PL_PHASE(pl_low_b);
   }
   if (sh_->status == 0 && sh_->nV == 0) {
-    PL_PHASE(pl_low_c);
+    PL_PHASE(pl_w_init);
     PL_PHASE(pl_ops_layout);
     PL_PHASE(pl_ops_clear);
     PL_PHASE(pl_ops_emit);
-    PL_PHASE(pl_mh);
+    /* W = X^-1 * A_U and the leftover rows' reduced coefficients: the op stream run on bit rows */
+    for (uint32_t lv_ = 1; lv_ <= sh_->nlev; lv_++) PL_PHASE1(pl_w_group, lv_);
+    PL_PHASE(pl_low_c);
+    PL_PHASE(pl_mh_init);
+    for (uint32_t tl_ = 0; tl_ * PL_MH_TILE < sh_->npiv; tl_++) {
+      PL_PHASE1(pl_mh_load, tl_);
+      PL_PHASE1(pl_mh_acc, tl_);
+    }
     {
       const uint32_t u_ = c.p.L - sh_->npiv;
       for (uint32_t x_ = 0; x_ < u_; x_++) {
