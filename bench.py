@@ -156,8 +156,6 @@ def main():
 
     def step():
         nonlocal retries
-        if not args.no_replan:
-            ctx.clear_plan_cache()
         ctx.encode_blocks(K, T, NB, src.data_ptr(), K * T, rep.data_ptr(), nrep * T, esis, inter.data_ptr(), L * T)
         enc_stats = ctx.stats()
         extra = np.full(NB, args.overhead, np.uint32)
@@ -168,6 +166,11 @@ def main():
             st = ctx.decode_blocks(K, T, NB, work.data_ptr(), K * T, lost_arr, todo, resi, nr, rep.data_ptr(), nrep * T)
             if dec_stats is None:
                 dec_stats = ctx.stats()
+                if not args.no_replan:
+                    # one encode plan per step (= per 256-block object, like nanorq_precalculate): the plan for
+                    # the NEXT step's encode is rebuilt on the host here, while the GPU runs this step's solve
+                    ctx.clear_plan_cache()
+                    ctx.precalculate(K)
             failed = np.nonzero((st == 0) & (todo > 0))[0]
             if len(failed) == 0:
                 break

@@ -157,6 +157,7 @@ enum {
   pl_tag_pl_lev_d = 7,
   pl_tag_pl_w_init = 8,
   pl_tag_pl_w_group = 8,
+  pl_tag_pl_w_stage = 8,
   pl_tag_pl_low_a = 9,
   pl_tag_pl_low_b = 9,
   pl_tag_pl_low_c = 9,
@@ -273,6 +274,10 @@ struct KConst {
 };
 
 struct EncPlan {
+  bool valid = false;     /* false after nrq_plan_cache_clear: rebuilt on next use, buffers are kept */
+  size_t dev_cap = 0;
+  uint8_t *pin = nullptr; /* pinned image for the asynchronous upload */
+  size_t pin_cap = 0;
   uint8_t *dev = nullptr; /* plan arena followed by rowsrc */
   uint32_t plan_bytes = 0;
   uint32_t rowsrc_off = 0;
@@ -298,6 +303,7 @@ struct nrq_ctx {
   int threads = 0;
   nrq_call_stats stats;
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipEvent_t encplan_uploaded = nullptr;
   bool attr_set[4] = {false, false, false, false};
   /* optional per-launch timing of the solve kernel (HIP events on the launch stream) */
   bool ktime_on = false;
@@ -379,7 +385,7 @@ int get_encplan(nrq_ctx *ctx, uint32_t K, uint32_t Kp, EncPlan **out) {
   if (rc) return rc;
   const uint64_t key = ((uint64_t)p.Kp << 32) | K;
   auto it = ctx->encplans.find(key);
-  if (it != ctx->encplans.end()) { *out = &it->second; return 0; }
+  if (it != ctx->encplans.end() && it->second.valid) { *out = &it->second; return 0; }
   KConst *kc;
   rc = get_kconst(ctx, p.Kp, &kc);
   if (rc) return rc;
@@ -390,23 +396,42 @@ int get_encplan(nrq_ctx *ctx, uint32_t K, uint32_t Kp, EncPlan **out) {
   uint32_t bytes = 0;
   if (nrq_host_plan_build(p.Kp, p.Kp, isis.data(), kc->host, &arena, &bytes) != 0)
     return fail(ctx, -2, "encode plan build failed for K=%u", K);
-  EncPlan ep;
+  if (it == ctx->encplans.end()) it = ctx->encplans.emplace(key, EncPlan()).first;
+  EncPlan &ep = it->second;
   memcpy(&ep.hdr, arena, sizeof(ep.hdr));
   if (ep.hdr.status) { nrq_host_free(arena); return fail(ctx, -3, "encode matrix singular for K=%u (cannot happen)", K); }
   ep.plan_bytes = bytes;
   ep.colslot.assign(reinterpret_cast<const uint16_t *>(arena + ep.hdr.off_colslot),
                     reinterpret_cast<const uint16_t *>(arena + ep.hdr.off_colslot) + p.L);
   ep.rowsrc_off = (uint32_t)r16(bytes);
-  std::vector<uint32_t> rowsrc(p.L, NRQ_ROW_ZERO);
+  const size_t total = ep.rowsrc_off + (size_t)p.L * 4;
+  /* device and pinned buffers survive a cache clear (same K => same size class); the upload is
+   * asynchronous on the context's stream, so rebuilding a plan never waits for the GPU */
+  if (ep.dev_cap < total) {
+    if (ep.dev) HIPCHK(ctx, hipFree(ep.dev));
+    ep.dev = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&ep.dev, total + total / 8));
+    ep.dev_cap = total + total / 8;
+  }
+  if (ep.pin_cap < total) {
+    if (ep.pin) HIPCHK(ctx, hipHostFree(ep.pin));
+    ep.pin = nullptr;
+    HIPCHK(ctx, hipHostMalloc((void **)&ep.pin, total + total / 8, hipHostMallocDefault));
+    ep.pin_cap = total + total / 8;
+  } else {
+    /* the previous upload from this pinned image must have been consumed */
+    HIPCHK(ctx, hipEventSynchronize(ctx->encplan_uploaded));
+  }
+  memcpy(ep.pin, arena, bytes);
+  uint32_t *rowsrc = reinterpret_cast<uint32_t *>(ep.pin + ep.rowsrc_off);
+  for (uint32_t r = 0; r < p.L; r++) rowsrc[r] = NRQ_ROW_ZERO;
   for (uint32_t j = 0; j < K; j++) rowsrc[p.S + p.H + j] = j;
-  size_t total = ep.rowsrc_off + (size_t)p.L * 4;
-  HIPCHK(ctx, hipMalloc((void **)&ep.dev, total));
-  HIPCHK(ctx, hipMemcpy(ep.dev, arena, bytes, hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemcpy(ep.dev + ep.rowsrc_off, rowsrc.data(), (size_t)p.L * 4, hipMemcpyHostToDevice));
   nrq_host_free(arena);
+  HIPCHK(ctx, hipMemcpyAsync(ep.dev, ep.pin, total, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->encplan_uploaded, ctx->stream));
+  ep.valid = true;
   ep.build_ms = now_ms() - t0;
-  it = ctx->encplans.emplace(key, ep).first;
-  *out = &it->second;
+  *out = &ep;
   return 0;
 }
 
@@ -539,6 +564,7 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
   if (getenv("NRQ_HOST_PLANNER")) ctx->planner = 0;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->encplan_uploaded, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->staged[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->staged[1], hipEventDisableTiming) != hipSuccess) {
     delete ctx;
@@ -550,9 +576,15 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
 
 void nrq_plan_cache_clear(nrq_ctx *ctx) {
   if (!ctx) return;
+  for (auto &kv : ctx->encplans) kv.second.valid = false; /* buffers are reused by the rebuild */
+}
+
+static void encplans_release(nrq_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
-  for (auto &kv : ctx->encplans)
+  for (auto &kv : ctx->encplans) {
     if (kv.second.dev) (void)hipFree(kv.second.dev);
+    if (kv.second.pin) (void)hipHostFree(kv.second.pin);
+  }
   ctx->encplans.clear();
 }
 
@@ -560,7 +592,8 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  nrq_plan_cache_clear(ctx);
+  encplans_release(ctx);
+  if (ctx->encplan_uploaded) (void)hipEventDestroy(ctx->encplan_uploaded);
   for (auto &kv : ctx->kconst) {
     if (kv.second.dev) (void)hipFree(kv.second.dev);
     nrq_host_free(kv.second.host);
@@ -632,7 +665,8 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   KConst *kc;
   rc = get_kconst(ctx, p.Kp, &kc);
   if (rc) return rc;
-  const bool cached = ctx->encplans.count(((uint64_t)p.Kp << 32) | K) != 0;
+  const auto cached_it = ctx->encplans.find(((uint64_t)p.Kp << 32) | K);
+  const bool cached = cached_it != ctx->encplans.end() && cached_it->second.valid;
   EncPlan *ep;
   rc = get_encplan(ctx, K, p.Kp, &ep);
   if (rc) return rc;

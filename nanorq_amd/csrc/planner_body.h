@@ -42,7 +42,7 @@
 #define PL_NONE 0xFFFFFFFFu
 #define PL_MAXH 16u
 #define PL_PATCH_STRIDE RQ_MAX_LT_COLS
-#define PL_MH_TILE 128u
+#define PL_MH_TILE 256u
 #define PL_LOWCAP 1344u /* leftover rows the dense stage can take (>= inactive-column cap 1280 + 32) */
 #define PL_DENSE_RESERVE (36u * 1024u) /* LDS kept for the dense stage when the peeling state is in LDS too */
 
@@ -102,6 +102,7 @@ typedef struct pl_shared {
   uint32_t arena_top, nchunk1, nchunk2, nops_real, opbase;
   uint32_t uslot_fill, tmp0, tmp1;
   uint32_t off_ops, off_sync, nsyncw;
+  uint32_t lv_in_lds, opq_group[2]; /* W pass: level tables staged in LDS; which group each op buffer holds */
   uint16_t queue[2][PL_QCAP];
   uint16_t claim_r[PL_QCAP], claim_c[PL_QCAP];
   uint32_t partial[PL_NT];
@@ -176,6 +177,8 @@ struct PlanCtx {
   uint32_t lds_dyn_bytes;
   uint8_t *dense_lds;
   uint32_t dense_bytes;
+  uint8_t *aux_lds; /* >= 32 KiB of LDS that is idle between the end of peeling and pl_low_c */
+  uint32_t aux_bytes;
   uint32_t Mcap, npcap, ucap;
   /* workspace views */
   pl_work_layout wl;
@@ -226,6 +229,8 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
    * dense stage (Mb, Mh) uses what is left of the dynamic region */
   c.dense_lds = lds_dyn;
   c.dense_bytes = lds_dyn_bytes;
+  c.aux_lds = lds_dyn;
+  c.aux_bytes = lds_dyn_bytes;
   {
     uint32_t need = pl_r16(Mcap * 4u) * 2u + pl_r16(c.p.L * 4u);
     if (lds_dyn && need + PL_DENSE_RESERVE <= lds_dyn_bytes) {
@@ -234,6 +239,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
       c.colinfo = reinterpret_cast<uint32_t *>(lds_dyn + 2u * pl_r16(Mcap * 4u));
       c.dense_lds = lds_dyn + need;
       c.dense_bytes = lds_dyn_bytes - need;
+      c.aux_bytes = pl_r16(Mcap * 4u); /* the rowstate image, dead once peeling is over */
     }
   }
   c.patch_of = reinterpret_cast<uint16_t *>(w + c.wl.patch_of);
@@ -653,15 +659,50 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
   (void)H;
 }
 
+#define PL_OPQ_WORDS 1024u /* op words a prefetch buffer holds (4 chunks) */
+SB_HD uint32_t *pl_aux_lvbase(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(c.aux_lds); }
+SB_HD uint32_t *pl_aux_lvops(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(c.aux_lds) + (c.sh->nlev + 2u); }
+SB_HD uint32_t *pl_aux_opq(const PlanCtx &c, uint32_t which) {
+  return reinterpret_cast<uint32_t *>(c.aux_lds + pl_r16((c.sh->nlev + 2u) * 8u)) + which * PL_OPQ_WORDS;
+}
+/* stage the per-level op counts / chunk bases in LDS so that a level of the W pass starts without a trip
+ * to HBM; prefetch the first group's ops */
+template <int Z> SB_HD void pl_w_stage(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t need = pl_r16((sh->nlev + 2u) * 8u) + 2u * PL_OPQ_WORDS * 4u;
+  const bool ok = need <= c.aux_bytes;
+  if (tid == 0) { sh->lv_in_lds = ok ? 1u : 0u; sh->opq_group[0] = sh->opq_group[1] = PL_NONE; }
+  if (!ok) return;
+  for (uint32_t l = tid; l < sh->nlev + 2u; l += nt) { pl_aux_lvbase(c)[l] = c.lev_base[l]; pl_aux_lvops(c)[l] = c.lev_ops[l]; }
+}
+
 /* One level group of the op stream applied to W: W[dst] ^= W[src] for every op of the group -- the same
  * forward substitution the solve kernel performs on symbols, here on the bit rows (8 lanes per op; for
- * wpr > 8 each lane takes several words). */
+ * wpr > 8 each lane takes several words).  While a group is processed the op words of the next group are
+ * fetched into the other LDS buffer. */
 template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
   const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr;
-  const uint32_t nops = ((c.lev_ops[group] + NRQ_CHUNK - 1u) / NRQ_CHUNK) * NRQ_CHUNK;
-  const uint32_t *ops = reinterpret_cast<const uint32_t *>(c.arena + sh->off_ops) + (size_t)c.lev_base[group] * NRQ_CHUNK;
+  const bool lds = sh->lv_in_lds != 0u;
+  const uint32_t n_real = lds ? pl_aux_lvops(c)[group] : c.lev_ops[group];
+  const uint32_t base = lds ? pl_aux_lvbase(c)[group] : c.lev_base[group];
+  const uint32_t nops = ((n_real + NRQ_CHUNK - 1u) / NRQ_CHUNK) * NRQ_CHUNK;
+  const uint32_t *gops = reinterpret_cast<const uint32_t *>(c.arena + sh->off_ops);
+  const bool staged = lds && sh->opq_group[group & 1u] == group;
+  const uint32_t *ops = staged ? pl_aux_opq(c, group & 1u) : gops + (size_t)base * NRQ_CHUNK;
+  /* issue the prefetch of the next group first: its loads overlap with this group's work */
+  uint32_t pf[PL_OPQ_WORDS / PL_NT], pf_n = 0;
+  if (lds && group + 1u <= sh->nlev) {
+    const uint32_t n2 = ((pl_aux_lvops(c)[group + 1u] + NRQ_CHUNK - 1u) / NRQ_CHUNK) * NRQ_CHUNK;
+    if (n2 <= PL_OPQ_WORDS) {
+      pf_n = n2;
+      const uint32_t *src = gops + (size_t)pl_aux_lvbase(c)[group + 1u] * NRQ_CHUNK;
+#pragma unroll
+      for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT; q++) pf[q] = (tid + q * nt) < n2 ? src[tid + q * nt] : NRQ_NOP;
+    }
+  }
   if (wpr <= 8u) {
     /* one word per lane; 8 ops per lane group in flight: all op words first, then all source words */
     const uint32_t wsel = w8 < wpr ? w8 : 0u;
@@ -681,18 +722,25 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
       for (uint32_t q = 0; q < 8; q++)
         if (op[q] != NRQ_NOP && w8 < wpr && v[q]) PL_ATOM_XOR(&c.wrows[(size_t)(op[q] & 0xFFFFu) * wpr + w8], v[q]);
     }
-    return;
-  }
-  for (uint32_t e = grp; e < nops; e += ngrp) {
-    const uint32_t op = ops[e];
-    if (op == NRQ_NOP) continue;
-    const uint32_t *src = c.wrows + (size_t)(op >> 16) * wpr;
-    uint32_t *dst = c.wrows + (size_t)(op & 0xFFFFu) * wpr;
-    for (uint32_t wd = w8; wd < wpr; wd += 8u) {
-      const uint32_t v = src[wd];
-      if (v) PL_ATOM_XOR(&dst[wd], v);
+  } else {
+    for (uint32_t e = grp; e < nops; e += ngrp) {
+      const uint32_t op = ops[e];
+      if (op == NRQ_NOP) continue;
+      const uint32_t *src = c.wrows + (size_t)(op >> 16) * wpr;
+      uint32_t *dst = c.wrows + (size_t)(op & 0xFFFFu) * wpr;
+      for (uint32_t wd = w8; wd < wpr; wd += 8u) {
+        const uint32_t v = src[wd];
+        if (v) PL_ATOM_XOR(&dst[wd], v);
+      }
     }
   }
+  if (pf_n) {
+    uint32_t *dstq = pl_aux_opq(c, (group + 1u) & 1u);
+#pragma unroll
+    for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT; q++)
+      if ((tid + q * nt) < pf_n) dstq[tid + q * nt] = pf[q];
+  }
+  if (tid == 0) sh->opq_group[(group + 1u) & 1u] = pf_n ? group + 1u : PL_NONE;
 }
 
 /* =============================== phase 3: leftover rows ====================================== */

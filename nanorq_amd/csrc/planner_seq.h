@@ -44,6 +44,7 @@
     PL_PHASE(pl_ops_clear);
     PL_PHASE(pl_ops_emit);
     /* W = X^-1 * A_U and the leftover rows' reduced coefficients: the op stream run on bit rows */
+    PL_PHASE(pl_w_stage);
     for (uint32_t lv_ = 1; lv_ <= sh_->nlev; lv_++) PL_PHASE1(pl_w_group, lv_);
     PL_PHASE(pl_low_c);
     PL_PHASE(pl_mh_init);
