@@ -99,6 +99,21 @@ def cpu_baseline(args, src_np, lost_np, nrep_enc):
     }, balg_enc / n, balg_dec / n
 
 
+def pmc_traffic(args):
+    """HBM bytes per solve-kernel launch from the committed rocprofv3 --pmc passes (profiles/r1_pmc_hbm.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command; see the file for caveats).
+    Only valid for the default workload; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if (rec.get("K"), rec.get("T"), rec.get("blocks")) != (args.K, args.T, args.blocks):
+        return None
+    return rec.get("bytes_per_launch")
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -116,15 +131,12 @@ def main():
     import nanorq_amd
     from util import loss_pattern
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from nanorq_amd import shard
+    rank, world, local = shard.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
+    shard.init("nccl", device_id=torch.device("cuda", local))  # RCCL; only barrier + timing reduction use it
     dev = torch.device("cuda", local)
     stream = torch.cuda.current_stream(dev)
     ctx = nanorq_amd.Context(local, stream.cuda_stream)
@@ -134,11 +146,13 @@ def main():
     K, T, NB = args.K, args.T, args.blocks
     prm = nanorq_amd.params(K)
     L = prm["L"]
-    # synthetic payload, resident in HBM (seeded per rank so that every GPU works on different blocks)
+    # weak scaling: the job has world*NB source blocks per step, block b lives on GPU b mod world;
+    # payload and loss pattern are functions of the GLOBAL block id, payload generated on the device
+    my_blocks = shard.blocks_of(rank, world, world * NB)
     g = torch.Generator(device=dev)
     g.manual_seed(1 + rank)
     src = torch.randint(0, 256, (NB, K, T), dtype=torch.uint8, device=dev, generator=g)
-    lost = [loss_pattern(K, args.loss, seed=1000 + rank, block=b) for b in range(NB)]
+    lost = [loss_pattern(K, args.loss, seed=1000, block=gb) for gb in my_blocks]
     max_lost = max(len(x) for x in lost)
     nrep = max_lost + args.overhead + 2  # repair symbols generated per block by the encoder
     esis = np.arange(K, K + nrep, dtype=np.uint32)
@@ -185,9 +199,7 @@ def main():
         return enc_stats, dec_stats
 
     def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
+        shard.barrier(world)
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
@@ -202,11 +214,8 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = ctx.ktime_read()
     ctx.ktime_enable(False)
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = shard.reduce_max(elapsed, world, device=dev)   # the slowest rank defines the step time
+    retries_total = int(shard.reduce_sum(retries, world, device=dev))
 
     # correctness of what was timed: every block decoded back to its source
     assert torch.equal(work, src), "decoded blocks differ from the source blocks"
@@ -227,7 +236,7 @@ def main():
             alg_per_launch = 0.5 * (balg_enc + balg_dec) * NB
             achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "nrq_solve_kernel<%d>" %
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args), "kernel": "nrq_solve_kernel<%d>" %
                     enc_stats["strip_bytes"], "avg_launch_ms": avg_ms, "launches_timed": len(ktimes),
                     "algorithmic_bytes_per_launch": alg_per_launch,
                     "algorithmic_bytes_per_block": {"encode": balg_enc, "decode": balg_dec},
@@ -243,18 +252,18 @@ def main():
                        "K": K, "T": T, "blocks_per_gpu": NB, "loss": args.loss, "overhead": args.overhead,
                        "repair_per_block": nrep, "sharding": "blocks over GPUs, no collective",
                        "encode_plan": "cached" if args.no_replan else "rebuilt every step",
-                       "planner": "host, %d threads/rank" % threads, "decode_retries": retries},
+                       "planner": ("device (nrq_plan_kernel, one workgroup per block)" if dec_stats["planner"] else
+                                   "host, %d threads/rank" % threads),
+                       "decode_retries": retries_total},
             "roofline": roof, "cpu_baseline": cpu,
             "detail": {"solve_kernel_ms_sum_per_step": sum(ktimes) / args.steps,
                        "encode": {k: enc_stats[k] for k in ("plan_ms", "host_ms", "strip_bytes", "lds_bytes", "grid",
                                                             "npiv", "u", "nlev")},
                        "decode": {k: dec_stats[k] for k in ("plan_ms", "host_ms", "strip_bytes", "lds_bytes", "grid",
-                                                            "npiv", "u", "nlev")}},
+                                                            "npiv", "u", "nlev", "planner")}},
         }
         print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    shard.finalize(world)
 
 
 if __name__ == "__main__":
