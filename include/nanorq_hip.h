@@ -92,6 +92,17 @@ int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
                       const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
                       size_t inter_stride, int *h_status);
 
+/* Same, using spare symbols only when needed.  Block b's system is first built from its first h_nrep[b]
+ * repair symbols (>= h_nlost[b]); if it is rank deficient the planner takes further symbols from the list,
+ * one at a time up to h_nrep_avail[b], as additional constraint rows -- on the GPU without redoing the
+ * elimination -- instead of failing.  This is what a receiver does that calls nanorq_repair_block again
+ * after one more packet (lib/nanorq.c:620-623), minus the second pass.  h_nrep_avail may be NULL (= h_nrep);
+ * h_used (nullable) receives the number of repair symbols each recovered block consumed. */
+int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                           const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                           const uint32_t *h_nrep, const uint32_t *h_nrep_avail, uint32_t rep_cap, const void *d_rep,
+                           size_t rep_stride, void *d_inter, size_t inter_stride, int *h_status, uint32_t *h_used);
+
 /* Generate encoding symbols from intermediate symbols already in HBM (after encode/decode with
  * d_inter != NULL): symbol q of block b = LT(C_b, isi[q]) -> d_out + b*out_stride + q*T.
  * h_isi are INTERNAL symbol ids (esi for esi < K, esi + K' - K for repair symbols). */

@@ -54,6 +54,8 @@ def lib():
     L.nrq_encode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, vp, sz, C.c_uint32, u32p, vp, sz]
     L.nrq_decode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, u32p, u32p, C.c_uint32, u32p,
                                     u32p, C.c_uint32, vp, sz, vp, sz, ip]
+    L.nrq_decode_blocks_lazy.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, u32p, u32p, C.c_uint32,
+                                         u32p, u32p, u32p, C.c_uint32, vp, sz, vp, sz, ip, u32p]
     L.nrq_gen_symbols.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, C.c_uint32, u32p, vp, sz]
     L.nrq_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.nrq_dev_free.argtypes = [vp, vp]
@@ -212,6 +214,24 @@ class Context:
                                             C.c_void_p(d_rep or 0), rep_stride, C.c_void_p(d_inter or 0),
                                             inter_stride, status.ctypes.data_as(C.POINTER(C.c_int))))
         return status
+
+    def decode_blocks_lazy(self, K, T, nblk, d_src, src_stride, lost, nlost, rep_esi, nrep, nrep_avail, d_rep, rep_stride,
+                           d_inter=0, inter_stride=0, Kp=0):
+        """Like decode_blocks, but block b starts from its first nrep[b] repair symbols and takes more (up to
+        nrep_avail[b]) only if its system is rank deficient.  Returns (status, used)."""
+        lost = np.ascontiguousarray(lost, dtype=np.uint32).reshape(nblk, -1)
+        rep_esi = np.ascontiguousarray(rep_esi, dtype=np.uint32).reshape(nblk, -1)
+        nlost = np.ascontiguousarray(nlost, dtype=np.uint32)
+        nrep = np.ascontiguousarray(nrep, dtype=np.uint32)
+        nrep_avail = np.ascontiguousarray(nrep_avail, dtype=np.uint32)
+        status = np.zeros(nblk, dtype=np.int32)
+        used = np.zeros(nblk, dtype=np.uint32)
+        self._chk(self._L.nrq_decode_blocks_lazy(self._h, K, Kp, T, nblk, C.c_void_p(d_src), src_stride, _u32(lost),
+                                                 _u32(nlost), lost.shape[1], _u32(rep_esi), _u32(nrep), _u32(nrep_avail),
+                                                 rep_esi.shape[1], C.c_void_p(d_rep or 0), rep_stride,
+                                                 C.c_void_p(d_inter or 0), inter_stride,
+                                                 status.ctypes.data_as(C.POINTER(C.c_int)), _u32(used)))
+        return status, used
 
     def gen_symbols(self, K, T, nblk, d_inter, inter_stride, isis, d_out, out_stride, Kp=0):
         isis = np.ascontiguousarray(isis, dtype=np.uint32)

@@ -177,6 +177,10 @@ enum {
   pl_tag_pl_dense_step_a = 14,
   pl_tag_pl_dense_step_b = 14,
   pl_tag_pl_dense_c = 14,
+  pl_tag_pl_extra_a = 14,
+  pl_tag_pl_extra_b = 14,
+  pl_tag_pl_extra_c = 14,
+  pl_tag_pl_extra_d = 14,
   pl_tag_pl_final_a = 15,
   pl_tag_pl_final_b = 15,
   pl_tag_pl_final_c = 15,
@@ -721,7 +725,7 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
 
 static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
                       const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
-                      const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
+                      const uint32_t *h_nrep, const uint32_t *h_avail, uint32_t *h_used, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
                       size_t inter_stride, int *h_status) {
   const double t_begin = now_ms();
   rq_params p;
@@ -738,6 +742,7 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
     std::vector<uint32_t> rowsrc, cptr, orow;
     std::vector<uint16_t> cols;
     int state = 0; /* 0 = nothing to do, 1 = solve, -1 = cannot */
+    uint32_t used = 0;
     size_t off_plan = 0, off_rowsrc = 0, off_cptr = 0, off_row = 0, off_cols = 0;
   };
   std::vector<Prep> prep(nblk);
@@ -751,28 +756,36 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
     if (nr < nl || nl > lost_cap || nr > rep_cap) { pr.state = -1; return; } /* nanorq.c:607-608 */
     const uint32_t *lost = h_lost + (size_t)b * lost_cap;
     const uint32_t *resi = h_rep_esi + (size_t)b * rep_cap;
-    const uint32_t overhead = nr - nl;
-    const uint32_t M = p.L + overhead;
-    if (M > 65535u) { pr.state = -1; return; }
-    std::vector<uint32_t> isis(p.Kp + overhead);
-    for (uint32_t j = 0; j < p.Kp; j++) isis[j] = j;
-    pr.rowsrc.assign(M, NRQ_ROW_ZERO);
-    for (uint32_t j = 0; j < K; j++) pr.rowsrc[p.S + p.H + j] = j;
-    for (uint32_t g = 0; g < nl; g++) {
-      if (lost[g] >= K || (g && lost[g] <= lost[g - 1]) || resi[g] < K || resi[g] >= (1u << 24)) { pr.state = -1; return; }
-      isis[lost[g]] = resi[g] + pad;
-      pr.rowsrc[p.S + p.H + lost[g]] = NRQ_ROW_REP | g;
+    uint32_t avail = h_avail ? h_avail[b] : nr;
+    if (avail < nr) avail = nr;
+    if (avail > rep_cap) avail = rep_cap;
+    /* use nr symbols; while the system is rank deficient and the caller holds more, take one more and re-plan */
+    for (uint32_t use = nr;; use++) {
+      const uint32_t overhead = use - nl;
+      const uint32_t M = p.L + overhead;
+      if (M > 65535u) { pr.state = -1; return; }
+      std::vector<uint32_t> isis(p.Kp + overhead);
+      for (uint32_t j = 0; j < p.Kp; j++) isis[j] = j;
+      pr.rowsrc.assign(M, NRQ_ROW_ZERO);
+      for (uint32_t j = 0; j < K; j++) pr.rowsrc[p.S + p.H + j] = j;
+      for (uint32_t g = 0; g < nl; g++) {
+        if (lost[g] >= K || (g && lost[g] <= lost[g - 1]) || resi[g] < K || resi[g] >= (1u << 24)) { pr.state = -1; return; }
+        isis[lost[g]] = resi[g] + pad;
+        pr.rowsrc[p.S + p.H + lost[g]] = NRQ_ROW_REP | g;
+      }
+      for (uint32_t e = 0; e < overhead; e++) {
+        if (resi[nl + e] < K || resi[nl + e] >= (1u << 24)) { pr.state = -1; return; }
+        isis[p.Kp + e] = resi[nl + e] + pad;
+        pr.rowsrc[p.L + e] = NRQ_ROW_REP | (nl + e);
+      }
+      if (pr.plan) { nrq_host_free(pr.plan); pr.plan = nullptr; }
+      if (nrq_host_plan_build(p.Kp, p.Kp + overhead, isis.data(), kc->host, &pr.plan, &pr.plan_bytes) != 0) {
+        pr.state = -1;
+        return;
+      }
+      if (reinterpret_cast<const nrq_plan_hdr *>(pr.plan)->status == 0) { pr.used = use; break; }
+      if (use + 1 > avail) { pr.state = -1; return; } /* rank(A) < L with everything the caller holds */
     }
-    for (uint32_t e = 0; e < overhead; e++) {
-      if (resi[nl + e] < K || resi[nl + e] >= (1u << 24)) { pr.state = -1; return; }
-      isis[p.Kp + e] = resi[nl + e] + pad;
-      pr.rowsrc[p.L + e] = NRQ_ROW_REP | (nl + e);
-    }
-    if (nrq_host_plan_build(p.Kp, p.Kp + overhead, isis.data(), kc->host, &pr.plan, &pr.plan_bytes) != 0) {
-      pr.state = -1;
-      return;
-    }
-    if (reinterpret_cast<const nrq_plan_hdr *>(pr.plan)->status) { pr.state = -1; return; } /* rank(A) < L */
     build_out_lists(p, reinterpret_cast<const uint16_t *>(pr.plan + reinterpret_cast<const nrq_plan_hdr *>(pr.plan)->off_colslot),
                     nl, lost, pr.cptr, pr.cols); /* ISI of a source symbol is its ESI */
     pr.orow.assign(lost, lost + nl);
@@ -809,7 +822,7 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
   uint32_t nsolve = 0;
   for (uint32_t b = 0; b < nblk; b++) {
     Prep &pr = prep[b];
-    if (pr.state != 2) h_status[b] = pr.state >= 0 ? 1 : 0;
+    if (pr.state != 2) { h_status[b] = pr.state >= 0 ? 1 : 0; if (h_used) h_used[b] = pr.state == 1 ? pr.used : 0; }
     if (pr.state != 1) continue;
     nsolve++;
     pr.off_plan = off;   off = r16(off + pr.plan_bytes);
@@ -878,7 +891,8 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
 static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
                          const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
                          const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
-                         size_t inter_stride, int *h_status, std::vector<uint8_t> *fallback) {
+                         size_t inter_stride, int *h_status, std::vector<uint8_t> *fallback, const uint32_t *h_avail,
+                         uint32_t *h_used) {
   const double t_begin = now_ms();
   rq_params p;
   int rc = block_params(ctx, K, Kp, &p);
@@ -891,8 +905,10 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   ctx->stats.planner = 1;
   uint32_t max_oh = 0, max_nrep = 0, max_nl = 0;
   for (uint32_t b = 0; b < nblk; b++) {
-    const uint32_t nl = h_nlost[b], nr = h_nrep[b];
+    const uint32_t nl = h_nlost[b];
+    uint32_t nr = h_nrep[b];
     if (nl == 0 || nr < nl || nl > lost_cap || nr > rep_cap) continue;
+    if (h_avail && h_avail[b] > nr) nr = h_avail[b] < rep_cap ? h_avail[b] : rep_cap; /* sizing: everything it may use */
     if (nr - nl > max_oh) max_oh = nr - nl;
     if (nr > max_nrep) max_nrep = nr;
     if (nl > max_nl) max_nl = nl;
@@ -900,7 +916,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   uint32_t ucap = p.P + 768u;
   if (ucap > 1280u) ucap = 1280u; /* 40 words per W row at most */
   if (ucap < p.P + 32u) return fail(ctx, -5, "K'=%u has too many permanently inactive columns for the device planner", p.Kp);
-  const uint32_t Mcap = p.L + max_oh + 8u, npcap = max_nrep + 8u;
+  const uint32_t Mcap = p.L + max_oh + PL_EXTRA_ROWS + 8u, npcap = max_nrep + PL_EXTRA_ROWS + 8u;
   const pl_work_layout wl = pl_work_plan(p.L, Mcap, npcap, ucap);
   const uint32_t arena_cap = pl_arena_bound(p.L, Mcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE, max_nl + 8u);
   if ((rc = ensure_dev(ctx, ctx->plan_work, (size_t)nblk * wl.total))) return rc;
@@ -936,6 +952,8 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
     j.nlost = sane ? h_nlost[b] : 0;
     j.nrep = sane ? h_nrep[b] : 0;
+    j.nrep_avail = j.nrep;
+    if (sane && h_avail && h_avail[b] > j.nrep) j.nrep_avail = h_avail[b] < rep_cap ? h_avail[b] : rep_cap;
     j.arena_cap = arena_cap;
   }
   HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -977,10 +995,12 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   std::vector<const nrq_plan_hdr *> hdrs;
   bool need_fallback = false;
   for (uint32_t b = 0; b < nblk; b++) {
+    if (h_used) h_used[b] = 0;
     if (h_nlost[b] == 0) { h_status[b] = 1; continue; } /* nothing missing (nanorq.c:605-606) */
     if (hd[b].magic != NRQ_PLAN_MAGIC) return fail(ctx, -11, "device planner produced no header for block %u", b);
     if (hd[b].status == 0) {
       h_status[b] = 1;
+      if (h_used) h_used[b] = h_nrep[b] + hd[b].reserved[1];
       hdrs.push_back(&hd[b]);
       if (ctx->stats.npiv == 0) {
         ctx->stats.npiv = hd[b].npiv; ctx->stats.u = hd[b].u; ctx->stats.nlev = hd[b].nlev; ctx->stats.nfree = hd[b].nfree;
@@ -1003,23 +1023,31 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   return need_fallback ? 1 : 0;
 }
 
-int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
-                      const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
-                      const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
-                      size_t inter_stride, int *h_status) {
+int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                           const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                           const uint32_t *h_nrep, const uint32_t *h_nrep_avail, uint32_t rep_cap, const void *d_rep,
+                           size_t rep_stride, void *d_inter, size_t inter_stride, int *h_status, uint32_t *h_used) {
   if (!ctx) return -1;
   if (!d_src || T == 0 || nblk == 0 || !h_nlost || !h_nrep || !h_status) return fail(ctx, -1, "bad arguments");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (!ctx->planner)
-    return decode_host(ctx, nullptr, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap,
-                       d_rep, rep_stride, d_inter, inter_stride, h_status);
+    return decode_host(ctx, nullptr, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
+                       h_nrep_avail, h_used, rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);
   std::vector<uint8_t> fallback(nblk, 0);
   int rc = decode_device(ctx, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap, d_rep,
-                         rep_stride, d_inter, inter_stride, h_status, &fallback);
+                         rep_stride, d_inter, inter_stride, h_status, &fallback, h_nrep_avail, h_used);
   if (rc <= 0) return rc;
   /* blocks that exceeded a device-planner capacity are planned on the host (rare) */
   return decode_host(ctx, fallback.data(), K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
-                     rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);
+                     h_nrep_avail, h_used, rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);
+}
+
+int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                      const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                      const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
+                      size_t inter_stride, int *h_status) {
+  return nrq_decode_blocks_lazy(ctx, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, nullptr,
+                                rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status, nullptr);
 }
 
 int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,

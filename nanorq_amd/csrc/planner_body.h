@@ -43,6 +43,8 @@
 #define PL_MAXH 16u
 #define PL_PATCH_STRIDE RQ_MAX_LT_COLS
 #define PL_MH_TILE 256u
+#define PL_EXTRA_ROWS 8u   /* repair symbols a block may take beyond nrep when rank deficient */
+#define PL_SPARE_CHUNKS 2u /* op chunks reserved for the rows added that way */
 #define PL_LOWCAP 1344u /* leftover rows the dense stage can take (>= inactive-column cap 1280 + 32) */
 #define PL_DENSE_RESERVE (36u * 1024u) /* LDS kept for the dense stage when the peeling state is in LDS too */
 
@@ -53,9 +55,9 @@ typedef struct nrq_planjob {
   uint64_t work;     /* this block's workspace (nrq_planwork_bytes) */
   uint64_t arena;    /* plan arena out (capacity arena_cap bytes) */
   uint64_t src, rep, inter; /* forwarded into the solve job: symbol buffers of the block */
-  uint32_t nlost, nrep;
+  uint32_t nlost, nrep; /* nrep: repair symbols to use up front (>= nlost) */
   uint32_t arena_cap;
-  uint32_t pad;
+  uint32_t nrep_avail;  /* >= nrep: further symbols the planner may take, one at a time, if the system is rank deficient */
 } nrq_planjob;
 
 /* ---- atomics: device intrinsics / plain memory in the emulator ---- */
@@ -102,7 +104,9 @@ typedef struct pl_shared {
   uint32_t arena_top, nchunk1, nchunk2, nops_real, opbase;
   uint32_t uslot_fill, tmp0, tmp1;
   uint32_t off_ops, off_sync, nsyncw;
-  uint32_t lv_in_lds, opq_group[2]; /* W pass: level tables staged in LDS; which group each op buffer holds */
+  uint32_t lv_in_lds, opq_group[2];
+  uint32_t tmp_mhoff; /* byte offset of MhT inside the dense LDS region (fixed once nlow is known) */
+  uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
   uint16_t queue[2][PL_QCAP];
   uint16_t claim_r[PL_QCAP], claim_c[PL_QCAP];
   uint32_t partial[PL_NT];
@@ -318,7 +322,8 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     const uint32_t nl = c.job.nlost, nr = c.job.nrep;
     if (nl == 0 || nr < nl) st = PL_FAIL_SINGULAR;
     uint32_t oh = st ? 0 : nr - nl;
-    if (!st && (p.L + oh > c.Mcap || nr > c.npcap || p.L + oh > 65534u)) st = PL_FAIL_CAPACITY;
+    if (!st && (p.L + oh + PL_EXTRA_ROWS > c.Mcap || nr + PL_EXTRA_ROWS > c.npcap || p.L + oh + PL_EXTRA_ROWS > 65534u))
+      st = PL_FAIL_CAPACITY;
     sh->status = st;
     sh->overhead = oh;
     sh->M = p.L + oh;
@@ -327,6 +332,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->nq[0] = sh->nq[1] = 0; sh->nclaim[0] = sh->nclaim[1] = 0; sh->best = PL_NONE;
     sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = PL_NONE;
     sh->nchunk1 = sh->nchunk2 = 0; sh->nops_real = 0; sh->uslot_fill = 0;
+    sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE;
   }
   /* GF(256) tables into LDS (RFC 6330 section 5.7): generated by one thread, 255 steps */
   if (tid == 1 % nt) {
@@ -756,16 +762,18 @@ template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /*
 template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (tid != 0) return;
-  sh->lpr = sh->nlow ? (sh->nlow + 31u) / 32u : 1u;
+  sh->lpr = (sh->nlow + PL_EXTRA_ROWS + 31u) / 32u; /* room for the rows a rank-deficient block may add */
   sh->rowlen = sh->wpr + sh->lpr;
   /* Mb (nlow x rowlen words) and Mh (H x u bytes) share the dynamic LDS region from here on */
-  uint32_t need = pl_r16(sh->nlow * sh->rowlen * 4u) + pl_r16(PL_MAXH * (c.p.L - sh->npiv)) + PL_MH_TILE * 16u +
+  if (sh->nlow + PL_EXTRA_ROWS > PL_LOWCAP) sh->status = PL_FAIL_CAPACITY;
+  sh->tmp_mhoff = pl_r16((sh->nlow + PL_EXTRA_ROWS) * sh->rowlen * 4u);
+  uint32_t need = pl_r16((sh->nlow + PL_EXTRA_ROWS) * sh->rowlen * 4u) + pl_r16(PL_MAXH * (c.p.L - sh->npiv)) + PL_MH_TILE * 16u +
                   PL_MH_TILE * sh->wpr * 4u;
   if (need > c.dense_bytes || sh->wpr > 40u) sh->status = PL_FAIL_CAPACITY;
 }
 SB_HD uint32_t *pl_mb(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(c.dense_lds); }
 /* HDPC rows over the inactive columns, transposed: 16 bytes (one per HDPC row) per inactive column */
-SB_HD uint8_t *pl_mhm(const PlanCtx &c) { return c.dense_lds + pl_r16(c.sh->nlow * c.sh->rowlen * 4u); }
+SB_HD uint8_t *pl_mhm(const PlanCtx &c) { return c.dense_lds + c.sh->tmp_mhoff; }
 SB_HD uint8_t *pl_gtile(const PlanCtx &c) { return pl_mhm(c) + pl_r16(PL_MAXH * (c.p.L - c.sh->npiv)); }
 SB_HD uint32_t *pl_wtile(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(pl_gtile(c) + PL_MH_TILE * 16u); }
 
@@ -795,9 +803,11 @@ template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt)
     c.lev_fill[l] = 0;
   }
   if (sh->nlev == 0) sh->nchunk1 = 0;
+  sh->spare_base = chunks; /* chunks reserved for rows added later; their barrier bit is set below */
+  chunks += PL_SPARE_CHUNKS;
   sh->tmp0 = chunks; /* chunks so far; the GF(2) combination group follows after the elimination */
   /* ops region: generous bound for the combination group (nlow ones per reduced row at most) */
-  uint32_t bin_bound = (sh->nlow * sh->nlow + NRQ_CHUNK - 1u) / NRQ_CHUNK + 1u;
+  uint32_t bin_bound = ((sh->nlow + PL_EXTRA_ROWS) * (sh->nlow + PL_EXTRA_ROWS) + NRQ_CHUNK - 1u) / NRQ_CHUNK + 1u;
   uint32_t total_chunks = chunks + bin_bound + 8u;
   sh->off_ops = pl_r16(c.fixed_end);
   sh->nsyncw = (total_chunks + 31u) / 32u + 2u;
@@ -813,7 +823,10 @@ template <int Z> SB_HD void pl_ops_clear(PlanCtx &c, uint32_t tid, uint32_t nt) 
   const uint32_t nw = sh->opbase * NRQ_CHUNK;
   for (uint32_t k = tid; k < nw; k += nt) ops[k] = NRQ_NOP;
   uint32_t *sy = reinterpret_cast<uint32_t *>(c.arena + sh->off_sync);
-  for (uint32_t k = tid; k < sh->nsyncw; k += nt) sy[k] = 0;
+  for (uint32_t k = tid; k < sh->nsyncw; k += nt) {
+    const uint32_t last = sh->spare_base + PL_SPARE_CHUNKS - 1u; /* barrier after the spare chunks */
+    sy[k] = (k == (last >> 5)) ? (1u << (last & 31u)) : 0u;
+  }
 }
 /* position of the i-th op of a run starting at `pos` inside a group of n ops: a multiplicative shuffle
  * keeps the ops of one row apart so that the lanes of a wave rarely hit the same target slot */
@@ -962,7 +975,6 @@ template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t x, uint32_t tid, uint32
 template <int Z> SB_HD void pl_bin_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (tid == 0) {
-    if (sh->status == 0 && (sh->nfree > c.p.H || sh->nfree > NRQ_MAX_FREE)) sh->status = PL_FAIL_SINGULAR;
     sh->tmp1 = 0;
   }
   const uint32_t *Mb = pl_mb(c);
@@ -1016,6 +1028,10 @@ template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 template <int Z> SB_HD void pl_dense_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
+  /* more free columns than HDPC rows: rank deficient for sure (decided identically by every thread) */
+  const bool feasible = sh->nfree <= c.p.H && sh->nfree <= NRQ_MAX_FREE;
+  if (tid == 0) sh->dense_ok = feasible ? 1u : 0u;
+  if (!feasible) return;
   const uint32_t H = c.p.H, r2 = sh->r2, nfree = sh->nfree;
   const uint32_t *Mb = pl_mb(c);
   const uint8_t *Mh = pl_mhm(c);
@@ -1035,7 +1051,7 @@ template <int Z> SB_HD void pl_dense_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 template <int Z> SB_HD void pl_dense_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  if (sh->status) return;
+  if (sh->status || !sh->dense_ok) return;
   const uint32_t H = c.p.H, r2 = sh->r2, nfree = sh->nfree, aw = nfree + H;
   const uint8_t *Mh = pl_mhm(c);
   for (uint32_t e = tid; e < H * aw; e += nt) {
@@ -1054,12 +1070,12 @@ template <int Z> SB_HD void pl_dense_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
 /* one elimination step on the augmented system: column f.  Thread w owns augmented column w. */
 template <int Z> SB_HD void pl_dense_step_a(PlanCtx &c, uint32_t f, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  if (sh->status || tid != 0) return;
+  if (sh->status || !sh->dense_ok || tid != 0) return;
   const uint32_t H = c.p.H, aw = sh->nfree + H;
   uint32_t pr = PL_NONE;
   for (uint32_t h = 0; h < H; h++)
     if (!sh->taken[h] && sh->aug[h * aw + f]) { pr = h; break; }
-  if (pr == PL_NONE) { sh->status = PL_FAIL_SINGULAR; return; }
+  if (pr == PL_NONE) { sh->dense_ok = 0; return; } /* the HDPC rows cannot resolve column f: rank deficient */
   sh->taken[pr] = 1;
   sh->solver[f] = (uint8_t)pr;
   sh->tmp1 = pr;
@@ -1067,7 +1083,7 @@ template <int Z> SB_HD void pl_dense_step_a(PlanCtx &c, uint32_t f, uint32_t tid
 }
 template <int Z> SB_HD void pl_dense_step_b(PlanCtx &c, uint32_t f, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  if (sh->status) return;
+  if (sh->status || !sh->dense_ok) return;
   const uint32_t H = c.p.H, aw = sh->nfree + H, pr = sh->tmp1;
   if (tid >= aw) return;
   /* thread = augmented column; the pivot column is read from the snapshot step A took */
@@ -1084,11 +1100,100 @@ template <int Z> SB_HD void pl_dense_step_b(PlanCtx &c, uint32_t f, uint32_t tid
 }
 template <int Z> SB_HD void pl_dense_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  if (sh->status) return;
+  if (sh->status == 0 && !sh->dense_ok && tid == 0) sh->status = PL_FAIL_SINGULAR; /* and no symbol left to add */
+  if (sh->status || !sh->dense_ok) return;
   const uint32_t H = c.p.H, nfree = sh->nfree, aw = nfree + H;
   for (uint32_t e = tid; e < nfree * H; e += nt) {
     const uint32_t f = e / H, h = e - f * H;
     c.hinv[e] = sh->aug[sh->solver[f] * aw + nfree + h];
+  }
+}
+
+/* =============================== phase 7b: one more symbol for a rank-deficient block ======= */
+/* The system is rank deficient with the symbols used so far.  If the caller holds further repair symbols
+ * (job.nrep_avail), take the next one as an additional constraint row WITHOUT redoing the peeling: its
+ * data ops go into the spare chunks of the op stream, its coefficient row over the inactive columns is
+ * reduced against the Gauss-Jordan state, and if something is left it pivots one free column. */
+template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status || tid != 0) return;
+  const rq_params &p = c.p;
+  const uint32_t i = sh->npatch;
+  if (i >= c.job.nrep_avail || sh->nextra >= PL_EXTRA_ROWS) { sh->status = PL_FAIL_SINGULAR; return; }
+  const uint32_t esi = c.rep_esi[i];
+  if (esi < p.K || esi >= (1u << 24)) { sh->status = PL_FAIL_SINGULAR; return; }
+  const uint32_t row = sh->M, j = sh->nlow;
+  if (row + 1u > c.Mcap || i + 1u > c.npcap || j + 1u > PL_LOWCAP) { sh->status = PL_FAIL_CAPACITY; return; }
+  uint32_t cols[RQ_MAX_LT_COLS];
+  const uint32_t n = rq_lt_columns(&p, esi + (p.Kp - p.K), cols);
+  uint16_t *dst = c.patch_cols + (size_t)i * PL_PATCH_STRIDE;
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops) + (size_t)sh->spare_base * NRQ_CHUNK;
+  for (uint32_t k = 0; k < n; k++) {
+    dst[k] = (uint16_t)cols[k];
+    const uint32_t info = c.colinfo[cols[k]];
+    if ((info >> 30) == PL_ST_PIVOT) {
+      if (sh->spare_fill >= PL_SPARE_CHUNKS * NRQ_CHUNK) { sh->status = PL_FAIL_CAPACITY; return; }
+      ops[sh->spare_fill++] = row | ((uint32_t)c.pivslot[info & 0x3FFFFFFFu] << 16);
+    }
+  }
+  c.patch_len[i] = (uint8_t)n;
+  c.patch_of[row] = (uint16_t)i;
+  c.rowinfo[row] = PL_UNASSIGNED | PL_PATCHED;
+  c.lowslot[j] = (uint16_t)row;
+  sh->gj_used[j] = 0;
+  sh->M = row + 1u; sh->npatch = i + 1u; sh->nlow = j + 1u; sh->nextra++;
+  sh->cand[0] = sh->cand[1] = PL_NONE;
+}
+/* its bit row over the inactive columns: own inactive entries plus the W rows of its pivot columns */
+template <int Z> SB_HD void pl_extra_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t wpr = sh->wpr, rowlen = sh->rowlen, j = sh->nlow - 1u, row = c.lowslot[j];
+  if (tid >= rowlen) return;
+  uint32_t acc = 0;
+  if (tid < wpr) {
+    const uint16_t *cols;
+    const uint32_t n = pl_row(c, row, &cols);
+    for (uint32_t k = 0; k < n; k++) {
+      const uint32_t info = c.colinfo[cols[k]], idx = info & 0x3FFFFFFFu;
+      if ((info >> 30) == PL_ST_INACT) { if ((idx >> 5) == tid) acc ^= 1u << (idx & 31u); }
+      else acc ^= c.wrows[(size_t)c.pivslot[idx] * wpr + tid];
+    }
+    c.wrows[(size_t)row * wpr + tid] = acc;
+  } else {
+    acc = ((tid - wpr) == (j >> 5)) ? (1u << (j & 31u)) : 0u;
+  }
+  sh->xrow[tid] = acc;
+}
+/* reduce it against the pivots found so far (pivot rows are fully reduced, so the order does not matter) */
+template <int Z> SB_HD void pl_extra_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t rowlen = sh->rowlen, j = sh->nlow - 1u;
+  if (tid >= rowlen) return;
+  uint32_t *Mb = pl_mb(c);
+  uint32_t acc = sh->xrow[tid];
+  for (uint32_t q = 0; q < sh->r2; q++) {
+    const uint32_t x = c.red_x[q];
+    if ((sh->xrow[x >> 5] >> (x & 31u)) & 1u) acc ^= Mb[(size_t)c.red_row[q] * rowlen + tid];
+  }
+  Mb[(size_t)j * rowlen + tid] = acc;
+}
+/* whatever is left sits in free columns: the first of them becomes this row's pivot column */
+template <int Z> SB_HD void pl_extra_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status || tid != 0) return;
+  const uint32_t *row = pl_mb(c) + (size_t)(sh->nlow - 1u) * sh->rowlen;
+  sh->xcol = PL_NONE;
+  const uint32_t nf = sh->nfree < NRQ_MAX_FREE ? sh->nfree : NRQ_MAX_FREE;
+  for (uint32_t f = 0; f < nf; f++) {
+    const uint32_t x = sh->freex[f];
+    if ((row[x >> 5] >> (x & 31u)) & 1u) {
+      sh->xcol = x;
+      for (uint32_t g = f; g + 1u < nf; g++) sh->freex[g] = sh->freex[g + 1u];
+      sh->nfree--; /* nfree may exceed the list capacity; entries beyond it were never recorded */
+      break;
+    }
   }
 }
 
@@ -1173,6 +1278,7 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   h.magic = NRQ_PLAN_MAGIC;
   h.status = sh->status ? 1u : 0u;
   h.reserved[0] = sh->status; /* PL_FAIL_* reason */
+  h.reserved[1] = sh->nextra; /* repair symbols taken beyond job.nrep */
   h.K = p.Kp; h.Kp = p.Kp; h.S = p.S; h.H = p.H; h.W = p.W; h.L = p.L; h.P = p.P; h.B = p.B;
   h.M = sh->M; h.npiv = sh->npiv; h.u = p.L - sh->npiv; h.nlow = sh->nlow; h.r2 = sh->r2; h.nfree = sh->nfree;
   h.nlev = sh->nlev; h.nchunk1 = sh->nchunk1; h.nchunk2 = sh->nchunk2; h.wpr = sh->wpr; h.lpr = sh->lpr;
@@ -1187,7 +1293,7 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
     uint32_t run = 0;
     for (uint32_t g = 0; g < nl; g++) { cptr[g] = run; run += c.pivdeg[g]; }
     cptr[nl] = run;
-    h.n_xor_ops = c.lev_ops[sh->nlev + 1u] + run;
+    h.n_xor_ops = c.lev_ops[sh->nlev + 1u] + run + sh->spare_fill;
     for (uint32_t l = 0; l <= sh->nlev; l++) h.n_xor_ops += c.lev_ops[l];
   }
   *c.hdr = h;

@@ -59,19 +59,33 @@
         PL_PHASE1(pl_gj_b, x_);
       }
     }
-    PL_PHASE(pl_bin_a);
-    PL_PHASE(pl_bin_b);
-    PL_PHASE(pl_bin_c);
-    PL_PHASE(pl_dense_a);
-    PL_PHASE(pl_dense_b);
-    if (sh_->status == 0) {
-      const uint32_t nf_ = sh_->nfree;
-      for (uint32_t f_ = 0; f_ < nf_; f_++) {
-        PL_PHASE1(pl_dense_step_a, f_);
-        PL_PHASE1(pl_dense_step_b, f_);
+    /* the free columns over GF(256); while that fails and the caller holds further symbols, add one row */
+    for (uint32_t try_ = 0; try_ <= PL_EXTRA_ROWS + 1u; try_++) {
+      PL_PHASE(pl_dense_a);
+      PL_PHASE(pl_dense_b);
+      if (sh_->status == 0 && sh_->dense_ok) {
+        const uint32_t nf_ = sh_->nfree;
+        for (uint32_t f_ = 0; f_ < nf_; f_++) {
+          PL_PHASE1(pl_dense_step_a, f_);
+          PL_PHASE1(pl_dense_step_b, f_);
+        }
+      }
+      if (sh_->status != 0 || sh_->dense_ok) break;
+      PL_PHASE(pl_extra_a);
+      if (sh_->status != 0) break;
+      PL_PHASE(pl_extra_b);
+      PL_PHASE(pl_extra_c);
+      PL_PHASE(pl_extra_d);
+      if (sh_->xcol != PL_NONE) {
+        const uint32_t xc_ = sh_->xcol;
+        PL_PHASE1(pl_gj_a, xc_);
+        PL_PHASE1(pl_gj_b, xc_);
       }
     }
     PL_PHASE(pl_dense_c);
+    PL_PHASE(pl_bin_a);
+    PL_PHASE(pl_bin_b);
+    PL_PHASE(pl_bin_c);
     PL_PHASE(pl_final_a);
     PL_PHASE(pl_final_b);
     PL_PHASE(pl_final_c);

@@ -19,14 +19,15 @@ extern "C" uint32_t emu_plan_arena_bound(uint32_t K, const uint8_t *kc, uint32_t
 
 /* returns 0 and fills arena (status in its header); job_out receives the solve job (host pointers) */
 extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const uint32_t *lost, uint32_t nlost,
-                        const uint32_t *rep_esi, uint32_t nrep, uint8_t *arena, uint32_t arena_cap,
-                        uint32_t lds_dyn_bytes, nrq_job *job_out) {
+                        const uint32_t *rep_esi, uint32_t nrep, uint32_t nrep_avail, uint8_t *arena,
+                        uint32_t arena_cap, uint32_t lds_dyn_bytes, nrq_job *job_out) {
   rq_params p;
   if (!rq_params_init(Kp_hint ? Kp_hint : K, &p)) return -1;
   p.K = K;
   const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(kc);
-  const uint32_t ohcap = nrep > nlost ? nrep - nlost : 0;
-  const uint32_t Mcap = kh->L + ohcap + 8, npcap = nrep + 8, ucap = kh->P + 768u;
+  if (nrep_avail < nrep) nrep_avail = nrep;
+  const uint32_t ohcap = nrep_avail > nlost ? nrep_avail - nlost : 0;
+  const uint32_t Mcap = kh->L + ohcap + PL_EXTRA_ROWS + 8, npcap = nrep_avail + PL_EXTRA_ROWS + 8, ucap = kh->P + 768u;
   pl_work_layout wl = pl_work_plan(kh->L, Mcap, npcap, ucap);
   std::vector<uint8_t> work(wl.total + 64, 0xCC), dyn(lds_dyn_bytes + 64, 0xDD);
   pl_shared *sh = new pl_shared;
@@ -37,7 +38,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   job.rep_esi = (uint64_t)(uintptr_t)rep_esi;
   job.work = (uint64_t)(uintptr_t)work.data();
   job.arena = (uint64_t)(uintptr_t)arena;
-  job.nlost = nlost; job.nrep = nrep; job.arena_cap = arena_cap;
+  job.nlost = nlost; job.nrep = nrep; job.arena_cap = arena_cap; job.nrep_avail = nrep_avail;
   PlanCtx c;
   pl_ctx_setup(c, p, kc, job, sh, lds_dyn_bytes ? dyn.data() : nullptr, lds_dyn_bytes, Mcap, npcap, ucap, job_out);
 #define PL_PHASE(fn) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, t_, PL_NT); } while (0)

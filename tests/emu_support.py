@@ -92,25 +92,27 @@ def pemu():
     if _PEMU is None:
         L = C.CDLL(nbuild.build_planner_emu())
         u32p = C.POINTER(C.c_uint32)
-        L.emu_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, u32p, C.c_uint32, u32p, C.c_uint32, C.c_void_p,
-                               C.c_uint32, C.c_uint32, C.POINTER(Job)]
+        L.emu_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, u32p, C.c_uint32, u32p, C.c_uint32, C.c_uint32,
+                               C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Job)]
         L.emu_plan_arena_bound.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
         L.emu_plan_arena_bound.restype = C.c_uint32
         _PEMU = L
     return _PEMU
 
 
-def emu_device_plan(K, kconst, lost, rep_esis, lds_bytes=140 * 1024, Kp=0):
-    """Run the GPU planner's phase code on the CPU. Returns the plan arena (bytes)."""
+def emu_device_plan(K, kconst, lost, rep_esis, lds_bytes=140 * 1024, Kp=0, use=None):
+    """Run the GPU planner's phase code on the CPU. Returns (plan arena bytes, header).  `use` = number of repair
+    symbols to use up front (default all); the rest may be taken one at a time if the system is rank deficient."""
     L_ = pemu()
     kcb = (C.c_uint8 * len(kconst)).from_buffer_copy(kconst)
     lost = np.ascontiguousarray(lost, np.uint32)
     rep_esis = np.ascontiguousarray(rep_esis, np.uint32)
-    cap = L_.emu_plan_arena_bound(K, C.addressof(kcb), max(0, len(rep_esis) - len(lost)) + 8, len(lost) + 8)
+    cap = L_.emu_plan_arena_bound(K, C.addressof(kcb), max(0, len(rep_esis) - len(lost)) + 24, len(lost) + 8)
+    use = len(rep_esis) if use is None else use
     arena = np.zeros(cap, np.uint8)
     job = Job()
     rc = L_.emu_plan(K, Kp, C.addressof(kcb), lost.ctypes.data_as(C.POINTER(C.c_uint32)), len(lost),
-                     rep_esis.ctypes.data_as(C.POINTER(C.c_uint32)), len(rep_esis), arena.ctypes.data, cap, lds_bytes,
+                     rep_esis.ctypes.data_as(C.POINTER(C.c_uint32)), use, len(rep_esis), arena.ctypes.data, cap, lds_bytes,
                      C.byref(job))
     assert rc == 0
     hdr = nanorq_amd.plan_header(arena.tobytes()[:256])

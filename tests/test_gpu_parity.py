@@ -176,3 +176,42 @@ def test_roundtrip_large_symbols(G):
     """BASELINE configs[3] shape: K=27000 with large symbols (T reduced to 4096 to bound host memory)."""
     st, out, src = _roundtrip(G, 27000, 4096, 1, 0.10, 2, seed=51)
     assert st[0] == 1 and np.array_equal(out[0], src[0])
+
+
+@pytest.mark.parametrize("planner", ["device", "host"])
+def test_lazy_decode_takes_spare_symbols_only_when_needed(G, orc, planner):
+    """nrq_decode_blocks_lazy: start from exactly K symbols; rank-deficient blocks consume spare repair symbols
+    one at a time (extra constraint rows) and still decode bit-exactly; the others use none."""
+    from emu_support import decode_setup
+    K, T, nblk = 12, 24, 300
+    c = G.ctx()
+    c.set_planner(planner == "device")
+    try:
+        src = payload(K * T, seed=33).reshape(K, T)
+        all_rep, _ = G.gpu_encode(src.reshape(1, K, T), K, T, np.arange(K, K + 64, dtype=np.uint32))
+        rng = np.random.default_rng(3)
+        lost = np.zeros((nblk, 8), np.uint32); resi = np.zeros((nblk, 12), np.uint32)
+        nlost = np.zeros(nblk, np.uint32); reps = np.zeros((nblk, 12, T), np.uint8)
+        need_more = []
+        for b in range(nblk):
+            nl = int(rng.integers(1, 7))
+            lo = np.sort(rng.choice(K, nl, replace=False)).astype(np.uint32)
+            es = (K + rng.choice(64, nl + 4, replace=False)).astype(np.uint32)
+            lost[b, :nl] = lo; resi[b, :nl + 4] = es; nlost[b] = nl; reps[b, :nl + 4] = all_rep[0][es - K]
+            isis, _ = decode_setup(orc, K, lo, es[:nl])
+            need_more.append(orc.plan_probe(K, isis)[0] == 0)
+        work = np.repeat(src.reshape(1, K, T), nblk, axis=0).copy()
+        for b in range(nblk):
+            work[b][lost[b, :nlost[b]]] = 0x3C
+        d_src = c.alloc(work.nbytes); d_rep = c.alloc(reps.nbytes)
+        c.upload(d_src, work); c.upload(d_rep, reps)
+        st, used = c.decode_blocks_lazy(K, T, nblk, d_src, K * T, lost, nlost, resi, nlost, nlost + 4, d_rep, 12 * T)
+        c.sync()
+        out = c.download(d_src, work.nbytes).reshape(nblk, K, T)
+        c.free(d_src); c.free(d_rep)
+        assert any(need_more)
+        for b in range(nblk):
+            assert st[b] == 1 and np.array_equal(out[b], src), b
+            assert (used[b] > nlost[b]) == need_more[b], (b, used[b], nlost[b])
+    finally:
+        c.set_planner(True)

@@ -158,3 +158,37 @@ def test_device_planner_rejects_bad_input(orc):
     assert emu_device_plan(K, kc, [5, 7], [100])[1]["status"] == 1           # fewer repair symbols than gaps
     assert emu_device_plan(K, kc, [5, 200], [100, 101])[1]["status"] == 1    # ESI outside the block
     assert emu_device_plan(K, kc, [5, 7], [100, 50])[1]["status"] == 1       # repair ESI below K
+
+
+def test_device_planner_takes_more_symbols_when_rank_deficient(orc):
+    """Lazy use of spare symbols: planned with exactly K symbols; where that system is rank deficient the planner
+    adds the next repair symbol(s) as extra rows without re-peeling.  The decoded block must equal the source."""
+    K, T = 12, 16
+    prm = orc.params(K)
+    kc = nanorq_amd.host_kconst(K)
+    src = payload(K * T, seed=21).reshape(K, T)
+    rng = np.random.default_rng(5)
+    took_extra = 0
+    for trial in range(900):
+        nl = int(rng.integers(1, 7))
+        lost = np.sort(rng.choice(K, nl, replace=False)).astype(np.uint32)
+        rep_esis = (K + rng.choice(60, nl + 4, replace=False)).astype(np.uint32)
+        isis0, _ = decode_setup(orc, K, lost, rep_esis[:nl])
+        r0, _ = orc.plan_probe(K, isis0)
+        plan, hdr = emu_device_plan(K, kc, lost, rep_esis, use=nl)
+        if hdr["status"] != 0:
+            # even all nl+4 symbols must then be insufficient for the reference algorithm
+            isis_all, _ = decode_setup(orc, K, lost, rep_esis)
+            assert orc.plan_probe(K, isis_all)[0] == 0
+            continue
+        nextra = hdr["M"] - prm["L"]
+        assert (nextra == 0) == (r0 == 1)
+        took_extra += nextra > 0
+        rep, _, _ = orc.encode_block(src, K, T, rep_esis[:nl + nextra])
+        _, rowsrc = decode_setup(orc, K, lost, rep_esis[:nl + nextra])
+        work = src.copy()
+        work[lost] = 0x11
+        lists = lt_lists(orc, K, lost, plan)
+        r, _ = emu_solve(plan, kc, rowsrc, work, rep, T, prm["L"], lists, lost, work, 16)
+        assert r == 1 and np.array_equal(work, src), trial
+    assert took_extra > 0
