@@ -30,7 +30,7 @@
 #include "rq_math.h"
 #include "solve_body.h"
 
-#define PL_NT 256u
+#define PL_NT 1024u
 #define PL_QCAP 2048u          /* frontier / claim queue capacity */
 #define PL_UNASSIGNED 0x80000000u /* rowinfo bit 31: row has no pivot column (yet) */
 #define PL_PATCHED 0x40000000u    /* rowinfo bit 30: this block replaced the base row (its base CSC entries are void) */
