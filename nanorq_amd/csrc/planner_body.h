@@ -498,8 +498,9 @@ template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid,
   if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
 }
 /* No claimant in the frontier: find the open row with the fewest V columns (workgroup-wide atomic min) */
-template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
+  const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24; /* rep-th row of this inactivation event */
   uint32_t best = PL_NONE;
   for (uint32_t r = tid; r < sh->M; r += nt) {
     if (!(c.rowinfo[r] & PL_UNASSIGNED)) continue;
@@ -510,13 +511,15 @@ template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rd, uint32_t tid,
     }
   }
   if (best != PL_NONE) PL_ATOM_MIN(&sh->best, best);
-  if (tid == 0) { sh->nq[(rd & 1u) ^ 1u] = 0; sh->nclaim[rd & 1u] = 0; }
+  if (tid == 0 && rep == 0) { sh->nq[(rd & 1u) ^ 1u] = 0; sh->nclaim[rd & 1u] = 0; }
 }
 /* inactivate all but one V column of that row (or every remaining V column if no row is left) */
-template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   const rq_params &p = c.p;
+  const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
   if (sh->best == PL_NONE) {
+    if (rep != 0) return; /* later rows of an event: nothing left to take, peeling resumes */
     for (uint32_t col = tid; col < p.W; col += nt) {
       if (c.colinfo[col] == 0u) {
         const uint32_t x = p.P + PL_ATOM_ADD(&sh->ninact, 1u);
@@ -551,16 +554,22 @@ template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rd, uint32_t t
   sh->nclaim[rd & 1u] = m; /* "columns to drop" */
   sh->nV -= m;
 }
-template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
+  const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
   const uint32_t pq = rd & 1u;
   if (sh->best == PL_NONE) {
-    if (tid == 0) sh->nV = 0;
+    if (tid == 0 && rep == 0) sh->nV = 0;
+    if (tid == 0) sh->tmp1 = 1u; /* event over */
     return;
   }
   const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
   for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column(c, sh->claim_c[i], 0u, pq ^ 1u, lane, 32u);
-  if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
+  if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; }
+}
+/* between two rows of one event: forget the previous choice */
+template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  if (tid == 0) { c.sh->best = PL_NONE; c.sh->nclaim[rdrep & 1u] = 0; }
 }
 
 /* =============================== phase 2: levels, W ========================================== */

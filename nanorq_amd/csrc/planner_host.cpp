@@ -275,31 +275,36 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
       frontier.swap(next);
       continue;
     }
-    /* no weight-1 row: take the sparsest unassigned row and inactivate all but one of its columns */
-    uint32_t best = M, bestc = 0xFFFFFFFFu;
-    for (uint32_t r = 0; r < M; r++)
-      if (!assigned[r] && cnt[r] >= 2 && cnt[r] < bestc) {
-        best = r; bestc = cnt[r];
-        if (bestc == 2) break;
-      }
+    /* no weight-1 row: take the sparsest open rows (up to NRQ_MULTI_INACT of them, one after the other) and
+     * inactivate all but one column of each */
     next.clear();
-    if (best == M) { /* nothing left that touches V: every remaining V column is inactivated */
+    bool none_left = false;
+    for (uint32_t rep = 0; rep < NRQ_MULTI_INACT; rep++) {
+      uint32_t best = M, bestc = 0xFFFFFFFFu;
+      for (uint32_t r = 0; r < M; r++)
+        if (!assigned[r] && cnt[r] >= 2 && cnt[r] < bestc) {
+          best = r; bestc = cnt[r];
+          if (bestc == 2) break;
+        }
+      if (best == M) { none_left = (rep == 0); break; }
+      uint32_t keep = 0xFFFFFFFFu, keepdeg = 0xFFFFFFFFu;
+      for (uint32_t e = rptr[best]; e < rptr[best + 1]; e++) {
+        uint32_t c = cidx[e];
+        if (cstate[c] != IN_V) continue;
+        uint32_t dg = cptr[c + 1] - cptr[c];
+        if (dg < keepdeg) { keepdeg = dg; keep = c; }
+      }
+      for (uint32_t e = rptr[best]; e < rptr[best + 1]; e++) {
+        uint32_t c = cidx[e];
+        if (cstate[c] != IN_V || c == keep) continue;
+        cstate[c] = INACTIVE; inact_order.push_back(c); nV--;
+        drop_column(c);
+      }
+    }
+    if (none_left) { /* nothing left that touches V: every remaining V column is inactivated */
       for (uint32_t c = 0; c < W; c++)
         if (cstate[c] == IN_V) { cstate[c] = INACTIVE; inact_order.push_back(c); nV--; }
       break;
-    }
-    uint32_t keep = 0xFFFFFFFFu, keepdeg = 0xFFFFFFFFu;
-    for (uint32_t e = rptr[best]; e < rptr[best + 1]; e++) {
-      uint32_t c = cidx[e];
-      if (cstate[c] != IN_V) continue;
-      uint32_t dg = cptr[c + 1] - cptr[c];
-      if (dg < keepdeg) { keepdeg = dg; keep = c; }
-    }
-    for (uint32_t e = rptr[best]; e < rptr[best + 1]; e++) {
-      uint32_t c = cidx[e];
-      if (cstate[c] != IN_V || c == keep) continue;
-      cstate[c] = INACTIVE; inact_order.push_back(c); nV--;
-      drop_column(c);
     }
     frontier.swap(next);
   }

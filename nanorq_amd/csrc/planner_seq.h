@@ -23,9 +23,15 @@
         PL_PHASE1(pl_round_claim, rd_);
         PL_PHASE1(pl_round_drop, rd_);
       } else {
-        PL_PHASE1(pl_inact_find, rd_);
-        PL_PHASE1(pl_inact_apply_a, rd_);
-        PL_PHASE1(pl_inact_apply_b, rd_);
+        /* one inactivation event: up to NRQ_MULTI_INACT open rows, sparsest first */
+        for (uint32_t rep_ = 0; rep_ < NRQ_MULTI_INACT; rep_++) {
+          const uint32_t a_ = rd_ | (rep_ << 24);
+          if (rep_) PL_PHASE1(pl_inact_next, a_);
+          PL_PHASE1(pl_inact_find, a_);
+          PL_PHASE1(pl_inact_apply_a, a_);
+          PL_PHASE1(pl_inact_apply_b, a_);
+          if (sh_->tmp1 || sh_->status != 0 || sh_->nV == 0) break;
+        }
       }
       rd_++;
     }
