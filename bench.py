@@ -52,6 +52,12 @@ def parse():
     ap.add_argument("--threads", type=int, default=0, help="host planner threads per rank (0 = cores / ranks)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="blocks timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-replan", action="store_true", help="keep the encode plan cached across steps")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams per GPU: the step's blocks are split into this many groups, each on its own stream, so "
+                         "that one group's (latency-bound, 1 workgroup/block) planner kernel runs beside another group's solve")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--force-device", type=int, default=-1,
+                    help="plumbing tests only: every rank uses this GPU (several ranks on one device; use with gloo)")
     return ap.parse_args()
 
 
@@ -135,13 +141,19 @@ def main():
     rank, world, local = shard.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.force_device >= 0:
+        local = args.force_device
     torch.cuda.set_device(local)
-    shard.init("nccl", device_id=torch.device("cuda", local))  # RCCL; only barrier + timing reduction use it
+    # RCCL; only the barrier and the timing reduction use it
+    shard.init(args.dist_backend, device_id=torch.device("cuda", local) if args.dist_backend == "nccl" else None)
     dev = torch.device("cuda", local)
-    stream = torch.cuda.current_stream(dev)
-    ctx = nanorq_amd.Context(local, stream.cuda_stream)
     threads = args.threads or max(1, (os.cpu_count() or 1) // max(1, world))
-    ctx.set_threads(threads)
+    nstreams = max(1, min(args.streams, args.blocks))
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
+    ctxs = [nanorq_amd.Context(local, st.cuda_stream) for st in streams]   # one context per stream, same GPU
+    for c_ in ctxs:
+        c_.set_threads(threads)
+    ctx = ctxs[0]
 
     K, T, NB = args.K, args.T, args.blocks
     prm = nanorq_amd.params(K)
@@ -171,24 +183,35 @@ def main():
     nr_first = (nlost + args.overhead).astype(np.uint32)
     nr_avail = (nlost + args.overhead + spare).astype(np.uint32)
 
+    # block ranges of the stream groups
+    bounds = [(NB * g_) // nstreams for g_ in range(nstreams + 1)]
+    groups = [(bounds[g_], bounds[g_ + 1]) for g_ in range(nstreams)]
+
     def step():
         nonlocal retries
-        ctx.encode_blocks(K, T, NB, src.data_ptr(), K * T, rep.data_ptr(), nrep * T, esis, inter.data_ptr(), L * T)
-        enc_stats = ctx.stats()
-        # decode from exactly (lost + overhead) repair symbols per block; a block whose system turns out rank deficient
-        # (about 1.5 % at overhead 0) takes one more symbol at a time inside the planner -- the receiver "got another
-        # packet" (nanorq_repair_block is retryable, lib/nanorq.c:620-623) without a second pass over the block
-        st, used = ctx.decode_blocks_lazy(K, T, NB, work.data_ptr(), K * T, lost_arr, nlost, resi, nr_first, nr_avail,
-                                          rep.data_ptr(), nrep * T)
-        dec_stats = ctx.stats()
-        if not st.all():
-            raise RuntimeError("decode failed for %d blocks" % int((st == 0).sum()))
-        retries += int((used - nr_first).sum())
+        enc_stats = dec_stats = None
+        for (lo, hi), c_ in zip(groups, ctxs):
+            n_ = hi - lo
+            c_.encode_blocks(K, T, n_, src[lo].data_ptr(), K * T, rep[lo].data_ptr(), nrep * T, esis, inter[lo].data_ptr(),
+                             L * T)
+            enc_stats = enc_stats or c_.stats()
+        for (lo, hi), c_ in zip(groups, ctxs):
+            n_ = hi - lo
+            # decode from exactly (lost + overhead) repair symbols per block; a block whose system turns out rank
+            # deficient (about 1.5 % at overhead 0) takes one more symbol at a time inside the planner -- the receiver
+            # "got another packet" (nanorq_repair_block is retryable, lib/nanorq.c:620-623) without a second pass
+            st, used = c_.decode_blocks_lazy(K, T, n_, work[lo].data_ptr(), K * T, lost_arr[lo:hi], nlost[lo:hi], resi[lo:hi],
+                                             nr_first[lo:hi], nr_avail[lo:hi], rep[lo].data_ptr(), nrep * T)
+            dec_stats = dec_stats or c_.stats()
+            if not st.all():
+                raise RuntimeError("decode failed for %d blocks" % int((st == 0).sum()))
+            retries += int((used - nr_first[lo:hi]).sum())
         if not args.no_replan:
             # one encode plan per step (= per 256-block object, like nanorq_precalculate): the plan for the NEXT step's
-            # encode is rebuilt on the host here, while the GPU runs this step's solve
-            ctx.clear_plan_cache()
-            ctx.precalculate(K)
+            # encode is rebuilt on the host here (once per context), while the GPU runs this step's solve
+            for c_ in ctxs:
+                c_.clear_plan_cache()
+                c_.precalculate(K)
         return enc_stats, dec_stats
 
     def barrier():
@@ -199,16 +222,22 @@ def main():
         step()
     barrier()
     retries = 0
-    ctx.ktime_enable(True)
+    for c_ in ctxs:
+        c_.ktime_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         enc_stats, dec_stats = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    ktimes = ctx.ktime_read()
-    ctx.ktime_enable(False)
-    elapsed = shard.reduce_max(elapsed, world, device=dev)   # the slowest rank defines the step time
-    retries_total = int(shard.reduce_sum(retries, world, device=dev))
+    # solve-kernel launches of all streams on one time axis (HIP events recorded around each launch)
+    intervals = []
+    for c_ in ctxs:
+        intervals += c_.ktime_read_intervals(ref=ctx)
+        c_.ktime_enable(False)
+    ktimes = [d for _, d in intervals]
+    rdev = dev if args.dist_backend == "nccl" else None
+    elapsed = shard.reduce_max(elapsed, world, device=rdev)   # the slowest rank defines the step time
+    retries_total = int(shard.reduce_sum(retries, world, device=rdev))
 
     # correctness of what was timed: every block decoded back to its source
     assert torch.equal(work, src), "decoded blocks differ from the source blocks"
@@ -223,18 +252,32 @@ def main():
         # solve-kernel launches in the timed region: [encode, decode(, retries...)] per step
         roof = None
         if balg_enc is not None and ktimes:
-            # two full-batch launches per step (encode, decode); retry launches are a few single blocks
-            full = sorted(ktimes, reverse=True)[:2 * args.steps]
-            avg_ms = sum(full) / len(full)
-            alg_per_launch = 0.5 * (balg_enc + balg_dec) * NB
-            achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
+            # every step launches the solve kernel 2*nstreams times (encode and decode of each stream group); launches of
+            # different streams overlap in time, so the kernel's rate is the algorithmic bytes of all launches divided by
+            # the time during which at least one of them was running (= the plain average duration when nstreams == 1)
+            avg_ms = sum(ktimes) / len(ktimes)
+            busy, cur_s, cur_e = 0.0, None, None
+            for s0, d0 in sorted(intervals):
+                if cur_e is None or s0 > cur_e:
+                    busy += 0.0 if cur_e is None else cur_e - cur_s
+                    cur_s, cur_e = s0, s0 + d0
+                else:
+                    cur_e = max(cur_e, s0 + d0)
+            busy += 0.0 if cur_e is None else cur_e - cur_s
+            blocks_per_launch = NB / float(nstreams)
+            alg_per_launch = 0.5 * (balg_enc + balg_dec) * blocks_per_launch
+            eff_ms = busy / len(ktimes)   # busy time attributable to one launch
+            achieved = alg_per_launch / (eff_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args), "kernel": "nrq_solve_kernel<%d>" %
-                    enc_stats["strip_bytes"], "avg_launch_ms": avg_ms, "launches_timed": len(ktimes),
+                    enc_stats["strip_bytes"], "avg_launch_ms": avg_ms, "busy_ms_per_launch": eff_ms,
+                    "launches_timed": len(ktimes), "blocks_per_launch": blocks_per_launch,
                     "algorithmic_bytes_per_launch": alg_per_launch,
                     "algorithmic_bytes_per_block": {"encode": balg_enc, "decode": balg_dec},
-                    "note": "algorithmic bytes = reference-equivalent row traffic (SURVEY 8d), not physical HBM "
-                            "bytes: the strip solver keeps rows in LDS"}
+                    "note": "algorithmic bytes = reference-equivalent row traffic (SURVEY 8d), not physical HBM bytes: the "
+                            "strip solver keeps rows in LDS. avg_launch_ms is the per-launch HIP-event duration (what rocprofv3 "
+                            "--kernel-trace reports); with %d streams launches overlap, so `achieved` divides by the union of "
+                            "the launches' busy time per launch" % nstreams}
         out = {
             "metric": "Gbit/s encode+decode, K=%d T=%d" % (K, T), "value": value, "unit": "Gbit/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,6 +287,7 @@ def main():
                                    "+decode" % (K, T, NB, args.loss * 100, args.overhead, nrep),
                        "K": K, "T": T, "blocks_per_gpu": NB, "loss": args.loss, "overhead": args.overhead,
                        "repair_per_block": nrep, "sharding": "blocks over GPUs, no collective",
+                       "streams_per_gpu": nstreams,
                        "encode_plan": "cached" if args.no_replan else "rebuilt every step",
                        "planner": ("device (nrq_plan_kernel, one workgroup per block)" if dec_stats["planner"] else
                                    "host, %d threads/rank" % threads),

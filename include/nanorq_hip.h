@@ -122,6 +122,9 @@ int nrq_dev_memset(nrq_ctx *ctx, void *d_dst, int value, size_t bytes);
  * synchronises, returns the durations of the launches since the last read/enable in launch order. */
 int nrq_ktime_enable(nrq_ctx *ctx, int on);
 int nrq_ktime_read(nrq_ctx *ctx, float *ms_out, uint32_t cap, uint32_t *count);
+/* same as intervals [start, start+dur) in ms after ref's nrq_ktime_enable(1); ref may be another context of the
+ * same GPU, so that launches of several streams can be put on one time axis */
+int nrq_ktime_read_intervals(nrq_ctx *ctx, nrq_ctx *ref, float *start_ms, float *dur_ms, uint32_t cap, uint32_t *count);
 
 /* Generic stream timer (HIP events on the context's stream). */
 int nrq_timer_start(nrq_ctx *ctx);

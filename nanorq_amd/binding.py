@@ -64,6 +64,7 @@ def lib():
     L.nrq_dev_memset.argtypes = [vp, vp, C.c_int, sz]
     L.nrq_ktime_enable.argtypes = [vp, C.c_int]
     L.nrq_ktime_read.argtypes = [vp, C.POINTER(C.c_float), C.c_uint32, u32p]
+    L.nrq_ktime_read_intervals.argtypes = [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, u32p]
     L.nrq_timer_start.argtypes = [vp]
     L.nrq_timer_stop_ms.argtypes = [vp, C.POINTER(C.c_float)]
     u8pp = C.POINTER(C.POINTER(C.c_uint8))
@@ -246,6 +247,14 @@ class Context:
         n = C.c_uint32()
         self._chk(self._L.nrq_ktime_read(self._h, buf, cap, C.byref(n)))
         return [float(buf[k]) for k in range(min(cap, n.value))]
+
+    def ktime_read_intervals(self, ref=None, cap=65536):
+        """[(start_ms, dur_ms)] of the solve-kernel launches since ktime_enable, on `ref`'s time axis."""
+        a = (C.c_float * cap)()
+        b = (C.c_float * cap)()
+        n = C.c_uint32()
+        self._chk(self._L.nrq_ktime_read_intervals(self._h, (ref or self)._h, a, b, cap, C.byref(n)))
+        return [(float(a[k]), float(b[k])) for k in range(min(cap, n.value))]
 
     def timer_start(self):
         self._chk(self._L.nrq_timer_start(self._h))

@@ -154,8 +154,6 @@ enum {
   pl_tag_pl_inact_next = 6,
   pl_tag_pl_lev_a = 7,
   pl_tag_pl_lev_b = 7,
-  pl_tag_pl_lev_c = 7,
-  pl_tag_pl_lev_d = 7,
   pl_tag_pl_w_init = 8,
   pl_tag_pl_w_group = 8,
   pl_tag_pl_w_stage = 8,
@@ -312,6 +310,7 @@ struct nrq_ctx {
   bool attr_set[4] = {false, false, false, false};
   /* optional per-launch timing of the solve kernel (HIP events on the launch stream) */
   bool ktime_on = false;
+  hipEvent_t ktime_base = nullptr; /* recorded by nrq_ktime_enable: origin of the launch intervals */
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ktime_pool;
   size_t ktime_used = 0;
   unsigned long long *prof = nullptr; /* NRQ_PROF=1 */
@@ -612,6 +611,7 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
     if (ctx->staged[i]) (void)hipEventDestroy(ctx->staged[i]);
   }
   for (auto &pr : ctx->ktime_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (ctx->ktime_base) (void)hipEventDestroy(ctx->ktime_base);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   delete ctx;
@@ -1108,6 +1108,25 @@ int nrq_ktime_enable(nrq_ctx *ctx, int on) {
   if (!ctx) return -1;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->ktime_on = on != 0;
+  ctx->ktime_used = 0;
+  if (on) {
+    if (!ctx->ktime_base) HIPCHK(ctx, hipEventCreate(&ctx->ktime_base));
+    HIPCHK(ctx, hipEventRecord(ctx->ktime_base, ctx->stream));
+  }
+  return 0;
+}
+/* launch intervals [start, start+dur) in ms relative to ref's nrq_ktime_enable (ref may be another context of
+ * the same device: kernels of several streams overlap and the caller wants the union of their busy time) */
+int nrq_ktime_read_intervals(nrq_ctx *ctx, nrq_ctx *ref, float *start_ms, float *dur_ms, uint32_t cap, uint32_t *count) {
+  if (!ctx || !ref || !count || !ref->ktime_base) return -1;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(ref->ktime_base));
+  uint32_t n = (uint32_t)ctx->ktime_used;
+  for (uint32_t k = 0; k < n && k < cap; k++) {
+    HIPCHK(ctx, hipEventElapsedTime(&start_ms[k], ref->ktime_base, ctx->ktime_pool[k].first));
+    HIPCHK(ctx, hipEventElapsedTime(&dur_ms[k], ctx->ktime_pool[k].first, ctx->ktime_pool[k].second));
+  }
+  *count = n;
   ctx->ktime_used = 0;
   return 0;
 }

@@ -122,7 +122,7 @@ typedef struct pl_shared {
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
   uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, ucol, wrows,
-      by_level, lev_cnt, lev_ops, lev_base, lev_fill, pivdeg, lowdeg, red_row, red_x, used, flag, total;
+      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, red_row, red_x, total;
 } pl_work_layout;
 
 SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uint32_t ucap) {
@@ -140,8 +140,6 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.pc_rows = o;    o = pl_r16(o + npcap * PL_PATCH_STRIDE * 2u);
   w.ucol = o;       o = pl_r16(o + ucap * 2u);
   w.wrows = o;      o = pl_r16(o + Mcap * wprcap * 4u); /* W rows by SLOT (pivot rows and leftover rows) */
-  w.by_level = o;   o = pl_r16(o + L * 4u);
-  w.lev_cnt = o;    o = pl_r16(o + (L + 2u) * 4u);
   w.lev_ops = o;    o = pl_r16(o + (L + 2u) * 4u);
   w.lev_base = o;   o = pl_r16(o + (L + 2u) * 4u);
   w.lev_fill = o;   o = pl_r16(o + (L + 2u) * 4u);
@@ -149,8 +147,6 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.lowdeg = o;     o = pl_r16(o + Mcap * 4u);
   w.red_row = o;    o = pl_r16(o + ucap * 4u);
   w.red_x = o;      o = pl_r16(o + ucap * 4u);
-  w.used = o;       o = pl_r16(o + Mcap);
-  w.flag = o;       o = pl_r16(o + Mcap);
   w.total = o;
   return w;
 }
@@ -189,8 +185,8 @@ struct PlanCtx {
   uint8_t *work;
   uint32_t *rowstate, *rowinfo, *colinfo;
   uint16_t *patch_of, *patch_cols, *pc_rows, *ucol;
-  uint8_t *patch_len, *used, *flag;
-  uint32_t *pc_ptr, *pc_fill, *wrows, *by_level, *lev_cnt, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *red_row,
+  uint8_t *patch_len;
+  uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *red_row,
       *red_x;
   /* arena views (fixed part laid out up front) */
   uint8_t *arena;
@@ -254,8 +250,6 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.pc_rows = reinterpret_cast<uint16_t *>(w + c.wl.pc_rows);
   c.ucol = reinterpret_cast<uint16_t *>(w + c.wl.ucol);
   c.wrows = reinterpret_cast<uint32_t *>(w + c.wl.wrows);
-  c.by_level = reinterpret_cast<uint32_t *>(w + c.wl.by_level);
-  c.lev_cnt = reinterpret_cast<uint32_t *>(w + c.wl.lev_cnt);
   c.lev_ops = reinterpret_cast<uint32_t *>(w + c.wl.lev_ops);
   c.lev_base = reinterpret_cast<uint32_t *>(w + c.wl.lev_base);
   c.lev_fill = reinterpret_cast<uint32_t *>(w + c.wl.lev_fill);
@@ -263,8 +257,6 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.lowdeg = reinterpret_cast<uint32_t *>(w + c.wl.lowdeg);
   c.red_row = reinterpret_cast<uint32_t *>(w + c.wl.red_row);
   c.red_x = reinterpret_cast<uint32_t *>(w + c.wl.red_x);
-  c.used = w + c.wl.used;
-  c.flag = w + c.wl.flag;
   /* arena: header, then the arrays whose size is bounded by (L, ucap) */
   c.arena = reinterpret_cast<uint8_t *>(job.arena);
   c.hdr = reinterpret_cast<nrq_plan_hdr *>(c.arena);
@@ -580,31 +572,15 @@ template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->wpr = u ? (u + 31u) / 32u : 1u;
     if (c.p.P + sh->ninact != u) sh->status = PL_FAIL_CAPACITY; /* cannot happen: every column is pivot or inactive */
   }
-  for (uint32_t l = tid; l < sh->nlev + 2u; l += nt) { c.lev_cnt[l] = 0; c.lev_ops[l] = 0; c.lev_fill[l] = 0; }
+  for (uint32_t l = tid; l < sh->nlev + 2u; l += nt) { c.lev_ops[l] = 0; c.lev_fill[l] = 0; }
 }
 template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  for (uint32_t k = tid; k < sh->npiv; k += nt) PL_ATOM_ADD(&c.lev_cnt[(c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK) + 1u], 1u);
   /* W rows are accumulated with XORs: start from zero */
   for (uint32_t e = tid; e < sh->M * sh->wpr; e += nt) c.wrows[e] = 0;
   for (uint32_t k = tid; k < sh->npiv; k += nt) c.pivdeg[k] = 0;
   for (uint32_t k = tid; k < sh->M; k += nt) c.lowdeg[k] = 0;
 }
-template <int Z> SB_HD void pl_lev_c(PlanCtx &c, uint32_t tid, uint32_t nt) { /* serial prefix over levels */
-  pl_shared *sh = c.sh;
-  if (tid != 0) return;
-  uint32_t run = 0;
-  for (uint32_t l = 0; l <= sh->nlev; l++) { run += c.lev_cnt[l]; c.lev_cnt[l] = run; }
-}
-template <int Z> SB_HD void pl_lev_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
-  for (uint32_t k = tid; k < sh->npiv; k += nt) {
-    uint32_t l = c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK;
-    uint32_t pos = PL_ATOM_ADD(&c.lev_fill[l], 1u);
-    c.by_level[c.lev_cnt[l] + pos] = k;
-  }
-}
-
 /* Own part of the bit row of constraint row r over the inactive columns (the entries of the row that sit in
  * inactive columns) plus the number of its pivot-column entries other than `own` = XOR ops the row needs.
  * 8 lanes cooperate, lane w8 owns words w8, w8+8, ...; `sub`/`stride` select a slice of the entries. */

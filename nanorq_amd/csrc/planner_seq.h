@@ -39,8 +39,6 @@
   PL_PHASE(pl_lev_a);
   if (sh_->status == 0 && sh_->nV == 0) {
     PL_PHASE(pl_lev_b);
-    PL_PHASE(pl_lev_c);
-    PL_PHASE(pl_lev_d);
     PL_PHASE(pl_low_a);
     PL_PHASE(pl_low_b);
   }
