@@ -94,3 +94,19 @@ def test_decode_retry_after_more_symbols():
     assert np.array_equal(out, data)
     L.nanorq_free(rq)
     io.contents.destroy(io)
+
+
+def test_reference_benchmark_harness_on_the_hip_path():
+    """oracle/_ref/benchmark_hip = the reference's benchmark.c compiled (in the build container, sources read in
+    place) against this library: encode / precalc-encode / decode / decode-with-overhead runs, 6 % loss, ending in
+    the harness's own assert(in[i] == out[i]) (reference benchmark.c:233-235)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "benchmark_hip")
+    if not os.path.isfile(exe):
+        pytest.skip("oracle/_ref/benchmark_hip not built (needs the reference tree at build time)")
+    for argv in (["1024", "100", "0"], ["1280", "1000", "5.0"]):
+        r = subprocess.run([exe] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, (argv, r.stderr.decode()[-500:])
+        cols = r.stdout.decode().split()
+        assert len(cols) == 5 and int(cols[0]) == int(argv[1]) and all(float(x) > 0 for x in cols[1:])
