@@ -32,7 +32,7 @@ def lib():
     if _LIB is not None:
         return _LIB
     from . import build
-    path = build.build_lib()
+    path = os.environ.get("NANORQ_HIP_LIB") or build.build_lib()  # the override loads a tuning variant of the same library
     L = C.CDLL(path)
     vp, u32p, ip = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)
     sz = C.c_size_t
@@ -77,7 +77,7 @@ def lib():
 
 
 PARAM_NAMES = ("Kp", "J", "S", "H", "W", "L", "P", "P1", "U", "B")
-PLAN_FIELDS = ("magic status K Kp J S H W L P P1 B M npiv u nlow r2 nfree nlev nchunk1 nchunk2 wpr lpr "
+PLAN_FIELDS = ("magic status K Kp J S H W L P P1 B M npiv u nlow r2 nfree nlev nrows pipe wpr lpr "
                "npiv_pad n_xor_ops off_ops off_pivslot off_pivcol off_wt off_lowslot off_g2 off_pivx off_fbits "
                "off_mh off_freex off_hinv off_colslot off_pivof off_uslot off_sync total_bytes").split()
 

@@ -45,14 +45,17 @@ def _deps():
     return out
 
 
-def build_lib(force=False, verbose=False):
-    if not force and not _newer(LIB, _deps()):
+def build_lib(force=False, verbose=False, out=None, extra=()):
+    """Build libnanorq_hip.so.  `out`/`extra` build a tuning variant (other file, extra compiler flags) that
+    NANORQ_HIP_LIB=<path> makes the binding load instead -- for A/B runs on the GPU box."""
+    if out is None and not force and not _newer(LIB, _deps()):
         return LIB
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if out is None else "build_" + os.path.basename(out))
     os.makedirs(objdir, exist_ok=True)
     objs = []
     common = ["-O3", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    common += list(extra)
     for s in HIP_SOURCES:
         o = os.path.join(objdir, s + ".o")
         subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", *common, "-c", os.path.join(CSRC, s), "-o", o],
@@ -69,10 +72,11 @@ def build_lib(force=False, verbose=False):
         o = os.path.join(objdir, s + ".o")
         subprocess.run(["gcc", "-std=gnu11", "-Wall", "-D_FILE_OFFSET_BITS=64", *common, "-c", src, "-o", o], check=True)
         objs.append(o)
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-lpthread"], check=True)
+    target = out or LIB
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target, *objs, "-lpthread"], check=True)
     if verbose:
-        print("built", LIB)
-    return LIB
+        print("built", target)
+    return target
 
 
 def build_emu(force=False):

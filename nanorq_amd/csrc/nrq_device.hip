@@ -30,7 +30,10 @@
 #include "planner_body.h"
 
 #define NRQ_LDS_MAX 163840u /* 160 KiB per workgroup on gfx950 */
-#define NRQ_WG 256
+#ifndef NRQ_WG
+#define NRQ_WG 512 /* threads of the solve workgroup: 2 waves per SIMD (the parallel phases are issue-bound with 1) */
+#endif
+#define NRQ_GEN_WG 256
 
 /* ============================================================================================
  * Kernels
@@ -38,13 +41,22 @@
 
 /* Workgroup -> (block, strip).  Workgroup n is dispatched to XCD n%8 (observed; speed only).  The
  * strips that share one 128-byte line of every symbol row are given consecutive slots on ONE XCD so
- * that the line is fetched into (and write-combined in) a single L2. */
-__device__ __forceinline__ bool nrq_map_strip(uint32_t wb, uint32_t nblk, uint32_t nstrips, uint32_t *blk,
+ * that the line is fetched into (and write-combined in) a single L2.  With many blocks in the launch
+ * (by_block) all strips of a block stay on one XCD, so that its plan -- every strip walks the whole op
+ * stream -- is served by that XCD's L2 instead of being pulled into all eight. */
+static inline bool nrq_map_by_block(uint32_t nblk) { return nblk >= 64u || (nblk >= 8u && (nblk & 7u) == 0u); }
+__device__ __forceinline__ bool nrq_map_strip(uint32_t wb, uint32_t nblk, uint32_t nstrips, bool by_block, uint32_t *blk,
                                               uint32_t *strip) {
   const uint32_t n = blockIdx.x, xcd = n & 7u, m = n >> 3;
   const uint32_t spl = 128u / wb;                       /* strips per 128-byte line */
   const uint32_t gpb = (nstrips + spl - 1u) / spl;      /* line groups per block */
-  const uint32_t q = (m / spl) * 8u + xcd, sidx = m % spl;
+  const uint32_t g = m / spl, sidx = m % spl;           /* g-th line group handled by this XCD */
+  if (by_block) {
+    *blk = (g / gpb) * 8u + xcd;
+    *strip = (g % gpb) * spl + sidx;
+    return *blk < nblk && *strip < nstrips;
+  }
+  const uint32_t q = g * 8u + xcd;
   if (q >= nblk * gpb) return false;
   *blk = q / gpb;
   *strip = (q % gpb) * spl + sidx;
@@ -53,7 +65,7 @@ __device__ __forceinline__ bool nrq_map_strip(uint32_t wb, uint32_t nblk, uint32
 
 template <int WB>
 __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
-                                                           uint32_t T, uint32_t nstrips,
+                                                           uint32_t T, uint32_t nstrips, uint32_t by_block,
                                                            const uint8_t *__restrict__ kc,
                                                            unsigned long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
 #define NRQ_STAMP(i) do { if (stamp) stamp[i] = (unsigned long long)clock64(); } while (0)
   NRQ_STAMP(0);
   uint32_t blk, strip;
-  if (!nrq_map_strip(WB, nblk, nstrips, &blk, &strip)) return;
+  if (!nrq_map_strip(WB, nblk, nstrips, by_block != 0u, &blk, &strip)) return;
   StripCtx<WB> c;
   c.job = jobs[blk];
   c.plan = reinterpret_cast<const uint8_t *>(c.job.plan);
@@ -82,40 +94,36 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
   __syncthreads();
   NRQ_STAMP(1);
 
-  /* forward passes: chunks of 256 independent-up-to-accumulation XOR ops.  Op words are fetched
-   * four chunks ahead into four fixed registers (no hand-over between them, so the loads stay
-   * outstanding across the LDS work and the barriers); the barrier schedule is one bit per chunk. */
-  {
-    const NRQ_GAS uint32_t *ops = c.template arr<uint32_t>(c.h->off_ops);
-    const NRQ_GAS uint32_t *sy = c.template arr<uint32_t>(c.h->off_sync);
-    const uint32_t nch = c.h->nchunk1 + c.h->nchunk2;
-    /* the plan pads the stream with 8 all-NOP chunks and the sync words with 2 words, so every
-     * read-ahead below is in bounds and needs no branch */
-    uint32_t q0 = ops[tid], q1 = ops[NRQ_WG + tid], q2 = ops[2 * NRQ_WG + tid], q3 = ops[3 * NRQ_WG + tid];
-    uint32_t swv = sy[0];
-    const NRQ_GAS uint32_t *nxt = ops + 4 * NRQ_WG + tid;
-    for (uint32_t base = 0; base < nch; base += 4, nxt += 4 * NRQ_WG) {
-      uint32_t sw = __builtin_amdgcn_readfirstlane(swv) >> (base & 31u);
-      if ((base & 31u) == 28u) swv = sy[(base >> 5) + 1];
-      uint32_t cur;
-      cur = q0; q0 = nxt[0];
-      ph_op<WB>(c, cur);
-      if (sw & 1u) __syncthreads();
-      cur = q1; q1 = nxt[NRQ_WG];
-      ph_op<WB>(c, cur);
-      if (sw & 2u) __syncthreads();
-      cur = q2; q2 = nxt[2 * NRQ_WG];
-      ph_op<WB>(c, cur);
-      if (sw & 4u) __syncthreads();
-      cur = q3; q3 = nxt[3 * NRQ_WG];
-      ph_op<WB>(c, cur);
-      if (sw & 8u) __syncthreads();
+  /* forward passes (plan.h): wave 0 walks the op stream alone, the other waves wait at the barrier below.  Step
+   * q applies row q-NRQ_PIPE and then reads the sources of row q; op words live in a ring of NRQ_RING fixed
+   * registers, each reloaded (NRQ_RING rows ahead) right after its row has been applied -- no hand-over
+   * between registers, so the loads stay outstanding across the LDS work.  The ring starts as the NRQ_RING
+   * all-NOP rows the stream begins with; the plan pads the stream so that every fetch is in bounds. */
+  if (tid < NRQ_ROW) {
+    constexpr uint32_t P = NRQ_PIPE, NS = NRQ_PIPE + 1u, U = NRQ_RING;
+    static_assert(U % NS == 0, "ring must be a multiple of the value sets");
+    const NRQ_GAS uint32_t *nxt = c.template arr<uint32_t>(c.h->off_ops) + tid;
+    const uint32_t nrows = c.h->nrows;
+    uint32_t o[U];
+    typename RowVal<WB>::type v[NS];
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) o[k] = NRQ_NOP_AT(tid);
+#pragma unroll
+    for (uint32_t k = 0; k < NS; k++) v[k] = row_zero<WB>();
+    for (uint32_t base = 0; base < nrows + P; base += U, nxt += U * NRQ_ROW) {
+#pragma unroll
+      for (uint32_t k = 0; k < U; k++) {
+        const uint32_t j = (k + U - P) % U; /* ring slot of row q - P */
+        ph_row_apply<WB>(c, o[j], v[(k + NS - P) % NS]);
+        o[j] = nxt[(k + U - P) * NRQ_ROW];
+        v[k % NS] = ph_row_read<WB>(c, o[k]);
+      }
     }
   }
   __syncthreads();
   NRQ_STAMP(2);
 
-  ph_hdpc<WB>(c, tid, NRQ_WG);
+  if (tid < 256u) ph_hdpc<WB>(c, tid, 256u); /* column chunks: more, shorter ones cost more in the closing folds than they gain */
   __syncthreads();
   NRQ_STAMP(3);
   NRQ_STAMP(4);
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(PL_NT) void nrq_plan_kernel(rq_params p, const uint
 
 /* One workgroup per (symbol, block): out = XOR of the LT neighbours of `isi` among the L
  * intermediate symbols in HBM (coalesced 16-byte lanes along the symbol). */
-__global__ __launch_bounds__(NRQ_WG) void nrq_gen_kernel(rq_params p, uint32_t T, const uint8_t *__restrict__ inter,
+__global__ __launch_bounds__(NRQ_GEN_WG) void nrq_gen_kernel(rq_params p, uint32_t T, const uint8_t *__restrict__ inter,
                                                          size_t inter_stride, const uint32_t *__restrict__ isis,
                                                          uint8_t *__restrict__ out, size_t out_stride) {
   __shared__ uint32_t cols[RQ_MAX_LT_COLS];
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_gen_kernel(rq_params p, uint32_t T
   const bool vec = ((T & 15u) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0) &&
                    ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
   if (vec) {
-    for (uint32_t off = threadIdx.x * 16u; off < T; off += NRQ_WG * 16u) {
+    for (uint32_t off = threadIdx.x * 16u; off < T; off += NRQ_GEN_WG * 16u) {
       uint4 acc = make_uint4(0, 0, 0, 0);
       for (uint32_t k = 0; k < n; k++) {
         uint4 v = *reinterpret_cast<const uint4 *>(C + (size_t)cols[k] * T + off);
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_gen_kernel(rq_params p, uint32_t T
       *reinterpret_cast<uint4 *>(dst + off) = acc;
     }
   } else {
-    for (uint32_t off = threadIdx.x; off < T; off += NRQ_WG) {
+    for (uint32_t off = threadIdx.x; off < T; off += NRQ_GEN_WG) {
       uint8_t acc = 0;
       for (uint32_t k = 0; k < n; k++) acc ^= C[(size_t)cols[k] * T + off];
       dst[off] = acc;
@@ -459,7 +467,8 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
                                 const uint8_t *d_kc, uint32_t lds_bytes) {
   const uint32_t nstrips = (T + WB - 1) / WB, spl = 128u / WB;
   const uint32_t gpb = (nstrips + spl - 1) / spl;
-  const uint64_t groups = (uint64_t)nblk * gpb;
+  const bool by_block = nrq_map_by_block(nblk) && !getenv("NRQ_MAP_SPREAD");
+  const uint64_t groups = by_block ? (uint64_t)((nblk + 7u) / 8u) * 8u * gpb : (uint64_t)nblk * gpb;
   const uint64_t grid = ((groups + 7) / 8) * 8 * spl;
   if (grid > 0x7FFFFFFFull) return fail(ctx, -4, "grid too large");
   if (!ctx->attr_set[slot]) {
@@ -487,7 +496,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     HIPCHK(ctx, hipMemsetAsync(ctx->prof, 0, (size_t)nprof * 16 * 8, ctx->stream));
   }
   hipLaunchKernelGGL(nrq_solve_kernel<WB>, dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T,
-                     nstrips, d_kc, ctx->prof);
+                     nstrips, by_block ? 1u : 0u, d_kc, ctx->prof);
   HIPCHK(ctx, hipGetLastError());
   if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
   if (ctx->prof) {
@@ -521,7 +530,9 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
 int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs, const nrq_job *d_jobs, uint32_t nblk,
                     uint32_t T, const uint8_t *d_kc) {
   static const uint32_t widths[4] = {16, 8, 4, 2};
+  const char *maxw = getenv("NRQ_MAX_WB"); /* tuning: widest strip to consider */
   for (int s = 0; s < 4; s++) {
+    if (maxw && widths[s] > (uint32_t)atoi(maxw)) continue;
     uint32_t need = 0;
     for (const nrq_plan_hdr *h : hdrs) {
       if (h->status) continue;
@@ -1068,7 +1079,7 @@ int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t 
   memcpy(ctx->staging[f].p, h_isi, (size_t)n * 4);
   HIPCHK(ctx, hipMemcpyAsync(ctx->scratch[f].p, ctx->staging[f].p, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->staged[f], ctx->stream));
-  hipLaunchKernelGGL(nrq_gen_kernel, dim3(n, nblk), dim3(NRQ_WG), 0, ctx->stream, p, T, (const uint8_t *)d_inter,
+  hipLaunchKernelGGL(nrq_gen_kernel, dim3(n, nblk), dim3(NRQ_GEN_WG), 0, ctx->stream, p, T, (const uint8_t *)d_inter,
                      inter_stride, (const uint32_t *)ctx->scratch[f].p, (uint8_t *)d_out, out_stride);
   HIPCHK(ctx, hipGetLastError());
   return 0;

@@ -5,8 +5,13 @@
  * marks) but is shaped for the LDS-resident column-strip solver, not
  * for a serial replay:
  *   - the forward substitution through the triangular block X is a list of XOR ops
- *     (dst ^= src on symbol rows) grouped by dependency level and padded to NRQ_CHUNK-op
- *     chunks; ops inside a chunk are independent of each other up to XOR-accumulation;
+ *     (dst ^= src on symbol rows) grouped by dependency level; ops of one level are independent
+ *     of each other up to XOR-accumulation.  The stream is cut into rows of NRQ_ROW ops that ONE
+ *     wave of the solve workgroup executes as a fixed software pipeline: the sources of row
+ *     k+NRQ_PIPE are read before row k is applied (the LDS pipeline keeps one wave's accesses in
+ *     order, so nothing but program order is needed -- no barriers).  Hence a row may only read
+ *     slots last written NRQ_PIPE or more rows earlier: every level group is followed by
+ *     NRQ_PIPE-1 all-NOP rows;
  *   - the fill-in block of the reference's U_upper is kept as a bit matrix W (i x u) and
  *     applied after the dense stage instead of re-running the sparse passes;
  *   - the dense stage is pre-inverted: a GF(2) combination matrix for the binary rows, GF(256)
@@ -22,8 +27,22 @@
 #include <stdint.h>
 
 #define NRQ_PLAN_MAGIC 0x4e525131u /* "NRQ1" */
-#define NRQ_CHUNK 256u             /* ops per chunk == threads of the solve workgroup */
-#define NRQ_NOP 0xFFFFFFFFu        /* padding op */
+#define NRQ_ROW 64u                /* ops per row == lanes of a wave */
+#ifndef NRQ_PIPE
+#define NRQ_PIPE 2u                /* rows between the read of a row's sources and its application (measured on
+                                    * MI355X: 2 beats 3 and 4 -- a row costs ~63 clocks of issue either way, spacer rows included) */
+#endif
+#define NRQ_RING (12u * (NRQ_PIPE + 1u)) /* rows whose op words the kernel holds in registers (fetched that far ahead);
+                                    * the stream starts with NRQ_RING all-NOP rows (the ring's initial content) */
+#define NRQ_PAD_ROWS (2u * NRQ_RING + NRQ_PIPE) /* all-NOP rows after the stream: op words are fetched ahead unconditionally */
+/* Op word: dst | src << 16, both as slot + NRQ_SCRATCH.  The first NRQ_SCRATCH slots of the LDS image are
+ * per-lane scratch: the padding op of lane l reads and writes scratch slot l, so padding needs no branch. */
+#define NRQ_SCRATCH 64u
+#define NRQ_OP(dst, src) (((uint32_t)(dst) + NRQ_SCRATCH) | (((uint32_t)(src) + NRQ_SCRATCH) << 16))
+#define NRQ_NOP_AT(pos) (((uint32_t)(pos) & (NRQ_ROW - 1u)) * 0x10001u) /* padding op at stream position pos */
+#define NRQ_OP_IS_NOP(op) (((op) & 0xFFFFu) < NRQ_SCRATCH)
+#define NRQ_OP_DST(op) (((op) & 0xFFFFu) - NRQ_SCRATCH)
+#define NRQ_OP_SRC(op) (((op) >> 16) - NRQ_SCRATCH)
 #define NRQ_NOSLOT 0xFFFFu
 #define NRQ_MAX_FREE 32u
 /* When a peeling round has no row of weight 1, this many open rows (sparsest first) are resolved by
@@ -42,16 +61,15 @@ typedef struct nrq_plan_hdr {
   uint32_t r2;      /* GF(2) rank reached on the u inactive columns with those rows */
   uint32_t nfree;   /* u - r2: columns that need the HDPC rows */
   uint32_t nlev;    /* dependency depth of the peeled block */
-  uint32_t nchunk1; /* chunks of the pivot forward pass */
-  uint32_t nchunk2; /* chunks of the low-row pass and of the GF(2) combination pass (E rows) */
+  uint32_t nrows;   /* rows of the op stream (pivot levels, leftover rows, GF(2) combinations) */
+  uint32_t pipe;    /* NRQ_PIPE the stream was laid out for */
   uint32_t wpr;     /* 32-bit words per W row: ceil(u/32) */
   uint32_t lpr;     /* reserved (was: words per G2 row) */
   uint32_t npiv_pad;/* stride (in pivots) of the transposed W image, multiple of 64 */
   uint32_t n_xor_ops; /* real (non-padding) ops in both passes, for statistics */
 
-  uint32_t off_ops;     /* u32[(nchunk1+nchunk2)*NRQ_CHUNK]: dst | src<<16, NRQ_NOP = padding
-                         * (8 more all-NOP chunks follow the last one: prefetch slack).  Slots >= M are the
-                         * r2 scratch rows E_p (slot M+p) of the dense stage: E_p = XOR of leftover rows */
+  uint32_t off_ops;     /* u32[(nrows+NRQ_PAD_ROWS)*NRQ_ROW]: op words (above), padding = NRQ_NOP_AT.  Slots >= M are
+                         * the r2 scratch rows E_p (slot M+p) of the dense stage: E_p = XOR of leftover rows */
   uint32_t off_pivslot; /* u16[npiv]: slot of pivot k */
   uint32_t off_pivcol;  /* u16[npiv]: column of pivot k */
   uint32_t off_wt;      /* u32[wpr*npiv_pad]: word w of W row k at [w*npiv_pad + k] */
@@ -65,7 +83,7 @@ typedef struct nrq_plan_hdr {
   uint32_t off_colslot; /* u16[L]: slot that finally holds intermediate symbol C[c] */
   uint32_t off_pivof;   /* u16[Kp+S]: slot of the pivot row of column c, NRQ_NOSLOT if inactive */
   uint32_t off_uslot;   /* u16[u]: slot that receives inactive column x */
-  uint32_t off_sync;    /* u32[ceil(nchunk/32)+2]: bit c set -> workgroup barrier after chunk c */
+  uint32_t off_sync;    /* reserved (was: barrier schedule of the op stream) */
   uint32_t total_bytes;
   uint32_t reserved[2];
 } nrq_plan_hdr;

@@ -44,7 +44,7 @@
 #define PL_PATCH_STRIDE RQ_MAX_LT_COLS
 #define PL_MH_TILE 256u
 #define PL_EXTRA_ROWS 8u   /* repair symbols a block may take beyond nrep when rank deficient */
-#define PL_SPARE_CHUNKS 2u /* op chunks reserved for the rows added that way */
+#define PL_SPARE_ROWS 8u /* op rows reserved for the rows added that way */
 #define PL_LOWCAP 1344u /* leftover rows the dense stage can take (>= inactive-column cap 1280 + 32) */
 #define PL_DENSE_RESERVE (36u * 1024u) /* LDS kept for the dense stage when the peeling state is in LDS too */
 
@@ -101,7 +101,7 @@ typedef struct pl_shared {
   uint32_t nq[2], nclaim[2]; /* frontier / claim counts, indexed by round parity */
   uint32_t best;
   uint32_t nlow, r2, nfree, cand[2];
-  uint32_t arena_top, nchunk1, nchunk2, nops_real, opbase;
+  uint32_t arena_top, nrows, nops_real, opbase;
   uint32_t uslot_fill, tmp0, tmp1;
   uint32_t off_ops, off_sync, nsyncw;
   uint32_t lv_in_lds, opq_group[2];
@@ -154,9 +154,11 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
 /* upper bound of a plan arena (header + arrays + rowsrc + output lists) for a block of this size */
 SB_HD uint32_t pl_arena_bound(uint32_t L, uint32_t Mcap, uint32_t ucap, uint32_t nnz, uint32_t nlost_cap) {
   const uint32_t wprcap = (ucap + 31u) / 32u, npad = (L + 63u) & ~63u;
-  uint32_t ops = (2u * nnz + 2u * ucap * 64u) + NRQ_CHUNK * (L / 4u + 64u);
+  /* op stream: the ops themselves, one partly filled row plus NRQ_PIPE-1 spacer rows per level, the spare and
+   * the lead/padding rows */
+  uint32_t ops = (2u * nnz + 2u * ucap * 64u) + NRQ_ROW * (NRQ_PIPE * (L / 2u + 8u) + PL_SPARE_ROWS + NRQ_RING + NRQ_PAD_ROWS);
   uint32_t b = 256u + L * 2u * 3u + (L + 16u) * 2u + ucap * 2u * 4u + ucap * 4u * 2u + PL_MAXH * ucap +
-               NRQ_MAX_FREE * PL_MAXH + wprcap * npad * 4u + ops * 4u + (ops / NRQ_CHUNK / 32u + 4u) * 4u +
+               NRQ_MAX_FREE * PL_MAXH + wprcap * npad * 4u + ops * 4u +
                Mcap * 4u + (nlost_cap + 1u) * 8u + nlost_cap * PL_PATCH_STRIDE * 2u + 1024u;
   return pl_r16(b);
 }
@@ -323,7 +325,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->nV = p.W; sh->npiv = 0; sh->ninact = 0; sh->nlev = 0;
     sh->nq[0] = sh->nq[1] = 0; sh->nclaim[0] = sh->nclaim[1] = 0; sh->best = PL_NONE;
     sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = PL_NONE;
-    sh->nchunk1 = sh->nchunk2 = 0; sh->nops_real = 0; sh->uslot_fill = 0;
+    sh->nrows = 0; sh->nops_real = 0; sh->uslot_fill = 0;
     sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE;
   }
   /* GF(256) tables into LDS (RFC 6330 section 5.7): generated by one thread, 255 steps */
@@ -656,6 +658,9 @@ SB_HD uint32_t *pl_aux_lvops(const PlanCtx &c) { return reinterpret_cast<uint32_
 SB_HD uint32_t *pl_aux_opq(const PlanCtx &c, uint32_t which) {
   return reinterpret_cast<uint32_t *>(c.aux_lds + pl_r16((c.sh->nlev + 2u) * 8u)) + which * PL_OPQ_WORDS;
 }
+/* rows a level group of n ops occupies in the stream (plan.h); lev_base[] counts rows */
+SB_HD uint32_t pl_group_rows(uint32_t n) { return (n + NRQ_ROW - 1u) / NRQ_ROW; }
+
 /* stage the per-level op counts / chunk bases in LDS so that a level of the W pass starts without a trip
  * to HBM; prefetch the first group's ops */
 template <int Z> SB_HD void pl_w_stage(PlanCtx &c, uint32_t tid, uint32_t nt) {
@@ -679,19 +684,19 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
   const bool lds = sh->lv_in_lds != 0u;
   const uint32_t n_real = lds ? pl_aux_lvops(c)[group] : c.lev_ops[group];
   const uint32_t base = lds ? pl_aux_lvbase(c)[group] : c.lev_base[group];
-  const uint32_t nops = ((n_real + NRQ_CHUNK - 1u) / NRQ_CHUNK) * NRQ_CHUNK;
+  const uint32_t nops = pl_group_rows(n_real) * NRQ_ROW;
   const uint32_t *gops = reinterpret_cast<const uint32_t *>(c.arena + sh->off_ops);
   const bool staged = lds && sh->opq_group[group & 1u] == group;
-  const uint32_t *ops = staged ? pl_aux_opq(c, group & 1u) : gops + (size_t)base * NRQ_CHUNK;
+  const uint32_t *ops = staged ? pl_aux_opq(c, group & 1u) : gops + (size_t)base * NRQ_ROW;
   /* issue the prefetch of the next group first: its loads overlap with this group's work */
   uint32_t pf[PL_OPQ_WORDS / PL_NT], pf_n = 0;
   if (lds && group + 1u <= sh->nlev) {
-    const uint32_t n2 = ((pl_aux_lvops(c)[group + 1u] + NRQ_CHUNK - 1u) / NRQ_CHUNK) * NRQ_CHUNK;
+    const uint32_t n2 = pl_group_rows(pl_aux_lvops(c)[group + 1u]) * NRQ_ROW;
     if (n2 <= PL_OPQ_WORDS) {
       pf_n = n2;
-      const uint32_t *src = gops + (size_t)pl_aux_lvbase(c)[group + 1u] * NRQ_CHUNK;
+      const uint32_t *src = gops + (size_t)pl_aux_lvbase(c)[group + 1u] * NRQ_ROW;
 #pragma unroll
-      for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT; q++) pf[q] = (tid + q * nt) < n2 ? src[tid + q * nt] : NRQ_NOP;
+      for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT; q++) pf[q] = (tid + q * nt) < n2 ? src[tid + q * nt] : 0u /* a padding op */;
     }
   }
   if (wpr <= 8u) {
@@ -702,23 +707,23 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
 #pragma unroll
       for (uint32_t q = 0; q < 8; q++) {
         const uint32_t e = e0 + q * ngrp;
-        op[q] = e < nops ? ops[e] : NRQ_NOP;
+        op[q] = e < nops ? ops[e] : 0u;
       }
 #pragma unroll
       for (uint32_t q = 0; q < 8; q++) {
-        const uint32_t srow = op[q] == NRQ_NOP ? 0u : (op[q] >> 16);
+        const uint32_t srow = NRQ_OP_IS_NOP(op[q]) ? 0u : NRQ_OP_SRC(op[q]);
         v[q] = c.wrows[(size_t)srow * wpr + wsel];
       }
 #pragma unroll
       for (uint32_t q = 0; q < 8; q++)
-        if (op[q] != NRQ_NOP && w8 < wpr && v[q]) PL_ATOM_XOR(&c.wrows[(size_t)(op[q] & 0xFFFFu) * wpr + w8], v[q]);
+        if (!NRQ_OP_IS_NOP(op[q]) && w8 < wpr && v[q]) PL_ATOM_XOR(&c.wrows[(size_t)NRQ_OP_DST(op[q]) * wpr + w8], v[q]);
     }
   } else {
     for (uint32_t e = grp; e < nops; e += ngrp) {
       const uint32_t op = ops[e];
-      if (op == NRQ_NOP) continue;
-      const uint32_t *src = c.wrows + (size_t)(op >> 16) * wpr;
-      uint32_t *dst = c.wrows + (size_t)(op & 0xFFFFu) * wpr;
+      if (NRQ_OP_IS_NOP(op)) continue;
+      const uint32_t *src = c.wrows + (size_t)NRQ_OP_SRC(op) * wpr;
+      uint32_t *dst = c.wrows + (size_t)NRQ_OP_DST(op) * wpr;
       for (uint32_t wd = w8; wd < wpr; wd += 8u) {
         const uint32_t v = src[wd];
         if (v) PL_ATOM_XOR(&dst[wd], v);
@@ -779,39 +784,33 @@ template <int Z> SB_HD void pl_low_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (tid != 0) return;
-  /* chunk base of every level group (levels 1..nlev-1 are pivot groups, index nlev = leftover rows) */
-  uint32_t chunks = 0;
+  /* row base of every level group (levels 1..nlev-1 are pivot groups, index nlev = leftover rows); the stream
+   * starts with the NRQ_RING lead rows and every non-empty group is followed by NRQ_PIPE-1 spacer rows */
+  uint32_t rows = NRQ_RING;
   for (uint32_t l = 0; l <= sh->nlev; l++) {
-    c.lev_base[l] = chunks;
-    chunks += (c.lev_ops[l] + NRQ_CHUNK - 1u) / NRQ_CHUNK;
-    if (l + 1 == sh->nlev) sh->nchunk1 = chunks;
+    const uint32_t n = c.lev_ops[l];
+    c.lev_base[l] = rows;
+    if (n) rows += pl_group_rows(n) + (NRQ_PIPE - 1u);
     c.lev_fill[l] = 0;
   }
-  if (sh->nlev == 0) sh->nchunk1 = 0;
-  sh->spare_base = chunks; /* chunks reserved for rows added later; their barrier bit is set below */
-  chunks += PL_SPARE_CHUNKS;
-  sh->tmp0 = chunks; /* chunks so far; the GF(2) combination group follows after the elimination */
+  sh->spare_base = rows; /* rows reserved for constraint rows added later */
+  rows += PL_SPARE_ROWS + (NRQ_PIPE - 1u);
+  sh->tmp0 = rows; /* rows so far; the GF(2) combination group follows after the elimination */
   /* ops region: generous bound for the combination group (nlow ones per reduced row at most) */
-  uint32_t bin_bound = ((sh->nlow + PL_EXTRA_ROWS) * (sh->nlow + PL_EXTRA_ROWS) + NRQ_CHUNK - 1u) / NRQ_CHUNK + 1u;
-  uint32_t total_chunks = chunks + bin_bound + 8u;
+  uint32_t bin_bound = ((sh->nlow + PL_EXTRA_ROWS) * (sh->nlow + PL_EXTRA_ROWS) + NRQ_ROW - 1u) / NRQ_ROW + 1u;
+  uint32_t total_rows = rows + bin_bound + NRQ_PAD_ROWS;
   sh->off_ops = pl_r16(c.fixed_end);
-  sh->nsyncw = (total_chunks + 31u) / 32u + 2u;
-  sh->off_sync = pl_r16(sh->off_ops + total_chunks * NRQ_CHUNK * 4u);
-  sh->arena_top = pl_r16(sh->off_sync + sh->nsyncw * 4u);
-  sh->opbase = total_chunks;
+  sh->off_sync = 0;
+  sh->arena_top = pl_r16(sh->off_ops + total_rows * NRQ_ROW * 4u);
+  sh->opbase = total_rows;
   if (sh->arena_top > c.job.arena_cap) sh->status = PL_FAIL_CAPACITY;
 }
 template <int Z> SB_HD void pl_ops_clear(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
   uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
-  const uint32_t nw = sh->opbase * NRQ_CHUNK;
-  for (uint32_t k = tid; k < nw; k += nt) ops[k] = NRQ_NOP;
-  uint32_t *sy = reinterpret_cast<uint32_t *>(c.arena + sh->off_sync);
-  for (uint32_t k = tid; k < sh->nsyncw; k += nt) {
-    const uint32_t last = sh->spare_base + PL_SPARE_CHUNKS - 1u; /* barrier after the spare chunks */
-    sy[k] = (k == (last >> 5)) ? (1u << (last & 31u)) : 0u;
-  }
+  const uint32_t nw = sh->opbase * NRQ_ROW;
+  for (uint32_t k = tid; k < nw; k += nt) ops[k] = NRQ_NOP_AT(k);
 }
 /* position of the i-th op of a run starting at `pos` inside a group of n ops: a multiplicative shuffle
  * keeps the ops of one row apart so that the lanes of a wave rarely hit the same target slot */
@@ -825,7 +824,7 @@ SB_HD uint32_t pl_spread(uint32_t pos, uint32_t n) {
   return (uint32_t)(((uint64_t)pos * m) % n);
 }
 SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t group, uint32_t start, uint32_t dst) {
-  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + c.sh->off_ops) + (size_t)c.lev_base[group] * NRQ_CHUNK;
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + c.sh->off_ops) + (size_t)c.lev_base[group] * NRQ_ROW;
   const uint32_t n = c.lev_ops[group];
   const uint16_t *cols;
   const uint32_t m = pl_row(c, r, &cols);
@@ -833,7 +832,7 @@ SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t group, uin
   for (uint32_t k = 0; k < m; k++) {
     const uint32_t col = cols[k], info = c.colinfo[col];
     if ((info >> 30) != PL_ST_PIVOT || col == own) continue;
-    ops[pl_spread(i, n)] = dst | ((uint32_t)c.pivslot[info & 0x3FFFFFFFu] << 16);
+    ops[pl_spread(i, n)] = NRQ_OP(dst, c.pivslot[info & 0x3FFFFFFFu]);
     i++;
   }
 }
@@ -852,14 +851,6 @@ template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
     if (!deg) continue;
     const uint32_t start = PL_ATOM_ADD(&c.lev_fill[sh->nlev], deg);
     pl_emit_row(c, c.lowslot[j], PL_NONE, sh->nlev, start, c.lowslot[j]);
-  }
-  /* barrier bits: after the last chunk of every non-empty group */
-  uint32_t *sy = reinterpret_cast<uint32_t *>(c.arena + sh->off_sync);
-  for (uint32_t l = tid; l <= sh->nlev; l += nt) {
-    const uint32_t nc = (c.lev_ops[l] + NRQ_CHUNK - 1u) / NRQ_CHUNK;
-    if (!nc) continue;
-    const uint32_t last = c.lev_base[l] + nc - 1u;
-    PL_ATOM_OR(&sy[last >> 5], 1u << (last & 31u));
   }
 }
 
@@ -978,20 +969,15 @@ template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t g = sh->nlev + 1u;
   c.lev_ops[g] = run;
   c.lev_base[g] = sh->tmp0;
-  const uint32_t nc = (run + NRQ_CHUNK - 1u) / NRQ_CHUNK;
-  sh->nchunk2 = sh->tmp0 + nc - sh->nchunk1;
-  if (sh->tmp0 + nc + 8u > sh->opbase && sh->status == 0) sh->status = PL_FAIL_CAPACITY;
-  if (nc) {
-    uint32_t *sy = reinterpret_cast<uint32_t *>(c.arena + sh->off_sync);
-    const uint32_t last = sh->tmp0 + nc - 1u;
-    sy[last >> 5] |= 1u << (last & 31u);
-  }
+  sh->nrows = sh->tmp0 + pl_group_rows(run);
+  if ((sh->nrows + NRQ_PAD_ROWS > sh->opbase || sh->M + sh->r2 + NRQ_SCRATCH > 65535u) && sh->status == 0)
+    sh->status = PL_FAIL_CAPACITY; /* op fields are 16 bits */
 }
 template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
   const uint32_t g = sh->nlev + 1u, n = c.lev_ops[g];
-  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops) + (size_t)c.lev_base[g] * NRQ_CHUNK;
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops) + (size_t)c.lev_base[g] * NRQ_ROW;
   const uint32_t *Mb = pl_mb(c);
   for (uint32_t q = tid; q < sh->r2; q += nt) {
     const uint32_t *aug = Mb + (size_t)c.red_row[q] * sh->rowlen + sh->wpr;
@@ -1001,7 +987,7 @@ template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
       while (bits) {
         const uint32_t j = w * 32u + (uint32_t)__builtin_ctz(bits);
         bits &= bits - 1u;
-        ops[pl_spread(i, n)] = (sh->M + q) | ((uint32_t)c.lowslot[j] << 16);
+        ops[pl_spread(i, n)] = NRQ_OP(sh->M + q, c.lowslot[j]);
         i++;
       }
     }
@@ -1112,13 +1098,13 @@ template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   uint32_t cols[RQ_MAX_LT_COLS];
   const uint32_t n = rq_lt_columns(&p, esi + (p.Kp - p.K), cols);
   uint16_t *dst = c.patch_cols + (size_t)i * PL_PATCH_STRIDE;
-  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops) + (size_t)sh->spare_base * NRQ_CHUNK;
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops) + (size_t)sh->spare_base * NRQ_ROW;
   for (uint32_t k = 0; k < n; k++) {
     dst[k] = (uint16_t)cols[k];
     const uint32_t info = c.colinfo[cols[k]];
     if ((info >> 30) == PL_ST_PIVOT) {
-      if (sh->spare_fill >= PL_SPARE_CHUNKS * NRQ_CHUNK) { sh->status = PL_FAIL_CAPACITY; return; }
-      ops[sh->spare_fill++] = row | ((uint32_t)c.pivslot[info & 0x3FFFFFFFu] << 16);
+      if (sh->spare_fill >= PL_SPARE_ROWS * NRQ_ROW) { sh->status = PL_FAIL_CAPACITY; return; }
+      ops[sh->spare_fill++] = NRQ_OP(row, c.pivslot[info & 0x3FFFFFFFu]);
     }
   }
   c.patch_len[i] = (uint8_t)n;
@@ -1266,7 +1252,7 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   h.reserved[1] = sh->nextra; /* repair symbols taken beyond job.nrep */
   h.K = p.Kp; h.Kp = p.Kp; h.S = p.S; h.H = p.H; h.W = p.W; h.L = p.L; h.P = p.P; h.B = p.B;
   h.M = sh->M; h.npiv = sh->npiv; h.u = p.L - sh->npiv; h.nlow = sh->nlow; h.r2 = sh->r2; h.nfree = sh->nfree;
-  h.nlev = sh->nlev; h.nchunk1 = sh->nchunk1; h.nchunk2 = sh->nchunk2; h.wpr = sh->wpr; h.lpr = sh->lpr;
+  h.nlev = sh->nlev; h.nrows = sh->nrows; h.pipe = NRQ_PIPE; h.wpr = sh->wpr; h.lpr = sh->lpr;
   h.npiv_pad = sh->tmp0;
   h.off_ops = sh->off_ops; h.off_pivslot = c.off_pivslot; h.off_pivcol = c.off_pivcol; h.off_wt = sh->partial[0];
   h.off_lowslot = c.off_lowslot; h.off_g2 = 0; h.off_pivx = c.off_pivx; h.off_fbits = c.off_fbits; h.off_mh = c.off_mh;

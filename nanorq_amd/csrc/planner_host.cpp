@@ -358,8 +358,18 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   }
 
   /* ---- XOR op stream: pivot pass by level, then the low-row pass ---- */
-  std::vector<uint32_t> ops, sync_bits;
-  uint32_t n_real_ops = 0, nchunk1 = 0, nchunk2 = 0;
+  std::vector<uint32_t> ops;
+  uint32_t n_real_ops = 0;
+  auto pad_rows = [&](uint32_t nrows_) { for (uint32_t k = 0; k < nrows_ * NRQ_ROW; k++) ops.push_back(NRQ_NOP_AT(ops.size())); };
+  pad_rows(NRQ_RING); /* lead rows: the initial content of the kernel's op-word ring */
+  /* place one level group (plan.h): whole rows, then the NRQ_PIPE-1 rows nothing may depend on yet */
+  auto place_group = [&](const std::vector<uint32_t> &g) {
+    if (g.empty()) return;
+    n_real_ops += (uint32_t)g.size();
+    ops.insert(ops.end(), g.begin(), g.end());
+    while (ops.size() % NRQ_ROW) ops.push_back(NRQ_NOP_AT(ops.size()));
+    pad_rows(NRQ_PIPE - 1u);
+  };
   {
     std::vector<uint32_t> lev_cnt(nlev + 1, 0);
     for (uint32_t k = 0; k < npiv; k++) lev_cnt[level[pivslot[k]] + 1]++;
@@ -368,8 +378,7 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
     for (uint32_t k = 0; k < npiv; k++) by_level[fill[level[pivslot[k]]]++] = k;
     auto emit_group = [&](const uint32_t *rows, uint32_t nr, bool pivots) {
       /* round-robin over the rows of the group so that neighbouring ops rarely share a target */
-      size_t start = ops.size();
-      std::vector<uint32_t> cur(nr);
+      std::vector<uint32_t> g, cur(nr);
       for (uint32_t q = 0; q < nr; q++) cur[q] = rptr[pivots ? pivslot[rows[q]] : lowslot[rows[q]]];
       bool any = true;
       while (any) {
@@ -380,26 +389,18 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
           uint32_t &e = cur[q];
           while (e < rptr[r + 1] && (cstate[cidx[e]] != PIVOT || cidx[e] == own)) e++;
           if (e < rptr[r + 1]) {
-            ops.push_back((uint32_t)r | ((uint32_t)owner[cidx[e]] << 16));
+            g.push_back(NRQ_OP(r, owner[cidx[e]]));
             e++; any = true;
           }
         }
       }
-      n_real_ops += (uint32_t)(ops.size() - start);
-      while ((ops.size() - start) % NRQ_CHUNK) ops.push_back(NRQ_NOP);
-      if (ops.size() > start) { /* ops of one group only accumulate: one barrier after its last chunk */
-        uint32_t last = (uint32_t)(ops.size() / NRQ_CHUNK) - 1;
-        if (sync_bits.size() <= last / 32) sync_bits.resize(last / 32 + 1, 0);
-        sync_bits[last / 32] |= 1u << (last % 32);
-      }
+      place_group(g);
     };
     for (uint32_t l = 1; l < nlev; l++) /* level 0 rows have nothing to gather */
       emit_group(&by_level[lev_cnt[l]], lev_cnt[l + 1] - lev_cnt[l], true);
-    nchunk1 = (uint32_t)(ops.size() / NRQ_CHUNK);
     std::vector<uint32_t> all_low(nlow);
     for (uint32_t j = 0; j < nlow; j++) all_low[j] = j;
     emit_group(all_low.data(), nlow, false);
-    nchunk2 = (uint32_t)(ops.size() / NRQ_CHUNK) - nchunk1;
   }
 
   /* ---- HDPC rows over the inactive columns: Mh = G_U ^ G_left * W ---- */
@@ -445,10 +446,9 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   /* GF(2) combinations E_p (slot M+p) = XOR of the leftover rows named by the augmented part of
    * reduced row p: appended to the op stream as one more accumulate-only group */
   {
-    size_t start = ops.size();
-    if (M + r2 > 65535u) return -3;
+    if (M + r2 + NRQ_SCRATCH > 65535u) return -3;
     /* round-robin over p so that neighbouring ops hit different targets */
-    std::vector<uint32_t> curj(r2, 0);
+    std::vector<uint32_t> g, curj(r2, 0);
     bool any = r2 > 0;
     while (any) {
       any = false;
@@ -457,20 +457,15 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
         uint32_t &j = curj[q];
         while (j < nlow && !bit(aug, j)) j++;
         if (j < nlow) {
-          ops.push_back((uint32_t)(M + q) | ((uint32_t)lowslot[j] << 16));
+          g.push_back(NRQ_OP(M + q, lowslot[j]));
           j++; any = true;
         }
       }
     }
-    n_real_ops += (uint32_t)(ops.size() - start);
-    while ((ops.size() - start) % NRQ_CHUNK) ops.push_back(NRQ_NOP);
-    if (ops.size() > start) {
-      uint32_t last = (uint32_t)(ops.size() / NRQ_CHUNK) - 1;
-      if (sync_bits.size() <= last / 32) sync_bits.resize(last / 32 + 1, 0);
-      sync_bits[last / 32] |= 1u << (last % 32);
-    }
-    nchunk2 = (uint32_t)(ops.size() / NRQ_CHUNK) - nchunk1;
+    place_group(g);
   }
+  const uint32_t op_rows = (uint32_t)(ops.size() / NRQ_ROW);
+  pad_rows(NRQ_PAD_ROWS);
   uint32_t status = 0;
   if (nfree > H || nfree > NRQ_MAX_FREE) status = 1;
 
@@ -541,14 +536,11 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   hd.magic = NRQ_PLAN_MAGIC; hd.status = status;
   hd.K = K; hd.Kp = p.Kp; hd.J = p.J; hd.S = S; hd.H = H; hd.W = W; hd.L = L; hd.P = p.P; hd.P1 = p.P1; hd.B = p.B;
   hd.M = M; hd.npiv = npiv; hd.u = u; hd.nlow = nlow; hd.r2 = r2; hd.nfree = nfree; hd.nlev = nlev;
-  hd.nchunk1 = nchunk1; hd.nchunk2 = nchunk2; hd.wpr = wpr; hd.lpr = lpr;
+  hd.nrows = op_rows; hd.pipe = NRQ_PIPE; hd.wpr = wpr; hd.lpr = lpr;
   hd.npiv_pad = (npiv + 63u) & ~63u;
   hd.n_xor_ops = n_real_ops;
-  /* 8 chunks of padding: the kernel walks the stream 4 chunks at a time and prefetches op words 4 chunks
-   * ahead without bounds checks, so it can touch up to chunk nchunk+6 */
-  hd.off_ops = A.reserve((uint32_t)((ops.size() + 8 * NRQ_CHUNK) * 4));
-  memset(A.at<uint8_t>(hd.off_ops), 0xFF, (ops.size() + 8 * NRQ_CHUNK) * 4);
-  if (!ops.empty()) memcpy(A.at<uint8_t>(hd.off_ops), ops.data(), ops.size() * 4);
+  hd.off_ops = A.reserve((uint32_t)(ops.size() * 4));
+  memcpy(A.at<uint8_t>(hd.off_ops), ops.data(), ops.size() * 4);
   hd.off_pivslot = A.reserve(npiv * 2);
   memcpy(A.at<uint8_t>(hd.off_pivslot), pivslot.data(), (size_t)npiv * 2);
   hd.off_pivcol = A.reserve(npiv * 2);
@@ -578,12 +570,7 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   memcpy(A.at<uint8_t>(hd.off_pivof), pivof.data(), (size_t)n_hd * 2);
   hd.off_uslot = A.reserve(std::max(1u, u) * 2);
   if (u) memcpy(A.at<uint8_t>(hd.off_uslot), uslot.data(), (size_t)u * 2);
-  {
-    uint32_t nw = (nchunk1 + nchunk2 + 31u) / 32u + 2u; /* +2: read-ahead padding */
-    sync_bits.resize(nw, 0);
-    hd.off_sync = A.reserve(nw * 4);
-    memcpy(A.at<uint8_t>(hd.off_sync), sync_bits.data(), (size_t)nw * 4);
-  }
+  hd.off_sync = 0;
   hd.total_bytes = align16((uint32_t)A.buf.size());
   A.buf.resize(hd.total_bytes, 0);
   memcpy(A.buf.data(), &hd, sizeof(hd));

@@ -143,7 +143,7 @@ template <int WB> SB_HD void lds_put(uint8_t *lds, uint32_t idx, const SV<WB> &v
 }
 /* slot ^= v, safe against other threads of the workgroup doing the same to the same slot */
 template <int WB> SB_HD void lds_xor(uint8_t *lds, uint32_t idx, const SV<WB> &v) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NRQ_EXP_NOATOMIC)
   if constexpr (WB == 16) {
     unsigned long long *p = reinterpret_cast<unsigned long long *>(lds) + 2 * (size_t)idx;
     atomicXor(p, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32));
@@ -211,6 +211,7 @@ SB_HD uint32_t nrq_r16(uint32_t x) { return (x + 15u) & ~15u; }
 SB_HD nrq_lds_layout nrq_lds_plan(const nrq_plan_hdr *h, uint32_t WB) {
   nrq_lds_layout l;
   uint32_t o = 0;
+  o = NRQ_SCRATCH * WB;                                  /* per-lane scratch slots of the padding ops */
   l.off_slots = o; o = nrq_r16(o + (h->M + h->r2) * WB); /* M slots, then the r2 scratch rows E_p */
   l.off_cu = o;    o = nrq_r16(o + (h->u ? h->u : 1u) * WB);
   /* region X: the free-column accumulators Cf during the dense stage, then the 4-bit XOR tables */
@@ -273,13 +274,60 @@ template <int WB> SB_HD void ph_load(const StripCtx<WB> &c, uint32_t tid, uint32
   for (uint32_t f = tid; f < NRQ_MAX_FREE; f += nt) lds_put<WB>(c.cf(), f, sv_zero<WB>());
 }
 
-/* phases 1+2: one XOR op of the forward passes (X^-1 on the peeled rows, the leftover rows, the
- * GF(2) combinations of the dense stage) */
-template <int WB> SB_HD void ph_op(const StripCtx<WB> &c, uint32_t op) {
-  if (op == NRQ_NOP) return;
-  SV<WB> v = lds_get<WB>(c.slots(), op >> 16);
-  lds_xor<WB>(c.slots(), op & 0xFFFFu, v);
+/* phases 1+2: the forward passes (X^-1 on the peeled rows, the leftover rows, the GF(2) combinations of the
+ * dense stage) are rows of 64 XOR ops that one wave runs as a software pipeline (plan.h): ph_row_read fetches
+ * the source strips of a row, ph_row_apply XORs them into the targets NRQ_PIPE rows later.  Op fields are
+ * slot + NRQ_SCRATCH, i.e. indices from the start of the LDS image; padding ops touch the lane's scratch slot.
+ * On the GPU the strip travels as one native vector register group and the LDS byte address is formed by a
+ * single sub-dword shift per field; the LDS image starts at LDS address 0 (the kernel has no static LDS). */
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int WB> struct RowVal;
+template <> struct RowVal<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <> struct RowVal<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct RowVal<4> { typedef uint32_t type; };
+template <> struct RowVal<2> { typedef uint32_t type; };
+#define NRQ_LDSP(T, addr) (reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(addr)))
+template <int WB> __device__ __forceinline__ uint32_t row_addr_hi(uint32_t op) { /* (op >> 16) * WB */
+  constexpr uint32_t sh = WB == 16 ? 4 : WB == 8 ? 3 : WB == 4 ? 2 : 1;
+  uint32_t r, s = sh;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(op));
+  return r;
 }
+template <int WB> __device__ __forceinline__ uint32_t row_addr_lo(uint32_t op) { /* (op & 0xFFFF) * WB */
+  constexpr uint32_t sh = WB == 16 ? 4 : WB == 8 ? 3 : WB == 4 ? 2 : 1;
+  uint32_t r, s = sh;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(op));
+  return r;
+}
+template <int WB> __device__ __forceinline__ typename RowVal<WB>::type ph_row_read(const StripCtx<WB> &, uint32_t op) {
+  const uint32_t a = row_addr_hi<WB>(op);
+  if constexpr (WB == 2) return *NRQ_LDSP(uint16_t, a);
+  else return *NRQ_LDSP(typename RowVal<WB>::type, a);
+}
+template <int WB> __device__ __forceinline__ void ph_row_apply(const StripCtx<WB> &, uint32_t op, typename RowVal<WB>::type v) {
+  const uint32_t a = row_addr_lo<WB>(op);
+  if constexpr (WB == 16) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const u2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a + 8u), __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else if constexpr (WB == 8) {
+    __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else if constexpr (WB == 4) {
+    __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a & ~3u), v << ((a & 2u) * 8u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+template <int WB> __device__ __forceinline__ typename RowVal<WB>::type row_zero() { typename RowVal<WB>::type z = {}; return z; }
+#else
+template <int WB> struct RowVal { typedef SV<WB> type; };
+template <int WB> SB_HD SV<WB> ph_row_read(const StripCtx<WB> &c, uint32_t op) { return lds_get<WB>(c.lds, op >> 16); }
+template <int WB> SB_HD void ph_row_apply(const StripCtx<WB> &c, uint32_t op, const SV<WB> &v) {
+  lds_xor<WB>(c.lds, op & 0xFFFFu, v);
+}
+template <int WB> SB_HD SV<WB> row_zero() { return sv_zero<WB>(); }
+#endif
 
 /* phase 3: HDPC right-hand sides R_h = SUM_c HDPC[h][c] * Y(c) over the peeled columns, through
  * HDPC = MT*GAMMA (RFC 6330 section 5.3.3.3): thread t owns columns [a,b); g follows the GAMMA

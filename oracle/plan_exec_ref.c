@@ -49,10 +49,10 @@ int orc_plan_exec(const uint8_t *plan, uint8_t *Din, uint32_t T, uint8_t *C) {
   const uint32_t H = h->H, n_hd = h->Kp + h->S;
 #define ROW(r) (D + (size_t)(r) * T)
   /* 1+2: forward substitution through X, then the leftover rows */
-  size_t nops = (size_t)(h->nchunk1 + h->nchunk2) * NRQ_CHUNK;
+  size_t nops = (size_t)h->nrows * NRQ_ROW;
   for (size_t e = 0; e < nops; e++) {
-    if (ops[e] == NRQ_NOP) continue;
-    xor_row(ROW(ops[e] & 0xFFFFu), ROW(ops[e] >> 16), T);
+    if (NRQ_OP_IS_NOP(ops[e])) continue;
+    xor_row(ROW(NRQ_OP_DST(ops[e])), ROW(NRQ_OP_SRC(ops[e])), T);
   }
   /* 3: HDPC right-hand sides */
   uint8_t *G = (uint8_t *)malloc((size_t)H * n_hd);

@@ -15,8 +15,31 @@
 
 #include "../../nanorq_amd/csrc/solve_body.h"
 
+/* The forward passes in the order the kernel's wave 0 issues them (plan.h): step q applies row q-NRQ_PIPE,
+ * then reads the sources of row q -- so a plan that puts dependent rows closer than NRQ_PIPE rows apart
+ * produces wrong symbols here, exactly as it would on the GPU. */
+template <int WB> static bool emu_forward(const StripCtx<WB> &c) {
+  const uint32_t *ops = c.template arr<uint32_t>(c.h->off_ops);
+  const uint32_t nrows = c.h->nrows, P = NRQ_PIPE;
+  if (c.h->pipe != NRQ_PIPE) return false;
+  std::vector<SV<WB>> v((size_t)(P + 1) * NRQ_ROW);
+  for (uint32_t q = 0; q < nrows + P; q++) {
+    if (q >= P) {
+      const uint32_t *row = ops + (size_t)(q - P) * NRQ_ROW;
+      const SV<WB> *vr = &v[(size_t)((q - P) % (P + 1)) * NRQ_ROW];
+      for (uint32_t l = 0; l < NRQ_ROW; l++) ph_row_apply<WB>(c, row[l], vr[l]);
+    }
+    if (q < nrows) {
+      const uint32_t *row = ops + (size_t)q * NRQ_ROW;
+      SV<WB> *vr = &v[(size_t)(q % (P + 1)) * NRQ_ROW];
+      for (uint32_t l = 0; l < NRQ_ROW; l++) vr[l] = ph_row_read<WB>(c, row[l]);
+    }
+  }
+  return true;
+}
+
 template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t strip, const uint8_t *kc) {
-  const uint32_t NT = NRQ_CHUNK;
+  const uint32_t NT = 256;
   StripCtx<WB> c;
   c.job = job;
   c.plan = reinterpret_cast<const uint8_t *>(job.plan);
@@ -32,10 +55,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
   c.valid = rem < (uint32_t)WB ? rem : (uint32_t)WB;
 #define PHASE(fn) for (uint32_t t = 0; t < NT; t++) fn<WB>(c, t, NT)
   PHASE(ph_load);
-  const uint32_t *ops = c.template arr<uint32_t>(c.h->off_ops);
-  const uint32_t nch = c.h->nchunk1 + c.h->nchunk2;
-  for (uint32_t ch = 0; ch < nch; ch++)
-    for (uint32_t t = 0; t < NT; t++) ph_op<WB>(c, ops[(size_t)ch * NT + t]);
+  if (!emu_forward<WB>(c)) return -7;
   PHASE(ph_hdpc);
   PHASE(ph_dense_fold);
   PHASE(ph_dense_free);

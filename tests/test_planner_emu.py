@@ -88,6 +88,35 @@ def test_failure_parity_small_blocks(orc):
     assert nfail > 0  # the sweep really contains singular systems
 
 
+def test_emulated_forward_pass_is_sensitive_to_row_spacing(orc):
+    """The emulator issues the op stream in the kernel's pipelined order (row q is read before rows q-1 and q-2
+    are applied), so a plan that puts dependent levels too close must NOT come out right -- otherwise the CPU
+    tier could not see a scheduling bug of either planner.  Here: the spacer rows are squeezed out."""
+    K, T = 1500, 32
+    p = orc.params(K)
+    src = payload(K * T, seed=3).reshape(K, T)
+    kc = nanorq_amd.host_kconst(K)
+    plan = bytearray(nanorq_amd.host_plan(K, np.arange(p["Kp"], dtype=np.uint32), kc))
+    h = nanorq_amd.plan_header(bytes(plan))
+    assert h["pipe"] >= 2
+    ops = np.frombuffer(plan, dtype=np.uint32, offset=h["off_ops"], count=h["nrows"] * 64).reshape(-1, 64)
+    real = ops[((ops & 0xFFFF) >= 64).any(axis=1)]          # rows with at least one real op, in order
+    assert len(real) < h["nrows"] - 32                      # there were spacer rows
+    squeezed = ops.copy()
+    lane_nop = (np.arange(64, dtype=np.uint32) * 0x10001).astype(np.uint32)
+    squeezed[:] = lane_nop
+    squeezed[32:32 + len(real)] = real
+    ops[:] = squeezed
+    rowsrc = np.full(p["L"], ROW_ZERO, np.uint32)
+    rowsrc[p["S"] + p["H"]: p["S"] + p["H"] + K] = np.arange(K, dtype=np.uint32)
+    esis = np.arange(K, K + 3, dtype=np.uint32)
+    out = np.zeros((3, T), np.uint8)
+    r, inter = emu_solve(bytes(plan), kc, rowsrc, src, None, T, p["L"], lt_lists(orc, K, esis + (p["Kp"] - K), bytes(plan)),
+                         np.arange(3), out, 16)
+    ref_rep, ref_inter, _ = orc.encode_block(src, K, T, esis, want_inter=True)
+    assert r != 1 or not np.array_equal(inter, ref_inter)
+
+
 def test_lds_budget_of_headline_config(orc):
     """K=8192: the 16-byte strip image must fit the 160 KiB LDS of one gfx950 workgroup."""
     K = 8192
