@@ -31,7 +31,9 @@
 
 #define NRQ_LDS_MAX 163840u /* 160 KiB per workgroup on gfx950 */
 #ifndef NRQ_WG
-#define NRQ_WG 512 /* threads of the solve workgroup: 2 waves per SIMD (the parallel phases are issue-bound with 1) */
+#define NRQ_WG 768 /* threads of the solve workgroup: 3 waves per SIMD.  One workgroup owns the CU (LDS), and its phases are
+                    * bound by instruction issue and LDS latency: measured 256 -> 512 -> 768 -> 1024 threads = 673 / 796 / 835 /
+                    * 807 Gbit/s on the headline workload */
 #endif
 #define NRQ_GEN_WG 256
 
@@ -82,6 +84,8 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
   c.h = reinterpret_cast<const nrq_plan_hdr *>(c.plan);
   if (c.h->status) return; /* rank deficient: nothing is written for this block */
   c.kc = kc;
+  c.dbg = (prof && (blockIdx.x & 1023u) == 0) ? prof + (size_t)(blockIdx.x >> 10) * 16 + 9 : nullptr;
+  c.dbg_t0 = threadIdx.x == 0;
   c.lds = smem;
   c.lay = nrq_lds_plan(c.h, WB);
   c.T = T;
@@ -123,7 +127,9 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
   __syncthreads();
   NRQ_STAMP(2);
 
-  if (tid < 256u) ph_hdpc<WB>(c, tid, 256u); /* column chunks: more, shorter ones cost more in the closing folds than they gain */
+  ph_hdpc<WB>(c, tid, NRQ_WG);
+  __syncthreads();
+  ph_hdpc_reduce<WB>(c, tid, NRQ_WG);
   __syncthreads();
   NRQ_STAMP(3);
   NRQ_STAMP(4);
@@ -516,6 +522,15 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     fprintf(stderr, "[NRQ_PROF] WB=%d grid=%llu sampled=%u total=%.0f clk:", WB, (unsigned long long)grid, cnt,
             cnt ? tot / cnt : 0.0);
     for (int k = 0; k < 8; k++) fprintf(stderr, " %s=%.0f", names[k], cnt ? sum[k] / cnt : 0.0);
+    /* slots 9..15: free-form marks a phase may leave through StripCtx::dbg (differences to the phase start) */
+    double ext[7] = {0};
+    for (uint32_t w = 0; w < nprof; w++) {
+      const unsigned long long *q = &hp[(size_t)w * 16];
+      if (!q[8]) continue;
+      for (int k = 0; k < 7; k++) if (q[9 + k]) ext[k] += (double)(q[9 + k] - q[getenv("NRQ_PROF_BASE") ? atoi(getenv("NRQ_PROF_BASE")) : 2]);
+    }
+    fprintf(stderr, " | marks since fwd end:");
+    for (int k = 0; k < 7; k++) fprintf(stderr, " %.0f", cnt ? ext[k] / cnt : 0.0);
     fprintf(stderr, "\n");
     (void)hipFree(ctx->prof);
     ctx->prof = nullptr;

@@ -64,6 +64,13 @@ typedef struct nrq_job {
   uint32_t pad;
 } nrq_job;
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NRQ_MARK(c, i) do { if ((c).dbg && (c).dbg_t0) (c).dbg[i] = (unsigned long long)clock64(); } while (0)
+#define NRQ_MARK_MAX(c, i) do { if ((c).dbg) atomicMax(&(c).dbg[i], (unsigned long long)clock64()); } while (0)
+#else
+#define NRQ_MARK(c, i) do { } while (0)
+#define NRQ_MARK_MAX(c, i) do { } while (0)
+#endif
 #define NRQ_ROW_ZERO 0xFFFFFFFFu
 #define NRQ_ROW_REP 0x80000000u
 
@@ -89,8 +96,10 @@ template <int WB> SB_HD void sv_xor_masked(SV<WB> &a, const SV<WB> &b, uint32_t 
 }
 /* multiply every byte by alpha (= 2) */
 SB_HD uint32_t xtime32(uint32_t x) {
-  uint32_t hi = (x >> 7) & 0x01010101u;
-  return ((x & 0x7f7f7f7fu) << 1) ^ (hi * 0x1du);
+  /* bytes with the top bit set get the reduction 0x1d: (0x80 - 0x01) & 0x1d per such byte -- shifts, a subtract and
+   * masks only (a 32-bit multiply by 0x1d is a quarter-rate instruction on CDNA) */
+  const uint32_t hi = x & 0x80808080u;
+  return ((x ^ hi) << 1) ^ ((hi - (hi >> 7)) & 0x1d1d1d1du);
 }
 template <int WB> SB_HD SV<WB> sv_xtime(const SV<WB> &a) {
   SV<WB> r;
@@ -143,7 +152,7 @@ template <int WB> SB_HD void lds_put(uint8_t *lds, uint32_t idx, const SV<WB> &v
 }
 /* slot ^= v, safe against other threads of the workgroup doing the same to the same slot */
 template <int WB> SB_HD void lds_xor(uint8_t *lds, uint32_t idx, const SV<WB> &v) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(NRQ_EXP_NOATOMIC)
+#if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (WB == 16) {
     unsigned long long *p = reinterpret_cast<unsigned long long *>(lds) + 2 * (size_t)idx;
     atomicXor(p, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32));
@@ -232,6 +241,8 @@ template <int WB> struct StripCtx {
   uint8_t *lds;
   nrq_lds_layout lay;
   uint32_t T, strip, valid; /* valid = bytes of this strip inside T */
+  unsigned long long *dbg = nullptr; /* NRQ_PROF: 7 clock marks (thread 0's, or the latest thread's) */
+  bool dbg_t0 = false;
   SB_MEM uint8_t *slots() const { return lds + lay.off_slots; }
   SB_MEM uint8_t *cu() const { return lds + lay.off_cu; }
   SB_MEM uint8_t *cf() const { return lds + lay.off_x; }
@@ -271,7 +282,9 @@ template <int WB> SB_HD void ph_load(const StripCtx<WB> &c, uint32_t tid, uint32
     }
   }
   for (uint32_t p = tid; p < c.h->r2; p += nt) lds_put<WB>(c.slots(), M + p, sv_zero<WB>());
-  for (uint32_t f = tid; f < NRQ_MAX_FREE; f += nt) lds_put<WB>(c.cf(), f, sv_zero<WB>());
+  /* region X starts as the private HDPC accumulators (ph_hdpc), which ph_hdpc_reduce leaves zeroed for Cf */
+  const uint32_t nx = (c.lay.total - c.lay.off_x) / WB;
+  for (uint32_t f = tid; f < nx; f += nt) lds_put<WB>(c.cf(), f, sv_zero<WB>());
 }
 
 /* phases 1+2: the forward passes (X^-1 on the peeled rows, the leftover rows, the GF(2) combinations of the
@@ -332,18 +345,42 @@ template <int WB> SB_HD SV<WB> row_zero() { return sv_zero<WB>(); }
 /* phase 3: HDPC right-hand sides R_h = SUM_c HDPC[h][c] * Y(c) over the peeled columns, through
  * HDPC = MT*GAMMA (RFC 6330 section 5.3.3.3): thread t owns columns [a,b); g follows the GAMMA
  * recurrence g = alpha*g + Y(c); the two unit entries of MT's column c add g to two of the H
- * accumulators (LDS atomics on the HDPC slots); whatever the chunk owes to the columns beyond b is
- * G[.][b] * alpha*g_end. */
+ * accumulators; whatever the chunk owes to the columns beyond b is G[.][b] * alpha*g_end.  The
+ * accumulators are private per lane (nsets copies of the H sums in region X, free until the dense
+ * stage): all threads XORing into the same H slots made this phase one long LDS atomic conflict.
+ * ph_hdpc_reduce folds the copies into the HDPC slots and zeroes them again. */
+template <int WB> SB_HD uint32_t hdpc_nsets(const StripCtx<WB> &c) {
+  const uint32_t cap = (c.lay.total - c.lay.off_x) / (c.h->H * WB);
+  uint32_t n = 1;
+  while (n * 2u <= cap && n < 64u) n *= 2u;
+  return n;
+}
+template <int WB> SB_HD void ph_hdpc_reduce(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint32_t H = c.h->H, nsets = hdpc_nsets<WB>(c);
+  const uint32_t hq = tid & 15u, part = tid >> 4, nparts = nt >> 4;
+  if (hq >= H) return;
+  SV<WB> acc = sv_zero<WB>();
+  bool any = false;
+  for (uint32_t s = part; s < nsets; s += nparts) {
+    sv_xor<WB>(acc, lds_get<WB>(c.cf(), s * H + hq));
+    lds_put<WB>(c.cf(), s * H + hq, sv_zero<WB>());
+    any = true;
+  }
+  if (any) lds_xor<WB>(c.slots(), c.h->S + hq, acc);
+}
 template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
   const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(c.kc);
   const NRQ_GAS uint8_t *G = gptr<uint8_t>(c.kc + kh->off_g);
   const NRQ_GAS uint8_t *b12 = gptr<uint8_t>(c.kc + kh->off_b12);
   const NRQ_GAS uint16_t *pivof = c.template arr<uint16_t>(c.h->off_pivof);
-  const uint32_t n = kh->n, H = c.h->H, S = c.h->S;
-  uint32_t len = (n + nt - 1) / nt;
-  len = (len + 7u) & ~7u;
-  const uint32_t a = tid * len;
-  if (a >= n) return;
+  const uint32_t n = kh->n, H = c.h->H;
+  const uint32_t mine = (tid & (hdpc_nsets<WB>(c) - 1u)) * H; /* this lane's copy of the H accumulators */
+  /* chunks of whole 8-column groups, as equal as possible; the threads that take one group more are the FIRST
+   * ones, so that a single wave (not one lane of every wave) runs the longer loop */
+  const uint32_t groups = (n + 7u) / 8u, base = groups / nt, extra = groups - base * nt;
+  const uint32_t a = 8u * (tid * base + (tid < extra ? tid : extra));
+  if (a >= n || (base == 0u && tid >= extra)) return;
+  const uint32_t len = 8u * (base + (tid < extra ? 1u : 0u));
   const uint32_t b = (a + len < n) ? a + len : n;
   SV<WB> g = sv_zero<WB>();
   /* 8 columns per step: their slot indices and MT rows come in two vector loads (the arrays are
@@ -365,22 +402,30 @@ template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32
       }
       if (col + 1 < n) {
         const uint32_t e = (bbw[q >> 2] >> ((q & 3u) * 8u)) & 0xFFu;
-        lds_xor<WB>(c.slots(), S + (e & 15u), g);
-        lds_xor<WB>(c.slots(), S + (e >> 4), g);
+        lds_xor<WB>(c.cf(), mine + (e & 15u), g);
+        lds_xor<WB>(c.cf(), mine + (e >> 4), g);
       } else { /* last column of MT is alpha^h */
         SV<WB> v = g;
         for (uint32_t h = 0; h < H; h++) {
-          lds_xor<WB>(c.slots(), S + h, v);
+          lds_xor<WB>(c.cf(), mine + h, v);
           v = sv_xtime<WB>(v);
         }
       }
     }
   }
+  NRQ_MARK(c, 0);
   if (b < n) {
-    SV<WB> carry = sv_xtime<WB>(g);
+    /* H products of the same vector: its 8 multiples by alpha^k once, then one masked XOR per set coefficient bit */
+    SV<WB> pw[8];
+    pw[0] = sv_xtime<WB>(g);
+#pragma unroll
+    for (int k = 1; k < 8; k++) pw[k] = sv_xtime<WB>(pw[k - 1]);
     for (uint32_t h = 0; h < H; h++) {
-      SV<WB> t = sv_mul<WB>(carry, G[(size_t)h * n + b]);
-      lds_xor<WB>(c.slots(), S + h, t);
+      const uint32_t coef = G[(size_t)h * n + b];
+      SV<WB> t = sv_zero<WB>();
+#pragma unroll
+      for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef >> k) & 1u));
+      lds_xor<WB>(c.cf(), mine + h, t);
     }
   }
 }

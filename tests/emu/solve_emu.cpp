@@ -57,6 +57,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
   PHASE(ph_load);
   if (!emu_forward<WB>(c)) return -7;
   PHASE(ph_hdpc);
+  PHASE(ph_hdpc_reduce);
   PHASE(ph_dense_fold);
   PHASE(ph_dense_free);
   PHASE(ph_dense_cu);

@@ -3,6 +3,8 @@
 
   python tools/rocprof_summary.py stats  <kernel-trace results.db>     per-kernel launch statistics
   python tools/rocprof_summary.py pmc    <pmc results.db> [...]        per-kernel counter values
+  python tools/rocprof_summary.py pmcjson <pmc results.db> [...]       solve-kernel counters per launch as JSON (bench.py reads
+                                                                       profiles/r1_pmc_hbm.json for roofline.traffic)
 
 Kernel names are shortened to the part before '('.  Durations in microseconds.
 """
@@ -43,8 +45,44 @@ def pmc(paths):
             print("%-64s %10d %-12s %6d %14.1f %14.1f" % (name, grid, cname, len(v), sum(v) / len(v), max(v)))
 
 
+def pmcjson(paths):
+    """Counters of the full-batch nrq_solve_kernel launches, per launch.  Launches alternate encode, decode (bench.py)."""
+    import json
+    per = defaultdict(list)  # counter -> [value per dispatch, in dispatch order]
+    grid_max = 0
+    rows_all = []
+    for path in paths:
+        db = sqlite3.connect(path)
+        rows = db.execute("select kernel_name, grid_size, counter_name, value, dispatch_id from counters_collection "
+                          "order by dispatch_id").fetchall()
+        rows = [r for r in rows if r[0].startswith("void nrq_solve_kernel") or r[0].startswith("nrq_solve_kernel")]
+        rows_all += rows
+        for r in rows:
+            grid_max = max(grid_max, r[1])
+    for name, grid, cname, val, did in rows_all:
+        if grid == grid_max:
+            per[cname].append(val)
+    out = {"method": "rocprofv3 --pmc, one counter group per pass (tools/collect_profiles.sh) of `python bench.py --steps 3 --warmup 1 "
+                     "--cpu-sample 0`; full-batch nrq_solve_kernel launches only; FETCH_SIZE / WRITE_SIZE are reported in KB (x1024 here); "
+                     "MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 -- this kernel reads 16-byte row "
+                     "segments (uncalibrated), so the read side is a lower bound, at most 2x higher",
+           "K": 8192, "T": 1280, "blocks": 256,  # bench.py's default workload, which collect_profiles.sh runs
+           "grid": grid_max, "launches": {k: len(v) for k, v in per.items()}, "per_launch": {}}
+    for k, v in per.items():
+        scale = 1024.0 if k in ("FETCH_SIZE", "WRITE_SIZE") else 1.0
+        enc = [x * scale for x in v[0::2]]
+        dec = [x * scale for x in v[1::2]]
+        out["per_launch"][k] = {"encode": sum(enc) / max(1, len(enc)), "decode": sum(dec) / max(1, len(dec)),
+                                "mean": sum(x * scale for x in v) / max(1, len(v))}
+    if "FETCH_SIZE" in out["per_launch"] and "WRITE_SIZE" in out["per_launch"]:
+        out["bytes_per_launch"] = out["per_launch"]["FETCH_SIZE"]["mean"] + out["per_launch"]["WRITE_SIZE"]["mean"]
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "pmcjson":
+        pmcjson(sys.argv[2:])
     else:
         pmc(sys.argv[2:])
