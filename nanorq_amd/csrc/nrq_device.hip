@@ -98,32 +98,8 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
   __syncthreads();
   NRQ_STAMP(1);
 
-  /* forward passes (plan.h): wave 0 walks the op stream alone, the other waves wait at the barrier below.  Step
-   * q applies row q-NRQ_PIPE and then reads the sources of row q; op words live in a ring of NRQ_RING fixed
-   * registers, each reloaded (NRQ_RING rows ahead) right after its row has been applied -- no hand-over
-   * between registers, so the loads stay outstanding across the LDS work.  The ring starts as the NRQ_RING
-   * all-NOP rows the stream begins with; the plan pads the stream so that every fetch is in bounds. */
-  if (tid < NRQ_ROW) {
-    constexpr uint32_t P = NRQ_PIPE, NS = NRQ_PIPE + 1u, U = NRQ_RING;
-    static_assert(U % NS == 0, "ring must be a multiple of the value sets");
-    const NRQ_GAS uint32_t *nxt = c.template arr<uint32_t>(c.h->off_ops) + tid;
-    const uint32_t nrows = c.h->nrows;
-    uint32_t o[U];
-    typename RowVal<WB>::type v[NS];
-#pragma unroll
-    for (uint32_t k = 0; k < U; k++) o[k] = NRQ_NOP_AT(tid);
-#pragma unroll
-    for (uint32_t k = 0; k < NS; k++) v[k] = row_zero<WB>();
-    for (uint32_t base = 0; base < nrows + P; base += U, nxt += U * NRQ_ROW) {
-#pragma unroll
-      for (uint32_t k = 0; k < U; k++) {
-        const uint32_t j = (k + U - P) % U; /* ring slot of row q - P */
-        ph_row_apply<WB>(c, o[j], v[(k + NS - P) % NS]);
-        o[j] = nxt[(k + U - P) * NRQ_ROW];
-        v[k % NS] = ph_row_read<WB>(c, o[k]);
-      }
-    }
-  }
+  /* forward passes (plan.h): wave 0 walks the op stream alone (fwd_rows), the other waves wait at the barrier below */
+  if (tid < NRQ_ROW) fwd_rows<WB>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
   __syncthreads();
   NRQ_STAMP(2);
 
@@ -169,8 +145,13 @@ enum {
   pl_tag_pl_lev_a = 7,
   pl_tag_pl_lev_b = 7,
   pl_tag_pl_w_init = 8,
+  pl_tag_pl_w_init_b = 8,
   pl_tag_pl_w_group = 8,
   pl_tag_pl_w_stage = 8,
+  pl_tag_pl_wfast_spill = 4,
+  pl_tag_pl_wfast_load = 4,
+  pl_tag_pl_wfast_store = 4,
+  pl_tag_pl_wfast_restore = 4,
   pl_tag_pl_low_a = 9,
   pl_tag_pl_low_b = 9,
   pl_tag_pl_low_c = 9,
@@ -212,8 +193,10 @@ __global__ __launch_bounds__(PL_NT) void nrq_plan_kernel(rq_params p, const uint
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= nblk) return;
-  pl_shared *sh = reinterpret_cast<pl_shared *>(smem);
-  uint8_t *dyn = smem + ((sizeof(pl_shared) + 15u) & ~(size_t)15u);
+  /* the dynamic region comes first (LDS address 0: the W strip image is addressed like the solve kernel's), the
+   * fixed workgroup state after it */
+  uint8_t *dyn = smem;
+  pl_shared *sh = reinterpret_cast<pl_shared *>(smem + lds_dyn_bytes);
   PlanCtx c;
   pl_ctx_setup(c, p, kc, pjobs[b], sh, dyn, lds_dyn_bytes, Mcap, npcap, ucap, jobs_out + b);
   /* NRQ_PROF=1: thread 0 of block 0 accumulates shader clocks per phase family (index = PL_TAG) */
@@ -222,9 +205,18 @@ __global__ __launch_bounds__(PL_NT) void nrq_plan_kernel(rq_params p, const uint
                                                           prof[tag] += t_ - t_prev; prof[16 + tag] += 1; t_prev = t_; } } while (0)
 #define PL_PHASE(fn) do { fn<0>(c, tid, PL_NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
 #define PL_PHASE1(fn, a) do { fn<0>(c, (a), tid, PL_NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
+#define PL_WFAST_RUN(wb) do { \
+    if (tid < NRQ_ROW) { \
+      const NRQ_GAS uint32_t *ops_ = gptr<uint32_t>(c.arena + c.sh->off_ops); \
+      if ((wb) == 16u) fwd_rows<16>(ops_, pl_wfast_rows(c), tid); \
+      else if ((wb) == 8u) fwd_rows<8>(ops_, pl_wfast_rows(c), tid); \
+      else fwd_rows<4>(ops_, pl_wfast_rows(c), tid); \
+    } \
+    __syncthreads(); PL_ACC(2); } while (0)
 #include "planner_seq.h"
 #undef PL_PHASE
 #undef PL_PHASE1
+#undef PL_WFAST_RUN
 #undef PL_ACC
 }
 
@@ -1004,7 +996,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     unsigned long long hp[32];
     HIPCHK(ctx, hipMemcpyAsync(hp, pprof, sizeof(hp), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    static const char *nm[16] = {"init", "claim", "pivot", "drop", "swap", "ifind", "iapply", "lev", "W", "low", "ops", "mh",
+    static const char *nm[16] = {"init", "claim", "Wrun", "drop", "Wmove", "ifind", "iapply", "lev", "W", "low", "ops", "mh",
                                  "gj", "bin", "dense", "final"};
     unsigned long long tot = 0;
     for (int k = 0; k < 16; k++) tot += hp[k];

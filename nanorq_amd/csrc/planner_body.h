@@ -567,6 +567,18 @@ template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t t
 }
 
 /* =============================== phase 2: levels, W ========================================== */
+/* Per-level counters (ops counted, ops placed).  Thousands of rows share a level, and that many atomics on ONE
+ * global address serialise in L2 (~1 M clocks per block measured), so the counters live in LDS -- at the end of
+ * the aux region (the rowstate image, dead once peeling is over) -- whenever they fit; lev_ops[] in HBM gets the
+ * counts when the layout is fixed (pl_ops_layout). */
+SB_HD uint32_t *pl_lds_lev(const PlanCtx &c) {
+  const uint32_t bytes = pl_r16((c.sh->nlev + 2u) * 8u);
+  if (!c.aux_lds || bytes + 16384u > c.aux_bytes) return nullptr; /* leave room for the level-by-level W pass staging */
+  return reinterpret_cast<uint32_t *>(c.aux_lds + c.aux_bytes - bytes);
+}
+SB_HD uint32_t *pl_lev_cnt(const PlanCtx &c) { uint32_t *l = pl_lds_lev(c); return l ? l : c.lev_ops; }
+SB_HD uint32_t *pl_lev_fillp(const PlanCtx &c) { uint32_t *l = pl_lds_lev(c); return l ? l + (c.sh->nlev + 2u) : c.lev_fill; }
+
 template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (tid == 0) {
@@ -578,6 +590,8 @@ template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
+  if (uint32_t *l = pl_lds_lev(c)) /* wpr / nlev are final now */
+    for (uint32_t k = tid; k < 2u * (sh->nlev + 2u); k += nt) l[k] = 0;
   /* W rows are accumulated with XORs: start from zero */
   for (uint32_t e = tid; e < sh->M * sh->wpr; e += nt) c.wrows[e] = 0;
   for (uint32_t k = tid; k < sh->npiv; k += nt) c.pivdeg[k] = 0;
@@ -607,35 +621,76 @@ SB_HD void pl_scan_row(const PlanCtx &c, uint32_t r, uint32_t own, uint32_t w8, 
 }
 
 /* W starts as A restricted to the inactive columns, row by slot; op counts per row and per level group.
- * Ordinary rows: 8 lanes per row.  The long LDPC rows (r < S): 8 slices of 8 lanes, merged with atomics. */
+ * Ordinary rows: 8 lanes per row, sharing its entries.  The long LDPC rows (r < S): 64 lanes each (pl_w_init_b). */
 template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
-  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr, S = c.p.S, H = c.p.H;
+  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr, S = c.p.S;
   const uint32_t total = sh->npiv + sh->nlow;
-  /* item i < npiv: pivot i; otherwise leftover row i - npiv (group nlev) */
-  for (uint32_t i = grp; i < total; i += ngrp) {
-    const bool piv = i < sh->npiv;
-    const uint32_t r = piv ? c.pivslot[i] : c.lowslot[i - sh->npiv];
-    if (r < S) continue;
-    uint32_t acc[5], deg;
-    pl_scan_row(c, r, piv ? c.pivcol[i] : PL_NONE, w8, 0u, 1u, acc, &deg);
-    uint32_t *dst = c.wrows + (size_t)r * wpr;
+  uint32_t *cnt = pl_lev_cnt(c);
+  /* item i < npiv: pivot i; otherwise leftover row i - npiv (group nlev).  Each step of a row is a dependent
+   * trip to L2/HBM (slot -> patch -> row pointers -> entries), so a lane group works on RB rows at once, stage
+   * by stage, to have their loads in flight together. */
+  constexpr uint32_t RB = 4;
+  for (uint32_t i0 = grp; i0 < total; i0 += RB * ngrp) {
+    uint32_t ii[RB], r[RB], own[RB], n[RB], e0[RB], e1[RB];
+    const uint16_t *cols[RB];
+    bool piv[RB], use[RB];
 #pragma unroll
-    for (uint32_t q = 0; q < 5; q++) {
-      const uint32_t wd = w8 + 8u * q;
-      if (wd < wpr) dst[wd] = acc[q];
+    for (uint32_t j = 0; j < RB; j++) {
+      ii[j] = i0 + j * ngrp;
+      use[j] = ii[j] < total;
+      piv[j] = ii[j] < sh->npiv;
+      r[j] = !use[j] ? 0u : piv[j] ? c.pivslot[ii[j]] : c.lowslot[ii[j] - sh->npiv];
+      own[j] = (use[j] && piv[j]) ? c.pivcol[ii[j]] : PL_NONE;
     }
-    if (w8 == 0) {
-      if (piv) { c.pivdeg[i] = deg; PL_ATOM_ADD(&c.lev_ops[c.rowinfo[r] & PL_LEVEL_MASK], deg); }
-      else { c.lowdeg[i - sh->npiv] = deg; PL_ATOM_ADD(&c.lev_ops[sh->nlev], deg); }
+#pragma unroll
+    for (uint32_t j = 0; j < RB; j++) {
+      n[j] = 0; cols[j] = c.patch_cols;
+      if (!use[j]) continue;
+      if (r[j] < S) { /* a long LDPC row: listed for pl_w_init_b (the frontier queue is free by now; S <= 907 < PL_QCAP) */
+        if (w8 == 0) sh->queue[0][PL_ATOM_ADD(&sh->nq[0], 1u)] = (uint16_t)ii[j];
+        use[j] = false;
+        continue;
+      }
+      n[j] = pl_row(c, r[j], &cols[j]);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < RB; j++) { /* the first two entries of every lane (covers rows of up to 16 entries) */
+      e0[j] = w8 < n[j] ? cols[j][w8] : PL_NONE;
+      e1[j] = w8 + 8u < n[j] ? cols[j][w8 + 8u] : PL_NONE;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < RB; j++) {
+      if (!use[j]) continue;
+      /* the 8 lanes share the row's entries; inactive ones toggle their bit in the (zeroed) W row, the others count */
+      uint32_t *dst = c.wrows + (size_t)r[j] * wpr;
+      uint32_t deg = 0;
+      for (uint32_t k = w8, t = 0; k < n[j]; k += 8u, t++) {
+        const uint32_t col = t == 0 ? e0[j] : t == 1 ? e1[j] : (uint32_t)cols[j][k];
+        const uint32_t info = c.colinfo[col], idx = info & 0x3FFFFFFFu;
+        if ((info >> 30) == PL_ST_INACT) PL_ATOM_XOR(&dst[idx >> 5], 1u << (idx & 31u));
+        else if (col != own[j]) deg++;
+      }
+      if (deg) {
+        if (piv[j]) { PL_ATOM_ADD(&c.pivdeg[ii[j]], deg); PL_ATOM_ADD(&cnt[c.rowinfo[r[j]] & PL_LEVEL_MASK], deg); }
+        else { PL_ATOM_ADD(&c.lowdeg[ii[j] - sh->npiv], deg); PL_ATOM_ADD(&cnt[sh->nlev], deg); }
+      }
     }
   }
-  /* long rows: slots [0,S); the destination words were zeroed in pl_lev_b */
-  for (uint32_t i = grp >> 3; i < total; i += ngrp >> 3) {
+}
+/* the long rows (slots [0,S)) listed by pl_w_init: 8 slices of 8 lanes each; the destination words were zeroed in
+ * pl_lev_b */
+template <int Z> SB_HD void pl_w_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr;
+  const uint32_t nlong = sh->nq[0];
+  uint32_t *cnt = pl_lev_cnt(c);
+  for (uint32_t q = grp >> 3; q < nlong; q += ngrp >> 3) {
+    const uint32_t i = sh->queue[0][q];
     const bool piv = i < sh->npiv;
     const uint32_t r = piv ? c.pivslot[i] : c.lowslot[i - sh->npiv];
-    if (r >= S) continue;
     uint32_t acc[5], deg;
     pl_scan_row(c, r, piv ? c.pivcol[i] : PL_NONE, w8, grp & 7u, 8u, acc, &deg);
     uint32_t *dst = c.wrows + (size_t)r * wpr;
@@ -645,11 +700,10 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
       if (wd < wpr && acc[q]) PL_ATOM_XOR(&dst[wd], acc[q]);
     }
     if (w8 == 0 && deg) {
-      if (piv) { PL_ATOM_ADD(&c.pivdeg[i], deg); PL_ATOM_ADD(&c.lev_ops[c.rowinfo[r] & PL_LEVEL_MASK], deg); }
-      else { PL_ATOM_ADD(&c.lowdeg[i - sh->npiv], deg); PL_ATOM_ADD(&c.lev_ops[sh->nlev], deg); }
+      if (piv) { PL_ATOM_ADD(&c.pivdeg[i], deg); PL_ATOM_ADD(&cnt[c.rowinfo[r] & PL_LEVEL_MASK], deg); }
+      else { PL_ATOM_ADD(&c.lowdeg[i - sh->npiv], deg); PL_ATOM_ADD(&cnt[sh->nlev], deg); }
     }
   }
-  (void)H;
 }
 
 #define PL_OPQ_WORDS 1024u /* op words a prefetch buffer holds (4 chunks) */
@@ -739,6 +793,56 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
   if (tid == 0) sh->opq_group[(group + 1u) & 1u] = pf_n ? group + 1u : PL_NONE;
 }
 
+/* ---- W pass, fast path ----
+ * W = X^-1 * A_U is the op stream applied to the bit rows -- the very computation the solve kernel performs on
+ * symbol strips.  So the planner does it the same way: a strip of `wb` bytes (wb/4 words) of every W row is
+ * brought into LDS as slot image (slot r at (r + NRQ_SCRATCH) * wb from LDS address 0, like the solve kernel),
+ * ONE wave runs the row pipeline over the stream (fwd_rows; no barriers, LDS atomics), the strip goes back to
+ * the HBM rows; ceil(wpr*4/wb) strips.  The image takes over the whole dynamic LDS region: the LDS-resident
+ * peeling arrays that are still needed afterwards (rowinfo, colinfo) are spilled to their HBM homes first and
+ * brought back at the end.  0 = does not fit even with 4-byte strips: the level-by-level pass on the HBM rows. */
+SB_HD uint32_t pl_wfast_wb(const PlanCtx &c) {
+  if (!c.lds_dyn) return 0u;
+  for (uint32_t wb = 16u; wb >= 4u; wb >>= 1)
+    if ((c.sh->M + NRQ_SCRATCH) * wb <= c.lds_dyn_bytes) return wb;
+  return 0u;
+}
+SB_HD bool pl_peel_in_lds(const PlanCtx &c) { return reinterpret_cast<const uint8_t *>(c.rowinfo) == c.lds_dyn + pl_r16(c.Mcap * 4u); }
+template <int Z> SB_HD void pl_wfast_spill(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  if (c.sh->status || !pl_peel_in_lds(c)) return;
+  uint32_t *ri = reinterpret_cast<uint32_t *>(c.work + c.wl.rowinfo), *ci = reinterpret_cast<uint32_t *>(c.work + c.wl.colinfo);
+  for (uint32_t k = tid; k < c.Mcap; k += nt) ri[k] = c.rowinfo[k];
+  for (uint32_t k = tid; k < c.p.L; k += nt) ci[k] = c.colinfo[k];
+}
+template <int Z> SB_HD void pl_wfast_restore(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  if (c.sh->status || !pl_peel_in_lds(c)) return;
+  const uint32_t *ri = reinterpret_cast<const uint32_t *>(c.work + c.wl.rowinfo), *ci = reinterpret_cast<const uint32_t *>(c.work + c.wl.colinfo);
+  for (uint32_t k = tid; k < c.Mcap; k += nt) c.rowinfo[k] = ri[k];
+  for (uint32_t k = tid; k < c.p.L; k += nt) c.colinfo[k] = ci[k];
+}
+template <int Z> SB_HD void pl_wfast_load(PlanCtx &c, uint32_t strip, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t wpl = pl_wfast_wb(c) / 4u, wpr = sh->wpr, n = (sh->M + NRQ_SCRATCH) * wpl;
+  uint32_t *img = reinterpret_cast<uint32_t *>(c.lds_dyn);
+  for (uint32_t e = tid; e < n; e += nt) {
+    const uint32_t slot = e / wpl, k = e - slot * wpl, wd = strip * wpl + k;
+    img[e] = (slot >= NRQ_SCRATCH && wd < wpr) ? c.wrows[(size_t)(slot - NRQ_SCRATCH) * wpr + wd] : 0u;
+  }
+}
+template <int Z> SB_HD void pl_wfast_store(PlanCtx &c, uint32_t strip, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (sh->status) return;
+  const uint32_t wpl = pl_wfast_wb(c) / 4u, wpr = sh->wpr, n = sh->M * wpl;
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(c.lds_dyn) + NRQ_SCRATCH * wpl;
+  for (uint32_t e = tid; e < n; e += nt) {
+    const uint32_t slot = e / wpl, k = e - slot * wpl, wd = strip * wpl + k;
+    if (wd < wpr) c.wrows[(size_t)slot * wpr + wd] = img[e];
+  }
+}
+/* the rows of the stream that exist at this point: the pivot levels and the leftover rows */
+SB_HD uint32_t pl_wfast_rows(const PlanCtx &c) { return c.sh->spare_base; }
+
 /* =============================== phase 3: leftover rows ====================================== */
 template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /* list them */
   pl_shared *sh = c.sh;
@@ -752,6 +856,7 @@ template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /*
 template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (tid != 0) return;
+  sh->nq[0] = 0; /* the frontier queue becomes pl_w_init's list of long rows */
   sh->lpr = (sh->nlow + PL_EXTRA_ROWS + 31u) / 32u; /* room for the rows a rank-deficient block may add */
   sh->rowlen = sh->wpr + sh->lpr;
   /* Mb (nlow x rowlen words) and Mh (H x u bytes) share the dynamic LDS region from here on */
@@ -787,11 +892,12 @@ template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt)
   /* row base of every level group (levels 1..nlev-1 are pivot groups, index nlev = leftover rows); the stream
    * starts with the NRQ_RING lead rows and every non-empty group is followed by NRQ_PIPE-1 spacer rows */
   uint32_t rows = NRQ_RING;
+  const uint32_t *cnt = pl_lev_cnt(c);
   for (uint32_t l = 0; l <= sh->nlev; l++) {
-    const uint32_t n = c.lev_ops[l];
+    const uint32_t n = cnt[l];
+    c.lev_ops[l] = n;
     c.lev_base[l] = rows;
     if (n) rows += pl_group_rows(n) + (NRQ_PIPE - 1u);
-    c.lev_fill[l] = 0;
   }
   sh->spare_base = rows; /* rows reserved for constraint rows added later */
   rows += PL_SPARE_ROWS + (NRQ_PIPE - 1u);
@@ -839,17 +945,18 @@ SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t group, uin
 template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
+  uint32_t *fill = pl_lev_fillp(c);
   for (uint32_t k = tid; k < sh->npiv; k += nt) {
     const uint32_t deg = c.pivdeg[k];
     if (!deg) continue;
     const uint32_t r = c.pivslot[k], l = c.rowinfo[r] & PL_LEVEL_MASK;
-    const uint32_t start = PL_ATOM_ADD(&c.lev_fill[l], deg);
+    const uint32_t start = PL_ATOM_ADD(&fill[l], deg);
     pl_emit_row(c, r, c.pivcol[k], l, start, r);
   }
   for (uint32_t j = tid; j < sh->nlow; j += nt) {
     const uint32_t deg = c.lowdeg[j];
     if (!deg) continue;
-    const uint32_t start = PL_ATOM_ADD(&c.lev_fill[sh->nlev], deg);
+    const uint32_t start = PL_ATOM_ADD(&fill[sh->nlev], deg);
     pl_emit_row(c, c.lowslot[j], PL_NONE, sh->nlev, start, c.lowslot[j]);
   }
 }

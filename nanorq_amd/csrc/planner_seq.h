@@ -3,6 +3,8 @@
  * CPU emulator.  The includer defines
  *     PL_PHASE(fn)        run phase fn(c, tid, PL_NT) on every thread of the workgroup, then barrier
  *     PL_PHASE1(fn, a)    same with one extra leading argument
+ *     PL_WFAST_RUN(wb)    run the op-stream rows [0, pl_wfast_rows(c)) on the wb-byte slot image at the start of
+ *                         the dynamic LDS region (one wave), then barrier
  * and provides `PlanCtx c`.  Every value that steers control flow is read from workgroup-shared state
  * right after a barrier, so all threads take the same path.
  */
@@ -44,12 +46,29 @@
   }
   if (sh_->status == 0 && sh_->nV == 0) {
     PL_PHASE(pl_w_init);
+    PL_PHASE(pl_w_init_b);
     PL_PHASE(pl_ops_layout);
     PL_PHASE(pl_ops_clear);
     PL_PHASE(pl_ops_emit);
-    /* W = X^-1 * A_U and the leftover rows' reduced coefficients: the op stream run on bit rows */
-    PL_PHASE(pl_w_stage);
-    for (uint32_t lv_ = 1; lv_ <= sh_->nlev; lv_++) PL_PHASE1(pl_w_group, lv_);
+    /* W = X^-1 * A_U and the leftover rows' reduced coefficients: the op stream run on bit rows -- on strips of
+     * them in LDS by the solve kernel's row pipeline (PL_WFAST_RUN: wave 0 only; defined by the includer),
+     * or, when no strip width fits, level by level on the HBM rows */
+    {
+      const uint32_t wb_ = sh_->status == 0 ? pl_wfast_wb(c) : 0u;
+      if (wb_) {
+        PL_PHASE(pl_wfast_spill);
+        const uint32_t ns_ = (sh_->wpr * 4u + wb_ - 1u) / wb_;
+        for (uint32_t s_ = 0; s_ < ns_; s_++) {
+          PL_PHASE1(pl_wfast_load, s_);
+          PL_WFAST_RUN(wb_);
+          PL_PHASE1(pl_wfast_store, s_);
+        }
+        PL_PHASE(pl_wfast_restore);
+      } else {
+        PL_PHASE(pl_w_stage);
+        for (uint32_t lv_ = 1; lv_ <= sh_->nlev; lv_++) PL_PHASE1(pl_w_group, lv_);
+      }
+    }
     PL_PHASE(pl_low_c);
     PL_PHASE(pl_mh_init);
     for (uint32_t tl_ = 0; tl_ * PL_MH_TILE < sh_->npiv; tl_++) {

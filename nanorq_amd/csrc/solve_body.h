@@ -333,6 +333,33 @@ template <int WB> __device__ __forceinline__ void ph_row_apply(const StripCtx<WB
   }
 }
 template <int WB> __device__ __forceinline__ typename RowVal<WB>::type row_zero() { typename RowVal<WB>::type z = {}; return z; }
+/* The row pipeline itself, run by ONE wave (lane = 0..63) on the LDS image that starts at LDS address 0: step q
+ * applies row q-NRQ_PIPE and then reads the sources of row q.  Op words live in a ring of NRQ_RING fixed
+ * registers, each reloaded (NRQ_RING rows ahead) right after its row has been applied -- no hand-over between
+ * registers, so the loads stay outstanding across the LDS work.  The ring starts as the NRQ_RING all-NOP rows the
+ * stream begins with; the stream is padded (NRQ_PAD_ROWS) so that every fetch is in bounds.  Used by the solve
+ * kernel on symbol strips and by the planner kernel on strips of the W bit rows. */
+template <int WB> __device__ __forceinline__ void fwd_rows(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
+  constexpr uint32_t P = NRQ_PIPE, NS = NRQ_PIPE + 1u, U = NRQ_RING;
+  static_assert(U % NS == 0, "ring must be a multiple of the value sets");
+  const StripCtx<WB> none{};
+  const NRQ_GAS uint32_t *nxt = ops + lane;
+  uint32_t o[U];
+  typename RowVal<WB>::type v[NS];
+#pragma unroll
+  for (uint32_t k = 0; k < U; k++) o[k] = NRQ_NOP_AT(lane);
+#pragma unroll
+  for (uint32_t k = 0; k < NS; k++) v[k] = row_zero<WB>();
+  for (uint32_t base = 0; base < nrows + P; base += U, nxt += U * NRQ_ROW) {
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) {
+      const uint32_t j = (k + U - P) % U; /* ring slot of row q - P */
+      ph_row_apply<WB>(none, o[j], v[(k + NS - P) % NS]);
+      o[j] = nxt[(k + U - P) * NRQ_ROW];
+      v[k % NS] = ph_row_read<WB>(none, o[k]);
+    }
+  }
+}
 #else
 template <int WB> struct RowVal { typedef SV<WB> type; };
 template <int WB> SB_HD SV<WB> ph_row_read(const StripCtx<WB> &c, uint32_t op) { return lds_get<WB>(c.lds, op >> 16); }
@@ -340,6 +367,9 @@ template <int WB> SB_HD void ph_row_apply(const StripCtx<WB> &c, uint32_t op, co
   lds_xor<WB>(c.lds, op & 0xFFFFu, v);
 }
 template <int WB> SB_HD SV<WB> row_zero() { return sv_zero<WB>(); }
+/* host compilation pass of the kernels only: the row pipeline exists on the device (the CPU emulators have
+ * their own row loops over ph_row_read / ph_row_apply) */
+template <int WB> SB_HD void fwd_rows(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
 #endif
 
 /* phase 3: HDPC right-hand sides R_h = SUM_c HDPC[h][c] * Y(c) over the peeled columns, through

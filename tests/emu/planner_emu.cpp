@@ -17,6 +17,29 @@ extern "C" uint32_t emu_plan_arena_bound(uint32_t K, const uint8_t *kc, uint32_t
   return pl_arena_bound(kh->L, kh->L + overhead_cap, kh->P + 768u, kh->nnz + (nlost_cap + overhead_cap) * 40u, nlost_cap);
 }
 
+/* PL_WFAST_RUN on the CPU: the op-stream rows in the order the kernel's wave 0 issues them (step q applies row
+ * q-NRQ_PIPE, then reads the sources of row q) on the wb-byte slot image at the start of the dynamic region. */
+static void emu_wfast_run(PlanCtx &c, uint32_t wb) {
+  const uint32_t wpl = wb / 4u, nrows = pl_wfast_rows(c), P = NRQ_PIPE;
+  uint32_t *img = reinterpret_cast<uint32_t *>(c.lds_dyn);
+  const uint32_t *ops = reinterpret_cast<const uint32_t *>(c.arena + c.sh->off_ops);
+  std::vector<uint32_t> v((size_t)(P + 1) * NRQ_ROW * wpl);
+  for (uint32_t q = 0; q < nrows + P; q++) {
+    if (q >= P) {
+      const uint32_t *row = ops + (size_t)(q - P) * NRQ_ROW;
+      const uint32_t *vr = &v[(size_t)((q - P) % (P + 1)) * NRQ_ROW * wpl];
+      for (uint32_t l = 0; l < NRQ_ROW; l++)
+        for (uint32_t k = 0; k < wpl; k++) img[(size_t)(row[l] & 0xFFFFu) * wpl + k] ^= vr[l * wpl + k];
+    }
+    if (q < nrows) {
+      const uint32_t *row = ops + (size_t)q * NRQ_ROW;
+      uint32_t *vr = &v[(size_t)(q % (P + 1)) * NRQ_ROW * wpl];
+      for (uint32_t l = 0; l < NRQ_ROW; l++)
+        for (uint32_t k = 0; k < wpl; k++) vr[l * wpl + k] = img[(size_t)(row[l] >> 16) * wpl + k];
+    }
+  }
+}
+
 /* returns 0 and fills arena (status in its header); job_out receives the solve job (host pointers) */
 extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const uint32_t *lost, uint32_t nlost,
                         const uint32_t *rep_esi, uint32_t nrep, uint32_t nrep_avail, uint8_t *arena,
@@ -43,9 +66,11 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   pl_ctx_setup(c, p, kc, job, sh, lds_dyn_bytes ? dyn.data() : nullptr, lds_dyn_bytes, Mcap, npcap, ucap, job_out);
 #define PL_PHASE(fn) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, t_, PL_NT); } while (0)
 #define PL_PHASE1(fn, a) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, (a), t_, PL_NT); } while (0)
+#define PL_WFAST_RUN(wb) emu_wfast_run(c, (wb))
 #include "../../nanorq_amd/csrc/planner_seq.h"
 #undef PL_PHASE
 #undef PL_PHASE1
+#undef PL_WFAST_RUN
   delete sh;
   return 0;
 }
