@@ -122,7 +122,7 @@ typedef struct pl_shared {
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
   uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, ucol, wrows,
-      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, red_row, red_x, total;
+      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, total;
 } pl_work_layout;
 
 SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uint32_t ucap) {
@@ -145,6 +145,7 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.lev_fill = o;   o = pl_r16(o + (L + 2u) * 4u);
   w.pivdeg = o;     o = pl_r16(o + L * 4u);
   w.lowdeg = o;     o = pl_r16(o + Mcap * 4u);
+  w.lev_fin = o;    o = pl_r16(o + (L + 2u) * 4u);
   w.red_row = o;    o = pl_r16(o + ucap * 4u);
   w.red_x = o;      o = pl_r16(o + ucap * 4u);
   w.total = o;
@@ -188,7 +189,7 @@ struct PlanCtx {
   uint32_t *rowstate, *rowinfo, *colinfo;
   uint16_t *patch_of, *patch_cols, *pc_rows, *ucol;
   uint8_t *patch_len;
-  uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *red_row,
+  uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *lev_fin, *red_row,
       *red_x;
   /* arena views (fixed part laid out up front) */
   uint8_t *arena;
@@ -257,6 +258,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.lev_fill = reinterpret_cast<uint32_t *>(w + c.wl.lev_fill);
   c.pivdeg = reinterpret_cast<uint32_t *>(w + c.wl.pivdeg);
   c.lowdeg = reinterpret_cast<uint32_t *>(w + c.wl.lowdeg);
+  c.lev_fin = reinterpret_cast<uint32_t *>(w + c.wl.lev_fin);
   c.red_row = reinterpret_cast<uint32_t *>(w + c.wl.red_row);
   c.red_x = reinterpret_cast<uint32_t *>(w + c.wl.red_x);
   /* arena: header, then the arrays whose size is bounded by (L, ucap) */
@@ -567,18 +569,41 @@ template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t t
 }
 
 /* =============================== phase 2: levels, W ========================================== */
-/* Per-level counters (ops counted, ops placed).  Thousands of rows share a level, and that many atomics on ONE
- * global address serialise in L2 (~1 M clocks per block measured), so the counters live in LDS -- at the end of
- * the aux region (the rowstate image, dead once peeling is over) -- whenever they fit; lev_ops[] in HBM gets the
- * counts when the layout is fixed (pl_ops_layout). */
-SB_HD uint32_t *pl_lds_lev(const PlanCtx &c) {
-  const uint32_t bytes = pl_r16((c.sh->nlev + 2u) * 8u);
-  if (!c.aux_lds || bytes + 16384u > c.aux_bytes) return nullptr; /* leave room for the level-by-level W pass staging */
-  return reinterpret_cast<uint32_t *>(c.aux_lds + c.aux_bytes - bytes);
+/* Per-group counters of the op stream.  Group l of the stream holds
+ *   - the "finishing" ops of level l: dst on level l, src on level l-1 (every row of the level has at least one), and
+ *   - "early" ops: dst on a later level t > l, src final before l; such an op may run in any group of its window
+ *     [level(src)+1, t-1] and is sent to one of them by a hash of (dst, column) -- it fills lanes that the narrow
+ *     levels would leave empty (plan.h: a group needs NRQ_PIPE-1 rows after its finishing ops anyway).
+ * Four counters per group -- finishing / early ops counted, finishing / early ops placed -- in LDS at the end of the
+ * aux region (the rowstate image, dead once peeling is over): thousands of rows share a level, and that many
+ * atomics on ONE global address serialise in L2 (~1 M clocks per block measured).  The level of every pivot
+ * column (what an op's window depends on) sits at the start of the aux region.  If LDS is too small for either,
+ * every op counts as finishing op of its dst level, with the counters in HBM and one atomic per row, not per op. */
+SB_HD uint32_t pl_lev_words(const PlanCtx &c) { return c.sh->nlev + 2u; }
+SB_HD uint16_t *pl_col_level(const PlanCtx &c) {
+  const uint32_t need = pl_r16(c.p.L * 2u) + pl_r16(pl_lev_words(c) * 16u); /* (the level-by-level W pass stages its tables here later) */
+  if (!c.aux_lds || need > c.aux_bytes) return nullptr;
+  return reinterpret_cast<uint16_t *>(c.aux_lds);
 }
-SB_HD uint32_t *pl_lev_cnt(const PlanCtx &c) { uint32_t *l = pl_lds_lev(c); return l ? l : c.lev_ops; }
-SB_HD uint32_t *pl_lev_fillp(const PlanCtx &c) { uint32_t *l = pl_lds_lev(c); return l ? l + (c.sh->nlev + 2u) : c.lev_fill; }
-
+SB_HD uint32_t *pl_lds_lev(const PlanCtx &c) {
+  if (!pl_col_level(c)) return nullptr;
+  return reinterpret_cast<uint32_t *>(c.aux_lds + c.aux_bytes - pl_r16(pl_lev_words(c) * 16u));
+}
+/* counters: [0] finishing counted (= lev_ops when in HBM), [1] early counted, [2] finishing placed (= lev_fill), [3] early placed */
+SB_HD uint32_t *pl_lev_ctr(const PlanCtx &c, uint32_t which) {
+  uint32_t *l = pl_lds_lev(c);
+  if (l) return l + which * pl_lev_words(c);
+  return which == 0 ? c.lev_ops : c.lev_fill; /* only 0 and 2 are used without LDS */
+}
+/* group of the op (dst row r on level t) <- (pivot column col): t itself for a finishing op */
+SB_HD uint32_t pl_op_group(const uint16_t *collev, uint32_t t, uint32_t r, uint32_t col) {
+  if (!collev) return t;
+  const uint32_t e = (uint32_t)collev[col] + 1u;
+  if (e >= t) return t;
+  uint32_t h = r * 0x9E3779B1u ^ col * 0x85EBCA6Bu;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+  return e + h % (t - e);
+}
 template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (tid == 0) {
@@ -590,36 +615,16 @@ template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  if (uint32_t *l = pl_lds_lev(c)) /* wpr / nlev are final now */
-    for (uint32_t k = tid; k < 2u * (sh->nlev + 2u); k += nt) l[k] = 0;
+  if (uint32_t *l = pl_lds_lev(c)) { /* nlev is final now */
+    for (uint32_t k = tid; k < 4u * pl_lev_words(c); k += nt) l[k] = 0;
+    uint16_t *collev = pl_col_level(c);
+    for (uint32_t k = tid; k < sh->npiv; k += nt) collev[c.pivcol[k]] = (uint16_t)(c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK);
+  }
   /* W rows are accumulated with XORs: start from zero */
   for (uint32_t e = tid; e < sh->M * sh->wpr; e += nt) c.wrows[e] = 0;
   for (uint32_t k = tid; k < sh->npiv; k += nt) c.pivdeg[k] = 0;
   for (uint32_t k = tid; k < sh->M; k += nt) c.lowdeg[k] = 0;
 }
-/* Own part of the bit row of constraint row r over the inactive columns (the entries of the row that sit in
- * inactive columns) plus the number of its pivot-column entries other than `own` = XOR ops the row needs.
- * 8 lanes cooperate, lane w8 owns words w8, w8+8, ...; `sub`/`stride` select a slice of the entries. */
-SB_HD void pl_scan_row(const PlanCtx &c, uint32_t r, uint32_t own, uint32_t w8, uint32_t sub, uint32_t stride,
-                       uint32_t (&acc)[5], uint32_t *deg) {
-#pragma unroll
-  for (int q = 0; q < 5; q++) acc[q] = 0;
-  const uint16_t *cols;
-  const uint32_t n = pl_row(c, r, &cols);
-  uint32_t d = 0;
-  for (uint32_t k = sub; k < n; k += stride) {
-    const uint32_t col = cols[k];
-    const uint32_t info = c.colinfo[col], st = info >> 30, idx = info & 0x3FFFFFFFu;
-    if (st == PL_ST_INACT) {
-      const uint32_t wd = idx >> 5;
-      if ((wd & 7u) == w8) acc[(wd >> 3) % 5u] ^= 1u << (idx & 31u);
-    } else if (col != own) {
-      d++;
-    }
-  }
-  *deg = d;
-}
-
 /* W starts as A restricted to the inactive columns, row by slot; op counts per row and per level group.
  * Ordinary rows: 8 lanes per row, sharing its entries.  The long LDPC rows (r < S): 64 lanes each (pl_w_init_b). */
 template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
@@ -627,7 +632,8 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (sh->status) return;
   const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr, S = c.p.S;
   const uint32_t total = sh->npiv + sh->nlow;
-  uint32_t *cnt = pl_lev_cnt(c);
+  uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lev_ctr(c, 1);
+  const uint16_t *collev = pl_col_level(c);
   /* item i < npiv: pivot i; otherwise leftover row i - npiv (group nlev).  Each step of a row is a dependent
    * trip to L2/HBM (slot -> patch -> row pointers -> entries), so a lane group works on RB rows at once, stage
    * by stage, to have their loads in flight together. */
@@ -665,43 +671,56 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
       if (!use[j]) continue;
       /* the 8 lanes share the row's entries; inactive ones toggle their bit in the (zeroed) W row, the others count */
       uint32_t *dst = c.wrows + (size_t)r[j] * wpr;
+      const uint32_t lev = piv[j] ? (c.rowinfo[r[j]] & PL_LEVEL_MASK) : sh->nlev;
       uint32_t deg = 0;
       for (uint32_t k = w8, t = 0; k < n[j]; k += 8u, t++) {
         const uint32_t col = t == 0 ? e0[j] : t == 1 ? e1[j] : (uint32_t)cols[j][k];
         const uint32_t info = c.colinfo[col], idx = info & 0x3FFFFFFFu;
         if ((info >> 30) == PL_ST_INACT) PL_ATOM_XOR(&dst[idx >> 5], 1u << (idx & 31u));
-        else if (col != own[j]) deg++;
+        else if (col != own[j]) {
+          if (collev) {
+            const uint32_t g = pl_op_group(collev, lev, r[j], col);
+            PL_ATOM_ADD(g == lev ? &cntF[g] : &cntN[g], 1u);
+          } else deg++;
+        }
       }
-      if (deg) {
-        if (piv[j]) { PL_ATOM_ADD(&c.pivdeg[ii[j]], deg); PL_ATOM_ADD(&cnt[c.rowinfo[r[j]] & PL_LEVEL_MASK], deg); }
-        else { PL_ATOM_ADD(&c.lowdeg[ii[j] - sh->npiv], deg); PL_ATOM_ADD(&cnt[sh->nlev], deg); }
+      if (deg) { /* no LDS counters: the row's ops as one run of its level group */
+        PL_ATOM_ADD(piv[j] ? &c.pivdeg[ii[j]] : &c.lowdeg[ii[j] - sh->npiv], deg);
+        PL_ATOM_ADD(&cntF[lev], deg);
       }
     }
   }
 }
-/* the long rows (slots [0,S)) listed by pl_w_init: 8 slices of 8 lanes each; the destination words were zeroed in
- * pl_lev_b */
+/* the long rows (slots [0,S)) listed by pl_w_init: 64 lanes each; the destination words were zeroed in pl_lev_b */
 template <int Z> SB_HD void pl_w_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
-  const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr;
-  const uint32_t nlong = sh->nq[0];
-  uint32_t *cnt = pl_lev_cnt(c);
-  for (uint32_t q = grp >> 3; q < nlong; q += ngrp >> 3) {
+  const uint32_t wpr = sh->wpr, lane = tid & 63u, nlong = sh->nq[0];
+  uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lev_ctr(c, 1);
+  const uint16_t *collev = pl_col_level(c);
+  for (uint32_t q = tid >> 6; q < nlong; q += nt >> 6) {
     const uint32_t i = sh->queue[0][q];
     const bool piv = i < sh->npiv;
-    const uint32_t r = piv ? c.pivslot[i] : c.lowslot[i - sh->npiv];
-    uint32_t acc[5], deg;
-    pl_scan_row(c, r, piv ? c.pivcol[i] : PL_NONE, w8, grp & 7u, 8u, acc, &deg);
+    const uint32_t r = piv ? c.pivslot[i] : c.lowslot[i - sh->npiv], own = piv ? c.pivcol[i] : PL_NONE;
+    const uint32_t lev = piv ? (c.rowinfo[r] & PL_LEVEL_MASK) : sh->nlev;
+    const uint16_t *cols;
+    const uint32_t n = pl_row(c, r, &cols);
     uint32_t *dst = c.wrows + (size_t)r * wpr;
-#pragma unroll
-    for (uint32_t q = 0; q < 5; q++) {
-      const uint32_t wd = w8 + 8u * q;
-      if (wd < wpr && acc[q]) PL_ATOM_XOR(&dst[wd], acc[q]);
+    uint32_t deg = 0;
+    for (uint32_t k = lane; k < n; k += 64u) {
+      const uint32_t col = cols[k];
+      const uint32_t info = c.colinfo[col], idx = info & 0x3FFFFFFFu;
+      if ((info >> 30) == PL_ST_INACT) PL_ATOM_XOR(&dst[idx >> 5], 1u << (idx & 31u));
+      else if (col != own) {
+        if (collev) {
+          const uint32_t g = pl_op_group(collev, lev, r, col);
+          PL_ATOM_ADD(g == lev ? &cntF[g] : &cntN[g], 1u);
+        } else deg++;
+      }
     }
-    if (w8 == 0 && deg) {
-      if (piv) { PL_ATOM_ADD(&c.pivdeg[i], deg); PL_ATOM_ADD(&cnt[c.rowinfo[r] & PL_LEVEL_MASK], deg); }
-      else { PL_ATOM_ADD(&c.lowdeg[i - sh->npiv], deg); PL_ATOM_ADD(&cnt[sh->nlev], deg); }
+    if (deg) {
+      PL_ATOM_ADD(piv ? &c.pivdeg[i] : &c.lowdeg[i - sh->npiv], deg);
+      PL_ATOM_ADD(&cntF[lev], deg);
     }
   }
 }
@@ -889,15 +908,20 @@ template <int Z> SB_HD void pl_low_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (tid != 0) return;
-  /* row base of every level group (levels 1..nlev-1 are pivot groups, index nlev = leftover rows); the stream
-   * starts with the NRQ_RING lead rows and every non-empty group is followed by NRQ_PIPE-1 spacer rows */
+  /* row base of every group (1..nlev-1: pivot levels, nlev: leftover rows); the stream starts with the NRQ_RING
+   * lead rows */
   uint32_t rows = NRQ_RING;
-  const uint32_t *cnt = pl_lev_cnt(c);
+  const uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lds_lev(c) ? pl_lev_ctr(c, 1) : nullptr;
   for (uint32_t l = 0; l <= sh->nlev; l++) {
-    const uint32_t n = cnt[l];
+    const uint32_t nf = cntF[l], n = nf + (cntN ? cntN[l] : 0u);
     c.lev_ops[l] = n;
+    c.lev_fin[l] = nf;
     c.lev_base[l] = rows;
-    if (n) rows += pl_group_rows(n) + (NRQ_PIPE - 1u);
+    if (l) { /* the finishing ops first; the last NRQ_PIPE-1 rows hold early ops only (or padding) -- also when the
+              * group is empty: early ops of the group before may complete rows that the group after reads */
+      const uint32_t need = pl_group_rows(nf) + (NRQ_PIPE - 1u), have = pl_group_rows(n);
+      rows += have > need ? have : need;
+    }
   }
   sh->spare_base = rows; /* rows reserved for constraint rows added later */
   rows += PL_SPARE_ROWS + (NRQ_PIPE - 1u);
@@ -929,36 +953,34 @@ SB_HD uint32_t pl_spread(uint32_t pos, uint32_t n) {
     if (n % mult[q]) m = mult[q];
   return (uint32_t)(((uint64_t)pos * m) % n);
 }
-SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t group, uint32_t start, uint32_t dst) {
-  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + c.sh->off_ops) + (size_t)c.lev_base[group] * NRQ_ROW;
-  const uint32_t n = c.lev_ops[group];
+/* the ops of constraint row r (dst; on level `lev`), each into its group (pl_op_group): finishing ops fill the
+ * group from the front, early ops follow them; the place inside either part is whatever the counter hands out,
+ * which also keeps the ops of one row apart */
+SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t lev, uint32_t deg) {
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + c.sh->off_ops);
+  uint32_t *fillF = pl_lev_ctr(c, 2), *fillN = pl_lds_lev(c) ? pl_lev_ctr(c, 3) : nullptr;
+  const uint16_t *collev = pl_col_level(c);
   const uint16_t *cols;
   const uint32_t m = pl_row(c, r, &cols);
-  uint32_t i = start;
+  /* without LDS counters: one run of `deg` places in the row's own group, shuffled (pl_spread) */
+  uint32_t run = collev ? 0u : PL_ATOM_ADD(&fillF[lev], deg);
   for (uint32_t k = 0; k < m; k++) {
     const uint32_t col = cols[k], info = c.colinfo[col];
     if ((info >> 30) != PL_ST_PIVOT || col == own) continue;
-    ops[pl_spread(i, n)] = NRQ_OP(dst, c.pivslot[info & 0x3FFFFFFFu]);
-    i++;
+    const uint32_t g = pl_op_group(collev, lev, r, col);
+    const uint32_t pos = !collev ? pl_spread(run++, c.lev_ops[lev])
+                         : g == lev ? PL_ATOM_ADD(&fillF[g], 1u) : c.lev_fin[g] + PL_ATOM_ADD(&fillN[g], 1u);
+    ops[(size_t)c.lev_base[g] * NRQ_ROW + pos] = NRQ_OP(r, c.pivslot[info & 0x3FFFFFFFu]);
   }
 }
 template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
-  uint32_t *fill = pl_lev_fillp(c);
   for (uint32_t k = tid; k < sh->npiv; k += nt) {
-    const uint32_t deg = c.pivdeg[k];
-    if (!deg) continue;
     const uint32_t r = c.pivslot[k], l = c.rowinfo[r] & PL_LEVEL_MASK;
-    const uint32_t start = PL_ATOM_ADD(&fill[l], deg);
-    pl_emit_row(c, r, c.pivcol[k], l, start, r);
+    if (l) pl_emit_row(c, r, c.pivcol[k], l, c.pivdeg[k]); /* level 0 rows have nothing to gather */
   }
-  for (uint32_t j = tid; j < sh->nlow; j += nt) {
-    const uint32_t deg = c.lowdeg[j];
-    if (!deg) continue;
-    const uint32_t start = PL_ATOM_ADD(&fill[sh->nlev], deg);
-    pl_emit_row(c, c.lowslot[j], PL_NONE, sh->nlev, start, c.lowslot[j]);
-  }
+  for (uint32_t j = tid; j < sh->nlow; j += nt) pl_emit_row(c, c.lowslot[j], PL_NONE, sh->nlev, c.lowdeg[j]);
 }
 
 /* =============================== phase 5: HDPC rows over the inactive columns ================= */

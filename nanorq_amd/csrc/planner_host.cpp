@@ -362,45 +362,53 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   uint32_t n_real_ops = 0;
   auto pad_rows = [&](uint32_t nrows_) { for (uint32_t k = 0; k < nrows_ * NRQ_ROW; k++) ops.push_back(NRQ_NOP_AT(ops.size())); };
   pad_rows(NRQ_RING); /* lead rows: the initial content of the kernel's op-word ring */
-  /* place one level group (plan.h): whole rows, then the NRQ_PIPE-1 rows nothing may depend on yet */
-  auto place_group = [&](const std::vector<uint32_t> &g) {
-    if (g.empty()) return;
-    n_real_ops += (uint32_t)g.size();
-    ops.insert(ops.end(), g.begin(), g.end());
+  /* place one group (plan.h): `fin` ops that complete rows other groups may read next, then `early` ops whose
+   * targets are read later; the last NRQ_PIPE-1 rows of a group hold no finishing op */
+  auto spread = [](std::vector<uint32_t> &v) { /* keep the ops of one row apart: a multiplicative shuffle */
+    const size_t n = v.size();
+    if (n < 128) return;
+    static const uint32_t mult[6] = {61u, 67u, 71u, 73u, 79u, 83u};
+    uint32_t m = 1;
+    for (int q = 5; q >= 0; q--)
+      if (n % mult[q]) m = mult[q];
+    std::vector<uint32_t> w(n);
+    for (size_t i = 0; i < n; i++) w[(i * m) % n] = v[i];
+    v.swap(w);
+  };
+  auto place_group = [&](std::vector<uint32_t> &fin, std::vector<uint32_t> &early) {
+    /* (an empty group still takes its NRQ_PIPE-1 rows: early ops in the group before it may complete rows that the
+     * group after it reads) */
+    spread(fin); spread(early);
+    n_real_ops += (uint32_t)(fin.size() + early.size());
+    const size_t r0 = ops.size() / NRQ_ROW;
+    ops.insert(ops.end(), fin.begin(), fin.end());
+    const size_t fin_rows = (fin.size() + NRQ_ROW - 1) / NRQ_ROW;
+    ops.insert(ops.end(), early.begin(), early.end());
     while (ops.size() % NRQ_ROW) ops.push_back(NRQ_NOP_AT(ops.size()));
-    pad_rows(NRQ_PIPE - 1u);
+    while (ops.size() / NRQ_ROW < r0 + fin_rows + (NRQ_PIPE - 1u)) pad_rows(1);
   };
   {
-    std::vector<uint32_t> lev_cnt(nlev + 1, 0);
-    for (uint32_t k = 0; k < npiv; k++) lev_cnt[level[pivslot[k]] + 1]++;
-    for (uint32_t l = 0; l < nlev; l++) lev_cnt[l + 1] += lev_cnt[l];
-    std::vector<uint32_t> by_level(npiv), fill(lev_cnt.begin(), lev_cnt.end() - 1);
-    for (uint32_t k = 0; k < npiv; k++) by_level[fill[level[pivslot[k]]]++] = k;
-    auto emit_group = [&](const uint32_t *rows, uint32_t nr, bool pivots) {
-      /* round-robin over the rows of the group so that neighbouring ops rarely share a target */
-      std::vector<uint32_t> g, cur(nr);
-      for (uint32_t q = 0; q < nr; q++) cur[q] = rptr[pivots ? pivslot[rows[q]] : lowslot[rows[q]]];
-      bool any = true;
-      while (any) {
-        any = false;
-        for (uint32_t q = 0; q < nr; q++) {
-          uint32_t r = pivots ? pivslot[rows[q]] : lowslot[rows[q]];
-          uint32_t own = pivots ? pivcol[rows[q]] : 0xFFFFFFFFu;
-          uint32_t &e = cur[q];
-          while (e < rptr[r + 1] && (cstate[cidx[e]] != PIVOT || cidx[e] == own)) e++;
-          if (e < rptr[r + 1]) {
-            g.push_back(NRQ_OP(r, owner[cidx[e]]));
-            e++; any = true;
-          }
+    /* group of an op dst <- src: the dst's level if src sits on the level right below (a "finishing" op), else any
+     * group of [level(src)+1, level(dst)-1], picked by a hash: such "early" ops fill lanes that narrow levels leave empty */
+    std::vector<std::vector<uint32_t>> fin(nlev + 1), early(nlev + 1);
+    auto add_row = [&](uint32_t r, uint32_t own, uint32_t t) {
+      for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++) {
+        const uint32_t col = cidx[e];
+        if (cstate[col] != PIVOT || col == own) continue;
+        const uint32_t src = owner[col], lo = level[src] + 1u;
+        uint32_t g = t;
+        if (lo < t) {
+          uint32_t h = r * 0x9E3779B1u ^ col * 0x85EBCA6Bu;
+          h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+          g = lo + h % (t - lo);
         }
+        (g == t ? fin[g] : early[g]).push_back(NRQ_OP(r, src));
       }
-      place_group(g);
     };
-    for (uint32_t l = 1; l < nlev; l++) /* level 0 rows have nothing to gather */
-      emit_group(&by_level[lev_cnt[l]], lev_cnt[l + 1] - lev_cnt[l], true);
-    std::vector<uint32_t> all_low(nlow);
-    for (uint32_t j = 0; j < nlow; j++) all_low[j] = j;
-    emit_group(all_low.data(), nlow, false);
+    for (uint32_t k = 0; k < npiv; k++)
+      if (level[pivslot[k]] > 0) add_row(pivslot[k], pivcol[k], level[pivslot[k]]); /* level 0 rows have nothing to gather */
+    for (uint32_t j = 0; j < nlow; j++) add_row(lowslot[j], 0xFFFFFFFFu, nlev);
+    for (uint32_t l = 1; l <= nlev; l++) place_group(fin[l], early[l]);
   }
 
   /* ---- HDPC rows over the inactive columns: Mh = G_U ^ G_left * W ---- */
@@ -462,7 +470,8 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
         }
       }
     }
-    place_group(g);
+    std::vector<uint32_t> none;
+    place_group(g, none);
   }
   const uint32_t op_rows = (uint32_t)(ops.size() / NRQ_ROW);
   pad_rows(NRQ_PAD_ROWS);

@@ -117,6 +117,38 @@ def test_emulated_forward_pass_is_sensitive_to_row_spacing(orc):
     assert r != 1 or not np.array_equal(inter, ref_inter)
 
 
+def _stream_hazards(plan):
+    """Rows are issued as: apply row q-P, read row q.  So a slot may be read only P or more rows after its last write,
+    and never written again once something read it (it must be final)."""
+    h = nanorq_amd.plan_header(plan)
+    ops = np.frombuffer(plan, dtype=np.uint32, offset=h["off_ops"], count=h["nrows"] * 64).reshape(-1, 64)
+    P = h["pipe"]
+    row = np.repeat(np.arange(len(ops)), 64)
+    flat = ops.ravel()
+    real = (flat & 0xFFFF) >= 64
+    dst, src, row = (flat[real] & 0xFFFF).astype(np.int64), (flat[real] >> 16).astype(np.int64), row[real]
+    n = int(max(dst.max(), src.max())) + 1
+    last_write = np.full(n, -10 ** 6)
+    np.maximum.at(last_write, dst, row)
+    first_read = np.full(n, 10 ** 6)
+    np.minimum.at(first_read, src, row)
+    return int((first_read - last_write < P).sum())  # slots whose first read comes less than P rows after their last write
+
+
+@pytest.mark.parametrize("K,p,oh", [(100, 0.3, 3), (1024, 0.05, 0), (1024, 0.2, 20), (8192, 0.1, 0)])
+def test_op_stream_respects_the_row_pipeline(orc, K, p, oh):
+    kc = nanorq_amd.host_kconst(K)
+    for seed in (1, 2, 3):
+        lost = loss_pattern(K, p, seed)
+        esis = received_set(K, lost, oh)
+        rep_esis = esis[esis >= K]
+        host = nanorq_amd.host_plan(K, decode_setup(orc, K, lost, rep_esis)[0], kc)
+        assert _stream_hazards(host) == 0
+        dev, hdr = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=(140 if seed != 2 else 48) * 1024)
+        if hdr["status"] == 0:
+            assert _stream_hazards(dev) == 0
+
+
 def test_lds_budget_of_headline_config(orc):
     """K=8192: the 16-byte strip image must fit the 160 KiB LDS of one gfx950 workgroup."""
     K = 8192
