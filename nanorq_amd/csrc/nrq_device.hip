@@ -41,92 +41,158 @@
  * Kernels
  * ========================================================================================== */
 
-/* Workgroup -> (block, strip).  Workgroup n is dispatched to XCD n%8 (observed; speed only).  The
- * strips that share one 128-byte line of every symbol row are given consecutive slots on ONE XCD so
- * that the line is fetched into (and write-combined in) a single L2.  With many blocks in the launch
- * (by_block) all strips of a block stay on one XCD, so that its plan -- every strip walks the whole op
- * stream -- is served by that XCD's L2 instead of being pulled into all eight. */
+/* Work: "line groups" -- the 128/WB strips of one block that share a 128-byte line of every symbol row.  Slot q
+ * of the work list -> (block, group); workgroup g takes the slots g, g + gridDim.x, ...  With many blocks in the
+ * launch (by_block) all groups of a block go to workgroups of one XCD (workgroup g runs on XCD g % 8, observed;
+ * speed only), so that the block's plan -- every strip walks the whole op stream -- is served by one L2. */
 static inline bool nrq_map_by_block(uint32_t nblk) { return nblk >= 64u || (nblk >= 8u && (nblk & 7u) == 0u); }
-__device__ __forceinline__ bool nrq_map_strip(uint32_t wb, uint32_t nblk, uint32_t nstrips, bool by_block, uint32_t *blk,
-                                              uint32_t *strip) {
-  const uint32_t n = blockIdx.x, xcd = n & 7u, m = n >> 3;
-  const uint32_t spl = 128u / wb;                       /* strips per 128-byte line */
-  const uint32_t gpb = (nstrips + spl - 1u) / spl;      /* line groups per block */
-  const uint32_t g = m / spl, sidx = m % spl;           /* g-th line group handled by this XCD */
+__device__ __forceinline__ bool nrq_map_group(uint32_t q, uint32_t nblk, uint32_t gpb, bool by_block, uint32_t *blk, uint32_t *grp) {
   if (by_block) {
-    *blk = (g / gpb) * 8u + xcd;
-    *strip = (g % gpb) * spl + sidx;
-    return *blk < nblk && *strip < nstrips;
+    const uint32_t m = q >> 3;
+    *blk = (m / gpb) * 8u + (q & 7u);
+    *grp = m % gpb;
+  } else {
+    *blk = q / gpb;
+    *grp = q % gpb;
   }
-  const uint32_t q = g * 8u + xcd;
-  if (q >= nblk * gpb) return false;
-  *blk = q / gpb;
-  *strip = (q % gpb) * spl + sidx;
-  return *strip < nstrips;
+  return *blk < nblk;
 }
 
+/* first slot >= q (stepping by gridDim.x) that holds a group of a solvable block; >= nslots if none */
+__device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, const nrq_job *__restrict__ jobs, uint32_t nblk,
+                                                   uint32_t gpb, bool by_block) {
+  for (; q < nslots; q += gridDim.x) {
+    uint32_t blk, grp;
+    if (!nrq_map_group(q, nblk, gpb, by_block, &blk, &grp)) continue;
+    const nrq_plan_hdr *h = reinterpret_cast<const nrq_plan_hdr *>(jobs[blk].plan);
+    if (h->status == 0) return q; /* rank deficient blocks: nothing is written for them */
+  }
+  return nslots;
+}
+
+/* The data stage: persistent workgroups, one line group at a time, its strips one after the other (solve_body.h:
+ * load -> forward passes -> HDPC -> dense stage -> back-substitution -> store).  While wave 0 runs the forward
+ * passes of a strip the other waves gather a portion of the NEXT line group into the staging buffers. */
 template <int WB>
 __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
-                                                           uint32_t T, uint32_t nstrips, uint32_t by_block,
-                                                           const uint8_t *__restrict__ kc,
-                                                           unsigned long long *__restrict__ prof) {
+                                                           uint32_t T, uint32_t nstrips, uint32_t by_block, uint32_t nslots,
+                                                           const uint8_t *__restrict__ kc, uint8_t *__restrict__ stage_all,
+                                                           uint32_t stage_stride, unsigned long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  /* NRQ_PROF=1 debugging aid: shader-clock stamps at phase boundaries of every 1024th workgroup */
-  unsigned long long *stamp = nullptr;
-  if (prof && (blockIdx.x & 1023u) == 0 && threadIdx.x == 0) stamp = prof + (size_t)(blockIdx.x >> 10) * 16;
-#define NRQ_STAMP(i) do { if (stamp) stamp[i] = (unsigned long long)clock64(); } while (0)
-  NRQ_STAMP(0);
-  uint32_t blk, strip;
-  if (!nrq_map_strip(WB, nblk, nstrips, by_block != 0u, &blk, &strip)) return;
-  StripCtx<WB> c;
-  c.job = jobs[blk];
-  c.plan = reinterpret_cast<const uint8_t *>(c.job.plan);
-  c.h = reinterpret_cast<const nrq_plan_hdr *>(c.plan);
-  if (c.h->status) return; /* rank deficient: nothing is written for this block */
-  c.kc = kc;
-  c.dbg = (prof && (blockIdx.x & 1023u) == 0) ? prof + (size_t)(blockIdx.x >> 10) * 16 + 9 : nullptr;
-  c.dbg_t0 = threadIdx.x == 0;
-  c.lds = smem;
-  c.lay = nrq_lds_plan(c.h, WB);
-  c.T = T;
-  c.strip = strip;
-  const uint32_t rem = T - strip * WB;
-  c.valid = rem < (uint32_t)WB ? rem : (uint32_t)WB;
   const uint32_t tid = threadIdx.x;
+#ifndef NRQ_GATHER_WAVES
+#define NRQ_GATHER_WAVES 3u
+#endif
+  constexpr uint32_t SPL = 128u / WB, NGW = NRQ_GATHER_WAVES; /* gathering waves */
+  const uint32_t gpb = (nstrips + SPL - 1u) / SPL;
+  /* two sets of SPL staging buffers (stage_stride bytes each): the group being solved, the group being gathered */
+  NRQ_GAS uint8_t *stage0 = gptr_w<uint8_t>((uint64_t)(uintptr_t)(stage_all + (size_t)blockIdx.x * 2u * SPL * stage_stride));
+  auto group_src = [&](uint32_t q, GroupSrc<WB> &g, uint32_t *blk_out) {
+    uint32_t blk, grp;
+    nrq_map_group(q, nblk, gpb, by_block != 0u, &blk, &grp);
+    const nrq_job *j = jobs + blk;
+    g.rowsrc = gptr<uint32_t>(j->rowsrc); g.src = gptr<uint8_t>(j->src); g.rep = gptr<uint8_t>(j->rep);
+    g.M = reinterpret_cast<const nrq_plan_hdr *>(j->plan)->M;
+    g.T = T; g.strip0 = grp * SPL; g.nstrips = nstrips;
+    *blk_out = blk;
+  };
+  uint32_t q = nrq_next_group(blockIdx.x, nslots, jobs, nblk, gpb, by_block != 0u);
+  if (q >= nslots) return;
+  uint32_t buf = 0, done = 0;
+  {
+    GroupSrc<WB> g0;
+    uint32_t b0;
+    group_src(q, g0, &b0);
+    pf_gather<WB>(g0, stage0, stage_stride, 0u, g0.M * SPL, tid, NRQ_WG); /* the first group: nothing to overlap it with */
+    __syncthreads();
+  }
+  while (q < nslots) {
+    const uint32_t qn = nrq_next_group(q + gridDim.x, nslots, jobs, nblk, gpb, by_block != 0u);
+    GroupSrc<WB> gn;
+    uint32_t blk, blkn = 0, units_n = 0;
+    if (qn < nslots) { group_src(qn, gn, &blkn); units_n = gn.M * SPL; }
+    {
+      GroupSrc<WB> gc;
+      group_src(q, gc, &blk);
+    }
+    NRQ_GAS uint8_t *stage_cur = stage0 + (size_t)buf * SPL * stage_stride, *stage_nxt = stage0 + (size_t)(buf ^ 1u) * SPL * stage_stride;
+    const uint32_t strip0 = ((by_block ? (q >> 3) : q) % gpb) * SPL;
+    for (uint32_t sidx = 0; sidx < SPL; sidx++) {
+      const uint32_t u0 = (uint32_t)((uint64_t)units_n * sidx / SPL), u1 = (uint32_t)((uint64_t)units_n * (sidx + 1u) / SPL);
+      const uint32_t strip = strip0 + sidx;
+      if (strip >= nstrips) { /* no such strip: everybody gathers this portion */
+        if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid, NRQ_WG);
+        continue;
+      }
+      StripCtx<WB> c;
+      c.job = jobs[blk];
+      c.plan = reinterpret_cast<const uint8_t *>(c.job.plan);
+      c.h = reinterpret_cast<const nrq_plan_hdr *>(c.plan);
+      c.kc = kc;
+      c.lds = smem;
+      c.lay = nrq_lds_plan(c.h, WB);
+      c.T = T;
+      c.strip = strip;
+      const uint32_t rem = T - strip * WB;
+      c.valid = rem < (uint32_t)WB ? rem : (uint32_t)WB;
+      /* NRQ_PROF=1 debugging aid: shader-clock stamps at phase boundaries, the 10th strip of every 16th workgroup */
+      unsigned long long *stamp = nullptr;
+      const bool sampled = prof && (blockIdx.x & 15u) == 0 && done == 9u;
+      if (sampled && tid == 0) stamp = prof + (size_t)(blockIdx.x >> 4) * 16;
+#define NRQ_STAMP(i) do { if (stamp) stamp[i] = (unsigned long long)clock64(); } while (0)
+      c.dbg = sampled ? prof + (size_t)(blockIdx.x >> 4) * 16 + 9 : nullptr;
+      c.dbg_t0 = tid == 0;
+      done++;
+      NRQ_STAMP(0);
+      pf_commit<WB>(c, stage_cur + (size_t)sidx * stage_stride, tid, NRQ_WG);
+      ph_clear<WB>(c, tid, NRQ_WG);
+      __syncthreads();
+      NRQ_STAMP(1);
 
-  ph_load<WB>(c, tid, NRQ_WG);
-  __syncthreads();
-  NRQ_STAMP(1);
+      /* forward passes (plan.h): wave 0 walks the op stream alone (fwd_rows); the other waves gather */
+      if (tid < NRQ_ROW) {
+        __builtin_amdgcn_s_setprio(3); /* the critical wave: ahead of the gathering waves at instruction issue */
+        fwd_rows<WB>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
+        __builtin_amdgcn_s_setprio(0);
+        NRQ_MARK(c, 1);
+      } else if (u1 > u0 && (tid >> 6) <= NGW) {
+        /* a few waves gather (waves 1..NGW: none of them shares wave 0's SIMD): the forward passes leave them plenty of
+         * time, and a deep queue of gather requests would delay wave 0's op words */
+        pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid - NRQ_ROW, NGW * 64u);
+        NRQ_MARK_MAX(c, 2);
+      }
+      __syncthreads();
+      NRQ_STAMP(2);
 
-  /* forward passes (plan.h): wave 0 walks the op stream alone (fwd_rows), the other waves wait at the barrier below */
-  if (tid < NRQ_ROW) fwd_rows<WB>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
-  __syncthreads();
-  NRQ_STAMP(2);
-
-  ph_hdpc<WB>(c, tid, NRQ_WG);
-  __syncthreads();
-  ph_hdpc_reduce<WB>(c, tid, NRQ_WG);
-  __syncthreads();
-  NRQ_STAMP(3);
-  NRQ_STAMP(4);
-  ph_dense_fold<WB>(c, tid, NRQ_WG);
-  __syncthreads();
-  ph_dense_free<WB>(c, tid, NRQ_WG);
-  __syncthreads();
-  ph_dense_cu<WB>(c, tid, NRQ_WG);
-  __syncthreads();
-  NRQ_STAMP(5);
-  ph_tables<WB>(c, tid, NRQ_WG);
-  __syncthreads();
-  NRQ_STAMP(6);
-  ph_backsub<WB>(c, tid, NRQ_WG);
-  ph_park<WB>(c, tid, NRQ_WG);
-  __syncthreads();
-  NRQ_STAMP(7);
-  ph_store<WB>(c, tid, NRQ_WG);
-  __syncthreads();
-  NRQ_STAMP(8);
+      ph_hdpc<WB>(c, tid, NRQ_WG);
+      __syncthreads();
+      ph_hdpc_reduce<WB>(c, tid, NRQ_WG);
+      __syncthreads();
+      NRQ_STAMP(3);
+      NRQ_STAMP(4);
+      ph_dense_fold<WB>(c, tid, NRQ_WG);
+      __syncthreads();
+      ph_dense_free<WB>(c, tid, NRQ_WG);
+      __syncthreads();
+      ph_dense_cu<WB>(c, tid, NRQ_WG);
+      __syncthreads();
+      NRQ_STAMP(5);
+      ph_tables<WB>(c, tid, NRQ_WG);
+      __syncthreads();
+      NRQ_STAMP(6);
+      ph_backsub<WB>(c, tid, NRQ_WG);
+      ph_park<WB>(c, tid, NRQ_WG);
+      __syncthreads();
+      NRQ_STAMP(7);
+      ph_store<WB>(c, tid, NRQ_WG);
+      __syncthreads();
+      NRQ_STAMP(8);
 #undef NRQ_STAMP
+    }
+    __syncthreads(); /* the gathered group is complete (and, for what a strip-less portion wrote, visible) */
+    q = qn;
+    buf ^= 1u;
+  }
 }
 
 enum {
@@ -301,6 +367,7 @@ inline size_t r16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 struct nrq_ctx {
   int device = 0;
+  int ncu = 256; /* compute units of the device */
   hipStream_t stream = nullptr;
   std::string err;
   std::map<uint32_t, KConst> kconst;    /* by K' */
@@ -323,6 +390,7 @@ struct nrq_ctx {
   /* device planner */
   int planner = 1; /* 1 = device planner for decode (default), 0 = host planner */
   DevBuf plan_work, plan_arena, plan_jobs;
+  DevBuf stage; /* solve kernel: staging buffers of the persistent workgroups */
   bool plan_attr = false;
 };
 
@@ -462,13 +530,24 @@ void build_out_lists(const rq_params &p, const uint16_t *colslot, uint32_t n, co
 }
 
 template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, uint32_t nblk, uint32_t T,
-                                const uint8_t *d_kc, uint32_t lds_bytes) {
+                                const uint8_t *d_kc, uint32_t lds_bytes, uint32_t max_slots) {
   const uint32_t nstrips = (T + WB - 1) / WB, spl = 128u / WB;
   const uint32_t gpb = (nstrips + spl - 1) / spl;
   const bool by_block = nrq_map_by_block(nblk) && !getenv("NRQ_MAP_SPREAD");
-  const uint64_t groups = by_block ? (uint64_t)((nblk + 7u) / 8u) * 8u * gpb : (uint64_t)nblk * gpb;
-  const uint64_t grid = ((groups + 7) / 8) * 8 * spl;
-  if (grid > 0x7FFFFFFFull) return fail(ctx, -4, "grid too large");
+  /* slots of the work list (nrq_map_group): line groups of the blocks, incl. the empty slots of a partial block octet */
+  const uint64_t nslots = by_block ? (uint64_t)((nblk + 7u) / 8u) * 8u * gpb : (uint64_t)nblk * gpb;
+  if (nslots > 0x7FFFFFFFull) return fail(ctx, -4, "grid too large");
+  /* persistent workgroups, one per CU (the LDS image owns the CU); a multiple of 8 keeps a workgroup's slots on its XCD */
+  uint64_t grid = (uint64_t)(ctx->ncu / 8) * 8;
+  if (const char *e = getenv("NRQ_SOLVE_GRID")) grid = (uint64_t)atoll(e) / 8 * 8;
+  if (grid < 8) grid = 8;
+  if (grid > nslots) grid = by_block ? (nslots + 7) / 8 * 8 : nslots;
+  /* per workgroup: two sets of `spl` staging buffers (the line group being solved, the one being gathered) */
+  const uint32_t stage_stride = (max_slots * WB + 255u) & ~255u;
+  {
+    int rc_ = ensure_dev(ctx, ctx->stage, (size_t)grid * 2u * spl * stage_stride);
+    if (rc_) return rc_;
+  }
   if (!ctx->attr_set[slot]) {
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
@@ -487,14 +566,14 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     ctx->ktime_used++;
     HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
   }
-  const uint32_t nprof = (uint32_t)((grid + 1023) / 1024);
+  const uint32_t nprof = (uint32_t)((grid + 15) / 16);
   if (getenv("NRQ_PROF")) {
     if (ctx->prof) { (void)hipFree(ctx->prof); ctx->prof = nullptr; }
     HIPCHK(ctx, hipMalloc((void **)&ctx->prof, (size_t)nprof * 16 * 8));
     HIPCHK(ctx, hipMemsetAsync(ctx->prof, 0, (size_t)nprof * 16 * 8, ctx->stream));
   }
   hipLaunchKernelGGL(nrq_solve_kernel<WB>, dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T,
-                     nstrips, by_block ? 1u : 0u, d_kc, ctx->prof);
+                     nstrips, by_block ? 1u : 0u, (uint32_t)nslots, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ctx->prof);
   HIPCHK(ctx, hipGetLastError());
   if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
   if (ctx->prof) {
@@ -538,6 +617,9 @@ int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs,
                     uint32_t T, const uint8_t *d_kc) {
   static const uint32_t widths[4] = {16, 8, 4, 2};
   const char *maxw = getenv("NRQ_MAX_WB"); /* tuning: widest strip to consider */
+  uint32_t max_slots = 0;
+  for (const nrq_plan_hdr *h : hdrs)
+    if (!h->status && h->M > max_slots) max_slots = h->M;
   for (int s = 0; s < 4; s++) {
     if (maxw && widths[s] > (uint32_t)atoi(maxw)) continue;
     uint32_t need = 0;
@@ -549,10 +631,10 @@ int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs,
     if (need == 0) return 0; /* nothing solvable in this batch */
     if (need > NRQ_LDS_MAX) continue;
     switch (widths[s]) {
-      case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need);
-      case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need);
-      case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need);
-      default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need);
+      case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need, max_slots);
+      case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need, max_slots);
+      case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need, max_slots);
+      default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need, max_slots);
     }
   }
   return fail(ctx, -5, "block too large for the LDS-resident solver");
@@ -583,6 +665,10 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
   nrq_ctx *ctx = new nrq_ctx();
   ctx->device = device;
   ctx->stream = (hipStream_t)stream;
+  {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ctx->ncu = n;
+  }
   if (getenv("NRQ_HOST_PLANNER")) ctx->planner = 0;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess ||
@@ -623,6 +709,7 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
   if (ctx->plan_work.p) (void)hipFree(ctx->plan_work.p);
   if (ctx->plan_arena.p) (void)hipFree(ctx->plan_arena.p);
   if (ctx->plan_jobs.p) (void)hipFree(ctx->plan_jobs.p);
+  if (ctx->stage.p) (void)hipFree(ctx->stage.p);
   for (int i = 0; i < 2; i++) {
     if (ctx->scratch[i].p) (void)hipFree(ctx->scratch[i].p);
     if (ctx->staging[i].p) (void)hipHostFree(ctx->staging[i].p);

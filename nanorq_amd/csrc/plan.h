@@ -32,7 +32,11 @@
 #define NRQ_PIPE 2u                /* rows between the read of a row's sources and its application (measured on
                                     * MI355X: 2 beats 3 and 4 -- a row costs ~63 clocks of issue either way, spacer rows included) */
 #endif
-#define NRQ_RING (12u * (NRQ_PIPE + 1u)) /* rows whose op words the kernel holds in registers (fetched that far ahead);
+#ifndef NRQ_RING_MULT
+#define NRQ_RING_MULT 20u
+#endif
+#define NRQ_RING (NRQ_RING_MULT * (NRQ_PIPE + 1u)) /* rows whose op words the kernel holds in registers (fetched that far ahead:
+                                    * 36 rows starve the pipeline when the L2 is busy streaming symbols, 60 and 84 measure the same);
                                     * the stream starts with NRQ_RING all-NOP rows (the ring's initial content) */
 #define NRQ_PAD_ROWS (2u * NRQ_RING + NRQ_PIPE) /* all-NOP rows after the stream: op words are fetched ahead unconditionally */
 /* Op word: dst | src << 16, both as slot + NRQ_SCRATCH.  The first NRQ_SCRATCH slots of the LDS image are

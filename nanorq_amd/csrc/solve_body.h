@@ -65,6 +65,11 @@ typedef struct nrq_job {
 } nrq_job;
 
 #if defined(__HIP_DEVICE_COMPILE__)
+#define NRQ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define NRQ_SCHED_FENCE() do { } while (0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 #define NRQ_MARK(c, i) do { if ((c).dbg && (c).dbg_t0) (c).dbg[i] = (unsigned long long)clock64(); } while (0)
 #define NRQ_MARK_MAX(c, i) do { if ((c).dbg) atomicMax(&(c).dbg[i], (unsigned long long)clock64()); } while (0)
 #else
@@ -192,6 +197,29 @@ template <int WB> SB_HD SV<WB> g_get(const NRQ_GAS uint8_t *p, uint32_t valid) {
   }
   return r;
 }
+/* an aligned, full-width strip element straight from L2 (staging data written earlier by this workgroup: never an
+ * older copy out of the CU's vector L1) */
+template <int WB> SB_HD SV<WB> g_get_l2(const NRQ_GAS uint8_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  SV<WB> r = sv_zero<WB>();
+  if constexpr (WB == 16) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u4 *>(p));
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  } else if constexpr (WB == 8) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const u2 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u2 *>(p));
+    r.w[0] = v.x; r.w[1] = v.y;
+  } else if constexpr (WB == 4) {
+    r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS uint32_t *>(p));
+  } else {
+    r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS uint16_t *>(p));
+  }
+  return r;
+#else
+  return g_get<WB>(p, WB);
+#endif
+}
 template <int WB> SB_HD void g_put(NRQ_GAS uint8_t *p, uint32_t valid, const SV<WB> &v) {
   if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
     if constexpr (WB == 16) {
@@ -208,6 +236,52 @@ template <int WB> SB_HD void g_put(NRQ_GAS uint8_t *p, uint32_t valid, const SV<
   } else {
     for (uint32_t k = 0; k < valid; k++) p[k] = (uint8_t)(v.w[k >> 2] >> ((k & 3u) * 8u));
   }
+}
+
+/* Streaming accesses (symbol rows read once, staging buffers, results written once): marked non-temporal so that
+ * they do not push the plans -- read over and over by every strip of a block -- out of L2. */
+template <int WB> SB_HD SV<WB> g_get_stream(const NRQ_GAS uint8_t *p, uint32_t valid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
+    SV<WB> r = sv_zero<WB>();
+    if constexpr (WB == 16) {
+      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+      const u4 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u4 *>(p));
+      r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    } else if constexpr (WB == 8) {
+      typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+      const u2 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u2 *>(p));
+      r.w[0] = v.x; r.w[1] = v.y;
+    } else if constexpr (WB == 4) {
+      r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS uint32_t *>(p));
+    } else {
+      r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS uint16_t *>(p));
+    }
+    return r;
+  }
+#endif
+  return g_get<WB>(p, valid);
+}
+template <int WB> SB_HD void g_put_stream(NRQ_GAS uint8_t *p, uint32_t valid, const SV<WB> &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
+    if constexpr (WB == 16) {
+      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+      const u4 t = {v.w[0], v.w[1], v.w[2], v.w[3]};
+      __builtin_nontemporal_store(t, reinterpret_cast<NRQ_GAS u4 *>(p));
+    } else if constexpr (WB == 8) {
+      typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+      const u2 t = {v.w[0], v.w[1]};
+      __builtin_nontemporal_store(t, reinterpret_cast<NRQ_GAS u2 *>(p));
+    } else if constexpr (WB == 4) {
+      __builtin_nontemporal_store(v.w[0], reinterpret_cast<NRQ_GAS uint32_t *>(p));
+    } else {
+      __builtin_nontemporal_store((uint16_t)v.w[0], reinterpret_cast<NRQ_GAS uint16_t *>(p));
+    }
+    return;
+  }
+#endif
+  g_put<WB>(p, valid, v);
 }
 
 /* ---- LDS carve-up, identical on host (launch sizing) and device ---- */
@@ -250,37 +324,74 @@ template <int WB> struct StripCtx {
   template <class X> SB_MEM const NRQ_GAS X *arr(uint32_t off) const { return gptr<X>(plan + off); }
 };
 
-/* phase 0: bring the strip of every slot into LDS (loads are issued LDB at a time so that their
- * HBM/L2 latencies overlap); clear the scratch rows and the free-column accumulators */
-template <int WB> SB_HD void ph_load(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  constexpr int LDB = 16;
-  const NRQ_GAS uint32_t *rowsrc = gptr<uint32_t>(c.job.rowsrc);
-  const NRQ_GAS uint8_t *src = gptr<uint8_t>(c.job.src);
-  const NRQ_GAS uint8_t *rep = gptr<uint8_t>(c.job.rep);
-  const size_t boff = (size_t)c.strip * WB;
-  const uint32_t M = c.h->M;
-  for (uint32_t base = tid; base < M; base += LDB * nt) {
-    uint32_t s[LDB];
-    SV<WB> v[LDB];
+/* phase 0: bring the strip of every slot into LDS; clear the scratch rows and region X.
+ * A strip is WB bytes out of every symbol row: fetched on its own, every 16-byte piece costs a whole 128-byte
+ * line of HBM/L2 traffic (measured: ~26 such requests per clock for the whole chip, i.e. HBM-bound at one line
+ * per piece).  So the persistent solve kernel works on LINE GROUPS -- the 128/WB strips that share a line of
+ * every row: while it solves the strips of one group one after the other, the waves that are idle during the
+ * forward passes gather the next group, whole lines at a time, into per-strip staging buffers (global memory,
+ * strip-major, contiguous), from where a strip image is filled by coalesced loads.
+ *   pf_gather    units [u0, u1) of the gather, unit = (row, piece of the line); thread p of np;
+ *   pf_commit    staging buffer -> LDS image;
+ *   ph_clear     the scratch rows E_p, the per-lane scratch slots and region X. */
+template <int WB> struct GroupSrc { /* where the rows of one line group of one block come from */
+  const NRQ_GAS uint32_t *rowsrc;
+  const NRQ_GAS uint8_t *src, *rep;
+  uint32_t M, T, strip0, nstrips; /* first strip of the group; strips of the block */
+};
+template <int WB> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
+                                       uint32_t p, uint32_t np) {
+  constexpr uint32_t SPL = 128u / WB; /* pieces (strips) per line */
+#ifndef NRQ_GATHER_PB
+#define NRQ_GATHER_PB 4
+#endif
+  constexpr int PB = NRQ_GATHER_PB; /* requests in flight per thread: few -- a deep queue of gather requests in the CU's
+                                     * memory pipeline delays the op words wave 0 is waiting for */
+  for (uint32_t base = u0 + p; base < u1; base += PB * np) {
+    uint32_t s[PB];
+    SV<WB> v[PB];
 #pragma unroll
-    for (int q = 0; q < LDB; q++) {
-      uint32_t r = base + (uint32_t)q * nt;
-      s[q] = r < M ? rowsrc[r] : NRQ_ROW_ZERO;
+    for (int q = 0; q < PB; q++) {
+      const uint32_t u = base + (uint32_t)q * np;
+      s[q] = u < u1 ? g.rowsrc[u / SPL] : NRQ_ROW_ZERO;
     }
 #pragma unroll
-    for (int q = 0; q < LDB; q++) {
+    for (int q = 0; q < PB; q++) {
+      const uint32_t u = base + (uint32_t)q * np, strip = g.strip0 + u % SPL;
       v[q] = sv_zero<WB>();
-      if (s[q] != NRQ_ROW_ZERO) {
-        const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? rep + (size_t)(s[q] & 0x7FFFFFFFu) * c.T : src + (size_t)s[q] * c.T;
-        v[q] = g_get<WB>(b + boff, c.valid);
+      if (s[q] != NRQ_ROW_ZERO && strip < g.nstrips) {
+        const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? g.rep + (size_t)(s[q] & 0x7FFFFFFFu) * g.T : g.src + (size_t)s[q] * g.T;
+        const uint32_t rem = g.T - strip * WB;
+        v[q] = g_get_stream<WB>(b + (size_t)strip * WB, rem < (uint32_t)WB ? rem : (uint32_t)WB);
       }
     }
 #pragma unroll
-    for (int q = 0; q < LDB; q++) {
-      uint32_t r = base + (uint32_t)q * nt;
+    for (int q = 0; q < PB; q++) {
+      const uint32_t u = base + (uint32_t)q * np;
+      if (u < u1) g_put_stream<WB>(stage + (size_t)(u % SPL) * stage_stride + (size_t)(u / SPL) * WB, WB, v[q]);
+    }
+  }
+}
+template <int WB> SB_HD void pf_commit(const StripCtx<WB> &c, const NRQ_GAS uint8_t *stage, uint32_t tid, uint32_t nt) {
+  constexpr int PB = 4;
+  const uint32_t M = c.h->M;
+  for (uint32_t base = tid; base < M; base += PB * nt) {
+    SV<WB> v[PB];
+#pragma unroll
+    for (int q = 0; q < PB; q++) {
+      const uint32_t r = base + (uint32_t)q * nt;
+      v[q] = r < M ? g_get_l2<WB>(stage + (size_t)r * WB) : sv_zero<WB>();
+    }
+#pragma unroll
+    for (int q = 0; q < PB; q++) {
+      const uint32_t r = base + (uint32_t)q * nt;
       if (r < M) lds_put<WB>(c.slots(), r, v[q]);
     }
   }
+}
+template <int WB> SB_HD void ph_clear(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+  const uint32_t M = c.h->M;
+  for (uint32_t p = tid; p < NRQ_SCRATCH; p += nt) lds_put<WB>(c.lds, p, sv_zero<WB>());
   for (uint32_t p = tid; p < c.h->r2; p += nt) lds_put<WB>(c.slots(), M + p, sv_zero<WB>());
   /* region X starts as the private HDPC accumulators (ph_hdpc), which ph_hdpc_reduce leaves zeroed for Cf */
   const uint32_t nx = (c.lay.total - c.lay.off_x) / WB;
@@ -544,6 +655,7 @@ SB_HD void backsub_one(const StripCtx<WB> &c, const uint8_t *t4, uint32_t slot, 
       SV<WB> t = lds_get<WB>(t4, (w * 8u + q) * 16u + nib);
       sv_xor<WB>(acc, t);
     }
+    NRQ_SCHED_FENCE(); /* 8 lookups in flight are enough; hoisting all NW*8 of them costs ~100 more registers */
   }
   lds_put<WB>(c.slots(), slot, acc);
 }

@@ -54,7 +54,20 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
   uint32_t rem = T - strip * WB;
   c.valid = rem < (uint32_t)WB ? rem : (uint32_t)WB;
 #define PHASE(fn) for (uint32_t t = 0; t < NT; t++) fn<WB>(c, t, NT)
-  PHASE(ph_load);
+  { /* the way the persistent kernel fills the image: the gathering threads bring the whole line group of this
+     * strip into the per-strip staging buffers, then all threads copy this strip's buffer into the image */
+    constexpr uint32_t SPL = 128u / WB;
+    const size_t stride = ((size_t)c.h->M * WB + 255u) & ~(size_t)255u;
+    std::vector<uint8_t> stage(stride * SPL + 64, 0x5A);
+    GroupSrc<WB> g;
+    g.rowsrc = gptr<uint32_t>(c.job.rowsrc); g.src = gptr<uint8_t>(c.job.src); g.rep = gptr<uint8_t>(c.job.rep);
+    g.M = c.h->M; g.T = T; g.strip0 = (strip / SPL) * SPL; g.nstrips = (T + WB - 1) / WB;
+    const uint32_t np = NT - NRQ_ROW, units = g.M * SPL, half = units / 2;
+    for (uint32_t p = 0; p < np; p++) pf_gather<WB>(g, stage.data(), stride, 0, half, p, np);   /* in two portions, */
+    for (uint32_t p = 0; p < np; p++) pf_gather<WB>(g, stage.data(), stride, half, units, p, np); /* as the kernel does */
+    for (uint32_t t = 0; t < NT; t++) pf_commit<WB>(c, stage.data() + (size_t)(strip % SPL) * stride, t, NT);
+    PHASE(ph_clear);
+  }
   if (!emu_forward<WB>(c)) return -7;
   PHASE(ph_hdpc);
   PHASE(ph_hdpc_reduce);
