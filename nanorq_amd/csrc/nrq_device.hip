@@ -72,21 +72,30 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
 
 /* The data stage: persistent workgroups, one line group at a time, its strips one after the other (solve_body.h:
  * load -> forward passes -> HDPC -> dense stage -> back-substitution -> store).  While wave 0 runs the forward
- * passes of a strip the other waves gather a portion of the NEXT line group into the staging buffers. */
+ * passes of a strip, a few of the other waves gather a portion of the NEXT line group into the input staging
+ * buffers and scatter a portion of the PREVIOUS group's results from the output staging buffers to their rows. */
+#ifndef NRQ_GATHER_WAVES
+#define NRQ_GATHER_WAVES 3u
+#endif
+#ifndef NRQ_SCATTER_WAVES
+#define NRQ_SCATTER_WAVES 4u
+#endif
 template <int WB>
 __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
                                                            uint32_t T, uint32_t nstrips, uint32_t by_block, uint32_t nslots,
                                                            const uint8_t *__restrict__ kc, uint8_t *__restrict__ stage_all,
-                                                           uint32_t stage_stride, unsigned long long *__restrict__ prof) {
+                                                           uint32_t stage_stride, uint32_t ostage_stride,
+                                                           unsigned long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t tid = threadIdx.x;
-#ifndef NRQ_GATHER_WAVES
-#define NRQ_GATHER_WAVES 3u
-#endif
-  constexpr uint32_t SPL = 128u / WB, NGW = NRQ_GATHER_WAVES; /* gathering waves */
+  constexpr uint32_t SPL = 128u / WB, NGW = NRQ_GATHER_WAVES, NSW = NRQ_SCATTER_WAVES; /* gathering / scattering waves */
+  static_assert((NRQ_WG / 64u) - (NRQ_WG / 64u + 3u) / 4u >= NRQ_GATHER_WAVES + NRQ_SCATTER_WAVES, "workgroup too small for the data movers");
   const uint32_t gpb = (nstrips + SPL - 1u) / SPL;
-  /* two sets of SPL staging buffers (stage_stride bytes each): the group being solved, the group being gathered */
-  NRQ_GAS uint8_t *stage0 = gptr_w<uint8_t>((uint64_t)(uintptr_t)(stage_all + (size_t)blockIdx.x * 2u * SPL * stage_stride));
+  /* per workgroup: two sets of SPL input staging buffers (the group being solved, the group being gathered) and two
+   * sets of SPL output staging buffers (the group being solved, the group being scattered) */
+  const size_t wg_bytes = 2u * SPL * ((size_t)stage_stride + ostage_stride);
+  NRQ_GAS uint8_t *stage0 = gptr_w<uint8_t>((uint64_t)(uintptr_t)(stage_all + (size_t)blockIdx.x * wg_bytes));
+  NRQ_GAS uint8_t *ostage0 = stage0 + 2u * SPL * (size_t)stage_stride;
   auto group_src = [&](uint32_t q, GroupSrc<WB> &g, uint32_t *blk_out) {
     uint32_t blk, grp;
     nrq_map_group(q, nblk, gpb, by_block != 0u, &blk, &grp);
@@ -96,9 +105,18 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
     g.T = T; g.strip0 = grp * SPL; g.nstrips = nstrips;
     *blk_out = blk;
   };
+  auto group_dst = [&](uint32_t q, GroupDst<WB> &g) -> uint32_t { /* returns the staged elements per strip */
+    uint32_t blk, grp;
+    nrq_map_group(q, nblk, gpb, by_block != 0u, &blk, &grp);
+    const nrq_job *j = jobs + blk;
+    g.inter = gptr_w<uint8_t>(j->inter); g.out = gptr_w<uint8_t>(j->out); g.orow = gptr<uint32_t>(j->out_row);
+    g.ni = j->inter ? reinterpret_cast<const nrq_plan_hdr *>(j->plan)->L : 0u;
+    g.nout = j->nout; g.T = T; g.strip0 = grp * SPL; g.nstrips = nstrips;
+    return g.ni + g.nout;
+  };
   uint32_t q = nrq_next_group(blockIdx.x, nslots, jobs, nblk, gpb, by_block != 0u);
   if (q >= nslots) return;
-  uint32_t buf = 0, done = 0;
+  uint32_t buf = 0, done = 0, qp = nslots; /* qp: the group whose results wait in the other output set */
   {
     GroupSrc<WB> g0;
     uint32_t b0;
@@ -109,19 +127,24 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
   while (q < nslots) {
     const uint32_t qn = nrq_next_group(q + gridDim.x, nslots, jobs, nblk, gpb, by_block != 0u);
     GroupSrc<WB> gn;
-    uint32_t blk, blkn = 0, units_n = 0;
+    GroupDst<WB> gp;
+    uint32_t blk, blkn = 0, units_n = 0, units_p = 0;
     if (qn < nslots) { group_src(qn, gn, &blkn); units_n = gn.M * SPL; }
+    if (qp < nslots) units_p = group_dst(qp, gp) * SPL;
     {
       GroupSrc<WB> gc;
       group_src(q, gc, &blk);
     }
     NRQ_GAS uint8_t *stage_cur = stage0 + (size_t)buf * SPL * stage_stride, *stage_nxt = stage0 + (size_t)(buf ^ 1u) * SPL * stage_stride;
+    NRQ_GAS uint8_t *ostage_cur = ostage0 + (size_t)buf * SPL * ostage_stride, *ostage_prv = ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride;
     const uint32_t strip0 = ((by_block ? (q >> 3) : q) % gpb) * SPL;
     for (uint32_t sidx = 0; sidx < SPL; sidx++) {
       const uint32_t u0 = (uint32_t)((uint64_t)units_n * sidx / SPL), u1 = (uint32_t)((uint64_t)units_n * (sidx + 1u) / SPL);
+      const uint32_t s0 = (uint32_t)((uint64_t)units_p * sidx / SPL), s1 = (uint32_t)((uint64_t)units_p * (sidx + 1u) / SPL);
       const uint32_t strip = strip0 + sidx;
-      if (strip >= nstrips) { /* no such strip: everybody gathers this portion */
+      if (strip >= nstrips) { /* no such strip: everybody moves this portion */
         if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid, NRQ_WG);
+        if (s1 > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, s1, tid, NRQ_WG);
         continue;
       }
       StripCtx<WB> c;
@@ -149,17 +172,24 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
       __syncthreads();
       NRQ_STAMP(1);
 
-      /* forward passes (plan.h): wave 0 walks the op stream alone (fwd_rows); the other waves gather */
-      if (tid < NRQ_ROW) {
-        __builtin_amdgcn_s_setprio(3); /* the critical wave: ahead of the gathering waves at instruction issue */
+      /* forward passes (plan.h): wave 0 walks the op stream alone (fwd_rows).  A few waves move data meanwhile -- few,
+       * because the forward passes leave them plenty of time and a deep queue of their requests in the CU's memory
+       * pipeline would delay the op words wave 0 is waiting for */
+      const uint32_t wv = tid >> 6;
+      if (wv == 0u) {
+        __builtin_amdgcn_s_setprio(3); /* the critical wave: ahead of the others at instruction issue */
         fwd_rows<WB>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
         __builtin_amdgcn_s_setprio(0);
         NRQ_MARK(c, 1);
-      } else if (u1 > u0 && (tid >> 6) <= NGW) {
-        /* a few waves gather (waves 1..NGW: none of them shares wave 0's SIMD): the forward passes leave them plenty of
-         * time, and a deep queue of gather requests would delay wave 0's op words */
-        pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid - NRQ_ROW, NGW * 64u);
-        NRQ_MARK_MAX(c, 2);
+      } else if ((wv & 3u) != 0u) { /* the waves that do not share wave 0's SIMD; index among them: */
+        const uint32_t mv = wv - 1u - (wv >> 2);
+        if (mv < NGW) {
+          if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, mv * 64u + (tid & 63u), NGW * 64u);
+          NRQ_MARK_MAX(c, 2);
+        } else if (mv < NGW + NSW) {
+          if (s1 > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, s1, (mv - NGW) * 64u + (tid & 63u), NSW * 64u);
+          NRQ_MARK_MAX(c, 3);
+        }
       }
       __syncthreads();
       NRQ_STAMP(2);
@@ -184,14 +214,21 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
       ph_park<WB>(c, tid, NRQ_WG);
       __syncthreads();
       NRQ_STAMP(7);
-      ph_store<WB>(c, tid, NRQ_WG);
+      ph_store<WB>(c, ostage_cur + (size_t)sidx * ostage_stride, tid, NRQ_WG);
       __syncthreads();
       NRQ_STAMP(8);
 #undef NRQ_STAMP
     }
-    __syncthreads(); /* the gathered group is complete (and, for what a strip-less portion wrote, visible) */
+    __syncthreads(); /* the gathered group is complete (and, for what a strip-less portion moved, visible) */
+    qp = q;
     q = qn;
     buf ^= 1u;
+  }
+  /* the results of the last group */
+  if (qp < nslots) {
+    GroupDst<WB> gp;
+    const uint32_t units_p = group_dst(qp, gp) * SPL;
+    pf_scatter<WB>(gp, ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride, ostage_stride, 0u, units_p, tid, NRQ_WG);
   }
 }
 
@@ -530,7 +567,7 @@ void build_out_lists(const rq_params &p, const uint16_t *colslot, uint32_t n, co
 }
 
 template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, uint32_t nblk, uint32_t T,
-                                const uint8_t *d_kc, uint32_t lds_bytes, uint32_t max_slots) {
+                                const uint8_t *d_kc, uint32_t lds_bytes, uint32_t max_slots, uint32_t max_out) {
   const uint32_t nstrips = (T + WB - 1) / WB, spl = 128u / WB;
   const uint32_t gpb = (nstrips + spl - 1) / spl;
   const bool by_block = nrq_map_by_block(nblk) && !getenv("NRQ_MAP_SPREAD");
@@ -542,10 +579,11 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   if (const char *e = getenv("NRQ_SOLVE_GRID")) grid = (uint64_t)atoll(e) / 8 * 8;
   if (grid < 8) grid = 8;
   if (grid > nslots) grid = by_block ? (nslots + 7) / 8 * 8 : nslots;
-  /* per workgroup: two sets of `spl` staging buffers (the line group being solved, the one being gathered) */
-  const uint32_t stage_stride = (max_slots * WB + 255u) & ~255u;
+  /* per workgroup: two sets of `spl` input staging buffers (the line group being solved, the one being gathered)
+   * and two sets of `spl` output staging buffers (the group being solved, the one being scattered) */
+  const uint32_t stage_stride = (max_slots * WB + 255u) & ~255u, ostage_stride = (max_out * WB + 255u) & ~255u;
   {
-    int rc_ = ensure_dev(ctx, ctx->stage, (size_t)grid * 2u * spl * stage_stride);
+    int rc_ = ensure_dev(ctx, ctx->stage, (size_t)grid * 2u * spl * ((size_t)stage_stride + ostage_stride));
     if (rc_) return rc_;
   }
   if (!ctx->attr_set[slot]) {
@@ -573,7 +611,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     HIPCHK(ctx, hipMemsetAsync(ctx->prof, 0, (size_t)nprof * 16 * 8, ctx->stream));
   }
   hipLaunchKernelGGL(nrq_solve_kernel<WB>, dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T,
-                     nstrips, by_block ? 1u : 0u, (uint32_t)nslots, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ctx->prof);
+                     nstrips, by_block ? 1u : 0u, (uint32_t)nslots, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
   HIPCHK(ctx, hipGetLastError());
   if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
   if (ctx->prof) {
@@ -614,7 +652,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
 
 /* widest strip whose LDS image fits for every plan header in hdrs */
 int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs, const nrq_job *d_jobs, uint32_t nblk,
-                    uint32_t T, const uint8_t *d_kc) {
+                    uint32_t T, const uint8_t *d_kc, uint32_t max_out) {
   static const uint32_t widths[4] = {16, 8, 4, 2};
   const char *maxw = getenv("NRQ_MAX_WB"); /* tuning: widest strip to consider */
   uint32_t max_slots = 0;
@@ -631,10 +669,10 @@ int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs,
     if (need == 0) return 0; /* nothing solvable in this batch */
     if (need > NRQ_LDS_MAX) continue;
     switch (widths[s]) {
-      case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need, max_slots);
-      case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need, max_slots);
-      case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need, max_slots);
-      default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need, max_slots);
+      case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need, max_slots, max_out);
+      case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need, max_slots, max_out);
+      case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need, max_slots, max_out);
+      default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need, max_slots, max_out);
     }
   }
   return fail(ctx, -5, "block too large for the LDS-resident solver");
@@ -824,7 +862,7 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   HIPCHK(ctx, hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->staged[f], ctx->stream));
   std::vector<const nrq_plan_hdr *> hdrs(1, &ep->hdr);
-  rc = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds + off_jobs), nblk, T, kc->dev);
+  rc = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds + off_jobs), nblk, T, kc->dev, (d_inter ? p.L : 0u) + nrep);
   ctx->stats.host_ms = now_ms() - t_begin;
   return rc;
 }
@@ -984,7 +1022,12 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
     hipError_t e = hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipEventRecord(ctx->staged[f], ctx->stream);
     if (e != hipSuccess) result = fail(ctx, -10, "staging copy failed: %s", hipGetErrorString(e));
-    else result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds), nblk, T, kc->dev);
+    else {
+      uint32_t max_out = 0;
+      for (uint32_t b = 0; b < nblk; b++)
+        if (prep[b].state == 1 && prep[b].orow.size() > max_out) max_out = (uint32_t)prep[b].orow.size();
+      result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds), nblk, T, kc->dev, (d_inter ? p.L : 0u) + max_out);
+    }
   }
   for (auto &pr : prep)
     if (pr.plan) nrq_host_free(pr.plan);
@@ -1123,7 +1166,8 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   }
   int result = 0;
   if (!hdrs.empty())
-    result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ctx->plan_jobs.p), nblk, T, kc->dev);
+    result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ctx->plan_jobs.p), nblk, T, kc->dev,
+                             (d_inter ? p.L : 0u) + max_nl);
   ctx->stats.host_ms = now_ms() - t_begin;
   if (result) return result;
   return need_fallback ? 1 : 0;

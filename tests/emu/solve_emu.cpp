@@ -38,7 +38,7 @@ template <int WB> static bool emu_forward(const StripCtx<WB> &c) {
   return true;
 }
 
-template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t strip, const uint8_t *kc) {
+template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t strip, const uint8_t *kc, std::vector<uint8_t> &ostage) {
   const uint32_t NT = 256;
   StripCtx<WB> c;
   c.job = job;
@@ -77,7 +77,21 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
   PHASE(ph_tables);
   PHASE(ph_backsub);
   PHASE(ph_park);
-  PHASE(ph_store);
+  { /* results: staged per strip, then scattered to the symbol rows a line group at a time */
+    constexpr uint32_t SPL = 128u / WB;
+    const uint32_t nstrips = (T + WB - 1) / WB, ne = out_elems<WB>(c.job, c.h);
+    const size_t ostride = ((size_t)ne * WB + 255u) & ~(size_t)255u;
+    if (strip % SPL == 0) ostage.assign(ostride * SPL + 64, 0x3C);
+    for (uint32_t t = 0; t < NT; t++) ph_store<WB>(c, ostage.data() + (size_t)(strip % SPL) * ostride, t, NT);
+    if (strip % SPL == SPL - 1 || strip + 1 == nstrips) {
+      GroupDst<WB> g;
+      g.inter = gptr_w<uint8_t>(c.job.inter); g.out = gptr_w<uint8_t>(c.job.out); g.orow = gptr<uint32_t>(c.job.out_row);
+      g.ni = c.job.inter ? c.h->L : 0u; g.nout = c.job.nout; g.T = T; g.strip0 = (strip / SPL) * SPL; g.nstrips = nstrips;
+      const uint32_t np = NT - NRQ_ROW, units = ne * SPL, cut = units / 3;
+      for (uint32_t p = 0; p < np; p++) pf_scatter<WB>(g, ostage.data(), ostride, 0, cut, p, np);
+      for (uint32_t p = 0; p < np; p++) pf_scatter<WB>(g, ostage.data(), ostride, cut, units, p, np);
+    }
+  }
 #undef PHASE
   return 1;
 }
@@ -90,12 +104,13 @@ extern "C" uint32_t emu_lds_bytes(const uint8_t *plan, uint32_t wb) {
 extern "C" int emu_solve(const nrq_job *job, uint32_t T, uint32_t wb, const uint8_t *kc) {
   const uint32_t nstrips = (T + wb - 1) / wb;
   int r = 1;
+  std::vector<uint8_t> ostage;
   for (uint32_t s = 0; s < nstrips && r; s++) {
     switch (wb) {
-      case 16: r = run_strip<16>(*job, T, s, kc); break;
-      case 8: r = run_strip<8>(*job, T, s, kc); break;
-      case 4: r = run_strip<4>(*job, T, s, kc); break;
-      case 2: r = run_strip<2>(*job, T, s, kc); break;
+      case 16: r = run_strip<16>(*job, T, s, kc, ostage); break;
+      case 8: r = run_strip<8>(*job, T, s, kc, ostage); break;
+      case 4: r = run_strip<4>(*job, T, s, kc, ostage); break;
+      case 2: r = run_strip<2>(*job, T, s, kc, ostage); break;
       default: return -1;
     }
   }
