@@ -74,26 +74,27 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
  * load -> forward passes -> HDPC -> dense stage -> back-substitution -> store).  While wave 0 runs the forward
  * passes of a strip, a few of the other waves gather a portion of the NEXT line group into the input staging
  * buffers and scatter a portion of the PREVIOUS group's results from the output staging buffers to their rows. */
-#ifndef NRQ_GATHER_WAVES
-#define NRQ_GATHER_WAVES 3u
-#endif
-#ifndef NRQ_SCATTER_WAVES
-#define NRQ_SCATTER_WAVES 4u
-#endif
-template <int WB>
-__global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
-                                                           uint32_t T, uint32_t nstrips, uint32_t by_block, uint32_t nslots,
-                                                           const uint8_t *__restrict__ kc, uint8_t *__restrict__ stage_all,
-                                                           uint32_t stage_stride, uint32_t ostage_stride,
-                                                           unsigned long long *__restrict__ prof) {
+/* NT threads per workgroup: NRQ_WG when one strip image owns the CU's LDS (big blocks), 256 when several fit (small
+ * blocks: more workgroups per CU beat more waves per workgroup, each has its own single-wave forward pass).
+ * `lsub`: log2 of the strips per work slot -- a whole line (128/WB strips) unless that leaves CUs without work. */
+template <int WB, int NT>
+__global__ __launch_bounds__(NT) void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
+                                                       uint32_t T, uint32_t nstrips, uint32_t by_block, uint32_t nslots,
+                                                       uint32_t lsub, const uint8_t *__restrict__ kc,
+                                                       uint8_t *__restrict__ stage_all, uint32_t stage_stride,
+                                                       uint32_t ostage_stride, unsigned long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t tid = threadIdx.x;
-  constexpr uint32_t SPL = 128u / WB, NGW = NRQ_GATHER_WAVES, NSW = NRQ_SCATTER_WAVES; /* gathering / scattering waves */
-  static_assert((NRQ_WG / 64u) - (NRQ_WG / 64u + 3u) / 4u >= NRQ_GATHER_WAVES + NRQ_SCATTER_WAVES, "workgroup too small for the data movers");
-  const uint32_t gpb = (nstrips + SPL - 1u) / SPL;
+  /* the waves that do not share wave 0's SIMD move data during the forward passes: NGW gather, NSW scatter */
+  constexpr uint32_t SPL = 128u / WB, NMV = NT / 64u - (NT / 64u + 3u) / 4u, NGW = NMV >= 7u ? 3u : NMV >= 3u ? 2u : 1u,
+                     NSW = NMV >= 7u ? 4u : NMV - NGW;
+  static_assert(NMV >= 2u, "workgroup too small for the data movers");
+  const uint32_t sub = 1u << lsub;               /* strips per slot */
+  const uint32_t gpb = (nstrips + sub - 1u) / sub; /* slots per block */
   /* per workgroup: two sets of SPL input staging buffers (the group being solved, the group being gathered) and two
    * sets of SPL output staging buffers (the group being solved, the group being scattered) */
   const size_t wg_bytes = 2u * SPL * ((size_t)stage_stride + ostage_stride);
+  (void)SPL;
   NRQ_GAS uint8_t *stage0 = gptr_w<uint8_t>((uint64_t)(uintptr_t)(stage_all + (size_t)blockIdx.x * wg_bytes));
   NRQ_GAS uint8_t *ostage0 = stage0 + 2u * SPL * (size_t)stage_stride;
   auto group_src = [&](uint32_t q, GroupSrc<WB> &g, uint32_t *blk_out) {
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
     const nrq_job *j = jobs + blk;
     g.rowsrc = gptr<uint32_t>(j->rowsrc); g.src = gptr<uint8_t>(j->src); g.rep = gptr<uint8_t>(j->rep);
     g.M = reinterpret_cast<const nrq_plan_hdr *>(j->plan)->M;
-    g.T = T; g.strip0 = grp * SPL; g.nstrips = nstrips;
+    g.T = T; g.strip0 = grp * sub; g.nstrips = nstrips; g.lsub = lsub;
     *blk_out = blk;
   };
   auto group_dst = [&](uint32_t q, GroupDst<WB> &g) -> uint32_t { /* returns the staged elements per strip */
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
     const nrq_job *j = jobs + blk;
     g.inter = gptr_w<uint8_t>(j->inter); g.out = gptr_w<uint8_t>(j->out); g.orow = gptr<uint32_t>(j->out_row);
     g.ni = j->inter ? reinterpret_cast<const nrq_plan_hdr *>(j->plan)->L : 0u;
-    g.nout = j->nout; g.T = T; g.strip0 = grp * SPL; g.nstrips = nstrips;
+    g.nout = j->nout; g.T = T; g.strip0 = grp * sub; g.nstrips = nstrips; g.lsub = lsub;
     return g.ni + g.nout;
   };
   uint32_t q = nrq_next_group(blockIdx.x, nslots, jobs, nblk, gpb, by_block != 0u);
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
     GroupSrc<WB> g0;
     uint32_t b0;
     group_src(q, g0, &b0);
-    pf_gather<WB>(g0, stage0, stage_stride, 0u, g0.M * SPL, tid, NRQ_WG); /* the first group: nothing to overlap it with */
+    pf_gather<WB>(g0, stage0, stage_stride, 0u, g0.M << lsub, tid, NT); /* the first group: nothing to overlap it with */
     __syncthreads();
   }
   while (q < nslots) {
@@ -129,27 +130,27 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
     GroupSrc<WB> gn;
     GroupDst<WB> gp;
     uint32_t blk, blkn = 0, units_n = 0, units_p = 0;
-    if (qn < nslots) { group_src(qn, gn, &blkn); units_n = gn.M * SPL; }
-    if (qp < nslots) units_p = group_dst(qp, gp) * SPL;
+    if (qn < nslots) { group_src(qn, gn, &blkn); units_n = gn.M << lsub; }
+    if (qp < nslots) units_p = group_dst(qp, gp) << lsub;
     {
       GroupSrc<WB> gc;
       group_src(q, gc, &blk);
     }
     NRQ_GAS uint8_t *stage_cur = stage0 + (size_t)buf * SPL * stage_stride, *stage_nxt = stage0 + (size_t)(buf ^ 1u) * SPL * stage_stride;
     NRQ_GAS uint8_t *ostage_cur = ostage0 + (size_t)buf * SPL * ostage_stride, *ostage_prv = ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride;
-    const uint32_t strip0 = ((by_block ? (q >> 3) : q) % gpb) * SPL;
-    for (uint32_t sidx = 0; sidx < SPL; sidx++) {
-      const uint32_t u0 = (uint32_t)((uint64_t)units_n * sidx / SPL), u1 = (uint32_t)((uint64_t)units_n * (sidx + 1u) / SPL);
-      const uint32_t s0 = (uint32_t)((uint64_t)units_p * sidx / SPL), s1 = (uint32_t)((uint64_t)units_p * (sidx + 1u) / SPL);
+    const uint32_t strip0 = ((by_block ? (q >> 3) : q) % gpb) * sub;
+    for (uint32_t sidx = 0; sidx < sub; sidx++) {
+      const uint32_t u0 = (uint32_t)(((uint64_t)units_n * sidx) >> lsub), u1 = (uint32_t)(((uint64_t)units_n * (sidx + 1u)) >> lsub);
+      const uint32_t s0 = (uint32_t)(((uint64_t)units_p * sidx) >> lsub), s1 = (uint32_t)(((uint64_t)units_p * (sidx + 1u)) >> lsub);
       const uint32_t strip = strip0 + sidx;
       if (strip >= nstrips) { /* no such strip: everybody moves this portion */
-        if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid, NRQ_WG);
-        if (s1 > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, s1, tid, NRQ_WG);
+        if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid, NT);
+        if (s1 > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, s1, tid, NT);
         continue;
       }
       StripCtx<WB> c;
-      c.job = jobs[blk];
-      c.plan = reinterpret_cast<const uint8_t *>(c.job.plan);
+      c.job = jobs + blk;
+      c.plan = reinterpret_cast<const uint8_t *>(c.job->plan);
       c.h = reinterpret_cast<const nrq_plan_hdr *>(c.plan);
       c.kc = kc;
       c.lds = smem;
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
       c.dbg_t0 = tid == 0;
       done++;
       NRQ_STAMP(0);
-      pf_commit<WB>(c, stage_cur + (size_t)sidx * stage_stride, tid, NRQ_WG);
-      ph_clear<WB>(c, tid, NRQ_WG);
+      pf_commit<WB>(c, stage_cur + (size_t)sidx * stage_stride, tid, NT);
+      ph_clear<WB>(c, tid, NT);
       __syncthreads();
       NRQ_STAMP(1);
 
@@ -194,27 +195,27 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
       __syncthreads();
       NRQ_STAMP(2);
 
-      ph_hdpc<WB>(c, tid, NRQ_WG);
+      ph_hdpc<WB>(c, tid, NT);
       __syncthreads();
-      ph_hdpc_reduce<WB>(c, tid, NRQ_WG);
+      ph_hdpc_reduce<WB>(c, tid, NT);
       __syncthreads();
       NRQ_STAMP(3);
       NRQ_STAMP(4);
-      ph_dense_fold<WB>(c, tid, NRQ_WG);
+      ph_dense_fold<WB>(c, tid, NT);
       __syncthreads();
-      ph_dense_free<WB>(c, tid, NRQ_WG);
+      ph_dense_free<WB>(c, tid, NT);
       __syncthreads();
-      ph_dense_cu<WB>(c, tid, NRQ_WG);
+      ph_dense_cu<WB>(c, tid, NT);
       __syncthreads();
       NRQ_STAMP(5);
-      ph_tables<WB>(c, tid, NRQ_WG);
+      ph_tables<WB>(c, tid, NT);
       __syncthreads();
       NRQ_STAMP(6);
-      ph_backsub<WB>(c, tid, NRQ_WG);
-      ph_park<WB>(c, tid, NRQ_WG);
+      ph_backsub<WB>(c, tid, NT);
+      ph_park<WB>(c, tid, NT);
       __syncthreads();
       NRQ_STAMP(7);
-      ph_store<WB>(c, ostage_cur + (size_t)sidx * ostage_stride, tid, NRQ_WG);
+      ph_store<WB>(c, ostage_cur + (size_t)sidx * ostage_stride, tid, NT);
       __syncthreads();
       NRQ_STAMP(8);
 #undef NRQ_STAMP
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(NRQ_WG) void nrq_solve_kernel(const nrq_job *__rest
   /* the results of the last group */
   if (qp < nslots) {
     GroupDst<WB> gp;
-    const uint32_t units_p = group_dst(qp, gp) * SPL;
-    pf_scatter<WB>(gp, ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride, ostage_stride, 0u, units_p, tid, NRQ_WG);
+    const uint32_t units_p = group_dst(qp, gp) << lsub;
+    pf_scatter<WB>(gp, ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride, ostage_stride, 0u, units_p, tid, NT);
   }
 }
 
@@ -569,15 +570,28 @@ void build_out_lists(const rq_params &p, const uint16_t *colslot, uint32_t n, co
 template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, uint32_t nblk, uint32_t T,
                                 const uint8_t *d_kc, uint32_t lds_bytes, uint32_t max_slots, uint32_t max_out) {
   const uint32_t nstrips = (T + WB - 1) / WB, spl = 128u / WB;
-  const uint32_t gpb = (nstrips + spl - 1) / spl;
   const bool by_block = nrq_map_by_block(nblk) && !getenv("NRQ_MAP_SPREAD");
-  /* slots of the work list (nrq_map_group): line groups of the blocks, incl. the empty slots of a partial block octet */
-  const uint64_t nslots = by_block ? (uint64_t)((nblk + 7u) / 8u) * 8u * gpb : (uint64_t)nblk * gpb;
-  if (nslots > 0x7FFFFFFFull) return fail(ctx, -4, "grid too large");
-  /* persistent workgroups, one per CU (the LDS image owns the CU); a multiple of 8 keeps a workgroup's slots on its XCD */
-  uint64_t grid = (uint64_t)(ctx->ncu / 8) * 8;
+  /* workgroup shape: the full-size workgroup when a strip image owns the CU's LDS, a 256-thread one when several fit */
+  const bool small = lds_bytes * 3u <= NRQ_LDS_MAX && !getenv("NRQ_BIG_WG");
+  const uint32_t nt = small ? 256u : (uint32_t)NRQ_WG;
+  uint32_t occ = NRQ_LDS_MAX / (lds_bytes ? lds_bytes : 1u);
+  if (occ > 2048u / nt) occ = 2048u / nt;
+  if (occ < 1u) occ = 1u;
+  /* persistent workgroups fill the device; a multiple of 8 keeps a workgroup's slots on its XCD */
+  uint64_t grid = (uint64_t)(ctx->ncu / 8) * 8 * occ;
   if (const char *e = getenv("NRQ_SOLVE_GRID")) grid = (uint64_t)atoll(e) / 8 * 8;
   if (grid < 8) grid = 8;
+  /* work slots (nrq_map_group): `sub` strips of a block each -- the strips of a whole line unless that would leave
+   * workgroups idle -- incl. the empty slots of a partial block octet */
+  uint32_t lsub = 0;
+  while ((1u << lsub) < spl) lsub++;
+  auto slots_for = [&](uint32_t ls) -> uint64_t {
+    const uint32_t sub = 1u << ls, spb = (nstrips + sub - 1) / sub;
+    return by_block ? (uint64_t)((nblk + 7u) / 8u) * 8u * spb : (uint64_t)nblk * spb;
+  };
+  while (lsub > 0 && slots_for(lsub) < grid) lsub--;
+  const uint64_t nslots = slots_for(lsub);
+  if (nslots > 0x7FFFFFFFull) return fail(ctx, -4, "grid too large");
   if (grid > nslots) grid = by_block ? (nslots + 7) / 8 * 8 : nslots;
   /* per workgroup: two sets of `spl` input staging buffers (the line group being solved, the one being gathered)
    * and two sets of `spl` output staging buffers (the group being solved, the one being scattered) */
@@ -587,7 +601,9 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     if (rc_) return rc_;
   }
   if (!ctx->attr_set[slot]) {
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB>),
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, NRQ_WG>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 256>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     ctx->attr_set[slot] = true;
   }
@@ -610,8 +626,12 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     HIPCHK(ctx, hipMalloc((void **)&ctx->prof, (size_t)nprof * 16 * 8));
     HIPCHK(ctx, hipMemsetAsync(ctx->prof, 0, (size_t)nprof * 16 * 8, ctx->stream));
   }
-  hipLaunchKernelGGL(nrq_solve_kernel<WB>, dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T,
-                     nstrips, by_block ? 1u : 0u, (uint32_t)nslots, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
+  if (small)
+    hipLaunchKernelGGL((nrq_solve_kernel<WB, 256>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
+                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
+  else
+    hipLaunchKernelGGL((nrq_solve_kernel<WB, NRQ_WG>), dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
+                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
   HIPCHK(ctx, hipGetLastError());
   if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
   if (ctx->prof) {

@@ -311,7 +311,7 @@ template <int WB> struct StripCtx {
   const uint8_t *plan;
   const nrq_plan_hdr *h;
   const uint8_t *kc; /* nrq_kconst_hdr arena of this K' */
-  nrq_job job;
+  const nrq_job *job; /* (a pointer, not a copy: the workgroup context stays in few registers) */
   uint8_t *lds;
   nrq_lds_layout lay;
   uint32_t T, strip, valid; /* valid = bytes of this strip inside T */
@@ -338,10 +338,11 @@ template <int WB> struct GroupSrc { /* where the rows of one line group of one b
   const NRQ_GAS uint32_t *rowsrc;
   const NRQ_GAS uint8_t *src, *rep;
   uint32_t M, T, strip0, nstrips; /* first strip of the group; strips of the block */
+  uint32_t lsub;                  /* log2 of the strips the group has (a whole line: 128/WB; fewer when work is scarce) */
 };
 template <int WB> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
                                        uint32_t p, uint32_t np) {
-  constexpr uint32_t SPL = 128u / WB; /* pieces (strips) per line */
+  const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u; /* unit u = (row u >> lsub, piece u & pmask) */
 #ifndef NRQ_GATHER_PB
 #define NRQ_GATHER_PB 4
 #endif
@@ -353,11 +354,11 @@ template <int WB> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *s
 #pragma unroll
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np;
-      s[q] = u < u1 ? g.rowsrc[u / SPL] : NRQ_ROW_ZERO;
+      s[q] = u < u1 ? g.rowsrc[u >> lsub] : NRQ_ROW_ZERO;
     }
 #pragma unroll
     for (int q = 0; q < PB; q++) {
-      const uint32_t u = base + (uint32_t)q * np, strip = g.strip0 + u % SPL;
+      const uint32_t u = base + (uint32_t)q * np, strip = g.strip0 + (u & pmask);
       v[q] = sv_zero<WB>();
       if (s[q] != NRQ_ROW_ZERO && strip < g.nstrips) {
         const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? g.rep + (size_t)(s[q] & 0x7FFFFFFFu) * g.T : g.src + (size_t)s[q] * g.T;
@@ -368,7 +369,7 @@ template <int WB> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *s
 #pragma unroll
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np;
-      if (u < u1) g_put_stream<WB>(stage + (size_t)(u % SPL) * stage_stride + (size_t)(u / SPL) * WB, WB, v[q]);
+      if (u < u1) g_put_stream<WB>(stage + (size_t)(u & pmask) * stage_stride + (size_t)(u >> lsub) * WB, WB, v[q]);
     }
   }
 }
@@ -654,8 +655,9 @@ SB_HD void backsub_one(const StripCtx<WB> &c, const uint8_t *t4, uint32_t slot, 
       const uint32_t nib = (bits >> (4u * q)) & 15u;
       SV<WB> t = lds_get<WB>(t4, (w * 8u + q) * 16u + nib);
       sv_xor<WB>(acc, t);
+      if (q == 3) NRQ_SCHED_FENCE(); /* 4 lookups in flight are enough; hoisting all NW*8 of them costs ~100 more registers */
     }
-    NRQ_SCHED_FENCE(); /* 8 lookups in flight are enough; hoisting all NW*8 of them costs ~100 more registers */
+    NRQ_SCHED_FENCE();
   }
   lds_put<WB>(c.slots(), slot, acc);
 }
@@ -717,11 +719,11 @@ template <int WB> SB_HD void ph_park(const StripCtx<WB> &c, uint32_t tid, uint32
  * (element i < L: intermediate symbol i, if the job wants them; then the nout generated symbols).  Results leave
  * for their rows in HBM a line group at a time (pf_scatter): written strip by strip, every 16-byte piece would be a
  * partial-line write of its own (measured: 3.7x the bytes at the HBM interface). */
-template <int WB> SB_HD uint32_t out_elems(const nrq_job &job, const nrq_plan_hdr *h) { return (job.inter ? h->L : 0u) + job.nout; }
+template <int WB> SB_HD uint32_t out_elems(const nrq_job *job, const nrq_plan_hdr *h) { return (job->inter ? h->L : 0u) + job->nout; }
 template <int WB> SB_HD void ph_store(const StripCtx<WB> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
   constexpr int STB = 8;
   const NRQ_GAS uint16_t *colslot = c.template arr<uint16_t>(c.h->off_colslot);
-  const uint32_t L = c.h->L, ni = c.job.inter ? L : 0u;
+  const uint32_t L = c.h->L, ni = c.job->inter ? L : 0u;
   for (uint32_t base = tid; base < ni; base += STB * nt) {
     uint32_t sl[STB];
 #pragma unroll
@@ -735,9 +737,9 @@ template <int WB> SB_HD void ph_store(const StripCtx<WB> &c, NRQ_GAS uint8_t *os
       if (col < L) g_put_stream<WB>(ostage + (size_t)col * WB, WB, lds_get<WB>(c.slots(), sl[q]));
     }
   }
-  const NRQ_GAS uint32_t *cptr = gptr<uint32_t>(c.job.out_cptr);
-  const NRQ_GAS uint16_t *osl = gptr<uint16_t>(c.job.out_slots);
-  for (uint32_t q = tid; q < c.job.nout; q += nt) {
+  const NRQ_GAS uint32_t *cptr = gptr<uint32_t>(c.job->out_cptr);
+  const NRQ_GAS uint16_t *osl = gptr<uint16_t>(c.job->out_slots);
+  for (uint32_t q = tid; q < c.job->nout; q += nt) {
     SV<WB> acc = sv_zero<WB>();
     const uint32_t e0 = cptr[q], e1 = cptr[q + 1];
     for (uint32_t e = e0; e < e1; e++) {
@@ -752,24 +754,25 @@ template <int WB> struct GroupDst {
   NRQ_GAS uint8_t *inter, *out;
   const NRQ_GAS uint32_t *orow;
   uint32_t ni, nout, T, strip0, nstrips; /* ni = intermediate symbols staged (0 or L) */
+  uint32_t lsub;
 };
 /* units [u0, u1) of the scatter, unit = (staged element, piece of the line): whole lines to the symbol rows */
 template <int WB> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
                                         uint32_t u1, uint32_t p, uint32_t np) {
-  constexpr uint32_t SPL = 128u / WB;
+  const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u;
   constexpr int PB = 4;
   for (uint32_t base = u0 + p; base < u1; base += PB * np) {
     SV<WB> v[PB];
     uint32_t row[PB];
 #pragma unroll
     for (int q = 0; q < PB; q++) {
-      const uint32_t u = base + (uint32_t)q * np, i = u / SPL;
+      const uint32_t u = base + (uint32_t)q * np, i = u >> lsub;
       row[q] = (u < u1 && i >= g.ni) ? g.orow[i - g.ni] : i;
-      v[q] = u < u1 ? g_get_l2<WB>(ostage + (size_t)(u % SPL) * stage_stride + (size_t)i * WB) : sv_zero<WB>();
+      v[q] = u < u1 ? g_get_l2<WB>(ostage + (size_t)(u & pmask) * stage_stride + (size_t)i * WB) : sv_zero<WB>();
     }
 #pragma unroll
     for (int q = 0; q < PB; q++) {
-      const uint32_t u = base + (uint32_t)q * np, i = u / SPL, strip = g.strip0 + u % SPL;
+      const uint32_t u = base + (uint32_t)q * np, i = u >> lsub, strip = g.strip0 + (u & pmask);
       if (u >= u1 || strip >= g.nstrips) continue;
       const uint32_t rem = g.T - strip * WB;
       NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB;

@@ -41,7 +41,7 @@ template <int WB> static bool emu_forward(const StripCtx<WB> &c) {
 template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t strip, const uint8_t *kc, std::vector<uint8_t> &ostage) {
   const uint32_t NT = 256;
   StripCtx<WB> c;
-  c.job = job;
+  c.job = &job;
   c.plan = reinterpret_cast<const uint8_t *>(job.plan);
   c.h = reinterpret_cast<const nrq_plan_hdr *>(c.plan);
   if (c.h->status) return 0;
@@ -60,8 +60,8 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
     const size_t stride = ((size_t)c.h->M * WB + 255u) & ~(size_t)255u;
     std::vector<uint8_t> stage(stride * SPL + 64, 0x5A);
     GroupSrc<WB> g;
-    g.rowsrc = gptr<uint32_t>(c.job.rowsrc); g.src = gptr<uint8_t>(c.job.src); g.rep = gptr<uint8_t>(c.job.rep);
-    g.M = c.h->M; g.T = T; g.strip0 = (strip / SPL) * SPL; g.nstrips = (T + WB - 1) / WB;
+    g.rowsrc = gptr<uint32_t>(c.job->rowsrc); g.src = gptr<uint8_t>(c.job->src); g.rep = gptr<uint8_t>(c.job->rep);
+    g.M = c.h->M; g.T = T; g.strip0 = (strip / SPL) * SPL; g.nstrips = (T + WB - 1) / WB; g.lsub = __builtin_ctz(SPL);
     const uint32_t np = NT - NRQ_ROW, units = g.M * SPL, half = units / 2;
     for (uint32_t p = 0; p < np; p++) pf_gather<WB>(g, stage.data(), stride, 0, half, p, np);   /* in two portions, */
     for (uint32_t p = 0; p < np; p++) pf_gather<WB>(g, stage.data(), stride, half, units, p, np); /* as the kernel does */
@@ -85,8 +85,8 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
     for (uint32_t t = 0; t < NT; t++) ph_store<WB>(c, ostage.data() + (size_t)(strip % SPL) * ostride, t, NT);
     if (strip % SPL == SPL - 1 || strip + 1 == nstrips) {
       GroupDst<WB> g;
-      g.inter = gptr_w<uint8_t>(c.job.inter); g.out = gptr_w<uint8_t>(c.job.out); g.orow = gptr<uint32_t>(c.job.out_row);
-      g.ni = c.job.inter ? c.h->L : 0u; g.nout = c.job.nout; g.T = T; g.strip0 = (strip / SPL) * SPL; g.nstrips = nstrips;
+      g.inter = gptr_w<uint8_t>(c.job->inter); g.out = gptr_w<uint8_t>(c.job->out); g.orow = gptr<uint32_t>(c.job->out_row);
+      g.ni = c.job->inter ? c.h->L : 0u; g.nout = c.job->nout; g.T = T; g.strip0 = (strip / SPL) * SPL; g.nstrips = nstrips; g.lsub = __builtin_ctz(SPL);
       const uint32_t np = NT - NRQ_ROW, units = ne * SPL, cut = units / 3;
       for (uint32_t p = 0; p < np; p++) pf_scatter<WB>(g, ostage.data(), ostride, 0, cut, p, np);
       for (uint32_t p = 0; p < np; p++) pf_scatter<WB>(g, ostage.data(), ostride, cut, units, p, np);
