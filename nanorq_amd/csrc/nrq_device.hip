@@ -2,12 +2,13 @@
  * nrq_device.hip -- gfx950 kernels and the C ABI of include/nanorq_hip.h.
  *
  * Kernels
- *   nrq_solve_kernel<WB>   the whole data stage of the precode solve for one WB-byte column strip
- *                          of one source block, LDS-resident (phases in solve_body.h)
- *   nrq_gen_kernel         LT symbol generation from intermediate symbols in HBM
- *                          (reference decode_row, nanorq.c:184-204)
+ *   nrq_solve_kernel<WB,NT>  the whole data stage of the precode solve: persistent workgroups, one WB-byte column
+ *                            strip of one source block at a time, LDS-resident (phases in solve_body.h)
+ *   nrq_plan_kernel          the symbolic stage of a decode block (phases in planner_body.h, order in planner_seq.h)
+ *   nrq_gen_kernel           LT symbol generation from intermediate symbols in HBM
+ *                            (reference decode_row, nanorq.c:184-204)
  * Host side: context, per-K' caches, plan staging, batching, launch geometry.
- * MI355X only: wave64, 160 KiB LDS per workgroup, XCD-aware workgroup->strip mapping.
+ * MI355X only: wave64, 160 KiB LDS per workgroup, XCD-aware placement of the work.
  */
 #include <hip/hip_runtime.h>
 
