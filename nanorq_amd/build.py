@@ -54,7 +54,7 @@ def build_lib(force=False, verbose=False, out=None, extra=()):
     objdir = os.path.join(HERE, "build" if out is None else "build_" + os.path.basename(out))
     os.makedirs(objdir, exist_ok=True)
     objs = []
-    common = ["-O3", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    common = ["-O3", "-fPIC", "-Wno-pass-failed", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     common += list(extra)
     for s in HIP_SOURCES:
         o = os.path.join(objdir, s + ".o")

@@ -373,10 +373,10 @@ template <int WB> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *s
     }
   }
 }
-template <int WB> SB_HD void pf_commit(const StripCtx<WB> &c, const NRQ_GAS uint8_t *stage, uint32_t tid, uint32_t nt) {
+template <int WB> SB_HD void pf_commit(const StripCtx<WB> &c, const NRQ_GAS uint8_t *stage, uint32_t r0, uint32_t tid, uint32_t nt) {
   constexpr int PB = 4;
   const uint32_t M = c.h->M;
-  for (uint32_t base = tid; base < M; base += PB * nt) {
+  for (uint32_t base = r0 + tid; base < M; base += PB * nt) {
     SV<WB> v[PB];
 #pragma unroll
     for (int q = 0; q < PB; q++) {
@@ -739,14 +739,31 @@ template <int WB> SB_HD void ph_store(const StripCtx<WB> &c, NRQ_GAS uint8_t *os
   }
   const NRQ_GAS uint32_t *cptr = gptr<uint32_t>(c.job->out_cptr);
   const NRQ_GAS uint16_t *osl = gptr<uint16_t>(c.job->out_slots);
-  for (uint32_t q = tid; q < c.job->nout; q += nt) {
-    SV<WB> acc = sv_zero<WB>();
-    const uint32_t e0 = cptr[q], e1 = cptr[q + 1];
-    for (uint32_t e = e0; e < e1; e++) {
-      SV<WB> t = lds_get<WB>(c.slots(), osl[e]);
-      sv_xor<WB>(acc, t);
+  /* two generated symbols per thread and trip (each step is a dependent trip to L2: list bounds, then the slot
+   * numbers 8 at a time, then the 8 strips from LDS) */
+  const uint32_t nout = c.job->nout;
+  for (uint32_t q0 = tid; q0 < nout; q0 += 2u * nt) {
+    const uint32_t q1 = q0 + nt;
+    const bool two = q1 < nout;
+    uint32_t e[2] = {cptr[q0], two ? cptr[q1] : 0u};
+    const uint32_t end[2] = {cptr[q0 + 1], two ? cptr[q1 + 1] : 0u};
+    SV<WB> acc[2] = {sv_zero<WB>(), sv_zero<WB>()};
+    while (e[0] < end[0] || e[1] < end[1]) {
+      uint32_t sl[2][8];
+#pragma unroll
+      for (uint32_t j = 0; j < 2; j++)
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) sl[j][k] = e[j] + k < end[j] ? (uint32_t)osl[e[j] + k] : NRQ_NOSLOT;
+#pragma unroll
+      for (uint32_t j = 0; j < 2; j++) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++)
+          if (sl[j][k] != NRQ_NOSLOT) sv_xor<WB>(acc[j], lds_get<WB>(c.slots(), sl[j][k]));
+        e[j] += 8u;
+      }
     }
-    g_put_stream<WB>(ostage + (size_t)(ni + q) * WB, WB, acc);
+    g_put_stream<WB>(ostage + (size_t)(ni + q0) * WB, WB, acc[0]);
+    if (two) g_put_stream<WB>(ostage + (size_t)(ni + q1) * WB, WB, acc[1]);
   }
 }
 /* where the results of one line group of one block go */

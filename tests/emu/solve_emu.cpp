@@ -65,7 +65,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
     const uint32_t np = NT - NRQ_ROW, units = g.M * SPL, half = units / 2;
     for (uint32_t p = 0; p < np; p++) pf_gather<WB>(g, stage.data(), stride, 0, half, p, np);   /* in two portions, */
     for (uint32_t p = 0; p < np; p++) pf_gather<WB>(g, stage.data(), stride, half, units, p, np); /* as the kernel does */
-    for (uint32_t t = 0; t < NT; t++) pf_commit<WB>(c, stage.data() + (size_t)(strip % SPL) * stride, t, NT);
+    for (uint32_t t = 0; t < NT; t++) pf_commit<WB>(c, stage.data() + (size_t)(strip % SPL) * stride, 0u, t, NT);
     PHASE(ph_clear);
   }
   if (!emu_forward<WB>(c)) return -7;
