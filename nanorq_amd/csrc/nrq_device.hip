@@ -86,9 +86,11 @@ __global__ __launch_bounds__(NT) void nrq_solve_kernel(const nrq_job *__restrict
                                                        uint32_t ostage_stride, unsigned long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t tid = threadIdx.x;
-  /* the waves that do not share wave 0's SIMD move data during the forward passes: NGW gather, NSW scatter */
-  constexpr uint32_t SPL = 128u / WB, NMV = NT / 64u - (NT / 64u + 3u) / 4u, NGW = NMV >= 7u ? 3u : NMV >= 3u ? 2u : 1u,
-                     NSW = NMV >= 7u ? 4u : NMV - NGW;
+  /* NFW waves run the forward passes (two, half the strip width each, when the strip is wide enough and the workgroup
+   * big enough to spare a second SIMD); the waves on the other SIMDs move data meanwhile: NGW gather, NSW scatter */
+  constexpr uint32_t SPL = 128u / WB, NFW = (WB >= 8 && NT >= 512) ? 2u : 1u,
+                     NMV = (NT / 64u) / 4u * (4u - NFW) + ((NT / 64u) % 4u > NFW ? (NT / 64u) % 4u - NFW : 0u),
+                     NGW = NMV >= 6u ? 3u : NMV >= 3u ? 2u : 1u, NSW = NMV >= 6u ? 3u : NMV - NGW;
   static_assert(NMV >= 2u, "workgroup too small for the data movers");
   const uint32_t sub = 1u << lsub;               /* strips per slot */
   const uint32_t gpb = (nstrips + sub - 1u) / sub; /* slots per block */
@@ -178,13 +180,19 @@ __global__ __launch_bounds__(NT) void nrq_solve_kernel(const nrq_job *__restrict
        * because the forward passes leave them plenty of time and a deep queue of their requests in the CU's memory
        * pipeline would delay the op words wave 0 is waiting for */
       const uint32_t wv = tid >> 6;
-      if (wv == 0u) {
-        __builtin_amdgcn_s_setprio(3); /* the critical wave: ahead of the others at instruction issue */
-        fwd_rows<WB>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
+      if (wv < NFW) {
+        __builtin_amdgcn_s_setprio(3); /* the critical waves: ahead of the others at instruction issue */
+        const NRQ_GAS uint32_t *ops_ = c.template arr<uint32_t>(c.h->off_ops);
+        if constexpr (NFW == 2u) { /* one half of the strip width each */
+          if (wv == 0u) fwd_rows_half<WB, 0>(ops_, c.h->nrows, tid);
+          else fwd_rows_half<WB, WB / 2>(ops_, c.h->nrows, tid & 63u);
+        } else {
+          fwd_rows<WB>(ops_, c.h->nrows, tid);
+        }
         __builtin_amdgcn_s_setprio(0);
         NRQ_MARK(c, 1);
-      } else if ((wv & 3u) != 0u) { /* the waves that do not share wave 0's SIMD; index among them: */
-        const uint32_t mv = wv - 1u - (wv >> 2);
+      } else if ((wv & 3u) >= NFW) { /* the waves that do not share a SIMD with the forward waves; index among them: */
+        const uint32_t mv = (wv >> 2) * (4u - NFW) + (wv & 3u) - NFW;
         if (mv < NGW) {
           if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, mv * 64u + (tid & 63u), NGW * 64u);
           NRQ_MARK_MAX(c, 2);

@@ -472,6 +472,40 @@ template <int WB> __device__ __forceinline__ void fwd_rows(const NRQ_GAS uint32_
     }
   }
 }
+/* The same pipeline on HALF of the strip width (bytes [OFF, OFF + WB/2) of every slot): the solve kernel runs two of
+ * them on two waves -- byte columns are independent, so the two never need to meet -- because a row costs a single
+ * wave ~63 clocks of instruction issue against ~44 of LDS time. */
+template <int WB> struct HalfVal;
+template <> struct HalfVal<16> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct HalfVal<8> { typedef uint32_t type; };
+template <int WB, int OFF> __device__ __forceinline__ void fwd_rows_half(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
+  static_assert(WB == 16 || WB == 8, "half-width pipeline: 16- and 8-byte strips only");
+  constexpr uint32_t P = NRQ_PIPE, NS = NRQ_PIPE + 1u, U = NRQ_RING;
+  typedef typename HalfVal<WB>::type V;
+  const NRQ_GAS uint32_t *nxt = ops + lane;
+  uint32_t o[U];
+  V v[NS];
+#pragma unroll
+  for (uint32_t k = 0; k < U; k++) o[k] = NRQ_NOP_AT(lane);
+#pragma unroll
+  for (uint32_t k = 0; k < NS; k++) { V z = {}; v[k] = z; }
+  for (uint32_t base = 0; base < nrows + P; base += U, nxt += U * NRQ_ROW) {
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) {
+      const uint32_t j = (k + U - P) % U;
+      {
+        const uint32_t a = row_addr_lo<WB>(o[j]) + (uint32_t)OFF;
+        const V x = v[(k + NS - P) % NS];
+        if constexpr (WB == 16)
+          __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+          __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      o[j] = nxt[(k + U - P) * NRQ_ROW];
+      v[k % NS] = *NRQ_LDSP(V, row_addr_hi<WB>(o[k]) + (uint32_t)OFF);
+    }
+  }
+}
 #else
 template <int WB> struct RowVal { typedef SV<WB> type; };
 template <int WB> SB_HD SV<WB> ph_row_read(const StripCtx<WB> &c, uint32_t op) { return lds_get<WB>(c.lds, op >> 16); }
@@ -482,6 +516,7 @@ template <int WB> SB_HD SV<WB> row_zero() { return sv_zero<WB>(); }
 /* host compilation pass of the kernels only: the row pipeline exists on the device (the CPU emulators have
  * their own row loops over ph_row_read / ph_row_apply) */
 template <int WB> SB_HD void fwd_rows(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
+template <int WB, int OFF> SB_HD void fwd_rows_half(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
 #endif
 
 /* phase 3: HDPC right-hand sides R_h = SUM_c HDPC[h][c] * Y(c) over the peeled columns, through
@@ -777,7 +812,10 @@ template <int WB> struct GroupDst {
 template <int WB> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
                                         uint32_t u1, uint32_t p, uint32_t np) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u;
-  constexpr int PB = 4;
+#ifndef NRQ_SCATTER_PB
+#define NRQ_SCATTER_PB 4
+#endif
+  constexpr int PB = NRQ_SCATTER_PB;
   for (uint32_t base = u0 + p; base < u1; base += PB * np) {
     SV<WB> v[PB];
     uint32_t row[PB];
