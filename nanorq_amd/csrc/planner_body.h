@@ -1025,15 +1025,24 @@ template <int Z> SB_HD void pl_mh_acc(PlanCtx &c, uint32_t tile, uint32_t tid, u
   uint4 *MhT = reinterpret_cast<uint4 *>(pl_mhm(c));
   const uint4 *Gt = reinterpret_cast<const uint4 *>(pl_gtile(c));
   const uint32_t *Wt = pl_wtile(c);
-  for (uint32_t x = tid; x < u; x += nt) {
-    uint4 acc = MhT[x];
+  /* u columns are far fewer than threads: `parts` threads share a column, each folds a slice of the tile's pivots in */
+  const uint32_t upad = (u + 63u) & ~63u, parts = upad && nt / upad ? nt / upad : 1u;
+  for (uint32_t t = tid; t < upad * parts; t += nt) {
+    const uint32_t x = t % upad, part = t / upad;
+    if (x >= u) continue;
+    const uint32_t i0 = cnt * part / parts, i1 = cnt * (part + 1u) / parts;
+    uint4 acc; acc.x = acc.y = acc.z = acc.w = 0u;
     const uint32_t wd = x >> 5, bt = x & 31u;
-    for (uint32_t i = 0; i < cnt; i++) {
+    for (uint32_t i = i0; i < i1; i++) {
       const uint32_t m = 0u - ((Wt[i * wpr + wd] >> bt) & 1u);
       const uint4 g = Gt[i];
       acc.x ^= g.x & m; acc.y ^= g.y & m; acc.z ^= g.z & m; acc.w ^= g.w & m;
     }
-    MhT[x] = acc;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&MhT[x]);
+    if (acc.x) PL_ATOM_XOR(&dst[0], acc.x);
+    if (acc.y) PL_ATOM_XOR(&dst[1], acc.y);
+    if (acc.z) PL_ATOM_XOR(&dst[2], acc.z);
+    if (acc.w) PL_ATOM_XOR(&dst[3], acc.w);
   }
 }
 
