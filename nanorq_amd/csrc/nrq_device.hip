@@ -75,6 +75,10 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
  * load -> forward passes -> HDPC -> dense stage -> back-substitution -> store).  While wave 0 runs the forward
  * passes of a strip, a few of the other waves gather a portion of the NEXT line group into the input staging
  * buffers and scatter a portion of the PREVIOUS group's results from the output staging buffers to their rows. */
+#ifndef NRQ_HDPC_NT
+#define NRQ_HDPC_NT 512 /* threads of the HDPC phase; measured: 256 / 512 / 768 -> 34 k / 28 k / 29 k clocks (the closing fold is per thread) */
+#endif
+#define NRQ_HDPC_NT_ ((uint32_t)NRQ_HDPC_NT)
 /* NT threads per workgroup: NRQ_WG when one strip image owns the CU's LDS (big blocks), 256 when several fit (small
  * blocks: more workgroups per CU beat more waves per workgroup, each has its own single-wave forward pass).
  * `lsub`: log2 of the strips per work slot -- a whole line (128/WB strips) unless that leaves CUs without work. */
@@ -145,6 +149,11 @@ __global__ __launch_bounds__(NT) void nrq_solve_kernel(const nrq_job *__restrict
     for (uint32_t sidx = 0; sidx < sub; sidx++) {
       const uint32_t u0 = (uint32_t)(((uint64_t)units_n * sidx) >> lsub), u1 = (uint32_t)(((uint64_t)units_n * (sidx + 1u)) >> lsub);
       const uint32_t s0 = (uint32_t)(((uint64_t)units_p * sidx) >> lsub), s1 = (uint32_t)(((uint64_t)units_p * (sidx + 1u)) >> lsub);
+      /* part of the scatter portion is left to the waves that the HDPC phase does not use (when there are any) */
+#ifndef NRQ_SCATTER_LATE_PCT
+#define NRQ_SCATTER_LATE_PCT 35u
+#endif
+      const uint32_t sm = NT > NRQ_HDPC_NT_ ? s1 - (uint32_t)((uint64_t)(s1 - s0) * NRQ_SCATTER_LATE_PCT / 100u) : s1;
       const uint32_t strip = strip0 + sidx;
       if (strip >= nstrips) { /* no such strip: everybody moves this portion */
         if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid, NT);
@@ -197,19 +206,17 @@ __global__ __launch_bounds__(NT) void nrq_solve_kernel(const nrq_job *__restrict
           if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, mv * 64u + (tid & 63u), NGW * 64u);
           NRQ_MARK_MAX(c, 2);
         } else if (mv < NGW + NSW) {
-          if (s1 > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, s1, (mv - NGW) * 64u + (tid & 63u), NSW * 64u);
+          if (sm > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, sm, (mv - NGW) * 64u + (tid & 63u), NSW * 64u);
           NRQ_MARK_MAX(c, 3);
         }
       }
       __syncthreads();
       NRQ_STAMP(2);
 
-#ifndef NRQ_HDPC_NT
-#define NRQ_HDPC_NT 512 /* measured: 256 / 512 / 768 threads -> 34 k / 28 k / 29 k clocks (the closing fold is per thread) */
-#endif
       {
-        constexpr uint32_t HNT = NT < NRQ_HDPC_NT ? NT : NRQ_HDPC_NT;
+        constexpr uint32_t HNT = NT < NRQ_HDPC_NT_ ? NT : NRQ_HDPC_NT_;
         if (tid < HNT) ph_hdpc<WB>(c, tid, HNT);
+        else if (s1 > sm) pf_scatter<WB>(gp, ostage_prv, ostage_stride, sm, s1, tid - HNT, NT - HNT); /* the waves HDPC leaves idle */
       }
       __syncthreads();
       ph_hdpc_reduce<WB>(c, tid, NT);
