@@ -50,9 +50,12 @@
 #define NRQ_NOSLOT 0xFFFFu
 #define NRQ_MAX_FREE 32u
 /* When a peeling round has no row of weight 1, this many open rows (sparsest first) are resolved by
- * inactivation before peeling resumes: fewer, wider cascades -> ~40 % fewer rounds in the planner and ~15 %
- * fewer dependency levels in the plan, for ~4 % more inactive columns. */
-#define NRQ_MULTI_INACT 8u
+ * inactivation before peeling resumes: fewer, wider cascades -> fewer rounds in the planner and fewer dependency
+ * levels in the plan, for a few more inactive columns (which the back-substitution pays for).  Measured on the
+ * headline workload: 2 / 3 / 4 / 6 / 8 / 12 / 16 -> 1061 / 1074 / 1080 / 1084 / 1074 / 1070 / 1051 Gbit/s. */
+#ifndef NRQ_MULTI_INACT
+#define NRQ_MULTI_INACT 6u
+#endif
 
 typedef struct nrq_plan_hdr {
   uint32_t magic;
