@@ -292,8 +292,8 @@ def main():
             eff_ms = busy / len(ktimes)   # busy time attributable to one launch
             achieved = alg_per_launch / (eff_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args), "kernel": "nrq_solve_kernel<%d>" %
-                    enc_stats["strip_bytes"], "avg_launch_ms": avg_ms, "busy_ms_per_launch": eff_ms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args), "kernel": "nrq_solve_kernel<%d, %d>" %
+                    (enc_stats["strip_bytes"], enc_stats["wg_threads"]), "avg_launch_ms": avg_ms, "busy_ms_per_launch": eff_ms,
                     "launches_timed": len(ktimes), "blocks_per_launch": blocks_per_launch,
                     "algorithmic_bytes_per_launch": alg_per_launch,
                     "algorithmic_bytes_per_block": {"encode": balg_enc, "decode": balg_dec},
@@ -317,10 +317,17 @@ def main():
                        "decode_retries": retries_total, "spare_symbols_taken": retries_total},
             "roofline": roof, "cpu_baseline": cpu,
             "detail": {"solve_kernel_ms_sum_per_step": sum(ktimes) / args.steps,
+                       # the solve launches of a step are [encode, decode] per stream group, in that order
+                       "encode_solve_ms": (sum(ktimes[0::2]) / max(1, len(ktimes[0::2]))) if nstreams == 1 else None,
+                       "decode_solve_ms": (sum(ktimes[1::2]) / max(1, len(ktimes[1::2]))) if nstreams == 1 else None,
+                       "encode_gbps_device": (8.0 * NB * K * T / (sum(ktimes[0::2]) / max(1, len(ktimes[0::2])) * 1e-3) / 1e9)
+                       if nstreams == 1 and ktimes else None,
+                       "decode_gbps_device_incl_planner": (8.0 * NB * K * T / ((elapsed / args.steps - sum(ktimes[0::2]) / max(
+                           1, len(ktimes[0::2])) * 1e-3)) / 1e9) if nstreams == 1 and ktimes and world == 1 else None,
                        "encode": {k: enc_stats[k] for k in ("plan_ms", "host_ms", "strip_bytes", "lds_bytes", "grid",
-                                                            "npiv", "u", "nlev")},
+                                                            "wg_threads", "strips_per_slot", "npiv", "u", "nlev")},
                        "decode": {k: dec_stats[k] for k in ("plan_ms", "host_ms", "strip_bytes", "lds_bytes", "grid",
-                                                            "npiv", "u", "nlev", "planner")}},
+                                                            "wg_threads", "strips_per_slot", "npiv", "u", "nlev", "planner")}},
         }
         print(json.dumps(out))
     shard.finalize(world)

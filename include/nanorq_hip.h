@@ -32,11 +32,13 @@ typedef struct nrq_call_stats {
   double host_ms;      /* whole host side of the call before the launch returns */
   uint32_t strip_bytes;/* column-strip width chosen (16/8/4/2) */
   uint32_t lds_bytes;  /* dynamic LDS per workgroup */
-  uint32_t grid;       /* workgroups launched */
+  uint32_t grid;       /* (persistent) workgroups launched */
   uint32_t planner;    /* 0 = host planner, 1 = device planner */
   uint64_t plan_bytes; /* plan bytes resident on the device for this call */
   uint64_t xor_ops;    /* row XOR ops in the forward passes, summed over blocks */
   uint32_t npiv, u, nlev, nfree; /* of block 0 */
+  uint32_t wg_threads; /* threads per workgroup of the solve launch */
+  uint32_t strips_per_slot; /* strips a work slot holds (a whole 128-byte line group unless work is scarce) */
 } nrq_call_stats;
 
 /* One context per GPU (one process per GPU: no cross-device state).  `stream` is a hipStream_t the

@@ -689,6 +689,8 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   ctx->stats.strip_bytes = WB;
   ctx->stats.lds_bytes = lds_bytes;
   ctx->stats.grid = (uint32_t)grid;
+  ctx->stats.wg_threads = nt;
+  ctx->stats.strips_per_slot = 1u << lsub;
   return 0;
 }
 
