@@ -118,6 +118,10 @@ int nrq_dev_free(nrq_ctx *ctx, void *p);
 int nrq_dev_upload(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* synchronous */
 int nrq_dev_download(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* synchronous */
 int nrq_dev_memset(nrq_ctx *ctx, void *d_dst, int value, size_t bytes);
+/* enqueue-only variants (ordered on the context's stream; complete after nrq_ctx_sync) */
+int nrq_dev_upload_async(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int nrq_dev_download_async(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int nrq_dev_copy(nrq_ctx *ctx, void *d_dst, const void *d_src, size_t bytes); /* device to device, enqueue-only */
 
 /* Per-launch duration of the solve kernel, measured with HIP events recorded on the launch stream
  * immediately around each launch (bench.py's roofline leg).  enable(1) starts collecting; read()

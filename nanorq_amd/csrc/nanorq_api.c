@@ -439,3 +439,158 @@ out:
   free(lost);
   return ok;
 }
+
+/* =============================================================== batched variants (nanorq_batch.h) ==== */
+/* blocks come in at most two sizes (RFC 6330 section 4.4.1.2 partition: JL blocks of IL symbols, JS of IS) */
+static uint32_t class_of(nanorq *rq, unsigned sbn) { return sbn < rq->src_part.JL ? 0u : 1u; }
+
+size_t nanorq_generate_symbols_all(nanorq *rq, struct ioctx *io) {
+  nrq_ctx *c = ctx();
+  const size_t Z = nanorq_blocks(rq), T = rq->T;
+  if (!c || !io) return 0;
+  for (uint32_t cls = 0; cls < 2; cls++) {
+    /* the blocks of this size that still need the solve */
+    unsigned todo[NRQ_Z_MAX], n = 0;
+    uint32_t K = 0;
+    for (unsigned sbn = 0; sbn < Z; sbn++) {
+      if (class_of(rq, sbn) != cls) continue;
+      struct blockst *b = get_block(rq, (uint8_t)sbn);
+      if (!b || b->K == 0 || b->inverted) continue;
+      if (!b->loaded) b->loaded = load_block(rq, (uint8_t)sbn, b, io);
+      if (!b->loaded) continue;
+      K = b->K;
+      todo[n++] = sbn;
+    }
+    if (!n) continue;
+    const size_t sbytes = (size_t)K * T, ibytes = (size_t)rq->L * T;
+    void *d_src = NULL, *d_inter = NULL;
+    if (nrq_dev_alloc(c, sbytes * n, &d_src) != 0) continue;
+    if (nrq_dev_alloc(c, ibytes * n, &d_inter) != 0) { nrq_dev_free(c, d_src); continue; }
+    bool ok = true;
+    for (unsigned k = 0; k < n && ok; k++)
+      ok = nrq_dev_upload_async(c, (uint8_t *)d_src + sbytes * k, rq->blocks[todo[k]]->src, sbytes) == 0;
+    ok = ok && nrq_encode_blocks(c, K, rq->Kp, (uint32_t)T, n, d_src, sbytes, d_inter, ibytes, 0, NULL, NULL, 0) == 0 &&
+         nrq_ctx_sync(c) == 0;
+    /* every block keeps its own intermediate symbols on the device, like after nanorq_generate_symbols */
+    for (unsigned k = 0; k < n && ok; k++) {
+      struct blockst *b = rq->blocks[todo[k]];
+      if (!b->d_inter && nrq_dev_alloc(c, ibytes, &b->d_inter) != 0) { ok = false; break; }
+      if (nrq_dev_copy(c, b->d_inter, (uint8_t *)d_inter + ibytes * k, ibytes) != 0) { ok = false; break; }
+      b->win_n = 0;
+      b->inverted = true;
+    }
+    if (ok) ok = nrq_ctx_sync(c) == 0;
+    nrq_dev_free(c, d_src);
+    nrq_dev_free(c, d_inter);
+  }
+  size_t done = 0;
+  for (unsigned sbn = 0; sbn < Z; sbn++)
+    if (rq->blocks[sbn] && rq->blocks[sbn]->inverted) done++;
+  return done;
+}
+
+size_t nanorq_encode_range(nanorq *rq, void *data, uint32_t esi0, uint32_t n, uint8_t sbn, struct ioctx *io) {
+  struct blockst *b = get_block(rq, sbn);
+  const size_t T = rq->T;
+  if (!b || !n || (uint64_t)esi0 + n > (1u << 24)) return 0;
+  uint8_t *out = data;
+  uint32_t esi = esi0, left = n;
+  /* source symbols: the loaded rows (nanorq_encode, esi < K) */
+  while (left && esi < b->K) {
+    if (nanorq_encode(rq, out, esi, sbn, io) != T) return 0;
+    out += T; esi++; left--;
+  }
+  if (!left) return (size_t)n * T;
+  if (!b->inverted) b->inverted = nanorq_generate_symbols(rq, sbn, io);
+  nrq_ctx *c = ctx();
+  if (!b->inverted || !c) return 0;
+  /* repair symbols: generated on the device in one go, one download */
+  uint32_t *isis = malloc((size_t)left * sizeof(uint32_t));
+  void *d_out = NULL;
+  bool ok = isis && nrq_dev_alloc(c, (size_t)left * T, &d_out) == 0;
+  if (ok) {
+    for (uint32_t k = 0; k < left; k++) isis[k] = esi + k + (rq->Kp - b->K);
+    ok = nrq_gen_symbols(c, b->K, rq->Kp, (uint32_t)T, 1, b->d_inter, (size_t)rq->L * T, left, isis, d_out, (size_t)left * T) == 0 &&
+         nrq_dev_download(c, out, d_out, (size_t)left * T) == 0;
+  }
+  if (d_out) nrq_dev_free(c, d_out);
+  free(isis);
+  return ok ? (size_t)n * T : 0;
+}
+
+size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io) {
+  size_t added = 0;
+  const uint8_t *p = data;
+  for (uint32_t k = 0; k < n; k++) {
+    /* (add_symbol copies; the const is cast away only because the per-symbol signature of the reference is void *) */
+    const int r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * rq->T), tags[k], io);
+    if (results) results[k] = r;
+    if (r == NANORQ_SYM_ADDED) added++;
+  }
+  return added;
+}
+
+size_t nanorq_repair_all(nanorq *rq, struct ioctx *io) {
+  nrq_ctx *c = ctx();
+  const size_t Z = nanorq_blocks(rq), T = rq->T;
+  if (c) {
+    for (uint32_t cls = 0; cls < 2; cls++) {
+      unsigned todo[NRQ_Z_MAX], n = 0;
+      uint32_t K = 0;
+      size_t lost_cap = 0, rep_cap = 0;
+      for (unsigned sbn = 0; sbn < Z; sbn++) {
+        if (class_of(rq, sbn) != cls) continue;
+        struct blockst *b = rq->blocks[sbn];
+        if (!b || b->K == 0) continue;
+        const size_t gaps = mask_gaps(b, b->K);
+        if (gaps == 0 || b->nrep < gaps || b->nrep - gaps > b->spare) continue; /* as nanorq_repair_block */
+        K = b->K;
+        if (gaps > lost_cap) lost_cap = gaps;
+        if (b->nrep > rep_cap) rep_cap = b->nrep;
+        todo[n++] = sbn;
+      }
+      if (!n) continue;
+      const size_t sbytes = (size_t)K * T, rbytes = rep_cap * T;
+      uint32_t *lost = calloc((size_t)n * lost_cap, sizeof(uint32_t)), *nlost = calloc(n, sizeof(uint32_t));
+      uint32_t *resi = calloc((size_t)n * rep_cap, sizeof(uint32_t)), *nrep = calloc(n, sizeof(uint32_t));
+      int *status = calloc(n, sizeof(int));
+      void *d_src = NULL, *d_rep = NULL;
+      bool ok = lost && nlost && resi && nrep && status && nrq_dev_alloc(c, sbytes * n, &d_src) == 0 &&
+                nrq_dev_alloc(c, rbytes * n, &d_rep) == 0;
+      for (unsigned k = 0; k < n && ok; k++) {
+        struct blockst *b = rq->blocks[todo[k]];
+        uint32_t g = 0;
+        for (uint32_t e = 0; e < b->K; e++)
+          if (!mask_get(b, e)) lost[(size_t)k * lost_cap + g++] = e;
+        nlost[k] = g;
+        nrep[k] = (uint32_t)b->nrep;
+        memcpy(resi + (size_t)k * rep_cap, b->rep_esi, b->nrep * sizeof(uint32_t));
+        ok = nrq_dev_upload_async(c, (uint8_t *)d_src + sbytes * k, b->src, sbytes) == 0 &&
+             nrq_dev_upload_async(c, (uint8_t *)d_rep + rbytes * k, b->rep_data, b->nrep * T) == 0;
+      }
+      ok = ok && nrq_decode_blocks(c, K, rq->Kp, (uint32_t)T, n, d_src, sbytes, lost, nlost, (uint32_t)lost_cap, resi, nrep,
+                                   (uint32_t)rep_cap, d_rep, rbytes, NULL, 0, status) == 0;
+      for (unsigned k = 0; k < n && ok; k++) /* the decoded blocks come back with one wait */
+        if (status[k]) ok = nrq_dev_download_async(c, rq->blocks[todo[k]]->src, (uint8_t *)d_src + sbytes * k, sbytes) == 0;
+      ok = ok && nrq_ctx_sync(c) == 0;
+      for (unsigned k = 0; k < n && ok; k++) {
+        if (!status[k]) continue; /* rank deficient: retry after more symbols (nanorq.c:620-623) */
+        struct blockst *b = rq->blocks[todo[k]];
+        for (uint32_t j = 0; j < nlost[k]; j++) {
+          const uint32_t e = lost[(size_t)k * lost_cap + j];
+          if (io) transfer_symbol(rq, (uint8_t)todo[k], e, b->K, b->src + (size_t)e * T, io, 1);
+          mask_set(b, e);
+        }
+      }
+      if (d_src) nrq_dev_free(c, d_src);
+      if (d_rep) nrq_dev_free(c, d_rep);
+      free(lost); free(nlost); free(resi); free(nrep); free(status);
+    }
+  }
+  size_t complete = 0;
+  for (unsigned sbn = 0; sbn < Z; sbn++) {
+    struct blockst *b = rq->blocks[sbn];
+    if (b && b->mask && mask_gaps(b, b->K) == 0) complete++;
+  }
+  return complete;
+}

@@ -1291,6 +1291,21 @@ int nrq_dev_download(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
+int nrq_dev_upload_async(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+int nrq_dev_download_async(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+int nrq_dev_copy(nrq_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
 int nrq_dev_memset(nrq_ctx *ctx, void *d_dst, int value, size_t bytes) {
   if (!ctx) return -1;
   HIPCHK(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));

@@ -68,6 +68,15 @@ def api():
         L.nanorq_num_repair.argtypes = [vp, C.c_uint8]
         L.nanorq_repair_block.restype = C.c_bool
         L.nanorq_repair_block.argtypes = [vp, iop, C.c_uint8]
+        # include/nanorq_batch.h
+        L.nanorq_generate_symbols_all.restype = C.c_size_t
+        L.nanorq_generate_symbols_all.argtypes = [vp, iop]
+        L.nanorq_encode_range.restype = C.c_size_t
+        L.nanorq_encode_range.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, iop]
+        L.nanorq_decoder_add_symbols.restype = C.c_size_t
+        L.nanorq_decoder_add_symbols.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int), iop]
+        L.nanorq_repair_all.restype = C.c_size_t
+        L.nanorq_repair_all.argtypes = [vp, iop]
         L.ioctx_from_mem.restype = iop
         L.ioctx_from_mem.argtypes = [vp, C.c_size_t]
         L.ioctx_from_file.restype = iop
@@ -133,3 +142,52 @@ def decode_object(oti_common, oti_scheme, packets, nbytes):
     L.nanorq_free(rq)
     io.contents.destroy(io)
     return ok, out
+
+
+def encode_object_batched(data, T, K=0, Z=0, Al=8, loss=0.06, overhead=0, seed=1):
+    """encode_object through include/nanorq_batch.h: all blocks solved by one call, symbols fetched in ranges.
+    Same packets (same rng consumption) as encode_object."""
+    L = api()
+    data = np.ascontiguousarray(data, np.uint8)
+    rq = L.nanorq_encoder_new_ex(data.nbytes, T, K, Z, Al)
+    assert rq, "encoder_new_ex failed"
+    io = mem_io(data)
+    nblk = L.nanorq_blocks(rq)
+    assert L.nanorq_generate_symbols_all(rq, io) == nblk
+    rng = np.random.default_rng(seed)
+    Tsz = L.nanorq_symbol_size(rq)
+    packets = []
+    for sbn in range(nblk):
+        nk = L.nanorq_block_symbols(rq, sbn)
+        keep = [esi for esi in range(nk) if not rng.random() < loss]
+        nrep = nk - len(keep) + overhead
+        buf = np.zeros((nk + nrep, Tsz), np.uint8)
+        assert L.nanorq_encode_range(rq, buf.ctypes.data_as(C.c_void_p), 0, nk + nrep, sbn, io) == (nk + nrep) * Tsz
+        for esi in keep + list(range(nk, nk + nrep)):
+            packets.append((L.nanorq_tag(sbn, esi), buf[esi].tobytes()))
+        L.nanorq_encoder_cleanup(rq, sbn)
+    oti = (L.nanorq_oti_common(rq), L.nanorq_oti_scheme_specific(rq))
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+    return oti[0], oti[1], packets
+
+
+def decode_object_batched(oti_common, oti_scheme, packets, nbytes):
+    """decode_object through include/nanorq_batch.h: one add call, one repair call."""
+    L = api()
+    rq = L.nanorq_decoder_new(oti_common, oti_scheme)
+    assert rq
+    out = np.zeros(nbytes, np.uint8)
+    io = mem_io(out)
+    Tsz = L.nanorq_symbol_size(rq)
+    blob = np.frombuffer(b"".join(p for _, p in packets), np.uint8).copy()
+    tags = np.array([t for t, _ in packets], np.uint32)
+    res = np.zeros(len(packets), np.int32)
+    added = L.nanorq_decoder_add_symbols(rq, blob.ctypes.data_as(C.c_void_p), tags.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         len(packets), res.ctypes.data_as(C.POINTER(C.c_int)), io)
+    assert added == int((res == SYM_ADDED).sum()) and not (res == SYM_ERR).any() and blob.nbytes == len(packets) * Tsz
+    nblk = L.nanorq_blocks(rq)
+    complete = L.nanorq_repair_all(rq, io)
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+    return complete == nblk, out

@@ -21,7 +21,7 @@ def _declared(header):
     return sorted(set(re.findall(r"\b((?:nanorq|nrq|ioctx)_[a-z0-9_]+)\s*\(", txt)))
 
 
-@pytest.mark.parametrize("header", ["nanorq.h", "io.h", "nanorq_hip.h"])
+@pytest.mark.parametrize("header", ["nanorq.h", "io.h", "nanorq_hip.h", "nanorq_batch.h"])
 def test_library_exports_every_declared_symbol(header):
     L = nanorq_amd.lib()
     names = _declared(header)

@@ -6,7 +6,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from capi import api, decode_object, encode_object, mem_io
+from capi import encode_object_batched, decode_object_batched, api, decode_object, encode_object, mem_io
 from test_oracle_kat import KAT_SHA, KAT_SMALL
 from util import kat_payload, payload
 
@@ -70,6 +70,20 @@ def test_multi_block_object_with_ragged_tail():
     data = payload(F, seed=3)
     c, s, packets = encode_object(data, T, K=25, loss=0.1, overhead=3, seed=2)
     ok, out = decode_object(c, s, packets, F)
+    assert ok and np.array_equal(out, data)
+
+
+@pytest.mark.parametrize("F,T,K,loss,oh", [(103 * 64 - 17, 64, 25, 0.1, 3), (700 * 1280, 1280, 100, 0.08, 2), (3000 * 256 + 5, 256, 0, 0.05, 4)])
+def test_batched_object_api_matches_the_per_block_calls(F, T, K, loss, oh):
+    """include/nanorq_batch.h: every block of the object in one device batch -- the packets must be byte-identical
+    to the per-block / per-symbol calls, and either decoder must recover the object from either packet set."""
+    data = payload(F, seed=13)
+    c1, s1, p1 = encode_object(data, T, K=K, loss=loss, overhead=oh, seed=5)
+    c2, s2, p2 = encode_object_batched(data, T, K=K, loss=loss, overhead=oh, seed=5)
+    assert (c1, s1) == (c2, s2) and p1 == p2
+    ok, out = decode_object_batched(c2, s2, p2, F)
+    assert ok and np.array_equal(out, data)
+    ok, out = decode_object(c1, s1, p2, F)
     assert ok and np.array_equal(out, data)
 
 
