@@ -143,6 +143,21 @@ def _roundtrip(G, K, T, nblk, p, oh, seed):
     return st, out, src
 
 
+@pytest.mark.parametrize("K,T,nblk", [(100, 200, 70), (333, 1, 9), (64, 136, 130), (1024, 1288, 16)])
+def test_launch_shapes(G, orc, K, T, nblk):
+    """Work distribution of the persistent solve kernel: block counts that are / are not multiples of 8 (blocks are
+    dealt to XCDs by octets), symbol sizes whose last 128-byte line group is partial, a single byte column; every
+    block must decode, a few are compared with the oracle byte for byte."""
+    st, out, src = _roundtrip(G, K, T, nblk, 0.12, 3, seed=61)
+    assert st.all()
+    assert np.array_equal(out, src)
+    esis = np.arange(K, K + 5, dtype=np.uint32)
+    rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+    for b in (0, nblk // 2, nblk - 1):
+        r_rep, r_int, _ = orc.encode_block(src[b], K, T, esis, want_inter=True)
+        assert np.array_equal(inter[b], r_int) and np.array_equal(rep[b], r_rep), "block %d" % b
+
+
 def test_roundtrip_headline_config(G):
     """BASELINE configs[1]/[2] at full size: K=8192, T=1280, 10 % loss, +2 overhead, 8 blocks."""
     st, out, src = _roundtrip(G, 8192, 1280, 8, 0.10, 2, seed=31)
