@@ -285,6 +285,21 @@ static size_t transfer_symbol(nanorq *rq, uint8_t sbn, uint32_t esi, uint32_t K,
 static bool load_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct ioctx *io) { /* nanorq.c:175-182 */
   if (!io) return false;
   memset(b->src, 0, (size_t)(b->K ? b->K : 1) * rq->T);
+  if (rq->N == 1) {
+    /* no sub-blocking (the only case nanorq creates, nanorq.c:78): the block's symbols are one contiguous stretch
+     * of the object -- one seek and one read instead of K of each; bytes beyond F stay zero */
+    const size_t off = symbol_offset(rq, sbn, 0, b->K, 0) * rq->Al, want = (size_t)b->K * rq->T;
+    if (off < rq->F && io->seek(io, off)) {
+      const size_t len = off + want > rq->F ? rq->F - off : want;
+      size_t got = 0;
+      while (got < len) {
+        const size_t n = io->read(io, b->src + got, len - got);
+        if (n == 0) break;
+        got += n;
+      }
+    }
+    return true;
+  }
   for (uint32_t esi = 0; esi < b->K; esi++) transfer_symbol(rq, sbn, esi, b->K, b->src + (size_t)esi * rq->T, io, 0);
   return true;
 }
