@@ -481,15 +481,18 @@ template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t rd, uint32_t tid
   }
   if (tid == 0) { sh->nq[pq ^ 1u] = 0; sh->best = PL_NONE; }
 }
-/* B: the claimed columns leave V (8 lanes per column) */
+/* B: the claimed columns leave V.  A group of 8..64 lanes per column -- as many as the round's claim count leaves
+ * (most rounds claim a dozen columns; each trip over a column's row list is a dependent HBM/L2 round trip) */
 template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   const uint32_t pq = rd & 1u;
-  const uint32_t grp = tid >> 3, lane = tid & 7u, ngrp = nt >> 3;
   const uint32_t nc = sh->nclaim[pq] < PL_QCAP ? sh->nclaim[pq] : PL_QCAP;
+  uint32_t lg = 3;
+  while (lg < 6u && (nc << (lg + 1u)) <= nt) lg++;
+  const uint32_t grp = tid >> lg, lane = tid & ((1u << lg) - 1u), ngrp = nt >> lg;
   for (uint32_t i = grp; i < nc; i += ngrp) {
     const uint32_t r = sh->claim_r[i], col = sh->claim_c[i];
-    pl_drop_column(c, col, (c.rowinfo[r] & PL_LEVEL_MASK) + 1u, pq ^ 1u, lane, 8u);
+    pl_drop_column(c, col, (c.rowinfo[r] & PL_LEVEL_MASK) + 1u, pq ^ 1u, lane, 1u << lg);
   }
   if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
 }
