@@ -202,6 +202,12 @@ struct PlanCtx {
   nrq_job *jobout;
 };
 
+/* a pointer read from a job record is generic to the compiler (FLAT accesses); these all point into HBM */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PL_HBM(T, v) ((T *)(__attribute__((address_space(1))) T *)(uintptr_t)(v))
+#else
+#define PL_HBM(T, v) (reinterpret_cast<T *>(v))
+#endif
 SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, const nrq_planjob &job, pl_shared *sh,
                         uint8_t *lds_dyn, uint32_t lds_dyn_bytes, uint32_t Mcap, uint32_t npcap, uint32_t ucap,
                         nrq_job *jobout) {
@@ -216,14 +222,14 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.G = kc + c.kh->off_g;
   c.GT = kc + c.kh->off_gt;
   c.job = job;
-  c.lost = reinterpret_cast<const uint32_t *>(job.lost);
-  c.rep_esi = reinterpret_cast<const uint32_t *>(job.rep_esi);
+  c.lost = PL_HBM(const uint32_t, job.lost);
+  c.rep_esi = PL_HBM(const uint32_t, job.rep_esi);
   c.sh = sh;
   c.lds_dyn = lds_dyn;
   c.lds_dyn_bytes = lds_dyn_bytes;
   c.Mcap = Mcap; c.npcap = npcap; c.ucap = ucap;
   c.wl = pl_work_plan(c.p.L, Mcap, npcap, ucap);
-  c.work = reinterpret_cast<uint8_t *>(job.work);
+  c.work = PL_HBM(uint8_t, job.work);
   uint8_t *w = c.work;
   c.rowstate = reinterpret_cast<uint32_t *>(w + c.wl.rowstate);
   c.rowinfo = reinterpret_cast<uint32_t *>(w + c.wl.rowinfo);
@@ -262,7 +268,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.red_row = reinterpret_cast<uint32_t *>(w + c.wl.red_row);
   c.red_x = reinterpret_cast<uint32_t *>(w + c.wl.red_x);
   /* arena: header, then the arrays whose size is bounded by (L, ucap) */
-  c.arena = reinterpret_cast<uint8_t *>(job.arena);
+  c.arena = PL_HBM(uint8_t, job.arena);
   c.hdr = reinterpret_cast<nrq_plan_hdr *>(c.arena);
   uint32_t o = pl_r16((uint32_t)sizeof(nrq_plan_hdr));
   const uint32_t L = c.p.L, n_hd = c.p.Kp + c.p.S;
@@ -430,10 +436,28 @@ template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) 
   }
 }
 
+/* The peeling state (rowstate / rowinfo / colinfo) lives in LDS when it fits and in the block's HBM workspace
+ * otherwise, so PlanCtx holds it behind generic pointers -- and every access through one is a FLAT instruction:
+ * slower than a DS one, and ordered (vmcnt) behind the phase's outstanding global stores.  The peeling phases are
+ * therefore compiled twice; the LDS instance tells the compiler where its three pointers point. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PL_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void *)(p)))
+#else
+#define PL_ASSUME_LDS(p) ((void)0)
+#endif
+struct PlPeel { uint32_t *rowstate, *rowinfo, *colinfo; };
+template <bool LDS> SB_HD PlPeel pl_peel_state(const PlanCtx &c) {
+  PlPeel s{c.rowstate, c.rowinfo, c.colinfo};
+  if (LDS) { PL_ASSUME_LDS(s.rowstate); PL_ASSUME_LDS(s.rowinfo); PL_ASSUME_LDS(s.colinfo); }
+  return s;
+}
+#define PL_PEEL_DISPATCH(fn, ...) do { if (pl_peel_in_lds(c)) fn<true>(__VA_ARGS__); else fn<false>(__VA_ARGS__); } while (0)
+SB_HD bool pl_peel_in_lds(const PlanCtx &c);
+
 /* column `col` leaves V: one atomic subtract per row that contains it; rows that drop to a single V
  * column join the next frontier (queue of parity `np`).  `lvl1` (pivot level + 1) is folded into the
  * rows' level-so-far; 0 for an inactivated column.  A group of `lanes` lanes strides over the row list. */
-SB_HD void pl_drop_column(PlanCtx &c, uint32_t col, uint32_t lvl1, uint32_t np, uint32_t lane0, uint32_t lanes) {
+SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lvl1, uint32_t np, uint32_t lane0, uint32_t lanes) {
   pl_shared *sh = c.sh;
   const uint32_t dec = (1u << 24) | col;
   uint16_t *nextq = sh->queue[np];
@@ -442,10 +466,10 @@ SB_HD void pl_drop_column(PlanCtx &c, uint32_t col, uint32_t lvl1, uint32_t np, 
   for (uint32_t e = lane0; e < nb + npc; e += lanes) {
     const bool base = e < nb;
     const uint32_t r = base ? c.b_ridx[a + e] : c.pc_rows[pa + (e - nb)];
-    const uint32_t info = c.rowinfo[r]; /* flags change in other phases only: stable here */
+    const uint32_t info = s.rowinfo[r]; /* flags change in other phases only: stable here */
     if (base && (info & PL_PATCHED)) continue; /* base entry of a row this block replaced */
-    if (lvl1 && (info & PL_UNASSIGNED)) PL_ATOM_MAX(&c.rowinfo[r], (info & ~PL_LEVEL_MASK) | lvl1);
-    const uint32_t old = PL_ATOM_SUB(&c.rowstate[r], dec);
+    if (lvl1 && (info & PL_UNASSIGNED)) PL_ATOM_MAX(&s.rowinfo[r], (info & ~PL_LEVEL_MASK) | lvl1);
+    const uint32_t old = PL_ATOM_SUB(&s.rowstate[r], dec);
     if ((old >> 24) == 2u && (info & PL_UNASSIGNED)) {
       const uint32_t j = PL_ATOM_ADD(&sh->nq[np], 1u);
       if (j < PL_QCAP) nextq[j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
@@ -457,34 +481,39 @@ SB_HD void pl_drop_column(PlanCtx &c, uint32_t col, uint32_t lvl1, uint32_t np, 
 /* Round `rd`: frontier = queue[rd&1], next frontier = queue[(rd+1)&1].
  * A: every frontier row that still has exactly one V column tries to claim it (compare-and-swap on the
  *    column); the winner becomes a pivot at the level its earlier column drops accumulated. */
-template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
+  const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t pq = rd & 1u;
   const uint16_t *fq = sh->queue[pq];
   const uint32_t nf = sh->nq[pq] < PL_QCAP ? sh->nq[pq] : PL_QCAP;
   for (uint32_t t = tid; t < nf; t += nt) {
     const uint32_t r = fq[t];
-    const uint32_t st = c.rowstate[r], info = c.rowinfo[r];
+    const uint32_t st = s.rowstate[r], info = s.rowinfo[r];
     if ((st >> 24) != 1u || !(info & PL_UNASSIGNED)) continue;
     const uint32_t col = st & 0xFFFFFFu;
-    if (PL_ATOM_CAS(&c.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue;
+    if (PL_ATOM_CAS(&s.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue;
     const uint32_t lv = info & PL_LEVEL_MASK;
     const uint32_t k = PL_ATOM_ADD(&sh->npiv, 1u);
-    c.pivslot[k] = (uint16_t)r;
-    c.pivcol[k] = (uint16_t)col;
-    c.rowinfo[r] = (info & PL_PATCHED) | lv; /* assigned: bit 31 cleared */
-    c.colinfo[col] = (PL_ST_PIVOT << 30) | k;
+    const uint32_t i = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
+    s.rowinfo[r] = (info & PL_PATCHED) | lv; /* assigned: bit 31 cleared */
+    s.colinfo[col] = (PL_ST_PIVOT << 30) | k;
     PL_ATOM_MAX(&sh->nlev, lv + 1u);
     PL_ATOM_SUB(&sh->nV, 1u);
-    const uint32_t i = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
     if (i < PL_QCAP) { sh->claim_r[i] = (uint16_t)r; sh->claim_c[i] = (uint16_t)col; } else sh->status = PL_FAIL_CAPACITY;
+    c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
+    c.pivcol[k] = (uint16_t)col;
   }
   if (tid == 0) { sh->nq[pq ^ 1u] = 0; sh->best = PL_NONE; }
 }
+template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  PL_PEEL_DISPATCH(pl_round_claim_t, c, rd, tid, nt);
+}
 /* B: the claimed columns leave V.  A group of 8..64 lanes per column -- as many as the round's claim count leaves
  * (most rounds claim a dozen columns; each trip over a column's row list is a dependent HBM/L2 round trip) */
-template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+template <bool LDS> SB_HD void pl_round_drop_t(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
+  const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t pq = rd & 1u;
   const uint32_t nc = sh->nclaim[pq] < PL_QCAP ? sh->nclaim[pq] : PL_QCAP;
   uint32_t lg = 3;
@@ -492,18 +521,22 @@ template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid,
   const uint32_t grp = tid >> lg, lane = tid & ((1u << lg) - 1u), ngrp = nt >> lg;
   for (uint32_t i = grp; i < nc; i += ngrp) {
     const uint32_t r = sh->claim_r[i], col = sh->claim_c[i];
-    pl_drop_column(c, col, (c.rowinfo[r] & PL_LEVEL_MASK) + 1u, pq ^ 1u, lane, 1u << lg);
+    pl_drop_column(c, s, col, (s.rowinfo[r] & PL_LEVEL_MASK) + 1u, pq ^ 1u, lane, 1u << lg);
   }
   if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
 }
+template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  PL_PEEL_DISPATCH(pl_round_drop_t, c, rd, tid, nt);
+}
 /* No claimant in the frontier: find the open row with the fewest V columns (workgroup-wide atomic min) */
-template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+template <bool LDS> SB_HD void pl_inact_find_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
+  const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24; /* rep-th row of this inactivation event */
   uint32_t best = PL_NONE;
   for (uint32_t r = tid; r < sh->M; r += nt) {
-    if (!(c.rowinfo[r] & PL_UNASSIGNED)) continue;
-    const uint32_t cnt = c.rowstate[r] >> 24;
+    if (!(s.rowinfo[r] & PL_UNASSIGNED)) continue;
+    const uint32_t cnt = s.rowstate[r] >> 24;
     if (cnt >= 2u) {
       const uint32_t key = (cnt << 16) | r;
       if (key < best) best = key;
@@ -512,17 +545,21 @@ template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rdrep, uint32_t t
   if (best != PL_NONE) PL_ATOM_MIN(&sh->best, best);
   if (tid == 0 && rep == 0) { sh->nq[(rd & 1u) ^ 1u] = 0; sh->nclaim[rd & 1u] = 0; }
 }
+template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  PL_PEEL_DISPATCH(pl_inact_find_t, c, rdrep, tid, nt);
+}
 /* inactivate all but one V column of that row (or every remaining V column if no row is left) */
-template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
+  const PlPeel s = pl_peel_state<LDS>(c);
   const rq_params &p = c.p;
   const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
   if (sh->best == PL_NONE) {
     if (rep != 0) return; /* later rows of an event: nothing left to take, peeling resumes */
     for (uint32_t col = tid; col < p.W; col += nt) {
-      if (c.colinfo[col] == 0u) {
+      if (s.colinfo[col] == 0u) {
         const uint32_t x = p.P + PL_ATOM_ADD(&sh->ninact, 1u);
-        if (x < c.ucap) { c.colinfo[col] = (PL_ST_INACT << 30) | x; c.ucol[x] = (uint16_t)col; }
+        if (x < c.ucap) { s.colinfo[col] = (PL_ST_INACT << 30) | x; c.ucol[x] = (uint16_t)col; }
         else sh->status = PL_FAIL_CAPACITY;
       }
     }
@@ -536,25 +573,29 @@ template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rdrep, uint32_
   uint32_t keep = PL_NONE, keepdeg = PL_NONE, m = 0;
   for (uint32_t k = 0; k < n; k++) {
     const uint32_t col = cols[k];
-    if (c.colinfo[col] != 0u) continue;
+    if (s.colinfo[col] != 0u) continue;
     const uint32_t dg = (c.b_cptr[col + 1] - c.b_cptr[col]) + (c.pc_ptr[col + 1] - c.pc_ptr[col]);
     if (dg < keepdeg) { keepdeg = dg; keep = col; }
   }
   for (uint32_t k = 0; k < n; k++) {
     const uint32_t col = cols[k];
-    if (c.colinfo[col] != 0u || col == keep) continue;
+    if (s.colinfo[col] != 0u || col == keep) continue;
     const uint32_t x = p.P + sh->ninact;
     if (x >= c.ucap || m >= PL_QCAP) { sh->status = PL_FAIL_CAPACITY; break; }
     sh->ninact++;
-    c.colinfo[col] = (PL_ST_INACT << 30) | x;
+    s.colinfo[col] = (PL_ST_INACT << 30) | x;
     c.ucol[x] = (uint16_t)col;
     sh->claim_c[m++] = (uint16_t)col;
   }
   sh->nclaim[rd & 1u] = m; /* "columns to drop" */
   sh->nV -= m;
 }
-template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  PL_PEEL_DISPATCH(pl_inact_apply_a_t, c, rdrep, tid, nt);
+}
+template <bool LDS> SB_HD void pl_inact_apply_b_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
+  const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
   const uint32_t pq = rd & 1u;
   if (sh->best == PL_NONE) {
@@ -563,8 +604,11 @@ template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rdrep, uint32_
     return;
   }
   const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
-  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column(c, sh->claim_c[i], 0u, pq ^ 1u, lane, 32u);
+  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column(c, s, sh->claim_c[i], 0u, pq ^ 1u, lane, 32u);
   if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; }
+}
+template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  PL_PEEL_DISPATCH(pl_inact_apply_b_t, c, rdrep, tid, nt);
 }
 /* between two rows of one event: forget the previous choice */
 template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
