@@ -424,6 +424,14 @@ template <int WB> __device__ __forceinline__ uint32_t row_addr_lo(uint32_t op) {
   asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(op));
   return r;
 }
+__device__ __forceinline__ uint32_t t4_addr(uint32_t base, uint32_t x, uint32_t byte) { /* base + byte `byte` of x */
+  uint32_t r;
+  if (byte == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(base), "v"(x));
+  else if (byte == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(base), "v"(x));
+  else if (byte == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(base), "v"(x));
+  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(base), "v"(x));
+  return r;
+}
 template <int WB> __device__ __forceinline__ typename RowVal<WB>::type ph_row_read(const StripCtx<WB> &, uint32_t op) {
   const uint32_t a = row_addr_hi<WB>(op);
   if constexpr (WB == 2) return *NRQ_LDSP(uint16_t, a);
@@ -685,6 +693,27 @@ SB_HD void backsub_one(const StripCtx<WB> &c, const uint8_t *t4, uint32_t slot, 
   for (uint32_t w = 0; w < (uint32_t)NW; w++) {
     if (w >= wpr) break; /* tables exist for wpr*8 groups only */
     const uint32_t bits = bitsw[w];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (WB == 16) {
+      /* the phase is bound by VALU issue and LDS reads about equally (the 4 XORs per lookup are a given): both
+       * nibbles of every byte are brought to "16 * nibble" in place with three operations per word, and a table
+       * address is ONE byte-select add (the compiler's own sequence is shift, mask, add per lookup).
+       * 8-bit tables in passes were measured too: half the lookups, but 64 lanes then read 64 different entries
+       * instead of at most 16, and the phase becomes LDS-bandwidth bound at 1.6x the time. */
+      uint32_t odd = bits & 0xF0F0F0F0u, even = (bits << 4) & 0xF0F0F0F0u;
+      asm volatile("" : "+v"(odd), "+v"(even)); /* keep the packed form */
+      const uint32_t tb = (uint32_t)(uintptr_t)t4;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) {
+        const uint32_t a = t4_addr(tb, (q & 1u) ? odd : even, q >> 1) + (w * 8u + q) * 256u;
+        const uint4 v = *NRQ_LDSP(uint4, a);
+        acc.w[0] ^= v.x; acc.w[1] ^= v.y; acc.w[2] ^= v.z; acc.w[3] ^= v.w;
+        if (q == 3) NRQ_SCHED_FENCE();
+      }
+      NRQ_SCHED_FENCE();
+      continue;
+    }
+#endif
 #pragma unroll
     for (uint32_t q = 0; q < 8; q++) {
       const uint32_t nib = (bits >> (4u * q)) & 15u;
