@@ -69,7 +69,12 @@ typedef struct nrq_planjob {
 #define PL_ATOM_OR(p, v) atomicOr((p), (v))
 #define PL_ATOM_XOR(p, v) atomicXor((p), (v))
 #define PL_ATOM_CAS(p, c, v) atomicCAS((p), (c), (v))
+/* minimum over the wave (every lane must call it), so that one lane per wave goes to the shared word */
+#define PL_WAVE_MIN(v) __reduce_min_sync(~0ull, (unsigned int)(v))
+#define PL_WAVE_LEADER(tid) (((tid) & 63u) == 0u)
 #else
+#define PL_WAVE_MIN(v) (v)
+#define PL_WAVE_LEADER(tid) true
 static inline uint32_t pl_add_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t pl_sub_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o - v; return o; }
 static inline uint32_t pl_max_(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
@@ -542,7 +547,8 @@ template <bool LDS> SB_HD void pl_inact_find_t(PlanCtx &c, uint32_t rdrep, uint3
       if (key < best) best = key;
     }
   }
-  if (best != PL_NONE) PL_ATOM_MIN(&sh->best, best);
+  best = PL_WAVE_MIN(best);
+  if (best != PL_NONE && PL_WAVE_LEADER(tid)) PL_ATOM_MIN(&sh->best, best);
   if (tid == 0 && rep == 0) { sh->nq[(rd & 1u) ^ 1u] = 0; sh->nclaim[rd & 1u] = 0; }
 }
 template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
