@@ -268,6 +268,7 @@ enum {
   pl_tag_pl_inact_apply_a = 6,
   pl_tag_pl_inact_apply_b = 6,
   pl_tag_pl_inact_next = 6,
+  pl_tag_pl_lev_0 = 7,
   pl_tag_pl_lev_a = 7,
   pl_tag_pl_lev_b = 7,
   pl_tag_pl_w_init = 8,

@@ -71,9 +71,11 @@ typedef struct nrq_planjob {
 #define PL_ATOM_CAS(p, c, v) atomicCAS((p), (c), (v))
 /* minimum over the wave (every lane must call it), so that one lane per wave goes to the shared word */
 #define PL_WAVE_MIN(v) __reduce_min_sync(~0ull, (unsigned int)(v))
+#define PL_WAVE_MAX(v) __reduce_max_sync(~0ull, (unsigned int)(v))
 #define PL_WAVE_LEADER(tid) (((tid) & 63u) == 0u)
 #else
 #define PL_WAVE_MIN(v) (v)
+#define PL_WAVE_MAX(v) (v)
 #define PL_WAVE_LEADER(tid) true
 static inline uint32_t pl_add_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t pl_sub_(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o - v; return o; }
@@ -113,7 +115,7 @@ typedef struct pl_shared {
   uint32_t tmp_mhoff; /* byte offset of MhT inside the dense LDS region (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
   uint16_t queue[2][PL_QCAP];
-  uint16_t claim_r[PL_QCAP], claim_c[PL_QCAP];
+  uint16_t claim_l[PL_QCAP], claim_c[PL_QCAP]; /* columns claimed this round: level + 1 of the pivot, column */
   uint32_t partial[PL_NT];
   uint32_t freex[NRQ_MAX_FREE];
   uint8_t gf_exp[512], gf_log[256];
@@ -503,9 +505,8 @@ template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_
     const uint32_t i = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
     s.rowinfo[r] = (info & PL_PATCHED) | lv; /* assigned: bit 31 cleared */
     s.colinfo[col] = (PL_ST_PIVOT << 30) | k;
-    PL_ATOM_MAX(&sh->nlev, lv + 1u);
-    PL_ATOM_SUB(&sh->nV, 1u);
-    if (i < PL_QCAP) { sh->claim_r[i] = (uint16_t)r; sh->claim_c[i] = (uint16_t)col; } else sh->status = PL_FAIL_CAPACITY;
+    PL_ATOM_SUB(&sh->nV, 1u); /* (the number of levels is taken from the pivots once peeling is over: pl_lev_0) */
+    if (i < PL_QCAP) { sh->claim_l[i] = (uint16_t)(lv + 1u); sh->claim_c[i] = (uint16_t)col; } else sh->status = PL_FAIL_CAPACITY;
     c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
     c.pivcol[k] = (uint16_t)col;
   }
@@ -525,8 +526,7 @@ template <bool LDS> SB_HD void pl_round_drop_t(PlanCtx &c, uint32_t rd, uint32_t
   while (lg < 6u && (nc << (lg + 1u)) <= nt) lg++;
   const uint32_t grp = tid >> lg, lane = tid & ((1u << lg) - 1u), ngrp = nt >> lg;
   for (uint32_t i = grp; i < nc; i += ngrp) {
-    const uint32_t r = sh->claim_r[i], col = sh->claim_c[i];
-    pl_drop_column(c, s, col, (s.rowinfo[r] & PL_LEVEL_MASK) + 1u, pq ^ 1u, lane, 1u << lg);
+    pl_drop_column(c, s, sh->claim_c[i], sh->claim_l[i], pq ^ 1u, lane, 1u << lg);
   }
   if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
 }
@@ -656,6 +656,17 @@ SB_HD uint32_t pl_op_group(const uint16_t *collev, uint32_t t, uint32_t r, uint3
   uint32_t h = r * 0x9E3779B1u ^ col * 0x85EBCA6Bu;
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
   return e + h % (t - e);
+}
+/* number of levels = deepest pivot + 1 (one reduction here instead of an atomic per claim) */
+template <int Z> SB_HD void pl_lev_0(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  uint32_t m = 0;
+  for (uint32_t k = tid; k < sh->npiv; k += nt) {
+    const uint32_t lv = (c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK) + 1u;
+    if (lv > m) m = lv;
+  }
+  m = PL_WAVE_MAX(m);
+  if (m && PL_WAVE_LEADER(tid)) PL_ATOM_MAX(&sh->nlev, m);
 }
 template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;

@@ -20,8 +20,11 @@
   {
     const uint32_t guard_max = 4u * c.p.L + 64u;
     uint32_t rd_ = 0;
-    while (sh_->status == 0 && sh_->nV > 0 && rd_ < guard_max) {
-      if (sh_->nq[rd_ & 1u] > 0) {
+    for (;;) {
+      /* (one LDS round trip for the three words, not one per test: a round is a chain of such trips) */
+      const uint32_t st_ = sh_->status, nv_ = sh_->nV, nq_ = sh_->nq[rd_ & 1u];
+      if (st_ != 0 || nv_ == 0 || rd_ >= guard_max) break;
+      if (nq_ > 0) {
         PL_PHASE1(pl_round_claim, rd_);
         PL_PHASE1(pl_round_drop, rd_);
       } else {
@@ -38,6 +41,7 @@
       rd_++;
     }
   }
+  PL_PHASE(pl_lev_0);
   PL_PHASE(pl_lev_a);
   if (sh_->status == 0 && sh_->nV == 0) {
     PL_PHASE(pl_lev_b);
