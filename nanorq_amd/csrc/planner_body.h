@@ -107,7 +107,7 @@ typedef struct pl_shared {
   uint32_t nV, npiv, ninact, nlev;
   uint32_t nq[2], nclaim[2]; /* frontier / claim counts, indexed by round parity */
   uint32_t best;
-  uint32_t nlow, r2, nfree, cand[2];
+  uint32_t nlow, r2, nfree, cand[3];
   uint32_t arena_top, nrows, nops_real, opbase;
   uint32_t uslot_fill, tmp0, tmp1;
   uint32_t off_ops, off_sync, nsyncw;
@@ -339,7 +339,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->npatch = st ? 0 : nr;
     sh->nV = p.W; sh->npiv = 0; sh->ninact = 0; sh->nlev = 0;
     sh->nq[0] = sh->nq[1] = 0; sh->nclaim[0] = sh->nclaim[1] = 0; sh->best = PL_NONE;
-    sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = PL_NONE;
+    sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = sh->cand[2] = PL_NONE;
     sh->nrows = 0; sh->nops_real = 0; sh->uslot_fill = 0;
     sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE;
   }
@@ -1111,41 +1111,56 @@ template <int Z> SB_HD void pl_mh_acc(PlanCtx &c, uint32_t tile, uint32_t tid, u
 }
 
 /* =============================== phase 6: GF(2) Gauss-Jordan in LDS =========================== */
-/* step A of column x: every leftover row publishes its bit; unused rows with the bit set bid */
+/* Column x: the unused row with the lowest index that has the column becomes its pivot row (atomic-min bids in
+ * cand[x % 3]); the column is eliminated from every other row that has it.  gj_flag[j] bit (x & 1) = row j has
+ * column x.  One barrier per column: while step B of column x rewrites the rows, the thread that owns the word with
+ * bit x+1 of a row publishes that bit and bids for column x+1 (step A is only run for a column that has no
+ * predecessor step).  Slot (x + 2) % 3 is cleared for the bids of the step after. */
 template <int Z> SB_HD void pl_gj_a(PlanCtx &c, uint32_t x, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   const uint32_t *Mb = pl_mb(c);
   const uint32_t rowlen = sh->rowlen;
   for (uint32_t j = tid; j < sh->nlow; j += nt) {
     const uint32_t f = (Mb[(size_t)j * rowlen + (x >> 5)] >> (x & 31u)) & 1u;
-    sh->gj_flag[j] = (uint8_t)f;
-    if (f && !sh->gj_used[j]) PL_ATOM_MIN(&sh->cand[x & 1u], j);
+    sh->gj_flag[j] = (uint8_t)(f << (x & 1u));
+    if (f && !sh->gj_used[j]) PL_ATOM_MIN(&sh->cand[x % 3u], j);
   }
-  if (tid == 0) sh->cand[(x & 1u) ^ 1u] = PL_NONE;
 }
-/* step B: eliminate the column from every other row that has it (or record a free column) */
-template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t x, uint32_t tid, uint32_t nt) {
+/* step B: eliminate the column from every other row that has it (or record a free column);
+ * bit 31 of the argument: prepare column x + 1 */
+template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t xarg, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  const uint32_t pr = sh->cand[x & 1u];
-  if (pr == PL_NONE) {
-    if (tid == 0) {
-      if (sh->nfree < NRQ_MAX_FREE) sh->freex[sh->nfree] = x;
-      sh->nfree++;
-    }
-    return;
-  }
+  const uint32_t x = xarg & 0x7FFFFFFFu, prep = xarg >> 31, xn = x + 1u;
+  const uint32_t pr = sh->cand[x % 3u];
   uint32_t *Mb = pl_mb(c);
   const uint32_t rowlen = sh->rowlen, total = sh->nlow * rowlen;
-  const uint32_t *src = Mb + (size_t)pr * rowlen;
-  for (uint32_t e = tid; e < total; e += nt) {
-    const uint32_t j = e / rowlen, wd = e - j * rowlen;
-    if (j != pr && sh->gj_flag[j]) Mb[e] ^= src[wd];
+  const uint32_t inv = 0xFFFFFFFFu / rowlen + 1u; /* e / rowlen == mulhi(e, inv) for e < 2^16 * rowlen */
+  const uint32_t *src = Mb + (size_t)(pr == PL_NONE ? 0u : pr) * rowlen;
+  const uint32_t cur = x & 1u, nxt = xn & 1u, wn = xn >> 5;
+  if (pr != PL_NONE || prep) {
+    for (uint32_t e = tid; e < total; e += nt) {
+      const uint32_t j = (uint32_t)(((uint64_t)e * inv) >> 32), wd = e - j * rowlen;
+      const uint32_t fl = sh->gj_flag[j];
+      uint32_t v = Mb[e];
+      if (pr != PL_NONE && j != pr && ((fl >> cur) & 1u)) { v ^= src[wd]; Mb[e] = v; }
+      if (prep && wd == wn) {
+        const uint32_t f = (v >> (xn & 31u)) & 1u;
+        sh->gj_flag[j] = (uint8_t)((fl & (1u << cur)) | (f << nxt)); /* (the only writer of this byte in this phase) */
+        if (f && j != pr && !sh->gj_used[j]) PL_ATOM_MIN(&sh->cand[xn % 3u], j);
+      }
+    }
   }
   if (tid == 0) {
-    sh->gj_used[pr] = 1;
-    c.red_row[sh->r2] = pr;
-    c.red_x[sh->r2] = x;
-    sh->r2++;
+    sh->cand[(x + 2u) % 3u] = PL_NONE;
+    if (pr == PL_NONE) {
+      if (sh->nfree < NRQ_MAX_FREE) sh->freex[sh->nfree] = x;
+      sh->nfree++;
+    } else {
+      sh->gj_used[pr] = 1;
+      c.red_row[sh->r2] = pr;
+      c.red_x[sh->r2] = x;
+      sh->r2++;
+    }
   }
 }
 
@@ -1315,7 +1330,7 @@ template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   c.lowslot[j] = (uint16_t)row;
   sh->gj_used[j] = 0;
   sh->M = row + 1u; sh->npatch = i + 1u; sh->nlow = j + 1u; sh->nextra++;
-  sh->cand[0] = sh->cand[1] = PL_NONE;
+  sh->cand[0] = sh->cand[1] = sh->cand[2] = PL_NONE;
 }
 /* its bit row over the inactive columns: own inactive entries plus the W rows of its pivot columns */
 template <int Z> SB_HD void pl_extra_b(PlanCtx &c, uint32_t tid, uint32_t nt) {

@@ -81,9 +81,10 @@
     }
     {
       const uint32_t u_ = c.p.L - sh_->npiv;
+      if (u_) PL_PHASE1(pl_gj_a, 0u);
       for (uint32_t x_ = 0; x_ < u_; x_++) {
-        PL_PHASE1(pl_gj_a, x_);
-        PL_PHASE1(pl_gj_b, x_);
+        const uint32_t a_ = x_ | (x_ + 1u < u_ ? 0x80000000u : 0u); /* step B also prepares the next column */
+        PL_PHASE1(pl_gj_b, a_);
       }
     }
     /* the free columns over GF(256); while that fails and the caller holds further symbols, add one row */
