@@ -1111,7 +1111,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   if (ucap > 1280u) ucap = 1280u; /* 40 words per W row at most */
   if (ucap < p.P + 32u) return fail(ctx, -5, "K'=%u has too many permanently inactive columns for the device planner", p.Kp);
   const uint32_t Mcap = p.L + max_oh + PL_EXTRA_ROWS + 8u, npcap = max_nrep + PL_EXTRA_ROWS + 8u;
-  const pl_work_layout wl = pl_work_plan(p.L, Mcap, npcap, ucap);
+  const pl_work_layout wl = pl_work_plan(p.L, Mcap, npcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE);
   const uint32_t arena_cap = pl_arena_bound(p.L, Mcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE, max_nl + 8u);
   if ((rc = ensure_dev(ctx, ctx->plan_work, (size_t)nblk * wl.total))) return rc;
   if ((rc = ensure_dev(ctx, ctx->plan_arena, (size_t)nblk * arena_cap))) return rc;

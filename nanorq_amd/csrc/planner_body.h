@@ -108,7 +108,7 @@ typedef struct pl_shared {
   uint32_t nq[2], nclaim[2]; /* frontier / claim counts, indexed by round parity */
   uint32_t best;
   uint32_t nlow, r2, nfree, cand[3];
-  uint32_t arena_top, nrows, nops_real, opbase;
+  uint32_t arena_top, nrows, nrec, opbase; /* nrec: op records written by pl_w_init */
   uint32_t uslot_fill, tmp0, tmp1;
   uint32_t off_ops, off_sync, nsyncw;
   uint32_t lv_in_lds, opq_group[2];
@@ -129,10 +129,11 @@ typedef struct pl_shared {
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
   uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, ucol, wrows,
-      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, total;
+      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, total;
 } pl_work_layout;
 
-SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uint32_t ucap) {
+/* nnzcap: entries of the base structure plus the patch rows (bounds the number of row ops) */
+SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uint32_t ucap, uint32_t nnzcap) {
   pl_work_layout w;
   uint32_t o = 0;
   const uint32_t wprcap = (ucap + 31u) / 32u;
@@ -155,6 +156,10 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.lev_fin = o;    o = pl_r16(o + (L + 2u) * 4u);
   w.red_row = o;    o = pl_r16(o + ucap * 4u);
   w.red_x = o;      o = pl_r16(o + ucap * 4u);
+  /* op records (pl_w_init -> pl_ops_emit): op word, place inside its group, group */
+  w.rec_word = o;   o = pl_r16(o + nnzcap * 4u);
+  w.rec_idx = o;    o = pl_r16(o + nnzcap * 4u);
+  w.rec_g = o;      o = pl_r16(o + nnzcap * 2u);
   w.total = o;
   return w;
 }
@@ -197,7 +202,9 @@ struct PlanCtx {
   uint16_t *patch_of, *patch_cols, *pc_rows, *ucol;
   uint8_t *patch_len;
   uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *lev_fin, *red_row,
-      *red_x;
+      *red_x, *rec_word, *rec_idx;
+  uint16_t *rec_g;
+  uint32_t reccap;
   /* arena views (fixed part laid out up front) */
   uint8_t *arena;
   nrq_plan_hdr *hdr;
@@ -235,7 +242,8 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.lds_dyn = lds_dyn;
   c.lds_dyn_bytes = lds_dyn_bytes;
   c.Mcap = Mcap; c.npcap = npcap; c.ucap = ucap;
-  c.wl = pl_work_plan(c.p.L, Mcap, npcap, ucap);
+  c.reccap = c.kh->nnz + npcap * PL_PATCH_STRIDE;
+  c.wl = pl_work_plan(c.p.L, Mcap, npcap, ucap, c.reccap);
   c.work = PL_HBM(uint8_t, job.work);
   uint8_t *w = c.work;
   c.rowstate = reinterpret_cast<uint32_t *>(w + c.wl.rowstate);
@@ -274,6 +282,9 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.lev_fin = reinterpret_cast<uint32_t *>(w + c.wl.lev_fin);
   c.red_row = reinterpret_cast<uint32_t *>(w + c.wl.red_row);
   c.red_x = reinterpret_cast<uint32_t *>(w + c.wl.red_x);
+  c.rec_word = reinterpret_cast<uint32_t *>(w + c.wl.rec_word);
+  c.rec_idx = reinterpret_cast<uint32_t *>(w + c.wl.rec_idx);
+  c.rec_g = reinterpret_cast<uint16_t *>(w + c.wl.rec_g);
   /* arena: header, then the arrays whose size is bounded by (L, ucap) */
   c.arena = PL_HBM(uint8_t, job.arena);
   c.hdr = reinterpret_cast<nrq_plan_hdr *>(c.arena);
@@ -340,7 +351,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->nV = p.W; sh->npiv = 0; sh->ninact = 0; sh->nlev = 0;
     sh->nq[0] = sh->nq[1] = 0; sh->nclaim[0] = sh->nclaim[1] = 0; sh->best = PL_NONE;
     sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = sh->cand[2] = PL_NONE;
-    sh->nrows = 0; sh->nops_real = 0; sh->uslot_fill = 0;
+    sh->nrows = 0; sh->nrec = 0; sh->uslot_fill = 0;
     sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE;
   }
   /* GF(256) tables into LDS (RFC 6330 section 5.7): generated by one thread, 255 steps */
@@ -689,6 +700,21 @@ template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   for (uint32_t k = tid; k < sh->npiv; k += nt) c.pivdeg[k] = 0;
   for (uint32_t k = tid; k < sh->M; k += nt) c.lowdeg[k] = 0;
 }
+/* One row op found by pl_w_init (LDS-counter path): counted in its group -- the counter's old value is its place
+ * among the group's finishing / early ops -- and recorded for pl_ops_emit, which then is a plain permutation pass
+ * instead of a second walk over the rows (a walk is a chain of dependent trips to L2 per row). */
+SB_HD void pl_record_op(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16_t *collev, uint32_t lev, uint32_t r,
+                        uint32_t col, uint32_t info) {
+  const uint32_t g = pl_op_group(collev, lev, r, col);
+  const uint32_t early = g == lev ? 0u : 0x80000000u;
+  const uint32_t idx = PL_ATOM_ADD(early ? &cntN[g] : &cntF[g], 1u);
+  const uint32_t src = c.pivslot[info & 0x3FFFFFFFu];
+  const uint32_t i = PL_ATOM_ADD(&c.sh->nrec, 1u);
+  if (i >= c.reccap) { c.sh->status = PL_FAIL_CAPACITY; return; }
+  c.rec_word[i] = NRQ_OP(r, src);
+  c.rec_idx[i] = early | idx;
+  c.rec_g[i] = (uint16_t)g;
+}
 /* W starts as A restricted to the inactive columns, row by slot; op counts per row and per level group.
  * Ordinary rows: 8 lanes per row, sharing its entries.  The long LDPC rows (r < S): 64 lanes each (pl_w_init_b). */
 template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
@@ -742,10 +768,8 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
         const uint32_t info = c.colinfo[col], idx = info & 0x3FFFFFFFu;
         if ((info >> 30) == PL_ST_INACT) PL_ATOM_XOR(&dst[idx >> 5], 1u << (idx & 31u));
         else if (col != own[j]) {
-          if (collev) {
-            const uint32_t g = pl_op_group(collev, lev, r[j], col);
-            PL_ATOM_ADD(g == lev ? &cntF[g] : &cntN[g], 1u);
-          } else deg++;
+          if (collev) pl_record_op(c, cntF, cntN, collev, lev, r[j], col, info);
+          else deg++;
         }
       }
       if (deg) { /* no LDS counters: the row's ops as one run of its level group */
@@ -776,10 +800,8 @@ template <int Z> SB_HD void pl_w_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
       const uint32_t info = c.colinfo[col], idx = info & 0x3FFFFFFFu;
       if ((info >> 30) == PL_ST_INACT) PL_ATOM_XOR(&dst[idx >> 5], 1u << (idx & 31u));
       else if (col != own) {
-        if (collev) {
-          const uint32_t g = pl_op_group(collev, lev, r, col);
-          PL_ATOM_ADD(g == lev ? &cntF[g] : &cntN[g], 1u);
-        } else deg++;
+        if (collev) pl_record_op(c, cntF, cntN, collev, lev, r, col, info);
+        else deg++;
       }
     }
     if (deg) {
@@ -1017,6 +1039,17 @@ SB_HD uint32_t pl_spread(uint32_t pos, uint32_t n) {
     if (n % mult[q]) m = mult[q];
   return (uint32_t)(((uint64_t)pos * m) % n);
 }
+/* The lanes that walk ONE constraint row take consecutive places of a group's counter; 64 consecutive places are one
+ * row of the op stream, i.e. one wave instruction of LDS atomics on the same target slot.  A bijection of [0, n)
+ * that keeps the lane (place mod 64) and shifts the stream row by it sends consecutive places to different rows. */
+SB_HD uint32_t pl_shear(uint32_t idx, uint32_t n) {
+  const uint32_t R = n / NRQ_ROW; /* whole rows; the ragged tail stays where it is */
+  if (idx >= R * NRQ_ROW || R < 2u) return idx;
+  const uint32_t b = idx % NRQ_ROW;
+  uint32_t a = idx / NRQ_ROW + b;
+  while (a >= R) a -= R;
+  return a * NRQ_ROW + b;
+}
 /* the ops of constraint row r (dst; on level `lev`), each into its group (pl_op_group): finishing ops fill the
  * group from the front, early ops follow them; the place inside either part is whatever the counter hands out,
  * which also keeps the ops of one row apart */
@@ -1040,6 +1073,16 @@ SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t lev, uint3
 template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
+  if (pl_col_level(c)) { /* the ops were recorded with their place: finishing ops from the front of the group, early ops behind them */
+    uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
+    for (uint32_t i = tid; i < sh->nrec; i += nt) {
+      const uint32_t m = c.rec_idx[i], g = c.rec_g[i];
+      const uint32_t nf = c.lev_fin[g];
+      const uint32_t pos = (m >> 31) ? nf + pl_shear(m & 0x7FFFFFFFu, c.lev_ops[g] - nf) : pl_shear(m, nf);
+      ops[(size_t)c.lev_base[g] * NRQ_ROW + pos] = c.rec_word[i];
+    }
+    return;
+  }
   for (uint32_t k = tid; k < sh->npiv; k += nt) {
     const uint32_t r = c.pivslot[k], l = c.rowinfo[r] & PL_LEVEL_MASK;
     if (l) pl_emit_row(c, r, c.pivcol[k], l, c.pivdeg[k]); /* level 0 rows have nothing to gather */

@@ -51,7 +51,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   if (nrep_avail < nrep) nrep_avail = nrep;
   const uint32_t ohcap = nrep_avail > nlost ? nrep_avail - nlost : 0;
   const uint32_t Mcap = kh->L + ohcap + PL_EXTRA_ROWS + 8, npcap = nrep_avail + PL_EXTRA_ROWS + 8, ucap = kh->P + 768u;
-  pl_work_layout wl = pl_work_plan(kh->L, Mcap, npcap, ucap);
+  pl_work_layout wl = pl_work_plan(kh->L, Mcap, npcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE);
   std::vector<uint8_t> work(wl.total + 64, 0xCC), dyn(lds_dyn_bytes + 64, 0xDD);
   pl_shared *sh = new pl_shared;
   memset(sh, 0xEE, sizeof(*sh));
