@@ -111,7 +111,8 @@ typedef struct nrq_kconst_hdr {
   uint32_t off_ridx;    /* u16[nnz]: base CSC row indices, ascending per column */
   uint32_t off_state;   /* u32[L]: per base row, (count << 24 | sum) of its column ids below W */
   uint32_t off_gt;      /* u8[n*16]: the HDPC block transposed, 16 bytes per column (rows >= H are 0) */
-  uint32_t reserved[2];
+  uint32_t off_erow;    /* u16[nnz]: the row of every base CSR entry (lets a pass run over entries, not rows) */
+  uint32_t reserved[1];
 } nrq_kconst_hdr;
 
 #endif

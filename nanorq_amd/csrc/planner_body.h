@@ -183,7 +183,7 @@ struct PlanCtx {
   const uint8_t *kc;
   const nrq_kconst_hdr *kh;
   const uint32_t *b_rptr, *b_cptr, *b_state;
-  const uint16_t *b_cidx, *b_ridx;
+  const uint16_t *b_cidx, *b_ridx, *b_erow;
   const uint8_t *G, *GT;
   nrq_planjob job;
   const uint32_t *lost, *rep_esi;
@@ -232,6 +232,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.b_cidx = reinterpret_cast<const uint16_t *>(kc + c.kh->off_cidx);
   c.b_cptr = reinterpret_cast<const uint32_t *>(kc + c.kh->off_cptr);
   c.b_ridx = reinterpret_cast<const uint16_t *>(kc + c.kh->off_ridx);
+  c.b_erow = reinterpret_cast<const uint16_t *>(kc + c.kh->off_erow);
   c.b_state = reinterpret_cast<const uint32_t *>(kc + c.kh->off_state);
   c.G = kc + c.kh->off_g;
   c.GT = kc + c.kh->off_gt;
@@ -717,6 +718,41 @@ SB_HD void pl_record_op(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16
 }
 /* W starts as A restricted to the inactive columns, row by slot; op counts per row and per level group.
  * Ordinary rows: 8 lanes per row, sharing its entries.  The long LDPC rows (r < S): 64 lanes each (pl_w_init_b). */
+/* one entry (row r, column col) of the constraint matrix: an inactive column toggles its bit of the row's W row,
+ * a pivot column other than the row's own is a row op */
+#define PL_WU 4u /* entries a thread has in flight: every step below is a trip to L2 or beyond (the planner's working
+                   set, ~2 MB per block, does not stay in the 4 MB of L2 that 32 blocks share) */
+SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16_t *collev, const uint32_t (&r)[PL_WU],
+                        const uint32_t (&col)[PL_WU], const bool (&use)[PL_WU], bool base) {
+  uint32_t rinfo[PL_WU], info[PL_WU], src[PL_WU];
+  bool on[PL_WU];
+#pragma unroll
+  for (uint32_t j = 0; j < PL_WU; j++) {
+    rinfo[j] = use[j] ? c.rowinfo[r[j]] : 0u;
+    info[j] = use[j] ? c.colinfo[col[j]] : 0u;
+    on[j] = use[j] && !(base && (rinfo[j] & PL_PATCHED)); /* (not: a base entry of a row this block replaced) */
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < PL_WU; j++)
+    src[j] = (on[j] && (info[j] >> 30) == PL_ST_PIVOT) ? c.pivslot[info[j] & 0x3FFFFFFFu] : PL_NONE;
+#pragma unroll
+  for (uint32_t j = 0; j < PL_WU; j++) {
+    if (!on[j]) continue;
+    const uint32_t idx = info[j] & 0x3FFFFFFFu;
+    if ((info[j] >> 30) == PL_ST_INACT) PL_ATOM_XOR(&c.wrows[(size_t)r[j] * c.sh->wpr + (idx >> 5)], 1u << (idx & 31u));
+    else if (src[j] != r[j]) { /* (== : the row's own pivot column) */
+      const uint32_t lev = (rinfo[j] & PL_UNASSIGNED) ? c.sh->nlev : (rinfo[j] & PL_LEVEL_MASK);
+      const uint32_t g = pl_op_group(collev, lev, r[j], col[j]);
+      const uint32_t early = g == lev ? 0u : 0x80000000u;
+      const uint32_t at = PL_ATOM_ADD(early ? &cntN[g] : &cntF[g], 1u);
+      const uint32_t i = PL_ATOM_ADD(&c.sh->nrec, 1u);
+      if (i >= c.reccap) { c.sh->status = PL_FAIL_CAPACITY; continue; }
+      c.rec_word[i] = NRQ_OP(r[j], src[j]);
+      c.rec_idx[i] = early | at;
+      c.rec_g[i] = (uint16_t)g;
+    }
+  }
+}
 template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   if (sh->status) return;
@@ -724,6 +760,36 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t total = sh->npiv + sh->nlow;
   uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lev_ctr(c, 1);
   const uint16_t *collev = pl_col_level(c);
+  if (collev) {
+    /* with the group counters in LDS every entry stands for itself: one pass over the entries of the base structure
+     * (rows this block patched excepted) and of the patch rows -- coalesced, no walk from row to row */
+    const uint32_t nnz = c.kh->nnz, nl = c.job.nlost, npq = sh->npatch * PL_PATCH_STRIDE;
+    for (uint32_t e0 = tid; e0 < nnz; e0 += PL_WU * nt) {
+      uint32_t r[PL_WU], col[PL_WU];
+      bool use[PL_WU];
+#pragma unroll
+      for (uint32_t j = 0; j < PL_WU; j++) {
+        const uint32_t e = e0 + j * nt;
+        use[j] = e < nnz;
+        r[j] = use[j] ? c.b_erow[e] : 0u;
+        col[j] = use[j] ? c.b_cidx[e] : 0u;
+      }
+      pl_w_entries(c, cntF, cntN, collev, r, col, use, true);
+    }
+    for (uint32_t q0 = tid; q0 < npq; q0 += PL_WU * nt) {
+      uint32_t r[PL_WU], col[PL_WU];
+      bool use[PL_WU];
+#pragma unroll
+      for (uint32_t j = 0; j < PL_WU; j++) {
+        const uint32_t q = q0 + j * nt, i = q / PL_PATCH_STRIDE, k = q - i * PL_PATCH_STRIDE;
+        use[j] = q < npq && k < c.patch_len[i];
+        r[j] = !use[j] ? 0u : i < nl ? c.p.S + c.p.H + c.lost[i] : c.p.L + (i - nl);
+        col[j] = use[j] ? c.patch_cols[q] : 0u;
+      }
+      pl_w_entries(c, cntF, cntN, collev, r, col, use, false);
+    }
+    return;
+  }
   /* item i < npiv: pivot i; otherwise leftover row i - npiv (group nlev).  Each step of a row is a dependent
    * trip to L2/HBM (slot -> patch -> row pointers -> entries), so a lane group works on RB rows at once, stage
    * by stage, to have their loads in flight together. */
@@ -1075,11 +1141,22 @@ template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (sh->status) return;
   if (pl_col_level(c)) { /* the ops were recorded with their place: finishing ops from the front of the group, early ops behind them */
     uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
-    for (uint32_t i = tid; i < sh->nrec; i += nt) {
-      const uint32_t m = c.rec_idx[i], g = c.rec_g[i];
-      const uint32_t nf = c.lev_fin[g];
-      const uint32_t pos = (m >> 31) ? nf + pl_shear(m & 0x7FFFFFFFu, c.lev_ops[g] - nf) : pl_shear(m, nf);
-      ops[(size_t)c.lev_base[g] * NRQ_ROW + pos] = c.rec_word[i];
+    const uint32_t nrec = sh->nrec;
+    for (uint32_t i0 = tid; i0 < nrec; i0 += PL_WU * nt) { /* PL_WU records in flight per thread */
+      uint32_t m[PL_WU], g[PL_WU], w[PL_WU], nf[PL_WU], n[PL_WU], base[PL_WU];
+#pragma unroll
+      for (uint32_t j = 0; j < PL_WU; j++) {
+        const uint32_t i = i0 + j * nt < nrec ? i0 + j * nt : i0;
+        m[j] = c.rec_idx[i]; g[j] = c.rec_g[i]; w[j] = c.rec_word[i];
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < PL_WU; j++) { nf[j] = c.lev_fin[g[j]]; n[j] = c.lev_ops[g[j]]; base[j] = c.lev_base[g[j]]; }
+#pragma unroll
+      for (uint32_t j = 0; j < PL_WU; j++) {
+        if (i0 + j * nt >= nrec) continue;
+        const uint32_t pos = (m[j] >> 31) ? nf[j] + pl_shear(m[j] & 0x7FFFFFFFu, n[j] - nf[j]) : pl_shear(m[j], nf[j]);
+        ops[(size_t)base[j] * NRQ_ROW + pos] = w[j];
+      }
     }
     return;
   }

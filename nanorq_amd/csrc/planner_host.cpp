@@ -126,6 +126,7 @@ extern "C" int nrq_host_kconst_build(uint32_t K, uint8_t **out, uint32_t *out_by
   h.off_ridx = off; off = align16(off + nnz * 2);
   h.off_state = off; off = align16(off + L * 4);
   h.off_gt = off; off = align16(off + n * 16);
+  h.off_erow = off; off = align16(off + nnz * 2);
   h.total_bytes = off;
   uint8_t *buf = (uint8_t *)calloc(off, 1);
   if (!buf) return -2;
@@ -149,6 +150,8 @@ extern "C" int nrq_host_kconst_build(uint32_t K, uint8_t **out, uint32_t *out_by
   memcpy(buf + h.off_cptr, cptr.data(), (size_t)(L + 1) * 4);
   memcpy(buf + h.off_ridx, ridx.data(), (size_t)nnz * 2);
   memcpy(buf + h.off_state, state.data(), (size_t)L * 4);
+  for (uint32_t r = 0; r < L; r++)
+    for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++) reinterpret_cast<uint16_t *>(buf + h.off_erow)[e] = (uint16_t)r;
   for (uint32_t c = 0; c < n; c++)
     for (uint32_t r = 0; r < H; r++) buf[h.off_gt + (size_t)c * 16 + r] = G[(size_t)r * n + c];
   memcpy(buf, &h, sizeof(h));
