@@ -292,8 +292,8 @@ def main():
             eff_ms = busy / len(ktimes)   # busy time attributable to one launch
             achieved = alg_per_launch / (eff_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args), "kernel": "nrq_solve_kernel<%d, %d>" %
-                    (enc_stats["strip_bytes"], enc_stats["wg_threads"]), "avg_launch_ms": avg_ms, "busy_ms_per_launch": eff_ms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args), "kernel": "nrq_solve_kernel<%d, %d, %d>" %
+                    (enc_stats["strip_bytes"], enc_stats["wg_threads"], enc_stats["wg_waves_per_simd"]), "avg_launch_ms": avg_ms, "busy_ms_per_launch": eff_ms,
                     "launches_timed": len(ktimes), "blocks_per_launch": blocks_per_launch,
                     "algorithmic_bytes_per_launch": alg_per_launch,
                     "algorithmic_bytes_per_block": {"encode": balg_enc, "decode": balg_dec},

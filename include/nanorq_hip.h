@@ -12,7 +12,7 @@
  *   decode_row / nanorq_encode (LT symbol generation)                          lib/nanorq.c:184-204, :403-435
  *   oblas oaxpy/oscal/oswaprow row kernels (absent submodule deps/oblas)       precode.c:7,18,20
  * The unit of work is a batch of independent source blocks of equal (K, T) that stay resident in
- * HBM; one 256-thread workgroup solves one 16/8/4/2-byte column strip of one block out of LDS.
+ * HBM; persistent workgroups solve one 16/8/4/2-byte column strip of one block at a time out of LDS.
  */
 #ifndef NANORQ_HIP_H
 #define NANORQ_HIP_H
@@ -39,6 +39,8 @@ typedef struct nrq_call_stats {
   uint32_t npiv, u, nlev, nfree; /* of block 0 */
   uint32_t wg_threads; /* threads per workgroup of the solve launch */
   uint32_t strips_per_slot; /* strips a work slot holds (a whole 128-byte line group unless work is scarce) */
+  uint32_t wg_waves_per_simd; /* register budget of the solve kernel variant launched: waves per SIMD it was compiled for */
+  uint32_t reserved_;
 } nrq_call_stats;
 
 /* One context per GPU (one process per GPU: no cross-device state).  `stream` is a hipStream_t the

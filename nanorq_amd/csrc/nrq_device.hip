@@ -2,7 +2,7 @@
  * nrq_device.hip -- gfx950 kernels and the C ABI of include/nanorq_hip.h.
  *
  * Kernels
- *   nrq_solve_kernel<WB,NT>  the whole data stage of the precode solve: persistent workgroups, one WB-byte column
+ *   nrq_solve_kernel<WB,NT,WV>  the whole data stage of the precode solve: persistent workgroups, one WB-byte column
  *                            strip of one source block at a time, LDS-resident (phases in solve_body.h)
  *   nrq_plan_kernel          the symbolic stage of a decode block (phases in planner_body.h, order in planner_seq.h)
  *   nrq_gen_kernel           LT symbol generation from intermediate symbols in HBM
@@ -82,8 +82,13 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
 /* NT threads per workgroup: NRQ_WG when one strip image owns the CU's LDS (big blocks), 256 when several fit (small
  * blocks: more workgroups per CU beat more waves per workgroup, each has its own single-wave forward pass).
  * `lsub`: log2 of the strips per work slot -- a whole line (128/WB strips) unless that leaves CUs without work. */
-template <int WB, int NT>
-__global__ __launch_bounds__(NT) void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
+/* WV: waves per SIMD the kernel is compiled for, i.e. its register budget (512 / WV).  The 768-thread variant has
+ * the CU to itself (3 waves per SIMD, 168 registers).  The 256-thread variant puts one wave on every SIMD, so WV is
+ * also the number of workgroups a CU holds: 4 (128 registers) or, when the LDS images are small enough for 5
+ * workgroups, 5 (96 registers, a few more spills).  Left to itself the compiler took 207 registers: 2 workgroups. */
+template <int WB, int NT, int WV>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WV)))
+void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
                                                        uint32_t T, uint32_t nstrips, uint32_t by_block, uint32_t nslots,
                                                        uint32_t lsub, const uint8_t *__restrict__ kc,
                                                        uint8_t *__restrict__ stage_all, uint32_t stage_stride,
@@ -599,6 +604,10 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   const uint32_t nt = small ? 256u : (uint32_t)NRQ_WG;
   uint32_t occ = NRQ_LDS_MAX / (lds_bytes ? lds_bytes : 1u);
   if (occ > 2048u / nt) occ = 2048u / nt;
+  /* registers: the 256-thread variant (one wave per SIMD) is compiled for NRQ_SMALL_WAVES waves per SIMD.  More
+   * workgroups than are resident at once would run as a second, thinner round of a statically partitioned job. */
+  const bool five = small && occ >= 5u && !getenv("NRQ_SMALL_WAVES4");
+  if (small && occ > (five ? 5u : 4u)) occ = five ? 5u : 4u;
   if (occ < 1u) occ = 1u;
   /* persistent workgroups fill the device; a multiple of 8 keeps a workgroup's slots on its XCD */
   uint64_t grid = (uint64_t)(ctx->ncu / 8) * 8 * occ;
@@ -624,9 +633,11 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     if (rc_) return rc_;
   }
   if (!ctx->attr_set[slot]) {
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, NRQ_WG>),
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, NRQ_WG, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 256>),
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 256, 4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 256, 5>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     ctx->attr_set[slot] = true;
   }
@@ -649,11 +660,14 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     HIPCHK(ctx, hipMalloc((void **)&ctx->prof, (size_t)nprof * 16 * 8));
     HIPCHK(ctx, hipMemsetAsync(ctx->prof, 0, (size_t)nprof * 16 * 8, ctx->stream));
   }
-  if (small)
-    hipLaunchKernelGGL((nrq_solve_kernel<WB, 256>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
+  if (five)
+    hipLaunchKernelGGL((nrq_solve_kernel<WB, 256, 5>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
+                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
+  else if (small)
+    hipLaunchKernelGGL((nrq_solve_kernel<WB, 256, 4>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
                        by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
   else
-    hipLaunchKernelGGL((nrq_solve_kernel<WB, NRQ_WG>), dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
+    hipLaunchKernelGGL((nrq_solve_kernel<WB, NRQ_WG, 1>), dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
                        by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
   HIPCHK(ctx, hipGetLastError());
   if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
@@ -692,6 +706,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   ctx->stats.grid = (uint32_t)grid;
   ctx->stats.wg_threads = nt;
   ctx->stats.strips_per_slot = 1u << lsub;
+  ctx->stats.wg_waves_per_simd = five ? 5u : small ? 4u : 1u;
   return 0;
 }
 
