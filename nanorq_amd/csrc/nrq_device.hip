@@ -317,7 +317,8 @@ enum {
 
 /* The symbolic stage of one decode block per workgroup (phases in planner_body.h, order in
  * planner_seq.h): reception pattern -> device plan + the block's solve job. */
-__global__ __launch_bounds__(PL_NT) void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
+template <int NT>
+__global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
                                                          const nrq_planjob *__restrict__ pjobs,
                                                          nrq_job *__restrict__ jobs_out, uint32_t nblk, uint32_t Mcap,
                                                          uint32_t npcap, uint32_t ucap, uint32_t lds_dyn_bytes,
@@ -335,8 +336,8 @@ __global__ __launch_bounds__(PL_NT) void nrq_plan_kernel(rq_params p, const uint
   unsigned long long t_prev = prof ? (unsigned long long)clock64() : 0ull;
 #define PL_ACC(tag) do { if (prof && b == 0 && tid == 0) { unsigned long long t_ = (unsigned long long)clock64(); \
                                                           prof[tag] += t_ - t_prev; prof[16 + tag] += 1; t_prev = t_; } } while (0)
-#define PL_PHASE(fn) do { fn<0>(c, tid, PL_NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
-#define PL_PHASE1(fn, a) do { fn<0>(c, (a), tid, PL_NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
+#define PL_PHASE(fn) do { fn<0>(c, tid, (uint32_t)NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
+#define PL_PHASE1(fn, a) do { fn<0>(c, (a), tid, (uint32_t)NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
 #define PL_WFAST_RUN(wb) do { \
     if (tid < NRQ_ROW) { \
       const NRQ_GAS uint32_t *ops_ = gptr<uint32_t>(c.arena + c.sh->off_ops); \
@@ -1167,9 +1168,20 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   }
   HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared));
-  const uint32_t dyn_bytes = NRQ_LDS_MAX - sh_bytes;
+  /* dynamic LDS: everything a CU has for a big block; for small blocks what the planner can use (peeling state plus the
+   * dense-stage reserve, or a 16-byte strip image of the W rows), so that two workgroups share a CU */
+  uint32_t dyn_bytes = NRQ_LDS_MAX - sh_bytes;
+  bool small_wg = false; /* 256-thread workgroups: a small block has no use for 1024 threads, a CU has for 4 blocks */
+  {
+    const uint32_t peel = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L);
+    const uint32_t wimg = (Mcap + 320u + NRQ_SCRATCH) * 16u;
+    const uint32_t fit = pl_r16((peel > wimg ? peel : wimg) + 2048u);
+    if (fit + sh_bytes <= NRQ_LDS_MAX / 2u && !getenv("NRQ_PLAN_LDS_MAX")) { dyn_bytes = fit; small_wg = !getenv("NRQ_PLAN_BIG_WG"); }
+  }
   if (!ctx->plan_attr) {
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel),
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT_MIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     ctx->plan_attr = true;
   }
@@ -1178,9 +1190,14 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     HIPCHK(ctx, hipMalloc((void **)&pprof, 32 * 8));
     HIPCHK(ctx, hipMemsetAsync(pprof, 0, 32 * 8, ctx->stream));
   }
-  hipLaunchKernelGGL(nrq_plan_kernel, dim3(nblk), dim3(PL_NT), NRQ_LDS_MAX, ctx->stream, p, (const uint8_t *)kc->dev,
-                     reinterpret_cast<const nrq_planjob *>(ds + off_pj), reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk,
-                     Mcap, npcap, ucap, dyn_bytes, pprof);
+  if (small_wg)
+    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ctx->stream, p,
+                       (const uint8_t *)kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
+                       reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, dyn_bytes, pprof);
+  else
+    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ctx->stream, p,
+                       (const uint8_t *)kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
+                       reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, dyn_bytes, pprof);
   HIPCHK(ctx, hipGetLastError());
   if (pprof) {
     unsigned long long hp[32];

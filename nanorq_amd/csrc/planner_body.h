@@ -30,7 +30,8 @@
 #include "rq_math.h"
 #include "solve_body.h"
 
-#define PL_NT 1024u
+#define PL_NT 1024u     /* threads of a planner workgroup: big blocks */
+#define PL_NT_MIN 256u  /* small blocks (several workgroups per CU) */
 #define PL_QCAP 2048u          /* frontier / claim queue capacity */
 #define PL_UNASSIGNED 0x80000000u /* rowinfo bit 31: row has no pivot column (yet) */
 #define PL_PATCHED 0x40000000u    /* rowinfo bit 30: this block replaced the base row (its base CSC entries are void) */
@@ -46,7 +47,9 @@
 #define PL_EXTRA_ROWS 8u   /* repair symbols a block may take beyond nrep when rank deficient */
 #define PL_SPARE_ROWS 8u /* op rows reserved for the rows added that way */
 #define PL_LOWCAP 1344u /* leftover rows the dense stage can take (>= inactive-column cap 1280 + 32) */
-#define PL_DENSE_RESERVE (36u * 1024u) /* LDS kept for the dense stage when the peeling state is in LDS too */
+/* LDS kept for the dense stage when the peeling state is in LDS too: 36 KB for big blocks, less for small ones (whose
+ * planner workgroups then share a CU) */
+SB_HD uint32_t pl_dense_reserve(uint32_t L) { const uint32_t r = 12u * 1024u + L * 6u; return r < 36u * 1024u ? (r + 15u) & ~15u : 36u * 1024u; }
 
 /* what the host hands the planner for one block */
 typedef struct nrq_planjob {
@@ -258,7 +261,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.aux_bytes = lds_dyn_bytes;
   {
     uint32_t need = pl_r16(Mcap * 4u) * 2u + pl_r16(c.p.L * 4u);
-    if (lds_dyn && need + PL_DENSE_RESERVE <= lds_dyn_bytes) {
+    if (lds_dyn && need + pl_dense_reserve(c.p.L) <= lds_dyn_bytes) {
       c.rowstate = reinterpret_cast<uint32_t *>(lds_dyn);
       c.rowinfo = reinterpret_cast<uint32_t *>(lds_dyn + pl_r16(Mcap * 4u));
       c.colinfo = reinterpret_cast<uint32_t *>(lds_dyn + 2u * pl_r16(Mcap * 4u));
@@ -914,14 +917,15 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
   const bool staged = lds && sh->opq_group[group & 1u] == group;
   const uint32_t *ops = staged ? pl_aux_opq(c, group & 1u) : gops + (size_t)base * NRQ_ROW;
   /* issue the prefetch of the next group first: its loads overlap with this group's work */
-  uint32_t pf[PL_OPQ_WORDS / PL_NT], pf_n = 0;
+  uint32_t pf[PL_OPQ_WORDS / PL_NT_MIN], pf_n = 0; /* (PL_OPQ_WORDS / nt of them are used) */
   if (lds && group + 1u <= sh->nlev) {
     const uint32_t n2 = pl_group_rows(pl_aux_lvops(c)[group + 1u]) * NRQ_ROW;
     if (n2 <= PL_OPQ_WORDS) {
       pf_n = n2;
       const uint32_t *src = gops + (size_t)pl_aux_lvbase(c)[group + 1u] * NRQ_ROW;
 #pragma unroll
-      for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT; q++) pf[q] = (tid + q * nt) < n2 ? src[tid + q * nt] : 0u /* a padding op */;
+      for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT_MIN; q++)
+        if (q < PL_OPQ_WORDS / nt) pf[q] = (tid + q * nt) < n2 ? src[tid + q * nt] : 0u /* a padding op */;
     }
   }
   if (wpr <= 8u) {
@@ -958,7 +962,8 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
   if (pf_n) {
     uint32_t *dstq = pl_aux_opq(c, (group + 1u) & 1u);
 #pragma unroll
-    for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT; q++)
+    for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT_MIN; q++)
+      if (q < PL_OPQ_WORDS / nt)
       if ((tid + q * nt) < pf_n) dstq[tid + q * nt] = pf[q];
   }
   if (tid == 0) sh->opq_group[(group + 1u) & 1u] = pf_n ? group + 1u : PL_NONE;
