@@ -600,8 +600,10 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
                                 const uint8_t *d_kc, uint32_t lds_bytes, uint32_t max_slots, uint32_t max_out) {
   const uint32_t nstrips = (T + WB - 1) / WB, spl = 128u / WB;
   const bool by_block = nrq_map_by_block(nblk) && !getenv("NRQ_MAP_SPREAD");
-  /* workgroup shape: the full-size workgroup when a strip image owns the CU's LDS, a 256-thread one when several fit */
-  const bool small = lds_bytes * 3u <= NRQ_LDS_MAX && !getenv("NRQ_BIG_WG");
+  /* workgroup shape: the full-size workgroup when a strip image needs more than half of the CU's LDS, 256-thread ones
+   * when two or more fit */
+  const uint32_t small_div = getenv("NRQ_SMALL_DIV") ? (uint32_t)atoi(getenv("NRQ_SMALL_DIV")) : 2u; /* measured: 2 beats 3 */
+  const bool small = lds_bytes * small_div <= NRQ_LDS_MAX && !getenv("NRQ_BIG_WG");
   const uint32_t nt = small ? 256u : (uint32_t)NRQ_WG;
   uint32_t occ = NRQ_LDS_MAX / (lds_bytes ? lds_bytes : 1u);
   if (occ > 2048u / nt) occ = 2048u / nt;
