@@ -158,6 +158,22 @@ def test_launch_shapes(G, orc, K, T, nblk):
         assert np.array_equal(inter[b], r_int) and np.array_equal(rep[b], r_rep), "block %d" % b
 
 
+@pytest.mark.parametrize("K,T,nblk", [(256, 80, 300), (700, 80, 90), (1500, 80, 40), (2048, 144, 24), (2300, 80, 24),
+                                      (2600, 80, 24), (3000, 80, 16), (4500, 80, 16), (5200, 80, 16)])
+def test_kernel_variant_boundaries(G, orc, K, T, nblk):
+    """Block sizes either side of every switch of kernel shape: the 256-thread solve variants (register budget for 5 or 4
+    workgroups per CU, chosen by how many LDS images fit), the 768-thread one, the 256- and 1024-thread planner.  All
+    blocks round-trip; the first and the last are compared with the oracle byte for byte (intermediate symbols too)."""
+    st, out, src = _roundtrip(G, K, T, nblk, 0.08, 4, seed=K)
+    assert st.all()
+    assert np.array_equal(out, src)
+    esis = np.array([K, K + 3, K + 77], np.uint32)
+    rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+    for b in (0, nblk - 1):
+        r_rep, r_int, _ = orc.encode_block(src[b], K, T, esis, want_inter=True)
+        assert np.array_equal(inter[b], r_int) and np.array_equal(rep[b], r_rep), "block %d" % b
+
+
 def test_roundtrip_headline_config(G):
     """BASELINE configs[1]/[2] at full size: K=8192, T=1280, 10 % loss, +2 overhead, 8 blocks."""
     st, out, src = _roundtrip(G, 8192, 1280, 8, 0.10, 2, seed=31)
