@@ -79,6 +79,17 @@ def build_lib(force=False, verbose=False, out=None, extra=()):
     return target
 
 
+def build_tools(force=False):
+    """tools/rqfile: the file encoder / decoder on the object API (C, linked against the library in place)."""
+    src = os.path.join(ROOT, "tools", "rqfile.c")
+    exe = os.path.join(ROOT, "tools", "rqfile")
+    deps = [src, LIB] + [os.path.join(ROOT, "include", h) for h in ("nanorq.h", "nanorq_batch.h", "io.h")]
+    if force or _newer(exe, deps):
+        subprocess.run(["gcc", "-std=c99", "-D_DEFAULT_SOURCE", "-D_FILE_OFFSET_BITS=64", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                        src, "-o", exe, "-L" + os.path.dirname(LIB), "-lnanorq_hip", "-Wl,-rpath,$ORIGIN/../nanorq_amd", "-lm"], check=True)
+    return exe
+
+
 def build_emu(force=False):
     src = os.path.join(ROOT, "tests", "emu", "solve_emu.cpp")
     deps = [src, os.path.join(CSRC, "solve_body.h"), os.path.join(CSRC, "plan.h")]
@@ -99,3 +110,4 @@ if __name__ == "__main__":
     build_lib(force="-f" in sys.argv, verbose=True)
     build_emu(force="-f" in sys.argv)
     build_planner_emu(force="-f" in sys.argv)
+    build_tools(force="-f" in sys.argv)
