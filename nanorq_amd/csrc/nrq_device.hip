@@ -230,6 +230,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       NRQ_STAMP(4);
       ph_dense_fold<WB>(c, tid, NT);
       __syncthreads();
+      if (dense_fold_shared(NT)) { /* (then the fold leaves its products in the accumulator copies) */
+        ph_hdpc_reduce<WB>(c, tid, NT);
+        __syncthreads();
+      }
       ph_dense_free<WB>(c, tid, NT);
       __syncthreads();
       ph_dense_cu<WB>(c, tid, NT);

@@ -615,20 +615,48 @@ template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32
   }
 }
 
-/* phase 4b: fold the columns resolved by binary rows out of the HDPC rows: R_h ^= mh[h][p]*E_p */
+/* phase 4b: fold the columns resolved by binary rows out of the HDPC rows: R_h ^= mh[h][p]*E_p.
+ * Big workgroups (dense_fold_shared): one thread per E_p -- its 8 multiples by alpha^k once, then every one of the H
+ * products is a masked XOR per set coefficient bit (a general GF(256) multiply per (h, p) pair is 3.4x the
+ * instructions).  The products go to the private accumulator copies of region X like those of ph_hdpc, and
+ * ph_hdpc_reduce has to run once more to fold them into the HDPC slots.  Small workgroups (small blocks, few E_p):
+ * one general multiply per (h, p) pair, spread over all threads, straight into the slots -- the extra phase costs
+ * more than the instructions saved (measured: 6 % at K <= 1024). */
+#ifndef NRQ_DENSE_SHARED_MIN_NT
+#define NRQ_DENSE_SHARED_MIN_NT 512u
+#endif
+SB_HD bool dense_fold_shared(uint32_t nt) { return nt >= NRQ_DENSE_SHARED_MIN_NT; }
 template <int WB> SB_HD void ph_dense_fold(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint8_t *mh = c.template arr<uint8_t>(c.h->off_mh);
   const uint32_t H = c.h->H, r2 = c.h->r2, M = c.h->M;
-  const uint32_t hq = tid & 15u, part = tid >> 4, nparts = nt >> 4;
-  if (hq >= H) return;
-  SV<WB> acc = sv_zero<WB>();
-  for (uint32_t p = part; p < r2; p += nparts) {
-    uint32_t coef = mh[(size_t)hq * r2 + p];
-    if (!coef) continue;
-    SV<WB> t = sv_mul<WB>(lds_get<WB>(c.slots(), M + p), coef);
-    sv_xor<WB>(acc, t);
+  if (!dense_fold_shared(nt)) {
+    const uint32_t hq = tid & 15u, part = tid >> 4, nparts = nt >> 4;
+    if (hq >= H) return;
+    SV<WB> acc = sv_zero<WB>();
+    for (uint32_t p = part; p < r2; p += nparts) {
+      uint32_t coef = mh[(size_t)hq * r2 + p];
+      if (!coef) continue;
+      SV<WB> t = sv_mul<WB>(lds_get<WB>(c.slots(), M + p), coef);
+      sv_xor<WB>(acc, t);
+    }
+    lds_xor<WB>(c.slots(), c.h->S + hq, acc);
+    return;
   }
-  lds_xor<WB>(c.slots(), c.h->S + hq, acc);
+  const uint32_t mine = (tid & (hdpc_nsets<WB>(c) - 1u)) * H;
+  for (uint32_t p = tid; p < r2; p += nt) {
+    SV<WB> pw[8];
+    pw[0] = lds_get<WB>(c.slots(), M + p);
+#pragma unroll
+    for (int k = 1; k < 8; k++) pw[k] = sv_xtime<WB>(pw[k - 1]);
+    for (uint32_t h = 0; h < H; h++) {
+      const uint32_t coef = mh[(size_t)h * r2 + p];
+      if (!coef) continue;
+      SV<WB> t = sv_zero<WB>();
+#pragma unroll
+      for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef >> k) & 1u));
+      lds_xor<WB>(c.cf(), mine + h, t);
+    }
+  }
 }
 
 /* phase 4c: free columns C_f = SUM_h hinv[f][h] * R_h */

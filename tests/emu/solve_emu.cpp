@@ -13,7 +13,10 @@
 #include <cstring>
 #include <vector>
 
+static uint32_t g_dense_shared_min_nt = 512; /* workgroup size from which the dense fold shares the multiples (kernel: 512) */
+#define NRQ_DENSE_SHARED_MIN_NT g_dense_shared_min_nt
 #include "../../nanorq_amd/csrc/solve_body.h"
+extern "C" void emu_set_dense_shared_min_nt(uint32_t v) { g_dense_shared_min_nt = v; }
 
 /* The forward passes in the order the kernel's wave 0 issues them (plan.h): step q applies row q-NRQ_PIPE,
  * then reads the sources of row q -- so a plan that puts dependent rows closer than NRQ_PIPE rows apart
@@ -72,6 +75,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
   PHASE(ph_hdpc);
   PHASE(ph_hdpc_reduce);
   PHASE(ph_dense_fold);
+  if (dense_fold_shared(NT)) PHASE(ph_hdpc_reduce);
   PHASE(ph_dense_free);
   PHASE(ph_dense_cu);
   PHASE(ph_tables);

@@ -26,6 +26,7 @@ def emu():
         L.emu_solve.argtypes = [C.POINTER(Job), C.c_uint32, C.c_uint32, C.c_void_p]
         L.emu_lds_bytes.argtypes = [C.c_void_p, C.c_uint32]
         L.emu_lds_bytes.restype = C.c_uint32
+        L.emu_set_dense_shared_min_nt.argtypes = [C.c_uint32]
         _EMU = L
     return _EMU
 

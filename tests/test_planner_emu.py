@@ -70,6 +70,18 @@ def test_decode_emulated_matches_oracle(orc, K, T, wb, p, oh):
     assert done >= 1
 
 
+@pytest.mark.parametrize("K,T,wb", [(100, 64, 16), (1024, 20, 8), (1024, 12, 4), (8192, 16, 16)])
+def test_dense_fold_with_shared_multiples(orc, K, T, wb):
+    """The big-workgroup variant of the dense fold (one thread per scratch row, products through the accumulator copies
+    and a second ph_hdpc_reduce) on the emulator's 256-thread workgroup."""
+    from emu_support import emu
+    emu().emu_set_dense_shared_min_nt(1)
+    try:
+        _encode_case(orc, K, T, wb)
+    finally:
+        emu().emu_set_dense_shared_min_nt(512)
+
+
 def test_failure_parity_small_blocks(orc):
     """rank(A) < L verdicts must agree with the reference algorithm (~1 % at +0)."""
     K = 12
