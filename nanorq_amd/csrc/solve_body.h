@@ -648,12 +648,15 @@ template <int WB> SB_HD void ph_dense_fold(const StripCtx<WB> &c, uint32_t tid, 
     pw[0] = lds_get<WB>(c.slots(), M + p);
 #pragma unroll
     for (int k = 1; k < 8; k++) pw[k] = sv_xtime<WB>(pw[k - 1]);
-    for (uint32_t h = 0; h < H; h++) {
-      const uint32_t coef = mh[(size_t)h * r2 + p];
-      if (!coef) continue;
+    uint32_t coef[16]; /* (H <= 16) all of them in flight together: one trip to L2, not one per HDPC row */
+#pragma unroll
+    for (uint32_t h = 0; h < 16; h++) coef[h] = h < H ? mh[(size_t)h * r2 + p] : 0u;
+#pragma unroll
+    for (uint32_t h = 0; h < 16; h++) {
+      if (!coef[h]) continue;
       SV<WB> t = sv_zero<WB>();
 #pragma unroll
-      for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef >> k) & 1u));
+      for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef[h] >> k) & 1u));
       lds_xor<WB>(c.cf(), mine + h, t);
     }
   }
