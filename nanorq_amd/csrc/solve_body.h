@@ -605,12 +605,27 @@ template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32
     pw[0] = sv_xtime<WB>(g);
 #pragma unroll
     for (int k = 1; k < 8; k++) pw[k] = sv_xtime<WB>(pw[k - 1]);
-    for (uint32_t h = 0; h < H; h++) {
-      const uint32_t coef = G[(size_t)h * n + b];
-      SV<WB> t = sv_zero<WB>();
+    if (nt >= 512u) { /* the big workgroup (168 registers per thread): the H coefficients loaded together, one trip to
+                       * L2 instead of one per HDPC row; the 256-thread variants have no registers to spare for it */
+      uint32_t coef[16]; /* (H <= 16) */
 #pragma unroll
-      for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef >> k) & 1u));
-      lds_xor<WB>(c.cf(), mine + h, t);
+      for (uint32_t h = 0; h < 16; h++) coef[h] = h < H ? G[(size_t)h * n + b] : 0u;
+#pragma unroll
+      for (uint32_t h = 0; h < 16; h++) {
+        if (h >= H) break;
+        SV<WB> t = sv_zero<WB>();
+#pragma unroll
+        for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef[h] >> k) & 1u));
+        lds_xor<WB>(c.cf(), mine + h, t);
+      }
+    } else {
+      for (uint32_t h = 0; h < H; h++) {
+        const uint32_t coef = G[(size_t)h * n + b];
+        SV<WB> t = sv_zero<WB>();
+#pragma unroll
+        for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef >> k) & 1u));
+        lds_xor<WB>(c.cf(), mine + h, t);
+      }
     }
   }
 }
