@@ -592,21 +592,39 @@ template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, ui
   const uint16_t *cols;
   const uint32_t n = pl_row(c, r, &cols);
   uint32_t keep = PL_NONE, keepdeg = PL_NONE, m = 0;
-  for (uint32_t k = 0; k < n; k++) {
-    const uint32_t col = cols[k];
-    if (s.colinfo[col] != 0u) continue;
-    const uint32_t dg = (c.b_cptr[col + 1] - c.b_cptr[col]) + (c.pc_ptr[col + 1] - c.pc_ptr[col]);
-    if (dg < keepdeg) { keepdeg = dg; keep = col; }
+  /* (one thread walks the row; eight entries at a time with all their loads in flight together -- entry, column
+   * state, four list bounds: a trip each if taken one by one) */
+  constexpr uint32_t CB = 8;
+  for (uint32_t k0 = 0; k0 < n; k0 += CB) {
+    uint32_t col[CB], inf[CB], dg[CB];
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) {
+      inf[q] = s.colinfo[col[q]];
+      dg[q] = (c.b_cptr[col[q] + 1] - c.b_cptr[col[q]]) + (c.pc_ptr[col[q] + 1] - c.pc_ptr[col[q]]);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++)
+      if (k0 + q < n && inf[q] == 0u && dg[q] < keepdeg) { keepdeg = dg[q]; keep = col[q]; }
   }
-  for (uint32_t k = 0; k < n; k++) {
-    const uint32_t col = cols[k];
-    if (s.colinfo[col] != 0u || col == keep) continue;
-    const uint32_t x = p.P + sh->ninact;
-    if (x >= c.ucap || m >= PL_QCAP) { sh->status = PL_FAIL_CAPACITY; break; }
-    sh->ninact++;
-    s.colinfo[col] = (PL_ST_INACT << 30) | x;
-    c.ucol[x] = (uint16_t)col;
-    sh->claim_c[m++] = (uint16_t)col;
+  bool full = false;
+  for (uint32_t k0 = 0; k0 < n && !full; k0 += CB) {
+    uint32_t col[CB], inf[CB];
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) inf[q] = s.colinfo[col[q]];
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) {
+      if (k0 + q >= n || inf[q] != 0u || col[q] == keep || full) continue;
+      const uint32_t x = p.P + sh->ninact;
+      if (x >= c.ucap || m >= PL_QCAP) { sh->status = PL_FAIL_CAPACITY; full = true; continue; }
+      sh->ninact++;
+      s.colinfo[col[q]] = (PL_ST_INACT << 30) | x;
+      c.ucol[x] = (uint16_t)col[q];
+      sh->claim_c[m++] = (uint16_t)col[q];
+    }
   }
   sh->nclaim[rd & 1u] = m; /* "columns to drop" */
   sh->nV -= m;
