@@ -1593,16 +1593,38 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + sh->partial[2]);
   uint32_t *orow = reinterpret_cast<uint32_t *>(c.arena + sh->partial[3]);
   uint16_t *osl = reinterpret_cast<uint16_t *>(c.arena + sh->partial[4]);
+  /* list lengths of the missing symbols: to LDS when they fit (the frontier queues are free by now), so that the
+   * running sum in pl_final_d -- one thread -- does not walk an array in HBM */
+  uint16_t *degq = &sh->queue[0][0];
+  const bool in_lds = nl <= 2u * PL_QCAP;
   for (uint32_t g = tid; g < nl; g += nt) {
     const uint32_t e = c.lost[g];
-    c.pivdeg[g] = c.b_rptr[p.S + p.H + e + 1] - c.b_rptr[p.S + p.H + e];
+    const uint32_t dg = c.b_rptr[p.S + p.H + e + 1] - c.b_rptr[p.S + p.H + e];
+    if (in_lds) degq[g] = (uint16_t)dg; else c.pivdeg[g] = dg;
     orow[g] = e;
   }
   (void)cptr; (void)osl;
 }
+/* sum of the first g list lengths staged in LDS by pl_final_c (g <= 2 * PL_QCAP) */
+SB_HD uint32_t pl_deg_prefix(const pl_shared *sh, uint32_t g) {
+  const uint16_t *degq = &sh->queue[0][0];
+  uint32_t run = 0, i = 0;
+  for (; i + 2u <= g; i += 2u) { /* two 16-bit lengths per word (the queues are 4-byte aligned) */
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(degq + i);
+    run += (w & 0xFFFFu) + (w >> 16);
+  }
+  if (i < g) run += degq[i];
+  return run;
+}
 template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   const rq_params &p = c.p;
+  if (!sh->status && c.job.nlost <= 2u * PL_QCAP) {
+    /* the list offsets of the missing symbols: every thread sums the lengths before its own entry (LDS reads, no
+     * stores in between) -- a running sum by one thread is a chain of LDS round trips, one per entry */
+    uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + sh->partial[2]);
+    for (uint32_t g = tid; g <= c.job.nlost; g += nt) cptr[g] = pl_deg_prefix(sh, g);
+  }
   if (tid != 0) return;
   nrq_plan_hdr h;
   memset(&h, 0, sizeof(h));
@@ -1622,8 +1644,11 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
     const uint32_t nl = c.job.nlost;
     uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + sh->partial[2]);
     uint32_t run = 0;
-    for (uint32_t g = 0; g < nl; g++) { cptr[g] = run; run += c.pivdeg[g]; }
-    cptr[nl] = run;
+    if (nl <= 2u * PL_QCAP) run = pl_deg_prefix(sh, nl);
+    else {
+      for (uint32_t g = 0; g < nl; g++) { cptr[g] = run; run += c.pivdeg[g]; }
+      cptr[nl] = run;
+    }
     h.n_xor_ops = c.lev_ops[sh->nlev + 1u] + run + sh->spare_fill;
     for (uint32_t l = 0; l <= sh->nlev; l++) h.n_xor_ops += c.lev_ops[l];
   }
@@ -1653,8 +1678,18 @@ template <int Z> SB_HD void pl_final_e(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t *cptr = reinterpret_cast<const uint32_t *>(c.arena + sh->partial[2]);
   uint16_t *osl = reinterpret_cast<uint16_t *>(c.arena + sh->partial[4]);
   for (uint32_t g = tid; g < nl; g += nt) {
-    const uint32_t e = c.lost[g], a = c.b_rptr[p.S + p.H + e], n = c.b_rptr[p.S + p.H + e + 1] - a;
-    for (uint32_t k = 0; k < n; k++) osl[cptr[g] + k] = c.colslot[c.b_cidx[a + k]];
+    const uint32_t e = c.lost[g], a = c.b_rptr[p.S + p.H + e], n = c.b_rptr[p.S + p.H + e + 1] - a, o = cptr[g];
+    constexpr uint32_t CB = 8; /* entries whose two dependent loads are in flight together */
+    for (uint32_t k0 = 0; k0 < n; k0 += CB) {
+      uint32_t col[CB], sl[CB];
+#pragma unroll
+      for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? c.b_cidx[a + k0 + q] : 0u;
+#pragma unroll
+      for (uint32_t q = 0; q < CB; q++) sl[q] = c.colslot[col[q]];
+#pragma unroll
+      for (uint32_t q = 0; q < CB; q++)
+        if (k0 + q < n) osl[o + k0 + q] = (uint16_t)sl[q];
+    }
   }
 }
 
