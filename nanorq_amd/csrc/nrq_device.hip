@@ -291,6 +291,7 @@ enum {
   pl_tag_pl_low_a = 9,
   pl_tag_pl_low_b = 9,
   pl_tag_pl_low_c = 9,
+  pl_tag_pl_ops_layout_a = 10,
   pl_tag_pl_ops_layout = 10,
   pl_tag_pl_ops_clear = 10,
   pl_tag_pl_ops_emit = 10,

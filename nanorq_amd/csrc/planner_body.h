@@ -1080,22 +1080,57 @@ template <int Z> SB_HD void pl_low_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 
 /* =============================== phase 4: op stream layout =================================== */
-template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt) {
+/* sum of the first g 16-bit counts staged in the (free) frontier queues: g <= 2 * PL_QCAP */
+SB_HD uint32_t pl_deg_prefix(const pl_shared *sh, uint32_t g) {
+  const uint16_t *degq = &sh->queue[0][0];
+  uint32_t run = 0, i = 0;
+  for (; i + 2u <= g; i += 2u) { /* two 16-bit lengths per word (the queues are 4-byte aligned) */
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(degq + i);
+    run += (w & 0xFFFFu) + (w >> 16);
+  }
+  if (i < g) run += degq[i];
+  return run;
+}
+/* rows of the stream that group l takes: the finishing ops first; the last NRQ_PIPE-1 rows hold early ops only (or
+ * padding) -- also when the group is empty: early ops of the group before may complete rows that the group after reads */
+SB_HD uint32_t pl_group_span(uint32_t l, uint32_t nf, uint32_t n) {
+  if (!l) return 0u;
+  const uint32_t need = pl_group_rows(nf) + (NRQ_PIPE - 1u), have = pl_group_rows(n);
+  return have > need ? have : need;
+}
+/* per group: op counts to the workspace, rows to LDS (the frontier queues are free by now) for the prefix sums of
+ * pl_ops_layout -- when the groups are too many for that, pl_ops_layout walks them alone */
+template <int Z> SB_HD void pl_ops_layout_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
-  if (tid != 0) return;
-  /* row base of every group (1..nlev-1: pivot levels, nlev: leftover rows); the stream starts with the NRQ_RING
-   * lead rows */
-  uint32_t rows = NRQ_RING;
   const uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lds_lev(c) ? pl_lev_ctr(c, 1) : nullptr;
-  for (uint32_t l = 0; l <= sh->nlev; l++) {
-    const uint32_t nf = cntF[l], n = nf + (cntN ? cntN[l] : 0u);
+  const bool in_lds = sh->nlev + 1u <= 2u * PL_QCAP;
+  uint16_t *rowq = &sh->queue[0][0];
+  for (uint32_t l = tid; l <= sh->nlev; l += nt) {
+    const uint32_t nf = cntF[l], n = nf + (cntN ? cntN[l] : 0u), span = pl_group_span(l, nf, n);
     c.lev_ops[l] = n;
     c.lev_fin[l] = nf;
-    c.lev_base[l] = rows;
-    if (l) { /* the finishing ops first; the last NRQ_PIPE-1 rows hold early ops only (or padding) -- also when the
-              * group is empty: early ops of the group before may complete rows that the group after reads */
-      const uint32_t need = pl_group_rows(nf) + (NRQ_PIPE - 1u), have = pl_group_rows(n);
-      rows += have > need ? have : need;
+    if (in_lds) {
+      if (span > 0xFFFFu) sh->status = PL_FAIL_CAPACITY;
+      rowq[l] = (uint16_t)span;
+    }
+  }
+}
+template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  /* row base of every group (1..nlev-1: pivot levels, nlev: leftover rows); the stream starts with the NRQ_RING
+   * lead rows */
+  const bool in_lds = sh->nlev + 1u <= 2u * PL_QCAP;
+  if (in_lds)
+    for (uint32_t l = tid; l <= sh->nlev; l += nt) c.lev_base[l] = NRQ_RING + pl_deg_prefix(sh, l);
+  if (tid != 0) return;
+  uint32_t rows = NRQ_RING;
+  if (in_lds) rows += pl_deg_prefix(sh, sh->nlev + 1u);
+  else {
+    const uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lds_lev(c) ? pl_lev_ctr(c, 1) : nullptr;
+    for (uint32_t l = 0; l <= sh->nlev; l++) {
+      const uint32_t nf = cntF[l], n = nf + (cntN ? cntN[l] : 0u);
+      c.lev_base[l] = rows;
+      rows += pl_group_span(l, nf, n);
     }
   }
   sh->spare_base = rows; /* rows reserved for constraint rows added later */
@@ -1604,17 +1639,6 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
     orow[g] = e;
   }
   (void)cptr; (void)osl;
-}
-/* sum of the first g list lengths staged in LDS by pl_final_c (g <= 2 * PL_QCAP) */
-SB_HD uint32_t pl_deg_prefix(const pl_shared *sh, uint32_t g) {
-  const uint16_t *degq = &sh->queue[0][0];
-  uint32_t run = 0, i = 0;
-  for (; i + 2u <= g; i += 2u) { /* two 16-bit lengths per word (the queues are 4-byte aligned) */
-    const uint32_t w = *reinterpret_cast<const uint32_t *>(degq + i);
-    run += (w & 0xFFFFu) + (w >> 16);
-  }
-  if (i < g) run += degq[i];
-  return run;
 }
 template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;

@@ -51,6 +51,7 @@
   if (sh_->status == 0 && sh_->nV == 0) {
     PL_PHASE(pl_w_init);
     PL_PHASE(pl_w_init_b);
+    PL_PHASE(pl_ops_layout_a);
     PL_PHASE(pl_ops_layout);
     PL_PHASE(pl_ops_clear);
     PL_PHASE(pl_ops_emit);
