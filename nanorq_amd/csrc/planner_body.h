@@ -558,10 +558,8 @@ template <bool LDS> SB_HD void pl_inact_find_t(PlanCtx &c, uint32_t rdrep, uint3
     if (!(s.rowinfo[r] & PL_UNASSIGNED)) continue;
     const uint32_t cnt = s.rowstate[r] >> 24;
     if (cnt >= 2u) {
-      /* sparsest first; among equals the row whose dropped columns so far sit on the lowest level (its pivot starts
-       * a shallow chain: 424 -> 312 levels and 643 -> 572 rounds at K=8192, same number of inactive columns) */
-      const uint32_t lv = s.rowinfo[r] & PL_LEVEL_MASK;
-      const uint32_t key = ((cnt < 15u ? cnt : 15u) << 28) | ((lv < 4095u ? lv : 4095u) << 16) | r;
+      const uint32_t key = (cnt << 16) | r; /* (ties by level-so-far give 424 -> 312 levels at the same u, but the kernel is
+                                              * 2.5 % slower for it: measured, not adopted) */
       if (key < best) best = key;
     }
   }
