@@ -45,6 +45,10 @@ def lib():
                                        C.POINTER(Stats)]
         L.orc_decode_block.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p, u8p, u8p,
                                        C.POINTER(Stats)]
+        L.orc_encode_block_kp.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u8p, u8p, C.c_uint32, u32p, u8p,
+                                          C.POINTER(Stats)]
+        L.orc_decode_block_kp.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u8p, u8p,
+                                          C.POINTER(Stats)]
         L.orc_plan_probe.argtypes = [C.c_uint32, C.c_uint32, u32p, C.POINTER(Stats)]
         _LIB = L
     return _LIB
@@ -109,27 +113,28 @@ def row_scal(dst, beta):
     lib().orc_row_scal(_u8(dst), dst.size, beta)
 
 
-def encode_block(src, K, T, repair_esis=(), want_inter=False):
-    """src: uint8 array of K*T bytes. Returns (repair[nrep,T], inter[L,T] or None, stats)."""
+def encode_block(src, K, T, repair_esis=(), want_inter=False, Kp=0):
+    """src: uint8 array of K*T bytes. Returns (repair[nrep,T], inter[L,T] or None, stats).
+    Kp: Table 2 row the block is coded with (0 = the row of K; the reference uses block 0's row for every block)."""
     src = np.ascontiguousarray(src, dtype=np.uint8).reshape(K, T)
     esis = np.ascontiguousarray(repair_esis, dtype=np.uint32)
     rep = np.zeros((max(len(esis), 1), T), np.uint8)
-    inter = np.zeros((params(K)["L"], T), np.uint8) if want_inter else None
+    inter = np.zeros((params(Kp or K)["L"], T), np.uint8) if want_inter else None
     st = Stats()
-    ok = lib().orc_encode_block(K, T, _u8(src), _u8(inter) if want_inter else None, len(esis),
-                                _u32(esis) if len(esis) else None, _u8(rep), C.byref(st))
+    ok = lib().orc_encode_block_kp(K, Kp, T, _u8(src), _u8(inter) if want_inter else None, len(esis),
+                                   _u32(esis) if len(esis) else None, _u8(rep), C.byref(st))
     if not ok:
         raise RuntimeError("oracle encode failed")
     return rep[:len(esis)], inter, st.as_dict()
 
 
-def decode_block(esis, syms, K, T):
+def decode_block(esis, syms, K, T, Kp=0):
     """esis[n] / syms[n,T] in arrival order. Returns (ok, out[K,T], stats)."""
     esis = np.ascontiguousarray(esis, dtype=np.uint32)
     syms = np.ascontiguousarray(syms, dtype=np.uint8).reshape(len(esis), T)
     out = np.zeros((K, T), np.uint8)
     st = Stats()
-    ok = lib().orc_decode_block(K, T, len(esis), _u32(esis), _u8(syms), _u8(out), C.byref(st))
+    ok = lib().orc_decode_block_kp(K, Kp, T, len(esis), _u32(esis), _u8(syms), _u8(out), C.byref(st))
     return bool(ok), out, st.as_dict()
 
 

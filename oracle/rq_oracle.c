@@ -691,12 +691,20 @@ void orc_row_scal(uint8_t *dst, size_t n, uint8_t beta) { gf_init(); row_scal(ds
 /* Encode one source block (reference nanorq.c:206-232 + :403-435).
  *   src: K*T bytes; inter (nullable): L*T bytes out; rep: nrep*T bytes out for ESIs esis[] (>= K)
  * returns 1 on success */
-int orc_encode_block(uint32_t K, uint32_t T, const uint8_t *src, uint8_t *inter, uint32_t nrep,
-                     const uint32_t *esis, uint8_t *rep, orc_stats *st) {
+/* Kp = the Table 2 row the block is coded with: 0 = the row of K itself; the reference codes every block of an
+ * object with block 0's row (nanorq.c:289 encoder, :372 decoder: `rq->P = params_init(nanorq_block_symbols(rq, 0))`),
+ * so a short last block carries a K' larger than its own and K' - K padding symbols (zero rows, nanorq.c:137-142). */
+static int derive_params_kp(uint32_t K, uint32_t Kp, orc_params_t *p) {
+  if (!derive_params(Kp ? Kp : K, p)) return 0;
+  return K != 0 && K <= p->Kp && (Kp == 0 || p->Kp == Kp);
+}
+
+int orc_encode_block_kp(uint32_t K, uint32_t Kp, uint32_t T, const uint8_t *src, uint8_t *inter, uint32_t nrep,
+                        const uint32_t *esis, uint8_t *rep, orc_stats *st) {
   orc_params_t p;
   gf_init();
   if (st) memset(st, 0, sizeof(*st));
-  if (!derive_params(K, &p) || T == 0) return 0;
+  if (!derive_params_kp(K, Kp, &p) || T == 0) return 0;
   size_t ld = ((size_t)T + 31u) & ~(size_t)31u;
   uint8_t *D = (uint8_t *)aligned_alloc(64, (size_t)p.L * ld);
   uint8_t *C = (uint8_t *)aligned_alloc(64, (size_t)p.L * ld);
@@ -722,18 +730,22 @@ int orc_encode_block(uint32_t K, uint32_t T, const uint8_t *src, uint8_t *inter,
   plan_free(s); free(D); free(C);
   return 1;
 }
+int orc_encode_block(uint32_t K, uint32_t T, const uint8_t *src, uint8_t *inter, uint32_t nrep,
+                     const uint32_t *esis, uint8_t *rep, orc_stats *st) {
+  return orc_encode_block_kp(K, 0, T, src, inter, nrep, esis, rep, st);
+}
 
 /* Decode one source block from received symbols in ARRIVAL order
  * (reference nanorq.c:478-509 add_symbol, :527-631 repair_block).
  *   esis[n], syms[n*T]; out: K*T bytes (received source symbols are written through, recovered
  *   ones after the solve).  returns 1 = block complete, 0 = not decodable (too few symbols or
  *   rank(A) < L). */
-int orc_decode_block(uint32_t K, uint32_t T, uint32_t n, const uint32_t *esis, const uint8_t *syms, uint8_t *out,
-                     orc_stats *st) {
+int orc_decode_block_kp(uint32_t K, uint32_t Kp, uint32_t T, uint32_t n, const uint32_t *esis, const uint8_t *syms,
+                        uint8_t *out, orc_stats *st) {
   orc_params_t p;
   gf_init();
   if (st) memset(st, 0, sizeof(*st));
-  if (!derive_params(K, &p) || T == 0) return 0;
+  if (!derive_params_kp(K, Kp, &p) || T == 0) return 0;
   uint32_t max_esi = 2 * p.Kp; /* reference nanorq.c:374 */
   uint8_t *seen = (uint8_t *)calloc((size_t)max_esi + 1, 1);
   uint32_t *rep_idx = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
@@ -802,6 +814,10 @@ int orc_decode_block(uint32_t K, uint32_t T, uint32_t n, const uint32_t *esis, c
 done:
   free(D); free(seen); free(rep_idx);
   return ok;
+}
+int orc_decode_block(uint32_t K, uint32_t T, uint32_t n, const uint32_t *esis, const uint8_t *syms, uint8_t *out,
+                     orc_stats *st) {
+  return orc_decode_block_kp(K, 0, T, n, esis, syms, out, st);
 }
 
 /* plan-only probe: rank verdict + schedule statistics for an arbitrary LT row set.

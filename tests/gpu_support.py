@@ -13,21 +13,21 @@ def ctx():
     return _CTX
 
 
-def gpu_encode(src_blocks, K, T, esis, want_inter=False):
+def gpu_encode(src_blocks, K, T, esis, want_inter=False, Kp=0):
     """src_blocks: [nblk, K, T] uint8 -> (repair [nblk, nrep, T], inter [nblk, L, T] or None)"""
     c = ctx()
     src_blocks = np.ascontiguousarray(src_blocks, np.uint8)
     nblk = src_blocks.shape[0]
     esis = np.ascontiguousarray(esis, np.uint32)
     nrep = len(esis)
-    L = nanorq_amd.params(K)["L"]
+    L = nanorq_amd.params(Kp or K)["L"]
     d_src = c.alloc(nblk * K * T)
     d_rep = c.alloc(max(1, nblk * nrep * T))
     d_int = c.alloc(nblk * L * T) if want_inter else 0
     try:
         c.upload(d_src, src_blocks)
         c.memset(d_rep, 0xCD, max(1, nblk * nrep * T))
-        c.encode_blocks(K, T, nblk, d_src, K * T, d_rep, nrep * T, esis, d_int, L * T)
+        c.encode_blocks(K, T, nblk, d_src, K * T, d_rep, nrep * T, esis, d_int, L * T, Kp=Kp)
         c.sync()
         rep = c.download(d_rep, nblk * nrep * T).reshape(nblk, nrep, T) if nrep else np.zeros((nblk, 0, T), np.uint8)
         inter = c.download(d_int, nblk * L * T).reshape(nblk, L, T) if want_inter else None
@@ -38,7 +38,7 @@ def gpu_encode(src_blocks, K, T, esis, want_inter=False):
     return rep, inter
 
 
-def gpu_decode(work_blocks, K, T, lost_lists, rep_esi_lists, rep_syms_lists, want_inter=False):
+def gpu_decode(work_blocks, K, T, lost_lists, rep_esi_lists, rep_syms_lists, want_inter=False, Kp=0):
     """work_blocks: [nblk, K, T] with received source symbols in place (missing rows arbitrary).
     Returns (status[nblk], recovered blocks [nblk,K,T], inter or None)."""
     c = ctx()
@@ -56,14 +56,14 @@ def gpu_decode(work_blocks, K, T, lost_lists, rep_esi_lists, rep_syms_lists, wan
             reps[b, :len(rep_esi_lists[b])] = rep_syms_lists[b]
     nlost = np.array([len(x) for x in lost_lists], np.uint32)
     nrep = np.array([len(x) for x in rep_esi_lists], np.uint32)
-    L = nanorq_amd.params(K)["L"]
+    L = nanorq_amd.params(Kp or K)["L"]
     d_src = c.alloc(nblk * K * T)
     d_rep = c.alloc(nblk * rep_cap * T)
     d_int = c.alloc(nblk * L * T) if want_inter else 0
     try:
         c.upload(d_src, work_blocks)
         c.upload(d_rep, reps)
-        st = c.decode_blocks(K, T, nblk, d_src, K * T, lost, nlost, resi, nrep, d_rep, rep_cap * T, d_int, L * T)
+        st = c.decode_blocks(K, T, nblk, d_src, K * T, lost, nlost, resi, nrep, d_rep, rep_cap * T, d_int, L * T, Kp=Kp)
         c.sync()
         out = c.download(d_src, nblk * K * T).reshape(nblk, K, T)
         inter = c.download(d_int, nblk * L * T).reshape(nblk, L, T) if want_inter else None

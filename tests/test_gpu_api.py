@@ -124,3 +124,48 @@ def test_reference_benchmark_harness_on_the_hip_path():
         assert r.returncode == 0, (argv, r.stderr.decode()[-500:])
         cols = r.stdout.decode().split()
         assert len(cols) == 5 and int(cols[0]) == int(argv[1]) and all(float(x) > 0 for x in cols[1:])
+
+
+def test_short_last_block_is_coded_with_block_zeros_table_row(orc):
+    """A two-block object whose blocks hold 102 and 101 symbols: the reference codes BOTH with block 0's K' = 114
+    (nanorq.c:289, :372) although K=101 has a table row of its own (101).  The packets of block 1 must equal the
+    oracle's with that K' passed explicitly -- and differ from what the block's own row would give."""
+    L = api()
+    T = 48
+    F = 203 * T
+    data = payload(F, seed=17)
+    rq = L.nanorq_encoder_new_ex(F, T, 102, 0, 8)
+    io = mem_io(data)
+    assert L.nanorq_blocks(rq) == 2 and L.nanorq_block_symbols(rq, 0) == 102 and L.nanorq_block_symbols(rq, 1) == 101
+    buf = (C.c_uint8 * T)()
+    esis = [101, 102, 103, 150, 5000]
+    got = []
+    for esi in esis:
+        assert L.nanorq_encode(rq, buf, esi, 1, io) == T
+        got.append(bytes(buf))
+    oti = (L.nanorq_oti_common(rq), L.nanorq_oti_scheme_specific(rq))
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+    src1 = data[102 * T:].reshape(101, T)
+    want, _, _ = orc.encode_block(src1, 101, T, esis, Kp=114)
+    own, _, _ = orc.encode_block(src1, 101, T, esis)
+    assert [w.tobytes() for w in want] == got
+    assert [w.tobytes() for w in own] != got
+    # and the decoder side: block 1 loses 7 source symbols, receives those repair symbols of the oracle
+    lost = [0, 9, 33, 34, 77, 99, 100]
+    resi = list(range(101, 101 + len(lost)))
+    reps, _, _ = orc.encode_block(src1, 101, T, resi, Kp=114)
+    rq = L.nanorq_decoder_new(*oti)
+    out = np.zeros(F, np.uint8)
+    io = mem_io(out)
+    for esi in range(102):
+        L.nanorq_decoder_add_symbol(rq, (C.c_uint8 * T).from_buffer_copy(data[esi * T:(esi + 1) * T].tobytes()), L.nanorq_tag(0, esi), io)
+    for esi in range(101):
+        if esi not in lost:
+            L.nanorq_decoder_add_symbol(rq, (C.c_uint8 * T).from_buffer_copy(src1[esi].tobytes()), L.nanorq_tag(1, esi), io)
+    for k, esi in enumerate(resi):
+        L.nanorq_decoder_add_symbol(rq, (C.c_uint8 * T).from_buffer_copy(reps[k].tobytes()), L.nanorq_tag(1, esi), io)
+    assert L.nanorq_repair_block(rq, io, 0) and L.nanorq_repair_block(rq, io, 1)
+    assert np.array_equal(out, data)
+    L.nanorq_free(rq)
+    io.contents.destroy(io)

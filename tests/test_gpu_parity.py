@@ -204,9 +204,86 @@ def test_roundtrip_max_k(G):
 
 
 def test_roundtrip_large_symbols(G):
-    """BASELINE configs[3] shape: K=27000 with large symbols (T reduced to 4096 to bound host memory)."""
+    """BASELINE configs[3] shape at a reduced symbol size (K=27000, T=4096) through host buffers; the full-size
+    block is test_cfg4_full_size_on_device."""
     st, out, src = _roundtrip(G, 27000, 4096, 1, 0.10, 2, seed=51)
     assert st[0] == 1 and np.array_equal(out[0], src[0])
+
+
+def test_max_k_overhead0_vs_oracle(G, orc):
+    """BASELINE configs[4] at full size on the GF(256)/HDPC path: K'=56403 (RFC 6330 maximum), T=1280, 20 % loss,
+    decode from EXACTLY K symbols (reference precode.c:365-371, not the XOR-only branch :362-363).  Repair symbols and
+    the recovered block are compared with the oracle's by SHA-256; the verdict must agree if the system is singular."""
+    K, T = 56403, 1280
+    src = payload(K * T, seed=43).reshape(K, T)
+    lost = loss_pattern(K, 0.20, seed=44)
+    esis = np.arange(K, K + len(lost), dtype=np.uint32)
+    rep, _ = G.gpu_encode(src.reshape(1, K, T), K, T, esis)
+    r_rep, _, _ = orc.encode_block(src, K, T, esis)
+    assert hashlib.sha256(rep[0].tobytes()).hexdigest() == hashlib.sha256(r_rep.tobytes()).hexdigest()
+    work = src.copy()
+    work[lost] = 0x77
+    st, out, _ = G.gpu_decode(work.reshape(1, K, T), K, T, [lost], [esis], [rep[0]])
+    keep = np.setdiff1d(np.arange(K, dtype=np.uint32), lost)
+    ok, r_out, stt = orc.decode_block(np.concatenate([keep, esis]), np.concatenate([src[keep], r_rep]), K, T)
+    assert stt["overhead"] == 0 and bool(st[0]) == ok
+    if ok:
+        assert hashlib.sha256(out[0].tobytes()).hexdigest() == hashlib.sha256(r_out.tobytes()).hexdigest()
+        assert np.array_equal(out[0], src)
+    else:
+        assert np.array_equal(out[0], work)
+
+
+def test_cfg4_full_size_on_device(G, orc):
+    """BASELINE configs[3] at FULL size: K=27000, T=65504, one 1.77 GB source block generated on the device, 10 % loss,
+    overhead 0.  Checked on the device: decode(encode) == source, the systematic property of the intermediate symbols
+    (LT(C, esi) == source symbol, through nrq_gen_symbols); against the oracle: one 4096-byte column slice of the
+    repair and intermediate symbols (byte columns are independent, so a slice of the block is a block of its own)."""
+    import torch
+    K, T, W0, WS = 27000, 65504, 20480, 4096
+    p = orc.params(K)
+    L = p["L"]
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    src = torch.randint(0, 256, (K, T), dtype=torch.uint8, device=dev, generator=g)
+    lost = loss_pattern(K, 0.10, seed=52)
+    nrep = len(lost) + 2
+    esis = np.arange(K, K + nrep, dtype=np.uint32)
+    rep = torch.empty((nrep, T), dtype=torch.uint8, device=dev)
+    inter = torch.empty((L, T), dtype=torch.uint8, device=dev)
+    c = G.ctx()
+    torch.cuda.synchronize()
+    c.encode_blocks(K, T, 1, src.data_ptr(), K * T, rep.data_ptr(), nrep * T, esis, inter.data_ptr(), L * T)
+    c.sync()
+    # systematic property on sampled ESIs (first, last, around the loss positions)
+    probe = np.unique(np.concatenate([[0, 1, K // 2, K - 1], lost[:20]])).astype(np.uint32)
+    sysout = torch.empty((len(probe), T), dtype=torch.uint8, device=dev)
+    c.gen_symbols(K, T, 1, inter.data_ptr(), L * T, probe, sysout.data_ptr(), len(probe) * T)
+    c.sync()
+    assert torch.equal(sysout, src[torch.from_numpy(probe.astype(np.int64)).to(dev)])
+    # one column slice against the oracle
+    src_sl = src[:, W0:W0 + WS].contiguous().cpu().numpy()
+    r_rep, r_int, _ = orc.encode_block(src_sl, K, WS, esis[:64], want_inter=True)
+    assert np.array_equal(rep[:64, W0:W0 + WS].cpu().numpy(), r_rep), "repair symbols, column slice"
+    assert np.array_equal(inter[:, W0:W0 + WS].cpu().numpy(), r_int), "intermediate symbols, column slice"
+    del inter, sysout
+    # decode from exactly K symbols (GF(256)/HDPC path); verdict as the oracle's on the slice
+    work = src.clone()
+    work[torch.from_numpy(lost.astype(np.int64)).to(dev)] = 0xEE
+    lost_arr = lost.reshape(1, -1)
+    st = c.decode_blocks(K, T, 1, work.data_ptr(), K * T, lost_arr, [len(lost)], esis[:len(lost)].reshape(1, -1), [len(lost)],
+                         rep.data_ptr(), nrep * T)
+    c.sync()
+    keep = np.setdiff1d(np.arange(K, dtype=np.uint32), lost)
+    rep_sl = rep[:len(lost), W0:W0 + WS].cpu().numpy()
+    ok, r_out, _ = orc.decode_block(np.concatenate([keep, esis[:len(lost)]]), np.concatenate([src_sl[keep], rep_sl]), K, WS)
+    assert bool(st[0]) == ok
+    if not ok:  # rank deficient at overhead 0 (about 1 % of receptions): one more symbol, as a receiver would
+        st = c.decode_blocks(K, T, 1, work.data_ptr(), K * T, lost_arr, [len(lost)], esis[:len(lost) + 1].reshape(1, -1),
+                             [len(lost) + 1], rep.data_ptr(), nrep * T)
+        c.sync()
+    assert st[0] == 1 and torch.equal(work, src)
 
 
 @pytest.mark.parametrize("planner", ["device", "host"])
