@@ -78,9 +78,9 @@ def lib():
 
 
 PARAM_NAMES = ("Kp", "J", "S", "H", "W", "L", "P", "P1", "U", "B")
-PLAN_FIELDS = ("magic status K Kp J S H W L P P1 B M npiv u nlow r2 nfree nlev nrows pipe wpr lpr "
-               "npiv_pad n_xor_ops off_ops off_pivslot off_pivcol off_wt off_lowslot off_g2 off_pivx off_fbits "
-               "off_mh off_freex off_hinv off_colslot off_pivof off_uslot off_sync total_bytes").split()
+PLAN_FIELDS = ("magic status K Kp J S H W L P P1 B M npiv u nlow r2 nfree nlev nrows pipe wpr "
+               "npiv_pad n_xor_ops off_ops off_pivslot off_pivcol off_wt off_lowslot off_pivx off_fbits "
+               "off_mh off_freex off_hinv off_colslot off_pivof off_uslot total_bytes").split()
 
 
 def params(K):

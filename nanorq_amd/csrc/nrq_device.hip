@@ -437,8 +437,32 @@ inline size_t r16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 } // namespace
 
+/* Tuning / debugging knobs from the environment, read ONCE when the context is created (the launch path does not
+ * call getenv). */
+struct Tuning {
+  bool map_spread = false;   /* NRQ_MAP_SPREAD: deal line groups round-robin instead of block octets per XCD */
+  bool big_wg = false;       /* NRQ_BIG_WG: never use the 256-thread solve variants */
+  bool small_waves4 = false; /* NRQ_SMALL_WAVES4: 256-thread variant compiled for 4 (not 5) workgroups per CU */
+  bool prof = false;         /* NRQ_PROF: per-phase shader-clock marks, printed to stderr */
+  bool plan_lds_max = false; /* NRQ_PLAN_LDS_MAX: planner always takes the whole LDS */
+  bool plan_big_wg = false;  /* NRQ_PLAN_BIG_WG: planner always 1024 threads */
+  uint32_t small_div = 2;    /* NRQ_SMALL_DIV: LDS images per CU from which the 256-thread variant is used (measured: 2 beats 3) */
+  uint64_t solve_grid = 0;   /* NRQ_SOLVE_GRID: persistent workgroups of the solve launch (0 = fill the device) */
+  uint32_t max_wb = 16;      /* NRQ_MAX_WB: widest strip considered */
+  int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
+  void read() {
+    auto flag = [](const char *n) { const char *e = getenv(n); return e != nullptr; };
+    auto num = [](const char *n, long long d) { const char *e = getenv(n); return (e && *e) ? atoll(e) : d; };
+    map_spread = flag("NRQ_MAP_SPREAD"); big_wg = flag("NRQ_BIG_WG"); small_waves4 = flag("NRQ_SMALL_WAVES4");
+    prof = flag("NRQ_PROF"); plan_lds_max = flag("NRQ_PLAN_LDS_MAX"); plan_big_wg = flag("NRQ_PLAN_BIG_WG");
+    small_div = (uint32_t)num("NRQ_SMALL_DIV", 2); solve_grid = (uint64_t)num("NRQ_SOLVE_GRID", 0);
+    max_wb = (uint32_t)num("NRQ_MAX_WB", 16); prof_base = (int)num("NRQ_PROF_BASE", 2);
+  }
+};
+
 struct nrq_ctx {
   int device = 0;
+  Tuning tune;
   int ncu = 256; /* compute units of the device */
   hipStream_t stream = nullptr;
   std::string err;
@@ -604,22 +628,21 @@ void build_out_lists(const rq_params &p, const uint16_t *colslot, uint32_t n, co
 template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, uint32_t nblk, uint32_t T,
                                 const uint8_t *d_kc, uint32_t lds_bytes, uint32_t max_slots, uint32_t max_out) {
   const uint32_t nstrips = (T + WB - 1) / WB, spl = 128u / WB;
-  const bool by_block = nrq_map_by_block(nblk) && !getenv("NRQ_MAP_SPREAD");
+  const bool by_block = nrq_map_by_block(nblk) && !ctx->tune.map_spread;
   /* workgroup shape: the full-size workgroup when a strip image needs more than half of the CU's LDS, 256-thread ones
    * when two or more fit */
-  const uint32_t small_div = getenv("NRQ_SMALL_DIV") ? (uint32_t)atoi(getenv("NRQ_SMALL_DIV")) : 2u; /* measured: 2 beats 3 */
-  const bool small = lds_bytes * small_div <= NRQ_LDS_MAX && !getenv("NRQ_BIG_WG");
+  const bool small = lds_bytes * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg;
   const uint32_t nt = small ? 256u : (uint32_t)NRQ_WG;
   uint32_t occ = NRQ_LDS_MAX / (lds_bytes ? lds_bytes : 1u);
   if (occ > 2048u / nt) occ = 2048u / nt;
   /* registers: the 256-thread variant (one wave per SIMD) is compiled for NRQ_SMALL_WAVES waves per SIMD.  More
    * workgroups than are resident at once would run as a second, thinner round of a statically partitioned job. */
-  const bool five = small && occ >= 5u && !getenv("NRQ_SMALL_WAVES4");
+  const bool five = small && occ >= 5u && !ctx->tune.small_waves4;
   if (small && occ > (five ? 5u : 4u)) occ = five ? 5u : 4u;
   if (occ < 1u) occ = 1u;
   /* persistent workgroups fill the device; a multiple of 8 keeps a workgroup's slots on its XCD */
   uint64_t grid = (uint64_t)(ctx->ncu / 8) * 8 * occ;
-  if (const char *e = getenv("NRQ_SOLVE_GRID")) grid = (uint64_t)atoll(e) / 8 * 8;
+  if (ctx->tune.solve_grid) grid = ctx->tune.solve_grid / 8 * 8;
   if (grid < 8) grid = 8;
   /* work slots (nrq_map_group): `sub` strips of a block each -- the strips of a whole line unless that would leave
    * workgroups idle -- incl. the empty slots of a partial block octet */
@@ -663,7 +686,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
   }
   const uint32_t nprof = (uint32_t)((grid + 15) / 16);
-  if (getenv("NRQ_PROF")) {
+  if (ctx->tune.prof) {
     if (ctx->prof) { (void)hipFree(ctx->prof); ctx->prof = nullptr; }
     HIPCHK(ctx, hipMalloc((void **)&ctx->prof, (size_t)nprof * 16 * 8));
     HIPCHK(ctx, hipMemsetAsync(ctx->prof, 0, (size_t)nprof * 16 * 8, ctx->stream));
@@ -701,7 +724,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     for (uint32_t w = 0; w < nprof; w++) {
       const unsigned long long *q = &hp[(size_t)w * 16];
       if (!q[8]) continue;
-      for (int k = 0; k < 7; k++) if (q[9 + k]) ext[k] += (double)(q[9 + k] - q[getenv("NRQ_PROF_BASE") ? atoi(getenv("NRQ_PROF_BASE")) : 2]);
+      for (int k = 0; k < 7; k++) if (q[9 + k]) ext[k] += (double)(q[9 + k] - q[ctx->tune.prof_base]);
     }
     fprintf(stderr, " | marks since fwd end:");
     for (int k = 0; k < 7; k++) fprintf(stderr, " %.0f", cnt ? ext[k] / cnt : 0.0);
@@ -722,12 +745,12 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
 int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs, const nrq_job *d_jobs, uint32_t nblk,
                     uint32_t T, const uint8_t *d_kc, uint32_t max_out) {
   static const uint32_t widths[4] = {16, 8, 4, 2};
-  const char *maxw = getenv("NRQ_MAX_WB"); /* tuning: widest strip to consider */
+
   uint32_t max_slots = 0;
   for (const nrq_plan_hdr *h : hdrs)
     if (!h->status && h->M > max_slots) max_slots = h->M;
   for (int s = 0; s < 4; s++) {
-    if (maxw && widths[s] > (uint32_t)atoi(maxw)) continue;
+    if (widths[s] > ctx->tune.max_wb) continue;
     uint32_t need = 0;
     for (const nrq_plan_hdr *h : hdrs) {
       if (h->status) continue;
@@ -775,6 +798,7 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ctx->ncu = n;
   }
+  ctx->tune.read();
   if (getenv("NRQ_HOST_PLANNER")) ctx->planner = 0;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess ||
@@ -958,6 +982,10 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
     size_t off_plan = 0, off_rowsrc = 0, off_cptr = 0, off_row = 0, off_cols = 0;
   };
   std::vector<Prep> prep(nblk);
+  struct PrepGuard { /* the host-built plan arenas are released on every way out of this function */
+    std::vector<Prep> &v;
+    ~PrepGuard() { for (auto &pr : v) if (pr.plan) { nrq_host_free(pr.plan); pr.plan = nullptr; } }
+  } prep_guard{prep};
   const uint32_t pad = p.Kp - K;
 
   auto prepare = [&](uint32_t b) {
@@ -1097,8 +1125,6 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
       result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds), nblk, T, kc->dev, (d_inter ? p.L : 0u) + max_out);
     }
   }
-  for (auto &pr : prep)
-    if (pr.plan) nrq_host_free(pr.plan);
   ctx->stats.host_ms += now_ms() - t_begin;
   return result;
 }
@@ -1183,7 +1209,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     const uint32_t peel = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L);
     const uint32_t wimg = (Mcap + 320u + NRQ_SCRATCH) * 16u;
     const uint32_t fit = pl_r16((peel > wimg ? peel : wimg) + 2048u);
-    if (fit + sh_bytes <= NRQ_LDS_MAX / 2u && !getenv("NRQ_PLAN_LDS_MAX")) { dyn_bytes = fit; small_wg = !getenv("NRQ_PLAN_BIG_WG"); }
+    if (fit + sh_bytes <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) { dyn_bytes = fit; small_wg = !ctx->tune.plan_big_wg; }
   }
   if (!ctx->plan_attr) {
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT>),
@@ -1193,7 +1219,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     ctx->plan_attr = true;
   }
   unsigned long long *pprof = nullptr;
-  if (getenv("NRQ_PROF")) {
+  if (ctx->tune.prof) {
     HIPCHK(ctx, hipMalloc((void **)&pprof, 32 * 8));
     HIPCHK(ctx, hipMemsetAsync(pprof, 0, 32 * 8, ctx->stream));
   }
@@ -1315,39 +1341,46 @@ int nrq_dev_alloc(nrq_ctx *ctx, size_t bytes, void **out) {
 }
 int nrq_dev_free(nrq_ctx *ctx, void *p) {
   if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipFree(p));
   return 0;
 }
 int nrq_dev_upload(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
   if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
 int nrq_dev_download(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
   if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
 int nrq_dev_upload_async(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
   if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
 int nrq_dev_download_async(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
   if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   return 0;
 }
 int nrq_dev_copy(nrq_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
   if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
 }
 int nrq_dev_memset(nrq_ctx *ctx, void *d_dst, int value, size_t bytes) {
   if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
   return 0;
 }

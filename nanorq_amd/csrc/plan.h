@@ -71,7 +71,6 @@ typedef struct nrq_plan_hdr {
   uint32_t nrows;   /* rows of the op stream (pivot levels, leftover rows, GF(2) combinations) */
   uint32_t pipe;    /* NRQ_PIPE the stream was laid out for */
   uint32_t wpr;     /* 32-bit words per W row: ceil(u/32) */
-  uint32_t lpr;     /* reserved (was: words per G2 row) */
   uint32_t npiv_pad;/* stride (in pivots) of the transposed W image, multiple of 64 */
   uint32_t n_xor_ops; /* real (non-padding) ops in both passes, for statistics */
 
@@ -81,7 +80,6 @@ typedef struct nrq_plan_hdr {
   uint32_t off_pivcol;  /* u16[npiv]: column of pivot k */
   uint32_t off_wt;      /* u32[wpr*npiv_pad]: word w of W row k at [w*npiv_pad + k] */
   uint32_t off_lowslot; /* u16[nlow] */
-  uint32_t off_g2;      /* reserved (the GF(2) combinations are part of the op stream) */
   uint32_t off_pivx;    /* u16[r2]: inactive-column index solved by reduced row p */
   uint32_t off_fbits;   /* u32[r2]: bit f set -> C_u[pivx[p]] ^= C_free[f] */
   uint32_t off_mh;      /* u8[H*r2], [h][p]: R_h ^= mh * E_p */
@@ -90,7 +88,6 @@ typedef struct nrq_plan_hdr {
   uint32_t off_colslot; /* u16[L]: slot that finally holds intermediate symbol C[c] */
   uint32_t off_pivof;   /* u16[Kp+S]: slot of the pivot row of column c, NRQ_NOSLOT if inactive */
   uint32_t off_uslot;   /* u16[u]: slot that receives inactive column x */
-  uint32_t off_sync;    /* reserved (was: barrier schedule of the op stream) */
   uint32_t total_bytes;
   uint32_t reserved[2];
 } nrq_plan_hdr;

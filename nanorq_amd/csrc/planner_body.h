@@ -113,7 +113,7 @@ typedef struct pl_shared {
   uint32_t nlow, r2, nfree, cand[3];
   uint32_t arena_top, nrows, nrec, opbase; /* nrec: op records written by pl_w_init */
   uint32_t uslot_fill, tmp0, tmp1;
-  uint32_t off_ops, off_sync, nsyncw;
+  uint32_t off_ops;
   uint32_t lv_in_lds, opq_group[2];
   uint32_t tmp_mhoff; /* byte offset of MhT inside the dense LDS region (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
@@ -1141,7 +1141,6 @@ template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt)
   uint32_t bin_bound = ((sh->nlow + PL_EXTRA_ROWS) * (sh->nlow + PL_EXTRA_ROWS) + NRQ_ROW - 1u) / NRQ_ROW + 1u;
   uint32_t total_rows = rows + bin_bound + NRQ_PAD_ROWS;
   sh->off_ops = pl_r16(c.fixed_end);
-  sh->off_sync = 0;
   sh->arena_top = pl_r16(sh->off_ops + total_rows * NRQ_ROW * 4u);
   sh->opbase = total_rows;
   if (sh->arena_top > c.job.arena_cap) sh->status = PL_FAIL_CAPACITY;
@@ -1659,12 +1658,12 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   h.reserved[1] = sh->nextra; /* repair symbols taken beyond job.nrep */
   h.K = p.Kp; h.Kp = p.Kp; h.S = p.S; h.H = p.H; h.W = p.W; h.L = p.L; h.P = p.P; h.B = p.B;
   h.M = sh->M; h.npiv = sh->npiv; h.u = p.L - sh->npiv; h.nlow = sh->nlow; h.r2 = sh->r2; h.nfree = sh->nfree;
-  h.nlev = sh->nlev; h.nrows = sh->nrows; h.pipe = NRQ_PIPE; h.wpr = sh->wpr; h.lpr = sh->lpr;
+  h.nlev = sh->nlev; h.nrows = sh->nrows; h.pipe = NRQ_PIPE; h.wpr = sh->wpr;
   h.npiv_pad = sh->tmp0;
   h.off_ops = sh->off_ops; h.off_pivslot = c.off_pivslot; h.off_pivcol = c.off_pivcol; h.off_wt = sh->partial[0];
-  h.off_lowslot = c.off_lowslot; h.off_g2 = 0; h.off_pivx = c.off_pivx; h.off_fbits = c.off_fbits; h.off_mh = c.off_mh;
+  h.off_lowslot = c.off_lowslot; h.off_pivx = c.off_pivx; h.off_fbits = c.off_fbits; h.off_mh = c.off_mh;
   h.off_freex = c.off_freex; h.off_hinv = c.off_hinv; h.off_colslot = c.off_colslot; h.off_pivof = c.off_pivof;
-  h.off_uslot = c.off_uslot; h.off_sync = sh->off_sync; h.total_bytes = sh->arena_top;
+  h.off_uslot = c.off_uslot; h.total_bytes = sh->arena_top;
   if (!sh->status) {
     const uint32_t nl = c.job.nlost;
     uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + sh->partial[2]);

@@ -15,7 +15,7 @@
  *   3. the u inactive columns: GF(2) Gauss-Jordan on the leftover binary rows first, the H HDPC
  *      rows (GF(256)) only for the columns the binary rows cannot resolve (reference:
  *      solve_gf2 / fill_HDPC / solve_gf256, precode.c:232-315).
- * The GPU planner (planner.hip) produces the same format; this one is the portable twin used
+ * The GPU planner (planner_body.h, instantiated by nrq_plan_kernel in nrq_device.hip) produces the same format; this one is the portable twin used
  * for plans that are built once per K' (encode) and as its cross-check.
  */
 #include <algorithm>
@@ -548,7 +548,7 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   hd.magic = NRQ_PLAN_MAGIC; hd.status = status;
   hd.K = K; hd.Kp = p.Kp; hd.J = p.J; hd.S = S; hd.H = H; hd.W = W; hd.L = L; hd.P = p.P; hd.P1 = p.P1; hd.B = p.B;
   hd.M = M; hd.npiv = npiv; hd.u = u; hd.nlow = nlow; hd.r2 = r2; hd.nfree = nfree; hd.nlev = nlev;
-  hd.nrows = op_rows; hd.pipe = NRQ_PIPE; hd.wpr = wpr; hd.lpr = lpr;
+  hd.nrows = op_rows; hd.pipe = NRQ_PIPE; hd.wpr = wpr;
   hd.npiv_pad = (npiv + 63u) & ~63u;
   hd.n_xor_ops = n_real_ops;
   hd.off_ops = A.reserve((uint32_t)(ops.size() * 4));
@@ -565,7 +565,6 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   }
   hd.off_lowslot = A.reserve(std::max(1u, nlow) * 2);
   if (nlow) memcpy(A.at<uint8_t>(hd.off_lowslot), lowslot.data(), (size_t)nlow * 2);
-  hd.off_g2 = 0;
   hd.off_pivx = A.reserve(std::max(1u, r2) * 2);
   for (uint32_t q = 0; q < r2; q++) A.at<uint16_t>(hd.off_pivx)[q] = (uint16_t)red_x[q];
   hd.off_fbits = A.reserve(std::max(1u, r2) * 4);
@@ -582,7 +581,6 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   memcpy(A.at<uint8_t>(hd.off_pivof), pivof.data(), (size_t)n_hd * 2);
   hd.off_uslot = A.reserve(std::max(1u, u) * 2);
   if (u) memcpy(A.at<uint8_t>(hd.off_uslot), uslot.data(), (size_t)u * 2);
-  hd.off_sync = 0;
   hd.total_bytes = align16((uint32_t)A.buf.size());
   A.buf.resize(hd.total_bytes, 0);
   memcpy(A.buf.data(), &hd, sizeof(hd));

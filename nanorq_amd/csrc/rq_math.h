@@ -4,7 +4,8 @@
  * Tuple (5.3.5.4) and the LT column expansion used for both constraint rows and symbol generation.
  *
  * Replaces, on this path, the reference's params.c:21-65, tuple.c:13-43, rand.c:183-190
- * (behaviour identical; verified against the oracle in tests/test_host_math.py).
+ * (behaviour identical; verified against the oracle in tests/test_planner_emu.py and, on the GPU,
+ * by every parity test of tests/test_gpu_parity.py).
  */
 #ifndef NRQ_RQ_MATH_H
 #define NRQ_RQ_MATH_H

@@ -1,9 +1,10 @@
 /*
  * solve_body.h -- the data stage of the precode solve for ONE column strip of ONE source block,
- * written as per-thread phase functions.  solve.hip instantiates them inside the gfx950 kernel
- * (one 256-thread workgroup per strip, `__syncthreads()` between phases); tests/emu compiles the
- * same functions with g++ and runs the 256 "threads" of a phase in a loop, so the indexing, the
- * GF(256) bit tricks and the strip handling are exercised on the CPU build machine as well.
+ * written as per-thread phase functions.  nrq_solve_kernel (nrq_device.hip) instantiates them inside the
+ * gfx950 kernel (persistent 768- or 256-thread workgroups, `__syncthreads()` between phases); tests/emu
+ * compiles the same functions with g++ and runs the threads of a phase in a loop, so the indexing, the
+ * GF(256) bit tricks and the strip handling are exercised on the CPU build machine as well (the row pipeline
+ * fwd_rows / fwd_rows_half exists on the device only: the emulator has its own row loop).
  *
  * What it replaces in the reference: precode_matrix_intermediate (precode.c:379-389 =
  * apply_sched :23-32 + permute :3-13), decode_row / APPLYROW (nanorq.c:8-13,:184-204) and the

@@ -17,3 +17,23 @@ def orc():
     import oracle
     oracle.lib()
     return oracle
+
+
+_TORCH_UP = False
+
+
+def pytest_runtest_setup(item):
+    """Before the first GPU test touches the HIP path: bring torch's GPU runtime up.  torch ships its own copy of the
+    HIP runtime and only finds the device if it initialises BEFORE the runtime libnanorq_hip.so links against opens
+    it (bench.py has the same order); some GPU tests keep blocks in HBM as torch tensors."""
+    global _TORCH_UP
+    if _TORCH_UP or item.get_closest_marker("gpu") is None:
+        return
+    _TORCH_UP = True
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.empty(1, device="cuda")
+    except ImportError:
+        pass

@@ -9,6 +9,16 @@ _CTX = None
 def ctx():
     global _CTX
     if _CTX is None:
+        # Tests that keep blocks in HBM use torch tensors.  torch brings its own copy of the HIP runtime, and it only
+        # finds the GPU if it initialises BEFORE the runtime libnanorq_hip.so is linked against opens the device
+        # (bench.py has the same order): bring torch up first.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+                torch.empty(1, device="cuda")
+        except ImportError:
+            pass
         _CTX = nanorq_amd.Context(0)
     return _CTX
 

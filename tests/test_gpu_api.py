@@ -111,14 +111,14 @@ def test_decode_retry_after_more_symbols():
 
 
 def test_reference_benchmark_harness_on_the_hip_path():
-    """oracle/_ref/benchmark_hip = the reference's benchmark.c compiled (in the build container, sources read in
+    """oracle/_refprog/benchmark_hip = the reference's benchmark.c compiled (in the build container, sources read in
     place) against this library: encode / precalc-encode / decode / decode-with-overhead runs, 6 % loss, ending in
     the harness's own assert(in[i] == out[i]) (reference benchmark.c:233-235)."""
     import os
     import subprocess
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "benchmark_hip")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_refprog", "benchmark_hip")
     if not os.path.isfile(exe):
-        pytest.skip("oracle/_ref/benchmark_hip not built (needs the reference tree at build time)")
+        pytest.skip("oracle/_refprog/benchmark_hip not built (needs the reference tree at build time)")
     for argv in (["1024", "100", "0"], ["1280", "1000", "5.0"]):
         r = subprocess.run([exe] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert r.returncode == 0, (argv, r.stderr.decode()[-500:])

@@ -59,10 +59,10 @@ def test_too_few_packets_is_reported(tmp_path):
     assert r.returncode == 2
 
 
-def _ref(name):
-    p = os.path.join(ROOT, "oracle", "_ref", name)
+def _refprog(name):
+    p = os.path.join(ROOT, "oracle", "_refprog", name)
     if not os.path.isfile(p):
-        pytest.skip("oracle/_ref/%s not built (needs the reference tree at build time)" % name)
+        pytest.skip("oracle/_refprog/%s not built (needs the reference tree at build time)" % name)
     return p
 
 
@@ -75,7 +75,7 @@ def test_container_is_the_reference_programs_container(tmp_path):
     src = tmp_path / "in.bin"
     data.tofile(src)
     # reference encode (6 % loss from the clock, +5) -> rqfile decode
-    r = subprocess.run([_ref("encode_hip"), str(src), str(T)], cwd=tmp_path / "a", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    r = subprocess.run([_refprog("encode_hip"), str(src), str(T)], cwd=tmp_path / "a", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-300:]
     r = subprocess.run([_exe(), "decode", str(tmp_path / "a" / "out.bin"), "-i", str(tmp_path / "a" / "data.rq")],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -85,7 +85,7 @@ def test_container_is_the_reference_programs_container(tmp_path):
     r = subprocess.run([_exe(), "encode", str(src), str(T), "-o", str(tmp_path / "b" / "data.rq"), "-l", "8", "-x", "6", "-s", "3"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-300:]
-    r = subprocess.run([_ref("decode_hip"), str(tmp_path / "b" / "out.bin")], cwd=tmp_path / "b", stdout=subprocess.PIPE,
+    r = subprocess.run([_refprog("decode_hip"), str(tmp_path / "b" / "out.bin")], cwd=tmp_path / "b", stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0 and b"failed" not in r.stdout, r.stdout.decode()[-300:]
     assert np.array_equal(np.fromfile(tmp_path / "b" / "out.bin", dtype=np.uint8), data)
