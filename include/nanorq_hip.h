@@ -40,7 +40,7 @@ typedef struct nrq_call_stats {
   uint32_t wg_threads; /* threads per workgroup of the solve launch */
   uint32_t strips_per_slot; /* strips a work slot holds (a whole 128-byte line group unless work is scarce) */
   uint32_t wg_waves_per_simd; /* register budget of the solve kernel variant launched: waves per SIMD it was compiled for */
-  uint32_t reserved_;
+  uint32_t host_planned; /* decode blocks whose plan exceeded a device-planner capacity and was rebuilt on the host */
 } nrq_call_stats;
 
 /* One context per GPU (one process per GPU: no cross-device state).  `stream` is a hipStream_t the

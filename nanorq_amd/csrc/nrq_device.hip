@@ -450,6 +450,9 @@ struct Tuning {
   uint64_t solve_grid = 0;   /* NRQ_SOLVE_GRID: persistent workgroups of the solve launch (0 = fill the device) */
   uint32_t max_wb = 16;      /* NRQ_MAX_WB: widest strip considered */
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
+  bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
+  int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
+  bool no_plan_stream = false; /* NRQ_NO_PLAN_STREAM: planner kernel on the caller's stream (no overlap with the solve before it) */
   void read() {
     auto flag = [](const char *n) { const char *e = getenv(n); return e != nullptr; };
     auto num = [](const char *n, long long d) { const char *e = getenv(n); return (e && *e) ? atoll(e) : d; };
@@ -457,6 +460,7 @@ struct Tuning {
     prof = flag("NRQ_PROF"); plan_lds_max = flag("NRQ_PLAN_LDS_MAX"); plan_big_wg = flag("NRQ_PLAN_BIG_WG");
     small_div = (uint32_t)num("NRQ_SMALL_DIV", 2); solve_grid = (uint64_t)num("NRQ_SOLVE_GRID", 0);
     max_wb = (uint32_t)num("NRQ_MAX_WB", 16); prof_base = (int)num("NRQ_PROF_BASE", 2);
+    no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
   }
 };
 
@@ -488,6 +492,18 @@ struct nrq_ctx {
   DevBuf plan_work, plan_arena, plan_jobs;
   DevBuf stage; /* solve kernel: staging buffers of the persistent workgroups */
   bool plan_attr = false;
+  /* The planner kernel runs on a stream of its own: it depends on the reception pattern only, not on the symbols, so
+   * it may run beside whatever the caller's stream is still doing (typically the encode solve launched just before).
+   * `planned`: planner + header download done (the host waits for it, the solve launch on the caller's stream is
+   * ordered behind it); `arena_free`: the solve that reads the plan arenas / job records has finished -- the next
+   * planner launch overwrites them and waits for it. */
+  hipStream_t plan_stream = nullptr;
+  hipEvent_t planned = nullptr, arena_free = nullptr;
+  bool arena_busy = false;
+  DevBuf pscratch[2]; /* planner inputs: buffers of their own (the per-call arrays above belong to the caller's stream) */
+  PinBuf pstaging[2];
+  hipEvent_t pstaged[2] = {nullptr, nullptr};
+  int pflip = 0;
 };
 
 namespace {
@@ -642,6 +658,15 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   if (occ < 1u) occ = 1u;
   /* persistent workgroups fill the device; a multiple of 8 keeps a workgroup's slots on its XCD */
   uint64_t grid = (uint64_t)(ctx->ncu / 8) * 8 * occ;
+  /* A batch of few big blocks: leave a compute unit per block (one per XCD at least) to the planner workgroups of the
+   * decode that follows or runs beside this launch on the context's planner stream (decode_device) -- a planner
+   * workgroup needs a whole CU's LDS, and the persistent workgroups of this launch would otherwise hold every CU until
+   * they are all done.  ~3 % of the solve's throughput for 8 blocks; the planner (one workgroup per block, latency
+   * bound: 12 ms at K=27000, 36 ms at K'=56403) then hides behind the encode solve. */
+  if (!small && occ == 1u) {
+    uint32_t reserve = ctx->tune.reserve_cus >= 0 ? (uint32_t)ctx->tune.reserve_cus : (nblk <= 16u ? (nblk + 7u) / 8u * 8u : 0u);
+    if (reserve + 64u <= grid) grid -= reserve / 8u * 8u;
+  }
   if (ctx->tune.solve_grid) grid = ctx->tune.solve_grid / 8 * 8;
   if (grid < 8) grid = 8;
   /* work slots (nrq_map_group): `sub` strips of a block each -- the strips of a whole line unless that would leave
@@ -653,6 +678,22 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     return by_block ? (uint64_t)((nblk + 7u) / 8u) * 8u * spb : (uint64_t)nblk * spb;
   };
   while (lsub > 0 && slots_for(lsub) < grid) lsub--;
+  {
+    /* Work is dealt statically (workgroup g takes slots g, g + grid, ...): with few big blocks the rounds do not come
+     * out even -- K'=56403, 8 blocks: 320 whole-line slots on 256 workgroups is two rounds for a quarter of them, 32
+     * strips against 20 on average.  Smaller slots even that out; what they cost is gather efficiency (pieces shorter
+     * than a 128-byte line), which matters for wide strips only: a 2- or 4-byte strip is solved at the same cost per
+     * strip as a 16-byte one, so its data movement is an eighth or a quarter of the time share. */
+    auto max_strips = [&](uint32_t ls) -> uint64_t {
+      const uint64_t ns = slots_for(ls), g = grid < ns ? grid : ns;
+      return ((ns + g - 1) / g) << ls;
+    };
+    const uint32_t min_ls = WB >= 8 ? (lsub < 2u ? lsub : 2u) : 0u;
+    uint32_t best = lsub;
+    for (uint32_t ls = lsub; ls-- > min_ls;)
+      if (max_strips(ls) * 100u < max_strips(best) * 93u) best = ls;
+    if (!ctx->tune.no_balance) lsub = best;
+  }
   const uint64_t nslots = slots_for(lsub);
   if (nslots > 0x7FFFFFFFull) return fail(ctx, -4, "grid too large");
   if (grid > nslots) grid = by_block ? (nslots + 7) / 8 * 8 : nslots;
@@ -801,7 +842,12 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
   ctx->tune.read();
   if (getenv("NRQ_HOST_PLANNER")) ctx->planner = 0;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
-  if (hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->planned, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->arena_free, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->pstaged[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->pstaged[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->encplan_uploaded, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->staged[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->staged[1], hipEventDisableTiming) != hipSuccess) {
@@ -836,11 +882,17 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
     if (kv.second.dev) (void)hipFree(kv.second.dev);
     nrq_host_free(kv.second.host);
   }
+  if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
+  if (ctx->planned) (void)hipEventDestroy(ctx->planned);
+  if (ctx->arena_free) (void)hipEventDestroy(ctx->arena_free);
   if (ctx->plan_work.p) (void)hipFree(ctx->plan_work.p);
   if (ctx->plan_arena.p) (void)hipFree(ctx->plan_arena.p);
   if (ctx->plan_jobs.p) (void)hipFree(ctx->plan_jobs.p);
   if (ctx->stage.p) (void)hipFree(ctx->stage.p);
   for (int i = 0; i < 2; i++) {
+    if (ctx->pscratch[i].p) (void)hipFree(ctx->pscratch[i].p);
+    if (ctx->pstaging[i].p) (void)hipHostFree(ctx->pstaging[i].p);
+    if (ctx->pstaged[i]) (void)hipEventDestroy(ctx->pstaged[i]);
     if (ctx->scratch[i].p) (void)hipFree(ctx->scratch[i].p);
     if (ctx->staging[i].p) (void)hipHostFree(ctx->staging[i].p);
     if (ctx->staged[i]) (void)hipEventDestroy(ctx->staged[i]);
@@ -1173,12 +1225,15 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   const size_t in_bytes = r16(off_resi + (size_t)nblk * rep_cap * 4);
   const size_t off_hdrs = in_bytes;
   const size_t total = r16(off_hdrs + (size_t)nblk * sizeof(nrq_plan_hdr));
-  const int f = ctx->flip;
-  ctx->flip ^= 1;
-  HIPCHK(ctx, hipEventSynchronize(ctx->staged[f]));
-  if ((rc = ensure_pin(ctx, ctx->staging[f], total))) return rc;
-  if ((rc = ensure_dev(ctx, ctx->scratch[f], in_bytes))) return rc;
-  uint8_t *hs = ctx->staging[f].p, *ds = ctx->scratch[f].p;
+  /* everything up to the headers' way back runs on the planner stream (see nrq_ctx::plan_stream) */
+  hipStream_t ps = ctx->tune.no_plan_stream ? ctx->stream : ctx->plan_stream;
+  const int f = ctx->pflip;
+  ctx->pflip ^= 1;
+  HIPCHK(ctx, hipEventSynchronize(ctx->pstaged[f]));
+  if ((rc = ensure_pin(ctx, ctx->pstaging[f], total))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->pscratch[f], in_bytes))) return rc;
+  uint8_t *hs = ctx->pstaging[f].p, *ds = ctx->pscratch[f].p;
+  if (ctx->arena_busy && ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ps, ctx->arena_free, 0));
   memcpy(hs + off_lost, h_lost, (size_t)nblk * lost_cap * 4);
   memcpy(hs + off_resi, h_rep_esi, (size_t)nblk * rep_cap * 4);
   nrq_planjob *pj = reinterpret_cast<nrq_planjob *>(hs + off_pj);
@@ -1199,7 +1254,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     if (sane && h_avail && h_avail[b] > j.nrep) j.nrep_avail = h_avail[b] < rep_cap ? h_avail[b] : rep_cap;
     j.arena_cap = arena_cap;
   }
-  HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ps));
   const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared));
   /* dynamic LDS: everything a CU has for a big block; for small blocks what the planner can use (peeling state plus the
    * dense-stage reserve, or a 16-byte strip image of the W rows), so that two workgroups share a CU */
@@ -1221,21 +1276,21 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   unsigned long long *pprof = nullptr;
   if (ctx->tune.prof) {
     HIPCHK(ctx, hipMalloc((void **)&pprof, 32 * 8));
-    HIPCHK(ctx, hipMemsetAsync(pprof, 0, 32 * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(pprof, 0, 32 * 8, ps));
   }
   if (small_wg)
-    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ctx->stream, p,
+    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p,
                        (const uint8_t *)kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
                        reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, dyn_bytes, pprof);
   else
-    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ctx->stream, p,
+    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p,
                        (const uint8_t *)kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
                        reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, dyn_bytes, pprof);
   HIPCHK(ctx, hipGetLastError());
   if (pprof) {
     unsigned long long hp[32];
-    HIPCHK(ctx, hipMemcpyAsync(hp, pprof, sizeof(hp), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hp, pprof, sizeof(hp), hipMemcpyDeviceToHost, ps));
+    HIPCHK(ctx, hipStreamSynchronize(ps));
     static const char *nm[16] = {"init", "claim", "Wrun", "drop", "Wmove", "ifind", "iapply", "lev", "W", "low", "ops", "mh",
                                  "gj", "bin", "dense", "final"};
     unsigned long long tot = 0;
@@ -1246,9 +1301,10 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     (void)hipFree(pprof);
   }
   HIPCHK(ctx, hipMemcpy2DAsync(hs + off_hdrs, sizeof(nrq_plan_hdr), ctx->plan_arena.p, arena_cap, sizeof(nrq_plan_hdr), nblk,
-                               hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipEventRecord(ctx->staged[f], ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                               hipMemcpyDeviceToHost, ps));
+  HIPCHK(ctx, hipEventRecord(ctx->pstaged[f], ps));
+  HIPCHK(ctx, hipEventRecord(ctx->planned, ps));
+  HIPCHK(ctx, hipEventSynchronize(ctx->planned));
   ctx->stats.plan_ms = now_ms() - t_begin;
   const nrq_plan_hdr *hd = reinterpret_cast<const nrq_plan_hdr *>(hs + off_hdrs);
   std::vector<const nrq_plan_hdr *> hdrs;
@@ -1267,6 +1323,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
       ctx->stats.xor_ops += hd[b].n_xor_ops;
       ctx->stats.plan_bytes += hd[b].total_bytes;
     } else if (hd[b].reserved[0] == PL_FAIL_CAPACITY) {
+      if (ctx->tune.prof) fprintf(stderr, "[NRQ_PROF] block %u: device planner capacity exceeded at planner_body.h:%u\n", b, hd[b].fail_site);
       (*fallback)[b] = 1;
       need_fallback = true;
       h_status[b] = 0;
@@ -1275,9 +1332,14 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     }
   }
   int result = 0;
-  if (!hdrs.empty())
+  if (!hdrs.empty()) {
+    if (ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->planned, 0));
     result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ctx->plan_jobs.p), nblk, T, kc->dev,
                              (d_inter ? p.L : 0u) + max_nl);
+    /* the launch reads the plan arenas and job records: the next planner run may not overwrite them before it is done */
+    HIPCHK(ctx, hipEventRecord(ctx->arena_free, ctx->stream));
+    ctx->arena_busy = true;
+  }
   ctx->stats.host_ms = now_ms() - t_begin;
   if (result) return result;
   return need_fallback ? 1 : 0;
@@ -1298,8 +1360,13 @@ int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, ui
                          rep_stride, d_inter, inter_stride, h_status, &fallback, h_nrep_avail, h_used);
   if (rc <= 0) return rc;
   /* blocks that exceeded a device-planner capacity are planned on the host (rare) */
-  return decode_host(ctx, fallback.data(), K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
+  uint32_t nfb = 0;
+  for (uint8_t f : fallback) nfb += f;
+  rc = decode_host(ctx, fallback.data(), K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
                      h_nrep_avail, h_used, rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);
+  ctx->stats.host_planned = nfb;
+  if (ctx->tune.prof) fprintf(stderr, "[NRQ_PROF] %u of %u blocks re-planned on the host (device planner capacity)\n", nfb, nblk);
+  return rc;
 }
 
 int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,

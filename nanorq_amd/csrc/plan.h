@@ -89,7 +89,8 @@ typedef struct nrq_plan_hdr {
   uint32_t off_pivof;   /* u16[Kp+S]: slot of the pivot row of column c, NRQ_NOSLOT if inactive */
   uint32_t off_uslot;   /* u16[u]: slot that receives inactive column x */
   uint32_t total_bytes;
-  uint32_t reserved[2];
+  uint32_t reserved[2]; /* device planner: [0] = PL_FAIL_* reason, [1] = repair symbols taken beyond the initial ones */
+  uint32_t fail_site;   /* device planner: planner_body.h line that raised a capacity failure (diagnostics) */
 } nrq_plan_hdr;
 
 /* Per-K' constants shared by every plan of that K': the HDPC block (RFC 6330 section 5.3.3.3) and the

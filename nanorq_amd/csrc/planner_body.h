@@ -105,7 +105,7 @@ SB_HD uint32_t pl_r16(uint32_t x) { return (x + 15u) & ~15u; }
 #define PL_FAIL_CAPACITY 2u
 
 typedef struct pl_shared {
-  uint32_t status;
+  uint32_t status, fail_site; /* fail_site: source line that raised PL_FAIL_CAPACITY (diagnostics) */
   uint32_t M, overhead, npatch, wpr, lpr, rowlen;
   uint32_t nV, npiv, ninact, nlev;
   uint32_t nq[2], nclaim[2]; /* frontier / claim counts, indexed by round parity */
@@ -115,7 +115,7 @@ typedef struct pl_shared {
   uint32_t uslot_fill, tmp0, tmp1;
   uint32_t off_ops;
   uint32_t lv_in_lds, opq_group[2];
-  uint32_t tmp_mhoff; /* byte offset of MhT inside the dense LDS region (fixed once nlow is known) */
+  uint32_t tmp_mhoff; /* byte offset of Mb inside the dense LDS region, behind MhT (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
   uint16_t queue[2][PL_QCAP];
   uint16_t claim_l[PL_QCAP], claim_c[PL_QCAP]; /* columns claimed this round: level + 1 of the pivot, column */
@@ -349,6 +349,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     if (!st && (p.L + oh + PL_EXTRA_ROWS > c.Mcap || nr + PL_EXTRA_ROWS > c.npcap || p.L + oh + PL_EXTRA_ROWS > 65534u))
       st = PL_FAIL_CAPACITY;
     sh->status = st;
+    sh->fail_site = 0;
     sh->overhead = oh;
     sh->M = p.L + oh;
     sh->npatch = st ? 0 : nr;
@@ -453,7 +454,7 @@ template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) 
   for (uint32_t r = tid; r < sh->M; r += nt) {
     if ((c.rowstate[r] >> 24) == 1u) {
       uint32_t j = PL_ATOM_ADD(&sh->nq[0], 1u);
-      if (j < PL_QCAP) sh->queue[0][j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
+      if (j < PL_QCAP) sh->queue[0][j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     }
   }
 }
@@ -494,7 +495,7 @@ SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lv
     const uint32_t old = PL_ATOM_SUB(&s.rowstate[r], dec);
     if ((old >> 24) == 2u && (info & PL_UNASSIGNED)) {
       const uint32_t j = PL_ATOM_ADD(&sh->nq[np], 1u);
-      if (j < PL_QCAP) nextq[j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
+      if (j < PL_QCAP) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     }
   }
 }
@@ -521,7 +522,7 @@ template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_
     s.rowinfo[r] = (info & PL_PATCHED) | lv; /* assigned: bit 31 cleared */
     s.colinfo[col] = (PL_ST_PIVOT << 30) | k;
     PL_ATOM_SUB(&sh->nV, 1u); /* (the number of levels is taken from the pivots once peeling is over: pl_lev_0) */
-    if (i < PL_QCAP) { sh->claim_l[i] = (uint16_t)(lv + 1u); sh->claim_c[i] = (uint16_t)col; } else sh->status = PL_FAIL_CAPACITY;
+    if (i < PL_QCAP) { sh->claim_l[i] = (uint16_t)(lv + 1u); sh->claim_c[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
     c.pivcol[k] = (uint16_t)col;
   }
@@ -582,7 +583,7 @@ template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, ui
       if (s.colinfo[col] == 0u) {
         const uint32_t x = p.P + PL_ATOM_ADD(&sh->ninact, 1u);
         if (x < c.ucap) { s.colinfo[col] = (PL_ST_INACT << 30) | x; c.ucol[x] = (uint16_t)col; }
-        else sh->status = PL_FAIL_CAPACITY;
+        else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
       }
     }
     return;
@@ -620,7 +621,7 @@ template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, ui
     for (uint32_t q = 0; q < CB; q++) {
       if (k0 + q >= n || inf[q] != 0u || col[q] == keep || full) continue;
       const uint32_t x = p.P + sh->ninact;
-      if (x >= c.ucap || m >= PL_QCAP) { sh->status = PL_FAIL_CAPACITY; full = true; continue; }
+      if (x >= c.ucap || m >= PL_QCAP) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); full = true; continue; }
       sh->ninact++;
       s.colinfo[col[q]] = (PL_ST_INACT << 30) | x;
       c.ucol[x] = (uint16_t)col[q];
@@ -707,7 +708,7 @@ template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (tid == 0) {
     const uint32_t u = c.p.L - sh->npiv;
     sh->wpr = u ? (u + 31u) / 32u : 1u;
-    if (c.p.P + sh->ninact != u) sh->status = PL_FAIL_CAPACITY; /* cannot happen: every column is pivot or inactive */
+    if (c.p.P + sh->ninact != u) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* cannot happen: every column is pivot or inactive */
   }
   for (uint32_t l = tid; l < sh->nlev + 2u; l += nt) { c.lev_ops[l] = 0; c.lev_fill[l] = 0; }
 }
@@ -733,7 +734,7 @@ SB_HD void pl_record_op(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16
   const uint32_t idx = PL_ATOM_ADD(early ? &cntN[g] : &cntF[g], 1u);
   const uint32_t src = c.pivslot[info & 0x3FFFFFFFu];
   const uint32_t i = PL_ATOM_ADD(&c.sh->nrec, 1u);
-  if (i >= c.reccap) { c.sh->status = PL_FAIL_CAPACITY; return; }
+  if (i >= c.reccap) { (c.sh->fail_site = __LINE__, c.sh->status = PL_FAIL_CAPACITY); return; }
   c.rec_word[i] = NRQ_OP(r, src);
   c.rec_idx[i] = early | idx;
   c.rec_g[i] = (uint16_t)g;
@@ -768,7 +769,7 @@ SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16
       const uint32_t early = g == lev ? 0u : 0x80000000u;
       const uint32_t at = PL_ATOM_ADD(early ? &cntN[g] : &cntF[g], 1u);
       const uint32_t i = PL_ATOM_ADD(&c.sh->nrec, 1u);
-      if (i >= c.reccap) { c.sh->status = PL_FAIL_CAPACITY; continue; }
+      if (i >= c.reccap) { (c.sh->fail_site = __LINE__, c.sh->status = PL_FAIL_CAPACITY); continue; }
       c.rec_word[i] = NRQ_OP(r[j], src[j]);
       c.rec_idx[i] = early | at;
       c.rec_g[i] = (uint16_t)g;
@@ -1045,7 +1046,7 @@ template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /*
   for (uint32_t r = tid; r < sh->M; r += nt) {
     if (!(c.rowinfo[r] & PL_UNASSIGNED) || (r >= p.S && r < p.S + p.H)) continue;
     uint32_t j = PL_ATOM_ADD(&sh->nlow, 1u);
-    if (j < c.ucap + 32u && j < PL_LOWCAP) c.lowslot[j] = (uint16_t)r; else sh->status = PL_FAIL_CAPACITY;
+    if (j < c.ucap + 32u && j < PL_LOWCAP) c.lowslot[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
   }
 }
 template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
@@ -1054,17 +1055,20 @@ template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   sh->nq[0] = 0; /* the frontier queue becomes pl_w_init's list of long rows */
   sh->lpr = (sh->nlow + PL_EXTRA_ROWS + 31u) / 32u; /* room for the rows a rank-deficient block may add */
   sh->rowlen = sh->wpr + sh->lpr;
-  /* Mb (nlow x rowlen words) and Mh (H x u bytes) share the dynamic LDS region from here on */
-  if (sh->nlow + PL_EXTRA_ROWS > PL_LOWCAP) sh->status = PL_FAIL_CAPACITY;
-  sh->tmp_mhoff = pl_r16((sh->nlow + PL_EXTRA_ROWS) * sh->rowlen * 4u);
-  uint32_t need = pl_r16((sh->nlow + PL_EXTRA_ROWS) * sh->rowlen * 4u) + pl_r16(PL_MAXH * (c.p.L - sh->npiv)) + PL_MH_TILE * 16u +
-                  PL_MH_TILE * sh->wpr * 4u;
-  if (need > c.dense_bytes || sh->wpr > 40u) sh->status = PL_FAIL_CAPACITY;
+  /* The dense stage's share of the dynamic LDS region from here on: MhT (16 bytes per inactive column) first, then
+   * Mb (nlow x rowlen words).  The tiles of the HDPC fold (pl_mh_load / pl_mh_acc) lie over Mb's place: Mb is loaded
+   * only after the fold (pl_low_c; planner_seq.h) -- with separate places K'=56403 at 20 % loss needed 141-147 KB of
+   * the ~140 KB there are, and one block in eight went to the host planner for it. */
+  if (sh->nlow + PL_EXTRA_ROWS > PL_LOWCAP) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+  sh->tmp_mhoff = pl_r16(PL_MAXH * (c.p.L - sh->npiv)); /* byte offset of Mb (and of the tiles) behind MhT */
+  const uint32_t mb_bytes = pl_r16((sh->nlow + PL_EXTRA_ROWS) * sh->rowlen * 4u), tile_bytes = PL_MH_TILE * 16u + PL_MH_TILE * sh->wpr * 4u;
+  const uint32_t need = sh->tmp_mhoff + (mb_bytes > tile_bytes ? mb_bytes : tile_bytes);
+  if (need > c.dense_bytes || sh->wpr > 40u) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
 }
-SB_HD uint32_t *pl_mb(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(c.dense_lds); }
 /* HDPC rows over the inactive columns, transposed: 16 bytes (one per HDPC row) per inactive column */
-SB_HD uint8_t *pl_mhm(const PlanCtx &c) { return c.dense_lds + c.sh->tmp_mhoff; }
-SB_HD uint8_t *pl_gtile(const PlanCtx &c) { return pl_mhm(c) + pl_r16(PL_MAXH * (c.p.L - c.sh->npiv)); }
+SB_HD uint8_t *pl_mhm(const PlanCtx &c) { return c.dense_lds; }
+SB_HD uint32_t *pl_mb(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(c.dense_lds + c.sh->tmp_mhoff); }
+SB_HD uint8_t *pl_gtile(const PlanCtx &c) { return c.dense_lds + c.sh->tmp_mhoff; }
 SB_HD uint32_t *pl_wtile(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(pl_gtile(c) + PL_MH_TILE * 16u); }
 
 /* reduced coefficient rows of the leftover rows over the inactive columns (their W rows after the op
@@ -1111,7 +1115,7 @@ template <int Z> SB_HD void pl_ops_layout_a(PlanCtx &c, uint32_t tid, uint32_t n
     c.lev_ops[l] = n;
     c.lev_fin[l] = nf;
     if (in_lds) {
-      if (span > 0xFFFFu) sh->status = PL_FAIL_CAPACITY;
+      if (span > 0xFFFFu) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
       rowq[l] = (uint16_t)span;
     }
   }
@@ -1143,7 +1147,7 @@ template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt)
   sh->off_ops = pl_r16(c.fixed_end);
   sh->arena_top = pl_r16(sh->off_ops + total_rows * NRQ_ROW * 4u);
   sh->opbase = total_rows;
-  if (sh->arena_top > c.job.arena_cap) sh->status = PL_FAIL_CAPACITY;
+  if (sh->arena_top > c.job.arena_cap) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
 }
 template <int Z> SB_HD void pl_ops_clear(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
@@ -1366,7 +1370,7 @@ template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   c.lev_base[g] = sh->tmp0;
   sh->nrows = sh->tmp0 + pl_group_rows(run);
   if ((sh->nrows + NRQ_PAD_ROWS > sh->opbase || sh->M + sh->r2 + NRQ_SCRATCH > 65535u) && sh->status == 0)
-    sh->status = PL_FAIL_CAPACITY; /* op fields are 16 bits */
+    (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* op fields are 16 bits */
 }
 template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
@@ -1489,7 +1493,7 @@ template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t esi = c.rep_esi[i];
   if (esi < p.K || esi >= (1u << 24)) { sh->status = PL_FAIL_SINGULAR; return; }
   const uint32_t row = sh->M, j = sh->nlow;
-  if (row + 1u > c.Mcap || i + 1u > c.npcap || j + 1u > PL_LOWCAP) { sh->status = PL_FAIL_CAPACITY; return; }
+  if (row + 1u > c.Mcap || i + 1u > c.npcap || j + 1u > PL_LOWCAP) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); return; }
   uint32_t cols[RQ_MAX_LT_COLS];
   const uint32_t n = rq_lt_columns(&p, esi + (p.Kp - p.K), cols);
   uint16_t *dst = c.patch_cols + (size_t)i * PL_PATCH_STRIDE;
@@ -1498,7 +1502,7 @@ template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     dst[k] = (uint16_t)cols[k];
     const uint32_t info = c.colinfo[cols[k]];
     if ((info >> 30) == PL_ST_PIVOT) {
-      if (sh->spare_fill >= PL_SPARE_ROWS * NRQ_ROW) { sh->status = PL_FAIL_CAPACITY; return; }
+      if (sh->spare_fill >= PL_SPARE_ROWS * NRQ_ROW) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); return; }
       ops[sh->spare_fill++] = NRQ_OP(row, c.pivslot[info & 0x3FFFFFFFu]);
     }
   }
@@ -1564,7 +1568,7 @@ template <int Z> SB_HD void pl_extra_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 
 template <int Z> SB_HD void pl_mark_failed(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  if (tid == 0) c.sh->status = PL_FAIL_CAPACITY;
+  if (tid == 0) (c.sh->fail_site = __LINE__, c.sh->status = PL_FAIL_CAPACITY);
 }
 
 /* =============================== phase 8: maps, W image, job ================================= */
@@ -1602,7 +1606,7 @@ template <int Z> SB_HD void pl_final_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->partial[3] = o; o = pl_r16(o + nl * 4u + 4u);                     /* out_row */
     sh->partial[4] = o; o = pl_r16(o + nl * PL_PATCH_STRIDE * 2u + 16u);  /* out_slots */
     sh->arena_top = o;
-    if (o > c.job.arena_cap) sh->status = PL_FAIL_CAPACITY;
+    if (o > c.job.arena_cap) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     (void)p;
   }
 }
@@ -1656,6 +1660,7 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   h.status = sh->status ? 1u : 0u;
   h.reserved[0] = sh->status; /* PL_FAIL_* reason */
   h.reserved[1] = sh->nextra; /* repair symbols taken beyond job.nrep */
+  h.fail_site = sh->fail_site;
   h.K = p.Kp; h.Kp = p.Kp; h.S = p.S; h.H = p.H; h.W = p.W; h.L = p.L; h.P = p.P; h.B = p.B;
   h.M = sh->M; h.npiv = sh->npiv; h.u = p.L - sh->npiv; h.nlow = sh->nlow; h.r2 = sh->r2; h.nfree = sh->nfree;
   h.nlev = sh->nlev; h.nrows = sh->nrows; h.pipe = NRQ_PIPE; h.wpr = sh->wpr;

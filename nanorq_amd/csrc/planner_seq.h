@@ -74,12 +74,12 @@
         for (uint32_t lv_ = 1; lv_ <= sh_->nlev; lv_++) PL_PHASE1(pl_w_group, lv_);
       }
     }
-    PL_PHASE(pl_low_c);
     PL_PHASE(pl_mh_init);
     for (uint32_t tl_ = 0; tl_ * PL_MH_TILE < sh_->npiv; tl_++) {
       PL_PHASE1(pl_mh_load, tl_);
       PL_PHASE1(pl_mh_acc, tl_);
     }
+    PL_PHASE(pl_low_c); /* (after the fold: Mb takes the place of the fold's tiles) */
     {
       const uint32_t u_ = c.p.L - sh_->npiv;
       if (u_) PL_PHASE1(pl_gj_a, 0u);
