@@ -54,6 +54,10 @@ void nrq_ctx_last_stats(nrq_ctx *ctx, nrq_call_stats *out);
 /* where decode plans are built: 1 = on the GPU (default; planner kernel, one workgroup per block),
  * 0 = on the host (thread pool).  The environment variable NRQ_HOST_PLANNER=1 selects 0 at creation. */
 int nrq_ctx_set_planner(nrq_ctx *ctx, int device_planner);
+/* Tuning / test knobs of the launch path (the NRQ_* environment variables read at nrq_ctx_create set the same
+ * fields): "max_wb" widest column strip considered (16/8/4/2), "no_split", "no_balance", "no_plan_stream",
+ * "reserve_cus", "solve_grid", "big_wg", "map_spread".  Results never depend on them, only speed. */
+int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value);
 /* threads used for host-side planning (0 = hardware concurrency) */
 int nrq_ctx_set_threads(nrq_ctx *ctx, int n);
 

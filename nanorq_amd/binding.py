@@ -48,6 +48,7 @@ def lib():
     L.nrq_ctx_last_stats.restype = None
     L.nrq_ctx_set_threads.argtypes = [vp, C.c_int]
     L.nrq_ctx_set_planner.argtypes = [vp, C.c_int]
+    L.nrq_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
     L.nrq_params.argtypes = [C.c_uint32, u32p]
     L.nrq_precalculate.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.nrq_plan_cache_clear.argtypes = [vp]
@@ -157,6 +158,9 @@ class Context:
 
     def set_planner(self, device=True):
         self._chk(self._L.nrq_ctx_set_planner(self._h, int(bool(device))))
+
+    def set_option(self, name, value):
+        self._chk(self._L.nrq_ctx_set_option(self._h, name.encode(), int(value)))
 
     def set_threads(self, n):
         self._chk(self._L.nrq_ctx_set_threads(self._h, n))

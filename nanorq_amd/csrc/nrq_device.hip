@@ -92,7 +92,8 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
                                                        uint32_t T, uint32_t nstrips, uint32_t by_block, uint32_t nslots,
                                                        uint32_t lsub, const uint8_t *__restrict__ kc,
                                                        uint8_t *__restrict__ stage_all, uint32_t stage_stride,
-                                                       uint32_t ostage_stride, unsigned long long *__restrict__ prof) {
+                                                       uint32_t ostage_stride, unsigned long long *__restrict__ prof,
+                                                       uint8_t *__restrict__ ybuf, size_t ybuf_stride) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t tid = threadIdx.x;
   /* NFW waves run the forward passes (two, half the strip width each, when the strip is wide enough and the workgroup
@@ -125,6 +126,12 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
     g.inter = gptr_w<uint8_t>(j->inter); g.out = gptr_w<uint8_t>(j->out); g.orow = gptr<uint32_t>(j->out_row);
     g.ni = j->inter ? reinterpret_cast<const nrq_plan_hdr *>(j->plan)->L : 0u;
     g.nout = j->nout; g.T = T; g.strip0 = grp * sub; g.nstrips = nstrips; g.lsub = lsub;
+    if (ybuf) { /* split solve: the slot image and C_u go to rows [0, M + u) of the block's work buffer */
+      const nrq_plan_hdr *h = reinterpret_cast<const nrq_plan_hdr *>(j->plan);
+      g.inter = gptr_w<uint8_t>((uint64_t)(uintptr_t)(ybuf + (size_t)blk * ybuf_stride));
+      g.ni = h->M + h->u;
+      g.nout = 0u;
+    }
     return g.ni + g.nout;
   };
   uint32_t q = nrq_next_group(blockIdx.x, nslots, jobs, nblk, gpb, by_block != 0u);
@@ -239,14 +246,20 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       ph_dense_cu<WB>(c, tid, NT);
       __syncthreads();
       NRQ_STAMP(5);
-      ph_tables<WB>(c, tid, NT);
-      __syncthreads();
-      NRQ_STAMP(6);
-      ph_backsub<WB>(c, tid, NT);
-      ph_park<WB>(c, tid, NT);
-      __syncthreads();
-      NRQ_STAMP(7);
-      ph_store<WB>(c, ostage_cur + (size_t)sidx * ostage_stride, tid, NT);
+      if (ybuf) { /* split solve (narrow strips): back-substitution and results are nrq_backsub_kernel / nrq_collect_kernel */
+        NRQ_STAMP(6);
+        NRQ_STAMP(7);
+        ph_store_raw<WB>(c, ostage_cur + (size_t)sidx * ostage_stride, tid, NT);
+      } else {
+        ph_tables<WB>(c, tid, NT);
+        __syncthreads();
+        NRQ_STAMP(6);
+        ph_backsub<WB>(c, tid, NT);
+        ph_park<WB>(c, tid, NT);
+        __syncthreads();
+        NRQ_STAMP(7);
+        ph_store<WB>(c, ostage_cur + (size_t)sidx * ostage_stride, tid, NT);
+      }
       __syncthreads();
       NRQ_STAMP(8);
 #undef NRQ_STAMP
@@ -358,6 +371,142 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
 #undef PL_ACC
 }
 
+/* ---- split solve of big blocks (strips of 2 or 4 bytes) ----
+ * An LDS-resident strip pays every per-row cost per WB bytes; at WB = 2 the back-substitution C(pivot k) = Y_k ^ W_k * C_u
+ * alone is 55 % of a strip (K'=56403: 160 table lookups of TWO bytes per pivot).  It needs no slot image, only Y_k and
+ * the u values C_u -- so for narrow strips the solve kernel stops after the dense stage and hands Y and C_u over as
+ * full-width rows of a per-block work buffer, and this kernel finishes on 32-byte strips: 16-entry XOR tables over
+ * groups of 4 inactive columns in LDS (80 KB at u <= 640), one pivot per thread, 32 bytes per lookup.
+ * Rows [0, M) of the work buffer: slot image (Y at the pivots' slots), rows [M, M + u): C_u.  On return the buffer
+ * holds the FINAL slot image: the pivot rows hold their intermediate symbols, the rows uslot[x] the inactive columns'. */
+template <int SB>
+__global__ __launch_bounds__(256) void nrq_backsub_kernel(const nrq_job *__restrict__ jobs, uint32_t T, uint8_t *__restrict__ ybuf,
+                                                          size_t ybuf_stride, uint32_t nchunks) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t tid = threadIdx.x, strip = blockIdx.x, chunk = blockIdx.y, blk = blockIdx.z;
+  const uint8_t *plan = reinterpret_cast<const uint8_t *>(jobs[blk].plan);
+  const nrq_plan_hdr *h = reinterpret_cast<const nrq_plan_hdr *>(plan);
+  if (h->status) return;
+  const uint32_t M = h->M, u = h->u, wpr = h->wpr, npiv = h->npiv, stride = h->npiv_pad;
+  const NRQ_GAS uint16_t *pivslot = gptr<uint16_t>(plan + h->off_pivslot);
+  const NRQ_GAS uint16_t *uslot = gptr<uint16_t>(plan + h->off_uslot);
+  const NRQ_GAS uint32_t *wt = gptr<uint32_t>(plan + h->off_wt);
+  NRQ_GAS uint8_t *Y = gptr_w<uint8_t>((uint64_t)(uintptr_t)(ybuf + (size_t)blk * ybuf_stride));
+  const NRQ_GAS uint8_t *Cu = Y + (size_t)M * T;
+  const uint32_t col0 = strip * SB, rem = T - col0, valid = rem < (uint32_t)SB ? rem : (uint32_t)SB;
+  constexpr int NQ = SB / 16;
+  auto load = [&](const NRQ_GAS uint8_t *p, SV<16> (&v)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const uint32_t o = (uint32_t)q * 16u;
+      v[q] = o < valid ? g_get<16>(p + o, valid - o < 16u ? valid - o : 16u) : sv_zero<16>();
+    }
+  };
+  auto store = [&](NRQ_GAS uint8_t *p, const SV<16> (&v)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const uint32_t o = (uint32_t)q * 16u;
+      if (o < valid) g_put<16>(p + o, valid - o < 16u ? valid - o : 16u, v[q]);
+    }
+  };
+  /* tables: entry (grp, nib) = XOR of C_u[4 grp + b] over the bits b of nib */
+  const uint32_t ngroups = wpr * 8u;
+  for (uint32_t e = tid; e < ngroups * 16u; e += 256u) {
+    const uint32_t grp = e >> 4, nib = e & 15u;
+    SV<16> acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = sv_zero<16>();
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++) {
+      const uint32_t x = grp * 4u + b;
+      if (((nib >> b) & 1u) && x < u) {
+        SV<16> t[NQ];
+        load(Cu + (size_t)x * T + col0, t);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) sv_xor<16>(acc[q], t[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) lds_put<16>(smem, e * NQ + q, acc[q]);
+  }
+  __syncthreads();
+  if (chunk == 0) /* park the inactive columns in the slots the plan reserved for them (rows that are no pivots) */
+    for (uint32_t x = tid; x < u; x += 256u) {
+      SV<16> t[NQ];
+      load(Cu + (size_t)x * T + col0, t);
+      store(Y + (size_t)uslot[x] * T + col0, t);
+    }
+  const uint32_t k0 = (uint32_t)(((uint64_t)npiv * chunk) / nchunks), k1 = (uint32_t)(((uint64_t)npiv * (chunk + 1u)) / nchunks);
+  for (uint32_t k = k0 + tid; k < k1; k += 256u) {
+    const uint32_t slot = pivslot[k];
+    SV<16> acc[NQ];
+    NRQ_GAS uint8_t *row = Y + (size_t)slot * T + col0;
+    load(row, acc);
+    for (uint32_t w0 = 0; w0 < wpr; w0 += 4u) { /* four W words in flight */
+      uint32_t bits[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) bits[j] = w0 + j < wpr ? wt[(size_t)(w0 + j) * stride + k] : 0u;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        if (w0 + j >= wpr) break;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+          const uint32_t e = ((w0 + j) * 8u + q) * 16u + ((bits[j] >> (4u * q)) & 15u);
+#pragma unroll
+          for (int z = 0; z < NQ; z++) sv_xor<16>(acc[z], lds_get<16>(smem, e * NQ + z));
+        }
+      }
+    }
+    store(row, acc);
+  }
+}
+
+/* Results of the split solve, from the final slot image in the work buffer: workgroup (e, blk) writes one row --
+ * intermediate symbol e = row colslot[e] (if the job wants them), or generated symbol q = XOR of the rows its list
+ * names (plan slots of its LT neighbours), to the row of `out` the job assigns. */
+__global__ __launch_bounds__(256) void nrq_collect_kernel(const nrq_job *__restrict__ jobs, uint32_t T, const uint8_t *__restrict__ ybuf,
+                                                          size_t ybuf_stride) {
+  const uint32_t e = blockIdx.x, blk = blockIdx.y, tid = threadIdx.x;
+  const nrq_job *j = jobs + blk;
+  const uint8_t *plan = reinterpret_cast<const uint8_t *>(j->plan);
+  const nrq_plan_hdr *h = reinterpret_cast<const nrq_plan_hdr *>(plan);
+  if (h->status) return;
+  const uint32_t ni = j->inter ? h->L : 0u;
+  if (e >= ni + j->nout) return;
+  const NRQ_GAS uint8_t *F = gptr<uint8_t>((uint64_t)(uintptr_t)(ybuf + (size_t)blk * ybuf_stride));
+  __shared__ uint32_t rows[RQ_MAX_LT_COLS + 1];
+  __shared__ uint32_t nrows;
+  NRQ_GAS uint8_t *dst;
+  if (e < ni) {
+    if (tid == 0) { rows[0] = gptr<uint16_t>(plan + h->off_colslot)[e]; nrows = 1u; }
+    dst = gptr_w<uint8_t>(j->inter) + (size_t)e * T;
+  } else {
+    const uint32_t q = e - ni;
+    const NRQ_GAS uint32_t *cptr = gptr<uint32_t>(j->out_cptr);
+    const NRQ_GAS uint16_t *osl = gptr<uint16_t>(j->out_slots);
+    const uint32_t a = cptr[q], n = cptr[q + 1] - a;
+    if (tid < n && tid <= RQ_MAX_LT_COLS) rows[tid] = osl[a + tid];
+    if (tid == 0) nrows = n <= RQ_MAX_LT_COLS ? n : RQ_MAX_LT_COLS;
+    dst = gptr_w<uint8_t>(j->out) + (size_t)gptr<uint32_t>(j->out_row)[q] * T;
+  }
+  __syncthreads();
+  const uint32_t n = nrows;
+  const bool vec = (T & 15u) == 0 && ((reinterpret_cast<uintptr_t>(F) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
+  if (vec) {
+    for (uint32_t off = tid * 16u; off < T; off += 256u * 16u) {
+      SV<16> acc = sv_zero<16>();
+      for (uint32_t k = 0; k < n; k++) sv_xor<16>(acc, g_get_stream<16>(F + (size_t)rows[k] * T + off, 16u));
+      g_put<16>(dst + off, 16u, acc);
+    }
+  } else {
+    for (uint32_t off = tid; off < T; off += 256u) {
+      uint8_t acc = 0;
+      for (uint32_t k = 0; k < n; k++) acc ^= F[(size_t)rows[k] * T + off];
+      dst[off] = acc;
+    }
+  }
+}
+
 /* One workgroup per (symbol, block): out = XOR of the LT neighbours of `isi` among the L
  * intermediate symbols in HBM (coalesced 16-byte lanes along the symbol). */
 __global__ __launch_bounds__(NRQ_GEN_WG) void nrq_gen_kernel(rq_params p, uint32_t T, const uint8_t *__restrict__ inter,
@@ -450,6 +599,7 @@ struct Tuning {
   uint64_t solve_grid = 0;   /* NRQ_SOLVE_GRID: persistent workgroups of the solve launch (0 = fill the device) */
   uint32_t max_wb = 16;      /* NRQ_MAX_WB: widest strip considered */
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
+  bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
   bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
   int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
   bool no_plan_stream = false; /* NRQ_NO_PLAN_STREAM: planner kernel on the caller's stream (no overlap with the solve before it) */
@@ -460,7 +610,7 @@ struct Tuning {
     prof = flag("NRQ_PROF"); plan_lds_max = flag("NRQ_PLAN_LDS_MAX"); plan_big_wg = flag("NRQ_PLAN_BIG_WG");
     small_div = (uint32_t)num("NRQ_SMALL_DIV", 2); solve_grid = (uint64_t)num("NRQ_SOLVE_GRID", 0);
     max_wb = (uint32_t)num("NRQ_MAX_WB", 16); prof_base = (int)num("NRQ_PROF_BASE", 2);
-    no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
+    no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
   }
 };
 
@@ -491,6 +641,7 @@ struct nrq_ctx {
   int planner = 1; /* 1 = device planner for decode (default), 0 = host planner */
   DevBuf plan_work, plan_arena, plan_jobs;
   DevBuf stage; /* solve kernel: staging buffers of the persistent workgroups */
+  DevBuf ybuf;  /* split solve of narrow strips: per block, (M + u) full-width rows (slot image + inactive columns) */
   bool plan_attr = false;
   /* The planner kernel runs on a stream of its own: it depends on the reception pattern only, not on the symbols, so
    * it may run beside whatever the caller's stream is still doing (typically the encode solve launched just before).
@@ -642,7 +793,13 @@ void build_out_lists(const rq_params &p, const uint16_t *colslot, uint32_t n, co
 }
 
 template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, uint32_t nblk, uint32_t T,
-                                const uint8_t *d_kc, uint32_t lds_bytes, uint32_t max_slots, uint32_t max_out) {
+                                const uint8_t *d_kc, uint32_t lds_bytes, uint32_t max_slots, uint32_t max_out, uint32_t max_u,
+                                uint32_t max_wpr) {
+  /* narrow strips: the solve kernel stops after the dense stage, nrq_backsub_kernel / nrq_collect_kernel finish on
+   * full-width rows of a per-block work buffer (see there) */
+  const bool split = WB <= 4 && !ctx->tune.no_split;
+  const uint32_t res_elems = max_out; /* rows nrq_collect_kernel writes per block at most */
+  if (split) max_out = max_slots + max_u;
   const uint32_t nstrips = (T + WB - 1) / WB, spl = 128u / WB;
   const bool by_block = nrq_map_by_block(nblk) && !ctx->tune.map_spread;
   /* workgroup shape: the full-size workgroup when a strip image needs more than half of the CU's LDS, 256-thread ones
@@ -704,7 +861,19 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     int rc_ = ensure_dev(ctx, ctx->stage, (size_t)grid * 2u * spl * ((size_t)stage_stride + ostage_stride));
     if (rc_) return rc_;
   }
+  size_t ybuf_stride = 0;
+  uint8_t *ybuf = nullptr;
+  if (split) {
+    ybuf_stride = ((size_t)(max_slots + max_u) * T + 255u) & ~(size_t)255u;
+    int rc_ = ensure_dev(ctx, ctx->ybuf, (size_t)nblk * ybuf_stride);
+    if (rc_) return rc_;
+    ybuf = ctx->ybuf.p;
+  }
   if (!ctx->attr_set[slot]) {
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_backsub_kernel<32>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_backsub_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, NRQ_WG, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 256, 4>),
@@ -734,14 +903,32 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   }
   if (five)
     hipLaunchKernelGGL((nrq_solve_kernel<WB, 256, 5>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
-                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
+                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
   else if (small)
     hipLaunchKernelGGL((nrq_solve_kernel<WB, 256, 4>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
-                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
+                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
   else
     hipLaunchKernelGGL((nrq_solve_kernel<WB, NRQ_WG, 1>), dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
-                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof);
+                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
   HIPCHK(ctx, hipGetLastError());
+  if (split) {
+    /* 32-byte strips while the tables (4 KiB per W word) leave room for two workgroups per CU, 16-byte strips beyond */
+    const bool wide = max_wpr <= 20u;
+    const uint32_t sb = wide ? 32u : 16u, nsb = (T + sb - 1u) / sb, tbl = max_wpr * 8u * 16u * sb;
+    if (tbl > NRQ_LDS_MAX) return fail(ctx, -5, "back-substitution tables do not fit the LDS (wpr=%u)", max_wpr);
+    uint32_t nchunks = (2048u + nsb * nblk - 1u) / (nsb * nblk);
+    if (nchunks < 1u) nchunks = 1u;
+    if (nchunks > 16u) nchunks = 16u;
+    if (wide)
+      hipLaunchKernelGGL(nrq_backsub_kernel<32>, dim3(nsb, nchunks, nblk), dim3(256), tbl, ctx->stream, d_jobs, T, ybuf, ybuf_stride, nchunks);
+    else
+      hipLaunchKernelGGL(nrq_backsub_kernel<16>, dim3(nsb, nchunks, nblk), dim3(256), tbl, ctx->stream, d_jobs, T, ybuf, ybuf_stride, nchunks);
+    HIPCHK(ctx, hipGetLastError());
+    if (res_elems) {
+      hipLaunchKernelGGL(nrq_collect_kernel, dim3(res_elems, nblk), dim3(256), 0, ctx->stream, d_jobs, T, (const uint8_t *)ybuf, ybuf_stride);
+      HIPCHK(ctx, hipGetLastError());
+    }
+  }
   if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
   if (ctx->prof) {
     std::vector<unsigned long long> hp((size_t)nprof * 16);
@@ -787,9 +974,13 @@ int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs,
                     uint32_t T, const uint8_t *d_kc, uint32_t max_out) {
   static const uint32_t widths[4] = {16, 8, 4, 2};
 
-  uint32_t max_slots = 0;
-  for (const nrq_plan_hdr *h : hdrs)
-    if (!h->status && h->M > max_slots) max_slots = h->M;
+  uint32_t max_slots = 0, max_u = 0, max_wpr = 0;
+  for (const nrq_plan_hdr *h : hdrs) {
+    if (h->status) continue;
+    if (h->M > max_slots) max_slots = h->M;
+    if (h->u > max_u) max_u = h->u;
+    if (h->wpr > max_wpr) max_wpr = h->wpr;
+  }
   for (int s = 0; s < 4; s++) {
     if (widths[s] > ctx->tune.max_wb) continue;
     uint32_t need = 0;
@@ -801,10 +992,10 @@ int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs,
     if (need == 0) return 0; /* nothing solvable in this batch */
     if (need > NRQ_LDS_MAX) continue;
     switch (widths[s]) {
-      case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need, max_slots, max_out);
-      case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need, max_slots, max_out);
-      case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need, max_slots, max_out);
-      default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need, max_slots, max_out);
+      case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr);
+      case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr);
+      case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr);
+      default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr);
     }
   }
   return fail(ctx, -5, "block too large for the LDS-resident solver");
@@ -889,6 +1080,7 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
   if (ctx->plan_arena.p) (void)hipFree(ctx->plan_arena.p);
   if (ctx->plan_jobs.p) (void)hipFree(ctx->plan_jobs.p);
   if (ctx->stage.p) (void)hipFree(ctx->stage.p);
+  if (ctx->ybuf.p) (void)hipFree(ctx->ybuf.p);
   for (int i = 0; i < 2; i++) {
     if (ctx->pscratch[i].p) (void)hipFree(ctx->pscratch[i].p);
     if (ctx->pstaging[i].p) (void)hipHostFree(ctx->pstaging[i].p);
@@ -926,6 +1118,22 @@ void nrq_ctx_last_stats(nrq_ctx *ctx, nrq_call_stats *out) {
 int nrq_ctx_set_planner(nrq_ctx *ctx, int device_planner) {
   if (!ctx) return -1;
   ctx->planner = device_planner ? 1 : 0;
+  return 0;
+}
+
+int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
+  if (!ctx || !name) return -1;
+  Tuning &t = ctx->tune;
+  const std::string n(name);
+  if (n == "max_wb") t.max_wb = (uint32_t)value;
+  else if (n == "no_split") t.no_split = value != 0;
+  else if (n == "no_balance") t.no_balance = value != 0;
+  else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
+  else if (n == "reserve_cus") t.reserve_cus = (int)value;
+  else if (n == "solve_grid") t.solve_grid = (uint64_t)value;
+  else if (n == "big_wg") t.big_wg = value != 0;
+  else if (n == "map_spread") t.map_spread = value != 0;
+  else return fail(ctx, -1, "unknown option %s", name);
   return 0;
 }
 

@@ -877,6 +877,27 @@ template <int WB> SB_HD void ph_store(const StripCtx<WB> &c, NRQ_GAS uint8_t *os
     if (two) g_put_stream<WB>(ostage + (size_t)(ni + q1) * WB, WB, acc[1]);
   }
 }
+/* phase 6b for the SPLIT solve of narrow strips (big blocks, nrq_device.hip): instead of back-substitution and results,
+ * the strip's slot image after the dense stage (element i < M: slot i, i.e. Y of the pivot rows) and the values of the
+ * inactive columns (element M + x: C_u[x]) go to the output staging buffer; they reach full-width rows of a per-block
+ * work buffer through the same scatter, where nrq_backsub_kernel finishes the solve on 32-byte strips. */
+template <int WB> SB_HD void ph_store_raw(const StripCtx<WB> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
+  const uint32_t M = c.h->M, u = c.h->u;
+  constexpr int STB = 4;
+  for (uint32_t base = tid; base < M + u; base += STB * nt) {
+    SV<WB> v[STB];
+#pragma unroll
+    for (int q = 0; q < STB; q++) {
+      const uint32_t i = base + (uint32_t)q * nt;
+      v[q] = i < M ? lds_get<WB>(c.slots(), i) : i < M + u ? lds_get<WB>(c.cu(), i - M) : sv_zero<WB>();
+    }
+#pragma unroll
+    for (int q = 0; q < STB; q++) {
+      const uint32_t i = base + (uint32_t)q * nt;
+      if (i < M + u) g_put_stream<WB>(ostage + (size_t)i * WB, WB, v[q]);
+    }
+  }
+}
 /* where the results of one line group of one block go */
 template <int WB> struct GroupDst {
   NRQ_GAS uint8_t *inter, *out;

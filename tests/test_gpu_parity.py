@@ -323,3 +323,28 @@ def test_lazy_decode_takes_spare_symbols_only_when_needed(G, orc, planner):
             assert (used[b] > nlost[b]) == need_more[b], (b, used[b], nlost[b])
     finally:
         c.set_planner(True)
+
+
+@pytest.mark.parametrize("wb,split", [(4, True), (2, True), (2, False), (8, False)])
+def test_narrow_strip_paths_at_small_sizes(G, orc, wb, split):
+    """The kernels big blocks use -- 8/4/2-byte strips and, for 4 and 2, the split solve (nrq_backsub_kernel +
+    nrq_collect_kernel finishing on full-width rows) -- forced at sizes the oracle checks in no time: intermediate,
+    repair and recovered symbols byte for byte, ragged symbol sizes included (T = 1, 50, 1288)."""
+    c = G.ctx()
+    c.set_option("max_wb", wb)
+    c.set_option("no_split", 0 if split else 1)
+    try:
+        for K, T, nblk, p, oh in [(300, 1288, 3, 0.1, 0), (1024, 50, 9, 0.05, 2), (64, 1, 5, 0.2, 1), (2000, 96, 2, 0.1, 0)]:
+            src = np.stack([payload(K * T, seed=K + wb, block=b).reshape(K, T) for b in range(nblk)])
+            esis = np.array([K, K + 1, K + 9, K + 500], np.uint32)
+            rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+            for b in (0, nblk - 1):
+                r_rep, r_int, _ = orc.encode_block(src[b], K, T, esis, want_inter=True)
+                assert np.array_equal(inter[b], r_int) and np.array_equal(rep[b], r_rep), (K, T, b)
+            st, out, src2 = _roundtrip(G, K, T, nblk, p, oh, seed=K + 7)
+            for b in range(nblk):
+                assert not st[b] or np.array_equal(out[b], src2[b]), (K, T, b)
+            assert st.sum() >= nblk - 1
+    finally:
+        c.set_option("max_wb", 16)
+        c.set_option("no_split", 0)
