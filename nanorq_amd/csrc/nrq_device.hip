@@ -287,6 +287,8 @@ enum {
   pl_tag_pl_round_claim = 1,
   pl_tag_pl_round_drop = 3,
   pl_tag_pl_inact_find = 5,
+  pl_tag_pl_inact_find_b = 5,
+  pl_tag_pl_inact_find_c = 5,
   pl_tag_pl_inact_apply_a = 6,
   pl_tag_pl_inact_apply_b = 6,
   pl_tag_pl_inact_next = 6,
@@ -1434,7 +1436,10 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   const size_t off_hdrs = in_bytes;
   const size_t total = r16(off_hdrs + (size_t)nblk * sizeof(nrq_plan_hdr));
   /* everything up to the headers' way back runs on the planner stream (see nrq_ctx::plan_stream) */
-  hipStream_t ps = ctx->tune.no_plan_stream ? ctx->stream : ctx->plan_stream;
+  /* (only while the planner workgroups leave at least half of the CUs alone: with one per CU the two kernels just take
+   * turns, and planner workgroups that get in first delay the persistent workgroups of the solve -- measured at 256
+   * blocks of K=8192: encode solve 7.6 -> 10.4 ms, step +0.4 ms; at 64 blocks of K=20000 the overlap is worth 10 %) */
+  hipStream_t ps = (ctx->tune.no_plan_stream || nblk * 2u > (uint32_t)ctx->ncu) ? ctx->stream : ctx->plan_stream;
   const int f = ctx->pflip;
   ctx->pflip ^= 1;
   HIPCHK(ctx, hipEventSynchronize(ctx->pstaged[f]));

@@ -109,6 +109,7 @@ typedef struct pl_shared {
   uint32_t M, overhead, npatch, wpr, lpr, rowlen;
   uint32_t nV, npiv, ninact, nlev;
   uint32_t nq[2], nclaim[2]; /* frontier / claim counts, indexed by round parity */
+  uint32_t ncand[2]; /* stack of open rows with two V columns: [0] entries, [1] scratch of the search (new top) */
   uint32_t best;
   uint32_t nlow, r2, nfree, cand[3];
   uint32_t arena_top, nrows, nrec, opbase; /* nrec: op records written by pl_w_init */
@@ -132,7 +133,7 @@ typedef struct pl_shared {
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
   uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, ucol, wrows,
-      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, total;
+      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, total;
 } pl_work_layout;
 
 /* nnzcap: entries of the base structure plus the patch rows (bounds the number of row ops) */
@@ -163,6 +164,7 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.rec_word = o;   o = pl_r16(o + nnzcap * 4u);
   w.rec_idx = o;    o = pl_r16(o + nnzcap * 4u);
   w.rec_g = o;      o = pl_r16(o + nnzcap * 2u);
+  w.cand = o;       o = pl_r16(o + Mcap * 2u); /* stack of open rows with exactly two V columns (pl_inact_find) */
   w.total = o;
   return w;
 }
@@ -206,7 +208,7 @@ struct PlanCtx {
   uint8_t *patch_len;
   uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *lev_fin, *red_row,
       *red_x, *rec_word, *rec_idx;
-  uint16_t *rec_g;
+  uint16_t *rec_g, *cand;
   uint32_t reccap;
   /* arena views (fixed part laid out up front) */
   uint8_t *arena;
@@ -289,6 +291,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.rec_word = reinterpret_cast<uint32_t *>(w + c.wl.rec_word);
   c.rec_idx = reinterpret_cast<uint32_t *>(w + c.wl.rec_idx);
   c.rec_g = reinterpret_cast<uint16_t *>(w + c.wl.rec_g);
+  c.cand = reinterpret_cast<uint16_t *>(w + c.wl.cand);
   /* arena: header, then the arrays whose size is bounded by (L, ucap) */
   c.arena = PL_HBM(uint8_t, job.arena);
   c.hdr = reinterpret_cast<nrq_plan_hdr *>(c.arena);
@@ -355,6 +358,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->npatch = st ? 0 : nr;
     sh->nV = p.W; sh->npiv = 0; sh->ninact = 0; sh->nlev = 0;
     sh->nq[0] = sh->nq[1] = 0; sh->nclaim[0] = sh->nclaim[1] = 0; sh->best = PL_NONE;
+    sh->ncand[0] = sh->ncand[1] = 0;
     sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = sh->cand[2] = PL_NONE;
     sh->nrows = 0; sh->nrec = 0; sh->uslot_fill = 0;
     sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE;
@@ -436,6 +440,7 @@ template <int Z> SB_HD void pl_scan_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   uint32_t a = tid * per, b = a + per < L ? a + per : L, run = c.sh->partial[tid];
   for (uint32_t k = a; k < b; k++) { uint32_t v = c.pc_fill[k]; c.pc_ptr[k] = run; run += v; c.pc_fill[k] = 0; }
 }
+SB_HD bool pl_peel_in_lds(const PlanCtx &c);
 /* fill the patch CSC; seed the first frontier with the rows that already have one V column */
 template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
@@ -452,9 +457,12 @@ template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) 
     }
   }
   for (uint32_t r = tid; r < sh->M; r += nt) {
-    if ((c.rowstate[r] >> 24) == 1u) {
+    const uint32_t cnt = c.rowstate[r] >> 24;
+    if (cnt == 1u) {
       uint32_t j = PL_ATOM_ADD(&sh->nq[0], 1u);
       if (j < PL_QCAP) sh->queue[0][j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    } else if (cnt == 2u && !pl_peel_in_lds(c)) {
+      c.cand[PL_ATOM_ADD(&sh->ncand[0], 1u)] = (uint16_t)r; /* (a row enters the stack once: at most M entries) */
     }
   }
 }
@@ -475,12 +483,11 @@ template <bool LDS> SB_HD PlPeel pl_peel_state(const PlanCtx &c) {
   return s;
 }
 #define PL_PEEL_DISPATCH(fn, ...) do { if (pl_peel_in_lds(c)) fn<true>(__VA_ARGS__); else fn<false>(__VA_ARGS__); } while (0)
-SB_HD bool pl_peel_in_lds(const PlanCtx &c);
 
 /* column `col` leaves V: one atomic subtract per row that contains it; rows that drop to a single V
  * column join the next frontier (queue of parity `np`).  `lvl1` (pivot level + 1) is folded into the
  * rows' level-so-far; 0 for an inactivated column.  A group of `lanes` lanes strides over the row list. */
-SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lvl1, uint32_t np, uint32_t lane0, uint32_t lanes) {
+template <bool LDS> SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lvl1, uint32_t np, uint32_t lane0, uint32_t lanes) {
   pl_shared *sh = c.sh;
   const uint32_t dec = (1u << 24) | col;
   uint16_t *nextq = sh->queue[np];
@@ -496,6 +503,9 @@ SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lv
     if ((old >> 24) == 2u && (info & PL_UNASSIGNED)) {
       const uint32_t j = PL_ATOM_ADD(&sh->nq[np], 1u);
       if (j < PL_QCAP) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    } else if (!LDS && (old >> 24) == 3u && (info & PL_UNASSIGNED)) { /* two V columns left: a candidate of the next inactivation */
+      const uint32_t j = PL_ATOM_ADD(&sh->ncand[0], 1u);
+      if (j < c.Mcap) c.cand[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     }
   }
 }
@@ -542,18 +552,51 @@ template <bool LDS> SB_HD void pl_round_drop_t(PlanCtx &c, uint32_t rd, uint32_t
   while (lg < 6u && (nc << (lg + 1u)) <= nt) lg++;
   const uint32_t grp = tid >> lg, lane = tid & ((1u << lg) - 1u), ngrp = nt >> lg;
   for (uint32_t i = grp; i < nc; i += ngrp) {
-    pl_drop_column(c, s, sh->claim_c[i], sh->claim_l[i], pq ^ 1u, lane, 1u << lg);
+    pl_drop_column<LDS>(c, s, sh->claim_c[i], sh->claim_l[i], pq ^ 1u, lane, 1u << lg);
   }
   if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
 }
 template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   PL_PEEL_DISPATCH(pl_round_drop_t, c, rd, tid, nt);
 }
-/* No claimant in the frontier: find the open row with the fewest V columns (workgroup-wide atomic min) */
+/* No claimant in the frontier: find an open row with the fewest V columns.  Almost always that is a row with two; those
+ * are kept on a stack as they come up (pl_drop_column pushes a row when its count drops to two; rows that start with
+ * two are pushed by pl_pcsc_fill), and the search looks at the top nt entries only -- the rows that reached two most
+ * recently, i.e. the ones most likely still open -- instead of all M rows (K'=56403: 41 k clocks per search, 264
+ * searches; half of all rows start with two V columns, so a list that is scanned whole is no better).  Entries above
+ * the highest valid one are popped; a chunk without a valid entry is popped whole and the search repeats
+ * (planner_seq.h).  Only when the stack runs empty are all rows scanned (pl_inact_find_b). */
 template <bool LDS> SB_HD void pl_inact_find_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh;
   const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24; /* rep-th row of this inactivation event */
+  const uint32_t n = sh->ncand[0], lo = n > nt ? n - nt : 0u, i = lo + tid;
+  uint32_t best = PL_NONE, hi = 0;
+  if (i < n) {
+    const uint32_t r = c.cand[i];
+    if ((s.rowinfo[r] & PL_UNASSIGNED) && (s.rowstate[r] >> 24) == 2u) { best = (2u << 16) | r; hi = i + 1u; }
+  }
+  best = PL_WAVE_MIN(best);
+  hi = PL_WAVE_MAX(hi);
+  if (best != PL_NONE && PL_WAVE_LEADER(tid)) { PL_ATOM_MIN(&sh->best, best); PL_ATOM_MAX(&sh->ncand[1], hi); }
+  if (tid == 0 && rep == 0) { sh->nq[(rd & 1u) ^ 1u] = 0; sh->nclaim[rd & 1u] = 0; }
+}
+template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  PL_PEEL_DISPATCH(pl_inact_find_t, c, rdrep, tid, nt);
+}
+/* pop what the search found invalid: everything above the highest valid entry, or the whole chunk */
+template <int Z> SB_HD void pl_inact_find_c(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  if (tid != 0) return;
+  const uint32_t n = sh->ncand[0];
+  sh->ncand[0] = sh->best != PL_NONE ? sh->ncand[1] : (n > nt ? n - nt : 0u);
+  sh->ncand[1] = 0;
+  (void)rdrep;
+}
+/* the stack is empty and nothing was found: the sparsest of all open rows (workgroup-wide atomic min) */
+template <bool LDS> SB_HD void pl_inact_find_b_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh;
+  const PlPeel s = pl_peel_state<LDS>(c);
   uint32_t best = PL_NONE;
   for (uint32_t r = tid; r < sh->M; r += nt) {
     if (!(s.rowinfo[r] & PL_UNASSIGNED)) continue;
@@ -566,10 +609,10 @@ template <bool LDS> SB_HD void pl_inact_find_t(PlanCtx &c, uint32_t rdrep, uint3
   }
   best = PL_WAVE_MIN(best);
   if (best != PL_NONE && PL_WAVE_LEADER(tid)) PL_ATOM_MIN(&sh->best, best);
-  if (tid == 0 && rep == 0) { sh->nq[(rd & 1u) ^ 1u] = 0; sh->nclaim[rd & 1u] = 0; }
+  (void)rdrep;
 }
-template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  PL_PEEL_DISPATCH(pl_inact_find_t, c, rdrep, tid, nt);
+template <int Z> SB_HD void pl_inact_find_b(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  PL_PEEL_DISPATCH(pl_inact_find_b_t, c, rdrep, tid, nt);
 }
 /* inactivate all but one V column of that row (or every remaining V column if no row is left) */
 template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
@@ -645,7 +688,7 @@ template <bool LDS> SB_HD void pl_inact_apply_b_t(PlanCtx &c, uint32_t rdrep, ui
     return;
   }
   const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
-  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column(c, s, sh->claim_c[i], 0u, pq ^ 1u, lane, 32u);
+  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column<LDS>(c, s, sh->claim_c[i], 0u, pq ^ 1u, lane, 32u);
   if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; }
 }
 template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
@@ -968,14 +1011,29 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
         if (!NRQ_OP_IS_NOP(op[q]) && w8 < wpr && v[q]) PL_ATOM_XOR(&c.wrows[(size_t)NRQ_OP_DST(op[q]) * wpr + w8], v[q]);
     }
   } else {
-    for (uint32_t e = grp; e < nops; e += ngrp) {
-      const uint32_t op = ops[e];
-      if (NRQ_OP_IS_NOP(op)) continue;
-      const uint32_t *src = c.wrows + (size_t)NRQ_OP_SRC(op) * wpr;
-      uint32_t *dst = c.wrows + (size_t)NRQ_OP_DST(op) * wpr;
-      for (uint32_t wd = w8; wd < wpr; wd += 8u) {
-        const uint32_t v = src[wd];
-        if (v) PL_ATOM_XOR(&dst[wd], v);
+    /* up to 5 words per lane (wpr <= 40); 4 ops per lane group in flight: all op words, then all source words, then
+     * the XORs -- one op at a time this is a chain of two dependent trips to L2 per op (K'=56403: 22 k clocks per level) */
+    constexpr uint32_t OB = 4, WL = 5;
+    for (uint32_t e0 = grp; e0 < nops; e0 += OB * ngrp) {
+      uint32_t op[OB], v[OB][WL];
+#pragma unroll
+      for (uint32_t q = 0; q < OB; q++) {
+        const uint32_t e = e0 + q * ngrp;
+        op[q] = e < nops ? ops[e] : 0u;
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < OB; q++) {
+        const uint32_t *src = c.wrows + (size_t)(NRQ_OP_IS_NOP(op[q]) ? 0u : NRQ_OP_SRC(op[q])) * wpr;
+#pragma unroll
+        for (uint32_t j = 0; j < WL; j++) v[q][j] = w8 + 8u * j < wpr ? src[w8 + 8u * j] : 0u;
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < OB; q++) {
+        if (NRQ_OP_IS_NOP(op[q])) continue;
+        uint32_t *dst = c.wrows + (size_t)NRQ_OP_DST(op[q]) * wpr;
+#pragma unroll
+        for (uint32_t j = 0; j < WL; j++)
+          if (v[q][j]) PL_ATOM_XOR(&dst[w8 + 8u * j], v[q][j]);
       }
     }
   }

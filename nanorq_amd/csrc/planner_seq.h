@@ -32,7 +32,14 @@
         for (uint32_t rep_ = 0; rep_ < NRQ_MULTI_INACT; rep_++) {
           const uint32_t a_ = rd_ | (rep_ << 24);
           if (rep_) PL_PHASE1(pl_inact_next, a_);
-          PL_PHASE1(pl_inact_find, a_);
+          /* peeling state in LDS: all open rows are scanned (cheap there, and ties go to the lowest row); in HBM: the
+           * top of the stack of two-column rows, a chunk at a time, all rows only if it runs empty */
+          while (!pl_peel_in_lds(c)) {
+            PL_PHASE1(pl_inact_find, a_);
+            PL_PHASE1(pl_inact_find_c, a_);
+            if (sh_->best != PL_NONE || sh_->ncand[0] == 0u) break;
+          }
+          if (sh_->best == PL_NONE) PL_PHASE1(pl_inact_find_b, a_);
           PL_PHASE1(pl_inact_apply_a, a_);
           PL_PHASE1(pl_inact_apply_b, a_);
           if (sh_->tmp1 || sh_->status != 0 || sh_->nV == 0) break;
