@@ -210,6 +210,8 @@ def main():
     bounds = [(NB * g_) // nstreams for g_ in range(nstreams + 1)]
     groups = [(bounds[g_], bounds[g_ + 1]) for g_ in range(nstreams)]
 
+    replan_early = L >= 12000   # (the library's threshold for device-built encode plans, NRQ_ENCPLAN_DEV_MIN_L)
+
     def step():
         nonlocal retries
         enc_stats = dec_stats = None
@@ -218,6 +220,12 @@ def main():
             c_.encode_blocks(K, T, n_, src[lo].data_ptr(), K * T, rep[lo].data_ptr(), nrep * T, esis, inter[lo].data_ptr(),
                              L * T)
             enc_stats = enc_stats or c_.stats()
+        if not args.no_replan and replan_early:
+            # big K': the NEXT step's encode plan is built by the device planner, asynchronously on a stream of its own
+            # (nrq_precalculate only enqueues it) -- issued before the decode so that it runs beside this step's work
+            for c_ in ctxs:
+                c_.clear_plan_cache()
+                c_.precalculate(K)
         for (lo, hi), c_ in zip(groups, ctxs):
             n_ = hi - lo
             # decode from exactly (lost + overhead) repair symbols per block; a block whose system turns out rank
@@ -229,7 +237,7 @@ def main():
             if not st.all():
                 raise RuntimeError("decode failed for %d blocks" % int((st == 0).sum()))
             retries += int((used - nr_first[lo:hi]).sum())
-        if not args.no_replan:
+        if not args.no_replan and not replan_early:
             # one encode plan per step (= per 256-block object, like nanorq_precalculate): the plan for the NEXT step's
             # encode is rebuilt on the host here (once per context), while the GPU runs this step's solve
             for c_ in ctxs:

@@ -574,14 +574,27 @@ struct KConst {
 struct EncPlan {
   bool valid = false;     /* false after nrq_plan_cache_clear: rebuilt on next use, buffers are kept */
   size_t dev_cap = 0;
-  uint8_t *pin = nullptr; /* pinned image for the asynchronous upload */
+  uint8_t *pin = nullptr; /* host planner: pinned image for the asynchronous upload; device planner: what comes back */
   size_t pin_cap = 0;
-  uint8_t *dev = nullptr; /* plan arena followed by rowsrc */
+  uint8_t *dev = nullptr; /* the plan in use: plan arena and rowsrc (one of devbuf[]) */
   uint32_t plan_bytes = 0;
   uint32_t rowsrc_off = 0;
   nrq_plan_hdr hdr;
   std::vector<uint16_t> colslot; /* host copy, to translate LT neighbour lists into slots */
   double build_ms = 0;
+  /* Two device buffers: a plan that is rebuilt ON THE DEVICE (big K', encplan_device_launch) goes to the buffer that is
+   * not in use, on a stream of its own, while solves may still read the other one.  The host planner keeps to buffer 0
+   * (its upload is ordered on the caller's stream). */
+  uint8_t *devbuf[2] = {nullptr, nullptr};
+  size_t devcap[2] = {0, 0};
+  hipEvent_t used[2] = {nullptr, nullptr}; /* last solve launch that reads devbuf[i] */
+  bool used_set[2] = {false, false};
+  int cur = 0;
+  bool pending = false;   /* a device build is in flight into devbuf[pend]; encplan_finish() completes it */
+  int pend = 0;
+  hipEvent_t ready = nullptr;
+  uint32_t rb_bytes = 0;  /* device build: bytes of the arena's front (header .. colslot) read back */
+  double t_launch = 0;
 };
 
 inline size_t r16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -601,6 +614,8 @@ struct Tuning {
   uint64_t solve_grid = 0;   /* NRQ_SOLVE_GRID: persistent workgroups of the solve launch (0 = fill the device) */
   uint32_t max_wb = 16;      /* NRQ_MAX_WB: widest strip considered */
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
+  uint32_t encplan_dev_min_l = 12000; /* NRQ_ENCPLAN_DEV_MIN_L: from this many intermediate symbols on, encode plans are built by
+                              * the device planner, asynchronously (the host planner takes 25 ms at K=27000, 95 ms at K'=56403) */
   bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
   bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
   int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
@@ -612,6 +627,7 @@ struct Tuning {
     prof = flag("NRQ_PROF"); plan_lds_max = flag("NRQ_PLAN_LDS_MAX"); plan_big_wg = flag("NRQ_PLAN_BIG_WG");
     small_div = (uint32_t)num("NRQ_SMALL_DIV", 2); solve_grid = (uint64_t)num("NRQ_SOLVE_GRID", 0);
     max_wb = (uint32_t)num("NRQ_MAX_WB", 16); prof_base = (int)num("NRQ_PROF_BASE", 2);
+    encplan_dev_min_l = (uint32_t)num("NRQ_ENCPLAN_DEV_MIN_L", 12000);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
   }
 };
@@ -653,6 +669,8 @@ struct nrq_ctx {
   hipStream_t plan_stream = nullptr;
   hipEvent_t planned = nullptr, arena_free = nullptr;
   bool arena_busy = false;
+  hipStream_t plan_stream2 = nullptr; /* encode plans built on the device (encplan_device_launch): beside both of the above */
+  DevBuf encplan_work;                /* planner workspace of that build */
   DevBuf pscratch[2]; /* planner inputs: buffers of their own (the per-call arrays above belong to the caller's stream) */
   PinBuf pstaging[2];
   hipEvent_t pstaged[2] = {nullptr, nullptr};
@@ -722,16 +740,49 @@ int get_kconst(nrq_ctx *ctx, uint32_t K, KConst **out) {
   return 0;
 }
 
-int get_encplan(nrq_ctx *ctx, uint32_t K, uint32_t Kp, EncPlan **out) {
-  rq_params p;
-  int rc = block_params(ctx, K, Kp, &p);
-  if (rc) return rc;
-  const uint64_t key = ((uint64_t)p.Kp << 32) | K;
-  auto it = ctx->encplans.find(key);
-  if (it != ctx->encplans.end() && it->second.valid) { *out = &it->second; return 0; }
-  KConst *kc;
-  rc = get_kconst(ctx, p.Kp, &kc);
-  if (rc) return rc;
+/* launch geometry of the planner kernel: LDS sizing, workgroup shape (shared by the decode planner and the device
+ * build of encode plans) */
+int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const uint8_t *d_kc, const nrq_planjob *d_pj,
+                       nrq_job *d_jobs, uint32_t nblk, uint32_t Mcap, uint32_t npcap, uint32_t ucap, unsigned long long *pprof) {
+  const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared));
+  /* dynamic LDS: everything a CU has for a big block; for small blocks what the planner can use (peeling state plus the
+   * dense-stage reserve, or a 16-byte strip image of the W rows), so that two workgroups share a CU */
+  uint32_t dyn_bytes = NRQ_LDS_MAX - sh_bytes;
+  bool small_wg = false; /* 256-thread workgroups: a small block has no use for 1024 threads, a CU has for 4 blocks */
+  {
+    const uint32_t peel = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L);
+    const uint32_t wimg = (Mcap + 320u + NRQ_SCRATCH) * 16u;
+    const uint32_t fit = pl_r16((peel > wimg ? peel : wimg) + 2048u);
+    if (fit + sh_bytes <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) { dyn_bytes = fit; small_wg = !ctx->tune.plan_big_wg; }
+  }
+  if (!ctx->plan_attr) {
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT_MIN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    ctx->plan_attr = true;
+  }
+  if (small_wg)
+    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
+                       nblk, Mcap, npcap, ucap, dyn_bytes, pprof);
+  else
+    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
+                       Mcap, npcap, ucap, dyn_bytes, pprof);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+int ensure_encbuf(nrq_ctx *ctx, EncPlan &ep, int i, size_t total) {
+  if (ep.devcap[i] >= total) return 0;
+  if (ep.devbuf[i]) HIPCHK(ctx, hipFree(ep.devbuf[i]));
+  ep.devbuf[i] = nullptr; ep.devcap[i] = 0;
+  HIPCHK(ctx, hipMalloc((void **)&ep.devbuf[i], total + total / 8));
+  ep.devcap[i] = total + total / 8;
+  return 0;
+}
+
+/* host planner: build, stage in pinned memory, upload on the caller's stream (buffer 0) */
+int encplan_host_build(nrq_ctx *ctx, const rq_params &p, uint32_t K, KConst *kc, EncPlan &ep) {
   double t0 = now_ms();
   std::vector<uint32_t> isis(p.Kp);
   for (uint32_t j = 0; j < p.Kp; j++) isis[j] = j;
@@ -739,8 +790,6 @@ int get_encplan(nrq_ctx *ctx, uint32_t K, uint32_t Kp, EncPlan **out) {
   uint32_t bytes = 0;
   if (nrq_host_plan_build(p.Kp, p.Kp, isis.data(), kc->host, &arena, &bytes) != 0)
     return fail(ctx, -2, "encode plan build failed for K=%u", K);
-  if (it == ctx->encplans.end()) it = ctx->encplans.emplace(key, EncPlan()).first;
-  EncPlan &ep = it->second;
   memcpy(&ep.hdr, arena, sizeof(ep.hdr));
   if (ep.hdr.status) { nrq_host_free(arena); return fail(ctx, -3, "encode matrix singular for K=%u (cannot happen)", K); }
   ep.plan_bytes = bytes;
@@ -750,12 +799,8 @@ int get_encplan(nrq_ctx *ctx, uint32_t K, uint32_t Kp, EncPlan **out) {
   const size_t total = ep.rowsrc_off + (size_t)p.L * 4;
   /* device and pinned buffers survive a cache clear (same K => same size class); the upload is
    * asynchronous on the context's stream, so rebuilding a plan never waits for the GPU */
-  if (ep.dev_cap < total) {
-    if (ep.dev) HIPCHK(ctx, hipFree(ep.dev));
-    ep.dev = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&ep.dev, total + total / 8));
-    ep.dev_cap = total + total / 8;
-  }
+  int rc = ensure_encbuf(ctx, ep, 0, total);
+  if (rc) { nrq_host_free(arena); return rc; }
   if (ep.pin_cap < total) {
     if (ep.pin) HIPCHK(ctx, hipHostFree(ep.pin));
     ep.pin = nullptr;
@@ -770,12 +815,118 @@ int get_encplan(nrq_ctx *ctx, uint32_t K, uint32_t Kp, EncPlan **out) {
   for (uint32_t r = 0; r < p.L; r++) rowsrc[r] = NRQ_ROW_ZERO;
   for (uint32_t j = 0; j < K; j++) rowsrc[p.S + p.H + j] = j;
   nrq_host_free(arena);
-  HIPCHK(ctx, hipMemcpyAsync(ep.dev, ep.pin, total, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ep.devbuf[0], ep.pin, total, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->encplan_uploaded, ctx->stream));
+  ep.cur = 0;
+  ep.dev = ep.devbuf[0];
   ep.valid = true;
+  ep.pending = false;
   ep.build_ms = now_ms() - t0;
-  *out = &ep;
   return 0;
+}
+
+/* Device planner for an encode plan: the constraint matrix of an encode is that of a decode in which nothing was
+ * replaced -- the planner kernel runs it as a job without missing symbols (nrq_planjob::mode).  Asynchronous, on
+ * plan_stream2, into the buffer that is not in use; encplan_finish() waits for it and reads the header, the job
+ * record and colslot[] back.  (reference: nanorq_precalculate, lib/nanorq.c:393-401) */
+int encplan_device_launch(nrq_ctx *ctx, const rq_params &p, uint32_t K, KConst *kc, EncPlan &ep) {
+  const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(kc->host);
+  uint32_t ucap = p.P + 768u;
+  if (ucap > 1280u) ucap = 1280u;
+  if (ucap < p.P + 32u) return 1; /* not for the device planner */
+  const uint32_t Mcap = p.L + PL_EXTRA_ROWS + 8u, npcap = PL_EXTRA_ROWS + 8u;
+  const pl_work_layout wl = pl_work_plan(p.L, Mcap, npcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE);
+  const uint32_t arena_cap = pl_arena_bound(p.L, Mcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE, 8u);
+  /* front of the arena that comes back: header, pivslot, pivcol, colslot (pl_ctx_setup's layout) */
+  const uint32_t rb = (uint32_t)(r16(r16(r16(r16(sizeof(nrq_plan_hdr)) + p.L * 2u) + p.L * 2u) + p.L * 2u));
+  const size_t off_pj = arena_cap, off_job = off_pj + r16(sizeof(nrq_planjob)), dev_total = off_job + r16(sizeof(nrq_job));
+  const size_t pin_pj = 0, pin_rb = r16(sizeof(nrq_planjob)), pin_job = pin_rb + rb, pin_total = pin_job + r16(sizeof(nrq_job));
+  const int buf = (ep.devbuf[ep.cur] && (ep.valid || ep.used_set[ep.cur])) ? ep.cur ^ 1 : ep.cur;
+  int rc;
+  if ((rc = ensure_encbuf(ctx, ep, buf, dev_total))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->encplan_work, wl.total))) return rc;
+  if (ep.pin_cap < pin_total) {
+    if (ep.pin) HIPCHK(ctx, hipHostFree(ep.pin));
+    ep.pin = nullptr;
+    HIPCHK(ctx, hipHostMalloc((void **)&ep.pin, pin_total + pin_total / 8, hipHostMallocDefault));
+    ep.pin_cap = pin_total + pin_total / 8;
+  }
+  if (!ep.ready) HIPCHK(ctx, hipEventCreateWithFlags(&ep.ready, hipEventDisableTiming));
+  for (int i = 0; i < 2; i++)
+    if (!ep.used[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ep.used[i], hipEventDisableTiming));
+  hipStream_t ps = ctx->plan_stream2;
+  if (ep.used_set[buf]) HIPCHK(ctx, hipStreamWaitEvent(ps, ep.used[buf], 0));
+  nrq_planjob *pj = reinterpret_cast<nrq_planjob *>(ep.pin + pin_pj);
+  memset(pj, 0, sizeof(*pj));
+  pj->work = (uint64_t)(uintptr_t)ctx->encplan_work.p;
+  pj->arena = (uint64_t)(uintptr_t)ep.devbuf[buf];
+  pj->arena_cap = arena_cap;
+  pj->mode = 1u;
+  HIPCHK(ctx, hipMemcpyAsync(ep.devbuf[buf] + off_pj, pj, sizeof(*pj), hipMemcpyHostToDevice, ps));
+  rq_params pk = p;
+  pk.K = K;
+  if ((rc = launch_plan_kernel(ctx, ps, pk, kc->dev, reinterpret_cast<const nrq_planjob *>(ep.devbuf[buf] + off_pj),
+                               reinterpret_cast<nrq_job *>(ep.devbuf[buf] + off_job), 1u, Mcap, npcap, ucap, nullptr)))
+    return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ep.pin + pin_rb, ep.devbuf[buf], rb, hipMemcpyDeviceToHost, ps));
+  HIPCHK(ctx, hipMemcpyAsync(ep.pin + pin_job, ep.devbuf[buf] + off_job, sizeof(nrq_job), hipMemcpyDeviceToHost, ps));
+  HIPCHK(ctx, hipEventRecord(ep.ready, ps));
+  ep.pending = true;
+  ep.pend = buf;
+  ep.rb_bytes = rb;
+  ep.t_launch = now_ms();
+  return 0;
+}
+
+int encplan_finish(nrq_ctx *ctx, const rq_params &p, uint32_t K, KConst *kc, EncPlan &ep) {
+  if (!ep.pending) return 0;
+  HIPCHK(ctx, hipEventSynchronize(ep.ready));
+  ep.pending = false;
+  const uint8_t *rbp = ep.pin + r16(sizeof(nrq_planjob));
+  nrq_plan_hdr hd;
+  memcpy(&hd, rbp, sizeof(hd));
+  nrq_job jb;
+  memcpy(&jb, rbp + ep.rb_bytes, sizeof(jb));
+  if (hd.magic != NRQ_PLAN_MAGIC || hd.status != 0 || hd.off_colslot + p.L * 2u > ep.rb_bytes || jb.plan != (uint64_t)(uintptr_t)ep.devbuf[ep.pend]) {
+    /* a planner capacity was exceeded (or worse): the host planner takes over */
+    if (ctx->tune.prof) fprintf(stderr, "[NRQ_PROF] encode plan K'=%u: device build failed (status %u, planner_body.h:%u), host planner\n",
+                                p.Kp, hd.reserved[0], hd.fail_site);
+    return encplan_host_build(ctx, p, K, kc, ep);
+  }
+  ep.hdr = hd;
+  ep.colslot.assign(reinterpret_cast<const uint16_t *>(rbp + hd.off_colslot), reinterpret_cast<const uint16_t *>(rbp + hd.off_colslot) + p.L);
+  ep.plan_bytes = hd.total_bytes;
+  ep.rowsrc_off = (uint32_t)(jb.rowsrc - jb.plan);
+  ep.cur = ep.pend;
+  ep.dev = ep.devbuf[ep.cur];
+  ep.valid = true;
+  ep.build_ms = now_ms() - ep.t_launch;
+  return 0;
+}
+
+/* The encode plan of (K', K): cached; built by the host planner (synchronously, uploaded on the caller's stream) or,
+ * for big K', by the device planner -- asynchronously: with finish == false (nrq_precalculate) the call returns once
+ * the build is enqueued, and the encode that needs the plan completes it. */
+int get_encplan(nrq_ctx *ctx, uint32_t K, uint32_t Kp, EncPlan **out, bool finish = true) {
+  rq_params p;
+  int rc = block_params(ctx, K, Kp, &p);
+  if (rc) return rc;
+  const uint64_t key = ((uint64_t)p.Kp << 32) | K;
+  auto it = ctx->encplans.find(key);
+  if (it != ctx->encplans.end() && it->second.valid) { *out = &it->second; return 0; }
+  KConst *kc;
+  rc = get_kconst(ctx, p.Kp, &kc);
+  if (rc) return rc;
+  if (it == ctx->encplans.end()) it = ctx->encplans.emplace(key, EncPlan()).first;
+  EncPlan &ep = it->second;
+  *out = &ep;
+  if (!ep.pending) {
+    rc = 1;
+    if (ctx->planner && p.L >= ctx->tune.encplan_dev_min_l) rc = encplan_device_launch(ctx, p, K, kc, ep);
+    if (rc < 0) return rc;
+    if (rc > 0) return encplan_host_build(ctx, p, K, kc, ep);
+  }
+  return finish ? encplan_finish(ctx, p, K, kc, ep) : 0;
 }
 
 /* LT neighbour lists of the symbols to generate, already translated to LDS slots through the plan's
@@ -1036,6 +1187,7 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
   if (getenv("NRQ_HOST_PLANNER")) ctx->planner = 0;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->plan_stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->planned, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->arena_free, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->pstaged[0], hipEventDisableTiming) != hipSuccess ||
@@ -1058,8 +1210,13 @@ void nrq_plan_cache_clear(nrq_ctx *ctx) {
 
 static void encplans_release(nrq_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->plan_stream2) (void)hipStreamSynchronize(ctx->plan_stream2);
   for (auto &kv : ctx->encplans) {
-    if (kv.second.dev) (void)hipFree(kv.second.dev);
+    for (int i = 0; i < 2; i++) {
+      if (kv.second.devbuf[i]) (void)hipFree(kv.second.devbuf[i]);
+      if (kv.second.used[i]) (void)hipEventDestroy(kv.second.used[i]);
+    }
+    if (kv.second.ready) (void)hipEventDestroy(kv.second.ready);
     if (kv.second.pin) (void)hipHostFree(kv.second.pin);
   }
   ctx->encplans.clear();
@@ -1076,6 +1233,8 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
     nrq_host_free(kv.second.host);
   }
   if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
+  if (ctx->plan_stream2) { (void)hipStreamSynchronize(ctx->plan_stream2); (void)hipStreamDestroy(ctx->plan_stream2); }
+  if (ctx->encplan_work.p) (void)hipFree(ctx->encplan_work.p);
   if (ctx->planned) (void)hipEventDestroy(ctx->planned);
   if (ctx->arena_free) (void)hipEventDestroy(ctx->arena_free);
   if (ctx->plan_work.p) (void)hipFree(ctx->plan_work.p);
@@ -1135,6 +1294,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "solve_grid") t.solve_grid = (uint64_t)value;
   else if (n == "big_wg") t.big_wg = value != 0;
   else if (n == "map_spread") t.map_spread = value != 0;
+  else if (n == "encplan_dev_min_l") t.encplan_dev_min_l = (uint32_t)value;
   else return fail(ctx, -1, "unknown option %s", name);
   return 0;
 }
@@ -1149,7 +1309,7 @@ int nrq_precalculate(nrq_ctx *ctx, uint32_t K, uint32_t Kp) {
   if (!ctx) return -1;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   EncPlan *ep;
-  return get_encplan(ctx, K, Kp, &ep);
+  return get_encplan(ctx, K, Kp, &ep, /*finish=*/false); /* a device build is only enqueued; the encode that needs it waits */
 }
 
 int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,
@@ -1217,6 +1377,10 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   HIPCHK(ctx, hipEventRecord(ctx->staged[f], ctx->stream));
   std::vector<const nrq_plan_hdr *> hdrs(1, &ep->hdr);
   rc = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds + off_jobs), nblk, T, kc->dev, (d_inter ? p.L : 0u) + nrep);
+  if (ep->used[ep->cur]) { /* (device-built plans: the next build may not overwrite this buffer before the launch is done) */
+    HIPCHK(ctx, hipEventRecord(ep->used[ep->cur], ctx->stream));
+    ep->used_set[ep->cur] = true;
+  }
   ctx->stats.host_ms = now_ms() - t_begin;
   return rc;
 }
@@ -1468,38 +1632,14 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     j.arena_cap = arena_cap;
   }
   HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ps));
-  const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared));
-  /* dynamic LDS: everything a CU has for a big block; for small blocks what the planner can use (peeling state plus the
-   * dense-stage reserve, or a 16-byte strip image of the W rows), so that two workgroups share a CU */
-  uint32_t dyn_bytes = NRQ_LDS_MAX - sh_bytes;
-  bool small_wg = false; /* 256-thread workgroups: a small block has no use for 1024 threads, a CU has for 4 blocks */
-  {
-    const uint32_t peel = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L);
-    const uint32_t wimg = (Mcap + 320u + NRQ_SCRATCH) * 16u;
-    const uint32_t fit = pl_r16((peel > wimg ? peel : wimg) + 2048u);
-    if (fit + sh_bytes <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) { dyn_bytes = fit; small_wg = !ctx->tune.plan_big_wg; }
-  }
-  if (!ctx->plan_attr) {
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT_MIN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
-    ctx->plan_attr = true;
-  }
   unsigned long long *pprof = nullptr;
   if (ctx->tune.prof) {
     HIPCHK(ctx, hipMalloc((void **)&pprof, 32 * 8));
     HIPCHK(ctx, hipMemsetAsync(pprof, 0, 32 * 8, ps));
   }
-  if (small_wg)
-    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p,
-                       (const uint8_t *)kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
-                       reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, dyn_bytes, pprof);
-  else
-    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p,
-                       (const uint8_t *)kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
-                       reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, dyn_bytes, pprof);
-  HIPCHK(ctx, hipGetLastError());
+  if ((rc = launch_plan_kernel(ctx, ps, p, kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
+                               reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, pprof)))
+    return rc;
   if (pprof) {
     unsigned long long hp[32];
     HIPCHK(ctx, hipMemcpyAsync(hp, pprof, sizeof(hp), hipMemcpyDeviceToHost, ps));

@@ -61,6 +61,8 @@ typedef struct nrq_planjob {
   uint32_t nlost, nrep; /* nrep: repair symbols to use up front (>= nlost) */
   uint32_t arena_cap;
   uint32_t nrep_avail;  /* >= nrep: further symbols the planner may take, one at a time, if the system is rank deficient */
+  uint32_t mode;        /* 0 = decode; 1 = encode plan: no symbol is missing, the system is the encoder's (nlost = nrep = 0) */
+  uint32_t pad_;
 } nrq_planjob;
 
 /* ---- atomics: device intrinsics / plain memory in the emulator ---- */
@@ -347,7 +349,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (tid == 0) {
     uint32_t st = 0;
     const uint32_t nl = c.job.nlost, nr = c.job.nrep;
-    if (nl == 0 || nr < nl) st = PL_FAIL_SINGULAR;
+    if ((nl == 0 && c.job.mode != 1u) || nr < nl) st = PL_FAIL_SINGULAR;
     uint32_t oh = st ? 0 : nr - nl;
     if (!st && (p.L + oh + PL_EXTRA_ROWS > c.Mcap || nr + PL_EXTRA_ROWS > c.npcap || p.L + oh + PL_EXTRA_ROWS > 65534u))
       st = PL_FAIL_CAPACITY;

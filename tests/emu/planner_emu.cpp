@@ -41,6 +41,8 @@ static void emu_wfast_run(PlanCtx &c, uint32_t wb) {
 }
 
 /* returns 0 and fills arena (status in its header); job_out receives the solve job (host pointers) */
+static uint32_t g_mode = 0; /* nrq_planjob::mode of the next emu_plan call (1 = encode plan) */
+extern "C" void emu_plan_set_mode(uint32_t mode) { g_mode = mode; }
 extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const uint32_t *lost, uint32_t nlost,
                         const uint32_t *rep_esi, uint32_t nrep, uint32_t nrep_avail, uint8_t *arena,
                         uint32_t arena_cap, uint32_t lds_dyn_bytes, nrq_job *job_out) {
@@ -62,6 +64,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   job.work = (uint64_t)(uintptr_t)work.data();
   job.arena = (uint64_t)(uintptr_t)arena;
   job.nlost = nlost; job.nrep = nrep; job.arena_cap = arena_cap; job.nrep_avail = nrep_avail;
+  job.mode = g_mode;
   PlanCtx c;
   pl_ctx_setup(c, p, kc, job, sh, lds_dyn_bytes ? dyn.data() : nullptr, lds_dyn_bytes, Mcap, npcap, ucap, job_out);
 #define PL_PHASE(fn) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, t_, PL_NT); } while (0)

@@ -348,3 +348,34 @@ def test_narrow_strip_paths_at_small_sizes(G, orc, wb, split):
     finally:
         c.set_option("max_wb", 16)
         c.set_option("no_split", 0)
+
+
+def test_device_built_encode_plans(G, orc):
+    """Encode plans of big blocks come from the device planner, built asynchronously (nrq_precalculate enqueues, the
+    encode that needs the plan waits; rebuilt plans alternate between two device buffers).  Forced for small K here:
+    intermediate and repair symbols against the oracle, across cache clears and back-to-back rebuilds."""
+    c = G.ctx()
+    c.set_option("encplan_dev_min_l", 0)
+    try:
+        for K, T in [(10, 8), (100, 1024), (1033, 16), (4000, 48), (8192, 32)]:
+            src = np.stack([payload(K * T, seed=K + 1, block=b).reshape(K, T) for b in range(2)])
+            esis = np.array([K, K + 1, K + 5, (1 << 24) - 1], np.uint32)
+            want = [orc.encode_block(src[b], K, T, esis, want_inter=True) for b in range(2)]
+            for rebuild in range(3):
+                c.clear_plan_cache()
+                c.precalculate(K)          # enqueue only
+                if rebuild == 2:
+                    c.clear_plan_cache()   # dropped before use: the next encode starts another build
+                rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+                for b in range(2):
+                    assert np.array_equal(inter[b], want[b][1]) and np.array_equal(rep[b], want[b][0]), (K, rebuild, b)
+        # a block coded with a larger table row than its own
+        K, Kp, T = 95, 101, 64
+        src = payload(K * T, seed=5).reshape(1, K, T)
+        c.clear_plan_cache()
+        rep, inter = G.gpu_encode(src, K, T, [95, 96, 300], want_inter=True, Kp=Kp)
+        r_rep, r_int, _ = orc.encode_block(src[0], K, T, [95, 96, 300], want_inter=True, Kp=Kp)
+        assert np.array_equal(inter[0], r_int) and np.array_equal(rep[0], r_rep)
+    finally:
+        c.set_option("encplan_dev_min_l", 12000)
+        c.clear_plan_cache()

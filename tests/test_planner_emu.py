@@ -265,3 +265,25 @@ def test_device_planner_takes_more_symbols_when_rank_deficient(orc):
         r, _ = emu_solve(plan, kc, rowsrc, work, rep, T, prm["L"], lists, lost, work, 16)
         assert r == 1 and np.array_equal(work, src), trial
     assert took_extra > 0
+
+
+@pytest.mark.parametrize("K,T,wb,lds", [(10, 8, 16, 140), (100, 36, 8, 140), (1024, 20, 16, 140), (1024, 12, 4, 24), (8192, 16, 16, 140)])
+def test_device_planner_builds_encode_plans(orc, K, T, wb, lds):
+    """Encode plans of big blocks are built by the GPU planner (a job without missing symbols, nrq_planjob::mode = 1,
+    what nrq_precalculate enqueues for K' from 12000 up): its phase code on the CPU, the plan through the emulated
+    solve workgroup, against the oracle -- intermediate and repair symbols."""
+    p = orc.params(K)
+    src = payload(K * T, seed=12).reshape(K, T)
+    kc = nanorq_amd.host_kconst(K)
+    plan, hdr = emu_device_plan(K, kc, [], [], lds_bytes=lds * 1024, encode=True)
+    assert hdr["status"] == 0 and hdr["npiv"] + hdr["u"] == p["L"] and hdr["M"] == p["L"]
+    rowsrc = np.full(p["L"], ROW_ZERO, np.uint32)
+    rowsrc[p["S"] + p["H"]: p["S"] + p["H"] + K] = np.arange(K, dtype=np.uint32)
+    esis = np.arange(K, K + 5, dtype=np.uint32)
+    lists = lt_lists(orc, K, esis + (p["Kp"] - K), plan)
+    out = np.zeros((5, T), np.uint8)
+    r, inter = emu_solve(plan, kc, rowsrc, src, None, T, p["L"], lists, np.arange(5), out, wb)
+    ref_rep, ref_inter, _ = orc.encode_block(src, K, T, esis, want_inter=True)
+    assert r == 1 and np.array_equal(inter, ref_inter) and np.array_equal(out, ref_rep)
+    # without the mode flag a job without missing symbols stays "nothing to do"
+    assert emu_device_plan(K, kc, [], [])[1]["status"] == 1
