@@ -5,28 +5,48 @@
 
 Workload (config.workload "cfg3"): BASELINE.json configs[2] -- K=8192 source symbols of T=1280 bytes per
 source block, 10 % independent random loss per block, decode with exactly K received symbols
-(overhead 0: the GF(256)/HDPC path; a block whose matrix is rank deficient is retried with one more
-repair symbol inside the timed region and counted).  One STEP = one batch of `--blocks` independent
-source blocks per GPU: encode (source -> intermediate symbols in HBM + R repair symbols; the encode
-plan is rebuilt every step, i.e. once per 256-block object like nanorq_precalculate) followed by
-decode (per-block plan from the loss pattern + solve + regeneration of the missing symbols).
-Payloads are synthetic and already resident in HBM when the timed region starts.  Blocks shard
-across GPUs with no data-path collective (weak scaling); rank 0 prints ONE JSON line.
+(overhead 0: the GF(256)/HDPC path; a block whose matrix is rank deficient takes one more repair symbol
+inside the timed region, counted).  One STEP = one batch of `--blocks` independent source blocks per
+GPU: the receiver's copy is damaged again (the head of every lost row overwritten on the device -- counted in
+the step: without it the decode of every step after the first would find nothing to repair), encode (source ->
+intermediate symbols in HBM + R repair symbols; the encode plan is rebuilt every step, i.e. once per
+256-block object like nanorq_precalculate) and decode (per-block plan from the loss pattern + solve +
+regeneration of the missing symbols).  Payloads are synthetic, a function of the GLOBAL block id, and
+already resident in HBM when the timed region starts.  Blocks shard across GPUs with no data-path
+collective (weak scaling); rank 0 prints ONE JSON line.
 
 `value` = 8 * (payload bytes encoded and decoded) / wall time, whole job.
-`roofline`: the solve kernel (nrq_solve_kernel) against the HBM roofline using the ALGORITHMIC
-bytes of SURVEY.md section 8(d) -- the row traffic the reference CPU path performs for the same blocks,
-counted live by the oracle on the sampled blocks -- divided by the kernel's average launch
-duration measured with HIP events on the launch stream.
+Proof of work: every step leaves a digest of two sampled blocks' repair + intermediate symbols (poisoned
+before the encode) and of their decoded rows (damaged before the decode); all digests must equal the
+digest of the oracle's results for those blocks, and after the last step every block must equal its
+source.  A step that did nothing fails the run.
+`roofline`: the solve kernel (nrq_solve_kernel) --
+  achieved/peak/frac  the ALGORITHMIC bytes of SURVEY.md section 8(d) (the row traffic the reference CPU path
+                      performs for the same blocks, counted by the oracle on the sampled blocks) over the kernel's
+                      average launch duration (HIP events on the launch stream) against the 8 TB/s HBM peak.  The
+                      strip solver keeps rows in LDS, so this "reference-equivalent work rate" exceeds 1: it is NOT a
+                      utilisation;
+  traffic             physical HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE and
+                      WRITE_SIZE in separate passes, collected at the end of the run when rocprofv3 is there;
+                      `traffic_source` says where the numbers come from), next to `compulsory` (every symbol byte
+                      once in, once out) and `staging` (the line-group staging buffers, once each way);
+  binding             what bounds an LDS-resident solver: `lds_frac` = cycles the CUs' LDS pipelines are busy /
+                      cycles available, `issue_frac` = VALU issue slots used / available, `hbm_frac` = physical
+                      traffic / (duration x 8 TB/s); `nearest` names the one closest to 1.
+`e2e`: the same step from pinned host buffers to pinned host buffers (PCIe both ways, one stream, nothing
+overlapped): never `value`.
 `cpu_baseline`: the oracle (C restatement of the reference algorithm with AVX2 GF(256) row kernels;
 upstream oblas is absent so this is a "port") timed on this host, one core, on a bounded sample of the
 same workload.
 """
 import argparse
 import json
-import math
 import os
+import shutil
+import signal
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -36,7 +56,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SE = 32               # shader engines (8 XCDs x 4): SQ_BUSY_CYCLES is summed over them
+SIMD_PER_CU = 4         # a wave64 VALU instruction occupies its SIMD for 4 cycles
+PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES",
+               "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]]
 
 
 def parse():
@@ -53,11 +78,16 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=6, help="blocks timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-replan", action="store_true", help="keep the encode plan cached across steps")
     ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams per GPU: the step's blocks are split into this many groups, each on its own stream, so "
-                         "that one group's (latency-bound, 1 workgroup/block) planner kernel runs beside another group's solve")
+                    help="HIP streams per GPU: the step's blocks are split into this many groups, each on its own stream")
+    ap.add_argument("--pmc", choices=("auto", "off"), default="auto",
+                    help="auto: at 1 GPU, collect HBM / LDS / issue counters of the solve kernel with rocprofv3 passes of this "
+                         "command after the timed run (falls back to the committed profiles/ file); off: skip")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffers-to-host-buffers leg")
+    ap.add_argument("--check-blocks", type=int, default=2, help="blocks whose results are digested every step and compared with the oracle")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="plumbing tests only: every rank uses this GPU (several ranks on one device; use with gloo)")
+    ap.add_argument("--digest-out", default="", help="plumbing tests: write the per-block SHA-256 of this rank's repair symbols here")
     return ap.parse_args()
 
 
@@ -128,21 +158,6 @@ def cpu_baseline(args, src_np, lost_np, nrep_enc):
     }, balg_enc / n, balg_dec / n
 
 
-def pmc_traffic(args):
-    """HBM bytes per solve-kernel launch from the committed rocprofv3 --pmc passes (profiles/r1_pmc_hbm.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command; see the file for caveats).
-    Only valid for the default workload; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except (OSError, ValueError):
-        return None
-    if (rec.get("K"), rec.get("T"), rec.get("blocks")) != (args.K, args.T, args.blocks):
-        return None
-    return rec.get("bytes_per_launch")
-
-
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -152,6 +167,101 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+# ------------------------------------------------------------------------------------ PMC (rocprofv3) ----
+def _run_group(cmd, cwd, env, timeout):
+    """subprocess with a process group of its own, so that a hung profiler run is ended as a whole"""
+    p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+    try:
+        return p.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        p.wait()
+        return -9
+
+
+def pmc_collect(args):
+    """rocprofv3 --pmc passes (one counter group per pass, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE
+    cannot share a pass) of a short run of THIS command; returns {counter: mean value per full-batch solve launch}."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    import sqlite3
+    inner = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--pmc", "off", "--no-e2e",
+             "--K", str(args.K), "--T", str(args.T), "--blocks", str(args.blocks), "--loss", str(args.loss), "--overhead", str(args.overhead)]
+    if args.no_replan:
+        inner.append("--no-replan")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="nrq_pmc_", dir="/tmp")
+    try:
+        for i, grp in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, "p%d" % i)
+            rc = _run_group([exe, "--pmc", *grp, "-d", d, "--"] + inner, "/tmp", env, 240)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")] if os.path.isdir(d) else []
+            if rc != 0 or not dbs:
+                return None, "rocprofv3 pass %s failed (rc %s)" % (grp, rc)
+            rows = []
+            for path in dbs:
+                db = sqlite3.connect(path)
+                rows += db.execute("select kernel_name, grid_size, counter_name, value from counters_collection").fetchall()
+                db.close()
+            rows = [r for r in rows if "nrq_solve_kernel" in r[0]]
+            if not rows:
+                return None, "no solve-kernel rows in pass %s" % grp
+            gmax = max(r[1] for r in rows)
+            for cname in grp:
+                v = [r[3] * (1024.0 if cname in ("FETCH_SIZE", "WRITE_SIZE") else 1.0) for r in rows if r[1] == gmax and r[2] == cname]
+                if v:
+                    out[cname] = sum(v) / len(v)
+    except Exception as e:  # noqa: BLE001 -- profiling is best effort, the bench line must still come out
+        return None, "pmc collection failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, "rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1` run by this process after the timed region"
+
+
+def pmc_committed(args):
+    """the counters of the committed profile (tools/collect_profiles.sh), if it is of this workload"""
+    for name in ("r2_pmc.json", "r1_pmc_hbm.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if (rec.get("K"), rec.get("T"), rec.get("blocks")) != (args.K, args.T, args.blocks):
+            continue
+        return {k: v["mean"] for k, v in rec.get("per_launch", {}).items()}, "committed profiles/%s" % name
+    return None, "none"
+
+
+def binding_model(c, avg_ms, ncu):
+    """What bounds an LDS-resident solver: LDS pipeline occupancy and VALU issue slots (and physical HBM traffic)."""
+    if not c or "SQ_BUSY_CYCLES" not in c:
+        return None
+    cyc = c["SQ_BUSY_CYCLES"] / N_SE                     # kernel duration in shader cycles
+    cu_cycles = cyc * ncu
+    out = {"kernel_cycles": cyc, "clock_ghz": cyc / (avg_ms * 1e-3) / 1e9 if avg_ms else None}
+    if "SQ_LDS_IDX_ACTIVE" in c:
+        out["lds_frac"] = c["SQ_LDS_IDX_ACTIVE"] / cu_cycles
+        if "SQ_LDS_BANK_CONFLICT" in c:
+            out["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    if "SQ_INSTS_VALU" in c:
+        out["issue_frac"] = c["SQ_INSTS_VALU"] * 4.0 / (cu_cycles * SIMD_PER_CU)
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        out["waves_waiting_share"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"):
+        if k in c:
+            out[k.lower() + "_per_launch"] = c[k]
+    out["model"] = ("lds_frac = SQ_LDS_IDX_ACTIVE / (CUs x kernel cycles), issue_frac = SQ_INSTS_VALU x 4 cycles / (CUs x 4 SIMDs x "
+                    "kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32 shader engines")
+    return out
 
 
 def main():
@@ -184,9 +294,11 @@ def main():
     # weak scaling: the job has world*NB source blocks per step, block b lives on GPU b mod world;
     # payload and loss pattern are functions of the GLOBAL block id, payload generated on the device
     my_blocks = shard.blocks_of(rank, world, world * NB)
+    src = torch.empty((NB, K, T), dtype=torch.uint8, device=dev)
     g = torch.Generator(device=dev)
-    g.manual_seed(1 + rank)
-    src = torch.randint(0, 256, (NB, K, T), dtype=torch.uint8, device=dev, generator=g)
+    for b, gb in enumerate(my_blocks):
+        g.manual_seed(1000003 * gb + 1)   # the payload is a function of the GLOBAL block id, not of the rank
+        src[b] = torch.randint(0, 256, (K, T), dtype=torch.uint8, device=dev, generator=g)
     lost = [loss_pattern(K, args.loss, seed=1000, block=gb) for gb in my_blocks]
     max_lost = max(len(x) for x in lost)
     nrep = max_lost + args.overhead + 3  # repair symbols generated per block by the encoder (incl. spares)
@@ -194,8 +306,10 @@ def main():
     rep = torch.empty((NB, nrep, T), dtype=torch.uint8, device=dev)
     inter = torch.empty((NB, L, T), dtype=torch.uint8, device=dev)
     work = src.clone()  # what the receiver holds: source block with the lost rows destroyed
-    for b in range(NB):
-        work[b, torch.from_numpy(lost[b].astype(np.int64)).to(dev)] = 0xEE
+    # rows (block * K + esi) the channel destroyed: overwritten again at the start of EVERY step
+    lost_rows = torch.from_numpy(np.concatenate([b * K + lost[b].astype(np.int64) for b in range(NB)])).to(dev)
+    work_rows = work.view(NB * K, T)
+    damage = work_rows.narrow(1, 0, min(T, 32))   # the first 32 bytes of a lost row are enough to lose it
     lost_arr = np.zeros((NB, max_lost + 1), np.uint32)
     for b in range(NB):
         lost_arr[b, :len(lost[b])] = lost[b]
@@ -206,15 +320,42 @@ def main():
     nr_first = (nlost + args.overhead).astype(np.uint32)
     nr_avail = (nlost + args.overhead + spare).astype(np.uint32)
 
+    # proof of work: blocks whose results are poisoned before and digested after every step
+    chk = sorted(set([0, NB - 1][:max(0, args.check_blocks)]))[:args.check_blocks] if args.check_blocks > 0 else []
+    chk_t = torch.tensor(chk, dtype=torch.int64, device=dev) if chk else None
+    nchk_rep = int(min(nr_first[chk].min(), nrep)) if chk else 0   # repair symbols every reception of theirs uses
+    digests = []
+
     # block ranges of the stream groups
     bounds = [(NB * g_) // nstreams for g_ in range(nstreams + 1)]
     groups = [(bounds[g_], bounds[g_ + 1]) for g_ in range(nstreams)]
 
     replan_early = L >= 12000   # (the library's threshold for device-built encode plans, NRQ_ENCPLAN_DEV_MIN_L)
 
+    # (a sample of each checked block's rows: the digest costs microseconds, not a pass over the block)
+    rep_rows = torch.arange(0, min(16, nchk_rep), device=dev) if chk else None
+    int_rows = torch.arange(0, L, 32, device=dev)
+    wrk_rows = (torch.from_numpy(np.concatenate([b * K + lost[b][:64].astype(np.int64) for b in chk])).to(dev) if chk else None)
+    rep_v, int_v = rep.view(NB, nrep, T), inter.view(NB, L, T)
+
+    def poison():
+        for b in chk:
+            rep_v[b].index_fill_(0, rep_rows, 0xCD)
+            int_v[b].index_fill_(0, int_rows, 0xCD)
+
+    def digest():
+        # sums are enough: the sampled rows are poisoned with constants before the step, the expected values come from the oracle
+        return torch.stack([torch.stack([rep_v[b].index_select(0, rep_rows).sum(dtype=torch.int64) for b in chk]).sum(),
+                            torch.stack([int_v[b].index_select(0, int_rows).sum(dtype=torch.int64) for b in chk]).sum(),
+                            work_rows.index_select(0, wrk_rows).sum(dtype=torch.int64)])
+
     def step():
         nonlocal retries
         enc_stats = dec_stats = None
+        # the channel: the receiver's copy loses its rows again (one small kernel; part of the step)
+        damage.index_fill_(0, lost_rows, 0xEE)
+        if chk:
+            poison()
         for (lo, hi), c_ in zip(groups, ctxs):
             n_ = hi - lo
             c_.encode_blocks(K, T, n_, src[lo].data_ptr(), K * T, rep[lo].data_ptr(), nrep * T, esis, inter[lo].data_ptr(),
@@ -237,6 +378,8 @@ def main():
             if not st.all():
                 raise RuntimeError("decode failed for %d blocks" % int((st == 0).sum()))
             retries += int((used - nr_first[lo:hi]).sum())
+        if chk and nstreams == 1:
+            digests.append(digest())
         if not args.no_replan and not replan_early:
             # one encode plan per step (= per 256-block object, like nanorq_precalculate): the plan for the NEXT step's
             # encode is rebuilt on the host here (once per context), while the GPU runs this step's solve
@@ -253,6 +396,7 @@ def main():
         step()
     barrier()
     retries = 0
+    digests.clear()
     for c_ in ctxs:
         c_.ktime_enable(True)
     t0 = time.perf_counter()
@@ -270,8 +414,68 @@ def main():
     elapsed = shard.reduce_max(elapsed, world, device=rdev)   # the slowest rank defines the step time
     retries_total = int(shard.reduce_sum(retries, world, device=rdev))
 
-    # correctness of what was timed: every block decoded back to its source
+    # ---- correctness of what was timed ----
     assert torch.equal(work, src), "decoded blocks differ from the source blocks"
+    check = {"blocks": chk, "steps_digested": len(digests), "oracle": False}
+    if digests:
+        d0 = digests[0]
+        for d in digests[1:]:
+            assert torch.equal(d, d0), "a timed step produced different results than the first one"
+        import oracle
+        exp_rep = exp_int = 0
+        for b in chk:   # the oracle's repair + intermediate symbols of the checked blocks, byte for byte
+            sb = src[b].cpu().numpy()
+            r_rep, r_int, _ = oracle.encode_block(sb, K, T, esis[:nchk_rep], want_inter=True)
+            assert np.array_equal(rep[b, :nchk_rep].cpu().numpy(), r_rep), "repair symbols of block %d differ from the oracle" % b
+            assert np.array_equal(inter[b].cpu().numpy(), r_int), "intermediate symbols of block %d differ from the oracle" % b
+            exp_rep += int(r_rep[:len(rep_rows)].sum(dtype=np.int64))
+            exp_int += int(r_int[::32].sum(dtype=np.int64))
+        exp_work = int(src.view(NB * K, T).index_select(0, wrk_rows).sum(dtype=torch.int64))   # (rows still holding 0xEE would not sum to this)
+        assert [int(x) for x in d0] == [exp_rep, exp_int, exp_work], "step digests differ from the oracle's results"
+        check["oracle"] = True
+    if args.digest_out:
+        import hashlib
+        with open(args.digest_out, "w") as f:
+            json.dump({str(gb): hashlib.sha256(rep[b, :int(nr_first[b])].cpu().numpy().tobytes()).hexdigest()
+                       for b, gb in enumerate(my_blocks)}, f)
+
+    # ---- host buffers -> host buffers (PCIe both ways), rank 0 / 1 GPU only ----
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e and nstreams == 1:
+        h_src = torch.empty((NB, K, T), dtype=torch.uint8).pin_memory()
+        h_src.copy_(src)
+        h_rep = torch.empty((NB, nrep, T), dtype=torch.uint8).pin_memory()
+        h_work = torch.empty((NB, K, T), dtype=torch.uint8).pin_memory()
+        h_work.copy_(work)
+        h_work.view(NB * K, T)[lost_rows.cpu()] = 0xEE
+        h_out = torch.empty((NB, K, T), dtype=torch.uint8).pin_memory()
+        d_src = torch.empty_like(src)
+        n_e2e = 3
+
+        def e2e_step():
+            d_src.copy_(h_src, non_blocking=True)                                  # sender: object -> GPU
+            ctx.encode_blocks(K, T, NB, d_src.data_ptr(), K * T, rep.data_ptr(), nrep * T, esis, inter.data_ptr(), L * T)
+            h_rep.copy_(rep, non_blocking=True)                                    # repair symbols -> host (to the network)
+            work.copy_(h_work, non_blocking=True)                                  # receiver: what arrived -> GPU
+            rep.copy_(h_rep, non_blocking=True)
+            st, _ = ctx.decode_blocks_lazy(K, T, NB, work.data_ptr(), K * T, lost_arr, nlost, resi, nr_first, nr_avail, rep.data_ptr(), nrep * T)
+            h_out.copy_(work, non_blocking=True)                                   # recovered object -> host
+            assert st.all()
+
+        e2e_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n_e2e):
+            e2e_step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / n_e2e
+        assert torch.equal(h_out, h_src), "end-to-end leg: decoded host buffer differs from the source"
+        moved = NB * T * (K + nrep + K + nrep + K)
+        e2e = {"value": 8.0 * NB * K * T / dt / 1e9, "unit": "Gbit/s", "ms_per_step": dt * 1e3, "pcie_bytes_per_step": moved,
+               "pcie_gbs": moved / dt / 1e9, "steps": n_e2e,
+               "what": "pinned host buffers -> H2D -> encode -> D2H repair | H2D received symbols -> decode -> D2H recovered block; "
+                       "one stream, copies and kernels serialised (the object API overlaps them: tools/bench_object_api.py)"}
+        del h_src, h_rep, h_work, h_out, d_src
 
     if rank == 0:
         payload_step = world * NB * K * T
@@ -282,33 +486,68 @@ def main():
             cpu, balg_enc, balg_dec = cpu_baseline(args, src_np, lost, nrep)
         # solve-kernel launches in the timed region: [encode, decode(, retries...)] per step
         roof = None
-        if balg_enc is not None and ktimes:
+        if ktimes:
             # every step launches the solve kernel 2*nstreams times (encode and decode of each stream group); launches of
             # different streams overlap in time, so the kernel's rate is the algorithmic bytes of all launches divided by
             # the time during which at least one of them was running (= the plain average duration when nstreams == 1)
             avg_ms = sum(ktimes) / len(ktimes)
             busy, cur_s, cur_e = 0.0, None, None
-            for s0, d0 in sorted(intervals):
+            for s0, d0_ in sorted(intervals):
                 if cur_e is None or s0 > cur_e:
                     busy += 0.0 if cur_e is None else cur_e - cur_s
-                    cur_s, cur_e = s0, s0 + d0
+                    cur_s, cur_e = s0, s0 + d0_
                 else:
-                    cur_e = max(cur_e, s0 + d0)
+                    cur_e = max(cur_e, s0 + d0_)
             busy += 0.0 if cur_e is None else cur_e - cur_s
             blocks_per_launch = NB / float(nstreams)
-            alg_per_launch = 0.5 * (balg_enc + balg_dec) * blocks_per_launch
             eff_ms = busy / len(ktimes)   # busy time attributable to one launch
-            achieved = alg_per_launch / (eff_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args), "kernel": "nrq_solve_kernel<%d, %d, %d>" %
-                    (enc_stats["strip_bytes"], enc_stats["wg_threads"], enc_stats["wg_waves_per_simd"]), "avg_launch_ms": avg_ms, "busy_ms_per_launch": eff_ms,
-                    "launches_timed": len(ktimes), "blocks_per_launch": blocks_per_launch,
-                    "algorithmic_bytes_per_launch": alg_per_launch,
-                    "algorithmic_bytes_per_block": {"encode": balg_enc, "decode": balg_dec},
-                    "note": "algorithmic bytes = reference-equivalent row traffic (SURVEY 8d), not physical HBM bytes: the "
-                            "strip solver keeps rows in LDS. avg_launch_ms is the per-launch HIP-event duration (what rocprofv3 "
-                            "--kernel-trace reports); with %d streams launches overlap, so `achieved` divides by the union of "
-                            "the launches' busy time per launch" % nstreams}
+            # physical bytes a launch cannot avoid / chooses to move (mean of the encode and the decode launch)
+            gaps = float(nlost.mean())
+            comp_enc = NB * T * (K + L + nrep)                       # source in; intermediate + repair symbols out
+            comp_dec = NB * T * (K + gaps + gaps)                    # received symbols in; recovered symbols out
+            stage_enc = NB * T * (L + (L + nrep))                    # slot image + results, once through the staging buffers
+            stage_dec = NB * T * ((L + args.overhead) + gaps)
+            compulsory, staging = 0.5 * (comp_enc + comp_dec), 0.5 * (stage_enc + stage_dec)
+            counters, csrc = (None, "off")
+            if args.pmc == "auto" and world == 1 and nstreams == 1:
+                for c_ in ctxs:
+                    c_.sync()
+                counters, csrc = pmc_collect(args)
+                if counters is None:
+                    why = csrc
+                    counters, csrc = pmc_committed(args)
+                    csrc += " (live collection: %s)" % why
+            traffic = None
+            if counters and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+                traffic = counters["FETCH_SIZE"] + counters["WRITE_SIZE"]
+            bind = binding_model(counters, avg_ms, torch.cuda.get_device_properties(dev).multi_processor_count)
+            if bind is not None and traffic:
+                bind["hbm_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if bind is not None:
+                cand = {k: bind[k] for k in ("lds_frac", "issue_frac", "hbm_frac") if bind.get(k) is not None}
+                bind["nearest"] = max(cand, key=cand.get) if cand else None
+            roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
+                    "kernel": "nrq_solve_kernel<%d, %d, %d>" % (enc_stats["strip_bytes"], enc_stats["wg_threads"], enc_stats["wg_waves_per_simd"]),
+                    "avg_launch_ms": avg_ms, "busy_ms_per_launch": eff_ms, "launches_timed": len(ktimes),
+                    "blocks_per_launch": blocks_per_launch,
+                    "traffic_source": csrc,
+                    "traffic_detail": ({"read": counters.get("FETCH_SIZE"), "written": counters.get("WRITE_SIZE"),
+                                        "note": "FETCH_SIZE as reported; MI355X_MICROARCH.md: on gfx950 it counts wide coalesced "
+                                                "reads at half their bytes (this kernel's row gathers are 16-byte pieces, "
+                                                "uncalibrated): the read side is a lower bound, at most 2x higher"} if counters else None),
+                    "compulsory": compulsory, "staging": staging,
+                    "traffic_over_compulsory": traffic / compulsory if traffic else None,
+                    "traffic_over_compulsory_plus_staging": traffic / (compulsory + staging) if traffic else None,
+                    "binding": bind}
+            if balg_enc is not None:
+                alg_per_launch = 0.5 * (balg_enc + balg_dec) * blocks_per_launch
+                achieved = alg_per_launch / (eff_ms * 1e-3) / 1e9
+                roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_per_launch,
+                             "algorithmic_bytes_per_block": {"encode": balg_enc, "decode": balg_dec},
+                             "note": "achieved/frac = reference-equivalent row traffic (SURVEY 8d) over the launch duration: a work "
+                                     "rate, not an HBM utilisation (the strip solver keeps rows in LDS, so it exceeds 1); the "
+                                     "utilisations are in `binding` (LDS pipeline, VALU issue, physical HBM). avg_launch_ms is the "
+                                     "per-launch HIP-event duration (what rocprofv3 --kernel-trace reports)"})
         out = {
             "metric": "Gbit/s encode+decode, K=%d T=%d" % (K, T), "value": value, "unit": "Gbit/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -322,8 +561,12 @@ def main():
                        "encode_plan": "cached" if args.no_replan else "rebuilt every step",
                        "planner": ("device (nrq_plan_kernel, one workgroup per block)" if dec_stats["planner"] else
                                    "host, %d threads/rank" % threads),
-                       "decode_retries": retries_total, "spare_symbols_taken": retries_total},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "host_planned_blocks": dec_stats.get("host_planned", 0),
+                       "decode_retries": retries_total, "spare_symbols_taken": retries_total,
+                       "in_step": "damage of the receiver's copy (lost rows overwritten on the device), poisoning and digest of the "
+                                  "checked blocks"},
+            "check": check,
+            "roofline": roof, "e2e": e2e, "cpu_baseline": cpu,
             "detail": {"solve_kernel_ms_sum_per_step": sum(ktimes) / args.steps,
                        # the solve launches of a step are [encode, decode] per stream group, in that order
                        "encode_solve_ms": (sum(ktimes[0::2]) / max(1, len(ktimes[0::2]))) if nstreams == 1 else None,
