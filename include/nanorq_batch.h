@@ -36,6 +36,28 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
  * the object that are complete afterwards; blocks whose system is rank deficient stay incomplete and retryable. */
 size_t nanorq_repair_all(nanorq *rq, struct ioctx *io);
 
+/* ---- streaming I/O: page-locked memory (second half) ----
+ * A GPU behind PCIe is fed fastest by asynchronous DMA copies straight out of (and into) page-locked host memory.  With
+ * the contexts below the batched calls above move whole blocks that way, overlapped with the solve of the neighbouring
+ * blocks: nanorq_generate_symbols_all reads the object from the context's memory without a host-side copy;
+ * nanorq_decoder_add_symbols, given a page-locked packet buffer, uploads it in one piece and sorts the symbols into their
+ * rows on the GPU; nanorq_repair_all writes whole decoded blocks into the context's memory.  Results are the bytes the
+ * per-symbol calls produce.  One difference in timing: on this path the source symbols a decoder receives reach the
+ * output context at the next nanorq_repair_all / nanorq_repair_block of their block (or nanorq_decoder_flush), not
+ * inside the add call (reference: write-through at lib/nanorq.c:498). */
+/* memory context over `sz` bytes of page-locked memory it allocates and owns (freed by destroy) */
+struct ioctx *ioctx_from_pinned_mem(size_t sz);
+/* memory context over caller memory that is page-locked in place for the life of the context */
+struct ioctx *ioctx_from_registered_mem(uint8_t *ptr, size_t sz);
+/* the bytes of a memory context (any of ioctx_from_mem / _pinned_mem / _registered_mem), NULL for other contexts */
+uint8_t *ioctx_mem_base(struct ioctx *io);
+/* page-locked buffers for packets (what a receive path hands to nanorq_decoder_add_symbols) */
+void *nanorq_pinned_alloc(size_t bytes);
+void nanorq_pinned_free(void *p);
+/* Decoder: write the received source symbols that have not reached `io` yet (blocks fed through the page-locked path
+ * and not repaired since).  Returns the number of blocks written. */
+size_t nanorq_decoder_flush(nanorq *rq, struct ioctx *io);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,15 @@ int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, ui
                            const uint32_t *h_nrep, const uint32_t *h_nrep_avail, uint32_t rep_cap, const void *d_rep,
                            size_t rep_stride, void *d_inter, size_t inter_stride, int *h_status, uint32_t *h_used);
 
+/* nrq_encode_blocks (no repair symbols) with block b's intermediate symbols going to device address d_inter_v[b]. */
+int nrq_encode_blocks_v(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,
+                        const uint64_t *d_inter_v);
+/* nrq_decode_blocks_lazy for blocks that do not lie at a fixed stride: block b's source rows at device address
+ * d_src_v[b], its repair symbols at d_rep_v[b] (host arrays of device addresses).  No intermediate symbols out. */
+int nrq_decode_blocks_v(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const uint64_t *d_src_v, const uint32_t *h_lost,
+                        const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi, const uint32_t *h_nrep,
+                        const uint32_t *h_nrep_avail, uint32_t rep_cap, const uint64_t *d_rep_v, int *h_status, uint32_t *h_used);
+
 /* Generate encoding symbols from intermediate symbols already in HBM (after encode/decode with
  * d_inter != NULL): symbol q of block b = LT(C_b, isi[q]) -> d_out + b*out_stride + q*T.
  * h_isi are INTERNAL symbol ids (esi for esi < K, esi + K' - K for repair symbols). */
@@ -128,6 +137,32 @@ int nrq_dev_memset(nrq_ctx *ctx, void *d_dst, int value, size_t bytes);
 int nrq_dev_upload_async(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int nrq_dev_download_async(nrq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int nrq_dev_copy(nrq_ctx *ctx, void *d_dst, const void *d_src, size_t bytes); /* device to device, enqueue-only */
+
+/* nrq_dev_alloc / nrq_dev_free come out of a caching pool of the context (no hipMalloc / hipFree per call, no
+ * synchronisation on free); nrq_dev_trim hands the cached blocks back to the driver. */
+int nrq_dev_trim(nrq_ctx *ctx);
+
+/* ---- what the object layer's streaming path is made of (reference: transfer_esi / load_symbol_matrix,
+ * lib/nanorq.c:148-182, and the seek+read/write loops of lib/io.c behind them) ----
+ * Page-locked host memory: the copy engines move it at PCIe speed and asynchronously. */
+int nrq_host_alloc_pinned(size_t bytes, void **out);
+void nrq_host_free_pinned(void *p);
+int nrq_host_register(void *p, size_t bytes);   /* page-lock caller memory in place */
+void nrq_host_unregister(void *p);
+int nrq_host_is_pinned(const void *p);          /* 1 if p lies in page-locked (allocated or registered) host memory */
+/* Copies and ordering on the context's streams.  `stream`: 0 = the context's stream (kernels), 1 = its upload stream,
+ * 2 = its download stream.  Everything is enqueue-only; events order the streams among each other. */
+int nrq_copy_on(nrq_ctx *ctx, int stream, void *dst, const void *src, size_t bytes); /* direction from the pointers */
+int nrq_memset_on(nrq_ctx *ctx, int stream, void *d_dst, int value, size_t bytes);
+int nrq_event_new(nrq_ctx *ctx, void **out);
+void nrq_event_free(void *ev);
+int nrq_event_record(nrq_ctx *ctx, void *ev, int stream);
+int nrq_stream_wait(nrq_ctx *ctx, int stream, void *ev);  /* later work on `stream` waits for ev */
+int nrq_event_sync(nrq_ctx *ctx, void *ev);                /* the host waits */
+int nrq_stream_sync(nrq_ctx *ctx, int stream);
+/* Symbol ingestion on the device: symbol k (T bytes at d_blob + k*T, device memory) is copied to device address
+ * h_dst[k] (0 = skip) -- received packets go up in one piece and are put into their rows by a kernel. */
+int nrq_scatter_symbols(nrq_ctx *ctx, int stream, const void *d_blob, uint32_t n, uint32_t T, const uint64_t *h_dst);
 
 /* Per-launch duration of the solve kernel, measured with HIP events recorded on the launch stream
  * immediately around each launch (bench.py's roofline leg).  enable(1) starts collecting; read()

@@ -16,6 +16,9 @@
 #include <unistd.h>
 
 #include "../../include/io.h"
+#include "../../include/nanorq_batch.h"
+#include "../../include/nanorq_hip.h"
+#include "io_priv.h"
 
 /* ------------------------------------------------------------------------------ stdio file ---- */
 struct file_io { struct ioctx io; FILE *fp; };
@@ -52,7 +55,7 @@ struct ioctx *ioctx_from_file(const char *fn, int t) {
 }
 
 /* --------------------------------------------------------------------------- caller memory ---- */
-struct mem_io { struct ioctx io; uint8_t *base; size_t pos, len; };
+struct mem_io { struct ioctx io; uint8_t *base; size_t pos, len; int pinned; /* 0 = caller memory, 1 = page-locked and owned, 2 = caller memory registered */ };
 
 static size_t m_clip(struct mem_io *m, size_t len) { return (m->pos + len > m->len) ? m->len - m->pos : len; }
 static size_t m_read(struct ioctx *io, uint8_t *buf, size_t len) {
@@ -89,6 +92,45 @@ struct ioctx *ioctx_from_mem(const uint8_t *ptr, size_t sz) {
   m->io.seekable = true;
   m->io.writable = true;
   return &m->io;
+}
+
+/* page-locked variants (include/nanorq_batch.h): the object layer moves whole blocks between such a context and the GPU
+ * with asynchronous DMA copies -- no staging copy on the host, no seek/read loop (reference: transfer_esi and
+ * load_symbol_matrix, lib/nanorq.c:148-182, over lib/io.c:82-157) */
+static void pm_destroy(struct ioctx *io) {
+  struct mem_io *m = (struct mem_io *)io;
+  if (m->pinned == 1) nrq_host_free_pinned(m->base);
+  else if (m->pinned == 2) nrq_host_unregister(m->base);
+  free(m);
+}
+struct ioctx *ioctx_from_pinned_mem(size_t sz) {
+  void *p = NULL;
+  if (nrq_host_alloc_pinned(sz ? sz : 1, &p) != 0) return NULL;
+  struct ioctx *io = ioctx_from_mem(p, sz);
+  if (!io) { nrq_host_free_pinned(p); return NULL; }
+  ((struct mem_io *)io)->pinned = 1;
+  io->destroy = pm_destroy;
+  return io;
+}
+struct ioctx *ioctx_from_registered_mem(uint8_t *ptr, size_t sz) {
+  if (!ptr || nrq_host_register(ptr, sz) != 0) return NULL;
+  struct ioctx *io = ioctx_from_mem(ptr, sz);
+  if (!io) { nrq_host_unregister(ptr); return NULL; }
+  ((struct mem_io *)io)->pinned = 2;
+  io->destroy = pm_destroy;
+  return io;
+}
+uint8_t *ioctx_mem_base(struct ioctx *io) {
+  if (!io || io->read != m_read) return NULL;
+  return ((struct mem_io *)io)->base;
+}
+bool ioctx_dma_region(struct ioctx *io, uint8_t **base, size_t *len) {
+  if (!io || io->read != m_read || io->write != m_write) return false; /* (a caller that replaced the vtable gets the generic path) */
+  struct mem_io *m = (struct mem_io *)io;
+  if (!m->pinned) return false;
+  *base = m->base;
+  *len = m->len;
+  return true;
 }
 
 /* ------------------------------------------------------------------------------ mmap file ---- */

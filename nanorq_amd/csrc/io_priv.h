@@ -1,0 +1,8 @@
+/* io_priv.h -- what nanorq_api.c knows about io.c beyond include/io.h */
+#ifndef NRQ_IO_PRIV_H
+#define NRQ_IO_PRIV_H
+#include "../../include/io.h"
+/* true (and the region) if `io` is a page-locked memory context of this library whose vtable is untouched: its bytes
+ * can be the source or the target of an asynchronous DMA copy */
+bool ioctx_dma_region(struct ioctx *io, uint8_t **base, size_t *len);
+#endif

@@ -9,6 +9,16 @@
  *     decode_row for repair symbols and for gaps  (nanorq.c:184-204, :567-577)
  * -- go through include/nanorq_hip.h to the GPU.  Nothing in this file solves or generates symbols
  * on the CPU; when no GPU context can be created those calls fail (false / 0).
+ *
+ * Data movement.  Device buffers come from the context's pool (no hipMalloc /
+ * hipFree per call), host staging rows are page-locked, and the batched calls (include/nanorq_batch.h) run a
+ * three-stream pipeline: the upload of block n+1 and the download of block n-1 run beside the solve of
+ * block n.  With page-locked memory contexts (ioctx_from_pinned_mem / _registered_mem) blocks move between the
+ * object's memory and the GPU by DMA with no copy on the host at all, and a decoder fed from a page-locked
+ * packet buffer keeps its received symbols on the device ("device-resident" blocks below).
+ *
+ * Threads: distinct nanorq objects may be used from different threads (as with the reference, which has no
+ * globals); the one GPU context of the process behind them is guarded by a lock.  One object is not thread-safe.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -16,29 +26,44 @@
 #include <string.h>
 
 #include "../../include/nanorq.h"
+#include "../../include/nanorq_batch.h"
+#include "../../include/nanorq_ext.h"
 #include "../../include/nanorq_hip.h"
+#include "io_priv.h"
 
 #define NRQ_Z_MAX 256u
 #define NRQ_K_MAX 56403u
 #define ENC_WINDOW 512u /* repair symbols fetched from the device per miss of the encode cache */
+#define PIN_MIN ((size_t)64 << 10)        /* host buffers from this size on are page-locked */
+#define CHUNK_BYTES ((size_t)192 << 20)   /* source bytes per pipeline step of the batched calls */
+#define REPAIR_CHUNK_BYTES ((size_t)384 << 20)
 
 struct part { /* RFC 6330 section 4.4.1.2 Partition[I, J] */
   size_t IL, IS, JL, JS;
 };
 
 struct blockst {
-  uint32_t K;
+  uint32_t K, Kp, L;  /* source symbols; the table row the block is coded with and its L (block 0's unless NANORQ_EXT_PER_BLOCK_KP) */
   bool loaded, inverted;
-  uint8_t *src;       /* K x T: source symbols (encoder) / received source symbols (decoder) */
-  void *d_src;        /* device copy */
+  uint8_t *src;       /* K x T: source symbols (encoder) / received source symbols (decoder); allocated on first use */
+  bool src_pinned;
+  void *d_src;        /* device copy (K x T) */
   void *d_inter;      /* device: L x T intermediate symbols once solved */
   /* decoder side */
   uint32_t *mask;     /* received-ESI bitmap */
   size_t mask_words;
+  uint32_t have;      /* received source symbols (K - have = gaps) */
   uint32_t *rep_esi;  /* repair symbols in arrival order */
-  uint8_t *rep_data;
+  uint8_t *rep_data;  /* their bytes -- host-resident blocks only */
+  bool rep_pinned;
   size_t nrep, rep_cap;
   size_t spare;       /* max_esi - K: rows available beyond L (reference D sizing, nanorq.c:137-142) */
+  /* device-resident decoder block: the received symbols were uploaded as a packet buffer and sorted into d_src / d_rep
+   * on the GPU (nanorq_decoder_add_symbols with page-locked packets); no host copy is kept */
+  bool dev;
+  void *d_rep;        /* device: repair symbols in arrival order, capacity d_rep_cap symbols */
+  size_t d_rep_cap;
+  bool dirty;         /* received source symbols have not reached the output context yet */
   /* encoder side: window of generated symbols */
   uint8_t *win;
   uint32_t win_isi0, win_n;
@@ -48,8 +73,9 @@ struct nanorq {
   size_t F, T, Al;         /* common OTI */
   size_t Z, N, Kt;         /* scheme specific */
   struct part src_part, sub_part;
-  uint32_t Kp, S, H, L;    /* parameters of block 0, shared by every block (nanorq.c:289, :372) */
+  uint32_t Kp, S, H, L;    /* parameters of block 0, shared by every block (nanorq.c:289, :372) unless NANORQ_EXT_PER_BLOCK_KP */
   uint32_t max_esi;
+  uint32_t flags;          /* NANORQ_EXT_* */
   bool precalc;
   struct blockst *blocks[NRQ_Z_MAX];
 };
@@ -57,17 +83,25 @@ struct nanorq {
 /* ---------------------------------------------------------------- GPU context (process-wide) ---- */
 static nrq_ctx *g_ctx;
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+static pthread_mutex_t g_lock; /* recursive: every entry point that touches g_ctx holds it */
 
 static void ctx_init(void) {
   int dev = 0;
   const char *e = getenv("NANORQ_HIP_DEVICE");
   if (e && *e) dev = atoi(e);
+  pthread_mutexattr_t a;
+  pthread_mutexattr_init(&a);
+  pthread_mutexattr_settype(&a, PTHREAD_MUTEX_RECURSIVE);
+  pthread_mutex_init(&g_lock, &a);
+  pthread_mutexattr_destroy(&a);
   if (nrq_ctx_create(dev, NULL, &g_ctx) != 0) g_ctx = NULL;
 }
 static nrq_ctx *ctx(void) {
   pthread_once(&g_once, ctx_init);
   return g_ctx;
 }
+static void gpu_lock(void) { pthread_once(&g_once, ctx_init); pthread_mutex_lock(&g_lock); }
+static void gpu_unlock(void) { pthread_mutex_unlock(&g_lock); }
 
 /* -------------------------------------------------------------------------- small helpers ---- */
 static size_t ceil_div(size_t a, size_t b) { return a / b + (a % b ? 1 : 0); }
@@ -81,6 +115,21 @@ static struct part partition(size_t I, size_t J) { /* nanorq.c:83-95 */
   p.JS = J - p.JL;
   if (p.JL == 0) p.IL = 0;
   return p;
+}
+
+static void *host_alloc(size_t bytes, bool *pinned) { /* zeroed; page-locked from PIN_MIN on when there is a GPU */
+  void *p = NULL;
+  *pinned = false;
+  if (bytes >= PIN_MIN && ctx() && nrq_host_alloc_pinned(bytes, &p) == 0 && p) {
+    memset(p, 0, bytes);
+    *pinned = true;
+    return p;
+  }
+  return calloc(bytes ? bytes : 1, 1);
+}
+static void host_free(void *p, bool pinned) {
+  if (!p) return;
+  if (pinned) nrq_host_free_pinned(p); else free(p);
 }
 
 static bool mask_get(const struct blockst *b, size_t id) {
@@ -97,9 +146,11 @@ static void mask_set(struct blockst *b, size_t id) {
     b->mask = m;
     b->mask_words = nw;
   }
+  if (id < b->K && !((b->mask[w] >> (id % 32)) & 1u)) b->have++;
   b->mask[w] |= 1u << (id % 32);
 }
-static size_t mask_gaps(const struct blockst *b, size_t until) { /* zero bits below `until` */
+static size_t mask_gaps(const struct blockst *b, size_t until) { /* zero bits below `until` (bitmask_gaps, bitmask.c:47-77) */
+  if (until == b->K) return b->K - b->have;
   size_t set = 0, full = until / 32;
   for (size_t w = 0; w < full && w < b->mask_words; w++) set += (size_t)__builtin_popcount(b->mask[w]);
   if ((until % 32) && full < b->mask_words) set += (size_t)__builtin_popcount(b->mask[full] & ((1u << (until % 32)) - 1u));
@@ -115,12 +166,17 @@ size_t nanorq_blocks(nanorq *rq) { return rq->src_part.JL + rq->src_part.JS; }
 size_t nanorq_max_blocks(nanorq *rq) { (void)rq; return NRQ_Z_MAX; }
 size_t nanorq_transfer_length(nanorq *rq) { return rq->F; }
 size_t nanorq_symbol_size(nanorq *rq) { return rq->T; }
+uint32_t nanorq_ext_flags(nanorq *rq) { return rq->flags; }
+size_t nanorq_sub_blocks(nanorq *rq) { return rq->N; }
 
-uint64_t nanorq_oti_common(nanorq *rq) { /* nanorq.c:309-315: F<<24 | (T-1) */
-  return ((uint64_t)rq->F << 24) | ((rq->T - 1) & 0xffff);
+uint64_t nanorq_oti_common(nanorq *rq) {
+  if (rq->flags & NANORQ_EXT_RFC_OTI) return ((uint64_t)rq->F << 24) | (rq->T & 0xffff); /* RFC 6330 section 3.3.2 */
+  return ((uint64_t)rq->F << 24) | ((rq->T - 1) & 0xffff);                                  /* nanorq.c:309-315 */
 }
-uint32_t nanorq_oti_scheme_specific(nanorq *rq) { /* nanorq.c:317-324: (Z-1)<<24 | (N-1)<<8 | Al */
-  return (uint32_t)((rq->Z - 1) << 24) | (uint32_t)((rq->N - 1) << 8) | (uint32_t)rq->Al;
+uint32_t nanorq_oti_scheme_specific(nanorq *rq) {
+  if (rq->flags & NANORQ_EXT_RFC_OTI) /* RFC 6330 section 3.3.3: Z | N | Al */
+    return (uint32_t)((rq->Z & 0xff) << 24) | (uint32_t)((rq->N & 0xffff) << 8) | (uint32_t)rq->Al;
+  return (uint32_t)((rq->Z - 1) << 24) | (uint32_t)((rq->N - 1) << 8) | (uint32_t)rq->Al; /* nanorq.c:317-324 */
 }
 uint32_t nanorq_tag(uint8_t sbn, uint32_t esi) { return ((uint32_t)sbn << 24) | (esi & 0x00ffffffu); }
 
@@ -132,9 +188,16 @@ static bool set_block_params(nanorq *rq) {
   rq->Kp = pr[0]; rq->S = pr[2]; rq->H = pr[3]; rq->L = pr[5];
   return true;
 }
+size_t nanorq_block_kprime(nanorq *rq, uint8_t sbn) {
+  const size_t k = nanorq_block_symbols(rq, sbn);
+  uint32_t pr[10];
+  if ((rq->flags & NANORQ_EXT_PER_BLOCK_KP) && k && nrq_params((uint32_t)k, pr) == 0) return pr[0];
+  return rq->Kp;
+}
 
 /* ---------------------------------------------------------------------- construction ---- */
-nanorq *nanorq_encoder_new_ex(size_t len, uint16_t T16, uint16_t K, uint16_t Z16, uint8_t Al8) { /* nanorq.c:241-296 */
+nanorq *nanorq_encoder_new_ext(size_t len, uint16_t T16, uint16_t K, uint16_t Z16, uint16_t N16, uint8_t Al8, uint32_t flags) {
+  /* nanorq.c:241-296 */
   static const uint8_t aligns[4] = {8, 4, 2, 1};
   size_t T = T16, Z = Z16, Al = Al8;
   if (len > NANORQ_MAX_TRANSFER) return NULL;
@@ -158,34 +221,53 @@ nanorq *nanorq_encoder_new_ex(size_t len, uint16_t T16, uint16_t K, uint16_t Z16
   }
   Z = ceil_div(Kt, Kn);
   if (Z == 0 || Z > NRQ_Z_MAX || ceil_div(Kt, Z) > NRQ_K_MAX) return NULL;
+  size_t N = 1; /* nanorq.c:78 "disable interleaving" */
+  if (flags & NANORQ_EXT_SUBBLOCKS) {
+    N = N16 ? N16 : 1;
+    if (N > T / Al) return NULL; /* a sub-symbol is at least Al bytes (RFC 6330 section 4.4.1.2) */
+  }
+  if ((flags & NANORQ_EXT_RFC_OTI) && (Z > 255 || T > 0xffff)) return NULL;
   nanorq *rq = calloc(1, sizeof(nanorq));
   if (!rq) return NULL;
-  rq->F = len; rq->T = T; rq->Al = Al; rq->Z = Z; rq->N = 1; rq->Kt = Kt;
+  rq->F = len; rq->T = T; rq->Al = Al; rq->Z = Z; rq->N = N; rq->Kt = Kt; rq->flags = flags;
   rq->src_part = partition(Kt, Z);
   rq->sub_part = partition(T / Al, rq->N);
   if (!set_block_params(rq)) { free(rq); return NULL; }
   return rq;
 }
-
+nanorq *nanorq_encoder_new_ex(size_t len, uint16_t T, uint16_t K, uint16_t Z, uint8_t Al) {
+  return nanorq_encoder_new_ext(len, T, K, Z, 1, Al, 0);
+}
 nanorq *nanorq_encoder_new(size_t len, uint16_t T, uint8_t Al) { return nanorq_encoder_new_ex(len, T, 0, 0, Al); }
 
-nanorq *nanorq_decoder_new(uint64_t common, uint32_t specific) { /* nanorq.c:336-377 */
+nanorq *nanorq_decoder_new_ext(uint64_t common, uint32_t specific, uint32_t flags) { /* nanorq.c:336-377 */
   uint64_t F = common >> 24;
-  size_t T = (size_t)((common & 0xffff) + 1) & 0xffff; /* 16-bit wrap as in the reference */
+  size_t T, Z, N, Al = specific & 0xff;
+  if (flags & NANORQ_EXT_RFC_OTI) {
+    T = (size_t)(common & 0xffff);
+    Z = (specific >> 24) & 0xff;
+    N = (specific >> 8) & 0xffff;
+  } else {
+    T = (size_t)((common & 0xffff) + 1) & 0xffff; /* 16-bit wrap as in the reference */
+    Z = ((specific >> 24) & 0xff) + 1;
+    N = ((specific >> 8) & 0xffff) + 1;
+  }
   if (F > NANORQ_MAX_TRANSFER) return NULL;
-  size_t Z = ((specific >> 24) & 0xff) + 1, N = ((specific >> 8) & 0xffff) + 1, Al = specific & 0xff;
-  if (T == 0 || Al == 0 || T < Al || T % Al != 0) return NULL;
+  if (T == 0 || Z == 0 || N == 0 || Al == 0 || T < Al || T % Al != 0) return NULL;
+  if (!(flags & NANORQ_EXT_SUBBLOCKS) && (flags & NANORQ_EXT_RFC_OTI) && N != 1) return NULL;
+  if (N > T / Al) return NULL;
   size_t Kt = ceil_div(F, T);
   if (ceil_div(Kt, Z) > NRQ_K_MAX) return NULL;
   nanorq *rq = calloc(1, sizeof(nanorq));
   if (!rq) return NULL;
-  rq->F = F; rq->T = T; rq->Al = Al; rq->Z = Z; rq->N = N; rq->Kt = Kt;
+  rq->F = F; rq->T = T; rq->Al = Al; rq->Z = Z; rq->N = N; rq->Kt = Kt; rq->flags = flags;
   rq->src_part = partition(Kt, Z);
   rq->sub_part = partition(T / Al, N);
   if (!set_block_params(rq)) { free(rq); return NULL; }
   rq->max_esi = 2 * rq->Kp;
   return rq;
 }
+nanorq *nanorq_decoder_new(uint64_t common, uint32_t specific) { return nanorq_decoder_new_ext(common, specific, 0); }
 
 bool nanorq_set_max_esi(nanorq *rq, uint32_t max_esi) { /* nanorq.c:471-476 */
   if (!rq || max_esi >= (1u << 24) || max_esi < rq->Kp) return false;
@@ -199,31 +281,48 @@ static struct blockst *get_block(nanorq *rq, uint8_t sbn) { /* nanorq.c:130-146 
   struct blockst *b = calloc(1, sizeof(*b));
   if (!b) return NULL;
   b->K = (uint32_t)nanorq_block_symbols(rq, sbn);
+  b->Kp = rq->Kp;
+  b->L = rq->L;
+  if ((rq->flags & NANORQ_EXT_PER_BLOCK_KP) && b->K) {
+    uint32_t pr[10];
+    if (nrq_params(b->K, pr) == 0) { b->Kp = pr[0]; b->L = pr[5]; }
+  }
   if (rq->max_esi) {
     b->mask_words = rq->max_esi / 32 + 1;
     b->mask = calloc(b->mask_words, sizeof(uint32_t));
     b->spare = rq->max_esi - b->K;
+    if (!b->mask) { free(b); return NULL; }
   }
-  b->src = calloc((size_t)(b->K ? b->K : 1) * rq->T, 1);
-  if (!b->src || (rq->max_esi && !b->mask)) { free(b->src); free(b->mask); free(b); return NULL; }
   rq->blocks[sbn] = b;
   return b;
+}
+/* the host rows of a block (zeroed), allocated when first needed: device-resident blocks never need them */
+static bool ensure_src(nanorq *rq, struct blockst *b) {
+  if (b->src) return true;
+  b->src = host_alloc((size_t)(b->K ? b->K : 1) * rq->T, &b->src_pinned);
+  return b->src != NULL;
 }
 
 static void drop_device(struct blockst *b) {
   nrq_ctx *c = g_ctx;
   if (c) {
+    gpu_lock();
     if (b->d_src) nrq_dev_free(c, b->d_src);
     if (b->d_inter) nrq_dev_free(c, b->d_inter);
+    if (b->d_rep) nrq_dev_free(c, b->d_rep);
+    gpu_unlock();
   }
-  b->d_src = b->d_inter = NULL;
+  b->d_src = b->d_inter = b->d_rep = NULL;
+  b->d_rep_cap = 0;
 }
 
 void nanorq_encoder_cleanup(nanorq *rq, uint8_t sbn) { /* nanorq.c:437-451 */
   struct blockst *b = rq->blocks[sbn];
   if (!b) return;
   drop_device(b);
-  free(b->src); free(b->mask); free(b->rep_esi); free(b->rep_data); free(b->win); free(b);
+  host_free(b->src, b->src_pinned);
+  host_free(b->rep_data, b->rep_pinned);
+  free(b->mask); free(b->rep_esi); free(b->win); free(b);
   rq->blocks[sbn] = NULL;
 }
 
@@ -231,9 +330,11 @@ void nanorq_encoder_reset(nanorq *rq, uint8_t sbn) { /* nanorq.c:453-469 */
   struct blockst *b = rq->blocks[sbn];
   if (!b) return;
   b->loaded = b->inverted = false;
-  memset(b->src, 0, (size_t)(b->K ? b->K : 1) * rq->T);
+  if (b->src) memset(b->src, 0, (size_t)(b->K ? b->K : 1) * rq->T);
   b->nrep = 0;
   b->win_n = 0;
+  b->have = 0;
+  b->dev = b->dirty = false;
   if (b->mask) memset(b->mask, 0, b->mask_words * sizeof(uint32_t));
 }
 
@@ -272,25 +373,33 @@ static size_t transfer_symbol(nanorq *rq, uint8_t sbn, uint32_t esi, uint32_t K,
     size_t stride = sublen * rq->Al;
     if (sublen == 0) break;
     i += sublen;
-    if (offset >= rq->F) continue;
+    if (offset >= rq->F) { col += stride; continue; } /* (the piece lies beyond the object: skip it, keep the column) */
     if (io->seek(io, offset)) {
       if (offset + stride >= rq->F) stride = rq->F - offset;
       moved += out ? io->write(io, ptr + col, stride) : io->read(io, ptr + col, stride);
-      col += stride;
     }
+    col += sublen * rq->Al;
   }
   return moved;
 }
 
+/* [off, off + len) of the object = the rows of block sbn, when they are one stretch (N == 1); bytes beyond F cut off */
+static bool block_extent(const nanorq *rq, uint8_t sbn, uint32_t K, size_t *off, size_t *len) {
+  if (rq->N != 1) return false;
+  *off = symbol_offset(rq, sbn, 0, K, 0) * rq->Al;
+  const size_t want = (size_t)K * rq->T;
+  *len = *off >= rq->F ? 0 : (*off + want > rq->F ? rq->F - *off : want);
+  return true;
+}
+
 static bool load_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct ioctx *io) { /* nanorq.c:175-182 */
-  if (!io) return false;
+  if (!io || !ensure_src(rq, b)) return false;
   memset(b->src, 0, (size_t)(b->K ? b->K : 1) * rq->T);
-  if (rq->N == 1) {
+  size_t off, len;
+  if (block_extent(rq, sbn, b->K, &off, &len)) {
     /* no sub-blocking (the only case nanorq creates, nanorq.c:78): the block's symbols are one contiguous stretch
      * of the object -- one seek and one read instead of K of each; bytes beyond F stay zero */
-    const size_t off = symbol_offset(rq, sbn, 0, b->K, 0) * rq->Al, want = (size_t)b->K * rq->T;
-    if (off < rq->F && io->seek(io, off)) {
-      const size_t len = off + want > rq->F ? rq->F - off : want;
+    if (len && io->seek(io, off)) {
       size_t got = 0;
       while (got < len) {
         const size_t n = io->read(io, b->src + got, len - got);
@@ -309,9 +418,11 @@ bool nanorq_precalculate(nanorq *rq) { /* nanorq.c:393-401 */
   nrq_ctx *c = ctx();
   size_t k0 = nanorq_block_symbols(rq, 0);
   if (!c || k0 == 0) return false;
-  if (nrq_precalculate(c, (uint32_t)k0, rq->Kp) != 0) return false;
-  rq->precalc = true;
-  return true;
+  gpu_lock();
+  const bool ok = nrq_precalculate(c, (uint32_t)k0, rq->Kp) == 0;
+  gpu_unlock();
+  if (ok) rq->precalc = true;
+  return ok;
 }
 
 bool nanorq_generate_symbols(nanorq *rq, uint8_t sbn, struct ioctx *io) { /* nanorq.c:206-232 */
@@ -323,16 +434,19 @@ bool nanorq_generate_symbols(nanorq *rq, uint8_t sbn, struct ioctx *io) { /* nan
   nrq_ctx *c = ctx();
   if (!c) return false; /* no GPU: no solve */
   const size_t T = rq->T, bytes = (size_t)b->K * T;
+  bool ok = false;
+  gpu_lock();
   /* every block of an object is coded with block 0's K' (nanorq.c:289); a short block just has more padding */
-  if (!b->d_src && nrq_dev_alloc(c, bytes, &b->d_src) != 0) return false;
-  if (!b->d_inter && nrq_dev_alloc(c, (size_t)rq->L * T, &b->d_inter) != 0) return false;
-  if (nrq_dev_upload(c, b->d_src, b->src, bytes) != 0) return false;
-  if (nrq_encode_blocks(c, b->K, rq->Kp, (uint32_t)T, 1, b->d_src, bytes, b->d_inter, (size_t)rq->L * T, 0, NULL, NULL, 0) != 0)
-    return false;
-  if (nrq_ctx_sync(c) != 0) return false;
-  b->win_n = 0;
-  b->inverted = true;
-  return true;
+  if (!b->d_src && nrq_dev_alloc(c, bytes, &b->d_src) != 0) goto out;
+  if (!b->d_inter && nrq_dev_alloc(c, (size_t)b->L * T, &b->d_inter) != 0) goto out;
+  if (nrq_dev_upload_async(c, b->d_src, b->src, bytes) != 0) goto out;
+  if (nrq_encode_blocks(c, b->K, b->Kp, (uint32_t)T, 1, b->d_src, bytes, b->d_inter, (size_t)b->L * T, 0, NULL, NULL, 0) != 0) goto out;
+  if (nrq_ctx_sync(c) != 0) goto out;
+  ok = true;
+out:
+  gpu_unlock();
+  if (ok) { b->win_n = 0; b->inverted = true; }
+  return ok;
 }
 
 /* repair symbol with internal id `isi` through a window of device-generated symbols */
@@ -345,10 +459,12 @@ static bool fetch_symbol(nanorq *rq, struct blockst *b, uint32_t isi, uint8_t *o
     uint32_t isis[ENC_WINDOW], n = ENC_WINDOW;
     for (uint32_t k = 0; k < n; k++) isis[k] = isi + k;
     void *d_out = NULL;
-    if (nrq_dev_alloc(c, (size_t)n * T, &d_out) != 0) return false;
-    bool ok = nrq_gen_symbols(c, b->K, rq->Kp, (uint32_t)T, 1, b->d_inter, (size_t)rq->L * T, n, isis, d_out, (size_t)n * T) == 0 &&
+    gpu_lock();
+    bool ok = nrq_dev_alloc(c, (size_t)n * T, &d_out) == 0 &&
+              nrq_gen_symbols(c, b->K, b->Kp, (uint32_t)T, 1, b->d_inter, (size_t)b->L * T, n, isis, d_out, (size_t)n * T) == 0 &&
               nrq_dev_download(c, b->win, d_out, (size_t)n * T) == 0;
-    nrq_dev_free(c, d_out);
+    if (d_out) nrq_dev_free(c, d_out);
+    gpu_unlock();
     if (!ok) return false;
     b->win_isi0 = isi;
     b->win_n = n;
@@ -363,19 +479,51 @@ size_t nanorq_encode(nanorq *rq, void *data, uint32_t esi, uint8_t sbn, struct i
   const size_t T = rq->T;
   if (esi < b->K) {
     /* before the solve: the source symbol itself; after it the reference regenerates the same bytes from
-     * the intermediate symbols (RFC 6330 is systematic) -- either way the loaded source row */
-    if (!b->inverted && !b->loaded) b->loaded = load_block(rq, sbn, b, io);
-    if (!b->inverted && !b->loaded) return 0;
+     * the intermediate symbols (RFC 6330 is systematic) -- either way the loaded source row (a block that was
+     * solved straight out of a page-locked context is read here on first use) */
+    if (!b->loaded) b->loaded = load_block(rq, sbn, b, io);
+    if (!b->loaded) return 0;
     memcpy(data, b->src + (size_t)esi * T, T);
     return T;
   }
   if (esi > (1u << 24) - 1) return 0;
   if (!b->inverted) b->inverted = nanorq_generate_symbols(rq, sbn, io);
   if (!b->inverted) return 0;
-  return fetch_symbol(rq, b, esi + (rq->Kp - b->K), data) ? T : 0;
+  return fetch_symbol(rq, b, esi + (b->Kp - b->K), data) ? T : 0;
 }
 
 /* ------------------------------------------------------------------------- decoding ---- */
+static bool rep_reserve_host(nanorq *rq, struct blockst *b) { /* room for one more repair symbol (esi list + host bytes) */
+  if (b->nrep < b->rep_cap) return true;
+  const size_t nc = b->rep_cap ? b->rep_cap * 2 : 64, T = rq->T;
+  uint32_t *e = realloc(b->rep_esi, nc * sizeof(uint32_t));
+  if (!e) return false;
+  b->rep_esi = e;
+  if (!b->dev) {
+    bool pin = false;
+    uint8_t *d = host_alloc(nc * T, &pin);
+    if (!d) return false;
+    if (b->rep_data) memcpy(d, b->rep_data, b->nrep * T);
+    host_free(b->rep_data, b->rep_pinned);
+    b->rep_data = d;
+    b->rep_pinned = pin;
+  }
+  b->rep_cap = nc;
+  return true;
+}
+
+/* one symbol of a device-resident block arriving through the per-symbol call: straight to its device row */
+static bool dev_put_row(nanorq *rq, struct blockst *b, void *d_row, const void *data) {
+  nrq_ctx *c = ctx();
+  (void)b;
+  if (!c) return false;
+  gpu_lock();
+  const bool ok = nrq_copy_on(c, 1, d_row, data, rq->T) == 0 && nrq_stream_sync(c, 1) == 0;
+  gpu_unlock();
+  return ok;
+}
+static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, void **old_out); /* (below) */
+
 int nanorq_decoder_add_symbol(nanorq *rq, void *data, uint32_t tag, struct ioctx *io) { /* nanorq.c:478-509 */
   uint8_t sbn = (uint8_t)(tag >> 24);
   uint32_t esi = tag & 0x00ffffffu;
@@ -385,21 +533,25 @@ int nanorq_decoder_add_symbol(nanorq *rq, void *data, uint32_t tag, struct ioctx
   if (mask_get(b, esi)) return NANORQ_SYM_DUP;
   const size_t T = rq->T;
   if (esi < b->K) {
-    memcpy(b->src + (size_t)esi * T, data, T);
+    if (b->dev) {
+      if (!dev_put_row(rq, b, (uint8_t *)b->d_src + (size_t)esi * T, data)) return NANORQ_SYM_ERR;
+    } else {
+      if (!ensure_src(rq, b)) return NANORQ_SYM_ERR;
+      memcpy(b->src + (size_t)esi * T, data, T);
+    }
     if (io) transfer_symbol(rq, sbn, esi, b->K, data, io, 1);
   } else {
-    if (b->nrep == b->rep_cap) {
-      size_t nc = b->rep_cap ? b->rep_cap * 2 : 64;
-      uint32_t *e = realloc(b->rep_esi, nc * sizeof(uint32_t));
-      if (!e) return NANORQ_SYM_ERR;
-      b->rep_esi = e;
-      uint8_t *d = realloc(b->rep_data, nc * T);
-      if (!d) return NANORQ_SYM_ERR;
-      b->rep_data = d;
-      b->rep_cap = nc;
+    if (!rep_reserve_host(rq, b)) return NANORQ_SYM_ERR;
+    if (b->dev) {
+      void *old = NULL;
+      if (!dev_rep_reserve(rq, b, b->nrep + 1, &old)) return NANORQ_SYM_ERR;
+      const bool ok = dev_put_row(rq, b, (uint8_t *)b->d_rep + b->nrep * T, data); /* (waits for the upload stream: `old` is idle then) */
+      if (old) { gpu_lock(); nrq_dev_free(ctx(), old); gpu_unlock(); }
+      if (!ok) return NANORQ_SYM_ERR;
+    } else {
+      memcpy(b->rep_data + b->nrep * T, data, T);
     }
     b->rep_esi[b->nrep] = esi;
-    memcpy(b->rep_data + b->nrep * T, data, T);
     b->nrep++;
   }
   mask_set(b, esi);
@@ -415,34 +567,103 @@ size_t nanorq_num_repair(nanorq *rq, uint8_t sbn) {
   return b ? b->nrep : 0;
 }
 
+/* the missing source ESIs of a block, ascending; returns their number */
+static uint32_t list_lost(const struct blockst *b, uint32_t *lost) {
+  uint32_t g = 0;
+  for (uint32_t w = 0; w * 32u < b->K; w++) {
+    uint32_t miss = ~(w < b->mask_words ? b->mask[w] : 0u);
+    if ((w + 1) * 32u > b->K) miss &= (b->K % 32u) ? ((1u << (b->K % 32u)) - 1u) : 0xFFFFFFFFu;
+    while (miss) {
+      const uint32_t bit = (uint32_t)__builtin_ctz(miss);
+      miss &= miss - 1u;
+      lost[g++] = w * 32u + bit;
+    }
+  }
+  return g;
+}
+/* Repair symbols handed to the solver up front: the gaps plus a couple; the rest stays in reserve and is taken one at a
+ * time only if the system turns out rank deficient (nrq_decode_blocks_lazy).  The reference makes every received
+ * repair symbol a constraint row (nanorq.c:527-565: overhead = num_repair - num_gaps); the verdict is the same --
+ * rows beyond rank L add nothing -- but M = L + overhead stays small: cheaper plans, and within the 16-bit slot range
+ * of the planners however many surplus symbols a receiver has collected. */
+static uint32_t rep_upfront(size_t gaps, size_t nrep) { return (uint32_t)(nrep - gaps > 2 ? gaps + 2 : nrep); }
+
+/* write the rows of a device-resident block that the output context has not seen: all of them when the block is
+ * complete (`all`), otherwise the runs of received rows only.  Enqueues on the download stream when `io` is a
+ * page-locked context (the caller waits), else goes through the block's host rows. */
+static bool flush_dev_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct ioctx *io, bool all) {
+  nrq_ctx *c = ctx();
+  if (!c || !io || !b->d_src) return false;
+  const size_t T = rq->T;
+  uint8_t *base;
+  size_t rlen, off, len;
+  const bool dma = ioctx_dma_region(io, &base, &rlen) && block_extent(rq, sbn, b->K, &off, &len) && off + len <= rlen;
+  if (!dma) {
+    if (!ensure_src(rq, b) || nrq_copy_on(c, 2, b->src, b->d_src, (size_t)b->K * T) != 0 || nrq_stream_sync(c, 2) != 0) return false;
+    for (uint32_t e = 0; e < b->K; e++)
+      if (all || mask_get(b, e)) transfer_symbol(rq, sbn, e, b->K, b->src + (size_t)e * T, io, 1);
+    return true;
+  }
+  if (all) return nrq_copy_on(c, 2, base + off, b->d_src, len) == 0;
+  for (uint32_t e = 0; e < b->K;) { /* runs of received rows */
+    if (!mask_get(b, e)) { e++; continue; }
+    uint32_t e1 = e;
+    while (e1 < b->K && mask_get(b, e1)) e1++;
+    const size_t o = (size_t)e * T, n0 = (size_t)(e1 - e) * T, n = o >= len ? 0 : (o + n0 > len ? len - o : n0);
+    if (n && nrq_copy_on(c, 2, base + off + o, (uint8_t *)b->d_src + o, n) != 0) return false;
+    e = e1;
+  }
+  return true;
+}
+
 bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.c:591-631 */
   struct blockst *b = get_block(rq, sbn);
   if (!b) return false;
   const size_t gaps = mask_gaps(b, b->K);
-  if (gaps == 0) return true;
+  nrq_ctx *c = ctx();
+  if (gaps == 0) {
+    if (b->dev && b->dirty && io && c) { /* received through the page-locked path and not written yet */
+      gpu_lock();
+      if (flush_dev_block(rq, sbn, b, io, true) && nrq_stream_sync(c, 2) == 0) b->dirty = false;
+      gpu_unlock();
+    }
+    return true;
+  }
   if (b->nrep < gaps) return false;
   const size_t overhead = b->nrep - gaps;
   if (overhead > b->spare) return false; /* D.rows < L + overhead in the reference */
-  nrq_ctx *c = ctx();
   if (!c) return false;
   const size_t T = rq->T, bytes = (size_t)b->K * T;
   uint32_t *lost = malloc(gaps * sizeof(uint32_t));
   if (!lost) return false;
-  size_t g = 0;
-  for (uint32_t e = 0; e < b->K; e++)
-    if (!mask_get(b, e)) lost[g++] = e;
+  list_lost(b, lost);
   bool ok = false;
   void *d_rep = NULL;
-  uint32_t nlost = (uint32_t)gaps, nrep = (uint32_t)b->nrep;
+  uint32_t nlost = (uint32_t)gaps, nuse = rep_upfront(gaps, b->nrep), navail = (uint32_t)b->nrep, used = 0;
   int status = 0;
+  gpu_lock();
+  if (b->dev) {
+    const uint64_t sv = (uint64_t)(uintptr_t)b->d_src, rv = (uint64_t)(uintptr_t)b->d_rep;
+    if (nrq_decode_blocks_v(c, b->K, b->Kp, (uint32_t)T, 1, &sv, lost, &nlost, nlost, b->rep_esi, &nuse, &navail, navail, &rv, &status, &used) != 0) goto out;
+    if (!status) goto out;
+    for (size_t k = 0; k < gaps; k++) mask_set(b, lost[k]);
+    if (nrq_ctx_sync(c) != 0) goto out; /* the recovered rows are in d_src */
+    if (io) {
+      if (!flush_dev_block(rq, sbn, b, io, true) || nrq_stream_sync(c, 2) != 0) goto out;
+      b->dirty = false;
+    }
+    ok = true;
+    goto out;
+  }
+  if (!ensure_src(rq, b)) goto out;
   if (!b->d_src && nrq_dev_alloc(c, bytes, &b->d_src) != 0) goto out;
   if (nrq_dev_alloc(c, b->nrep * T, &d_rep) != 0) goto out;
-  if (nrq_dev_upload(c, b->d_src, b->src, bytes) != 0) goto out;
-  if (nrq_dev_upload(c, d_rep, b->rep_data, b->nrep * T) != 0) goto out;
-  if (nrq_decode_blocks(c, b->K, rq->Kp, (uint32_t)T, 1, b->d_src, bytes, lost, &nlost, nlost, b->rep_esi, &nrep, nrep, d_rep,
-                        b->nrep * T, NULL, 0, &status) != 0)
+  if (nrq_dev_upload_async(c, b->d_src, b->src, bytes) != 0) goto out;
+  if (nrq_dev_upload_async(c, d_rep, b->rep_data, b->nrep * T) != 0) goto out;
+  if (nrq_decode_blocks_lazy(c, b->K, b->Kp, (uint32_t)T, 1, b->d_src, bytes, lost, &nlost, nlost, b->rep_esi, &nuse, &navail, navail, d_rep,
+                             b->nrep * T, NULL, 0, &status, &used) != 0)
     goto out;
-  if (!status) goto out; /* rank deficient: retry after more symbols (nanorq.c:620-623) */
+  if (!status) { nrq_ctx_sync(c); goto out; } /* rank deficient: retry after more symbols (nanorq.c:620-623) */
   if (nrq_dev_download(c, b->src, b->d_src, bytes) != 0) goto out;
   for (size_t k = 0; k < gaps; k++) { /* write_repair_rows, nanorq.c:579-589 */
     if (io) transfer_symbol(rq, sbn, lost[k], b->K, b->src + (size_t)lost[k] * T, io, 1);
@@ -450,7 +671,8 @@ bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.
   }
   ok = mask_gaps(b, b->K) == 0;
 out:
-  if (d_rep) nrq_dev_free(c, d_rep);
+  if (d_rep) { nrq_ctx_sync(c); nrq_dev_free(c, d_rep); }
+  gpu_unlock();
   free(lost);
   return ok;
 }
@@ -459,45 +681,97 @@ out:
 /* blocks come in at most two sizes (RFC 6330 section 4.4.1.2 partition: JL blocks of IL symbols, JS of IS) */
 static uint32_t class_of(nanorq *rq, unsigned sbn) { return sbn < rq->src_part.JL ? 0u : 1u; }
 
+void *nanorq_pinned_alloc(size_t bytes) {
+  void *p = NULL;
+  if (!ctx() || nrq_host_alloc_pinned(bytes, &p) != 0) return NULL;
+  return p;
+}
+void nanorq_pinned_free(void *p) { nrq_host_free_pinned(p); }
+
+/* Encoder, all blocks: a pipeline of chunks of blocks -- chunk n+1 goes up (upload stream; straight out of a page-locked
+ * context, or out of the blocks' page-locked host rows) while chunk n is solved (the context's stream).  Every block
+ * keeps its intermediate symbols on the device, like after nanorq_generate_symbols. */
 size_t nanorq_generate_symbols_all(nanorq *rq, struct ioctx *io) {
   nrq_ctx *c = ctx();
   const size_t Z = nanorq_blocks(rq), T = rq->T;
   if (!c || !io) return 0;
+  uint8_t *base = NULL;
+  size_t rlen = 0;
+  const bool dma = ioctx_dma_region(io, &base, &rlen) && rq->N == 1 && rlen >= rq->F;
+  gpu_lock();
   for (uint32_t cls = 0; cls < 2; cls++) {
     /* the blocks of this size that still need the solve */
     unsigned todo[NRQ_Z_MAX], n = 0;
-    uint32_t K = 0;
+    uint32_t K = 0, Kp = 0, L = 0;
     for (unsigned sbn = 0; sbn < Z; sbn++) {
       if (class_of(rq, sbn) != cls) continue;
       struct blockst *b = get_block(rq, (uint8_t)sbn);
       if (!b || b->K == 0 || b->inverted) continue;
-      if (!b->loaded) b->loaded = load_block(rq, (uint8_t)sbn, b, io);
-      if (!b->loaded) continue;
-      K = b->K;
+      if (!dma && !b->loaded) b->loaded = load_block(rq, (uint8_t)sbn, b, io);
+      if (!dma && !b->loaded) continue;
+      K = b->K; Kp = b->Kp; L = b->L;
       todo[n++] = sbn;
     }
     if (!n) continue;
-    const size_t sbytes = (size_t)K * T, ibytes = (size_t)rq->L * T;
-    void *d_src = NULL, *d_inter = NULL;
-    if (nrq_dev_alloc(c, sbytes * n, &d_src) != 0) continue;
-    if (nrq_dev_alloc(c, ibytes * n, &d_inter) != 0) { nrq_dev_free(c, d_src); continue; }
+    const size_t sbytes = (size_t)K * T, ibytes = (size_t)L * T;
+    unsigned C = (unsigned)(CHUNK_BYTES / sbytes);
+    if (C < 1) C = 1;
+    if (C > n) C = n;
+    void *dsrc[2] = {NULL, NULL}, *up_done[2] = {NULL, NULL}, *solved[2] = {NULL, NULL};
     bool ok = true;
-    for (unsigned k = 0; k < n && ok; k++)
-      ok = nrq_dev_upload_async(c, (uint8_t *)d_src + sbytes * k, rq->blocks[todo[k]]->src, sbytes) == 0;
-    ok = ok && nrq_encode_blocks(c, K, rq->Kp, (uint32_t)T, n, d_src, sbytes, d_inter, ibytes, 0, NULL, NULL, 0) == 0 &&
-         nrq_ctx_sync(c) == 0;
-    /* every block keeps its own intermediate symbols on the device, like after nanorq_generate_symbols */
-    for (unsigned k = 0; k < n && ok; k++) {
+    for (int i = 0; i < 2 && ok; i++)
+      ok = nrq_dev_alloc(c, sbytes * C, &dsrc[i]) == 0 && nrq_event_new(c, &up_done[i]) == 0 && nrq_event_new(c, &solved[i]) == 0;
+    unsigned done_blocks = 0;
+    for (unsigned c0 = 0, step = 0; c0 < n && ok; c0 += C, step++) {
+      const int i = (int)(step & 1u);
+      const unsigned m = n - c0 < C ? n - c0 : C;
+      if (step >= 2) ok = nrq_stream_wait(c, 1, solved[i]) == 0; /* the solve that read this buffer two steps ago */
+      for (unsigned k = 0; k < m && ok;) {
+        struct blockst *b = rq->blocks[todo[c0 + k]];
+        uint8_t *dst = (uint8_t *)dsrc[i] + sbytes * k;
+        if (dma) {
+          /* consecutive blocks of a class are consecutive in the object: one copy for the run */
+          size_t off = 0, len = 0, run = 1, tot;
+          block_extent(rq, (uint8_t)todo[c0 + k], K, &off, &len);
+          tot = len;
+          while (k + run < m && todo[c0 + k + run] == todo[c0 + k] + run && tot == run * sbytes) {
+            size_t o2 = 0, l2 = 0;
+            block_extent(rq, (uint8_t)todo[c0 + k + run], K, &o2, &l2);
+            tot += l2;
+            run++;
+          }
+          ok = nrq_copy_on(c, 1, dst, base + off, tot) == 0;
+          if (ok && tot < run * sbytes) ok = nrq_memset_on(c, 1, dst + tot, 0, run * sbytes - tot) == 0; /* padding beyond F */
+          k += (unsigned)run;
+        } else {
+          ok = nrq_copy_on(c, 1, dst, b->src, sbytes) == 0;
+          k++;
+        }
+      }
+      uint64_t iv[NRQ_Z_MAX];
+      for (unsigned k = 0; k < m && ok; k++) {
+        struct blockst *b = rq->blocks[todo[c0 + k]];
+        if (!b->d_inter) ok = nrq_dev_alloc(c, ibytes, &b->d_inter) == 0;
+        iv[k] = (uint64_t)(uintptr_t)b->d_inter;
+      }
+      ok = ok && nrq_event_record(c, up_done[i], 1) == 0 && nrq_stream_wait(c, 0, up_done[i]) == 0 &&
+           nrq_encode_blocks_v(c, K, Kp, (uint32_t)T, m, dsrc[i], sbytes, iv) == 0 && nrq_event_record(c, solved[i], 0) == 0;
+      if (ok) done_blocks = c0 + m;
+    }
+    ok = nrq_ctx_sync(c) == 0 && ok;
+    nrq_stream_sync(c, 1);
+    for (unsigned k = 0; k < done_blocks && ok; k++) {
       struct blockst *b = rq->blocks[todo[k]];
-      if (!b->d_inter && nrq_dev_alloc(c, ibytes, &b->d_inter) != 0) { ok = false; break; }
-      if (nrq_dev_copy(c, b->d_inter, (uint8_t *)d_inter + ibytes * k, ibytes) != 0) { ok = false; break; }
       b->win_n = 0;
       b->inverted = true;
     }
-    if (ok) ok = nrq_ctx_sync(c) == 0;
-    nrq_dev_free(c, d_src);
-    nrq_dev_free(c, d_inter);
+    for (int i = 0; i < 2; i++) {
+      if (dsrc[i]) nrq_dev_free(c, dsrc[i]);
+      nrq_event_free(up_done[i]);
+      nrq_event_free(solved[i]);
+    }
   }
+  gpu_unlock();
   size_t done = 0;
   for (unsigned sbn = 0; sbn < Z; sbn++)
     if (rq->blocks[sbn] && rq->blocks[sbn]->inverted) done++;
@@ -522,85 +796,230 @@ size_t nanorq_encode_range(nanorq *rq, void *data, uint32_t esi0, uint32_t n, ui
   /* repair symbols: generated on the device in one go, one download */
   uint32_t *isis = malloc((size_t)left * sizeof(uint32_t));
   void *d_out = NULL;
+  gpu_lock();
   bool ok = isis && nrq_dev_alloc(c, (size_t)left * T, &d_out) == 0;
   if (ok) {
-    for (uint32_t k = 0; k < left; k++) isis[k] = esi + k + (rq->Kp - b->K);
-    ok = nrq_gen_symbols(c, b->K, rq->Kp, (uint32_t)T, 1, b->d_inter, (size_t)rq->L * T, left, isis, d_out, (size_t)left * T) == 0 &&
+    for (uint32_t k = 0; k < left; k++) isis[k] = esi + k + (b->Kp - b->K);
+    ok = nrq_gen_symbols(c, b->K, b->Kp, (uint32_t)T, 1, b->d_inter, (size_t)b->L * T, left, isis, d_out, (size_t)left * T) == 0 &&
          nrq_dev_download(c, out, d_out, (size_t)left * T) == 0;
   }
   if (d_out) nrq_dev_free(c, d_out);
+  gpu_unlock();
   free(isis);
   return ok ? (size_t)n * T : 0;
 }
 
+/* room for `need` repair symbols in a device-resident block's d_rep; an outgrown buffer is handed back through *old_out
+ * (the caller frees it once the copy out of it -- enqueued on the upload stream -- is done) */
+static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, void **old_out) {
+  nrq_ctx *c = ctx();
+  *old_out = NULL;
+  if (need <= b->d_rep_cap) return true;
+  size_t nc = b->d_rep_cap ? b->d_rep_cap * 2 : (b->K / 8 > 64 ? b->K / 8 : 64);
+  while (nc < need) nc *= 2;
+  void *p = NULL;
+  gpu_lock();
+  bool ok = nrq_dev_alloc(c, nc * rq->T, &p) == 0;
+  if (ok && b->d_rep && b->nrep) ok = nrq_copy_on(c, 1, p, b->d_rep, b->nrep * rq->T) == 0;
+  gpu_unlock();
+  if (!ok) return false;
+  *old_out = b->d_rep;
+  b->d_rep = p;
+  b->d_rep_cap = nc;
+  return true;
+}
+
+/* Decoder, many symbols.  With a page-locked packet buffer (and a page-locked or no output context, no sub-blocking)
+ * the packets go to the GPU in one DMA copy and a kernel sorts them into their rows (nrq_scatter_symbols); the host
+ * does the bookkeeping of nanorq_decoder_add_symbol (nanorq.c:478-509) and touches no symbol byte.  Otherwise: the
+ * per-symbol call in a loop. */
 size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io) {
   size_t added = 0;
   const uint8_t *p = data;
+  const size_t T = rq->T;
+  nrq_ctx *c = ctx();
+  uint8_t *obase;
+  size_t olen;
+  const bool dma = c && n >= 16 && rq->N == 1 && nrq_host_is_pinned(data) && (!io || (ioctx_dma_region(io, &obase, &olen) && olen >= rq->F));
+  uint64_t *dst = dma ? calloc(n, sizeof(uint64_t)) : NULL;
+  if (!dst) {
+    for (uint32_t k = 0; k < n; k++) {
+      /* (add_symbol copies; the const is cast away only because the per-symbol signature of the reference is void *) */
+      const int r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * T), tags[k], io);
+      if (results) results[k] = r;
+      if (r == NANORQ_SYM_ADDED) added++;
+    }
+    return added;
+  }
+  void *olds[NRQ_Z_MAX];
+  unsigned nold = 0;
+  uint32_t nput = 0;
+  gpu_lock();
   for (uint32_t k = 0; k < n; k++) {
-    /* (add_symbol copies; the const is cast away only because the per-symbol signature of the reference is void *) */
-    const int r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * rq->T), tags[k], io);
+    const uint8_t sbn = (uint8_t)(tags[k] >> 24);
+    const uint32_t esi = tags[k] & 0x00ffffffu;
+    struct blockst *b = get_block(rq, sbn);
+    int r = NANORQ_SYM_ADDED;
+    if (!b || esi > rq->max_esi) r = NANORQ_SYM_ERR;
+    else if (mask_gaps(b, b->K) == 0) r = NANORQ_SYM_IGN;
+    else if (mask_get(b, esi)) r = NANORQ_SYM_DUP;
+    else if (!b->dev && (b->have || b->nrep)) {
+      /* the block already holds symbols on the host (per-symbol calls came first): it stays host-resident */
+      r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * T), tags[k], io);
+    } else {
+      if (!b->dev) { /* first symbol of the block: it becomes device-resident */
+        if (nrq_dev_alloc(c, (size_t)b->K * T, &b->d_src) != 0 || nrq_memset_on(c, 1, b->d_src, 0, (size_t)b->K * T) != 0) r = NANORQ_SYM_ERR;
+        else b->dev = true;
+      }
+      if (r == NANORQ_SYM_ADDED && esi < b->K) {
+        dst[k] = (uint64_t)(uintptr_t)((uint8_t *)b->d_src + (size_t)esi * T);
+        b->dirty = true;
+      } else if (r == NANORQ_SYM_ADDED) {
+        void *old = NULL;
+        if (!rep_reserve_host(rq, b) || !dev_rep_reserve(rq, b, b->nrep + 1, &old)) r = NANORQ_SYM_ERR;
+        else {
+          if (old && nold < NRQ_Z_MAX) olds[nold++] = old;
+          else if (old) { nrq_stream_sync(c, 1); nrq_dev_free(c, old); }
+          dst[k] = (uint64_t)(uintptr_t)((uint8_t *)b->d_rep + b->nrep * T);
+          b->rep_esi[b->nrep++] = esi;
+        }
+      }
+      if (r == NANORQ_SYM_ADDED) { mask_set(b, esi); nput++; }
+    }
     if (results) results[k] = r;
     if (r == NANORQ_SYM_ADDED) added++;
   }
+  if (nput) {
+    /* packets up in pieces, each sorted into its rows as soon as it has landed (same stream: the order is the stream's) */
+    void *d_blob = NULL;
+    const uint32_t piece = (uint32_t)((CHUNK_BYTES / T) ? (CHUNK_BYTES / T) : 1);
+    bool ok = nrq_dev_alloc(c, (size_t)(n < piece ? n : piece) * T, &d_blob) == 0;
+    for (uint32_t k0 = 0; k0 < n && ok; k0 += piece) {
+      const uint32_t m = n - k0 < piece ? n - k0 : piece;
+      ok = nrq_copy_on(c, 1, d_blob, p + (size_t)k0 * T, (size_t)m * T) == 0 && nrq_scatter_symbols(c, 1, d_blob, m, (uint32_t)T, dst + k0) == 0;
+    }
+    ok = nrq_stream_sync(c, 1) == 0 && ok;
+    if (d_blob) nrq_dev_free(c, d_blob);
+    if (!ok) added = 0; /* the device state is unusable; nothing better to report through this signature */
+  } else {
+    nrq_stream_sync(c, 1);
+  }
+  for (unsigned i = 0; i < nold; i++) nrq_dev_free(c, olds[i]);
+  gpu_unlock();
+  free(dst);
   return added;
 }
 
+/* Decoder, all blocks that can be repaired: per block size a pipeline of chunks -- host-resident blocks go up chunk by
+ * chunk (upload stream), the chunk is decoded (the context's stream), the decoded blocks come down (download stream)
+ * beside the next chunk's decode; device-resident blocks skip the upload.  What comes down: whole blocks into a
+ * page-locked output context, else the blocks' host rows and the repaired symbols from there through the context. */
 size_t nanorq_repair_all(nanorq *rq, struct ioctx *io) {
   nrq_ctx *c = ctx();
   const size_t Z = nanorq_blocks(rq), T = rq->T;
   if (c) {
+    gpu_lock();
     for (uint32_t cls = 0; cls < 2; cls++) {
       unsigned todo[NRQ_Z_MAX], n = 0;
-      uint32_t K = 0;
+      uint32_t K = 0, Kp = 0;
       size_t lost_cap = 0, rep_cap = 0;
       for (unsigned sbn = 0; sbn < Z; sbn++) {
         if (class_of(rq, sbn) != cls) continue;
         struct blockst *b = rq->blocks[sbn];
         if (!b || b->K == 0) continue;
         const size_t gaps = mask_gaps(b, b->K);
-        if (gaps == 0 || b->nrep < gaps || b->nrep - gaps > b->spare) continue; /* as nanorq_repair_block */
-        K = b->K;
+        if (gaps == 0) { /* complete; a device-resident block may still owe the output its received symbols */
+          if (b->dev && b->dirty && io && flush_dev_block(rq, (uint8_t)sbn, b, io, true)) b->dirty = false; /* (the sync is at the end) */
+          continue;
+        }
+        if (b->nrep < gaps || b->nrep - gaps > b->spare) continue; /* as nanorq_repair_block */
+        K = b->K; Kp = b->Kp;
         if (gaps > lost_cap) lost_cap = gaps;
         if (b->nrep > rep_cap) rep_cap = b->nrep;
         todo[n++] = sbn;
       }
       if (!n) continue;
-      const size_t sbytes = (size_t)K * T, rbytes = rep_cap * T;
-      uint32_t *lost = calloc((size_t)n * lost_cap, sizeof(uint32_t)), *nlost = calloc(n, sizeof(uint32_t));
-      uint32_t *resi = calloc((size_t)n * rep_cap, sizeof(uint32_t)), *nrep = calloc(n, sizeof(uint32_t));
-      int *status = calloc(n, sizeof(int));
-      void *d_src = NULL, *d_rep = NULL;
-      bool ok = lost && nlost && resi && nrep && status && nrq_dev_alloc(c, sbytes * n, &d_src) == 0 &&
-                nrq_dev_alloc(c, rbytes * n, &d_rep) == 0;
-      for (unsigned k = 0; k < n && ok; k++) {
-        struct blockst *b = rq->blocks[todo[k]];
-        uint32_t g = 0;
-        for (uint32_t e = 0; e < b->K; e++)
-          if (!mask_get(b, e)) lost[(size_t)k * lost_cap + g++] = e;
-        nlost[k] = g;
-        nrep[k] = (uint32_t)b->nrep;
-        memcpy(resi + (size_t)k * rep_cap, b->rep_esi, b->nrep * sizeof(uint32_t));
-        ok = nrq_dev_upload_async(c, (uint8_t *)d_src + sbytes * k, b->src, sbytes) == 0 &&
-             nrq_dev_upload_async(c, (uint8_t *)d_rep + rbytes * k, b->rep_data, b->nrep * T) == 0;
-      }
-      ok = ok && nrq_decode_blocks(c, K, rq->Kp, (uint32_t)T, n, d_src, sbytes, lost, nlost, (uint32_t)lost_cap, resi, nrep,
-                                   (uint32_t)rep_cap, d_rep, rbytes, NULL, 0, status) == 0;
-      for (unsigned k = 0; k < n && ok; k++) /* the decoded blocks come back with one wait */
-        if (status[k]) ok = nrq_dev_download_async(c, rq->blocks[todo[k]]->src, (uint8_t *)d_src + sbytes * k, sbytes) == 0;
-      ok = ok && nrq_ctx_sync(c) == 0;
-      for (unsigned k = 0; k < n && ok; k++) {
-        if (!status[k]) continue; /* rank deficient: retry after more symbols (nanorq.c:620-623) */
-        struct blockst *b = rq->blocks[todo[k]];
-        for (uint32_t j = 0; j < nlost[k]; j++) {
-          const uint32_t e = lost[(size_t)k * lost_cap + j];
-          if (io) transfer_symbol(rq, (uint8_t)todo[k], e, b->K, b->src + (size_t)e * T, io, 1);
-          mask_set(b, e);
+      const size_t sbytes = (size_t)K * T;
+      /* chunks: each costs a planner launch the host waits for (~3 ms whatever the number of blocks) before its solve
+       * can go, and only the download of the chunk BEFORE runs beside it: few, big chunks (two to four) */
+      unsigned C = (unsigned)(REPAIR_CHUNK_BYTES / sbytes);
+      if (C < 1) C = 1;
+      if (C > n) C = n;
+      if (C == n && n >= 8 && (size_t)n * sbytes >= ((size_t)128 << 20)) C = (n + 1) / 2; /* at least two, so that something overlaps */
+      uint32_t *lost = calloc((size_t)C * lost_cap, sizeof(uint32_t)), *nlost = calloc(C, sizeof(uint32_t));
+      uint32_t *resi = calloc((size_t)C * rep_cap, sizeof(uint32_t)), *nuse = calloc(C, sizeof(uint32_t)), *navail = calloc(C, sizeof(uint32_t));
+      int *status = calloc(C, sizeof(int));
+      uint64_t *sv = calloc(C, sizeof(uint64_t)), *rv = calloc(C, sizeof(uint64_t));
+      void *ev_up = NULL, *ev_dec = NULL;
+      void *tmp_rep[NRQ_Z_MAX]; /* device copies of host-resident blocks' repair symbols (freed at the end) */
+      unsigned ntmp = 0;
+      bool ok = lost && nlost && resi && nuse && navail && status && sv && rv && nrq_event_new(c, &ev_up) == 0 && nrq_event_new(c, &ev_dec) == 0;
+      for (unsigned c0 = 0; c0 < n && ok; c0 += C) {
+        const unsigned m = n - c0 < C ? n - c0 : C;
+        bool any_up = false;
+        for (unsigned k = 0; k < m && ok; k++) {
+          struct blockst *b = rq->blocks[todo[c0 + k]];
+          nlost[k] = list_lost(b, lost + (size_t)k * lost_cap);
+          nuse[k] = rep_upfront(nlost[k], b->nrep);
+          navail[k] = (uint32_t)b->nrep;
+          memcpy(resi + (size_t)k * rep_cap, b->rep_esi, b->nrep * sizeof(uint32_t));
+          if (!b->dev) { /* host-resident: rows and repair symbols go up now */
+            void *d_rep = NULL;
+            ok = ensure_src(rq, b) && (b->d_src || nrq_dev_alloc(c, sbytes, &b->d_src) == 0) && nrq_dev_alloc(c, b->nrep * T, &d_rep) == 0 &&
+                 nrq_copy_on(c, 1, b->d_src, b->src, sbytes) == 0 && nrq_copy_on(c, 1, d_rep, b->rep_data, b->nrep * T) == 0;
+            if (d_rep) tmp_rep[ntmp++] = d_rep;
+            rv[k] = (uint64_t)(uintptr_t)d_rep;
+            any_up = true;
+          } else {
+            rv[k] = (uint64_t)(uintptr_t)b->d_rep;
+          }
+          sv[k] = (uint64_t)(uintptr_t)b->d_src;
+        }
+        if (any_up) ok = ok && nrq_event_record(c, ev_up, 1) == 0 && nrq_stream_wait(c, 0, ev_up) == 0;
+        ok = ok && nrq_decode_blocks_v(c, K, Kp, (uint32_t)T, m, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv,
+                                       status, NULL) == 0 &&
+             nrq_event_record(c, ev_dec, 0) == 0 && nrq_stream_wait(c, 2, ev_dec) == 0;
+        for (unsigned k = 0; k < m && ok; k++) { /* the decoded blocks come down beside the next chunk's decode */
+          struct blockst *b = rq->blocks[todo[c0 + k]];
+          const uint8_t sbn = (uint8_t)todo[c0 + k];
+          if (!status[k]) { /* rank deficient: retry after more symbols (nanorq.c:620-623); what was received is written */
+            if (b->dev && b->dirty && io && flush_dev_block(rq, sbn, b, io, false)) b->dirty = false;
+            continue;
+          }
+          if (b->dev) {
+            if (io) ok = flush_dev_block(rq, sbn, b, io, true);
+            for (uint32_t j = 0; j < nlost[k]; j++) mask_set(b, lost[(size_t)k * lost_cap + j]);
+            if (io && ok) b->dirty = false;
+          } else {
+            ok = nrq_copy_on(c, 2, b->src, b->d_src, sbytes) == 0;
+          }
+        }
+        /* host-resident blocks: their repaired symbols go through the context once the rows are down */
+        bool any_host = false;
+        for (unsigned k = 0; k < m; k++) any_host = any_host || (status[k] && !rq->blocks[todo[c0 + k]]->dev);
+        if (any_host && ok) {
+          ok = nrq_stream_sync(c, 2) == 0;
+          for (unsigned k = 0; k < m && ok; k++) {
+            struct blockst *b = rq->blocks[todo[c0 + k]];
+            if (!status[k] || b->dev) continue;
+            for (uint32_t j = 0; j < nlost[k]; j++) {
+              const uint32_t e = lost[(size_t)k * lost_cap + j];
+              if (io) transfer_symbol(rq, (uint8_t)todo[c0 + k], e, b->K, b->src + (size_t)e * T, io, 1);
+              mask_set(b, e);
+            }
+          }
         }
       }
-      if (d_src) nrq_dev_free(c, d_src);
-      if (d_rep) nrq_dev_free(c, d_rep);
-      free(lost); free(nlost); free(resi); free(nrep); free(status);
+      nrq_ctx_sync(c);
+      nrq_stream_sync(c, 1);
+      nrq_stream_sync(c, 2);
+      for (unsigned i = 0; i < ntmp; i++) nrq_dev_free(c, tmp_rep[i]);
+      nrq_event_free(ev_up);
+      nrq_event_free(ev_dec);
+      free(lost); free(nlost); free(resi); free(nuse); free(navail); free(status); free(sv); free(rv);
     }
+    nrq_stream_sync(c, 2);
+    gpu_unlock();
   }
   size_t complete = 0;
   for (unsigned sbn = 0; sbn < Z; sbn++) {
@@ -608,4 +1027,19 @@ size_t nanorq_repair_all(nanorq *rq, struct ioctx *io) {
     if (b && b->mask && mask_gaps(b, b->K) == 0) complete++;
   }
   return complete;
+}
+
+size_t nanorq_decoder_flush(nanorq *rq, struct ioctx *io) {
+  nrq_ctx *c = ctx();
+  if (!c || !io) return 0;
+  size_t nflushed = 0;
+  gpu_lock();
+  for (unsigned sbn = 0; sbn < NRQ_Z_MAX; sbn++) {
+    struct blockst *b = rq->blocks[sbn];
+    if (!b || !b->dev || !b->dirty) continue;
+    if (flush_dev_block(rq, (uint8_t)sbn, b, io, mask_gaps(b, b->K) == 0)) { b->dirty = false; nflushed++; }
+  }
+  nrq_stream_sync(c, 2);
+  gpu_unlock();
+  return nflushed;
 }

@@ -509,6 +509,23 @@ __global__ __launch_bounds__(256) void nrq_collect_kernel(const nrq_job *__restr
   }
 }
 
+/* Symbol ingestion on the device (nrq_scatter_symbols): symbol k of a contiguous packet buffer goes to the row its
+ * tag names -- dst[k] is the row's device address (0 = drop).  One workgroup per symbol. */
+__global__ __launch_bounds__(128) void nrq_scatter_kernel(const uint8_t *__restrict__ blob, uint32_t T, const uint64_t *__restrict__ dst,
+                                                          uint32_t n) {
+  const uint32_t k = blockIdx.x;
+  if (k >= n) return;
+  uint8_t *d = reinterpret_cast<uint8_t *>(dst[k]);
+  if (!d) return;
+  const uint8_t *s = blob + (size_t)k * T;
+  if ((T & 15u) == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
+    for (uint32_t off = threadIdx.x * 16u; off < T; off += 128u * 16u)
+      *reinterpret_cast<uint4 *>(d + off) = *reinterpret_cast<const uint4 *>(s + off);
+  } else {
+    for (uint32_t off = threadIdx.x; off < T; off += 128u) d[off] = s[off];
+  }
+}
+
 /* One workgroup per (symbol, block): out = XOR of the LT neighbours of `isi` among the L
  * intermediate symbols in HBM (coalesced 16-byte lanes along the symbol). */
 __global__ __launch_bounds__(NRQ_GEN_WG) void nrq_gen_kernel(rq_params p, uint32_t T, const uint8_t *__restrict__ inter,
@@ -660,6 +677,20 @@ struct nrq_ctx {
   DevBuf plan_work, plan_arena, plan_jobs;
   DevBuf stage; /* solve kernel: staging buffers of the persistent workgroups */
   DevBuf ybuf;  /* split solve of narrow strips: per block, (M + u) full-width rows (slot image + inactive columns) */
+  /* nrq_dev_alloc / nrq_dev_free: a caching pool (the object API allocates per call; hipMalloc / hipFree are
+   * device-wide synchronisation points).  Freed blocks are reused for requests of up to 1.25x less; reuse is safe
+   * because all work on a block is ordered on the context's streams and the object layer waits for its copy
+   * streams before it frees. */
+  const uint64_t *vec_inter = nullptr; /* nrq_encode_blocks_v: per-block addresses of the intermediate symbols */
+  const uint64_t *vec_src = nullptr, *vec_rep = nullptr; /* nrq_decode_blocks_v: per-block buffer addresses instead of base + stride */
+  std::multimap<size_t, void *> pool_free;
+  std::map<void *, size_t> pool_size;
+  size_t pool_cached = 0;
+  hipStream_t aux[2] = {nullptr, nullptr}; /* copy streams of the object layer: [0] host -> device, [1] device -> host */
+  DevBuf scat_dev[2];
+  PinBuf scat_pin[2];
+  hipEvent_t scat_ev[2] = {nullptr, nullptr};
+  int scat_flip = 0;
   bool plan_attr = false;
   /* The planner kernel runs on a stream of its own: it depends on the reception pattern only, not on the symbols, so
    * it may run beside whatever the caller's stream is still doing (typically the encode solve launched just before).
@@ -1188,6 +1219,10 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->plan_stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->aux[0], hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->aux[1], hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->scat_ev[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->scat_ev[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->planned, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->arena_free, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->pstaged[0], hipEventDisableTiming) != hipSuccess ||
@@ -1235,6 +1270,14 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
   if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
   if (ctx->plan_stream2) { (void)hipStreamSynchronize(ctx->plan_stream2); (void)hipStreamDestroy(ctx->plan_stream2); }
   if (ctx->encplan_work.p) (void)hipFree(ctx->encplan_work.p);
+  for (int i = 0; i < 2; i++) {
+    if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
+    if (ctx->scat_dev[i].p) (void)hipFree(ctx->scat_dev[i].p);
+    if (ctx->scat_pin[i].p) (void)hipHostFree(ctx->scat_pin[i].p);
+    if (ctx->scat_ev[i]) (void)hipEventDestroy(ctx->scat_ev[i]);
+  }
+  for (auto &kv : ctx->pool_size) (void)hipFree(kv.first);
+  ctx->pool_size.clear(); ctx->pool_free.clear();
   if (ctx->planned) (void)hipEventDestroy(ctx->planned);
   if (ctx->arena_free) (void)hipEventDestroy(ctx->arena_free);
   if (ctx->plan_work.p) (void)hipFree(ctx->plan_work.p);
@@ -1366,7 +1409,7 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
     j.rowsrc = (uint64_t)(uintptr_t)(ep->dev + ep->rowsrc_off);
     j.src = (uint64_t)(uintptr_t)((const uint8_t *)d_src + (size_t)b * src_stride);
     j.rep = 0;
-    j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
+    j.inter = ctx->vec_inter ? ctx->vec_inter[b] : d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
     j.out = nrep ? (uint64_t)(uintptr_t)((uint8_t *)d_rep + (size_t)b * rep_stride) : 0;
     j.out_cptr = (uint64_t)(uintptr_t)(ds + off_cptr);
     j.out_slots = (uint64_t)(uintptr_t)(ds + off_cols);
@@ -1376,7 +1419,7 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   HIPCHK(ctx, hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->staged[f], ctx->stream));
   std::vector<const nrq_plan_hdr *> hdrs(1, &ep->hdr);
-  rc = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds + off_jobs), nblk, T, kc->dev, (d_inter ? p.L : 0u) + nrep);
+  rc = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ds + off_jobs), nblk, T, kc->dev, ((d_inter || ctx->vec_inter) ? p.L : 0u) + nrep);
   if (ep->used[ep->cur]) { /* (device-built plans: the next build may not overwrite this buffer before the launch is done) */
     HIPCHK(ctx, hipEventRecord(ep->used[ep->cur], ctx->stream));
     ep->used_set[ep->cur] = true;
@@ -1532,8 +1575,8 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
       ctx->stats.plan_bytes += pr.plan_bytes;
       j.plan = (uint64_t)(uintptr_t)(ds + pr.off_plan);
       j.rowsrc = (uint64_t)(uintptr_t)(ds + pr.off_rowsrc);
-      j.src = (uint64_t)(uintptr_t)((uint8_t *)d_src + (size_t)b * src_stride);
-      j.rep = (uint64_t)(uintptr_t)((const uint8_t *)d_rep + (size_t)b * rep_stride);
+      j.src = (ctx->vec_src ? ctx->vec_src[b] : (uint64_t)(uintptr_t)((uint8_t *)d_src + (size_t)b * src_stride));
+      j.rep = (ctx->vec_rep ? ctx->vec_rep[b] : (uint64_t)(uintptr_t)((const uint8_t *)d_rep + (size_t)b * rep_stride));
       j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
       j.out = j.src; /* recovered symbols go back into the block's own rows */
       j.out_cptr = (uint64_t)(uintptr_t)(ds + pr.off_cptr);
@@ -1622,8 +1665,8 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     j.rep_esi = (uint64_t)(uintptr_t)(ds + off_resi + (size_t)b * rep_cap * 4);
     j.work = (uint64_t)(uintptr_t)(ctx->plan_work.p + (size_t)b * wl.total);
     j.arena = (uint64_t)(uintptr_t)(ctx->plan_arena.p + (size_t)b * arena_cap);
-    j.src = (uint64_t)(uintptr_t)((uint8_t *)d_src + (size_t)b * src_stride);
-    j.rep = (uint64_t)(uintptr_t)((const uint8_t *)d_rep + (size_t)b * rep_stride);
+    j.src = (ctx->vec_src ? ctx->vec_src[b] : (uint64_t)(uintptr_t)((uint8_t *)d_src + (size_t)b * src_stride));
+    j.rep = (ctx->vec_rep ? ctx->vec_rep[b] : (uint64_t)(uintptr_t)((const uint8_t *)d_rep + (size_t)b * rep_stride));
     j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
     j.nlost = sane ? h_nlost[b] : 0;
     j.nrep = sane ? h_nrep[b] : 0;
@@ -1722,6 +1765,27 @@ int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, ui
   return rc;
 }
 
+int nrq_encode_blocks_v(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,
+                        const uint64_t *d_inter_v) {
+  if (!ctx || !d_inter_v) return -1;
+  ctx->vec_inter = d_inter_v;
+  const int rc = nrq_encode_blocks(ctx, K, Kp, T, nblk, d_src, src_stride, nullptr, 0, 0, nullptr, nullptr, 0);
+  ctx->vec_inter = nullptr;
+  return rc;
+}
+
+int nrq_decode_blocks_v(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const uint64_t *d_src_v, const uint32_t *h_lost,
+                        const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi, const uint32_t *h_nrep,
+                        const uint32_t *h_nrep_avail, uint32_t rep_cap, const uint64_t *d_rep_v, int *h_status, uint32_t *h_used) {
+  if (!ctx || !d_src_v || !d_rep_v) return -1;
+  ctx->vec_src = d_src_v;
+  ctx->vec_rep = d_rep_v;
+  const int rc = nrq_decode_blocks_lazy(ctx, K, Kp, T, nblk, (void *)(uintptr_t)16, 0, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, h_nrep_avail,
+                                        rep_cap, (const void *)(uintptr_t)16, 0, nullptr, 0, h_status, h_used);
+  ctx->vec_src = ctx->vec_rep = nullptr;
+  return rc;
+}
+
 int nrq_decode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
                       const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
                       const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
@@ -1756,16 +1820,134 @@ int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t 
 int nrq_dev_alloc(nrq_ctx *ctx, size_t bytes, void **out) {
   if (!ctx || !out) return -1;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipMalloc(out, bytes ? bytes : 16));
+  size_t want = bytes ? bytes : 16;
+  want = (want + 4095) & ~(size_t)4095;
+  auto it = ctx->pool_free.lower_bound(want);
+  if (it != ctx->pool_free.end() && it->first <= want + want / 4 + 65536) {
+    *out = it->second;
+    ctx->pool_cached -= it->first;
+    ctx->pool_free.erase(it);
+    return 0;
+  }
+  hipError_t e = hipMalloc(out, want);
+  if (e != hipSuccess && !ctx->pool_free.empty()) { /* give the cached blocks back and try once more */
+    (void)hipGetLastError();
+    nrq_dev_trim(ctx);
+    e = hipMalloc(out, want);
+  }
+  if (e != hipSuccess) { *out = nullptr; return fail(ctx, -10, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+  ctx->pool_size[*out] = want;
   return 0;
 }
 int nrq_dev_free(nrq_ctx *ctx, void *p) {
   if (!ctx) return -1;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  HIPCHK(ctx, hipFree(p));
+  if (!p) return 0;
+  auto it = ctx->pool_size.find(p);
+  if (it == ctx->pool_size.end()) return fail(ctx, -1, "nrq_dev_free: not a block of this context");
+  ctx->pool_free.emplace(it->second, p);
+  ctx->pool_cached += it->second;
+  if (ctx->pool_cached > ((size_t)24 << 30)) nrq_dev_trim(ctx); /* keep the cache bounded */
   return 0;
 }
+int nrq_dev_trim(nrq_ctx *ctx) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  for (auto &kv : ctx->pool_free) {
+    (void)hipFree(kv.second);
+    ctx->pool_size.erase(kv.second);
+  }
+  ctx->pool_free.clear();
+  ctx->pool_cached = 0;
+  return 0;
+}
+
+/* page-locked host memory (what the copy engines read and write at PCIe speed without a staging pass) */
+int nrq_host_alloc_pinned(size_t bytes, void **out) {
+  if (!out) return -1;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? 0 : -10;
+}
+void nrq_host_free_pinned(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+int nrq_host_register(void *p, size_t bytes) { return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? 0 : -10; }
+void nrq_host_unregister(void *p) {
+  if (p) (void)hipHostUnregister(p);
+}
+int nrq_host_is_pinned(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return a.type == hipMemoryTypeHost ? 1 : 0;
+}
+
+/* streams and events of the object layer's copy pipeline; stream selector: 0 = the context's stream, 1 = upload
+ * stream, 2 = download stream */
+static hipStream_t sel_stream(nrq_ctx *ctx, int which) { return which == 1 ? ctx->aux[0] : which == 2 ? ctx->aux[1] : ctx->stream; }
+int nrq_copy_on(nrq_ctx *ctx, int stream, void *dst, const void *src, size_t bytes) {
+  if (!ctx) return -1;
+  if (!bytes) return 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, sel_stream(ctx, stream)));
+  return 0;
+}
+int nrq_memset_on(nrq_ctx *ctx, int stream, void *d_dst, int value, size_t bytes) {
+  if (!ctx) return -1;
+  if (!bytes) return 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemsetAsync(d_dst, value, bytes, sel_stream(ctx, stream)));
+  return 0;
+}
+int nrq_event_new(nrq_ctx *ctx, void **out) {
+  if (!ctx || !out) return -1;
+  hipEvent_t e;
+  HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *out = e;
+  return 0;
+}
+void nrq_event_free(void *ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+int nrq_event_record(nrq_ctx *ctx, void *ev, int stream) {
+  if (!ctx || !ev) return -1;
+  HIPCHK(ctx, hipEventRecord((hipEvent_t)ev, sel_stream(ctx, stream)));
+  return 0;
+}
+int nrq_stream_wait(nrq_ctx *ctx, int stream, void *ev) {
+  if (!ctx || !ev) return -1;
+  HIPCHK(ctx, hipStreamWaitEvent(sel_stream(ctx, stream), (hipEvent_t)ev, 0));
+  return 0;
+}
+int nrq_event_sync(nrq_ctx *ctx, void *ev) {
+  if (!ctx || !ev) return -1;
+  HIPCHK(ctx, hipEventSynchronize((hipEvent_t)ev));
+  return 0;
+}
+int nrq_stream_sync(nrq_ctx *ctx, int stream) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipStreamSynchronize(sel_stream(ctx, stream)));
+  return 0;
+}
+
+int nrq_scatter_symbols(nrq_ctx *ctx, int stream, const void *d_blob, uint32_t n, uint32_t T, const uint64_t *h_dst) {
+  if (!ctx || !d_blob || !h_dst || T == 0) return -1;
+  if (n == 0) return 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int f = ctx->scat_flip;
+  ctx->scat_flip ^= 1;
+  HIPCHK(ctx, hipEventSynchronize(ctx->scat_ev[f])); /* the copy out of this pinned image two calls ago */
+  int rc;
+  if ((rc = ensure_pin(ctx, ctx->scat_pin[f], (size_t)n * 8))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->scat_dev[f], (size_t)n * 8))) return rc;
+  memcpy(ctx->scat_pin[f].p, h_dst, (size_t)n * 8);
+  hipStream_t st = sel_stream(ctx, stream);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->scat_dev[f].p, ctx->scat_pin[f].p, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(ctx, hipEventRecord(ctx->scat_ev[f], st));
+  hipLaunchKernelGGL(nrq_scatter_kernel, dim3(n), dim3(128), 0, st, (const uint8_t *)d_blob, T, (const uint64_t *)ctx->scat_dev[f].p, n);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
 int nrq_dev_upload(nrq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
   if (!ctx) return -1;
   HIPCHK(ctx, hipSetDevice(ctx->device));

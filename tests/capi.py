@@ -77,6 +77,29 @@ def api():
         L.nanorq_decoder_add_symbols.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int), iop]
         L.nanorq_repair_all.restype = C.c_size_t
         L.nanorq_repair_all.argtypes = [vp, iop]
+        # include/nanorq_batch.h: page-locked memory; include/nanorq_ext.h: RFC 6330 options
+        L.ioctx_from_pinned_mem.restype = iop
+        L.ioctx_from_pinned_mem.argtypes = [C.c_size_t]
+        L.ioctx_from_registered_mem.restype = iop
+        L.ioctx_from_registered_mem.argtypes = [vp, C.c_size_t]
+        L.ioctx_mem_base.restype = vp
+        L.ioctx_mem_base.argtypes = [iop]
+        L.nanorq_pinned_alloc.restype = vp
+        L.nanorq_pinned_alloc.argtypes = [C.c_size_t]
+        L.nanorq_pinned_free.restype = None
+        L.nanorq_pinned_free.argtypes = [vp]
+        L.nanorq_decoder_flush.restype = C.c_size_t
+        L.nanorq_decoder_flush.argtypes = [vp, iop]
+        L.nanorq_encoder_new_ext.restype = vp
+        L.nanorq_encoder_new_ext.argtypes = [C.c_size_t, C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint8, C.c_uint32]
+        L.nanorq_decoder_new_ext.restype = vp
+        L.nanorq_decoder_new_ext.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.nanorq_ext_flags.restype = C.c_uint32
+        L.nanorq_ext_flags.argtypes = [vp]
+        L.nanorq_sub_blocks.restype = C.c_size_t
+        L.nanorq_sub_blocks.argtypes = [vp]
+        L.nanorq_block_kprime.restype = C.c_size_t
+        L.nanorq_block_kprime.argtypes = [vp, C.c_uint8]
         L.ioctx_from_mem.restype = iop
         L.ioctx_from_mem.argtypes = [vp, C.c_size_t]
         L.ioctx_from_file.restype = iop
@@ -89,6 +112,25 @@ def api():
 
 def mem_io(arr):
     return api().ioctx_from_mem(arr.ctypes.data_as(C.c_void_p), arr.nbytes)
+
+
+EXT_RFC_OTI, EXT_PER_BLOCK_KP, EXT_SUBBLOCKS = 1, 2, 4
+
+
+def pinned_io(nbytes):
+    """(ioctx over page-locked memory it owns, numpy view of that memory)"""
+    L = api()
+    io = L.ioctx_from_pinned_mem(nbytes)
+    assert io, "ioctx_from_pinned_mem failed"
+    return io, np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(L.ioctx_mem_base(io)))
+
+
+def pinned_array(nbytes):
+    """(address, numpy view) of a page-locked packet buffer; free with api().nanorq_pinned_free(address)"""
+    L = api()
+    p = L.nanorq_pinned_alloc(max(1, nbytes))
+    assert p, "nanorq_pinned_alloc failed"
+    return p, np.ctypeslib.as_array((C.c_uint8 * max(1, nbytes)).from_address(p))[:nbytes]
 
 
 def encode_object(data, T, K=0, Z=0, Al=8, loss=0.06, overhead=0, seed=1, precalc=False):

@@ -199,3 +199,267 @@ def test_two_ranks_through_the_real_library(tmp_path):
     two = dict(json.load(open(tmp_path / "r0.json")), **json.load(open(tmp_path / "r1.json")))
     solo = json.load(open(tmp_path / "solo.json"))
     assert sorted(two, key=int) == [str(b) for b in range(16)] and two == solo
+
+
+# ------------------------------------------------------------------ streaming path (page-locked memory) ----
+def _packets(F, T, K, loss, oh, seed):
+    """object bytes, OTI and the packets of a lossy transmission (through the plain per-block calls)"""
+    data = payload(F, seed=seed)
+    c, s, packets = encode_object(data, T, K=K, loss=loss, overhead=oh, seed=seed)
+    return data, c, s, packets
+
+
+@pytest.mark.parametrize("F,T,K,loss,oh", [(103 * 64 - 17, 64, 25, 0.1, 3), (700 * 1280, 1280, 100, 0.08, 2), (3000 * 256 + 5, 256, 0, 0.05, 4),
+                                           (40 * 8192, 8192, 10, 0.2, 1)])
+def test_page_locked_contexts_give_the_same_bytes(F, T, K, loss, oh):
+    """The DMA paths of the batched calls -- object read straight out of a page-locked context, packets uploaded in one
+    piece and sorted into rows on the GPU, decoded blocks written whole into a page-locked context -- against the plain
+    calls: identical packets, identical recovered object, identical per-symbol result codes."""
+    from capi import SYM_ADDED, pinned_array, pinned_io
+    L = api()
+    data, c, s, packets = _packets(F, T, K, loss, oh, seed=21)
+    # encoder side: batched + page-locked source
+    io, mem = pinned_io(F)
+    mem[:] = data
+    rq = L.nanorq_encoder_new_ex(F, T, K, 0, 8)
+    nblk = L.nanorq_blocks(rq)
+    assert L.nanorq_generate_symbols_all(rq, io) == nblk
+    want = dict(packets)
+    Tsz = L.nanorq_symbol_size(rq)
+    for sbn in range(nblk):
+        nk = L.nanorq_block_symbols(rq, sbn)
+        tags = [t for t in want if (t >> 24) == sbn]
+        top = max(t & 0xffffff for t in tags) + 1
+        buf = np.zeros((top, Tsz), np.uint8)
+        assert L.nanorq_encode_range(rq, buf.ctypes.data_as(C.c_void_p), 0, top, sbn, io) == top * Tsz
+        for t in tags:
+            assert buf[t & 0xffffff].tobytes() == want[t], (sbn, t & 0xffffff, nk)
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+    # decoder side: page-locked packet buffer (with a duplicate and an out-of-range tag) + page-locked sink
+    tags = np.array([t for t, _ in packets] + [packets[0][0], L.nanorq_tag(0, (1 << 24) - 1)], np.uint32)
+    addr, blob = pinned_array(len(tags) * Tsz)
+    blob[:len(packets) * Tsz] = np.frombuffer(b"".join(p for _, p in packets), np.uint8)
+    blob[len(packets) * Tsz:] = 0x11
+    dq = L.nanorq_decoder_new(c, s)
+    oio, out = pinned_io(F)
+    out[:] = 0
+    res = np.zeros(len(tags), np.int32)
+    added = L.nanorq_decoder_add_symbols(dq, C.c_void_p(addr), tags.ctypes.data_as(C.POINTER(C.c_uint32)), len(tags),
+                                         res.ctypes.data_as(C.POINTER(C.c_int)), oio)
+    # the same stream of symbols through the per-symbol call gives the reference result codes
+    dq2 = L.nanorq_decoder_new(c, s)
+    out2 = np.zeros(F, np.uint8)
+    oio2 = mem_io(out2)
+    res2 = [L.nanorq_decoder_add_symbol(dq2, (C.c_uint8 * Tsz).from_buffer_copy(blob[k * Tsz:(k + 1) * Tsz].tobytes()), int(tags[k]), oio2)
+            for k in range(len(tags))]
+    assert list(res) == res2 and added == res2.count(SYM_ADDED)
+    nb = L.nanorq_blocks(dq)
+    assert [L.nanorq_num_missing(dq, b) for b in range(nb)] == [L.nanorq_num_missing(dq2, b) for b in range(nb)]
+    assert [L.nanorq_num_repair(dq, b) for b in range(nb)] == [L.nanorq_num_repair(dq2, b) for b in range(nb)]
+    done = L.nanorq_repair_all(dq, oio)
+    ok2 = all(L.nanorq_repair_block(dq2, oio2, b) for b in range(nb))
+    assert (done == nb) == ok2
+    if ok2:
+        assert np.array_equal(out, data) and np.array_equal(out2, data)
+    L.nanorq_free(dq); L.nanorq_free(dq2)
+    oio.contents.destroy(oio); oio2.contents.destroy(oio2)
+    L.nanorq_pinned_free(addr)
+
+
+def test_device_resident_blocks_mix_with_per_symbol_calls():
+    """A block fed through the page-locked path first and the per-symbol call afterwards (and the other way round); a
+    block that stays undecodable keeps what it received, writes it on flush, and is repaired after more symbols."""
+    from capi import pinned_array, pinned_io
+    L = api()
+    K, T = 200, 96
+    F = 2 * K * T
+    data = payload(F, seed=33)
+    c, s, packets = encode_object(data, T, K=K, loss=0.0, overhead=20, seed=3)
+    blk = {0: [p for p in packets if (p[0] >> 24) == 0], 1: [p for p in packets if (p[0] >> 24) == 1]}
+    src0 = [p for p in blk[0] if (p[0] & 0xffffff) < K]
+    rep0 = [p for p in blk[0] if (p[0] & 0xffffff) >= K]
+    src1 = [p for p in blk[1] if (p[0] & 0xffffff) < K]
+    rep1 = [p for p in blk[1] if (p[0] & 0xffffff) >= K]
+    dq = L.nanorq_decoder_new(c, s)
+    oio, out = pinned_io(F)
+    out[:] = 0
+
+    def add_pinned(pk):
+        addr, blob = pinned_array(len(pk) * T)
+        blob[:] = np.frombuffer(b"".join(p for _, p in pk), np.uint8)
+        tags = np.array([t for t, _ in pk], np.uint32)
+        n = L.nanorq_decoder_add_symbols(dq, C.c_void_p(addr), tags.ctypes.data_as(C.POINTER(C.c_uint32)), len(pk), None, oio)
+        L.nanorq_pinned_free(addr)
+        return n
+
+    def add_single(pk):
+        return [L.nanorq_decoder_add_symbol(dq, (C.c_uint8 * T).from_buffer_copy(p), t, oio) for t, p in pk]
+
+    # block 0: page-locked path first (30 source symbols missing), then single symbols: too few repair symbols at first
+    assert add_pinned(src0[30:] + rep0[:10]) == K - 30 + 10
+    assert add_single(rep0[10:15]) == [0] * 5
+    assert L.nanorq_num_missing(dq, 0) == 30 and not L.nanorq_repair_block(dq, oio, 0)
+    assert L.nanorq_decoder_flush(dq, oio) == 1                       # what was received reaches the output now
+    assert np.array_equal(out[30 * T:K * T], data[30 * T:K * T]) and not out[:30 * T].any()
+    # block 1: single symbols first (host-resident), then the page-locked call falls back to the host path for it
+    assert add_single(src1[:50]) == [0] * 50
+    assert add_pinned(src1[60:] + rep1[:12]) == K - 60 + 12
+    assert add_single(rep0[15:]) == [0] * 5 and add_pinned(rep0[:16] + [rep0[0]] * 16) == 0   # block 0: 5 more, then duplicates only
+    assert L.nanorq_repair_all(dq, oio) == 1 and L.nanorq_num_missing(dq, 0) == 30            # 20 repair symbols for 30 gaps
+    assert np.array_equal(out[K * T:], data[K * T:])
+    assert add_pinned(src0[:16] + src0[16:20]) == 20                                         # 10 gaps left, 20 repair symbols held
+    assert L.nanorq_repair_all(dq, oio) == 2
+    assert np.array_equal(out, data)
+    L.nanorq_free(dq)
+    oio.contents.destroy(oio)
+
+
+def test_objects_on_two_threads():
+    """Distinct nanorq objects are independent (reference: no globals); here they share one GPU context, guarded by a
+    lock: two threads, each encoding and decoding its own objects, must not disturb each other."""
+    import threading
+    errs = []
+
+    def work(seed):
+        try:
+            for rnd in range(3):
+                K, T = 150 + 37 * seed, 64 + 32 * seed
+                data = payload(3 * K * T - 5, seed=seed * 10 + rnd)
+                c, s, pk = encode_object_batched(data, T, K=K, loss=0.1, overhead=3, seed=seed + rnd)
+                ok, out = decode_object_batched(c, s, pk, len(data))
+                assert ok and np.array_equal(out, data)
+                c2, s2, pk2 = encode_object(data, T, K=K, loss=0.1, overhead=3, seed=seed + rnd)
+                assert (c2, s2) == (c, s) and pk2 == pk
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in (1, 2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
+def test_surplus_repair_symbols_are_held_in_reserve():
+    """A receiver that collected far more repair symbols than gaps: only gaps + 2 become constraint rows up front, the
+    rest is taken one at a time when the system is rank deficient -- so the plan stays small and M never leaves the
+    planners' 16-bit slot range however many symbols arrived (here: 3 gaps, 4000 repair symbols, K = 2000)."""
+    L = api()
+    K, T = 2000, 32
+    data = payload(K * T, seed=44)
+    rq = L.nanorq_encoder_new_ex(K * T, T, K, 0, 8)
+    io = mem_io(data)
+    buf = np.zeros((4000, T), np.uint8)
+    assert L.nanorq_encode_range(rq, buf.ctypes.data_as(C.c_void_p), K, 4000, 0, io) == 4000 * T
+    oti = (L.nanorq_oti_common(rq), L.nanorq_oti_scheme_specific(rq))
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+    dq = L.nanorq_decoder_new(*oti)
+    assert L.nanorq_set_max_esi(dq, K + 4500)
+    out = np.zeros(K * T, np.uint8)
+    oio = mem_io(out)
+    for e in range(K):
+        if e not in (5, 700, 1999):
+            L.nanorq_decoder_add_symbol(dq, (C.c_uint8 * T).from_buffer_copy(data[e * T:(e + 1) * T].tobytes()), L.nanorq_tag(0, e), oio)
+    for j in range(4000):
+        L.nanorq_decoder_add_symbol(dq, (C.c_uint8 * T).from_buffer_copy(buf[j].tobytes()), L.nanorq_tag(0, K + j), oio)
+    assert L.nanorq_num_repair(dq, 0) == 4000 and L.nanorq_repair_block(dq, oio, 0)
+    assert np.array_equal(out, data)
+    L.nanorq_free(dq)
+    oio.contents.destroy(oio)
+
+
+# ------------------------------------------------------------------ RFC 6330 options (include/nanorq_ext.h) ----
+def _ext_roundtrip(F, T, K, N, flags, seed, loss=0.1, oh=3):
+    from capi import SYM_ERR
+    L = api()
+    data = payload(F, seed=seed)
+    rq = L.nanorq_encoder_new_ext(F, T, K, 0, N, 8, flags)
+    assert rq
+    io = mem_io(data)
+    rng = np.random.default_rng(seed)
+    Tsz = L.nanorq_symbol_size(rq)
+    pk = []
+    buf = (C.c_uint8 * Tsz)()
+    for sbn in range(L.nanorq_blocks(rq)):
+        nk = L.nanorq_block_symbols(rq, sbn)
+        drop = [e for e in range(nk) if rng.random() < loss]
+        for e in [e for e in range(nk) if e not in drop] + list(range(nk, nk + len(drop) + oh)):
+            assert L.nanorq_encode(rq, buf, e, sbn, io) == Tsz
+            pk.append((L.nanorq_tag(sbn, e), bytes(buf)))
+    oti = (L.nanorq_oti_common(rq), L.nanorq_oti_scheme_specific(rq))
+    info = (L.nanorq_sub_blocks(rq), [L.nanorq_block_symbols(rq, b) for b in range(L.nanorq_blocks(rq))],
+            [L.nanorq_block_kprime(rq, b) for b in range(L.nanorq_blocks(rq))])
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+    dq = L.nanorq_decoder_new_ext(oti[0], oti[1], flags)
+    assert dq and L.nanorq_ext_flags(dq) == flags and L.nanorq_sub_blocks(dq) == info[0]
+    out = np.zeros(F, np.uint8)
+    oio = mem_io(out)
+    for t, p in pk:
+        assert L.nanorq_decoder_add_symbol(dq, (C.c_uint8 * len(p)).from_buffer_copy(p), t, oio) != SYM_ERR
+    ok = all(L.nanorq_repair_block(dq, oio, b) for b in range(L.nanorq_blocks(dq)))
+    L.nanorq_free(dq)
+    oio.contents.destroy(oio)
+    return ok, np.array_equal(out, data), oti, info, pk, data
+
+
+def test_rfc_oti_packing():
+    """RFC 6330 section 3.3.2 / 3.3.3: common = F | reserved | T, scheme-specific = Z | N | Al, values as they are (the
+    nanorq packing stores T-1, Z-1, N-1: reference lib/nanorq.c:309-324)."""
+    from capi import EXT_RFC_OTI
+    ok, same, oti, info, _, _ = _ext_roundtrip(5 * 100 * 64 - 9, 64, 100, 1, EXT_RFC_OTI, seed=5)
+    assert ok and same
+    F = 5 * 100 * 64 - 9
+    assert oti[0] == (F << 24) | 64 and oti[1] == (5 << 24) | (1 << 8) | 8
+    L = api()
+    rq = L.nanorq_encoder_new_ex(F, 64, 100, 0, 8)
+    assert L.nanorq_oti_common(rq) == (F << 24) | 63 and L.nanorq_oti_scheme_specific(rq) == (4 << 24) | 8   # nanorq's own packing
+    L.nanorq_free(rq)
+    assert not L.nanorq_decoder_new_ext((F << 24) | 64, (0 << 24) | (1 << 8) | 8, EXT_RFC_OTI)   # Z = 0 is not an object
+
+
+def test_per_block_kprime(orc):
+    """RFC 6330 section 5.3.1.2: a short block is coded with the table row of its own K.  203 symbols in blocks of 102
+    and 101: rows 114 and 101 (nanorq: 114 for both, test_short_last_block_is_coded_with_block_zeros_table_row)."""
+    from capi import EXT_PER_BLOCK_KP
+    T = 48
+    ok, same, oti, info, pk, data = _ext_roundtrip(203 * T, T, 102, 1, EXT_PER_BLOCK_KP, seed=6)
+    assert ok and same and info[1] == [102, 101] and info[2] == [114, 101]
+    src1 = data[102 * T:].reshape(101, T)
+    rep1 = [(t & 0xffffff, p) for t, p in pk if (t >> 24) == 1 and (t & 0xffffff) >= 101]
+    want, _, _ = orc.encode_block(src1, 101, T, [e for e, _ in rep1])          # the oracle with the block's OWN row
+    assert [w.tobytes() for w in want] == [p for _, p in rep1]
+
+
+@pytest.mark.parametrize("N,T,F", [(2, 64, 3 * 50 * 64), (4, 96, 2 * 40 * 96 - 13), (8, 64, 50 * 64 - 1)])
+def test_sub_blocking(orc, N, T, F):
+    """RFC 6330 section 4.4.1.2 with N > 1: every symbol is N sub-symbols that lie in N different regions of the block
+    (the transfer_symbol branch nanorq never reaches: lib/nanorq.c:78 forces N = 1).  Round trip, and the first repair
+    symbol against the oracle on symbols gathered the RFC's way."""
+    from capi import EXT_SUBBLOCKS
+    K = 50 if N != 4 else 40
+    ok, same, oti, info, pk, data = _ext_roundtrip(F, T, K, N, EXT_SUBBLOCKS, seed=7 + N)
+    assert ok and same and info[0] == N
+    # block 0 gathered by hand: Al = 8, T/Al units split into N sub-symbols (TL/TS units, NL/NS of each)
+    unit = T // 8
+    TL, TS = -(-unit // N), unit // N
+    NL = unit - TS * N
+    k0 = info[1][0]
+    padded = np.zeros(sum(info[1]) * T + T, np.uint8)
+    padded[:F] = data
+    sym = np.zeros((k0, T), np.uint8)
+    off, col = 0, 0
+    for j in range(N):
+        w = (TL if j < NL else TS) * 8
+        for e in range(k0):
+            sym[e, col:col + w] = padded[off + e * w: off + (e + 1) * w]
+        off += k0 * w
+        col += w
+    rep = [(t & 0xffffff, p) for t, p in pk if (t >> 24) == 0 and (t & 0xffffff) >= k0]
+    want, _, _ = orc.encode_block(sym, k0, T, [rep[0][0]])
+    assert want[0].tobytes() == rep[0][1]
+    src = [(t & 0xffffff, p) for t, p in pk if (t >> 24) == 0 and (t & 0xffffff) < k0]
+    assert src[0][1] == sym[src[0][0]].tobytes()
