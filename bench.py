@@ -294,11 +294,20 @@ def main():
     # weak scaling: the job has world*NB source blocks per step, block b lives on GPU b mod world;
     # payload and loss pattern are functions of the GLOBAL block id, payload generated on the device
     my_blocks = shard.blocks_of(rank, world, world * NB)
+    # byte i of global block gb = low byte of a 64-bit mix of (gb * K * T + i): a function of the GLOBAL block id,
+    # not of the rank or of how many GPUs share the job; generated on the device, a few blocks per pass
     src = torch.empty((NB, K, T), dtype=torch.uint8, device=dev)
-    g = torch.Generator(device=dev)
-    for b, gb in enumerate(my_blocks):
-        g.manual_seed(1000003 * gb + 1)   # the payload is a function of the GLOBAL block id, not of the rank
-        src[b] = torch.randint(0, 256, (K, T), dtype=torch.uint8, device=dev, generator=g)
+    per = K * T
+    ar = torch.arange(per, device=dev, dtype=torch.int64).view(1, per)
+    ch = max(1, (32 << 20) // per)
+    for b0 in range(0, NB, ch):
+        gbs = torch.tensor(my_blocks[b0:b0 + ch], device=dev, dtype=torch.int64).view(-1, 1)
+        x = gbs * per + ar + 0x1234567
+        x = (x ^ (x >> 31)) * 0x7FB5D329728EA185           # (int64 arithmetic wraps)
+        x = (x ^ (x >> 27)) * -0x7E25210B43D22BB3
+        x = x ^ (x >> 33)
+        src[b0:b0 + ch] = ((x >> 24) & 0xFF).to(torch.uint8).view(-1, K, T)
+    del ar, x
     lost = [loss_pattern(K, args.loss, seed=1000, block=gb) for gb in my_blocks]
     max_lost = max(len(x) for x in lost)
     nrep = max_lost + args.overhead + 3  # repair symbols generated per block by the encoder (incl. spares)

@@ -101,7 +101,11 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
   constexpr uint32_t SPL = 128u / WB, NFW = (WB >= 8 && NT >= 512) ? 2u : 1u,
                      NMV = (NT / 64u) / 4u * (4u - NFW) + ((NT / 64u) % 4u > NFW ? (NT / 64u) % 4u - NFW : 0u),
                      NGW = NMV >= 6u ? 3u : NMV >= 3u ? 2u : 1u, NSW = NMV >= 6u ? 3u : NMV - NGW;
-  static_assert(NMV >= 2u, "workgroup too small for the data movers");
+  static_assert(NMV >= 2u || NT == 64, "workgroup too small for the data movers");
+  /* NT == 64: ONE wave solves the strip on its own (no mover waves: it gathers and scatters its portions itself after
+   * the forward passes; barriers are free).  For images of a few KB -- K up to ~400 -- where a strip is a chain of
+   * short phases with little parallel work: 19-20 such workgroups share a CU instead of five 256-thread ones, i.e.
+   * four times as many strips are in flight to hide the phases' latencies. */
   const uint32_t sub = 1u << lsub;               /* strips per slot */
   const uint32_t gpb = (nstrips + sub - 1u) / sub; /* slots per block */
   /* per workgroup: two sets of SPL input staging buffers (the group being solved, the group being gathered) and two
@@ -201,7 +205,11 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
        * because the forward passes leave them plenty of time and a deep queue of their requests in the CU's memory
        * pipeline would delay the op words wave 0 is waiting for */
       const uint32_t wv = tid >> 6;
-      if (wv < NFW) {
+      if constexpr (NT == 64) {
+        fwd_rows<WB>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
+        if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid, 64u);
+        if (sm > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, sm, tid, 64u);
+      } else if (wv < NFW) {
         __builtin_amdgcn_s_setprio(3); /* the critical waves: ahead of the others at instruction issue */
         const NRQ_GAS uint32_t *ops_ = c.template arr<uint32_t>(c.h->off_ops);
         if constexpr (NFW == 2u) { /* one half of the strip width each */
@@ -633,6 +641,8 @@ struct Tuning {
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
   uint32_t encplan_dev_min_l = 12000; /* NRQ_ENCPLAN_DEV_MIN_L: from this many intermediate symbols on, encode plans are built by
                               * the device planner, asynchronously (the host planner takes 25 ms at K=27000, 95 ms at K'=56403) */
+  bool no_tiny = false;      /* NRQ_NO_TINY: no single-wave workgroups for tiny strip images */
+  uint32_t tiny_div = 12;    /* NRQ_TINY_DIV: LDS images per CU from which the single-wave variant is used */
   bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
   bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
   int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
@@ -645,6 +655,7 @@ struct Tuning {
     small_div = (uint32_t)num("NRQ_SMALL_DIV", 2); solve_grid = (uint64_t)num("NRQ_SOLVE_GRID", 0);
     max_wb = (uint32_t)num("NRQ_MAX_WB", 16); prof_base = (int)num("NRQ_PROF_BASE", 2);
     encplan_dev_min_l = (uint32_t)num("NRQ_ENCPLAN_DEV_MIN_L", 12000);
+    no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
   }
 };
@@ -989,13 +1000,18 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   /* workgroup shape: the full-size workgroup when a strip image needs more than half of the CU's LDS, 256-thread ones
    * when two or more fit */
   const bool small = lds_bytes * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg;
-  const uint32_t nt = small ? 256u : (uint32_t)NRQ_WG;
+  /* single-wave workgroups when 12 or more images fit a CU (see the kernel; K=256: +26 % over five 256-thread workgroups) */
+  const bool tiny = small && (uint64_t)lds_bytes * ctx->tune.tiny_div <= NRQ_LDS_MAX && !ctx->tune.no_tiny;
+  const uint32_t nt = tiny ? 64u : small ? 256u : (uint32_t)NRQ_WG;
   uint32_t occ = NRQ_LDS_MAX / (lds_bytes ? lds_bytes : 1u);
   if (occ > 2048u / nt) occ = 2048u / nt;
   /* registers: the 256-thread variant (one wave per SIMD) is compiled for NRQ_SMALL_WAVES waves per SIMD.  More
    * workgroups than are resident at once would run as a second, thinner round of a statically partitioned job. */
-  const bool five = small && occ >= 5u && !ctx->tune.small_waves4;
-  if (small && occ > (five ? 5u : 4u)) occ = five ? 5u : 4u;
+  const bool five = small && !tiny && occ >= 5u && !ctx->tune.small_waves4;
+  if (tiny) { if (occ > 18u) occ = 18u; } /* one wave per workgroup, compiled for 5 waves per SIMD; 20 per CU by the LDS sum, but
+                                              * measured: with 20 x 256 workgroups not all are resident and the rest runs as a second
+                                              * round (10.4 ms against 8.7 ms with 18 x 256 at K=100, T=1024, 8192 blocks) */
+  else if (small && occ > (five ? 5u : 4u)) occ = five ? 5u : 4u;
   if (occ < 1u) occ = 1u;
   /* persistent workgroups fill the device; a multiple of 8 keeps a workgroup's slots on its XCD */
   uint64_t grid = (uint64_t)(ctx->ncu / 8) * 8 * occ;
@@ -1064,6 +1080,8 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 256, 5>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 64, 5>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     ctx->attr_set[slot] = true;
   }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1085,7 +1103,10 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     HIPCHK(ctx, hipMalloc((void **)&ctx->prof, (size_t)nprof * 16 * 8));
     HIPCHK(ctx, hipMemsetAsync(ctx->prof, 0, (size_t)nprof * 16 * 8, ctx->stream));
   }
-  if (five)
+  if (tiny)
+    hipLaunchKernelGGL((nrq_solve_kernel<WB, 64, 5>), dim3((uint32_t)grid), dim3(64), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
+                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
+  else if (five)
     hipLaunchKernelGGL((nrq_solve_kernel<WB, 256, 5>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
                        by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
   else if (small)
@@ -1149,7 +1170,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   ctx->stats.grid = (uint32_t)grid;
   ctx->stats.wg_threads = nt;
   ctx->stats.strips_per_slot = 1u << lsub;
-  ctx->stats.wg_waves_per_simd = five ? 5u : small ? 4u : 1u;
+  ctx->stats.wg_waves_per_simd = (five || tiny) ? 5u : small ? 4u : 1u;
   return 0;
 }
 
@@ -1331,6 +1352,8 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   const std::string n(name);
   if (n == "max_wb") t.max_wb = (uint32_t)value;
   else if (n == "no_split") t.no_split = value != 0;
+  else if (n == "no_tiny") t.no_tiny = value != 0;
+  else if (n == "tiny_div") t.tiny_div = (uint32_t)value;
   else if (n == "no_balance") t.no_balance = value != 0;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;

@@ -641,7 +641,9 @@ template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32
 #ifndef NRQ_DENSE_SHARED_MIN_NT
 #define NRQ_DENSE_SHARED_MIN_NT 512u
 #endif
-SB_HD bool dense_fold_shared(uint32_t nt) { return nt >= NRQ_DENSE_SHARED_MIN_NT; }
+/* (a single-wave workgroup, nt == 64, also shares the multiples: with one wave the few (h, p) pairs of a small block
+ * leave most lanes idle either way, and the general multiply is 3.4x the instructions of the shared form) */
+SB_HD bool dense_fold_shared(uint32_t nt) { return nt >= NRQ_DENSE_SHARED_MIN_NT || nt == 64u; }
 template <int WB> SB_HD void ph_dense_fold(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint8_t *mh = c.template arr<uint8_t>(c.h->off_mh);
   const uint32_t H = c.h->H, r2 = c.h->r2, M = c.h->M;

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun): the BASELINE configs other than the default one (cfg1, cfg2, cfg4, cfg5 and the K values of
+# the reference's chart) through bench.py, one JSON line each into gpurun_out/cfg/ -- copy what is to be judged to profiles/.
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/bench_configs.sh [tag]'
+REPO=${GRAFT_REPO_ROOT:-$PWD}
+TAG=${1:-r2}
+OUT=$REPO/gpurun_out/cfg
+mkdir -p "$OUT"
+cd /tmp; export TMPDIR=/tmp
+run() { # name K T blocks loss overhead
+  timeout 900 python $REPO/bench.py --K $2 --T $3 --blocks $4 --loss $5 --overhead $6 --steps 5 --warmup 2 --cpu-sample ${7:-2} > "$OUT/${TAG}_bench_$1.json" 2> "$OUT/${TAG}_bench_$1.err"
+  python3 - "$OUT/${TAG}_bench_$1.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+    b = (d.get("roofline") or {}).get("binding") or {}
+    print("%-28s %8.1f Gbit/s  %7.2f ms/step  lds_frac %s issue_frac %s hbm_frac %s  e2e %s" % (
+        d["metric"].split(",")[1].strip(), d["value"], d["ms_per_step"], b.get("lds_frac"), b.get("issue_frac"), b.get("hbm_frac"),
+        (d.get("e2e") or {}).get("value")))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+}
+run cfg1_K100_T1024      100  1024 8192 0.06 0
+run cfg2_K1024_T1280    1024  1280 2048 0.05 0
+run cfg4_K27000_T65504 27000 65504    1 0.10 0 0
+run cfg5_K56403_T1280  56403  1280    8 0.20 0 1
+run K1000_T1280         1000  1280 2048 0.06 0
+run K500_T1280           500  1280 4096 0.06 0
+run K5000_T1280         5000  1280  512 0.06 0
+run K10000_T1280       10000  1280  256 0.06 0
+run K20000_T1280       20000  1280   64 0.10 0 1
+run K50000_T1280       50000  1280   16 0.06 0 1

@@ -79,10 +79,27 @@ def pmcjson(paths):
     print(json.dumps(out, indent=1))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and sys.argv[1] != "timeline":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
     elif sys.argv[1] == "pmcjson":
         pmcjson(sys.argv[2:])
     else:
         pmc(sys.argv[2:])
+
+
+def timeline(path, last=40):
+    """the last `last` kernel dispatches with start offsets: where the gaps between kernels are"""
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    rows = rows[-last:]
+    t0 = rows[0][1]
+    prev_end = t0
+    print("# start_us  gap_before_us  dur_us  kernel")
+    for name, s, e in rows:
+        print("%10.1f %10.1f %10.1f  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, short(name)))
+        prev_end = max(prev_end, e)
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "timeline":
+    timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40)
