@@ -2,7 +2,8 @@
  * rq_oracle.c -- CPU ORACLE for the RaptorQ precode-solve + symbol-generation path.
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing in the product (nanorq_amd/, include/) links, loads or
- * calls this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ * calls this file; only tests/, __graft_entry__.smoke() and bench.py (its cpu_baseline leg and, after
+ * the timed region, the check of the sampled blocks) do.
  *
  * What it is: a from-scratch C restatement of the algorithm of sleepybishop/nanorq
  * (reference tree mounted read-only at /root/reference; citations below are file:line in
@@ -23,11 +24,14 @@
  * Because that dependency is missing the reference is UNBUILDABLE in this image and no
  * oracle/_ref binary exists.
  *
- * PARITY PIN: the known-answer vectors of SURVEY.md section 8(c) (repair symbols / SHA-256 for
- * K=10/100/1024/8192, produced during the survey by the reference's own lib/*.c) are
- * checked in tests/test_oracle_kat.py, together with RFC 6330's systematic property.
- * The reference itself ships no golden vectors, so beyond those KATs
- * parity is pinned by uniqueness of the solution of A*C = D, not by reference fixtures.
+ * PARITY PIN -- "parity unpinned" in the sense of the task statement: the reference ships no golden
+ * vectors and cannot be built here, so the only reference-derived answers are the
+ * known-answer vectors of SURVEY.md section 8(c) (repair symbols / SHA-256 for K=10/100/1024/8192 and the
+ * reference planner's schedule statistics, recorded during the survey from the reference's own lib/*.c).
+ * They are committed as tests/golden/survey_kat.json and checked in tests/test_golden.py /
+ * tests/test_oracle_kat.py together with RFC 6330's systematic property.  tests/golden/oracle_vectors.json
+ * (tools/gen_golden.py) is produced BY this oracle: it pins the HIP path and later edits of this file, not
+ * the reference.  Beyond the section 8(c) answers parity rests on uniqueness of the solution of A*C = D.
  */
 #define _GNU_SOURCE
 #include <stdint.h>
