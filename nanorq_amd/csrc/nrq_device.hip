@@ -86,7 +86,9 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
  * the CU to itself (3 waves per SIMD, 168 registers).  The 256-thread variant puts one wave on every SIMD, so WV is
  * also the number of workgroups a CU holds: 4 (128 registers) or, when the LDS images are small enough for 5
  * workgroups, 5 (96 registers, a few more spills).  Left to itself the compiler took 207 registers: 2 workgroups. */
-template <int WB, int NT, int WV>
+/* G > 1: WIDE strips -- an element is G adjacent 16-byte columns, one lane each (solve_body.h): thread t is lane t % G of
+ * virtual thread t / G, and every phase runs on the NT / G virtual threads.  For small blocks. */
+template <int WB, int NT, int WV, int G = 1>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WV)))
 void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
                                                        uint32_t T, uint32_t nstrips, uint32_t by_block, uint32_t nslots,
@@ -98,7 +100,11 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
   const uint32_t tid = threadIdx.x;
   /* NFW waves run the forward passes (two, half the strip width each, when the strip is wide enough and the workgroup
    * big enough to spare a second SIMD); the waves on the other SIMDs move data meanwhile: NGW gather, NSW scatter */
-  constexpr uint32_t SPL = 128u / WB, NFW = (WB >= 8 && NT >= 512) ? 2u : 1u,
+  static_assert(G == 1 || WB == 16, "wide strips are made of 16-byte lanes");
+  constexpr uint32_t WBE = (uint32_t)WB * G; /* bytes of a strip */
+  const uint32_t vt = tid / G, subl = tid % G; /* virtual thread, lane inside it */
+  constexpr uint32_t VNT = NT / G;
+  constexpr uint32_t SPL = WBE >= 128u ? 1u : 128u / WBE, NFW = (G == 1 && WB >= 8 && NT >= 512) ? 2u : 1u,
                      NMV = (NT / 64u) / 4u * (4u - NFW) + ((NT / 64u) % 4u > NFW ? (NT / 64u) % 4u - NFW : 0u),
                      NGW = NMV >= 6u ? 3u : NMV >= 3u ? 2u : 1u, NSW = NMV >= 6u ? 3u : NMV - NGW;
   static_assert(NMV >= 2u || NT == 64, "workgroup too small for the data movers");
@@ -145,7 +151,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
     GroupSrc<WB> g0;
     uint32_t b0;
     group_src(q, g0, &b0);
-    pf_gather<WB>(g0, stage0, stage_stride, 0u, g0.M << lsub, tid, NT); /* the first group: nothing to overlap it with */
+    pf_gather<WB, G>(g0, stage0, stage_stride, 0u, g0.M << lsub, (tid) / G, (NT) / G, subl); /* the first group: nothing to overlap it with */
     __syncthreads();
   }
   while (q < nslots) {
@@ -172,20 +178,20 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       const uint32_t sm = NT > NRQ_HDPC_NT_ ? s1 - (uint32_t)((uint64_t)(s1 - s0) * NRQ_SCATTER_LATE_PCT / 100u) : s1;
       const uint32_t strip = strip0 + sidx;
       if (strip >= nstrips) { /* no such strip: everybody moves this portion */
-        if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid, NT);
-        if (s1 > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, s1, tid, NT);
+        if (u1 > u0) pf_gather<WB, G>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (NT) / G, subl);
+        if (s1 > s0) pf_scatter<WB, G>(gp, ostage_prv, ostage_stride, s0, s1, (tid) / G, (NT) / G, subl);
         continue;
       }
-      StripCtx<WB> c;
+      StripCtx<WB, G> c;
       c.job = jobs + blk;
       c.plan = reinterpret_cast<const uint8_t *>(c.job->plan);
       c.h = reinterpret_cast<const nrq_plan_hdr *>(c.plan);
       c.kc = kc;
-      c.lds = smem;
-      c.lay = nrq_lds_plan(c.h, WB);
+      c.lds = smem + subl * WB;
+      c.lay = nrq_lds_plan(c.h, WBE);
       c.T = T;
       c.strip = strip;
-      const uint32_t rem = T - strip * WB;
+      const uint32_t at = strip * WBE + subl * WB, rem = at < T ? T - at : 0u;
       c.valid = rem < (uint32_t)WB ? rem : (uint32_t)WB;
       /* NRQ_PROF=1 debugging aid: shader-clock stamps at phase boundaries, the 10th strip of every 16th workgroup */
       unsigned long long *stamp = nullptr;
@@ -196,8 +202,8 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       c.dbg_t0 = tid == 0;
       done++;
       NRQ_STAMP(0);
-      pf_commit<WB>(c, stage_cur + (size_t)sidx * stage_stride, 0u, tid, NT);
-      ph_clear<WB>(c, tid, NT);
+      pf_commit<WB, G>(c, stage_cur + (size_t)sidx * stage_stride + subl * WB, 0u, vt, VNT);
+      ph_clear<WB, G>(c, vt, VNT);
       __syncthreads();
       NRQ_STAMP(1);
 
@@ -206,13 +212,16 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
        * pipeline would delay the op words wave 0 is waiting for */
       const uint32_t wv = tid >> 6;
       if constexpr (NT == 64) {
-        fwd_rows<WB>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
-        if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, tid, 64u);
-        if (sm > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, sm, tid, 64u);
+        if constexpr (G > 1) fwd_rows_wide<G>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
+        else fwd_rows<WB>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
+        if (u1 > u0) pf_gather<WB, G>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (64u) / G, subl);
+        if (sm > s0) pf_scatter<WB, G>(gp, ostage_prv, ostage_stride, s0, sm, (tid) / G, (64u) / G, subl);
       } else if (wv < NFW) {
         __builtin_amdgcn_s_setprio(3); /* the critical waves: ahead of the others at instruction issue */
         const NRQ_GAS uint32_t *ops_ = c.template arr<uint32_t>(c.h->off_ops);
-        if constexpr (NFW == 2u) { /* one half of the strip width each */
+        if constexpr (G > 1) {
+          fwd_rows_wide<G>(ops_, c.h->nrows, tid);
+        } else if constexpr (NFW == 2u) { /* one half of the strip width each */
           if (wv == 0u) fwd_rows_half<WB, 0>(ops_, c.h->nrows, tid);
           else fwd_rows_half<WB, WB / 2>(ops_, c.h->nrows, tid & 63u);
         } else {
@@ -223,10 +232,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       } else if ((wv & 3u) >= NFW) { /* the waves that do not share a SIMD with the forward waves; index among them: */
         const uint32_t mv = (wv >> 2) * (4u - NFW) + (wv & 3u) - NFW;
         if (mv < NGW) {
-          if (u1 > u0) pf_gather<WB>(gn, stage_nxt, stage_stride, u0, u1, mv * 64u + (tid & 63u), NGW * 64u);
+          if (u1 > u0) pf_gather<WB, G>(gn, stage_nxt, stage_stride, u0, u1, (mv * 64u + (tid & 63u)) / G, (NGW * 64u) / G, subl);
           NRQ_MARK_MAX(c, 2);
         } else if (mv < NGW + NSW) {
-          if (sm > s0) pf_scatter<WB>(gp, ostage_prv, ostage_stride, s0, sm, (mv - NGW) * 64u + (tid & 63u), NSW * 64u);
+          if (sm > s0) pf_scatter<WB, G>(gp, ostage_prv, ostage_stride, s0, sm, ((mv - NGW) * 64u + (tid & 63u)) / G, (NSW * 64u) / G, subl);
           NRQ_MARK_MAX(c, 3);
         }
       }
@@ -235,38 +244,38 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
 
       {
         constexpr uint32_t HNT = NT < NRQ_HDPC_NT_ ? NT : NRQ_HDPC_NT_;
-        if (tid < HNT) ph_hdpc<WB>(c, tid, HNT);
-        else if (s1 > sm) pf_scatter<WB>(gp, ostage_prv, ostage_stride, sm, s1, tid - HNT, NT - HNT); /* the waves HDPC leaves idle */
+        if (tid < HNT) ph_hdpc<WB, G>(c, tid / G, HNT / G);
+        else if (s1 > sm) pf_scatter<WB, G>(gp, ostage_prv, ostage_stride, sm, s1, (tid - HNT) / G, (NT - HNT) / G, subl); /* the waves HDPC leaves idle */
       }
       __syncthreads();
-      ph_hdpc_reduce<WB>(c, tid, NT);
+      ph_hdpc_reduce<WB, G>(c, vt, VNT);
       __syncthreads();
       NRQ_STAMP(3);
       NRQ_STAMP(4);
-      ph_dense_fold<WB>(c, tid, NT);
+      ph_dense_fold<WB, G>(c, vt, VNT);
       __syncthreads();
-      if (dense_fold_shared(NT)) { /* (then the fold leaves its products in the accumulator copies) */
-        ph_hdpc_reduce<WB>(c, tid, NT);
+      if (dense_fold_shared(VNT) || G > 1) { /* (then the fold leaves its products in the accumulator copies) */
+        ph_hdpc_reduce<WB, G>(c, vt, VNT);
         __syncthreads();
       }
-      ph_dense_free<WB>(c, tid, NT);
+      ph_dense_free<WB, G>(c, vt, VNT);
       __syncthreads();
-      ph_dense_cu<WB>(c, tid, NT);
+      ph_dense_cu<WB, G>(c, vt, VNT);
       __syncthreads();
       NRQ_STAMP(5);
       if (ybuf) { /* split solve (narrow strips): back-substitution and results are nrq_backsub_kernel / nrq_collect_kernel */
         NRQ_STAMP(6);
         NRQ_STAMP(7);
-        ph_store_raw<WB>(c, ostage_cur + (size_t)sidx * ostage_stride, tid, NT);
+        ph_store_raw<WB, G>(c, ostage_cur + (size_t)sidx * ostage_stride + subl * WB, vt, VNT);
       } else {
-        ph_tables<WB>(c, tid, NT);
+        ph_tables<WB, G>(c, vt, VNT);
         __syncthreads();
         NRQ_STAMP(6);
-        ph_backsub<WB>(c, tid, NT);
-        ph_park<WB>(c, tid, NT);
+        ph_backsub<WB, G>(c, vt, VNT);
+        ph_park<WB, G>(c, vt, VNT);
         __syncthreads();
         NRQ_STAMP(7);
-        ph_store<WB>(c, ostage_cur + (size_t)sidx * ostage_stride, tid, NT);
+        ph_store<WB, G>(c, ostage_cur + (size_t)sidx * ostage_stride + subl * WB, vt, VNT);
       }
       __syncthreads();
       NRQ_STAMP(8);
@@ -281,7 +290,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
   if (qp < nslots) {
     GroupDst<WB> gp;
     const uint32_t units_p = group_dst(qp, gp) << lsub;
-    pf_scatter<WB>(gp, ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride, ostage_stride, 0u, units_p, tid, NT);
+    pf_scatter<WB, G>(gp, ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride, ostage_stride, 0u, units_p, (tid) / G, (NT) / G, subl);
   }
 }
 
@@ -641,6 +650,7 @@ struct Tuning {
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
   uint32_t encplan_dev_min_l = 12000; /* NRQ_ENCPLAN_DEV_MIN_L: from this many intermediate symbols on, encode plans are built by
                               * the device planner, asynchronously (the host planner takes 25 ms at K=27000, 95 ms at K'=56403) */
+  uint32_t wide_g = 0;       /* NRQ_WIDE_G: wide strips of G = 2, 4, 8 lanes per element where two such images fit a CU */
   bool no_tiny = false;      /* NRQ_NO_TINY: no single-wave workgroups for tiny strip images */
   uint32_t tiny_div = 12;    /* NRQ_TINY_DIV: LDS images per CU from which the single-wave variant is used */
   bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
@@ -655,6 +665,8 @@ struct Tuning {
     small_div = (uint32_t)num("NRQ_SMALL_DIV", 2); solve_grid = (uint64_t)num("NRQ_SOLVE_GRID", 0);
     max_wb = (uint32_t)num("NRQ_MAX_WB", 16); prof_base = (int)num("NRQ_PROF_BASE", 2);
     encplan_dev_min_l = (uint32_t)num("NRQ_ENCPLAN_DEV_MIN_L", 12000);
+    wide_g = (uint32_t)num("NRQ_WIDE_G", 0);
+    if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
     no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
   }
@@ -989,25 +1001,39 @@ void build_out_lists(const rq_params &p, const uint16_t *colslot, uint32_t n, co
 
 template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, uint32_t nblk, uint32_t T,
                                 const uint8_t *d_kc, uint32_t lds_bytes, uint32_t max_slots, uint32_t max_out, uint32_t max_u,
-                                uint32_t max_wpr) {
+                                uint32_t max_wpr, const std::vector<const nrq_plan_hdr *> &hdrs) {
+  /* WIDE strips (G lanes per element, 16 * G bytes per strip; solve_body.h) -- an experiment for small blocks, whose levels
+   * hold a dozen ops and whose HDPC / dense phases a dozen rows, so that most lanes of a wave idle through them on a
+   * 16-byte strip.  Measured (K=100 / 500 / 1000, G = 8 / 4 / 2, two or three 256-thread workgroups per CU): 270-313 /
+   * 600-619 / 727-731 Gbit/s against 326 / 613 / 881 with 16-byte strips: the LDS holds the same number of symbol bytes
+   * either way, a strip's chain of phases is no shorter for being wider, and G x fewer virtual threads make its
+   * per-thread loops longer.  Not selected automatically; NRQ_WIDE_G / "wide_g" forces it (tests keep it correct). */
+  uint32_t G = 1;
+  if (WB == 16 && ctx->tune.wide_g > 1u && T >= 16u * ctx->tune.wide_g) {
+    uint32_t need = 0;
+    for (const nrq_plan_hdr *h : hdrs)
+      if (!h->status) { const uint32_t t = nrq_lds_plan(h, 16u * ctx->tune.wide_g).total; if (t > need) need = t; }
+    if (need * 2u <= NRQ_LDS_MAX) { G = ctx->tune.wide_g; lds_bytes = need; }
+  }
+  const uint32_t WBE = WB * G;
   /* narrow strips: the solve kernel stops after the dense stage, nrq_backsub_kernel / nrq_collect_kernel finish on
    * full-width rows of a per-block work buffer (see there) */
   const bool split = WB <= 4 && !ctx->tune.no_split;
   const uint32_t res_elems = max_out; /* rows nrq_collect_kernel writes per block at most */
   if (split) max_out = max_slots + max_u;
-  const uint32_t nstrips = (T + WB - 1) / WB, spl = 128u / WB;
+  const uint32_t nstrips = (T + WBE - 1) / WBE, spl = WBE >= 128u ? 1u : 128u / WBE;
   const bool by_block = nrq_map_by_block(nblk) && !ctx->tune.map_spread;
   /* workgroup shape: the full-size workgroup when a strip image needs more than half of the CU's LDS, 256-thread ones
    * when two or more fit */
   const bool small = lds_bytes * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg;
   /* single-wave workgroups when 12 or more images fit a CU (see the kernel; K=256: +26 % over five 256-thread workgroups) */
-  const bool tiny = small && (uint64_t)lds_bytes * ctx->tune.tiny_div <= NRQ_LDS_MAX && !ctx->tune.no_tiny;
+  const bool tiny = G == 1 && small && (uint64_t)lds_bytes * ctx->tune.tiny_div <= NRQ_LDS_MAX && !ctx->tune.no_tiny;
   const uint32_t nt = tiny ? 64u : small ? 256u : (uint32_t)NRQ_WG;
   uint32_t occ = NRQ_LDS_MAX / (lds_bytes ? lds_bytes : 1u);
   if (occ > 2048u / nt) occ = 2048u / nt;
   /* registers: the 256-thread variant (one wave per SIMD) is compiled for NRQ_SMALL_WAVES waves per SIMD.  More
    * workgroups than are resident at once would run as a second, thinner round of a statically partitioned job. */
-  const bool five = small && !tiny && occ >= 5u && !ctx->tune.small_waves4;
+  const bool five = G == 1 && small && !tiny && occ >= 5u && !ctx->tune.small_waves4;
   if (tiny) { if (occ > 18u) occ = 18u; } /* one wave per workgroup, compiled for 5 waves per SIMD; 20 per CU by the LDS sum, but
                                               * measured: with 20 x 256 workgroups not all are resident and the rest runs as a second
                                               * round (10.4 ms against 8.7 ms with 18 x 256 at K=100, T=1024, 8192 blocks) */
@@ -1056,7 +1082,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   if (grid > nslots) grid = by_block ? (nslots + 7) / 8 * 8 : nslots;
   /* per workgroup: two sets of `spl` input staging buffers (the line group being solved, the one being gathered)
    * and two sets of `spl` output staging buffers (the group being solved, the one being scattered) */
-  const uint32_t stage_stride = (max_slots * WB + 255u) & ~255u, ostage_stride = (max_out * WB + 255u) & ~255u;
+  const uint32_t stage_stride = (max_slots * WBE + 255u) & ~255u, ostage_stride = (max_out * WBE + 255u) & ~255u;
   {
     int rc_ = ensure_dev(ctx, ctx->stage, (size_t)grid * 2u * spl * ((size_t)stage_stride + ostage_stride));
     if (rc_) return rc_;
@@ -1082,6 +1108,14 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 64, 5>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    if constexpr (WB == 16) {
+      HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<16, 256, 4, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+      HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<16, 256, 4, 4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+      HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<16, 256, 4, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    }
     ctx->attr_set[slot] = true;
   }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1103,7 +1137,14 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     HIPCHK(ctx, hipMalloc((void **)&ctx->prof, (size_t)nprof * 16 * 8));
     HIPCHK(ctx, hipMemsetAsync(ctx->prof, 0, (size_t)nprof * 16 * 8, ctx->stream));
   }
-  if (tiny)
+#define NRQ_LAUNCH_WIDE(GG)                                                                                                          \
+  hipLaunchKernelGGL((nrq_solve_kernel<16, 256, 4, GG>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips, \
+                     by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof,     \
+                     ybuf, ybuf_stride)
+  if (WB == 16 && G == 8) { if constexpr (WB == 16) NRQ_LAUNCH_WIDE(8); }
+  else if (WB == 16 && G == 4) { if constexpr (WB == 16) NRQ_LAUNCH_WIDE(4); }
+  else if (WB == 16 && G == 2) { if constexpr (WB == 16) NRQ_LAUNCH_WIDE(2); }
+  else if (tiny)
     hipLaunchKernelGGL((nrq_solve_kernel<WB, 64, 5>), dim3((uint32_t)grid), dim3(64), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
                        by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
   else if (five)
@@ -1165,7 +1206,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     (void)hipFree(ctx->prof);
     ctx->prof = nullptr;
   }
-  ctx->stats.strip_bytes = WB;
+  ctx->stats.strip_bytes = WBE;
   ctx->stats.lds_bytes = lds_bytes;
   ctx->stats.grid = (uint32_t)grid;
   ctx->stats.wg_threads = nt;
@@ -1197,10 +1238,10 @@ int pick_and_launch(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hdrs,
     if (need == 0) return 0; /* nothing solvable in this batch */
     if (need > NRQ_LDS_MAX) continue;
     switch (widths[s]) {
-      case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr);
-      case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr);
-      case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr);
-      default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr);
+      case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr, hdrs);
+      case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr, hdrs);
+      case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr, hdrs);
+      default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr, hdrs);
     }
   }
   return fail(ctx, -5, "block too large for the LDS-resident solver");
@@ -1353,6 +1394,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   if (n == "max_wb") t.max_wb = (uint32_t)value;
   else if (n == "no_split") t.no_split = value != 0;
   else if (n == "no_tiny") t.no_tiny = value != 0;
+  else if (n == "wide_g") t.wide_g = (value == 2 || value == 4 || value == 8) ? (uint32_t)value : 0u;
   else if (n == "tiny_div") t.tiny_div = (uint32_t)value;
   else if (n == "no_balance") t.no_balance = value != 0;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;

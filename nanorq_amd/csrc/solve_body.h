@@ -125,11 +125,15 @@ template <int WB> SB_HD SV<WB> sv_mul(SV<WB> v, uint32_t coef) {
   return acc;
 }
 
-/* ---- LDS access (plain memory in the emulator) ---- */
-template <int WB> SB_HD SV<WB> lds_get(const uint8_t *lds, uint32_t idx) {
+/* ---- LDS access (plain memory in the emulator) ----
+ * G > 1 ("wide strips", 16-byte lanes only): an element is G adjacent 16-byte columns, each handled by its own lane;
+ * element idx of lane `sub` lies at base + idx * (16 * G) + sub * 16 -- the lane's column offset is folded into the
+ * base pointer (StripCtx), the accessors only scale the index. */
+template <int WB, int G = 1> SB_HD SV<WB> lds_get(const uint8_t *lds, uint32_t idx) {
+  static_assert(G == 1 || WB == 16, "wide strips are made of 16-byte lanes");
   SV<WB> r;
   if constexpr (WB == 16) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(lds) + idx;
+    const uint4 *p = reinterpret_cast<const uint4 *>(lds) + (size_t)idx * G;
     uint4 v = *p;
     r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
   } else if constexpr (WB == 8) {
@@ -143,10 +147,11 @@ template <int WB> SB_HD SV<WB> lds_get(const uint8_t *lds, uint32_t idx) {
   }
   return r;
 }
-template <int WB> SB_HD void lds_put(uint8_t *lds, uint32_t idx, const SV<WB> &v) {
+template <int WB, int G = 1> SB_HD void lds_put(uint8_t *lds, uint32_t idx, const SV<WB> &v) {
+  static_assert(G == 1 || WB == 16, "wide strips are made of 16-byte lanes");
   if constexpr (WB == 16) {
     uint4 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2]; t.w = v.w[3];
-    reinterpret_cast<uint4 *>(lds)[idx] = t;
+    reinterpret_cast<uint4 *>(lds)[(size_t)idx * G] = t;
   } else if constexpr (WB == 8) {
     uint2 t; t.x = v.w[0]; t.y = v.w[1];
     reinterpret_cast<uint2 *>(lds)[idx] = t;
@@ -157,10 +162,11 @@ template <int WB> SB_HD void lds_put(uint8_t *lds, uint32_t idx, const SV<WB> &v
   }
 }
 /* slot ^= v, safe against other threads of the workgroup doing the same to the same slot */
-template <int WB> SB_HD void lds_xor(uint8_t *lds, uint32_t idx, const SV<WB> &v) {
+template <int WB, int G = 1> SB_HD void lds_xor(uint8_t *lds, uint32_t idx, const SV<WB> &v) {
+  static_assert(G == 1 || WB == 16, "wide strips are made of 16-byte lanes");
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (WB == 16) {
-    unsigned long long *p = reinterpret_cast<unsigned long long *>(lds) + 2 * (size_t)idx;
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(lds) + 2 * (size_t)idx * G;
     atomicXor(p, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32));
     atomicXor(p + 1, (unsigned long long)v.w[2] | ((unsigned long long)v.w[3] << 32));
   } else if constexpr (WB == 8) {
@@ -172,9 +178,9 @@ template <int WB> SB_HD void lds_xor(uint8_t *lds, uint32_t idx, const SV<WB> &v
     atomicXor(reinterpret_cast<unsigned int *>(lds) + (idx >> 1), v.w[0] << ((idx & 1u) * 16u));
   }
 #else
-  SV<WB> t = lds_get<WB>(lds, idx);
+  SV<WB> t = lds_get<WB, G>(lds, idx);
   sv_xor<WB>(t, v);
-  lds_put<WB>(lds, idx, t);
+  lds_put<WB, G>(lds, idx, t);
 #endif
 }
 
@@ -308,7 +314,9 @@ SB_HD nrq_lds_layout nrq_lds_plan(const nrq_plan_hdr *h, uint32_t WB) {
 }
 
 /* ---- per-workgroup context (uniform across the threads of a strip) ---- */
-template <int WB> struct StripCtx {
+/* (G > 1: `lds` already carries the lane's column offset sub * 16, `lay` is the layout of the 16*G-byte wide image, `valid`
+ * the bytes of the lane's own column inside T, and the staging pointers the kernel passes to the phases are offset alike) */
+template <int WB, int G = 1> struct StripCtx {
   const uint8_t *plan;
   const nrq_plan_hdr *h;
   const uint8_t *kc; /* nrq_kconst_hdr arena of this K' */
@@ -341,8 +349,9 @@ template <int WB> struct GroupSrc { /* where the rows of one line group of one b
   uint32_t M, T, strip0, nstrips; /* first strip of the group; strips of the block */
   uint32_t lsub;                  /* log2 of the strips the group has (a whole line: 128/WB; fewer when work is scarce) */
 };
-template <int WB> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
-                                       uint32_t p, uint32_t np) {
+/* (G > 1: a unit is moved by the G lanes of a virtual thread p of np; `sub` is the lane's 16-byte column of the wide strip) */
+template <int WB, int G = 1> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
+                                       uint32_t p, uint32_t np, uint32_t sub = 0) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u; /* unit u = (row u >> lsub, piece u & pmask) */
 #ifndef NRQ_GATHER_PB
 #define NRQ_GATHER_PB 4
@@ -363,18 +372,18 @@ template <int WB> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *s
       v[q] = sv_zero<WB>();
       if (s[q] != NRQ_ROW_ZERO && strip < g.nstrips) {
         const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? g.rep + (size_t)(s[q] & 0x7FFFFFFFu) * g.T : g.src + (size_t)s[q] * g.T;
-        const uint32_t rem = g.T - strip * WB;
-        v[q] = g_get_stream<WB>(b + (size_t)strip * WB, rem < (uint32_t)WB ? rem : (uint32_t)WB);
+        const uint32_t at = strip * (WB * G) + sub * WB, rem = at < g.T ? g.T - at : 0u;
+        if (rem) v[q] = g_get_stream<WB>(b + at, rem < (uint32_t)WB ? rem : (uint32_t)WB);
       }
     }
 #pragma unroll
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np;
-      if (u < u1) g_put_stream<WB>(stage + (size_t)(u & pmask) * stage_stride + (size_t)(u >> lsub) * WB, WB, v[q]);
+      if (u < u1) g_put_stream<WB>(stage + (size_t)(u & pmask) * stage_stride + (size_t)(u >> lsub) * (WB * G) + sub * WB, WB, v[q]);
     }
   }
 }
-template <int WB> SB_HD void pf_commit(const StripCtx<WB> &c, const NRQ_GAS uint8_t *stage, uint32_t r0, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void pf_commit(const StripCtx<WB, G> &c, const NRQ_GAS uint8_t *stage, uint32_t r0, uint32_t tid, uint32_t nt) {
   constexpr int PB = 4;
   const uint32_t M = c.h->M;
   for (uint32_t base = r0 + tid; base < M; base += PB * nt) {
@@ -382,22 +391,22 @@ template <int WB> SB_HD void pf_commit(const StripCtx<WB> &c, const NRQ_GAS uint
 #pragma unroll
     for (int q = 0; q < PB; q++) {
       const uint32_t r = base + (uint32_t)q * nt;
-      v[q] = r < M ? g_get_l2<WB>(stage + (size_t)r * WB) : sv_zero<WB>();
+      v[q] = r < M ? g_get_l2<WB>(stage + (size_t)r * (WB * G)) : sv_zero<WB>();
     }
 #pragma unroll
     for (int q = 0; q < PB; q++) {
       const uint32_t r = base + (uint32_t)q * nt;
-      if (r < M) lds_put<WB>(c.slots(), r, v[q]);
+      if (r < M) lds_put<WB, G>(c.slots(), r, v[q]);
     }
   }
 }
-template <int WB> SB_HD void ph_clear(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void ph_clear(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const uint32_t M = c.h->M;
-  for (uint32_t p = tid; p < NRQ_SCRATCH; p += nt) lds_put<WB>(c.lds, p, sv_zero<WB>());
-  for (uint32_t p = tid; p < c.h->r2; p += nt) lds_put<WB>(c.slots(), M + p, sv_zero<WB>());
+  for (uint32_t p = tid; p < NRQ_SCRATCH; p += nt) lds_put<WB, G>(c.lds, p, sv_zero<WB>());
+  for (uint32_t p = tid; p < c.h->r2; p += nt) lds_put<WB, G>(c.slots(), M + p, sv_zero<WB>());
   /* region X starts as the private HDPC accumulators (ph_hdpc), which ph_hdpc_reduce leaves zeroed for Cf */
-  const uint32_t nx = (c.lay.total - c.lay.off_x) / WB;
-  for (uint32_t f = tid; f < nx; f += nt) lds_put<WB>(c.cf(), f, sv_zero<WB>());
+  const uint32_t nx = (c.lay.total - c.lay.off_x) / (WB * G);
+  for (uint32_t f = tid; f < nx; f += nt) lds_put<WB, G>(c.cf(), f, sv_zero<WB>());
 }
 
 /* phases 1+2: the forward passes (X^-1 on the peeled rows, the leftover rows, the GF(2) combinations of the
@@ -515,7 +524,62 @@ template <int WB, int OFF> __device__ __forceinline__ void fwd_rows_half(const N
     }
   }
 }
+/* The forward passes on a WIDE strip (G lanes per op, 16 bytes each; lane = op * G + sub): a row of 64 op slots is G
+ * wave instructions of 64 / G ops.  Ops of one row never read what the row writes (plan.h), so a row is: fetch the G
+ * source pieces, then the G XORs; instructions whose 64 / G ops are all padding are skipped (the planners fill a row from
+ * the front, so a thin level costs one or two instructions, not a row), and so are the NRQ_RING lead rows.  For small
+ * blocks: their levels hold a dozen ops, which leaves most of a 64-op row's lanes empty on a 16-byte strip. */
+template <int G> __device__ __forceinline__ void fwd_rows_wide(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
+  constexpr uint32_t NV = NRQ_ROW / G, SH = G == 8 ? 7u : G == 4 ? 6u : G == 2 ? 5u : 4u; /* log2(16 * G) */
+  constexpr uint32_t R = 32u; /* op words held in registers: instructions (of NV ops) fetched that far ahead -- like
+                               * fwd_rows' ring: every register is reloaded right after its instruction has run, so the loads
+                               * stay outstanding across the LDS work (a load per row that is waited for in the next row is a trip
+                               * to L2 per row: measured 390 clocks per row) */
+  static_assert(R % G == 0, "whole rows in the ring");
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const uint32_t vl = lane / G, subofs = (lane % G) * 16u;
+  const NRQ_GAS uint32_t *p = ops + vl;
+  const uint32_t s0 = (NRQ_RING < nrows ? NRQ_RING : nrows) * G, S = nrows * G; /* instructions; the lead rows are all padding */
+  uint32_t o[R];
+#pragma unroll
+  for (uint32_t k = 0; k < R; k++) o[k] = p[(size_t)(s0 + k) * NV];
+  /* software pipeline, one row deep: the sources of row r + 1 are fetched before row r is applied (rows that follow
+   * each other never depend on each other, plan.h), so an LDS round trip is not exposed per row */
+  bool live[2][G];
+  u4 v[2][G];
+#pragma unroll
+  for (uint32_t s = 0; s < (uint32_t)G; s++) { live[1][s] = false; v[1][s] = u4{0u, 0u, 0u, 0u}; }
+  uint32_t oa[G]; /* op words of the row being applied (its ring entries are reloaded meanwhile) */
+#pragma unroll
+  for (uint32_t s = 0; s < (uint32_t)G; s++) oa[s] = 0u;
+  for (uint32_t base = s0; base < S + G; base += R) { /* (runs up to R - 1 instructions into the padding rows: all skipped) */
+#pragma unroll
+    for (uint32_t g0 = 0; g0 < R; g0 += G) { /* read row (base + g0) / G, apply the row before it */
+      constexpr uint32_t dummy = 0;
+      (void)dummy;
+      const uint32_t cur = (g0 / G) & 1u, prv = cur ^ 1u;
+#pragma unroll
+      for (uint32_t s = 0; s < (uint32_t)G; s++) {
+        live[cur][s] = __ballot(!NRQ_OP_IS_NOP(o[g0 + s])) != 0ull;
+        if (live[cur][s]) v[cur][s] = *NRQ_LDSP(u4, ((o[g0 + s] >> 16) << SH) + subofs);
+      }
+#pragma unroll
+      for (uint32_t s = 0; s < (uint32_t)G; s++) {
+        if (live[prv][s]) {
+          const uint32_t a = ((oa[s] & 0xFFFFu) << SH) + subofs;
+          const u2 lo = {v[prv][s].x, v[prv][s].y}, hi = {v[prv][s].z, v[prv][s].w};
+          __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a + 8u), __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        oa[s] = o[g0 + s];
+        o[g0 + s] = p[(size_t)(base + g0 + s + R) * NV]; /* (the stream is padded by NRQ_PAD_ROWS: in bounds) */
+      }
+    }
+  }
+}
 #else
+template <int G> SB_HD void fwd_rows_wide(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
 template <int WB> struct RowVal { typedef SV<WB> type; };
 template <int WB> SB_HD SV<WB> ph_row_read(const StripCtx<WB> &c, uint32_t op) { return lds_get<WB>(c.lds, op >> 16); }
 template <int WB> SB_HD void ph_row_apply(const StripCtx<WB> &c, uint32_t op, const SV<WB> &v) {
@@ -535,32 +599,32 @@ template <int WB, int OFF> SB_HD void fwd_rows_half(const NRQ_GAS uint32_t *, ui
  * accumulators are private per lane (nsets copies of the H sums in region X, free until the dense
  * stage): all threads XORing into the same H slots made this phase one long LDS atomic conflict.
  * ph_hdpc_reduce folds the copies into the HDPC slots and zeroes them again. */
-template <int WB> SB_HD uint32_t hdpc_nsets(const StripCtx<WB> &c) {
-  const uint32_t cap = (c.lay.total - c.lay.off_x) / (c.h->H * WB);
+template <int WB, int G = 1> SB_HD uint32_t hdpc_nsets(const StripCtx<WB, G> &c) {
+  const uint32_t cap = (c.lay.total - c.lay.off_x) / (c.h->H * WB * G);
   uint32_t n = 1;
   while (n * 2u <= cap && n < 64u) n *= 2u;
   return n;
 }
-template <int WB> SB_HD void ph_hdpc_reduce(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
-  const uint32_t H = c.h->H, nsets = hdpc_nsets<WB>(c);
+template <int WB, int G = 1> SB_HD void ph_hdpc_reduce(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+  const uint32_t H = c.h->H, nsets = hdpc_nsets<WB, G>(c);
   const uint32_t hq = tid & 15u, part = tid >> 4, nparts = nt >> 4;
   if (hq >= H) return;
   SV<WB> acc = sv_zero<WB>();
   bool any = false;
   for (uint32_t s = part; s < nsets; s += nparts) {
-    sv_xor<WB>(acc, lds_get<WB>(c.cf(), s * H + hq));
-    lds_put<WB>(c.cf(), s * H + hq, sv_zero<WB>());
+    sv_xor<WB>(acc, lds_get<WB, G>(c.cf(), s * H + hq));
+    lds_put<WB, G>(c.cf(), s * H + hq, sv_zero<WB>());
     any = true;
   }
-  if (any) lds_xor<WB>(c.slots(), c.h->S + hq, acc);
+  if (any) lds_xor<WB, G>(c.slots(), c.h->S + hq, acc);
 }
-template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void ph_hdpc(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(c.kc);
-  const NRQ_GAS uint8_t *G = gptr<uint8_t>(c.kc + kh->off_g);
+  const NRQ_GAS uint8_t *Gm = gptr<uint8_t>(c.kc + kh->off_g); /* the HDPC block */
   const NRQ_GAS uint8_t *b12 = gptr<uint8_t>(c.kc + kh->off_b12);
   const NRQ_GAS uint16_t *pivof = c.template arr<uint16_t>(c.h->off_pivof);
   const uint32_t n = kh->n, H = c.h->H;
-  const uint32_t mine = (tid & (hdpc_nsets<WB>(c) - 1u)) * H; /* this lane's copy of the H accumulators */
+  const uint32_t mine = (tid & (hdpc_nsets<WB, G>(c) - 1u)) * H; /* this lane's copy of the H accumulators */
   /* chunks of whole 8-column groups, as equal as possible; the threads that take one group more are the FIRST
    * ones, so that a single wave (not one lane of every wave) runs the longer loop */
   const uint32_t groups = (n + 7u) / 8u, base = groups / nt, extra = groups - base * nt;
@@ -583,17 +647,17 @@ template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32
       const uint32_t s = (slw[q >> 1] >> ((q & 1u) * 16u)) & 0xFFFFu;
       g = sv_xtime<WB>(g);
       if (s != NRQ_NOSLOT) {
-        SV<WB> y = lds_get<WB>(c.slots(), s);
+        SV<WB> y = lds_get<WB, G>(c.slots(), s);
         sv_xor<WB>(g, y);
       }
       if (col + 1 < n) {
         const uint32_t e = (bbw[q >> 2] >> ((q & 3u) * 8u)) & 0xFFu;
-        lds_xor<WB>(c.cf(), mine + (e & 15u), g);
-        lds_xor<WB>(c.cf(), mine + (e >> 4), g);
+        lds_xor<WB, G>(c.cf(), mine + (e & 15u), g);
+        lds_xor<WB, G>(c.cf(), mine + (e >> 4), g);
       } else { /* last column of MT is alpha^h */
         SV<WB> v = g;
         for (uint32_t h = 0; h < H; h++) {
-          lds_xor<WB>(c.cf(), mine + h, v);
+          lds_xor<WB, G>(c.cf(), mine + h, v);
           v = sv_xtime<WB>(v);
         }
       }
@@ -610,22 +674,22 @@ template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32
                        * L2 instead of one per HDPC row; the 256-thread variants have no registers to spare for it */
       uint32_t coef[16]; /* (H <= 16) */
 #pragma unroll
-      for (uint32_t h = 0; h < 16; h++) coef[h] = h < H ? G[(size_t)h * n + b] : 0u;
+      for (uint32_t h = 0; h < 16; h++) coef[h] = h < H ? Gm[(size_t)h * n + b] : 0u;
 #pragma unroll
       for (uint32_t h = 0; h < 16; h++) {
         if (h >= H) break;
         SV<WB> t = sv_zero<WB>();
 #pragma unroll
         for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef[h] >> k) & 1u));
-        lds_xor<WB>(c.cf(), mine + h, t);
+        lds_xor<WB, G>(c.cf(), mine + h, t);
       }
     } else {
       for (uint32_t h = 0; h < H; h++) {
-        const uint32_t coef = G[(size_t)h * n + b];
+        const uint32_t coef = Gm[(size_t)h * n + b];
         SV<WB> t = sv_zero<WB>();
 #pragma unroll
         for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef >> k) & 1u));
-        lds_xor<WB>(c.cf(), mine + h, t);
+        lds_xor<WB, G>(c.cf(), mine + h, t);
       }
     }
   }
@@ -644,26 +708,26 @@ template <int WB> SB_HD void ph_hdpc(const StripCtx<WB> &c, uint32_t tid, uint32
 /* (a single-wave workgroup, nt == 64, also shares the multiples: with one wave the few (h, p) pairs of a small block
  * leave most lanes idle either way, and the general multiply is 3.4x the instructions of the shared form) */
 SB_HD bool dense_fold_shared(uint32_t nt) { return nt >= NRQ_DENSE_SHARED_MIN_NT || nt == 64u; }
-template <int WB> SB_HD void ph_dense_fold(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void ph_dense_fold(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint8_t *mh = c.template arr<uint8_t>(c.h->off_mh);
   const uint32_t H = c.h->H, r2 = c.h->r2, M = c.h->M;
-  if (!dense_fold_shared(nt)) {
+  if (!dense_fold_shared(nt) && G == 1) {
     const uint32_t hq = tid & 15u, part = tid >> 4, nparts = nt >> 4;
     if (hq >= H) return;
     SV<WB> acc = sv_zero<WB>();
     for (uint32_t p = part; p < r2; p += nparts) {
       uint32_t coef = mh[(size_t)hq * r2 + p];
       if (!coef) continue;
-      SV<WB> t = sv_mul<WB>(lds_get<WB>(c.slots(), M + p), coef);
+      SV<WB> t = sv_mul<WB>(lds_get<WB, G>(c.slots(), M + p), coef);
       sv_xor<WB>(acc, t);
     }
-    lds_xor<WB>(c.slots(), c.h->S + hq, acc);
+    lds_xor<WB, G>(c.slots(), c.h->S + hq, acc);
     return;
   }
-  const uint32_t mine = (tid & (hdpc_nsets<WB>(c) - 1u)) * H;
+  const uint32_t mine = (tid & (hdpc_nsets<WB, G>(c) - 1u)) * H;
   for (uint32_t p = tid; p < r2; p += nt) {
     SV<WB> pw[8];
-    pw[0] = lds_get<WB>(c.slots(), M + p);
+    pw[0] = lds_get<WB, G>(c.slots(), M + p);
 #pragma unroll
     for (int k = 1; k < 8; k++) pw[k] = sv_xtime<WB>(pw[k - 1]);
     uint32_t coef[16]; /* (H <= 16) all of them in flight together: one trip to L2, not one per HDPC row */
@@ -675,13 +739,13 @@ template <int WB> SB_HD void ph_dense_fold(const StripCtx<WB> &c, uint32_t tid, 
       SV<WB> t = sv_zero<WB>();
 #pragma unroll
       for (int k = 0; k < 8; k++) sv_xor_masked<WB>(t, pw[k], 0u - ((coef[h] >> k) & 1u));
-      lds_xor<WB>(c.cf(), mine + h, t);
+      lds_xor<WB, G>(c.cf(), mine + h, t);
     }
   }
 }
 
 /* phase 4c: free columns C_f = SUM_h hinv[f][h] * R_h */
-template <int WB> SB_HD void ph_dense_free(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void ph_dense_free(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint8_t *hinv = c.template arr<uint8_t>(c.h->off_hinv);
   const uint32_t H = c.h->H, nfree = c.h->nfree;
   const uint32_t hq = tid & 15u;
@@ -689,32 +753,32 @@ template <int WB> SB_HD void ph_dense_free(const StripCtx<WB> &c, uint32_t tid, 
   for (uint32_t f = tid >> 4; f < nfree; f += nt >> 4) {
     uint32_t coef = hinv[(size_t)f * H + hq];
     if (!coef) continue;
-    SV<WB> t = sv_mul<WB>(lds_get<WB>(c.slots(), c.h->S + hq), coef);
-    lds_xor<WB>(c.cf(), f, t);
+    SV<WB> t = sv_mul<WB>(lds_get<WB, G>(c.slots(), c.h->S + hq), coef);
+    lds_xor<WB, G>(c.cf(), f, t);
   }
 }
 
 /* phase 4d: values of all u inactive columns */
-template <int WB> SB_HD void ph_dense_cu(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void ph_dense_cu(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint16_t *pivx = c.template arr<uint16_t>(c.h->off_pivx);
   const NRQ_GAS uint32_t *fbits = c.template arr<uint32_t>(c.h->off_fbits);
   const NRQ_GAS uint16_t *freex = c.template arr<uint16_t>(c.h->off_freex);
   for (uint32_t p = tid; p < c.h->r2; p += nt) {
-    SV<WB> v = lds_get<WB>(c.slots(), c.h->M + p);
+    SV<WB> v = lds_get<WB, G>(c.slots(), c.h->M + p);
     uint32_t fb = fbits[p];
     while (fb) {
       uint32_t f = (uint32_t)__builtin_ctz(fb);
       fb &= fb - 1u;
-      SV<WB> t = lds_get<WB>(c.cf(), f);
+      SV<WB> t = lds_get<WB, G>(c.cf(), f);
       sv_xor<WB>(v, t);
     }
-    lds_put<WB>(c.cu(), pivx[p], v);
+    lds_put<WB, G>(c.cu(), pivx[p], v);
   }
-  for (uint32_t f = tid; f < c.h->nfree; f += nt) lds_put<WB>(c.cu(), freex[f], lds_get<WB>(c.cf(), f));
+  for (uint32_t f = tid; f < c.h->nfree; f += nt) lds_put<WB, G>(c.cu(), freex[f], lds_get<WB, G>(c.cf(), f));
 }
 
 /* phase 5a: 16-entry XOR tables over groups of 4 inactive columns (region X is reused) */
-template <int WB> SB_HD void ph_tables(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void ph_tables(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const uint32_t ngroups = c.h->wpr * 8u, u = c.h->u;
   for (uint32_t e = tid; e < ngroups * 16u; e += nt) {
     uint32_t grp = e >> 4, nib = e & 15u;
@@ -723,27 +787,27 @@ template <int WB> SB_HD void ph_tables(const StripCtx<WB> &c, uint32_t tid, uint
     for (uint32_t bq = 0; bq < 4; bq++) {
       uint32_t x = grp * 4u + bq;
       if (((nib >> bq) & 1u) && x < u) {
-        SV<WB> t = lds_get<WB>(c.cu(), x);
+        SV<WB> t = lds_get<WB, G>(c.cu(), x);
         sv_xor<WB>(v, t);
       }
     }
-    lds_put<WB>(c.t4(), e, v);
+    lds_put<WB, G>(c.t4(), e, v);
   }
 }
 
 /* phase 5b: back substitution C(pivot k) = Y_k ^ W_k * C_u.  Two pivots per trip with separate
  * register sets: the W words of the second are in flight while the first does its table lookups
  * (no register hand-over between trips, so the compiler can leave the loads outstanding). */
-template <int WB, int NW>
-SB_HD void backsub_one(const StripCtx<WB> &c, const uint8_t *t4, uint32_t slot, const uint32_t (&bitsw)[NW],
+template <int WB, int NW, int G = 1>
+SB_HD void backsub_one(const StripCtx<WB, G> &c, const uint8_t *t4, uint32_t slot, const uint32_t (&bitsw)[NW],
                        uint32_t wpr) {
-  SV<WB> acc = lds_get<WB>(c.slots(), slot);
+  SV<WB> acc = lds_get<WB, G>(c.slots(), slot);
 #pragma unroll
   for (uint32_t w = 0; w < (uint32_t)NW; w++) {
     if (w >= wpr) break; /* tables exist for wpr*8 groups only */
     const uint32_t bits = bitsw[w];
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (WB == 16) {
+    if constexpr (WB == 16 && G == 1) {
       /* the phase is bound by VALU issue and LDS reads about equally (the 4 XORs per lookup are a given): both
        * nibbles of every byte are brought to "16 * nibble" in place with three operations per word, and a table
        * address is ONE byte-select add (the compiler's own sequence is shift, mask, add per lookup).
@@ -766,16 +830,16 @@ SB_HD void backsub_one(const StripCtx<WB> &c, const uint8_t *t4, uint32_t slot, 
 #pragma unroll
     for (uint32_t q = 0; q < 8; q++) {
       const uint32_t nib = (bits >> (4u * q)) & 15u;
-      SV<WB> t = lds_get<WB>(t4, (w * 8u + q) * 16u + nib);
+      SV<WB> t = lds_get<WB, G>(t4, (w * 8u + q) * 16u + nib);
       sv_xor<WB>(acc, t);
       if (q == 3) NRQ_SCHED_FENCE(); /* 4 lookups in flight are enough; hoisting all NW*8 of them costs ~100 more registers */
     }
     NRQ_SCHED_FENCE();
   }
-  lds_put<WB>(c.slots(), slot, acc);
+  lds_put<WB, G>(c.slots(), slot, acc);
 }
 
-template <int WB, int NW> SB_HD void backsub_fixed(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int NW, int G = 1> SB_HD void backsub_fixed(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint16_t *pivslot = c.template arr<uint16_t>(c.h->off_pivslot);
   const NRQ_GAS uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
   const uint32_t wpr = c.h->wpr, stride = c.h->npiv_pad, npiv = c.h->npiv;
@@ -789,17 +853,17 @@ template <int WB, int NW> SB_HD void backsub_fixed(const StripCtx<WB> &c, uint32
     for (uint32_t w = 0; w < (uint32_t)NW; w++) a[w] = w < wpr ? wt[(size_t)w * stride + k] : 0u;
 #pragma unroll
     for (uint32_t w = 0; w < (uint32_t)NW; w++) b[w] = (w < wpr && k2 < npiv) ? wt[(size_t)w * stride + k2] : 0u;
-    backsub_one<WB, NW>(c, t4, sa, a, wpr);
-    if (k2 < npiv) backsub_one<WB, NW>(c, t4, sb, b, wpr);
+    backsub_one<WB, NW, G>(c, t4, sa, a, wpr);
+    if (k2 < npiv) backsub_one<WB, NW, G>(c, t4, sb, b, wpr);
   }
 }
 
-template <int WB> SB_HD void ph_backsub(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void ph_backsub(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const uint32_t wpr = c.h->wpr;
-  if (wpr <= 4) backsub_fixed<WB, 4>(c, tid, nt);
-  else if (wpr <= 8) backsub_fixed<WB, 8>(c, tid, nt);
-  else if (wpr <= 12) backsub_fixed<WB, 12>(c, tid, nt);
-  else if (wpr <= 24) backsub_fixed<WB, 24>(c, tid, nt);
+  if (wpr <= 4) backsub_fixed<WB, 4, G>(c, tid, nt);
+  else if (wpr <= 8) backsub_fixed<WB, 8, G>(c, tid, nt);
+  else if (wpr <= 12) backsub_fixed<WB, 12, G>(c, tid, nt);
+  else if (wpr <= 24) backsub_fixed<WB, 24, G>(c, tid, nt);
   else {
     const NRQ_GAS uint16_t *pivslot = c.template arr<uint16_t>(c.h->off_pivslot);
     const NRQ_GAS uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
@@ -807,33 +871,33 @@ template <int WB> SB_HD void ph_backsub(const StripCtx<WB> &c, uint32_t tid, uin
     const uint8_t *t4 = c.t4();
     for (uint32_t k = tid; k < npiv; k += nt) {
       uint32_t s = pivslot[k];
-      SV<WB> acc = lds_get<WB>(c.slots(), s);
+      SV<WB> acc = lds_get<WB, G>(c.slots(), s);
       for (uint32_t w = 0; w < wpr; w++) {
         uint32_t bits = wt[(size_t)w * stride + k];
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
           uint32_t nib = (bits >> (4u * q)) & 15u;
-          SV<WB> t = lds_get<WB>(t4, (w * 8u + q) * 16u + nib);
+          SV<WB> t = lds_get<WB, G>(t4, (w * 8u + q) * 16u + nib);
           sv_xor<WB>(acc, t);
         }
       }
-      lds_put<WB>(c.slots(), s, acc);
+      lds_put<WB, G>(c.slots(), s, acc);
     }
   }
 }
 
 /* phase 6a: park the inactive columns in the slots the plan reserved for them */
-template <int WB> SB_HD void ph_park(const StripCtx<WB> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void ph_park(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint16_t *uslot = c.template arr<uint16_t>(c.h->off_uslot);
-  for (uint32_t x = tid; x < c.h->u; x += nt) lds_put<WB>(c.slots(), uslot[x], lds_get<WB>(c.cu(), x));
+  for (uint32_t x = tid; x < c.h->u; x += nt) lds_put<WB, G>(c.slots(), uslot[x], lds_get<WB, G>(c.cu(), x));
 }
 
 /* phase 6b: results: intermediate symbols (optional) and generated symbols, into this strip's OUTPUT staging buffer
  * (element i < L: intermediate symbol i, if the job wants them; then the nout generated symbols).  Results leave
  * for their rows in HBM a line group at a time (pf_scatter): written strip by strip, every 16-byte piece would be a
  * partial-line write of its own (measured: 3.7x the bytes at the HBM interface). */
-template <int WB> SB_HD uint32_t out_elems(const nrq_job *job, const nrq_plan_hdr *h) { return (job->inter ? h->L : 0u) + job->nout; }
-template <int WB> SB_HD void ph_store(const StripCtx<WB> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD uint32_t out_elems(const nrq_job *job, const nrq_plan_hdr *h) { return (job->inter ? h->L : 0u) + job->nout; }
+template <int WB, int G = 1> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
   constexpr int STB = 8;
   const NRQ_GAS uint16_t *colslot = c.template arr<uint16_t>(c.h->off_colslot);
   const uint32_t L = c.h->L, ni = c.job->inter ? L : 0u;
@@ -847,7 +911,7 @@ template <int WB> SB_HD void ph_store(const StripCtx<WB> &c, NRQ_GAS uint8_t *os
 #pragma unroll
     for (int q = 0; q < STB; q++) {
       uint32_t col = base + (uint32_t)q * nt;
-      if (col < L) g_put_stream<WB>(ostage + (size_t)col * WB, WB, lds_get<WB>(c.slots(), sl[q]));
+      if (col < L) g_put_stream<WB>(ostage + (size_t)col * (WB * G), WB, lds_get<WB, G>(c.slots(), sl[q]));
     }
   }
   const NRQ_GAS uint32_t *cptr = gptr<uint32_t>(c.job->out_cptr);
@@ -871,19 +935,19 @@ template <int WB> SB_HD void ph_store(const StripCtx<WB> &c, NRQ_GAS uint8_t *os
       for (uint32_t j = 0; j < 2; j++) {
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++)
-          if (sl[j][k] != NRQ_NOSLOT) sv_xor<WB>(acc[j], lds_get<WB>(c.slots(), sl[j][k]));
+          if (sl[j][k] != NRQ_NOSLOT) sv_xor<WB>(acc[j], lds_get<WB, G>(c.slots(), sl[j][k]));
         e[j] += 8u;
       }
     }
-    g_put_stream<WB>(ostage + (size_t)(ni + q0) * WB, WB, acc[0]);
-    if (two) g_put_stream<WB>(ostage + (size_t)(ni + q1) * WB, WB, acc[1]);
+    g_put_stream<WB>(ostage + (size_t)(ni + q0) * (WB * G), WB, acc[0]);
+    if (two) g_put_stream<WB>(ostage + (size_t)(ni + q1) * (WB * G), WB, acc[1]);
   }
 }
 /* phase 6b for the SPLIT solve of narrow strips (big blocks, nrq_device.hip): instead of back-substitution and results,
  * the strip's slot image after the dense stage (element i < M: slot i, i.e. Y of the pivot rows) and the values of the
  * inactive columns (element M + x: C_u[x]) go to the output staging buffer; they reach full-width rows of a per-block
  * work buffer through the same scatter, where nrq_backsub_kernel finishes the solve on 32-byte strips. */
-template <int WB> SB_HD void ph_store_raw(const StripCtx<WB> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1> SB_HD void ph_store_raw(const StripCtx<WB, G> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
   const uint32_t M = c.h->M, u = c.h->u;
   constexpr int STB = 4;
   for (uint32_t base = tid; base < M + u; base += STB * nt) {
@@ -891,12 +955,12 @@ template <int WB> SB_HD void ph_store_raw(const StripCtx<WB> &c, NRQ_GAS uint8_t
 #pragma unroll
     for (int q = 0; q < STB; q++) {
       const uint32_t i = base + (uint32_t)q * nt;
-      v[q] = i < M ? lds_get<WB>(c.slots(), i) : i < M + u ? lds_get<WB>(c.cu(), i - M) : sv_zero<WB>();
+      v[q] = i < M ? lds_get<WB, G>(c.slots(), i) : i < M + u ? lds_get<WB, G>(c.cu(), i - M) : sv_zero<WB>();
     }
 #pragma unroll
     for (int q = 0; q < STB; q++) {
       const uint32_t i = base + (uint32_t)q * nt;
-      if (i < M + u) g_put_stream<WB>(ostage + (size_t)i * WB, WB, v[q]);
+      if (i < M + u) g_put_stream<WB>(ostage + (size_t)i * (WB * G), WB, v[q]);
     }
   }
 }
@@ -908,8 +972,8 @@ template <int WB> struct GroupDst {
   uint32_t lsub;
 };
 /* units [u0, u1) of the scatter, unit = (staged element, piece of the line): whole lines to the symbol rows */
-template <int WB> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
-                                        uint32_t u1, uint32_t p, uint32_t np) {
+template <int WB, int G = 1> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
+                                        uint32_t u1, uint32_t p, uint32_t np, uint32_t sub = 0) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u;
 #ifndef NRQ_SCATTER_PB
 #define NRQ_SCATTER_PB 4
@@ -922,14 +986,16 @@ template <int WB> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uin
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np, i = u >> lsub;
       row[q] = (u < u1 && i >= g.ni) ? g.orow[i - g.ni] : i;
-      v[q] = u < u1 ? g_get_l2<WB>(ostage + (size_t)(u & pmask) * stage_stride + (size_t)i * WB) : sv_zero<WB>();
+      v[q] = u < u1 ? g_get_l2<WB>(ostage + (size_t)(u & pmask) * stage_stride + (size_t)i * (WB * G) + sub * WB) : sv_zero<WB>();
     }
 #pragma unroll
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np, i = u >> lsub, strip = g.strip0 + (u & pmask);
       if (u >= u1 || strip >= g.nstrips) continue;
-      const uint32_t rem = g.T - strip * WB;
-      NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB;
+      const uint32_t at = strip * (WB * G) + sub * WB;
+      if (at >= g.T) continue;
+      const uint32_t rem = g.T - at;
+      NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + at;
       g_put<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
     }
   }

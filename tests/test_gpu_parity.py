@@ -379,3 +379,27 @@ def test_device_built_encode_plans(G, orc):
     finally:
         c.set_option("encplan_dev_min_l", 12000)
         c.clear_plan_cache()
+
+
+@pytest.mark.parametrize("g", [2, 4, 8])
+def test_wide_strips(G, orc, g):
+    """Wide strips (g lanes of 16 bytes per element, nrq_ctx_set_option "wide_g"): an option for small blocks that is not
+    selected automatically (nrq_device.hip launch_wb has the measurements); forced here -- intermediate, repair and
+    recovered symbols byte for byte, symbol sizes that end inside a strip (T = 50, 136, 1288)."""
+    c = G.ctx()
+    c.set_option("wide_g", g)
+    try:
+        for K, T, nblk, p, oh in [(100, 1024, 5, 0.06, 0), (300, 1288, 3, 0.1, 0), (1024, 136, 9, 0.05, 2), (64, 50 if g <= 2 else 160, 5, 0.2, 1)]:
+            src = np.stack([payload(K * T, seed=K + g, block=b).reshape(K, T) for b in range(nblk)])
+            esis = np.array([K, K + 1, K + 9, K + 500], np.uint32)
+            rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+            assert c.stats()["strip_bytes"] == (16 * g if K <= 100 else c.stats()["strip_bytes"])   # (wide only where two images fit a CU)
+            for b in (0, nblk - 1):
+                r_rep, r_int, _ = orc.encode_block(src[b], K, T, esis, want_inter=True)
+                assert np.array_equal(inter[b], r_int) and np.array_equal(rep[b], r_rep), (K, T, b)
+            st, out, src2 = _roundtrip(G, K, T, nblk, p, oh, seed=K + 7)
+            for b in range(nblk):
+                assert not st[b] or np.array_equal(out[b], src2[b]), (K, T, b)
+            assert st.sum() >= nblk - 1
+    finally:
+        c.set_option("wide_g", 0)
