@@ -327,6 +327,10 @@ enum {
   pl_tag_pl_ops_layout = 10,
   pl_tag_pl_ops_clear = 10,
   pl_tag_pl_ops_emit = 10,
+  pl_tag_pl_sh_restore = 0,
+  pl_tag_pl_sh_save = 15,
+  pl_tag_pl_mh_ext_clear = 15,
+  pl_tag_pl_mh_fetch = 11,
   pl_tag_pl_mh_init = 11,
   pl_tag_pl_mh_load = 11,
   pl_tag_pl_mh_acc = 11,
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
                                                          const nrq_planjob *__restrict__ pjobs,
                                                          nrq_job *__restrict__ jobs_out, uint32_t nblk, uint32_t Mcap,
                                                          uint32_t npcap, uint32_t ucap, uint32_t lds_dyn_bytes,
-                                                         unsigned long long *__restrict__ prof) {
+                                                         unsigned long long *__restrict__ prof, uint32_t seg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= nblk) return;
@@ -383,11 +387,50 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
       else fwd_rows<4>(ops_, pl_wfast_rows(c), tid); \
     } \
     __syncthreads(); PL_ACC(2); } while (0)
+#define PL_SEG seg
+  if (seg == 2u) PL_PHASE(pl_sh_restore);
 #include "planner_seq.h"
+  if (seg == 1u) { PL_PHASE(pl_mh_ext_clear); PL_PHASE(pl_sh_save); }
+#undef PL_SEG
 #undef PL_PHASE
 #undef PL_PHASE1
 #undef PL_WFAST_RUN
 #undef PL_ACC
+}
+
+/* Between the two parts of a segmented planner run (planner_seq.h): the HDPC fold over the pivots,
+ * MhT[x] = G_U[:,x] ^ SUM_k W[k][x] * G[:, pivcol k], by `nparts` workgroups per block -- each folds every nparts-th tile
+ * of 256 pivots into a private MhT in LDS (the planner's own phases pl_mh_load / pl_mh_acc) and XORs it into the copy in
+ * the block's workspace.  One workgroup did this alone in 12 M clocks at K'=56403 (18 % of the plan). */
+__global__ __launch_bounds__(1024) void nrq_mh_kernel(rq_params p, const uint8_t *__restrict__ kc, const nrq_planjob *__restrict__ pjobs,
+                                                      uint32_t Mcap, uint32_t npcap, uint32_t ucap, uint32_t lds_dyn_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t part = blockIdx.x, nparts = gridDim.x, b = blockIdx.y, tid = threadIdx.x;
+  pl_shared *sh = reinterpret_cast<pl_shared *>(smem + lds_dyn_bytes);
+  PlanCtx c;
+  pl_ctx_setup(c, p, kc, pjobs[b], sh, smem, lds_dyn_bytes, Mcap, npcap, ucap, nullptr);
+  pl_sh_restore<0>(c, tid, 1024u);
+  __syncthreads();
+  if (sh->status != 0 || sh->nV != 0) return;
+  if (part == 0) pl_mh_init<0>(c, tid, 1024u); else pl_mh_part_zero<0>(c, tid, 1024u);
+  __syncthreads();
+  const uint32_t ntiles = (sh->npiv + PL_MH_TILE - 1u) / PL_MH_TILE;
+  for (uint32_t tl = part; tl < ntiles; tl += nparts) {
+    pl_mh_load<0>(c, tl, tid, 1024u);
+    __syncthreads();
+    pl_mh_acc<0>(c, tl, tid, 1024u);
+    __syncthreads();
+  }
+  pl_mh_part_flush<0>(c, tid, 1024u);
+}
+
+/* After a segmented planner run: W transposed by word into the plan (pl_wt_fill), by many workgroups. */
+__global__ __launch_bounds__(256) void nrq_wt_kernel(const nrq_planjob *__restrict__ pjobs, uint32_t L, uint32_t Mcap, uint32_t npcap,
+                                                     uint32_t ucap, uint32_t nnzcap) {
+  const nrq_planjob &j = pjobs[blockIdx.y];
+  const pl_work_layout wl = pl_work_plan(L, Mcap, npcap, ucap, nnzcap);
+  pl_wt_fill(PL_HBM(uint8_t, j.arena), reinterpret_cast<const uint32_t *>(PL_HBM(uint8_t, j.work) + wl.wrows),
+             blockIdx.x * 256u + threadIdx.x, gridDim.x * 256u);
 }
 
 /* ---- split solve of big blocks (strips of 2 or 4 bytes) ----
@@ -656,6 +699,7 @@ struct Tuning {
   bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
   bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
   int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
+  bool no_plan_split = false;  /* NRQ_NO_PLAN_SPLIT: big blocks planned by one kernel (no helper kernels for the HDPC fold / W transposition) */
   bool no_plan_stream = false; /* NRQ_NO_PLAN_STREAM: planner kernel on the caller's stream (no overlap with the solve before it) */
   void read() {
     auto flag = [](const char *n) { const char *e = getenv(n); return e != nullptr; };
@@ -669,6 +713,7 @@ struct Tuning {
     if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
     no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
+    no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
   }
 };
 
@@ -796,8 +841,18 @@ int get_kconst(nrq_ctx *ctx, uint32_t K, KConst **out) {
 
 /* launch geometry of the planner kernel: LDS sizing, workgroup shape (shared by the decode planner and the device
  * build of encode plans) */
+/* Big blocks, whose peeling state does not fit the LDS next to the dense-stage reserve (pl_ctx_setup's rule), run the
+ * planner in two parts with helper kernels between and after them (planner_seq.h).  The jobs carry the choice in
+ * bit 8 of nrq_planjob::mode (pl_final_c then leaves the W transposition to nrq_wt_kernel). */
+bool plan_is_segmented(const nrq_ctx *ctx, const rq_params &p, uint32_t Mcap) {
+  const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared)), dyn = NRQ_LDS_MAX - sh_bytes;
+  const uint32_t need = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u);
+  return need + pl_dense_reserve(p.L) > dyn && !ctx->tune.no_plan_split;
+}
+
 int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const uint8_t *d_kc, const nrq_planjob *d_pj,
-                       nrq_job *d_jobs, uint32_t nblk, uint32_t Mcap, uint32_t npcap, uint32_t ucap, unsigned long long *pprof) {
+                       nrq_job *d_jobs, uint32_t nblk, uint32_t Mcap, uint32_t npcap, uint32_t ucap, unsigned long long *pprof,
+                       uint32_t nnzcap) {
   const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared));
   /* dynamic LDS: everything a CU has for a big block; for small blocks what the planner can use (peeling state plus the
    * dense-stage reserve, or a 16-byte strip image of the W rows), so that two workgroups share a CU */
@@ -809,20 +864,37 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     const uint32_t fit = pl_r16((peel > wimg ? peel : wimg) + 2048u);
     if (fit + sh_bytes <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) { dyn_bytes = fit; small_wg = !ctx->tune.plan_big_wg; }
   }
+  const bool seg = plan_is_segmented(ctx, p, Mcap);
+  const uint32_t mh_dyn = 72u * 1024u; /* nrq_mh_kernel: MhT (16 B x u <= 20 KB) + the tiles (4 KB + 256 x wpr words <= 40 KB) */
   if (!ctx->plan_attr) {
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT_MIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_mh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)NRQ_LDS_MAX));
     ctx->plan_attr = true;
   }
-  if (small_wg)
-    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
-                       nblk, Mcap, npcap, ucap, dyn_bytes, pprof);
-  else
-    hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
-                       Mcap, npcap, ucap, dyn_bytes, pprof);
-  HIPCHK(ctx, hipGetLastError());
+  for (uint32_t part = seg ? 1u : 0u; part <= (seg ? 2u : 0u); part++) {
+    if (small_wg)
+      hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
+                         nblk, Mcap, npcap, ucap, dyn_bytes, pprof, part);
+    else
+      hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
+                         Mcap, npcap, ucap, dyn_bytes, pprof, part);
+    HIPCHK(ctx, hipGetLastError());
+    if (part == 1u) { /* the HDPC fold: as many workgroups per block as leave the whole batch ~256 */
+      uint32_t nparts = 256u / (nblk ? nblk : 1u);
+      if (nparts < 1u) nparts = 1u;
+      if (nparts > 64u) nparts = 64u;
+      hipLaunchKernelGGL(nrq_mh_kernel, dim3(nparts, nblk), dim3(1024), mh_dyn + sh_bytes, ps, p, d_kc, d_pj, Mcap, npcap, ucap, mh_dyn);
+      HIPCHK(ctx, hipGetLastError());
+    }
+  }
+  if (seg) {
+    hipLaunchKernelGGL(nrq_wt_kernel, dim3(64, nblk), dim3(256), 0, ps, d_pj, p.L, Mcap, npcap, ucap, nnzcap);
+    HIPCHK(ctx, hipGetLastError());
+  }
   return 0;
 }
 
@@ -915,12 +987,13 @@ int encplan_device_launch(nrq_ctx *ctx, const rq_params &p, uint32_t K, KConst *
   pj->work = (uint64_t)(uintptr_t)ctx->encplan_work.p;
   pj->arena = (uint64_t)(uintptr_t)ep.devbuf[buf];
   pj->arena_cap = arena_cap;
-  pj->mode = 1u;
+  pj->mode = 1u | (plan_is_segmented(ctx, p, Mcap) ? 0x100u : 0u);
   HIPCHK(ctx, hipMemcpyAsync(ep.devbuf[buf] + off_pj, pj, sizeof(*pj), hipMemcpyHostToDevice, ps));
   rq_params pk = p;
   pk.K = K;
   if ((rc = launch_plan_kernel(ctx, ps, pk, kc->dev, reinterpret_cast<const nrq_planjob *>(ep.devbuf[buf] + off_pj),
-                               reinterpret_cast<nrq_job *>(ep.devbuf[buf] + off_job), 1u, Mcap, npcap, ucap, nullptr)))
+                               reinterpret_cast<nrq_job *>(ep.devbuf[buf] + off_job), 1u, Mcap, npcap, ucap, nullptr,
+                               kh->nnz + npcap * PL_PATCH_STRIDE)))
     return rc;
   HIPCHK(ctx, hipMemcpyAsync(ep.pin + pin_rb, ep.devbuf[buf], rb, hipMemcpyDeviceToHost, ps));
   HIPCHK(ctx, hipMemcpyAsync(ep.pin + pin_job, ep.devbuf[buf] + off_job, sizeof(nrq_job), hipMemcpyDeviceToHost, ps));
@@ -1398,6 +1471,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "tiny_div") t.tiny_div = (uint32_t)value;
   else if (n == "no_balance") t.no_balance = value != 0;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
+  else if (n == "no_plan_split") t.no_plan_split = value != 0;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "solve_grid") t.solve_grid = (uint64_t)value;
   else if (n == "big_wg") t.big_wg = value != 0;
@@ -1738,6 +1812,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     j.nrep_avail = j.nrep;
     if (sane && h_avail && h_avail[b] > j.nrep) j.nrep_avail = h_avail[b] < rep_cap ? h_avail[b] : rep_cap;
     j.arena_cap = arena_cap;
+    j.mode = plan_is_segmented(ctx, p, Mcap) ? 0x100u : 0u;
   }
   HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ps));
   unsigned long long *pprof = nullptr;
@@ -1746,7 +1821,8 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     HIPCHK(ctx, hipMemsetAsync(pprof, 0, 32 * 8, ps));
   }
   if ((rc = launch_plan_kernel(ctx, ps, p, kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
-                               reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, pprof)))
+                               reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, pprof,
+                               kh->nnz + npcap * PL_PATCH_STRIDE)))
     return rc;
   if (pprof) {
     unsigned long long hp[32];

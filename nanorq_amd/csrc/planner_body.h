@@ -108,6 +108,7 @@ SB_HD uint32_t pl_r16(uint32_t x) { return (x + 15u) & ~15u; }
 
 typedef struct pl_shared {
   uint32_t status, fail_site; /* fail_site: source line that raised PL_FAIL_CAPACITY (diagnostics) */
+  uint32_t defer_wt;          /* segmented run: W is transposed by nrq_wt_kernel, not by pl_final_c */
   uint32_t M, overhead, npatch, wpr, lpr, rowlen;
   uint32_t nV, npiv, ninact, nlev;
   uint32_t nq[2], nclaim[2]; /* frontier / claim counts, indexed by round parity */
@@ -135,7 +136,7 @@ typedef struct pl_shared {
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
   uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, ucol, wrows,
-      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, total;
+      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, sh_save, mh_ext, total;
 } pl_work_layout;
 
 /* nnzcap: entries of the base structure plus the patch rows (bounds the number of row ops) */
@@ -167,6 +168,8 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.rec_idx = o;    o = pl_r16(o + nnzcap * 4u);
   w.rec_g = o;      o = pl_r16(o + nnzcap * 2u);
   w.cand = o;       o = pl_r16(o + Mcap * 2u); /* stack of open rows with exactly two V columns (pl_inact_find) */
+  w.sh_save = o;    o = pl_r16(o + (uint32_t)sizeof(pl_shared)); /* pl_shared between the parts of a segmented run (planner_seq.h) */
+  w.mh_ext = o;     o = pl_r16(o + ucap * PL_MAXH);               /* MhT as nrq_mh_kernel leaves it (16 bytes per inactive column) */
   w.total = o;
   return w;
 }
@@ -349,12 +352,13 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (tid == 0) {
     uint32_t st = 0;
     const uint32_t nl = c.job.nlost, nr = c.job.nrep;
-    if ((nl == 0 && c.job.mode != 1u) || nr < nl) st = PL_FAIL_SINGULAR;
+    if ((nl == 0 && (c.job.mode & 0xFFu) != 1u) || nr < nl) st = PL_FAIL_SINGULAR;
     uint32_t oh = st ? 0 : nr - nl;
     if (!st && (p.L + oh + PL_EXTRA_ROWS > c.Mcap || nr + PL_EXTRA_ROWS > c.npcap || p.L + oh + PL_EXTRA_ROWS > 65534u))
       st = PL_FAIL_CAPACITY;
     sh->status = st;
     sh->fail_site = 0;
+    sh->defer_wt = c.job.mode >> 8; /* (bit 8 of the job's mode: set by the host for segmented runs) */
     sh->overhead = oh;
     sh->M = p.L + oh;
     sh->npatch = st ? 0 : nr;
@@ -1352,6 +1356,44 @@ template <int Z> SB_HD void pl_mh_acc(PlanCtx &c, uint32_t tile, uint32_t tid, u
   }
 }
 
+/* ---- segmented runs (planner_seq.h): pl_shared through the workspace, MhT from nrq_mh_kernel ---- */
+template <int Z> SB_HD void pl_sh_save(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  uint32_t *dst = reinterpret_cast<uint32_t *>(c.work + c.wl.sh_save);
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(c.sh);
+  for (uint32_t k = tid; k < (uint32_t)(sizeof(pl_shared) / 4u); k += nt) dst[k] = src[k];
+}
+template <int Z> SB_HD void pl_sh_restore(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(c.work + c.wl.sh_save);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(c.sh);
+  for (uint32_t k = tid; k < (uint32_t)(sizeof(pl_shared) / 4u); k += nt) dst[k] = src[k];
+}
+template <int Z> SB_HD void pl_mh_fetch(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  if (c.sh->status) return;
+  const uint32_t u = c.p.L - c.sh->npiv;
+  const uint4 *src = reinterpret_cast<const uint4 *>(c.work + c.wl.mh_ext);
+  uint4 *MhT = reinterpret_cast<uint4 *>(pl_mhm(c));
+  for (uint32_t x = tid; x < u; x += nt) MhT[x] = src[x];
+}
+/* nrq_mh_kernel: workgroup `part` of `nparts` folds its share of the pivot tiles into a private MhT (LDS) and XORs it
+ * into the workspace copy (which the first part of the run zeroed: pl_mh_ext_clear).  Part 0 also contributes G_U. */
+template <int Z> SB_HD void pl_mh_ext_clear(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  uint32_t *dst = reinterpret_cast<uint32_t *>(c.work + c.wl.mh_ext);
+  for (uint32_t k = tid; k < c.ucap * PL_MAXH / 4u; k += nt) dst[k] = 0u;
+}
+template <int Z> SB_HD void pl_mh_part_zero(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  const uint32_t u = c.p.L - c.sh->npiv;
+  uint4 *MhT = reinterpret_cast<uint4 *>(pl_mhm(c));
+  uint4 z; z.x = z.y = z.z = z.w = 0u;
+  for (uint32_t x = tid; x < u; x += nt) MhT[x] = z;
+}
+template <int Z> SB_HD void pl_mh_part_flush(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  const uint32_t u = c.p.L - c.sh->npiv;
+  const uint32_t *MhT = reinterpret_cast<const uint32_t *>(pl_mhm(c));
+  uint32_t *dst = reinterpret_cast<uint32_t *>(c.work + c.wl.mh_ext);
+  for (uint32_t k = tid; k < u * 4u; k += nt)
+    if (MhT[k]) PL_ATOM_XOR(&dst[k], MhT[k]);
+}
+
 /* =============================== phase 6: GF(2) Gauss-Jordan in LDS =========================== */
 /* Column x: the unused row with the lowest index that has the column becomes its pivot row (atomic-min bids in
  * cand[x % 3]); the column is eliminated from every other row that has it.  gj_flag[j] bit (x & 1) = row j has
@@ -1676,10 +1718,11 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const rq_params &p = c.p;
   const uint32_t wpr = sh->wpr, stride = sh->tmp0, nl = c.job.nlost;
   uint32_t *wt = reinterpret_cast<uint32_t *>(c.arena + sh->partial[0]);
-  for (uint32_t e = tid; e < wpr * stride; e += nt) {
-    const uint32_t w = e / stride, k = e - w * stride;
-    wt[e] = k < sh->npiv ? c.wrows[(size_t)c.pivslot[k] * wpr + w] : 0u;
-  }
+  if (!sh->defer_wt) /* (a segmented run leaves the transposition to nrq_wt_kernel: many workgroups) */
+    for (uint32_t e = tid; e < wpr * stride; e += nt) {
+      const uint32_t w = e / stride, k = e - w * stride;
+      wt[e] = k < sh->npiv ? c.wrows[(size_t)c.pivslot[k] * wpr + w] : 0u;
+    }
   uint32_t *rowsrc = reinterpret_cast<uint32_t *>(c.arena + sh->partial[1]);
   for (uint32_t r = tid; r < sh->M; r += nt) {
     uint32_t v = NRQ_ROW_ZERO;
@@ -1755,6 +1798,20 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
       j.nout = c.job.nlost;
     }
     *c.jobout = j;
+  }
+}
+
+/* W transposed by word (plan.h off_wt), elements e0, e0 + step, ...: what pl_final_c does in an unsegmented run and
+ * nrq_wt_kernel (many workgroups) after a segmented one -- from the finished header and the block's W rows */
+SB_HD void pl_wt_fill(uint8_t *arena, const uint32_t *wrows, uint32_t e0, uint32_t step) {
+  const nrq_plan_hdr *h = reinterpret_cast<const nrq_plan_hdr *>(arena);
+  if (h->status) return;
+  const uint32_t wpr = h->wpr, stride = h->npiv_pad, npiv = h->npiv;
+  const uint16_t *pivslot = reinterpret_cast<const uint16_t *>(arena + h->off_pivslot);
+  uint32_t *wt = reinterpret_cast<uint32_t *>(arena + h->off_wt);
+  for (uint32_t e = e0; e < wpr * stride; e += step) {
+    const uint32_t w = e / stride, k = e - w * stride;
+    wt[e] = k < npiv ? wrows[(size_t)pivslot[k] * wpr + w] : 0u;
   }
 }
 

@@ -5,11 +5,17 @@
  *     PL_PHASE1(fn, a)    same with one extra leading argument
  *     PL_WFAST_RUN(wb)    run the op-stream rows [0, pl_wfast_rows(c)) on the wb-byte slot image at the start of
  *                         the dynamic LDS region (one wave), then barrier
+ *     PL_SEG              which part to run: 0 = everything (small and medium blocks, the emulator);
+ *                         1 = up to and including the W pass, 2 = the rest.  Big blocks (peeling state in HBM) run as
+ *                         1 | nrq_mh_kernel | 2 | nrq_wt_kernel: the HDPC fold over the pivots and the transposition of
+ *                         W are embarrassingly parallel and take 25 % of a one-workgroup planner at K'=56403, so many
+ *                         workgroups do them between the two parts (pl_shared travels through the block's workspace)
  * and provides `PlanCtx c`.  Every value that steers control flow is read from workgroup-shared state
  * right after a barrier, so all threads take the same path.
  */
 {
   pl_shared *sh_ = c.sh;
+  if (PL_SEG != 2) {
   PL_PHASE(pl_init_a);
   PL_PHASE(pl_init_b);
   PL_PHASE(pl_scan_a);
@@ -55,7 +61,9 @@
     PL_PHASE(pl_low_a);
     PL_PHASE(pl_low_b);
   }
+  } /* PL_SEG != 2 */
   if (sh_->status == 0 && sh_->nV == 0) {
+    if (PL_SEG != 2) {
     PL_PHASE(pl_w_init);
     PL_PHASE(pl_w_init_b);
     PL_PHASE(pl_ops_layout_a);
@@ -81,10 +89,16 @@
         for (uint32_t lv_ = 1; lv_ <= sh_->nlev; lv_++) PL_PHASE1(pl_w_group, lv_);
       }
     }
-    PL_PHASE(pl_mh_init);
-    for (uint32_t tl_ = 0; tl_ * PL_MH_TILE < sh_->npiv; tl_++) {
-      PL_PHASE1(pl_mh_load, tl_);
-      PL_PHASE1(pl_mh_acc, tl_);
+    } /* PL_SEG != 2 */
+    if (PL_SEG != 1) {
+    if (PL_SEG == 0) {
+      PL_PHASE(pl_mh_init);
+      for (uint32_t tl_ = 0; tl_ * PL_MH_TILE < sh_->npiv; tl_++) {
+        PL_PHASE1(pl_mh_load, tl_);
+        PL_PHASE1(pl_mh_acc, tl_);
+      }
+    } else {
+      PL_PHASE(pl_mh_fetch); /* nrq_mh_kernel left MhT in the block's workspace */
     }
     PL_PHASE(pl_low_c); /* (after the fold: Mb takes the place of the fold's tiles) */
     {
@@ -125,9 +139,12 @@
     PL_PHASE(pl_final_a);
     PL_PHASE(pl_final_b);
     PL_PHASE(pl_final_c);
-  } else if (sh_->status == 0) {
+    } /* PL_SEG != 1 */
+  } else if (sh_->status == 0 && PL_SEG != 1) {
     PL_PHASE(pl_mark_failed); /* peeling did not terminate: report the block as undecodable */
   }
-  PL_PHASE(pl_final_d);
-  PL_PHASE(pl_final_e);
+  if (PL_SEG != 1) {
+    PL_PHASE(pl_final_d);
+    PL_PHASE(pl_final_e);
+  }
 }

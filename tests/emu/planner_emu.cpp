@@ -42,7 +42,8 @@ static void emu_wfast_run(PlanCtx &c, uint32_t wb) {
 
 /* returns 0 and fills arena (status in its header); job_out receives the solve job (host pointers) */
 static uint32_t g_mode = 0; /* nrq_planjob::mode of the next emu_plan call (1 = encode plan) */
-extern "C" void emu_plan_set_mode(uint32_t mode) { g_mode = mode; }
+static uint32_t g_split = 0; /* run the phase sequence in its two parts (what big blocks do on the GPU) */
+extern "C" void emu_plan_set_mode(uint32_t mode) { g_mode = mode & 0xFFu; g_split = (mode >> 8) & 1u; }
 extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const uint32_t *lost, uint32_t nlost,
                         const uint32_t *rep_esi, uint32_t nrep, uint32_t nrep_avail, uint8_t *arena,
                         uint32_t arena_cap, uint32_t lds_dyn_bytes, nrq_job *job_out) {
@@ -64,13 +65,31 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   job.work = (uint64_t)(uintptr_t)work.data();
   job.arena = (uint64_t)(uintptr_t)arena;
   job.nlost = nlost; job.nrep = nrep; job.arena_cap = arena_cap; job.nrep_avail = nrep_avail;
-  job.mode = g_mode;
+  job.mode = g_mode | (g_split << 8);
   PlanCtx c;
   pl_ctx_setup(c, p, kc, job, sh, lds_dyn_bytes ? dyn.data() : nullptr, lds_dyn_bytes, Mcap, npcap, ucap, job_out);
 #define PL_PHASE(fn) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, t_, PL_NT); } while (0)
 #define PL_PHASE1(fn, a) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, (a), t_, PL_NT); } while (0)
 #define PL_WFAST_RUN(wb) emu_wfast_run(c, (wb))
+#define PL_SEG g_seg
+  for (uint32_t pass_ = 0; pass_ < (g_split ? 2u : 1u); pass_++) {
+    const uint32_t g_seg = g_split ? pass_ + 1u : 0u;
+    if (g_seg == 2u) { /* what nrq_mh_kernel does between the parts: the fold in two "workgroups" */
+      PL_PHASE(pl_sh_restore);
+      if (sh->status == 0 && sh->nV == 0) {
+        const uint32_t ntiles = (sh->npiv + PL_MH_TILE - 1u) / PL_MH_TILE;
+        for (uint32_t part = 0; part < 2u; part++) {
+          if (part == 0) PL_PHASE(pl_mh_init); else PL_PHASE(pl_mh_part_zero);
+          for (uint32_t tl_ = part; tl_ < ntiles; tl_ += 2u) { PL_PHASE1(pl_mh_load, tl_); PL_PHASE1(pl_mh_acc, tl_); }
+          PL_PHASE(pl_mh_part_flush);
+        }
+      }
+    }
 #include "../../nanorq_amd/csrc/planner_seq.h"
+    if (g_seg == 1u) { PL_PHASE(pl_mh_ext_clear); PL_PHASE(pl_sh_save); memset(sh, 0xEE, sizeof(*sh)); }
+  }
+#undef PL_SEG
+  if (g_split) pl_wt_fill(arena, reinterpret_cast<const uint32_t *>(work.data() + wl.wrows), 0u, 1u); /* = nrq_wt_kernel */
 #undef PL_PHASE
 #undef PL_PHASE1
 #undef PL_WFAST_RUN

@@ -179,7 +179,10 @@ def test_lds_budget_of_headline_config(orc):
                                              (8192, 16, 16, 0.1, 2, 60)])
 def test_device_planner_emulated_matches_oracle(orc, K, T, wb, p, oh, lds):
     """The GPU planner's phase code (planner_body.h), emulated, then the emulated solve: decoded data must be
-    the oracle's; `lds` (KiB) small enough forces the peeling state out of LDS into the HBM workspace."""
+    the oracle's; `lds` (KiB) small enough forces the peeling state out of LDS into the HBM workspace.  Every case
+    also runs SEGMENTED, the way big blocks run on the GPU (planner_seq.h): part 1, the HDPC fold by two "workgroups"
+    (nrq_mh_kernel), part 2 with pl_shared restored from the workspace, W transposed afterwards (nrq_wt_kernel) --
+    and must produce the identical plan."""
     prm = orc.params(K)
     src = payload(K * T, seed=15).reshape(K, T)
     kc = nanorq_amd.host_kconst(K)
@@ -195,8 +198,11 @@ def test_device_planner_emulated_matches_oracle(orc, K, T, wb, p, oh, lds):
         ok, ref_out, _ = orc.decode_block(esis, syms, K, T)
         plan, hdr = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=lds * 1024)
         assert (hdr["status"] == 0) == ok
+        plan2, hdr2 = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=lds * 1024, split=True)
+        assert hdr2["status"] == hdr["status"]
         if not ok:
             continue
+        assert plan2 == plan, "the segmented run built a different plan"
         _, rowsrc = decode_setup(orc, K, lost, rep_esis)
         work = src.copy()
         work[lost] = 0x77
