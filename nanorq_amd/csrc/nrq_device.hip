@@ -424,6 +424,32 @@ __global__ __launch_bounds__(1024) void nrq_mh_kernel(rq_params p, const uint8_t
   pl_mh_part_flush<0>(c, tid, 1024u);
 }
 
+/* Between the two parts of a segmented planner run: the W pass -- W = X^-1 * A_U and the leftover rows' reduced
+ * coefficients are the op stream applied to the bit rows (planner_body.h "W pass, fast path").  Bit columns are
+ * independent, so every workgroup takes a 2-byte strip of all W rows into LDS (slot image like the solve kernel's),
+ * one wave runs the row pipeline over the stream (fwd_rows<2>), the strip goes back: wpr * 2 workgroups per block
+ * instead of a level-by-level pass on the HBM rows by one (12 M clocks at K'=56403). */
+__global__ __launch_bounds__(256) void nrq_wpass_kernel(rq_params p, const uint8_t *__restrict__ kc, const nrq_planjob *__restrict__ pjobs,
+                                                        uint32_t Mcap, uint32_t npcap, uint32_t ucap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; /* the strip image, from LDS address 0 */
+  const uint32_t strip = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const nrq_planjob &j = pjobs[b];
+  const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(kc);
+  const pl_work_layout wl = pl_work_plan(p.L, Mcap, npcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE);
+  uint8_t *work = PL_HBM(uint8_t, j.work);
+  const pl_shared *sv = reinterpret_cast<const pl_shared *>(work + wl.sh_save); /* part 1's state */
+  if (sv->status != 0 || sv->nV != 0 || strip >= sv->wpr * 2u) return;
+  const uint32_t M = sv->M, wpr = sv->wpr, nrows = sv->spare_base;
+  uint16_t *rows16 = reinterpret_cast<uint16_t *>(work + wl.wrows); /* W row r, halfword h at [r * wpr * 2 + h] */
+  uint16_t *img = reinterpret_cast<uint16_t *>(smem);
+  for (uint32_t e = tid; e < M + NRQ_SCRATCH; e += 256u)
+    img[e] = e >= NRQ_SCRATCH ? rows16[(size_t)(e - NRQ_SCRATCH) * wpr * 2u + strip] : (uint16_t)0;
+  __syncthreads();
+  if (tid < NRQ_ROW) fwd_rows<2>(gptr<uint32_t>(PL_HBM(uint8_t, j.arena) + sv->off_ops), nrows, tid);
+  __syncthreads();
+  for (uint32_t r = tid; r < M; r += 256u) rows16[(size_t)r * wpr * 2u + strip] = img[r + NRQ_SCRATCH];
+}
+
 /* After a segmented planner run: W transposed by word into the plan (pl_wt_fill), by many workgroups. */
 __global__ __launch_bounds__(256) void nrq_wt_kernel(const nrq_planjob *__restrict__ pjobs, uint32_t L, uint32_t Mcap, uint32_t npcap,
                                                      uint32_t ucap, uint32_t nnzcap) {
@@ -873,6 +899,8 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_mh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)NRQ_LDS_MAX));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_wpass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)NRQ_LDS_MAX));
     ctx->plan_attr = true;
   }
   for (uint32_t part = seg ? 1u : 0u; part <= (seg ? 2u : 0u); part++) {
@@ -883,7 +911,11 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
                          Mcap, npcap, ucap, dyn_bytes, pprof, part);
     HIPCHK(ctx, hipGetLastError());
-    if (part == 1u) { /* the HDPC fold: as many workgroups per block as leave the whole batch ~256 */
+    if (part == 1u) {
+      const uint32_t wp_lds = (Mcap + NRQ_SCRATCH) * 2u + 64u;
+      hipLaunchKernelGGL(nrq_wpass_kernel, dim3(((ucap + 31u) / 32u) * 2u, nblk), dim3(256), wp_lds, ps, p, d_kc, d_pj, Mcap, npcap, ucap);
+      HIPCHK(ctx, hipGetLastError());
+      /* the HDPC fold: as many workgroups per block as leave the whole batch ~256 */
       uint32_t nparts = 256u / (nblk ? nblk : 1u);
       if (nparts < 1u) nparts = 1u;
       if (nparts > 64u) nparts = 64u;

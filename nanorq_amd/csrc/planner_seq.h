@@ -6,9 +6,10 @@
  *     PL_WFAST_RUN(wb)    run the op-stream rows [0, pl_wfast_rows(c)) on the wb-byte slot image at the start of
  *                         the dynamic LDS region (one wave), then barrier
  *     PL_SEG              which part to run: 0 = everything (small and medium blocks, the emulator);
- *                         1 = up to and including the W pass, 2 = the rest.  Big blocks (peeling state in HBM) run as
- *                         1 | nrq_mh_kernel | 2 | nrq_wt_kernel: the HDPC fold over the pivots and the transposition of
- *                         W are embarrassingly parallel and take 25 % of a one-workgroup planner at K'=56403, so many
+ *                         1 = up to the op stream, 2 = from the leftover rows' coefficients on.  Big blocks (peeling state
+ *                         in HBM) run as 1 | nrq_wpass_kernel | nrq_mh_kernel | 2 | nrq_wt_kernel: the W pass (the op stream
+ *                         on 2-byte strips of the bit rows, a workgroup per strip), the HDPC fold over the pivots and the
+ *                         transposition of W are parallel work and take 40 % of a one-workgroup planner at K'=56403, so many
  *                         workgroups do them between the two parts (pl_shared travels through the block's workspace)
  * and provides `PlanCtx c`.  Every value that steers control flow is read from workgroup-shared state
  * right after a barrier, so all threads take the same path.
@@ -73,7 +74,7 @@
     /* W = X^-1 * A_U and the leftover rows' reduced coefficients: the op stream run on bit rows -- on strips of
      * them in LDS by the solve kernel's row pipeline (PL_WFAST_RUN: wave 0 only; defined by the includer),
      * or, when no strip width fits, level by level on the HBM rows */
-    {
+    if (PL_SEG == 0) { /* (a segmented run leaves the W pass to nrq_wpass_kernel: one workgroup per 2-byte strip of the W rows) */
       const uint32_t wb_ = sh_->status == 0 ? pl_wfast_wb(c) : 0u;
       if (wb_) {
         PL_PHASE(pl_wfast_spill);

@@ -41,6 +41,25 @@ static void emu_wfast_run(PlanCtx &c, uint32_t wb) {
 }
 
 /* returns 0 and fills arena (status in its header); job_out receives the solve job (host pointers) */
+/* nrq_wpass_kernel on the CPU: every 2-byte strip of the W rows through the op stream, rows applied in stream order
+ * (what fwd_rows<2> computes: a row never reads what it or its predecessor writes) */
+static void emu_wpass_strips(PlanCtx &c) {
+  pl_shared *sh = c.sh;
+  const uint32_t M = sh->M, wpr = sh->wpr, nrows = sh->spare_base;
+  const uint32_t *ops = reinterpret_cast<const uint32_t *>(c.arena + sh->off_ops);
+  uint16_t *rows16 = reinterpret_cast<uint16_t *>(c.wrows);
+  std::vector<uint16_t> img(M + NRQ_SCRATCH);
+  for (uint32_t strip = 0; strip < wpr * 2u; strip++) {
+    for (uint32_t e = 0; e < M + NRQ_SCRATCH; e++) img[e] = e >= NRQ_SCRATCH ? rows16[(size_t)(e - NRQ_SCRATCH) * wpr * 2u + strip] : 0;
+    for (uint32_t r = 0; r < nrows; r++) {
+      uint16_t v[NRQ_ROW];
+      for (uint32_t l = 0; l < NRQ_ROW; l++) v[l] = img[ops[(size_t)r * NRQ_ROW + l] >> 16];
+      for (uint32_t l = 0; l < NRQ_ROW; l++) img[ops[(size_t)r * NRQ_ROW + l] & 0xFFFFu] ^= v[l];
+    }
+    for (uint32_t r = 0; r < M; r++) rows16[(size_t)r * wpr * 2u + strip] = img[r + NRQ_SCRATCH];
+  }
+}
+
 static uint32_t g_mode = 0; /* nrq_planjob::mode of the next emu_plan call (1 = encode plan) */
 static uint32_t g_split = 0; /* run the phase sequence in its two parts (what big blocks do on the GPU) */
 extern "C" void emu_plan_set_mode(uint32_t mode) { g_mode = mode & 0xFFu; g_split = (mode >> 8) & 1u; }
@@ -74,9 +93,10 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
 #define PL_SEG g_seg
   for (uint32_t pass_ = 0; pass_ < (g_split ? 2u : 1u); pass_++) {
     const uint32_t g_seg = g_split ? pass_ + 1u : 0u;
-    if (g_seg == 2u) { /* what nrq_mh_kernel does between the parts: the fold in two "workgroups" */
+    if (g_seg == 2u) { /* what the helper kernels do between the parts */
       PL_PHASE(pl_sh_restore);
       if (sh->status == 0 && sh->nV == 0) {
+        emu_wpass_strips(c); /* nrq_wpass_kernel: the op stream on 2-byte strips of the W rows */
         const uint32_t ntiles = (sh->npiv + PL_MH_TILE - 1u) / PL_MH_TILE;
         for (uint32_t part = 0; part < 2u; part++) {
           if (part == 0) PL_PHASE(pl_mh_init); else PL_PHASE(pl_mh_part_zero);
