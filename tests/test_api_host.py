@@ -21,7 +21,7 @@ def _declared(header):
     return sorted(set(re.findall(r"\b((?:nanorq|nrq|ioctx)_[a-z0-9_]+)\s*\(", txt)))
 
 
-@pytest.mark.parametrize("header", ["nanorq.h", "io.h", "nanorq_hip.h", "nanorq_batch.h"])
+@pytest.mark.parametrize("header", ["nanorq.h", "io.h", "nanorq_hip.h", "nanorq_batch.h", "nanorq_ext.h"])
 def test_library_exports_every_declared_symbol(header):
     L = nanorq_amd.lib()
     names = _declared(header)
@@ -188,4 +188,42 @@ def test_mem_ioctx_clips():
     assert io.contents.write(io, src.ctypes.data_as(C.POINTER(C.c_uint8)), 16) == 4
     assert io.contents.tell(io) == 10 and io.contents.size(io) == 10
     assert list(buf[6:]) == [0, 1, 2, 3]
+    io.contents.destroy(io)
+
+
+def test_rfc_options_host_logic():
+    """include/nanorq_ext.h on the CPU tier (no solve involved): OTI words packed the RFC 6330 way and read back, the
+    table row of a short block, and the object <-> symbol mapping with N > 1 sub-blocks -- source symbols come out of
+    nanorq_encode (a plain gather before the solve) the way RFC 6330 section 4.4.1.2 lays them out."""
+    from capi import EXT_PER_BLOCK_KP, EXT_RFC_OTI, EXT_SUBBLOCKS
+    L = api()
+    F, T = 203 * 48, 48
+    rq = L.nanorq_encoder_new_ext(F, T, 102, 0, 1, 8, EXT_RFC_OTI | EXT_PER_BLOCK_KP)
+    assert L.nanorq_oti_common(rq) == (F << 24) | T and L.nanorq_oti_scheme_specific(rq) == (2 << 24) | (1 << 8) | 8
+    assert [L.nanorq_block_kprime(rq, b) for b in range(2)] == [114, 101] and L.nanorq_ext_flags(rq) == 3
+    dq = L.nanorq_decoder_new_ext(L.nanorq_oti_common(rq), L.nanorq_oti_scheme_specific(rq), EXT_RFC_OTI | EXT_PER_BLOCK_KP)
+    assert dq and L.nanorq_blocks(dq) == 2 and L.nanorq_symbol_size(dq) == T and L.nanorq_transfer_length(dq) == F
+    assert [L.nanorq_block_symbols(dq, b) for b in range(2)] == [102, 101]
+    L.nanorq_free(dq)
+    L.nanorq_free(rq)
+    # the same words are not a valid nanorq-packed OTI of the same object (T - 1, Z - 1, N - 1 there)
+    dq = L.nanorq_decoder_new((F << 24) | T, (2 << 24) | (1 << 8) | 8)   # read the nanorq way: T = 49, not a multiple of Al
+    assert not dq
+    assert not L.nanorq_encoder_new_ext(F, T, 102, 0, 7, 8, EXT_SUBBLOCKS)        # N > T / Al
+    assert L.nanorq_sub_blocks(L.nanorq_encoder_new_ext(F, T, 102, 0, 3, 8, 0)) == 1  # N ignored without the flag
+    # sub-blocking: T = 64, Al = 8 -> 8 units; N = 3 -> sub-symbols of 3, 3, 2 units; K = 10 symbols, one block
+    K, T, N = 10, 64, 3
+    data = np.arange(K * T, dtype=np.uint32).astype(np.uint8) ^ (np.arange(K * T) // 251).astype(np.uint8)
+    rq = L.nanorq_encoder_new_ext(K * T, T, K, 0, N, 8, EXT_SUBBLOCKS)
+    io = mem_io(data)
+    buf = (C.c_uint8 * T)()
+    widths = [24, 24, 16]
+    for esi in (0, 3, 9):
+        assert L.nanorq_encode(rq, buf, esi, 0, io) == T
+        want, off = b"", 0
+        for w in widths:   # sub-block j holds the j-th sub-symbol of every symbol, symbol after symbol
+            want += data[off + esi * w: off + (esi + 1) * w].tobytes()
+            off += K * w
+        assert bytes(buf) == want, esi
+    L.nanorq_free(rq)
     io.contents.destroy(io)
