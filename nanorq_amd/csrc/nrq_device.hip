@@ -725,6 +725,7 @@ struct Tuning {
   bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
   bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
   int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
+  bool plan_split_force = false; /* "plan_split_force": every block planned in two parts + helper kernels (tests) */
   bool no_plan_split = false;  /* NRQ_NO_PLAN_SPLIT: big blocks planned by one kernel (no helper kernels for the HDPC fold / W transposition) */
   bool no_plan_stream = false; /* NRQ_NO_PLAN_STREAM: planner kernel on the caller's stream (no overlap with the solve before it) */
   void read() {
@@ -873,6 +874,7 @@ int get_kconst(nrq_ctx *ctx, uint32_t K, KConst **out) {
 bool plan_is_segmented(const nrq_ctx *ctx, const rq_params &p, uint32_t Mcap) {
   const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared)), dyn = NRQ_LDS_MAX - sh_bytes;
   const uint32_t need = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u);
+  if (ctx->tune.plan_split_force) return true; /* (tests: the segmented path at sizes the oracle checks quickly) */
   return need + pl_dense_reserve(p.L) > dyn && !ctx->tune.no_plan_split;
 }
 
@@ -891,6 +893,14 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     if (fit + sh_bytes <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) { dyn_bytes = fit; small_wg = !ctx->tune.plan_big_wg; }
   }
   const bool seg = plan_is_segmented(ctx, p, Mcap);
+  if (seg && ctx->tune.plan_split_force) {
+    /* a segmented run keeps nothing in LDS between its parts: its peeling state must live in the workspace, which
+     * pl_ctx_setup chooses when the dynamic region is too small for it -- so make it too small (dense stage only) */
+    const uint32_t need = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u);
+    const uint32_t only_dense = (pl_dense_reserve(p.L) + need - 16u) & ~15u; /* 16 bytes short of holding the peeling state */
+    if (only_dense < dyn_bytes) dyn_bytes = only_dense;
+    small_wg = false;
+  }
   const uint32_t mh_dyn = 72u * 1024u; /* nrq_mh_kernel: MhT (16 B x u <= 20 KB) + the tiles (4 KB + 256 x wpr words <= 40 KB) */
   if (!ctx->plan_attr) {
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT>),
@@ -1504,6 +1514,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "no_balance") t.no_balance = value != 0;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
   else if (n == "no_plan_split") t.no_plan_split = value != 0;
+  else if (n == "plan_split_force") t.plan_split_force = value != 0;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "solve_grid") t.solve_grid = (uint64_t)value;
   else if (n == "big_wg") t.big_wg = value != 0;

@@ -403,3 +403,46 @@ def test_wide_strips(G, orc, g):
             assert st.sum() >= nblk - 1
     finally:
         c.set_option("wide_g", 0)
+
+
+def test_segmented_planner_at_small_sizes(G, orc):
+    """Big blocks are planned in two kernel parts with helper kernels between and after (W pass on 2-byte strips, HDPC
+    fold, W transposition; planner_seq.h).  Forced here for sizes the oracle checks quickly: decoded data against the
+    source, verdicts of rank-deficient receptions against the reference algorithm's, device-built encode plans too."""
+    from emu_support import decode_setup
+    c = G.ctx()
+    c.set_option("plan_split_force", 1)
+    c.set_option("encplan_dev_min_l", 0)
+    try:
+        for K, T, nblk, p, oh in [(100, 64, 6, 0.1, 0), (1024, 48, 5, 0.06, 0), (1024, 48, 5, 0.2, 30), (8192, 32, 3, 0.1, 0), (20000, 16, 2, 0.1, 1)]:
+            c.clear_plan_cache()
+            src = np.stack([payload(K * T, seed=K + 3, block=b).reshape(K, T) for b in range(nblk)])
+            esis = np.array([K, K + 7], np.uint32)
+            rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+            r_rep, r_int, _ = orc.encode_block(src[0], K, T, esis, want_inter=True)
+            assert np.array_equal(inter[0], r_int) and np.array_equal(rep[0], r_rep), K
+            st, out, src2 = _roundtrip(G, K, T, nblk, p, oh, seed=K + 11)
+            for b in range(nblk):
+                assert not st[b] or np.array_equal(out[b], src2[b]), (K, b)
+            assert st.sum() >= nblk - 1
+        # failure parity
+        K, T = 12, 8
+        src = payload(K * T, seed=4).reshape(K, T)
+        rng = np.random.default_rng(17)
+        all_rep, _ = G.gpu_encode(src.reshape(1, K, T), K, T, np.arange(K, K + 60, dtype=np.uint32))
+        lost_l, resi_l, reps_l, expect = [], [], [], []
+        for trial in range(150):
+            nl = int(rng.integers(1, 7))
+            lost = np.sort(rng.choice(K, nl, replace=False)).astype(np.uint32)
+            resi = (K + rng.choice(60, nl, replace=False)).astype(np.uint32)
+            isis, _ = decode_setup(orc, K, lost, resi)
+            lost_l.append(lost); resi_l.append(resi); reps_l.append(all_rep[0][resi - K]); expect.append(orc.plan_probe(K, isis)[0] == 1)
+        work = np.repeat(src.reshape(1, K, T), 150, axis=0).copy()
+        for b in range(150):
+            work[b][lost_l[b]] = 0xFF
+        st, out, _ = G.gpu_decode(work, K, T, lost_l, resi_l, reps_l)
+        assert [bool(x) for x in st] == expect and not all(expect)
+    finally:
+        c.set_option("plan_split_force", 0)
+        c.set_option("encplan_dev_min_l", 12000)
+        c.clear_plan_cache()
