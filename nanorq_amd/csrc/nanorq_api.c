@@ -117,19 +117,62 @@ static struct part partition(size_t I, size_t J) { /* nanorq.c:83-95 */
   return p;
 }
 
+/* Page-locking memory costs about as much as copying it three times (hipHostMalloc pins at ~3 GB/s), so page-locked
+ * host rows are recycled through a small cache: an object that is freed leaves its buffers to the next one. */
+#define PIN_CACHE_SLOTS 512
+#define PIN_CACHE_BYTES ((size_t)8 << 30)
+static struct { void *p; size_t cap; } g_pin_cache[PIN_CACHE_SLOTS];
+static size_t g_pin_cached;
+static pthread_mutex_t g_pin_lock = PTHREAD_MUTEX_INITIALIZER;
+
 static void *host_alloc(size_t bytes, bool *pinned) { /* zeroed; page-locked from PIN_MIN on when there is a GPU */
   void *p = NULL;
   *pinned = false;
-  if (bytes >= PIN_MIN && ctx() && nrq_host_alloc_pinned(bytes, &p) == 0 && p) {
-    memset(p, 0, bytes);
-    *pinned = true;
-    return p;
+  if (bytes >= PIN_MIN && ctx()) {
+    pthread_mutex_lock(&g_pin_lock);
+    int best = -1;
+    for (int i = 0; i < PIN_CACHE_SLOTS; i++)
+      if (g_pin_cache[i].p && g_pin_cache[i].cap >= bytes && g_pin_cache[i].cap <= bytes + bytes / 4 &&
+          (best < 0 || g_pin_cache[i].cap < g_pin_cache[best].cap))
+        best = i;
+    if (best >= 0) {
+      p = g_pin_cache[best].p;
+      g_pin_cached -= g_pin_cache[best].cap;
+      g_pin_cache[best].p = NULL;
+    }
+    pthread_mutex_unlock(&g_pin_lock);
+    if (!p) {
+      /* the capacity rides in front of the block (64 bytes keep the rows' alignment) */
+      void *raw = NULL;
+      if (nrq_host_alloc_pinned(bytes + 64, &raw) == 0 && raw) {
+        *(size_t *)raw = bytes;
+        p = (uint8_t *)raw + 64;
+      }
+    }
+    if (p) {
+      memset(p, 0, bytes);
+      *pinned = true;
+      return p;
+    }
   }
   return calloc(bytes ? bytes : 1, 1);
 }
 static void host_free(void *p, bool pinned) {
   if (!p) return;
-  if (pinned) nrq_host_free_pinned(p); else free(p);
+  if (!pinned) { free(p); return; }
+  const size_t cap = *(size_t *)((uint8_t *)p - 64);
+  pthread_mutex_lock(&g_pin_lock);
+  if (g_pin_cached + cap <= PIN_CACHE_BYTES)
+    for (int i = 0; i < PIN_CACHE_SLOTS; i++)
+      if (!g_pin_cache[i].p) {
+        g_pin_cache[i].p = p;
+        g_pin_cache[i].cap = cap;
+        g_pin_cached += cap;
+        p = NULL;
+        break;
+      }
+  pthread_mutex_unlock(&g_pin_lock);
+  if (p) nrq_host_free_pinned((uint8_t *)p - 64);
 }
 
 static bool mask_get(const struct blockst *b, size_t id) {
@@ -394,21 +437,22 @@ static bool block_extent(const nanorq *rq, uint8_t sbn, uint32_t K, size_t *off,
 
 static bool load_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct ioctx *io) { /* nanorq.c:175-182 */
   if (!io || !ensure_src(rq, b)) return false;
-  memset(b->src, 0, (size_t)(b->K ? b->K : 1) * rq->T);
   size_t off, len;
   if (block_extent(rq, sbn, b->K, &off, &len)) {
     /* no sub-blocking (the only case nanorq creates, nanorq.c:78): the block's symbols are one contiguous stretch
-     * of the object -- one seek and one read instead of K of each; bytes beyond F stay zero */
+     * of the object -- one seek and one read instead of K of each; bytes beyond F (or not delivered) are zero */
+    size_t got = 0;
     if (len && io->seek(io, off)) {
-      size_t got = 0;
       while (got < len) {
         const size_t n = io->read(io, b->src + got, len - got);
         if (n == 0) break;
         got += n;
       }
     }
+    memset(b->src + got, 0, (size_t)(b->K ? b->K : 1) * rq->T - got);
     return true;
   }
+  memset(b->src, 0, (size_t)(b->K ? b->K : 1) * rq->T);
   for (uint32_t esi = 0; esi < b->K; esi++) transfer_symbol(rq, sbn, esi, b->K, b->src + (size_t)esi * rq->T, io, 0);
   return true;
 }

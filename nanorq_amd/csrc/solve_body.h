@@ -372,8 +372,13 @@ template <int WB, int G = 1> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS
       v[q] = sv_zero<WB>();
       if (s[q] != NRQ_ROW_ZERO && strip < g.nstrips) {
         const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? g.rep + (size_t)(s[q] & 0x7FFFFFFFu) * g.T : g.src + (size_t)s[q] * g.T;
-        const uint32_t at = strip * (WB * G) + sub * WB, rem = at < g.T ? g.T - at : 0u;
-        if (rem) v[q] = g_get_stream<WB>(b + at, rem < (uint32_t)WB ? rem : (uint32_t)WB);
+        if constexpr (G == 1) {
+          const uint32_t rem = g.T - strip * WB;
+          v[q] = g_get_stream<WB>(b + (size_t)strip * WB, rem < (uint32_t)WB ? rem : (uint32_t)WB);
+        } else {
+          const uint32_t at = strip * (WB * G) + sub * WB, rem = at < g.T ? g.T - at : 0u;
+          if (rem) v[q] = g_get_stream<WB>(b + at, rem < (uint32_t)WB ? rem : (uint32_t)WB);
+        }
       }
     }
 #pragma unroll
@@ -992,11 +997,17 @@ template <int WB, int G = 1> SB_HD void pf_scatter(const GroupDst<WB> &g, const 
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np, i = u >> lsub, strip = g.strip0 + (u & pmask);
       if (u >= u1 || strip >= g.nstrips) continue;
-      const uint32_t at = strip * (WB * G) + sub * WB;
-      if (at >= g.T) continue;
-      const uint32_t rem = g.T - at;
-      NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + at;
-      g_put<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
+      if constexpr (G == 1) {
+        const uint32_t rem = g.T - strip * WB;
+        NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB;
+        g_put<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
+      } else {
+        const uint32_t at = strip * (WB * G) + sub * WB;
+        if (at >= g.T) continue;
+        const uint32_t rem = g.T - at;
+        NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + at;
+        g_put<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
+      }
     }
   }
 }
