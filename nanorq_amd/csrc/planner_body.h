@@ -100,6 +100,15 @@ static inline uint32_t pl_cas_(uint32_t *p, uint32_t c, uint32_t v) { uint32_t o
 
 SB_HD uint32_t pl_r16(uint32_t x) { return (x + 15u) & ~15u; }
 
+/* A pointer held in PlanCtx is generic as far as the compiler can tell, and every access through it a FLAT instruction:
+ * slower than a DS one, and ordered (vmcnt) behind the phase's outstanding global stores.  The workgroup state
+ * (pl_shared) and the dense-stage region always live in LDS, the peeling arrays when they fit: say so. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PL_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void *)(p)))
+#else
+#define PL_ASSUME_LDS(p) ((void)0)
+#endif
+
 /* ---- workgroup-shared scalars and small arrays (LDS) ---- */
 /* status: 0 ok, 1 = not decodable (too few symbols / rank deficient), 2 = a planner capacity was
  * exceeded (queues, inactive-column cap, arena, LDS): the caller re-plans that block on the host */
@@ -347,7 +356,7 @@ SB_HD uint8_t pl_gfmul(const pl_shared *sh, uint8_t a, uint8_t b) {
 
 /* =============================== phase 0: inputs, patch rows, state ========================== */
 template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const rq_params &p = c.p;
   if (tid == 0) {
     uint32_t st = 0;
@@ -397,7 +406,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 
 /* validate the inputs and expand the patched rows (thread per received repair symbol) */
 template <int Z> SB_HD void pl_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const rq_params &p = c.p;
   const uint32_t nl = c.job.nlost, pad = p.Kp - p.K;
@@ -449,7 +458,7 @@ template <int Z> SB_HD void pl_scan_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 SB_HD bool pl_peel_in_lds(const PlanCtx &c);
 /* fill the patch CSC; seed the first frontier with the rows that already have one V column */
 template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const rq_params &p = c.p;
   const uint32_t nl = c.job.nlost;
@@ -477,11 +486,6 @@ template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) 
  * otherwise, so PlanCtx holds it behind generic pointers -- and every access through one is a FLAT instruction:
  * slower than a DS one, and ordered (vmcnt) behind the phase's outstanding global stores.  The peeling phases are
  * therefore compiled twice; the LDS instance tells the compiler where its three pointers point. */
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PL_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void *)(p)))
-#else
-#define PL_ASSUME_LDS(p) ((void)0)
-#endif
 struct PlPeel { uint32_t *rowstate, *rowinfo, *colinfo; };
 template <bool LDS> SB_HD PlPeel pl_peel_state(const PlanCtx &c) {
   PlPeel s{c.rowstate, c.rowinfo, c.colinfo};
@@ -494,7 +498,7 @@ template <bool LDS> SB_HD PlPeel pl_peel_state(const PlanCtx &c) {
  * column join the next frontier (queue of parity `np`).  `lvl1` (pivot level + 1) is folded into the
  * rows' level-so-far; 0 for an inactivated column.  A group of `lanes` lanes strides over the row list. */
 template <bool LDS> SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lvl1, uint32_t np, uint32_t lane0, uint32_t lanes) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const uint32_t dec = (1u << 24) | col;
   uint16_t *nextq = sh->queue[np];
   const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a;
@@ -521,7 +525,7 @@ template <bool LDS> SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint3
  * A: every frontier row that still has exactly one V column tries to claim it (compare-and-swap on the
  *    column); the winner becomes a pivot at the level its earlier column drops accumulated. */
 template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t pq = rd & 1u;
   const uint16_t *fq = sh->queue[pq];
@@ -550,7 +554,7 @@ template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t rd, uint32_t tid
 /* B: the claimed columns leave V.  A group of 8..64 lanes per column -- as many as the round's claim count leaves
  * (most rounds claim a dozen columns; each trip over a column's row list is a dependent HBM/L2 round trip) */
 template <bool LDS> SB_HD void pl_round_drop_t(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t pq = rd & 1u;
   const uint32_t nc = sh->nclaim[pq] < PL_QCAP ? sh->nclaim[pq] : PL_QCAP;
@@ -573,7 +577,7 @@ template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid,
  * the highest valid one are popped; a chunk without a valid entry is popped whole and the search repeats
  * (planner_seq.h).  Only when the stack runs empty are all rows scanned (pl_inact_find_b). */
 template <bool LDS> SB_HD void pl_inact_find_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24; /* rep-th row of this inactivation event */
   const uint32_t n = sh->ncand[0], lo = n > nt ? n - nt : 0u, i = lo + tid;
@@ -592,7 +596,7 @@ template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rdrep, uint32_t t
 }
 /* pop what the search found invalid: everything above the highest valid entry, or the whole chunk */
 template <int Z> SB_HD void pl_inact_find_c(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (tid != 0) return;
   const uint32_t n = sh->ncand[0];
   sh->ncand[0] = sh->best != PL_NONE ? sh->ncand[1] : (n > nt ? n - nt : 0u);
@@ -601,7 +605,7 @@ template <int Z> SB_HD void pl_inact_find_c(PlanCtx &c, uint32_t rdrep, uint32_t
 }
 /* the stack is empty and nothing was found: the sparsest of all open rows (workgroup-wide atomic min) */
 template <bool LDS> SB_HD void pl_inact_find_b_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   uint32_t best = PL_NONE;
   for (uint32_t r = tid; r < sh->M; r += nt) {
@@ -622,7 +626,7 @@ template <int Z> SB_HD void pl_inact_find_b(PlanCtx &c, uint32_t rdrep, uint32_t
 }
 /* inactivate all but one V column of that row (or every remaining V column if no row is left) */
 template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   const rq_params &p = c.p;
   const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
@@ -684,7 +688,7 @@ template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rdrep, uint32_
   PL_PEEL_DISPATCH(pl_inact_apply_a_t, c, rdrep, tid, nt);
 }
 template <bool LDS> SB_HD void pl_inact_apply_b_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
   const uint32_t pq = rd & 1u;
@@ -743,7 +747,7 @@ SB_HD uint32_t pl_op_group(const uint16_t *collev, uint32_t t, uint32_t r, uint3
 }
 /* number of levels = deepest pivot + 1 (one reduction here instead of an atomic per claim) */
 template <int Z> SB_HD void pl_lev_0(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   uint32_t m = 0;
   for (uint32_t k = tid; k < sh->npiv; k += nt) {
     const uint32_t lv = (c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK) + 1u;
@@ -753,7 +757,7 @@ template <int Z> SB_HD void pl_lev_0(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (m && PL_WAVE_LEADER(tid)) PL_ATOM_MAX(&sh->nlev, m);
 }
 template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (tid == 0) {
     const uint32_t u = c.p.L - sh->npiv;
     sh->wpr = u ? (u + 31u) / 32u : 1u;
@@ -762,7 +766,7 @@ template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   for (uint32_t l = tid; l < sh->nlev + 2u; l += nt) { c.lev_ops[l] = 0; c.lev_fill[l] = 0; }
 }
 template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (uint32_t *l = pl_lds_lev(c)) { /* nlev is final now */
     for (uint32_t k = tid; k < 4u * pl_lev_words(c); k += nt) l[k] = 0;
     uint16_t *collev = pl_col_level(c);
@@ -826,7 +830,7 @@ SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16
   }
 }
 template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr, S = c.p.S;
   const uint32_t total = sh->npiv + sh->nlow;
@@ -919,7 +923,7 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 /* the long rows (slots [0,S)) listed by pl_w_init: 64 lanes each; the destination words were zeroed in pl_lev_b */
 template <int Z> SB_HD void pl_w_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t wpr = sh->wpr, lane = tid & 63u, nlong = sh->nq[0];
   uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lev_ctr(c, 1);
@@ -961,7 +965,7 @@ SB_HD uint32_t pl_group_rows(uint32_t n) { return (n + NRQ_ROW - 1u) / NRQ_ROW; 
 /* stage the per-level op counts / chunk bases in LDS so that a level of the W pass starts without a trip
  * to HBM; prefetch the first group's ops */
 template <int Z> SB_HD void pl_w_stage(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t need = pl_r16((sh->nlev + 2u) * 8u) + 2u * PL_OPQ_WORDS * 4u;
   const bool ok = need <= c.aux_bytes;
@@ -975,7 +979,7 @@ template <int Z> SB_HD void pl_w_stage(PlanCtx &c, uint32_t tid, uint32_t nt) {
  * wpr > 8 each lane takes several words).  While a group is processed the op words of the next group are
  * fetched into the other LDS buffer. */
 template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr;
   const bool lds = sh->lv_in_lds != 0u;
@@ -1081,7 +1085,7 @@ template <int Z> SB_HD void pl_wfast_restore(PlanCtx &c, uint32_t tid, uint32_t 
   for (uint32_t k = tid; k < c.p.L; k += nt) c.colinfo[k] = ci[k];
 }
 template <int Z> SB_HD void pl_wfast_load(PlanCtx &c, uint32_t strip, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t wpl = pl_wfast_wb(c) / 4u, wpr = sh->wpr, n = (sh->M + NRQ_SCRATCH) * wpl;
   uint32_t *img = reinterpret_cast<uint32_t *>(c.lds_dyn);
@@ -1091,7 +1095,7 @@ template <int Z> SB_HD void pl_wfast_load(PlanCtx &c, uint32_t strip, uint32_t t
   }
 }
 template <int Z> SB_HD void pl_wfast_store(PlanCtx &c, uint32_t strip, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t wpl = pl_wfast_wb(c) / 4u, wpr = sh->wpr, n = sh->M * wpl;
   const uint32_t *img = reinterpret_cast<const uint32_t *>(c.lds_dyn) + NRQ_SCRATCH * wpl;
@@ -1105,7 +1109,7 @@ SB_HD uint32_t pl_wfast_rows(const PlanCtx &c) { return c.sh->spare_base; }
 
 /* =============================== phase 3: leftover rows ====================================== */
 template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /* list them */
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const rq_params &p = c.p;
   for (uint32_t r = tid; r < sh->M; r += nt) {
     if (!(c.rowinfo[r] & PL_UNASSIGNED) || (r >= p.S && r < p.S + p.H)) continue;
@@ -1114,7 +1118,7 @@ template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /*
   }
 }
 template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (tid != 0) return;
   sh->nq[0] = 0; /* the frontier queue becomes pl_w_init's list of long rows */
   sh->lpr = (sh->nlow + PL_EXTRA_ROWS + 31u) / 32u; /* room for the rows a rank-deficient block may add */
@@ -1130,15 +1134,15 @@ template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (need > c.dense_bytes || sh->wpr > 40u) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
 }
 /* HDPC rows over the inactive columns, transposed: 16 bytes (one per HDPC row) per inactive column */
-SB_HD uint8_t *pl_mhm(const PlanCtx &c) { return c.dense_lds; }
-SB_HD uint32_t *pl_mb(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(c.dense_lds + c.sh->tmp_mhoff); }
-SB_HD uint8_t *pl_gtile(const PlanCtx &c) { return c.dense_lds + c.sh->tmp_mhoff; }
+SB_HD uint8_t *pl_mhm(const PlanCtx &c) { uint8_t *q = c.dense_lds; PL_ASSUME_LDS(q); return q; }
+SB_HD uint32_t *pl_mb(const PlanCtx &c) { uint32_t *q = reinterpret_cast<uint32_t *>(c.dense_lds + c.sh->tmp_mhoff); PL_ASSUME_LDS(q); return q; }
+SB_HD uint8_t *pl_gtile(const PlanCtx &c) { uint8_t *q = c.dense_lds + c.sh->tmp_mhoff; PL_ASSUME_LDS(q); return q; }
 SB_HD uint32_t *pl_wtile(const PlanCtx &c) { return reinterpret_cast<uint32_t *>(pl_gtile(c) + PL_MH_TILE * 16u); }
 
 /* reduced coefficient rows of the leftover rows over the inactive columns (their W rows after the op
  * stream has run), with the augmented identity, into LDS */
 template <int Z> SB_HD void pl_low_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t wpr = sh->wpr, rowlen = sh->rowlen;
   uint32_t *Mb = pl_mb(c);
@@ -1170,7 +1174,7 @@ SB_HD uint32_t pl_group_span(uint32_t l, uint32_t nf, uint32_t n) {
 /* per group: op counts to the workspace, rows to LDS (the frontier queues are free by now) for the prefix sums of
  * pl_ops_layout -- when the groups are too many for that, pl_ops_layout walks them alone */
 template <int Z> SB_HD void pl_ops_layout_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lds_lev(c) ? pl_lev_ctr(c, 1) : nullptr;
   const bool in_lds = sh->nlev + 1u <= 2u * PL_QCAP;
   uint16_t *rowq = &sh->queue[0][0];
@@ -1185,7 +1189,7 @@ template <int Z> SB_HD void pl_ops_layout_a(PlanCtx &c, uint32_t tid, uint32_t n
   }
 }
 template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   /* row base of every group (1..nlev-1: pivot levels, nlev: leftover rows); the stream starts with the NRQ_RING
    * lead rows */
   const bool in_lds = sh->nlev + 1u <= 2u * PL_QCAP;
@@ -1214,7 +1218,7 @@ template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt)
   if (sh->arena_top > c.job.arena_cap) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
 }
 template <int Z> SB_HD void pl_ops_clear(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
   const uint32_t nw = sh->opbase * NRQ_ROW;
@@ -1263,7 +1267,7 @@ SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t lev, uint3
   }
 }
 template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   if (pl_col_level(c)) { /* the ops were recorded with their place: finishing ops from the front of the group, early ops behind them */
     uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
@@ -1297,7 +1301,7 @@ template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
 /* MhT[x] = G_U[:,x] ^ SUM_k W[k][x] * G[:, pivcol k]  (16 bytes per inactive column x, in LDS).  The pivots
  * are streamed through LDS in tiles: their HDPC columns (16 bytes each, kconst GT) and their W rows. */
 template <int Z> SB_HD void pl_mh_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const rq_params &p = c.p;
   const uint32_t u = p.L - sh->npiv, n_hd = p.Kp + p.S;
@@ -1315,7 +1319,7 @@ template <int Z> SB_HD void pl_mh_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
   }
 }
 template <int Z> SB_HD void pl_mh_load(PlanCtx &c, uint32_t tile, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t k0 = tile * PL_MH_TILE, wpr = sh->wpr;
   const uint32_t cnt = (sh->npiv - k0) < PL_MH_TILE ? (sh->npiv - k0) : PL_MH_TILE;
@@ -1328,7 +1332,7 @@ template <int Z> SB_HD void pl_mh_load(PlanCtx &c, uint32_t tile, uint32_t tid, 
   }
 }
 template <int Z> SB_HD void pl_mh_acc(PlanCtx &c, uint32_t tile, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t k0 = tile * PL_MH_TILE, wpr = sh->wpr, u = c.p.L - sh->npiv;
   const uint32_t cnt = (sh->npiv - k0) < PL_MH_TILE ? (sh->npiv - k0) : PL_MH_TILE;
@@ -1401,7 +1405,7 @@ template <int Z> SB_HD void pl_mh_part_flush(PlanCtx &c, uint32_t tid, uint32_t 
  * bit x+1 of a row publishes that bit and bids for column x+1 (step A is only run for a column that has no
  * predecessor step).  Slot (x + 2) % 3 is cleared for the bids of the step after. */
 template <int Z> SB_HD void pl_gj_a(PlanCtx &c, uint32_t x, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const uint32_t *Mb = pl_mb(c);
   const uint32_t rowlen = sh->rowlen;
   for (uint32_t j = tid; j < sh->nlow; j += nt) {
@@ -1413,7 +1417,7 @@ template <int Z> SB_HD void pl_gj_a(PlanCtx &c, uint32_t x, uint32_t tid, uint32
 /* step B: eliminate the column from every other row that has it (or record a free column);
  * bit 31 of the argument: prepare column x + 1 */
 template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t xarg, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const uint32_t x = xarg & 0x7FFFFFFFu, prep = xarg >> 31, xn = x + 1u;
   const uint32_t pr = sh->cand[x % 3u];
   uint32_t *Mb = pl_mb(c);
@@ -1450,7 +1454,7 @@ template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t xarg, uint32_t tid, uin
 
 /* the GF(2) combinations E_q (slot M+q) as one more accumulate-only group of XOR ops */
 template <int Z> SB_HD void pl_bin_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (tid == 0) {
     sh->tmp1 = 0;
   }
@@ -1463,7 +1467,7 @@ template <int Z> SB_HD void pl_bin_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   }
 }
 template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (tid != 0) return;
   uint32_t run = 0;
   for (uint32_t q = 0; q < sh->r2; q++) { uint32_t n = c.pivdeg[q]; c.pivdeg[q] = run; run += n; }
@@ -1475,7 +1479,7 @@ template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
     (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* op fields are 16 bits */
 }
 template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t g = sh->nlev + 1u, n = c.lev_ops[g];
   uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops) + (size_t)c.lev_base[g] * NRQ_ROW;
@@ -1498,7 +1502,7 @@ template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 /* =============================== phase 7: the free columns over GF(256) ====================== */
 /* coefficient columns mh[h][q], free-column masks fbits[q], and the H x (nfree+H) augmented system */
 template <int Z> SB_HD void pl_dense_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   /* more free columns than HDPC rows: rank deficient for sure (decided identically by every thread) */
   const bool feasible = sh->nfree <= c.p.H && sh->nfree <= NRQ_MAX_FREE;
@@ -1522,7 +1526,7 @@ template <int Z> SB_HD void pl_dense_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   for (uint32_t h = tid; h < PL_MAXH; h += nt) sh->taken[h] = 0;
 }
 template <int Z> SB_HD void pl_dense_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status || !sh->dense_ok) return;
   const uint32_t H = c.p.H, r2 = sh->r2, nfree = sh->nfree, aw = nfree + H;
   const uint8_t *Mh = pl_mhm(c);
@@ -1541,7 +1545,7 @@ template <int Z> SB_HD void pl_dense_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 /* one elimination step on the augmented system: column f.  Thread w owns augmented column w. */
 template <int Z> SB_HD void pl_dense_step_a(PlanCtx &c, uint32_t f, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status || !sh->dense_ok || tid != 0) return;
   const uint32_t H = c.p.H, aw = sh->nfree + H;
   uint32_t pr = PL_NONE;
@@ -1554,7 +1558,7 @@ template <int Z> SB_HD void pl_dense_step_a(PlanCtx &c, uint32_t f, uint32_t tid
   for (uint32_t h = 0; h < H; h++) sh->colf[h] = sh->aug[h * aw + f]; /* snapshot of the pivot column */
 }
 template <int Z> SB_HD void pl_dense_step_b(PlanCtx &c, uint32_t f, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status || !sh->dense_ok) return;
   const uint32_t H = c.p.H, aw = sh->nfree + H, pr = sh->tmp1;
   if (tid >= aw) return;
@@ -1571,7 +1575,7 @@ template <int Z> SB_HD void pl_dense_step_b(PlanCtx &c, uint32_t f, uint32_t tid
   sh->aug[pr * aw + tid] = scaled;
 }
 template <int Z> SB_HD void pl_dense_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status == 0 && !sh->dense_ok && tid == 0) sh->status = PL_FAIL_SINGULAR; /* and no symbol left to add */
   if (sh->status || !sh->dense_ok) return;
   const uint32_t H = c.p.H, nfree = sh->nfree, aw = nfree + H;
@@ -1587,7 +1591,7 @@ template <int Z> SB_HD void pl_dense_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
  * data ops go into the spare chunks of the op stream, its coefficient row over the inactive columns is
  * reduced against the Gauss-Jordan state, and if something is left it pivots one free column. */
 template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status || tid != 0) return;
   const rq_params &p = c.p;
   const uint32_t i = sh->npatch;
@@ -1618,7 +1622,7 @@ template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 /* its bit row over the inactive columns: own inactive entries plus the W rows of its pivot columns */
 template <int Z> SB_HD void pl_extra_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t wpr = sh->wpr, rowlen = sh->rowlen, j = sh->nlow - 1u, row = c.lowslot[j];
   if (tid >= rowlen) return;
@@ -1639,7 +1643,7 @@ template <int Z> SB_HD void pl_extra_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 /* reduce it against the pivots found so far (pivot rows are fully reduced, so the order does not matter) */
 template <int Z> SB_HD void pl_extra_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t rowlen = sh->rowlen, j = sh->nlow - 1u;
   if (tid >= rowlen) return;
@@ -1653,7 +1657,7 @@ template <int Z> SB_HD void pl_extra_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 /* whatever is left sits in free columns: the first of them becomes this row's pivot column */
 template <int Z> SB_HD void pl_extra_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status || tid != 0) return;
   const uint32_t *row = pl_mb(c) + (size_t)(sh->nlow - 1u) * sh->rowlen;
   sh->xcol = PL_NONE;
@@ -1675,7 +1679,7 @@ template <int Z> SB_HD void pl_mark_failed(PlanCtx &c, uint32_t tid, uint32_t nt
 
 /* =============================== phase 8: maps, W image, job ================================= */
 template <int Z> SB_HD void pl_final_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const rq_params &p = c.p;
   const uint32_t n_hd = p.Kp + p.S, u = p.L - sh->npiv;
@@ -1692,7 +1696,7 @@ template <int Z> SB_HD void pl_final_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   }
 }
 template <int Z> SB_HD void pl_final_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   for (uint32_t k = tid; k < sh->npiv; k += nt) {
     c.colslot[c.pivcol[k]] = c.pivslot[k];
@@ -1713,7 +1717,7 @@ template <int Z> SB_HD void pl_final_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   }
 }
 template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const rq_params &p = c.p;
   const uint32_t wpr = sh->wpr, stride = sh->tmp0, nl = c.job.nlost;
@@ -1748,7 +1752,7 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   (void)cptr; (void)osl;
 }
 template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const rq_params &p = c.p;
   if (!sh->status && c.job.nlost <= 2u * PL_QCAP) {
     /* the list offsets of the missing symbols: every thread sums the lengths before its own entry (LDS reads, no
@@ -1817,7 +1821,7 @@ SB_HD void pl_wt_fill(uint8_t *arena, const uint32_t *wrows, uint32_t e0, uint32
 
 /* the missing source symbols' LT neighbour lists, translated to slots (uses cptr from the step before) */
 template <int Z> SB_HD void pl_final_e(PlanCtx &c, uint32_t tid, uint32_t nt) {
-  pl_shared *sh = c.sh;
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const rq_params &p = c.p;
   const uint32_t nl = c.job.nlost;
