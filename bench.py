@@ -414,8 +414,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     # solve-kernel launches of all streams on one time axis (HIP events recorded around each launch)
-    intervals = []
+    intervals, ptimes = [], []
     for c_ in ctxs:
+        ptimes += c_.ptime_read()
         intervals += c_.ktime_read_intervals(ref=ctx)
         c_.ktime_enable(False)
     ktimes = [d for _, d in intervals]
@@ -577,6 +578,7 @@ def main():
             "check": check,
             "roofline": roof, "e2e": e2e, "cpu_baseline": cpu,
             "detail": {"solve_kernel_ms_sum_per_step": sum(ktimes) / args.steps,
+                       "planner_ms": (sum(ptimes) / len(ptimes)) if ptimes else None,
                        # the solve launches of a step are [encode, decode] per stream group, in that order
                        "encode_solve_ms": (sum(ktimes[0::2]) / max(1, len(ktimes[0::2]))) if nstreams == 1 else None,
                        "decode_solve_ms": (sum(ktimes[1::2]) / max(1, len(ktimes[1::2]))) if nstreams == 1 else None,

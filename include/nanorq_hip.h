@@ -169,6 +169,8 @@ int nrq_scatter_symbols(nrq_ctx *ctx, int stream, const void *d_blob, uint32_t n
  * synchronises, returns the durations of the launches since the last read/enable in launch order. */
 int nrq_ktime_enable(nrq_ctx *ctx, int on);
 int nrq_ktime_read(nrq_ctx *ctx, float *ms_out, uint32_t cap, uint32_t *count);
+/* same for the decode planner (all kernels of a planner run, on the stream they run on) */
+int nrq_ptime_read(nrq_ctx *ctx, float *ms_out, uint32_t cap, uint32_t *count);
 /* same as intervals [start, start+dur) in ms after ref's nrq_ktime_enable(1); ref may be another context of the
  * same GPU, so that launches of several streams can be put on one time axis */
 int nrq_ktime_read_intervals(nrq_ctx *ctx, nrq_ctx *ref, float *start_ms, float *dur_ms, uint32_t cap, uint32_t *count);

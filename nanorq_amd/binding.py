@@ -66,6 +66,7 @@ def lib():
     L.nrq_dev_memset.argtypes = [vp, vp, C.c_int, sz]
     L.nrq_ktime_enable.argtypes = [vp, C.c_int]
     L.nrq_ktime_read.argtypes = [vp, C.POINTER(C.c_float), C.c_uint32, u32p]
+    L.nrq_ptime_read.argtypes = [vp, C.POINTER(C.c_float), C.c_uint32, u32p]
     L.nrq_ktime_read_intervals.argtypes = [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, u32p]
     L.nrq_timer_start.argtypes = [vp]
     L.nrq_timer_stop_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -251,6 +252,13 @@ class Context:
         buf = (C.c_float * cap)()
         n = C.c_uint32()
         self._chk(self._L.nrq_ktime_read(self._h, buf, cap, C.byref(n)))
+        return [float(buf[k]) for k in range(min(cap, n.value))]
+
+    def ptime_read(self, cap=65536):
+        """durations (ms) of the decode planner runs since ktime_enable"""
+        buf = (C.c_float * cap)()
+        n = C.c_uint32()
+        self._chk(self._L.nrq_ptime_read(self._h, buf, cap, C.byref(n)))
         return [float(buf[k]) for k in range(min(cap, n.value))]
 
     def ktime_read_intervals(self, ref=None, cap=65536):

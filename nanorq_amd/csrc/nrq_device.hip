@@ -363,7 +363,8 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
                                                          const nrq_planjob *__restrict__ pjobs,
                                                          nrq_job *__restrict__ jobs_out, uint32_t nblk, uint32_t Mcap,
                                                          uint32_t npcap, uint32_t ucap, uint32_t lds_dyn_bytes,
-                                                         unsigned long long *__restrict__ prof, uint32_t seg) {
+                                                         unsigned long long *__restrict__ prof, uint32_t seg, uint32_t qcap,
+                                                         uint32_t lowcap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (b >= nblk) return;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
   uint8_t *dyn = smem;
   pl_shared *sh = reinterpret_cast<pl_shared *>(smem + lds_dyn_bytes);
   PlanCtx c;
-  pl_ctx_setup(c, p, kc, pjobs[b], sh, dyn, lds_dyn_bytes, Mcap, npcap, ucap, jobs_out + b);
+  pl_ctx_setup(c, p, kc, pjobs[b], sh, dyn, lds_dyn_bytes, Mcap, npcap, ucap, jobs_out + b, qcap, lowcap, (uint32_t)NT);
   /* NRQ_PROF=1: thread 0 of block 0 accumulates shader clocks per phase family (index = PL_TAG) */
   unsigned long long t_prev = prof ? (unsigned long long)clock64() : 0ull;
 #define PL_ACC(tag) do { if (prof && b == 0 && tid == 0) { unsigned long long t_ = (unsigned long long)clock64(); \
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(1024) void nrq_mh_kernel(rq_params p, const uint8_t
   const uint32_t part = blockIdx.x, nparts = gridDim.x, b = blockIdx.y, tid = threadIdx.x;
   pl_shared *sh = reinterpret_cast<pl_shared *>(smem + lds_dyn_bytes);
   PlanCtx c;
-  pl_ctx_setup(c, p, kc, pjobs[b], sh, smem, lds_dyn_bytes, Mcap, npcap, ucap, nullptr);
+  pl_ctx_setup(c, p, kc, pjobs[b], sh, smem, lds_dyn_bytes, Mcap, npcap, ucap, nullptr, PL_QCAP, PL_LOWCAP, PL_NT); /* (as the big planner workgroup) */
   pl_sh_restore<0>(c, tid, 1024u);
   __syncthreads();
   if (sh->status != 0 || sh->nV != 0) return;
@@ -725,6 +726,7 @@ struct Tuning {
   bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
   bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
   int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
+  bool plan_small_state = true;  /* NRQ_PLAN_BIG_STATE clears it: small blocks' planner workgroups keep the full-size queues */
   bool plan_split_force = false; /* "plan_split_force": every block planned in two parts + helper kernels (tests) */
   bool no_plan_split = false;  /* NRQ_NO_PLAN_SPLIT: big blocks planned by one kernel (no helper kernels for the HDPC fold / W transposition) */
   bool no_plan_stream = false; /* NRQ_NO_PLAN_STREAM: planner kernel on the caller's stream (no overlap with the solve before it) */
@@ -741,6 +743,7 @@ struct Tuning {
     no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
+    plan_small_state = !flag("NRQ_PLAN_BIG_STATE");
   }
 };
 
@@ -766,6 +769,8 @@ struct nrq_ctx {
   hipEvent_t ktime_base = nullptr; /* recorded by nrq_ktime_enable: origin of the launch intervals */
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ktime_pool;
   size_t ktime_used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ptime_pool; /* same for the planner launches (all kernels of a planner run) */
+  size_t ptime_used = 0;
   unsigned long long *prof = nullptr; /* NRQ_PROF=1 */
   /* device planner */
   int planner = 1; /* 1 = device planner for decode (default), 0 = host planner */
@@ -872,7 +877,7 @@ int get_kconst(nrq_ctx *ctx, uint32_t K, KConst **out) {
  * planner in two parts with helper kernels between and after them (planner_seq.h).  The jobs carry the choice in
  * bit 8 of nrq_planjob::mode (pl_final_c then leaves the W transposition to nrq_wt_kernel). */
 bool plan_is_segmented(const nrq_ctx *ctx, const rq_params &p, uint32_t Mcap) {
-  const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared)), dyn = NRQ_LDS_MAX - sh_bytes;
+  const uint32_t sh_bytes = pl_shared_bytes(PL_QCAP, PL_LOWCAP, PL_NT), dyn = NRQ_LDS_MAX - sh_bytes;
   const uint32_t need = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u);
   if (ctx->tune.plan_split_force) return true; /* (tests: the segmented path at sizes the oracle checks quickly) */
   return need + pl_dense_reserve(p.L) > dyn && !ctx->tune.no_plan_split;
@@ -881,16 +886,27 @@ bool plan_is_segmented(const nrq_ctx *ctx, const rq_params &p, uint32_t Mcap) {
 int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const uint8_t *d_kc, const nrq_planjob *d_pj,
                        nrq_job *d_jobs, uint32_t nblk, uint32_t Mcap, uint32_t npcap, uint32_t ucap, unsigned long long *pprof,
                        uint32_t nnzcap) {
-  const uint32_t sh_bytes = (uint32_t)r16(sizeof(pl_shared));
+  /* The workgroup state (pl_shared and the arrays behind it: frontier queues, claim lists, per-thread scratch, Gauss-Jordan
+   * flags) is sized by the launch: 25 KB for big blocks; a small block's frontier and dense stage need a fraction, and
+   * with 8 KB of it four 256-thread planner workgroups share a CU instead of two (the planner is latency bound: twice
+   * the workgroups, half the time).  Overflowing a capacity is reported as such and re-planned on the host. */
+  uint32_t qcap = PL_QCAP, lowcap = PL_LOWCAP;
+  uint32_t sh_bytes = pl_shared_bytes(qcap, lowcap, PL_NT);
   /* dynamic LDS: everything a CU has for a big block; for small blocks what the planner can use (peeling state plus the
-   * dense-stage reserve, or a 16-byte strip image of the W rows), so that two workgroups share a CU */
+   * dense-stage reserve, or a 16-byte strip image of the W rows), so that several workgroups share a CU */
   uint32_t dyn_bytes = NRQ_LDS_MAX - sh_bytes;
   bool small_wg = false; /* 256-thread workgroups: a small block has no use for 1024 threads, a CU has for 4 blocks */
   {
     const uint32_t peel = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L);
     const uint32_t wimg = (Mcap + 320u + NRQ_SCRATCH) * 16u;
     const uint32_t fit = pl_r16((peel > wimg ? peel : wimg) + 2048u);
-    if (fit + sh_bytes <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) { dyn_bytes = fit; small_wg = !ctx->tune.plan_big_wg; }
+    const uint32_t q_s = p.L <= 1500u ? 512u : 1024u, low_s = p.L <= 1500u ? 384u : 768u;
+    const uint32_t sh_s = ctx->tune.plan_small_state ? pl_shared_bytes(q_s, low_s, PL_NT_MIN) : sh_bytes;
+    if (fit + sh_s <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) {
+      dyn_bytes = fit;
+      small_wg = !ctx->tune.plan_big_wg;
+      if (small_wg && ctx->tune.plan_small_state) { qcap = q_s; lowcap = low_s; sh_bytes = sh_s; }
+    }
   }
   const bool seg = plan_is_segmented(ctx, p, Mcap);
   if (seg && ctx->tune.plan_split_force) {
@@ -900,6 +916,7 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     const uint32_t only_dense = (pl_dense_reserve(p.L) + need - 16u) & ~15u; /* 16 bytes short of holding the peeling state */
     if (only_dense < dyn_bytes) dyn_bytes = only_dense;
     small_wg = false;
+    qcap = PL_QCAP; lowcap = PL_LOWCAP; sh_bytes = pl_shared_bytes(qcap, lowcap, PL_NT);
   }
   const uint32_t mh_dyn = 72u * 1024u; /* nrq_mh_kernel: MhT (16 B x u <= 20 KB) + the tiles (4 KB + 256 x wpr words <= 40 KB) */
   if (!ctx->plan_attr) {
@@ -916,10 +933,10 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
   for (uint32_t part = seg ? 1u : 0u; part <= (seg ? 2u : 0u); part++) {
     if (small_wg)
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
-                         nblk, Mcap, npcap, ucap, dyn_bytes, pprof, part);
+                         nblk, Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
     else
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
-                         Mcap, npcap, ucap, dyn_bytes, pprof, part);
+                         Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
     HIPCHK(ctx, hipGetLastError());
     if (part == 1u) {
       const uint32_t wp_lds = (Mcap + NRQ_SCRATCH) * 2u + 64u;
@@ -1471,6 +1488,7 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
     if (ctx->staged[i]) (void)hipEventDestroy(ctx->staged[i]);
   }
   for (auto &pr : ctx->ktime_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto &pr : ctx->ptime_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (ctx->ktime_base) (void)hipEventDestroy(ctx->ktime_base);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
@@ -1515,6 +1533,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
   else if (n == "no_plan_split") t.no_plan_split = value != 0;
   else if (n == "plan_split_force") t.plan_split_force = value != 0;
+  else if (n == "plan_small_state") t.plan_small_state = value != 0;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "solve_grid") t.solve_grid = (uint64_t)value;
   else if (n == "big_wg") t.big_wg = value != 0;
@@ -1863,10 +1882,24 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     HIPCHK(ctx, hipMalloc((void **)&pprof, 32 * 8));
     HIPCHK(ctx, hipMemsetAsync(pprof, 0, 32 * 8, ps));
   }
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  if (ctx->ktime_on) {
+    if (ctx->ptime_used == ctx->ptime_pool.size()) {
+      hipEvent_t a, b;
+      HIPCHK(ctx, hipEventCreate(&a));
+      HIPCHK(ctx, hipEventCreate(&b));
+      ctx->ptime_pool.emplace_back(a, b);
+    }
+    pe0 = ctx->ptime_pool[ctx->ptime_used].first;
+    pe1 = ctx->ptime_pool[ctx->ptime_used].second;
+    ctx->ptime_used++;
+    HIPCHK(ctx, hipEventRecord(pe0, ps));
+  }
   if ((rc = launch_plan_kernel(ctx, ps, p, kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
                                reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, pprof,
                                kh->nnz + npcap * PL_PATCH_STRIDE)))
     return rc;
+  if (pe1) HIPCHK(ctx, hipEventRecord(pe1, ps));
   if (pprof) {
     unsigned long long hp[32];
     HIPCHK(ctx, hipMemcpyAsync(hp, pprof, sizeof(hp), hipMemcpyDeviceToHost, ps));
@@ -2176,6 +2209,7 @@ int nrq_ktime_enable(nrq_ctx *ctx, int on) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->ktime_on = on != 0;
   ctx->ktime_used = 0;
+  ctx->ptime_used = 0;
   if (on) {
     if (!ctx->ktime_base) HIPCHK(ctx, hipEventCreate(&ctx->ktime_base));
     HIPCHK(ctx, hipEventRecord(ctx->ktime_base, ctx->stream));
@@ -2195,6 +2229,17 @@ int nrq_ktime_read_intervals(nrq_ctx *ctx, nrq_ctx *ref, float *start_ms, float 
   }
   *count = n;
   ctx->ktime_used = 0;
+  return 0;
+}
+int nrq_ptime_read(nrq_ctx *ctx, float *ms_out, uint32_t cap, uint32_t *count) {
+  if (!ctx || !count) return -1;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->plan_stream));
+  uint32_t n = (uint32_t)ctx->ptime_used;
+  for (uint32_t k = 0; k < n && k < cap; k++)
+    HIPCHK(ctx, hipEventElapsedTime(&ms_out[k], ctx->ptime_pool[k].first, ctx->ptime_pool[k].second));
+  *count = n;
+  ctx->ptime_used = 0;
   return 0;
 }
 int nrq_ktime_read(nrq_ctx *ctx, float *ms_out, uint32_t cap, uint32_t *count) {

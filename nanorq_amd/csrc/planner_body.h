@@ -49,7 +49,7 @@
 #define PL_LOWCAP 1344u /* leftover rows the dense stage can take (>= inactive-column cap 1280 + 32) */
 /* LDS kept for the dense stage when the peeling state is in LDS too: 36 KB for big blocks, less for small ones (whose
  * planner workgroups then share a CU) */
-SB_HD uint32_t pl_dense_reserve(uint32_t L) { const uint32_t r = 12u * 1024u + L * 6u; return r < 36u * 1024u ? (r + 15u) & ~15u : 36u * 1024u; }
+SB_HD uint32_t pl_dense_reserve(uint32_t L) { const uint32_t r = 8u * 1024u + L * 6u; return r < 36u * 1024u ? (r + 15u) & ~15u : 36u * 1024u; }
 
 /* what the host hands the planner for one block */
 typedef struct nrq_planjob {
@@ -130,17 +130,21 @@ typedef struct pl_shared {
   uint32_t lv_in_lds, opq_group[2];
   uint32_t tmp_mhoff; /* byte offset of Mb inside the dense LDS region, behind MhT (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
-  uint16_t queue[2][PL_QCAP];
-  uint16_t claim_l[PL_QCAP], claim_c[PL_QCAP]; /* columns claimed this round: level + 1 of the pivot, column */
-  uint32_t partial[PL_NT];
+  uint32_t pad_to_16[3];
+  /* The arrays whose size depends on the launch follow the struct in LDS (pl_tail_*): frontier queues queue[2][qcap],
+   * claim lists claim_l[qcap] / claim_c[qcap] (columns claimed this round: level + 1 of the pivot, column),
+   * partial[nt] (per-thread scratch), gj_flag[lowcap] / gj_used[lowcap] (Gauss-Jordan: bit of the current column /
+   * row already a pivot).  Small blocks get small ones, so that four planner workgroups share a CU. */
   uint32_t freex[NRQ_MAX_FREE];
   uint8_t gf_exp[512], gf_log[256];
   uint8_t aug[PL_MAXH * (NRQ_MAX_FREE + PL_MAXH)];
   uint8_t solver[NRQ_MAX_FREE];
   uint8_t taken[PL_MAXH];
   uint8_t colf[PL_MAXH];
-  uint8_t gj_flag[PL_LOWCAP], gj_used[PL_LOWCAP]; /* Gauss-Jordan: bit of the current column / row already a pivot */
 } pl_shared;
+SB_HD uint32_t pl_shared_bytes(uint32_t qcap, uint32_t lowcap, uint32_t nt) {
+  return pl_r16((uint32_t)sizeof(pl_shared)) + pl_r16(qcap * 8u) + pl_r16(nt * 4u) + pl_r16(lowcap * 2u);
+}
 
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
@@ -177,7 +181,7 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.rec_idx = o;    o = pl_r16(o + nnzcap * 4u);
   w.rec_g = o;      o = pl_r16(o + nnzcap * 2u);
   w.cand = o;       o = pl_r16(o + Mcap * 2u); /* stack of open rows with exactly two V columns (pl_inact_find) */
-  w.sh_save = o;    o = pl_r16(o + (uint32_t)sizeof(pl_shared)); /* pl_shared between the parts of a segmented run (planner_seq.h) */
+  w.sh_save = o;    o = pl_r16(o + pl_shared_bytes(PL_QCAP, PL_LOWCAP, PL_NT)); /* pl_shared (with its arrays) between the parts of a segmented run (planner_seq.h) */
   w.mh_ext = o;     o = pl_r16(o + ucap * PL_MAXH);               /* MhT as nrq_mh_kernel leaves it (16 bytes per inactive column) */
   w.total = o;
   return w;
@@ -207,6 +211,16 @@ struct PlanCtx {
   nrq_planjob job;
   const uint32_t *lost, *rep_esi;
   pl_shared *sh;
+  uint32_t qcap, lowcap, sh_bytes; /* capacities of the arrays behind pl_shared (pl_shared_bytes) */
+  uint16_t *qmem;    /* queue[2][qcap], claim_l[qcap], claim_c[qcap] */
+  uint32_t *partial; /* [nt] */
+  uint8_t *gjmem;    /* gj_flag[lowcap], gj_used[lowcap] */
+  SB_MEM uint16_t *queue(uint32_t pq) const { uint16_t *q = qmem + (size_t)pq * qcap; PL_ASSUME_LDS(q); return q; }
+  SB_MEM uint16_t *claim_l() const { uint16_t *q = qmem + 2u * (size_t)qcap; PL_ASSUME_LDS(q); return q; }
+  SB_MEM uint16_t *claim_c() const { uint16_t *q = qmem + 3u * (size_t)qcap; PL_ASSUME_LDS(q); return q; }
+  SB_MEM uint32_t *part() const { uint32_t *q = partial; PL_ASSUME_LDS(q); return q; }
+  SB_MEM uint8_t *gj_flag() const { uint8_t *q = gjmem; PL_ASSUME_LDS(q); return q; }
+  SB_MEM uint8_t *gj_used() const { uint8_t *q = gjmem + lowcap; PL_ASSUME_LDS(q); return q; }
   uint8_t *lds_dyn; /* dynamic LDS region: peeling state (if it fits) and the dense stage (Mb, Mh) */
   uint32_t lds_dyn_bytes;
   uint8_t *dense_lds;
@@ -243,7 +257,15 @@ struct PlanCtx {
 #endif
 SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, const nrq_planjob &job, pl_shared *sh,
                         uint8_t *lds_dyn, uint32_t lds_dyn_bytes, uint32_t Mcap, uint32_t npcap, uint32_t ucap,
-                        nrq_job *jobout) {
+                        nrq_job *jobout, uint32_t qcap = PL_QCAP, uint32_t lowcap = PL_LOWCAP, uint32_t nt = PL_NT) {
+  c.qcap = qcap; c.lowcap = lowcap;
+  c.sh_bytes = pl_shared_bytes(qcap, lowcap, nt);
+  {
+    uint8_t *t = reinterpret_cast<uint8_t *>(sh) + pl_r16((uint32_t)sizeof(pl_shared));
+    c.qmem = reinterpret_cast<uint16_t *>(t); t += pl_r16(qcap * 8u);
+    c.partial = reinterpret_cast<uint32_t *>(t); t += pl_r16(nt * 4u);
+    c.gjmem = t;
+  }
   c.kc = kc;
   c.kh = reinterpret_cast<const nrq_kconst_hdr *>(kc);
   c.p = prm;
@@ -401,7 +423,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     c.pc_fill[col] = 0;
   }
   for (uint32_t x = tid; x < p.P; x += nt) c.ucol[x] = (uint16_t)(p.W + x);
-  for (uint32_t j = tid; j < PL_LOWCAP; j += nt) sh->gj_used[j] = 0;
+  for (uint32_t j = tid; j < c.lowcap; j += nt) c.gj_used()[j] = 0;
 }
 
 /* validate the inputs and expand the patched rows (thread per received repair symbol) */
@@ -442,17 +464,17 @@ template <int Z> SB_HD void pl_scan_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t L = c.p.L, per = (L + nt - 1) / nt;
   uint32_t a = tid * per, b = a + per < L ? a + per : L, s = 0;
   for (uint32_t k = a; k < b; k++) s += c.pc_fill[k];
-  c.sh->partial[tid] = s;
+  c.part()[tid] = s;
 }
 template <int Z> SB_HD void pl_scan_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (tid != 0) return;
   uint32_t run = 0;
-  for (uint32_t t = 0; t < nt; t++) { uint32_t v = c.sh->partial[t]; c.sh->partial[t] = run; run += v; }
+  for (uint32_t t = 0; t < nt; t++) { uint32_t v = c.part()[t]; c.part()[t] = run; run += v; }
   c.pc_ptr[c.p.L] = run;
 }
 template <int Z> SB_HD void pl_scan_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t L = c.p.L, per = (L + nt - 1) / nt;
-  uint32_t a = tid * per, b = a + per < L ? a + per : L, run = c.sh->partial[tid];
+  uint32_t a = tid * per, b = a + per < L ? a + per : L, run = c.part()[tid];
   for (uint32_t k = a; k < b; k++) { uint32_t v = c.pc_fill[k]; c.pc_ptr[k] = run; run += v; c.pc_fill[k] = 0; }
 }
 SB_HD bool pl_peel_in_lds(const PlanCtx &c);
@@ -475,7 +497,7 @@ template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) 
     const uint32_t cnt = c.rowstate[r] >> 24;
     if (cnt == 1u) {
       uint32_t j = PL_ATOM_ADD(&sh->nq[0], 1u);
-      if (j < PL_QCAP) sh->queue[0][j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+      if (j < c.qcap) c.queue(0u)[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     } else if (cnt == 2u && !pl_peel_in_lds(c)) {
       c.cand[PL_ATOM_ADD(&sh->ncand[0], 1u)] = (uint16_t)r; /* (a row enters the stack once: at most M entries) */
     }
@@ -500,7 +522,7 @@ template <bool LDS> SB_HD PlPeel pl_peel_state(const PlanCtx &c) {
 template <bool LDS> SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lvl1, uint32_t np, uint32_t lane0, uint32_t lanes) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const uint32_t dec = (1u << 24) | col;
-  uint16_t *nextq = sh->queue[np];
+  uint16_t *nextq = c.queue(np);
   const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a;
   const uint32_t pa = c.pc_ptr[col], npc = c.pc_ptr[col + 1] - pa;
   for (uint32_t e = lane0; e < nb + npc; e += lanes) {
@@ -512,7 +534,7 @@ template <bool LDS> SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint3
     const uint32_t old = PL_ATOM_SUB(&s.rowstate[r], dec);
     if ((old >> 24) == 2u && (info & PL_UNASSIGNED)) {
       const uint32_t j = PL_ATOM_ADD(&sh->nq[np], 1u);
-      if (j < PL_QCAP) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+      if (j < c.qcap) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     } else if (!LDS && (old >> 24) == 3u && (info & PL_UNASSIGNED)) { /* two V columns left: a candidate of the next inactivation */
       const uint32_t j = PL_ATOM_ADD(&sh->ncand[0], 1u);
       if (j < c.Mcap) c.cand[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
@@ -528,8 +550,8 @@ template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t pq = rd & 1u;
-  const uint16_t *fq = sh->queue[pq];
-  const uint32_t nf = sh->nq[pq] < PL_QCAP ? sh->nq[pq] : PL_QCAP;
+  const uint16_t *fq = c.queue(pq);
+  const uint32_t nf = sh->nq[pq] < c.qcap ? sh->nq[pq] : c.qcap;
   for (uint32_t t = tid; t < nf; t += nt) {
     const uint32_t r = fq[t];
     const uint32_t st = s.rowstate[r], info = s.rowinfo[r];
@@ -542,7 +564,7 @@ template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_
     s.rowinfo[r] = (info & PL_PATCHED) | lv; /* assigned: bit 31 cleared */
     s.colinfo[col] = (PL_ST_PIVOT << 30) | k;
     PL_ATOM_SUB(&sh->nV, 1u); /* (the number of levels is taken from the pivots once peeling is over: pl_lev_0) */
-    if (i < PL_QCAP) { sh->claim_l[i] = (uint16_t)(lv + 1u); sh->claim_c[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    if (i < c.qcap) { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
     c.pivcol[k] = (uint16_t)col;
   }
@@ -557,12 +579,12 @@ template <bool LDS> SB_HD void pl_round_drop_t(PlanCtx &c, uint32_t rd, uint32_t
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t pq = rd & 1u;
-  const uint32_t nc = sh->nclaim[pq] < PL_QCAP ? sh->nclaim[pq] : PL_QCAP;
+  const uint32_t nc = sh->nclaim[pq] < c.qcap ? sh->nclaim[pq] : c.qcap;
   uint32_t lg = 3;
   while (lg < 6u && (nc << (lg + 1u)) <= nt) lg++;
   const uint32_t grp = tid >> lg, lane = tid & ((1u << lg) - 1u), ngrp = nt >> lg;
   for (uint32_t i = grp; i < nc; i += ngrp) {
-    pl_drop_column<LDS>(c, s, sh->claim_c[i], sh->claim_l[i], pq ^ 1u, lane, 1u << lg);
+    pl_drop_column<LDS>(c, s, c.claim_c()[i], c.claim_l()[i], pq ^ 1u, lane, 1u << lg);
   }
   if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
 }
@@ -674,11 +696,11 @@ template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, ui
     for (uint32_t q = 0; q < CB; q++) {
       if (k0 + q >= n || inf[q] != 0u || col[q] == keep || full) continue;
       const uint32_t x = p.P + sh->ninact;
-      if (x >= c.ucap || m >= PL_QCAP) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); full = true; continue; }
+      if (x >= c.ucap || m >= c.qcap) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); full = true; continue; }
       sh->ninact++;
       s.colinfo[col[q]] = (PL_ST_INACT << 30) | x;
       c.ucol[x] = (uint16_t)col[q];
-      sh->claim_c[m++] = (uint16_t)col[q];
+      c.claim_c()[m++] = (uint16_t)col[q];
     }
   }
   sh->nclaim[rd & 1u] = m; /* "columns to drop" */
@@ -698,7 +720,7 @@ template <bool LDS> SB_HD void pl_inact_apply_b_t(PlanCtx &c, uint32_t rdrep, ui
     return;
   }
   const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
-  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column<LDS>(c, s, sh->claim_c[i], 0u, pq ^ 1u, lane, 32u);
+  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column<LDS>(c, s, c.claim_c()[i], 0u, pq ^ 1u, lane, 32u);
   if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; }
 }
 template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
@@ -887,7 +909,7 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
       n[j] = 0; cols[j] = c.patch_cols;
       if (!use[j]) continue;
       if (r[j] < S) { /* a long LDPC row: listed for pl_w_init_b (the frontier queue is free by now; S <= 907 < PL_QCAP) */
-        if (w8 == 0) sh->queue[0][PL_ATOM_ADD(&sh->nq[0], 1u)] = (uint16_t)ii[j];
+        if (w8 == 0) c.queue(0u)[PL_ATOM_ADD(&sh->nq[0], 1u)] = (uint16_t)ii[j];
         use[j] = false;
         continue;
       }
@@ -929,7 +951,7 @@ template <int Z> SB_HD void pl_w_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lev_ctr(c, 1);
   const uint16_t *collev = pl_col_level(c);
   for (uint32_t q = tid >> 6; q < nlong; q += nt >> 6) {
-    const uint32_t i = sh->queue[0][q];
+    const uint32_t i = c.queue(0u)[q];
     const bool piv = i < sh->npiv;
     const uint32_t r = piv ? c.pivslot[i] : c.lowslot[i - sh->npiv], own = piv ? c.pivcol[i] : PL_NONE;
     const uint32_t lev = piv ? (c.rowinfo[r] & PL_LEVEL_MASK) : sh->nlev;
@@ -1114,7 +1136,7 @@ template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /*
   for (uint32_t r = tid; r < sh->M; r += nt) {
     if (!(c.rowinfo[r] & PL_UNASSIGNED) || (r >= p.S && r < p.S + p.H)) continue;
     uint32_t j = PL_ATOM_ADD(&sh->nlow, 1u);
-    if (j < c.ucap + 32u && j < PL_LOWCAP) c.lowslot[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    if (j < c.ucap + 32u && j < c.lowcap) c.lowslot[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
   }
 }
 template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
@@ -1127,7 +1149,7 @@ template <int Z> SB_HD void pl_low_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
    * Mb (nlow x rowlen words).  The tiles of the HDPC fold (pl_mh_load / pl_mh_acc) lie over Mb's place: Mb is loaded
    * only after the fold (pl_low_c; planner_seq.h) -- with separate places K'=56403 at 20 % loss needed 141-147 KB of
    * the ~140 KB there are, and one block in eight went to the host planner for it. */
-  if (sh->nlow + PL_EXTRA_ROWS > PL_LOWCAP) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+  if (sh->nlow + PL_EXTRA_ROWS > c.lowcap) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
   sh->tmp_mhoff = pl_r16(PL_MAXH * (c.p.L - sh->npiv)); /* byte offset of Mb (and of the tiles) behind MhT */
   const uint32_t mb_bytes = pl_r16((sh->nlow + PL_EXTRA_ROWS) * sh->rowlen * 4u), tile_bytes = PL_MH_TILE * 16u + PL_MH_TILE * sh->wpr * 4u;
   const uint32_t need = sh->tmp_mhoff + (mb_bytes > tile_bytes ? mb_bytes : tile_bytes);
@@ -1154,8 +1176,8 @@ template <int Z> SB_HD void pl_low_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 
 /* =============================== phase 4: op stream layout =================================== */
 /* sum of the first g 16-bit counts staged in the (free) frontier queues: g <= 2 * PL_QCAP */
-SB_HD uint32_t pl_deg_prefix(const pl_shared *sh, uint32_t g) {
-  const uint16_t *degq = &sh->queue[0][0];
+SB_HD uint32_t pl_deg_prefix(const PlanCtx &c, uint32_t g) {
+  const uint16_t *degq = c.queue(0u);
   uint32_t run = 0, i = 0;
   for (; i + 2u <= g; i += 2u) { /* two 16-bit lengths per word (the queues are 4-byte aligned) */
     const uint32_t w = *reinterpret_cast<const uint32_t *>(degq + i);
@@ -1176,8 +1198,8 @@ SB_HD uint32_t pl_group_span(uint32_t l, uint32_t nf, uint32_t n) {
 template <int Z> SB_HD void pl_ops_layout_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lds_lev(c) ? pl_lev_ctr(c, 1) : nullptr;
-  const bool in_lds = sh->nlev + 1u <= 2u * PL_QCAP;
-  uint16_t *rowq = &sh->queue[0][0];
+  const bool in_lds = sh->nlev + 1u <= 2u * c.qcap;
+  uint16_t *rowq = c.queue(0u);
   for (uint32_t l = tid; l <= sh->nlev; l += nt) {
     const uint32_t nf = cntF[l], n = nf + (cntN ? cntN[l] : 0u), span = pl_group_span(l, nf, n);
     c.lev_ops[l] = n;
@@ -1192,12 +1214,12 @@ template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt)
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   /* row base of every group (1..nlev-1: pivot levels, nlev: leftover rows); the stream starts with the NRQ_RING
    * lead rows */
-  const bool in_lds = sh->nlev + 1u <= 2u * PL_QCAP;
+  const bool in_lds = sh->nlev + 1u <= 2u * c.qcap;
   if (in_lds)
-    for (uint32_t l = tid; l <= sh->nlev; l += nt) c.lev_base[l] = NRQ_RING + pl_deg_prefix(sh, l);
+    for (uint32_t l = tid; l <= sh->nlev; l += nt) c.lev_base[l] = NRQ_RING + pl_deg_prefix(c, l);
   if (tid != 0) return;
   uint32_t rows = NRQ_RING;
-  if (in_lds) rows += pl_deg_prefix(sh, sh->nlev + 1u);
+  if (in_lds) rows += pl_deg_prefix(c, sh->nlev + 1u);
   else {
     const uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lds_lev(c) ? pl_lev_ctr(c, 1) : nullptr;
     for (uint32_t l = 0; l <= sh->nlev; l++) {
@@ -1364,12 +1386,12 @@ template <int Z> SB_HD void pl_mh_acc(PlanCtx &c, uint32_t tile, uint32_t tid, u
 template <int Z> SB_HD void pl_sh_save(PlanCtx &c, uint32_t tid, uint32_t nt) {
   uint32_t *dst = reinterpret_cast<uint32_t *>(c.work + c.wl.sh_save);
   const uint32_t *src = reinterpret_cast<const uint32_t *>(c.sh);
-  for (uint32_t k = tid; k < (uint32_t)(sizeof(pl_shared) / 4u); k += nt) dst[k] = src[k];
+  for (uint32_t k = tid; k < c.sh_bytes / 4u; k += nt) dst[k] = src[k];
 }
 template <int Z> SB_HD void pl_sh_restore(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t *src = reinterpret_cast<const uint32_t *>(c.work + c.wl.sh_save);
   uint32_t *dst = reinterpret_cast<uint32_t *>(c.sh);
-  for (uint32_t k = tid; k < (uint32_t)(sizeof(pl_shared) / 4u); k += nt) dst[k] = src[k];
+  for (uint32_t k = tid; k < c.sh_bytes / 4u; k += nt) dst[k] = src[k];
 }
 template <int Z> SB_HD void pl_mh_fetch(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (c.sh->status) return;
@@ -1410,8 +1432,8 @@ template <int Z> SB_HD void pl_gj_a(PlanCtx &c, uint32_t x, uint32_t tid, uint32
   const uint32_t rowlen = sh->rowlen;
   for (uint32_t j = tid; j < sh->nlow; j += nt) {
     const uint32_t f = (Mb[(size_t)j * rowlen + (x >> 5)] >> (x & 31u)) & 1u;
-    sh->gj_flag[j] = (uint8_t)(f << (x & 1u));
-    if (f && !sh->gj_used[j]) PL_ATOM_MIN(&sh->cand[x % 3u], j);
+    c.gj_flag()[j] = (uint8_t)(f << (x & 1u));
+    if (f && !c.gj_used()[j]) PL_ATOM_MIN(&sh->cand[x % 3u], j);
   }
 }
 /* step B: eliminate the column from every other row that has it (or record a free column);
@@ -1428,13 +1450,13 @@ template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t xarg, uint32_t tid, uin
   if (pr != PL_NONE || prep) {
     for (uint32_t e = tid; e < total; e += nt) {
       const uint32_t j = (uint32_t)(((uint64_t)e * inv) >> 32), wd = e - j * rowlen;
-      const uint32_t fl = sh->gj_flag[j];
+      const uint32_t fl = c.gj_flag()[j];
       uint32_t v = Mb[e];
       if (pr != PL_NONE && j != pr && ((fl >> cur) & 1u)) { v ^= src[wd]; Mb[e] = v; }
       if (prep && wd == wn) {
         const uint32_t f = (v >> (xn & 31u)) & 1u;
-        sh->gj_flag[j] = (uint8_t)((fl & (1u << cur)) | (f << nxt)); /* (the only writer of this byte in this phase) */
-        if (f && j != pr && !sh->gj_used[j]) PL_ATOM_MIN(&sh->cand[xn % 3u], j);
+        c.gj_flag()[j] = (uint8_t)((fl & (1u << cur)) | (f << nxt)); /* (the only writer of this byte in this phase) */
+        if (f && j != pr && !c.gj_used()[j]) PL_ATOM_MIN(&sh->cand[xn % 3u], j);
       }
     }
   }
@@ -1444,7 +1466,7 @@ template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t xarg, uint32_t tid, uin
       if (sh->nfree < NRQ_MAX_FREE) sh->freex[sh->nfree] = x;
       sh->nfree++;
     } else {
-      sh->gj_used[pr] = 1;
+      c.gj_used()[pr] = 1;
       c.red_row[sh->r2] = pr;
       c.red_x[sh->r2] = x;
       sh->r2++;
@@ -1599,7 +1621,7 @@ template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t esi = c.rep_esi[i];
   if (esi < p.K || esi >= (1u << 24)) { sh->status = PL_FAIL_SINGULAR; return; }
   const uint32_t row = sh->M, j = sh->nlow;
-  if (row + 1u > c.Mcap || i + 1u > c.npcap || j + 1u > PL_LOWCAP) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); return; }
+  if (row + 1u > c.Mcap || i + 1u > c.npcap || j + 1u > c.lowcap) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); return; }
   uint32_t cols[RQ_MAX_LT_COLS];
   const uint32_t n = rq_lt_columns(&p, esi + (p.Kp - p.K), cols);
   uint16_t *dst = c.patch_cols + (size_t)i * PL_PATCH_STRIDE;
@@ -1616,7 +1638,7 @@ template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   c.patch_of[row] = (uint16_t)i;
   c.rowinfo[row] = PL_UNASSIGNED | PL_PATCHED;
   c.lowslot[j] = (uint16_t)row;
-  sh->gj_used[j] = 0;
+  c.gj_used()[j] = 0;
   sh->M = row + 1u; sh->npatch = i + 1u; sh->nlow = j + 1u; sh->nextra++;
   sh->cand[0] = sh->cand[1] = sh->cand[2] = PL_NONE;
 }
@@ -1706,11 +1728,11 @@ template <int Z> SB_HD void pl_final_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
     const rq_params &p = c.p;
     const uint32_t nl = c.job.nlost;
     uint32_t o = sh->arena_top;
-    sh->partial[0] = o; o = pl_r16(o + sh->wpr * sh->tmp0 * 4u);          /* wt */
-    sh->partial[1] = o; o = pl_r16(o + sh->M * 4u);                       /* rowsrc */
-    sh->partial[2] = o; o = pl_r16(o + (nl + 1u) * 4u);                   /* out_cptr */
-    sh->partial[3] = o; o = pl_r16(o + nl * 4u + 4u);                     /* out_row */
-    sh->partial[4] = o; o = pl_r16(o + nl * PL_PATCH_STRIDE * 2u + 16u);  /* out_slots */
+    c.part()[0] = o; o = pl_r16(o + sh->wpr * sh->tmp0 * 4u);          /* wt */
+    c.part()[1] = o; o = pl_r16(o + sh->M * 4u);                       /* rowsrc */
+    c.part()[2] = o; o = pl_r16(o + (nl + 1u) * 4u);                   /* out_cptr */
+    c.part()[3] = o; o = pl_r16(o + nl * 4u + 4u);                     /* out_row */
+    c.part()[4] = o; o = pl_r16(o + nl * PL_PATCH_STRIDE * 2u + 16u);  /* out_slots */
     sh->arena_top = o;
     if (o > c.job.arena_cap) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     (void)p;
@@ -1721,13 +1743,13 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (sh->status) return;
   const rq_params &p = c.p;
   const uint32_t wpr = sh->wpr, stride = sh->tmp0, nl = c.job.nlost;
-  uint32_t *wt = reinterpret_cast<uint32_t *>(c.arena + sh->partial[0]);
+  uint32_t *wt = reinterpret_cast<uint32_t *>(c.arena + c.part()[0]);
   if (!sh->defer_wt) /* (a segmented run leaves the transposition to nrq_wt_kernel: many workgroups) */
     for (uint32_t e = tid; e < wpr * stride; e += nt) {
       const uint32_t w = e / stride, k = e - w * stride;
       wt[e] = k < sh->npiv ? c.wrows[(size_t)c.pivslot[k] * wpr + w] : 0u;
     }
-  uint32_t *rowsrc = reinterpret_cast<uint32_t *>(c.arena + sh->partial[1]);
+  uint32_t *rowsrc = reinterpret_cast<uint32_t *>(c.arena + c.part()[1]);
   for (uint32_t r = tid; r < sh->M; r += nt) {
     uint32_t v = NRQ_ROW_ZERO;
     const uint32_t pi = c.patch_of[r];
@@ -1736,13 +1758,13 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
     rowsrc[r] = v;
   }
   /* the missing source symbols as LT combinations of slots (ISI of a source symbol = its ESI) */
-  uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + sh->partial[2]);
-  uint32_t *orow = reinterpret_cast<uint32_t *>(c.arena + sh->partial[3]);
-  uint16_t *osl = reinterpret_cast<uint16_t *>(c.arena + sh->partial[4]);
+  uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + c.part()[2]);
+  uint32_t *orow = reinterpret_cast<uint32_t *>(c.arena + c.part()[3]);
+  uint16_t *osl = reinterpret_cast<uint16_t *>(c.arena + c.part()[4]);
   /* list lengths of the missing symbols: to LDS when they fit (the frontier queues are free by now), so that the
    * running sum in pl_final_d -- one thread -- does not walk an array in HBM */
-  uint16_t *degq = &sh->queue[0][0];
-  const bool in_lds = nl <= 2u * PL_QCAP;
+  uint16_t *degq = c.queue(0u);
+  const bool in_lds = nl <= 2u * c.qcap;
   for (uint32_t g = tid; g < nl; g += nt) {
     const uint32_t e = c.lost[g];
     const uint32_t dg = c.b_rptr[p.S + p.H + e + 1] - c.b_rptr[p.S + p.H + e];
@@ -1754,11 +1776,11 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
 template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const rq_params &p = c.p;
-  if (!sh->status && c.job.nlost <= 2u * PL_QCAP) {
+  if (!sh->status && c.job.nlost <= 2u * c.qcap) {
     /* the list offsets of the missing symbols: every thread sums the lengths before its own entry (LDS reads, no
      * stores in between) -- a running sum by one thread is a chain of LDS round trips, one per entry */
-    uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + sh->partial[2]);
-    for (uint32_t g = tid; g <= c.job.nlost; g += nt) cptr[g] = pl_deg_prefix(sh, g);
+    uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + c.part()[2]);
+    for (uint32_t g = tid; g <= c.job.nlost; g += nt) cptr[g] = pl_deg_prefix(c, g);
   }
   if (tid != 0) return;
   nrq_plan_hdr h;
@@ -1772,15 +1794,15 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   h.M = sh->M; h.npiv = sh->npiv; h.u = p.L - sh->npiv; h.nlow = sh->nlow; h.r2 = sh->r2; h.nfree = sh->nfree;
   h.nlev = sh->nlev; h.nrows = sh->nrows; h.pipe = NRQ_PIPE; h.wpr = sh->wpr;
   h.npiv_pad = sh->tmp0;
-  h.off_ops = sh->off_ops; h.off_pivslot = c.off_pivslot; h.off_pivcol = c.off_pivcol; h.off_wt = sh->partial[0];
+  h.off_ops = sh->off_ops; h.off_pivslot = c.off_pivslot; h.off_pivcol = c.off_pivcol; h.off_wt = c.part()[0];
   h.off_lowslot = c.off_lowslot; h.off_pivx = c.off_pivx; h.off_fbits = c.off_fbits; h.off_mh = c.off_mh;
   h.off_freex = c.off_freex; h.off_hinv = c.off_hinv; h.off_colslot = c.off_colslot; h.off_pivof = c.off_pivof;
   h.off_uslot = c.off_uslot; h.total_bytes = sh->arena_top;
   if (!sh->status) {
     const uint32_t nl = c.job.nlost;
-    uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + sh->partial[2]);
+    uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + c.part()[2]);
     uint32_t run = 0;
-    if (nl <= 2u * PL_QCAP) run = pl_deg_prefix(sh, nl);
+    if (nl <= 2u * c.qcap) run = pl_deg_prefix(c, nl);
     else {
       for (uint32_t g = 0; g < nl; g++) { cptr[g] = run; run += c.pivdeg[g]; }
       cptr[nl] = run;
@@ -1794,11 +1816,11 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
     memset(&j, 0, sizeof(j));
     j.plan = (uint64_t)(uintptr_t)c.arena;
     if (!sh->status) {
-      j.rowsrc = (uint64_t)(uintptr_t)(c.arena + sh->partial[1]);
+      j.rowsrc = (uint64_t)(uintptr_t)(c.arena + c.part()[1]);
       j.src = c.job.src; j.rep = c.job.rep; j.inter = c.job.inter; j.out = c.job.src;
-      j.out_cptr = (uint64_t)(uintptr_t)(c.arena + sh->partial[2]);
-      j.out_row = (uint64_t)(uintptr_t)(c.arena + sh->partial[3]);
-      j.out_slots = (uint64_t)(uintptr_t)(c.arena + sh->partial[4]);
+      j.out_cptr = (uint64_t)(uintptr_t)(c.arena + c.part()[2]);
+      j.out_row = (uint64_t)(uintptr_t)(c.arena + c.part()[3]);
+      j.out_slots = (uint64_t)(uintptr_t)(c.arena + c.part()[4]);
       j.nout = c.job.nlost;
     }
     *c.jobout = j;
@@ -1825,8 +1847,8 @@ template <int Z> SB_HD void pl_final_e(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (sh->status) return;
   const rq_params &p = c.p;
   const uint32_t nl = c.job.nlost;
-  const uint32_t *cptr = reinterpret_cast<const uint32_t *>(c.arena + sh->partial[2]);
-  uint16_t *osl = reinterpret_cast<uint16_t *>(c.arena + sh->partial[4]);
+  const uint32_t *cptr = reinterpret_cast<const uint32_t *>(c.arena + c.part()[2]);
+  uint16_t *osl = reinterpret_cast<uint16_t *>(c.arena + c.part()[4]);
   for (uint32_t g = tid; g < nl; g += nt) {
     const uint32_t e = c.lost[g], a = c.b_rptr[p.S + p.H + e], n = c.b_rptr[p.S + p.H + e + 1] - a, o = cptr[g];
     constexpr uint32_t CB = 8; /* entries whose two dependent loads are in flight together */

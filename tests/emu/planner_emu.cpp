@@ -61,6 +61,8 @@ static void emu_wpass_strips(PlanCtx &c) {
 }
 
 static uint32_t g_mode = 0; /* nrq_planjob::mode of the next emu_plan call (1 = encode plan) */
+static uint32_t g_qcap = PL_QCAP, g_lowcap = PL_LOWCAP; /* capacities of the arrays behind pl_shared (small blocks get small ones) */
+extern "C" void emu_plan_set_caps(uint32_t qcap, uint32_t lowcap) { g_qcap = qcap ? qcap : PL_QCAP; g_lowcap = lowcap ? lowcap : PL_LOWCAP; }
 static uint32_t g_split = 0; /* run the phase sequence in its two parts (what big blocks do on the GPU) */
 extern "C" void emu_plan_set_mode(uint32_t mode) { g_mode = mode & 0xFFu; g_split = (mode >> 8) & 1u; }
 extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const uint32_t *lost, uint32_t nlost,
@@ -75,8 +77,9 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   const uint32_t Mcap = kh->L + ohcap + PL_EXTRA_ROWS + 8, npcap = nrep_avail + PL_EXTRA_ROWS + 8, ucap = kh->P + 768u;
   pl_work_layout wl = pl_work_plan(kh->L, Mcap, npcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE);
   std::vector<uint8_t> work(wl.total + 64, 0xCC), dyn(lds_dyn_bytes + 64, 0xDD);
-  pl_shared *sh = new pl_shared;
-  memset(sh, 0xEE, sizeof(*sh));
+  const uint32_t shb = pl_shared_bytes(g_qcap, g_lowcap, PL_NT);
+  std::vector<uint8_t> shmem(shb + 64, 0xEE); /* pl_shared and the arrays behind it */
+  pl_shared *sh = reinterpret_cast<pl_shared *>(shmem.data());
   nrq_planjob job;
   memset(&job, 0, sizeof(job));
   job.lost = (uint64_t)(uintptr_t)lost;
@@ -86,7 +89,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   job.nlost = nlost; job.nrep = nrep; job.arena_cap = arena_cap; job.nrep_avail = nrep_avail;
   job.mode = g_mode | (g_split << 8);
   PlanCtx c;
-  pl_ctx_setup(c, p, kc, job, sh, lds_dyn_bytes ? dyn.data() : nullptr, lds_dyn_bytes, Mcap, npcap, ucap, job_out);
+  pl_ctx_setup(c, p, kc, job, sh, lds_dyn_bytes ? dyn.data() : nullptr, lds_dyn_bytes, Mcap, npcap, ucap, job_out, g_qcap, g_lowcap, PL_NT);
 #define PL_PHASE(fn) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, t_, PL_NT); } while (0)
 #define PL_PHASE1(fn, a) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, (a), t_, PL_NT); } while (0)
 #define PL_WFAST_RUN(wb) emu_wfast_run(c, (wb))
@@ -106,13 +109,12 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
       }
     }
 #include "../../nanorq_amd/csrc/planner_seq.h"
-    if (g_seg == 1u) { PL_PHASE(pl_mh_ext_clear); PL_PHASE(pl_sh_save); memset(sh, 0xEE, sizeof(*sh)); }
+    if (g_seg == 1u) { PL_PHASE(pl_mh_ext_clear); PL_PHASE(pl_sh_save); memset(sh, 0xEE, shb); }
   }
 #undef PL_SEG
   if (g_split) pl_wt_fill(arena, reinterpret_cast<const uint32_t *>(work.data() + wl.wrows), 0u, 1u); /* = nrq_wt_kernel */
 #undef PL_PHASE
 #undef PL_PHASE1
 #undef PL_WFAST_RUN
-  delete sh;
   return 0;
 }

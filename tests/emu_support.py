@@ -101,7 +101,7 @@ def pemu():
     return _PEMU
 
 
-def emu_device_plan(K, kconst, lost, rep_esis, lds_bytes=140 * 1024, Kp=0, use=None, encode=False, split=False):
+def emu_device_plan(K, kconst, lost, rep_esis, lds_bytes=140 * 1024, Kp=0, use=None, encode=False, split=False, caps=None):
     """Run the GPU planner's phase code on the CPU. Returns (plan arena bytes, header).  `use` = number of repair
     symbols to use up front (default all); the rest may be taken one at a time if the system is rank deficient."""
     L_ = pemu()
@@ -112,6 +112,7 @@ def emu_device_plan(K, kconst, lost, rep_esis, lds_bytes=140 * 1024, Kp=0, use=N
     use = len(rep_esis) if use is None else use
     arena = np.zeros(cap, np.uint8)
     job = Job()
+    L_.emu_plan_set_caps(*(caps or (0, 0)))  # capacities of the arrays behind pl_shared (0 = the big-block ones)
     L_.emu_plan_set_mode((1 if encode else 0) | (0x100 if split else 0))  # encode plan: a job without missing symbols; split: the phase sequence in its two parts
     try:
         rc = L_.emu_plan(K, Kp, C.addressof(kcb), lost.ctypes.data_as(C.POINTER(C.c_uint32)), len(lost),
@@ -119,6 +120,7 @@ def emu_device_plan(K, kconst, lost, rep_esis, lds_bytes=140 * 1024, Kp=0, use=N
                          C.byref(job))
     finally:
         L_.emu_plan_set_mode(0)
+        L_.emu_plan_set_caps(0, 0)
     assert rc == 0
     hdr = nanorq_amd.plan_header(arena.tobytes()[:256])
     return arena.tobytes()[:max(hdr["total_bytes"], 256)], hdr

@@ -203,6 +203,9 @@ def test_device_planner_emulated_matches_oracle(orc, K, T, wb, p, oh, lds):
         if not ok:
             continue
         assert plan2 == plan, "the segmented run built a different plan"
+        if K <= 1024:   # small blocks run with small queues / claim lists / Gauss-Jordan flags behind pl_shared
+            plan3, hdr3 = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=lds * 1024, caps=(512, 384))
+            assert plan3 == plan
         _, rowsrc = decode_setup(orc, K, lost, rep_esis)
         work = src.copy()
         work[lost] = 0x77
@@ -293,3 +296,16 @@ def test_device_planner_builds_encode_plans(orc, K, T, wb, lds):
     assert r == 1 and np.array_equal(inter, ref_inter) and np.array_equal(out, ref_rep)
     # without the mode flag a job without missing symbols stays "nothing to do"
     assert emu_device_plan(K, kc, [], [])[1]["status"] == 1
+
+
+def test_small_planner_state_reports_overflow(orc):
+    """Capacities of the arrays behind pl_shared are the launch's choice; a block that does not fit them must come back
+    as a capacity failure (the host planner then takes it), never as a wrong plan."""
+    K = 1024
+    kc = nanorq_amd.host_kconst(K)
+    lost = loss_pattern(K, 0.3, 5)
+    esis = received_set(K, lost, 0)
+    rep_esis = esis[esis >= K]
+    _, ok_hdr = emu_device_plan(K, kc, lost, rep_esis)
+    _, hdr = emu_device_plan(K, kc, lost, rep_esis, caps=(64, 16))
+    assert ok_hdr["status"] == 0 and hdr["status"] == 1
