@@ -6,7 +6,7 @@ offers a thin ctypes mirror for tests and bench.py; there is no Python or CPU im
 the hot path, and every entry point raises when the HIP library or a GPU is missing.
 """
 from .binding import (NrqError, Context, lib, lib_path, params, host_plan, host_kconst, PLAN_FIELDS,
-                      plan_header)
+                      plan_header, plan_ops, plan_ops_store)
 
 __all__ = ["NrqError", "Context", "lib", "lib_path", "params", "host_plan", "host_kconst", "PLAN_FIELDS",
-           "plan_header"]
+           "plan_header", "plan_ops", "plan_ops_store"]

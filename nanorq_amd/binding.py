@@ -276,3 +276,24 @@ class Context:
         ms = C.c_float()
         self._chk(self._L.nrq_timer_stop_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+def plan_ops(plan, header=None):
+    """The op stream of a plan as an array [row, lane] (a copy).  plan.h: the stream is stored quad-interleaved -- the words
+    of rows 4g..4g+3 of a lane lie next to each other (NRQ_OP_INDEX)."""
+    import numpy as np
+    h = header or plan_header(bytes(plan))
+    rows = (h["nrows"] + 3) & ~3
+    a = np.frombuffer(bytes(plan), dtype=np.uint32, offset=h["off_ops"], count=rows * 64)
+    return a.reshape(rows // 4, 64, 4).transpose(0, 2, 1).reshape(rows, 64)[:h["nrows"]].copy()
+
+
+def plan_ops_store(plan, ops, header=None):
+    """Write an array [row, lane] (all nrows rows) back into the bytearray `plan` (tests that tamper with a stream)."""
+    import numpy as np
+    h = header or plan_header(bytes(plan))
+    rows = (h["nrows"] + 3) & ~3
+    assert ops.shape == (h["nrows"], 64)
+    full = np.frombuffer(plan, dtype=np.uint32, offset=h["off_ops"], count=rows * 64).reshape(rows // 4, 64, 4)
+    for r in range(h["nrows"]):
+        full[r // 4, :, r % 4] = ops[r]

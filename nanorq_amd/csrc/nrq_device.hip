@@ -79,6 +79,15 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
 #define NRQ_HDPC_NT 512 /* threads of the HDPC phase; measured: 256 / 512 / 768 -> 34 k / 28 k / 29 k clocks (the closing fold is per thread) */
 #endif
 #define NRQ_HDPC_NT_ ((uint32_t)NRQ_HDPC_NT)
+#ifndef NRQ_MOVER_WAVES
+#define NRQ_MOVER_WAVES 2u
+#endif
+#ifndef NRQ_RING_5W
+#define NRQ_RING_5W 36u /* five waves per SIMD: 102 registers per thread */
+#endif
+#ifndef NRQ_BIG_RING
+#define NRQ_BIG_RING NRQ_RING_MAX /* op-word ring (rows) of the two forward waves of the 768-thread workgroup */
+#endif
 /* NT threads per workgroup: NRQ_WG when one strip image owns the CU's LDS (big blocks), 256 when several fit (small
  * blocks: more workgroups per CU beat more waves per workgroup, each has its own single-wave forward pass).
  * `lsub`: log2 of the strips per work slot -- a whole line (128/WB strips) unless that leaves CUs without work. */
@@ -106,8 +115,14 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
   constexpr uint32_t VNT = NT / G;
   constexpr uint32_t SPL = WBE >= 128u ? 1u : 128u / WBE, NFW = (G == 1 && WB >= 8 && NT >= 512) ? 2u : 1u,
                      NMV = (NT / 64u) / 4u * (4u - NFW) + ((NT / 64u) % 4u > NFW ? (NT / 64u) % 4u - NFW : 0u),
-                     NGW = NMV >= 6u ? 3u : NMV >= 3u ? 2u : 1u, NSW = NMV >= 6u ? 3u : NMV - NGW;
+                     /* two gather and two scatter waves in the big workgroup, not three: every mover wave that keeps loads in
+                      * flight slows the forward waves' op words down (measured, headline encode: 3+3 -> row pipeline 89 k clocks,
+                      * gather done at 70 k; 2+2 -> 79 k / 83 k; 1+1 -> 72 k / 125 k) */
+                     NGW = NMV >= 6u ? NRQ_MOVER_WAVES : NMV >= 3u ? 2u : 1u, NSW = NMV >= 6u ? NRQ_MOVER_WAVES : NMV - NGW;
   static_assert(NMV >= 2u || NT == 64, "workgroup too small for the data movers");
+  /* op-word ring of the forward wave(s), in rows: what the variant's register budget holds without spilling */
+  constexpr bool MPIPE = NT >= 512; /* software-pipelined data movers: where the registers allow (168 per thread) */
+  constexpr uint32_t RU = NT >= 512 ? NRQ_BIG_RING : WV >= 5 ? NRQ_RING_5W : NRQ_RING;
   /* NT == 64: ONE wave solves the strip on its own (no mover waves: it gathers and scatters its portions itself after
    * the forward passes; barriers are free).  For images of a few KB -- K up to ~400 -- where a strip is a chain of
    * short phases with little parallel work: 19-20 such workgroups share a CU instead of five 256-thread ones, i.e.
@@ -151,7 +166,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
     GroupSrc<WB> g0;
     uint32_t b0;
     group_src(q, g0, &b0);
-    pf_gather<WB, G>(g0, stage0, stage_stride, 0u, g0.M << lsub, (tid) / G, (NT) / G, subl); /* the first group: nothing to overlap it with */
+    pf_gather<WB, G, MPIPE>(g0, stage0, stage_stride, 0u, g0.M << lsub, (tid) / G, (NT) / G, subl); /* the first group: nothing to overlap it with */
     __syncthreads();
   }
   while (q < nslots) {
@@ -178,8 +193,8 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       const uint32_t sm = NT > NRQ_HDPC_NT_ ? s1 - (uint32_t)((uint64_t)(s1 - s0) * NRQ_SCATTER_LATE_PCT / 100u) : s1;
       const uint32_t strip = strip0 + sidx;
       if (strip >= nstrips) { /* no such strip: everybody moves this portion */
-        if (u1 > u0) pf_gather<WB, G>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (NT) / G, subl);
-        if (s1 > s0) pf_scatter<WB, G>(gp, ostage_prv, ostage_stride, s0, s1, (tid) / G, (NT) / G, subl);
+        if (u1 > u0) pf_gather<WB, G, MPIPE>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (NT) / G, subl);
+        if (s1 > s0) pf_scatter<WB, G, MPIPE>(gp, ostage_prv, ostage_stride, s0, s1, (tid) / G, (NT) / G, subl);
         continue;
       }
       StripCtx<WB, G> c;
@@ -213,29 +228,30 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       const uint32_t wv = tid >> 6;
       if constexpr (NT == 64) {
         if constexpr (G > 1) fwd_rows_wide<G>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
-        else fwd_rows<WB>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
-        if (u1 > u0) pf_gather<WB, G>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (64u) / G, subl);
-        if (sm > s0) pf_scatter<WB, G>(gp, ostage_prv, ostage_stride, s0, sm, (tid) / G, (64u) / G, subl);
+        else fwd_rows<WB, RU>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
+        if (u1 > u0) pf_gather<WB, G, MPIPE>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (64u) / G, subl);
+        if (sm > s0) pf_scatter<WB, G, MPIPE>(gp, ostage_prv, ostage_stride, s0, sm, (tid) / G, (64u) / G, subl);
       } else if (wv < NFW) {
         __builtin_amdgcn_s_setprio(3); /* the critical waves: ahead of the others at instruction issue */
         const NRQ_GAS uint32_t *ops_ = c.template arr<uint32_t>(c.h->off_ops);
         if constexpr (G > 1) {
           fwd_rows_wide<G>(ops_, c.h->nrows, tid);
         } else if constexpr (NFW == 2u) { /* one half of the strip width each */
-          if (wv == 0u) fwd_rows_half<WB, 0>(ops_, c.h->nrows, tid);
-          else fwd_rows_half<WB, WB / 2>(ops_, c.h->nrows, tid & 63u);
+          /* (the big workgroup has the registers for the deep ring: 168 per thread) */
+          if (wv == 0u) fwd_rows_half<WB, 0, RU>(ops_, c.h->nrows, tid);
+          else fwd_rows_half<WB, WB / 2, RU>(ops_, c.h->nrows, tid & 63u);
         } else {
-          fwd_rows<WB>(ops_, c.h->nrows, tid);
+          fwd_rows<WB, RU>(ops_, c.h->nrows, tid);
         }
         __builtin_amdgcn_s_setprio(0);
         NRQ_MARK(c, 1);
       } else if ((wv & 3u) >= NFW) { /* the waves that do not share a SIMD with the forward waves; index among them: */
         const uint32_t mv = (wv >> 2) * (4u - NFW) + (wv & 3u) - NFW;
         if (mv < NGW) {
-          if (u1 > u0) pf_gather<WB, G>(gn, stage_nxt, stage_stride, u0, u1, (mv * 64u + (tid & 63u)) / G, (NGW * 64u) / G, subl);
+          if (u1 > u0) pf_gather<WB, G, MPIPE>(gn, stage_nxt, stage_stride, u0, u1, (mv * 64u + (tid & 63u)) / G, (NGW * 64u) / G, subl);
           NRQ_MARK_MAX(c, 2);
         } else if (mv < NGW + NSW) {
-          if (sm > s0) pf_scatter<WB, G>(gp, ostage_prv, ostage_stride, s0, sm, ((mv - NGW) * 64u + (tid & 63u)) / G, (NSW * 64u) / G, subl);
+          if (sm > s0) pf_scatter<WB, G, MPIPE>(gp, ostage_prv, ostage_stride, s0, sm, ((mv - NGW) * 64u + (tid & 63u)) / G, (NSW * 64u) / G, subl);
           NRQ_MARK_MAX(c, 3);
         }
       }
@@ -245,7 +261,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       {
         constexpr uint32_t HNT = NT < NRQ_HDPC_NT_ ? NT : NRQ_HDPC_NT_;
         if (tid < HNT) ph_hdpc<WB, G>(c, tid / G, HNT / G);
-        else if (s1 > sm) pf_scatter<WB, G>(gp, ostage_prv, ostage_stride, sm, s1, (tid - HNT) / G, (NT - HNT) / G, subl); /* the waves HDPC leaves idle */
+        else if (s1 > sm) pf_scatter<WB, G, MPIPE>(gp, ostage_prv, ostage_stride, sm, s1, (tid - HNT) / G, (NT - HNT) / G, subl); /* the waves HDPC leaves idle */
       }
       __syncthreads();
       ph_hdpc_reduce<WB, G>(c, vt, VNT);
@@ -290,7 +306,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
   if (qp < nslots) {
     GroupDst<WB> gp;
     const uint32_t units_p = group_dst(qp, gp) << lsub;
-    pf_scatter<WB, G>(gp, ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride, ostage_stride, 0u, units_p, (tid) / G, (NT) / G, subl);
+    pf_scatter<WB, G, MPIPE>(gp, ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride, ostage_stride, 0u, units_p, (tid) / G, (NT) / G, subl);
   }
 }
 
@@ -327,6 +343,9 @@ enum {
   pl_tag_pl_ops_layout = 10,
   pl_tag_pl_ops_clear = 10,
   pl_tag_pl_ops_emit = 10,
+  pl_tag_pl_ops_check_a = 10,
+  pl_tag_pl_ops_check_b = 10,
+  pl_tag_pl_ops_check_c = 10,
   pl_tag_pl_sh_restore = 0,
   pl_tag_pl_sh_save = 15,
   pl_tag_pl_mh_ext_clear = 15,
@@ -389,10 +408,12 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
     } \
     __syncthreads(); PL_ACC(2); } while (0)
 #define PL_SEG seg
+#define PL_STEER_SYNC __syncthreads()
   if (seg == 2u) PL_PHASE(pl_sh_restore);
 #include "planner_seq.h"
   if (seg == 1u) { PL_PHASE(pl_mh_ext_clear); PL_PHASE(pl_sh_save); }
 #undef PL_SEG
+#undef PL_STEER_SYNC
 #undef PL_PHASE
 #undef PL_PHASE1
 #undef PL_WFAST_RUN
@@ -710,8 +731,11 @@ inline size_t r16(size_t x) { return (x + 15) & ~(size_t)15; }
 struct Tuning {
   bool map_spread = false;   /* NRQ_MAP_SPREAD: deal line groups round-robin instead of block octets per XCD */
   bool big_wg = false;       /* NRQ_BIG_WG: never use the 256-thread solve variants */
-  bool small_waves4 = false; /* NRQ_SMALL_WAVES4: 256-thread variant compiled for 4 (not 5) workgroups per CU */
+  bool small_waves4 = true;  /* NRQ_SMALL_WAVES5 clears it: the 256-thread variant compiled for 5 workgroups per CU (96 registers per
+                              * thread) is used where five images fit; since the row pipeline forms its addresses ahead of the LDS wait the
+                              * 4-workgroup one (128 registers) is faster there: K=1000 930 -> 980 Gbit/s */
   bool prof = false;         /* NRQ_PROF: per-phase shader-clock marks, printed to stderr */
+  bool diag = false;         /* NRQ_DIAG: why a block was reported not decodable, to stderr */
   bool plan_lds_max = false; /* NRQ_PLAN_LDS_MAX: planner always takes the whole LDS */
   bool plan_big_wg = false;  /* NRQ_PLAN_BIG_WG: planner always 1024 threads */
   uint32_t small_div = 2;    /* NRQ_SMALL_DIV: LDS images per CU from which the 256-thread variant is used (measured: 2 beats 3) */
@@ -733,8 +757,8 @@ struct Tuning {
   void read() {
     auto flag = [](const char *n) { const char *e = getenv(n); return e != nullptr; };
     auto num = [](const char *n, long long d) { const char *e = getenv(n); return (e && *e) ? atoll(e) : d; };
-    map_spread = flag("NRQ_MAP_SPREAD"); big_wg = flag("NRQ_BIG_WG"); small_waves4 = flag("NRQ_SMALL_WAVES4");
-    prof = flag("NRQ_PROF"); plan_lds_max = flag("NRQ_PLAN_LDS_MAX"); plan_big_wg = flag("NRQ_PLAN_BIG_WG");
+    map_spread = flag("NRQ_MAP_SPREAD"); big_wg = flag("NRQ_BIG_WG"); small_waves4 = !flag("NRQ_SMALL_WAVES5");
+    prof = flag("NRQ_PROF"); diag = flag("NRQ_DIAG"); plan_lds_max = flag("NRQ_PLAN_LDS_MAX"); plan_big_wg = flag("NRQ_PLAN_BIG_WG");
     small_div = (uint32_t)num("NRQ_SMALL_DIV", 2); solve_grid = (uint64_t)num("NRQ_SOLVE_GRID", 0);
     max_wb = (uint32_t)num("NRQ_MAX_WB", 16); prof_base = (int)num("NRQ_PROF_BASE", 2);
     encplan_dev_min_l = (uint32_t)num("NRQ_ENCPLAN_DEV_MIN_L", 12000);
@@ -1537,6 +1561,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "solve_grid") t.solve_grid = (uint64_t)value;
   else if (n == "big_wg") t.big_wg = value != 0;
+  else if (n == "small_waves4") t.small_waves4 = value != 0;
   else if (n == "map_spread") t.map_spread = value != 0;
   else if (n == "encplan_dev_min_l") t.encplan_dev_min_l = (uint32_t)value;
   else return fail(ctx, -1, "unknown option %s", name);
@@ -1936,11 +1961,14 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
       ctx->stats.xor_ops += hd[b].n_xor_ops;
       ctx->stats.plan_bytes += hd[b].total_bytes;
     } else if (hd[b].reserved[0] == PL_FAIL_CAPACITY) {
-      if (ctx->tune.prof) fprintf(stderr, "[NRQ_PROF] block %u: device planner capacity exceeded at planner_body.h:%u\n", b, hd[b].fail_site);
+      if (ctx->tune.prof || ctx->tune.diag) fprintf(stderr, "[NRQ_PROF] block %u: device planner capacity exceeded at planner_body.h:%u (npiv %u u %u nlev %u nrows %u M %u nlost %u)\n", b, hd[b].fail_site, hd[b].npiv, hd[b].u, hd[b].nlev, hd[b].nrows, hd[b].M, h_nlost[b]);
       (*fallback)[b] = 1;
       need_fallback = true;
       h_status[b] = 0;
     } else {
+      if (ctx->tune.prof || ctx->tune.diag)
+        fprintf(stderr, "[NRQ_PROF] block %u: not decodable: status %u reason %u site %u npiv %u u %u nlev %u nlow %u r2 %u nfree %u taken %u\n", b, hd[b].status,
+                hd[b].reserved[0], hd[b].fail_site, hd[b].npiv, hd[b].u, hd[b].nlev, hd[b].nlow, hd[b].r2, hd[b].nfree, hd[b].reserved[1]);
       h_status[b] = 0;
     }
   }

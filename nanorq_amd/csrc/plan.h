@@ -32,13 +32,23 @@
 #define NRQ_PIPE 2u                /* rows between the read of a row's sources and its application (measured on
                                     * MI355X: 2 beats 3 and 4 -- a row costs ~63 clocks of issue either way, spacer rows included) */
 #endif
+/* The row pipeline holds the op words of the next NRQ_RING rows (or 2 * NRQ_RING: the big solve workgroup) in registers,
+ * fetched FOUR ROWS AT A TIME: the stream is stored quad-interleaved -- the words of rows 4g .. 4g+3 of a lane lie next to
+ * each other (one 16-byte load per lane and quad), word (row, lane) at NRQ_OP_INDEX(row, lane).  Why: a wave may have 63
+ * vector-memory instructions in flight, no more (vmcnt is 6 bits), and the CU's vector L1 returns loads in order, so while
+ * the data movers of the workgroup have HBM misses in flight every op word waits an HBM latency D behind them: one dword
+ * load per row gives at most 63 rows per D (measured: rows of 62-70 clocks as soon as the movers keep loads in flight all the
+ * time, at 44 without them; tools/microbench/fwd_loop.hip), a quad load per four rows four times that. */
 #ifndef NRQ_RING_MULT
-#define NRQ_RING_MULT 20u
+#define NRQ_RING_MULT 5u
 #endif
-#define NRQ_RING (NRQ_RING_MULT * (NRQ_PIPE + 1u)) /* rows whose op words the kernel holds in registers (fetched that far ahead:
-                                    * 36 rows starve the pipeline when the L2 is busy streaming symbols, 60 and 84 measure the same);
-                                    * the stream starts with NRQ_RING all-NOP rows (the ring's initial content) */
-#define NRQ_PAD_ROWS (2u * NRQ_RING + NRQ_PIPE) /* all-NOP rows after the stream: op words are fetched ahead unconditionally */
+#define NRQ_RING (NRQ_RING_MULT * 4u * (NRQ_PIPE + 1u)) /* 60 rows: a multiple of the quad and of the pipeline's value sets */
+#define NRQ_RING_MAX (2u * NRQ_RING)
+#define NRQ_PAD_ROWS (2u * NRQ_RING_MAX + NRQ_PIPE + 4u) /* all-NOP rows after the stream: op words are fetched ahead unconditionally,
+                                    * and the pipeline runs whole trips of its ring */
+#define NRQ_OP_INDEX(row, lane) ((((size_t)(row) >> 2) * NRQ_ROW + (size_t)(lane)) * 4u + ((size_t)(row) & 3u))
+#define NRQ_OP_LANE_OF_INDEX(i) ((uint32_t)((i) >> 2) & (NRQ_ROW - 1u))
+#define NRQ_STREAM_ROWS(rows) (((rows) + 3u) & ~3u) /* rows the stream's memory holds: whole quads */
 /* Op word: dst | src << 16, both as slot + NRQ_SCRATCH.  The first NRQ_SCRATCH slots of the LDS image are
  * per-lane scratch: the padding op of lane l reads and writes scratch slot l, so padding needs no branch. */
 #define NRQ_SCRATCH 64u
@@ -49,6 +59,46 @@
 #define NRQ_OP_SRC(op) (((op) >> 16) - NRQ_SCRATCH)
 #define NRQ_NOSLOT 0xFFFFu
 #define NRQ_MAX_FREE 32u
+
+/* Lane placement inside a level group.  The ops of a group are independent of each other, so which lane of which row an
+ * op takes is free -- and it decides the LDS bank conflicts of the row pipeline: a 64-lane LDS atomic (ds_xor_b64, like
+ * ds_write_b64) is served in four groups of 16 CONTIGUOUS lanes with bank = dword address mod 32
+ * (MI355X_MICROARCH.md, LDS), so with 16-byte slots the targets of a 16-lane block fall into 8 classes (slot mod 8) and a
+ * block costs as many LDS cycles as its busiest class has different slots: ~4.1 with random lanes, 2 at best.  Measured
+ * (tools/microbench/lds_half.hip, two waves on 8-byte halves): 54.6 clocks per row with random lanes, 35 with two targets
+ * per class and block, 28 with no conflict at all.  So: an op of class d that is the r-th of its class in the group --
+ * finishing ops counted first, they must stay out of the group's last NRQ_PIPE-1 rows -- takes lane 2d + (r & 1) of the
+ * group's 16-lane block r >> 1; what a class has beyond two per block goes to the lanes other classes leave empty, class
+ * by class.  Both planners place ops this way (the device planner when its per-class counters fit the LDS). */
+#define NRQ_LANE_CLASSES 8u
+#if defined(__HIPCC__)
+#define NRQ_PLAN_FN __host__ __device__ static inline
+#else
+#define NRQ_PLAN_FN static inline
+#endif
+NRQ_PLAN_FN uint32_t nrq_op_class(uint32_t op) { return op & (NRQ_LANE_CLASSES - 1u); } /* (NRQ_SCRATCH is a multiple of 8) */
+/* rows a group takes: its n ops, and its finishing ops (cf[d] of class d) in all but the last NRQ_PIPE-1 rows */
+NRQ_PLAN_FN uint32_t nrq_group_span(uint32_t n, const uint32_t *cf) {
+  uint32_t mf = 0;
+  for (uint32_t d = 0; d < NRQ_LANE_CLASSES; d++) mf = cf[d] > mf ? cf[d] : mf;
+  const uint32_t need = (mf + NRQ_LANE_CLASSES - 1u) / NRQ_LANE_CLASSES + (NRQ_PIPE - 1u); /* (2 per block, 4 blocks per row) */
+  const uint32_t have = (n + NRQ_ROW - 1u) / NRQ_ROW;
+  return have > need ? have : need;
+}
+/* place (offset from the group's first op word) of the op of class d with rank r; ct[] = ops per class of the whole group */
+NRQ_PLAN_FN uint32_t nrq_lane_place(uint32_t span, const uint32_t *ct, uint32_t d, uint32_t r) {
+  const uint32_t cap = span * NRQ_LANE_CLASSES; /* two per block, span * 4 blocks */
+  if (r >= cap) { /* beyond the class's own lanes: the o-th lane left empty by the classes, in class order */
+    uint32_t o = r - cap;
+    for (uint32_t e = 0; e < d; e++) o += ct[e] > cap ? ct[e] - cap : 0u;
+    for (uint32_t e = 0; e < NRQ_LANE_CLASSES; e++) {
+      const uint32_t holes = ct[e] < cap ? cap - ct[e] : 0u;
+      if (o < holes) { d = e; r = ct[e] + o; break; }
+      o -= holes;
+    }
+  }
+  return (r >> 1) * 16u + 2u * d + (r & 1u);
+}
 /* When a peeling round has no row of weight 1, this many open rows (sparsest first) are resolved by
  * inactivation before peeling resumes: fewer, wider cascades -> fewer rounds in the planner and fewer dependency
  * levels in the plan, for a few more inactive columns (which the back-substitution pays for).  Measured on the

@@ -131,6 +131,7 @@ typedef struct pl_shared {
   uint32_t tmp_mhoff; /* byte offset of Mb inside the dense LDS region, behind MhT (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
   uint32_t pad_to_16[3];
+  uint32_t bin_ct[NRQ_LANE_CLASSES]; /* ops of the GF(2) combination group per lane class of the target */
   /* The arrays whose size depends on the launch follow the struct in LDS (pl_tail_*): frontier queues queue[2][qcap],
    * claim lists claim_l[qcap] / claim_c[qcap] (columns claimed this round: level + 1 of the pivot, column),
    * partial[nt] (per-thread scratch), gj_flag[lowcap] / gj_used[lowcap] (Gauss-Jordan: bit of the current column /
@@ -192,7 +193,7 @@ SB_HD uint32_t pl_arena_bound(uint32_t L, uint32_t Mcap, uint32_t ucap, uint32_t
   const uint32_t wprcap = (ucap + 31u) / 32u, npad = (L + 63u) & ~63u;
   /* op stream: the ops themselves, one partly filled row plus NRQ_PIPE-1 spacer rows per level, the spare and
    * the lead/padding rows */
-  uint32_t ops = (2u * nnz + 2u * ucap * 64u) + NRQ_ROW * (NRQ_PIPE * (L / 2u + 8u) + PL_SPARE_ROWS + NRQ_RING + NRQ_PAD_ROWS);
+  uint32_t ops = (2u * nnz + nnz / 2u + 2u * ucap * 64u) + NRQ_ROW * (NRQ_PIPE * (L / 2u + 8u) + PL_SPARE_ROWS + NRQ_PAD_ROWS + 4u);
   uint32_t b = 256u + L * 2u * 3u + (L + 16u) * 2u + ucap * 2u * 4u + ucap * 4u * 2u + PL_MAXH * ucap +
                NRQ_MAX_FREE * PL_MAXH + wprcap * npad * 4u + ops * 4u +
                Mcap * 4u + (nlost_cap + 1u) * 8u + nlost_cap * PL_PATCH_STRIDE * 2u + 1024u;
@@ -737,27 +738,54 @@ template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t t
  *   - "early" ops: dst on a later level t > l, src final before l; such an op may run in any group of its window
  *     [level(src)+1, t-1] and is sent to one of them by a hash of (dst, column) -- it fills lanes that the narrow
  *     levels would leave empty (plan.h: a group needs NRQ_PIPE-1 rows after its finishing ops anyway).
- * Four counters per group -- finishing / early ops counted, finishing / early ops placed -- in LDS at the end of the
- * aux region (the rowstate image, dead once peeling is over): thousands of rows share a level, and that many
- * atomics on ONE global address serialise in L2 (~1 M clocks per block measured).  The level of every pivot
- * column (what an op's window depends on) sits at the start of the aux region.  If LDS is too small for either,
- * every op counts as finishing op of its dst level, with the counters in HBM and one atomic per row, not per op. */
+ * Sixteen 16-bit counters per group -- finishing / early ops counted, by lane class of the target (plan.h "lane
+ * placement") -- in LDS at the end of the aux region (the rowstate image, dead once peeling is over): thousands of rows
+ * share a level, and that many atomics on ONE global address serialise in L2 (~1 M clocks per block measured).  The level
+ * of every pivot column (what an op's window depends on) sits at the start of the aux region.  If LDS is too small for
+ * either, every op counts as finishing op of its dst level, with the counters in HBM (lev_ops / lev_fill), one atomic
+ * per row, not per op, and lanes handed out in counter order. */
 SB_HD uint32_t pl_lev_words(const PlanCtx &c) { return c.sh->nlev + 2u; }
+#define PL_CLS_BYTES (2u * NRQ_LANE_CLASSES * 2u) /* per group: [part 0 = finishing, 1 = early][class] x u16 */
+/* where the class counters go: the dense stage's region when the peeling state has its own place in LDS (that region is
+ * idle until the HDPC fold), else behind the column levels at the end of the aux region */
+SB_HD uint8_t *pl_cls_place(const PlanCtx &c) {
+  const uint32_t bytes = pl_r16(pl_lev_words(c) * PL_CLS_BYTES);
+  if (!c.aux_lds) return nullptr;
+  if (c.dense_lds != c.aux_lds && bytes <= c.dense_bytes) return c.dense_lds;
+  if (pl_r16(c.p.L * 2u) + bytes <= c.aux_bytes) return c.aux_lds + c.aux_bytes - bytes;
+  return nullptr;
+}
 SB_HD uint16_t *pl_col_level(const PlanCtx &c) {
-  const uint32_t need = pl_r16(c.p.L * 2u) + pl_r16(pl_lev_words(c) * 16u); /* (the level-by-level W pass stages its tables here later) */
-  if (!c.aux_lds || need > c.aux_bytes) return nullptr;
+  if (!c.aux_lds || pl_r16(c.p.L * 2u) > c.aux_bytes || !pl_cls_place(c)) return nullptr; /* (the level-by-level W pass stages its tables in the aux region later) */
   return reinterpret_cast<uint16_t *>(c.aux_lds);
 }
-SB_HD uint32_t *pl_lds_lev(const PlanCtx &c) {
+/* the class counters (nullptr: the HBM counters are in use) */
+SB_HD uint32_t *pl_cls(const PlanCtx &c) {
   if (!pl_col_level(c)) return nullptr;
-  return reinterpret_cast<uint32_t *>(c.aux_lds + c.aux_bytes - pl_r16(pl_lev_words(c) * 16u));
+  uint32_t *q = reinterpret_cast<uint32_t *>(pl_cls_place(c));
+  PL_ASSUME_LDS(q);
+  return q;
 }
-/* counters: [0] finishing counted (= lev_ops when in HBM), [1] early counted, [2] finishing placed (= lev_fill), [3] early placed */
-SB_HD uint32_t *pl_lev_ctr(const PlanCtx &c, uint32_t which) {
-  uint32_t *l = pl_lds_lev(c);
-  if (l) return l + which * pl_lev_words(c);
-  return which == 0 ? c.lev_ops : c.lev_fill; /* only 0 and 2 are used without LDS */
+/* count one op of (group g, part, class d): its rank among them */
+SB_HD uint32_t pl_cls_take(uint32_t *cls, uint32_t g, uint32_t part, uint32_t d) {
+  const uint32_t i = (g * 2u + part) * NRQ_LANE_CLASSES + d, sh16 = (i & 1u) * 16u;
+  return (PL_ATOM_ADD(&cls[i >> 1], 1u << sh16) >> sh16) & 0xFFFFu;
 }
+/* the counts of group g: cf[] finishing ops per class, ct[] all ops per class; returns the number of ops (nf: finishing ones) */
+SB_HD uint32_t pl_cls_counts(const uint32_t *cls, uint32_t g, uint32_t *cf, uint32_t *ct, uint32_t *nf) {
+  uint32_t n = 0, f = 0;
+  const uint32_t *w = cls + (size_t)g * NRQ_LANE_CLASSES; /* (two counters per word: 8 words per group) */
+#pragma unroll
+  for (uint32_t d = 0; d < NRQ_LANE_CLASSES; d++) {
+    const uint32_t a = (w[d >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu;
+    const uint32_t e = (w[(NRQ_LANE_CLASSES + d) >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu;
+    cf[d] = a; ct[d] = a + e; f += a; n += a + e;
+  }
+  *nf = f;
+  return n;
+}
+/* without the class counters: [0] ops counted per group (= lev_ops), [2] ops placed (= lev_fill) */
+SB_HD uint32_t *pl_lev_ctr(const PlanCtx &c, uint32_t which) { return which == 0 ? c.lev_ops : c.lev_fill; }
 /* group of the op (dst row r on level t) <- (pivot column col): t itself for a finishing op */
 SB_HD uint32_t pl_op_group(const uint16_t *collev, uint32_t t, uint32_t r, uint32_t col) {
   if (!collev) return t;
@@ -789,8 +817,8 @@ template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
-  if (uint32_t *l = pl_lds_lev(c)) { /* nlev is final now */
-    for (uint32_t k = tid; k < 4u * pl_lev_words(c); k += nt) l[k] = 0;
+  if (uint32_t *l = pl_cls(c)) { /* nlev is final now */
+    for (uint32_t k = tid; k < pl_lev_words(c) * (PL_CLS_BYTES / 4u); k += nt) l[k] = 0;
     uint16_t *collev = pl_col_level(c);
     for (uint32_t k = tid; k < sh->npiv; k += nt) collev[c.pivcol[k]] = (uint16_t)(c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK);
   }
@@ -802,15 +830,16 @@ template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
 /* One row op found by pl_w_init (LDS-counter path): counted in its group -- the counter's old value is its place
  * among the group's finishing / early ops -- and recorded for pl_ops_emit, which then is a plain permutation pass
  * instead of a second walk over the rows (a walk is a chain of dependent trips to L2 per row). */
-SB_HD void pl_record_op(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16_t *collev, uint32_t lev, uint32_t r,
+SB_HD void pl_record_op(PlanCtx &c, uint32_t *cls, const uint16_t *collev, uint32_t lev, uint32_t r,
                         uint32_t col, uint32_t info) {
   const uint32_t g = pl_op_group(collev, lev, r, col);
   const uint32_t early = g == lev ? 0u : 0x80000000u;
-  const uint32_t idx = PL_ATOM_ADD(early ? &cntN[g] : &cntF[g], 1u);
   const uint32_t src = c.pivslot[info & 0x3FFFFFFFu];
+  const uint32_t word = NRQ_OP(r, src);
+  const uint32_t idx = pl_cls_take(cls, g, early ? 1u : 0u, nrq_op_class(word));
   const uint32_t i = PL_ATOM_ADD(&c.sh->nrec, 1u);
   if (i >= c.reccap) { (c.sh->fail_site = __LINE__, c.sh->status = PL_FAIL_CAPACITY); return; }
-  c.rec_word[i] = NRQ_OP(r, src);
+  c.rec_word[i] = word;
   c.rec_idx[i] = early | idx;
   c.rec_g[i] = (uint16_t)g;
 }
@@ -820,7 +849,7 @@ SB_HD void pl_record_op(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16
  * a pivot column other than the row's own is a row op */
 #define PL_WU 4u /* entries a thread has in flight: every step below is a trip to L2 or beyond (the planner's working
                    set, ~2 MB per block, does not stay in the 4 MB of L2 that 32 blocks share) */
-SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16_t *collev, const uint32_t (&r)[PL_WU],
+SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cls, const uint16_t *collev, const uint32_t (&r)[PL_WU],
                         const uint32_t (&col)[PL_WU], const bool (&use)[PL_WU], bool base) {
   uint32_t rinfo[PL_WU], info[PL_WU], src[PL_WU];
   bool on[PL_WU];
@@ -842,10 +871,11 @@ SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cntF, uint32_t *cntN, const uint16
       const uint32_t lev = (rinfo[j] & PL_UNASSIGNED) ? c.sh->nlev : (rinfo[j] & PL_LEVEL_MASK);
       const uint32_t g = pl_op_group(collev, lev, r[j], col[j]);
       const uint32_t early = g == lev ? 0u : 0x80000000u;
-      const uint32_t at = PL_ATOM_ADD(early ? &cntN[g] : &cntF[g], 1u);
+      const uint32_t word = NRQ_OP(r[j], src[j]);
+      const uint32_t at = pl_cls_take(cls, g, early ? 1u : 0u, nrq_op_class(word));
       const uint32_t i = PL_ATOM_ADD(&c.sh->nrec, 1u);
       if (i >= c.reccap) { (c.sh->fail_site = __LINE__, c.sh->status = PL_FAIL_CAPACITY); continue; }
-      c.rec_word[i] = NRQ_OP(r[j], src[j]);
+      c.rec_word[i] = word;
       c.rec_idx[i] = early | at;
       c.rec_g[i] = (uint16_t)g;
     }
@@ -856,7 +886,7 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (sh->status) return;
   const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr, S = c.p.S;
   const uint32_t total = sh->npiv + sh->nlow;
-  uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lev_ctr(c, 1);
+  uint32_t *cntF = pl_lev_ctr(c, 0), *cls = pl_cls(c);
   const uint16_t *collev = pl_col_level(c);
   if (collev) {
     /* with the group counters in LDS every entry stands for itself: one pass over the entries of the base structure
@@ -872,7 +902,7 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
         r[j] = use[j] ? c.b_erow[e] : 0u;
         col[j] = use[j] ? c.b_cidx[e] : 0u;
       }
-      pl_w_entries(c, cntF, cntN, collev, r, col, use, true);
+      pl_w_entries(c, cls, collev, r, col, use, true);
     }
     for (uint32_t q0 = tid; q0 < npq; q0 += PL_WU * nt) {
       uint32_t r[PL_WU], col[PL_WU];
@@ -884,7 +914,7 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
         r[j] = !use[j] ? 0u : i < nl ? c.p.S + c.p.H + c.lost[i] : c.p.L + (i - nl);
         col[j] = use[j] ? c.patch_cols[q] : 0u;
       }
-      pl_w_entries(c, cntF, cntN, collev, r, col, use, false);
+      pl_w_entries(c, cls, collev, r, col, use, false);
     }
     return;
   }
@@ -932,7 +962,7 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
         const uint32_t info = c.colinfo[col], idx = info & 0x3FFFFFFFu;
         if ((info >> 30) == PL_ST_INACT) PL_ATOM_XOR(&dst[idx >> 5], 1u << (idx & 31u));
         else if (col != own[j]) {
-          if (collev) pl_record_op(c, cntF, cntN, collev, lev, r[j], col, info);
+          if (collev) pl_record_op(c, cls, collev, lev, r[j], col, info);
           else deg++;
         }
       }
@@ -948,7 +978,7 @@ template <int Z> SB_HD void pl_w_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t wpr = sh->wpr, lane = tid & 63u, nlong = sh->nq[0];
-  uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lev_ctr(c, 1);
+  uint32_t *cntF = pl_lev_ctr(c, 0), *cls = pl_cls(c);
   const uint16_t *collev = pl_col_level(c);
   for (uint32_t q = tid >> 6; q < nlong; q += nt >> 6) {
     const uint32_t i = c.queue(0u)[q];
@@ -964,7 +994,7 @@ template <int Z> SB_HD void pl_w_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
       const uint32_t info = c.colinfo[col], idx = info & 0x3FFFFFFFu;
       if ((info >> 30) == PL_ST_INACT) PL_ATOM_XOR(&dst[idx >> 5], 1u << (idx & 31u));
       else if (col != own) {
-        if (collev) pl_record_op(c, cntF, cntN, collev, lev, r, col, info);
+        if (collev) pl_record_op(c, cls, collev, lev, r, col, info);
         else deg++;
       }
     }
@@ -1005,22 +1035,26 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
   if (sh->status) return;
   const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr;
   const bool lds = sh->lv_in_lds != 0u;
-  const uint32_t n_real = lds ? pl_aux_lvops(c)[group] : c.lev_ops[group];
+  /* the group's rows [base, next): every place of them is looked at (padding ops are skipped), place e = (row base + e / 64, lane e % 64) */
   const uint32_t base = lds ? pl_aux_lvbase(c)[group] : c.lev_base[group];
-  const uint32_t nops = pl_group_rows(n_real) * NRQ_ROW;
+  const uint32_t next = lds ? pl_aux_lvbase(c)[group + 1u] : c.lev_base[group + 1u];
+  const uint32_t nops = (next - base) * NRQ_ROW;
   const uint32_t *gops = reinterpret_cast<const uint32_t *>(c.arena + sh->off_ops);
   const bool staged = lds && sh->opq_group[group & 1u] == group;
-  const uint32_t *ops = staged ? pl_aux_opq(c, group & 1u) : gops + (size_t)base * NRQ_ROW;
+  const uint32_t *opq = pl_aux_opq(c, group & 1u);
+  auto op_at = [&](uint32_t e) { return staged ? opq[e] : gops[NRQ_OP_INDEX(base + e / NRQ_ROW, e % NRQ_ROW)]; };
   /* issue the prefetch of the next group first: its loads overlap with this group's work */
   uint32_t pf[PL_OPQ_WORDS / PL_NT_MIN], pf_n = 0; /* (PL_OPQ_WORDS / nt of them are used) */
   if (lds && group + 1u <= sh->nlev) {
-    const uint32_t n2 = pl_group_rows(pl_aux_lvops(c)[group + 1u]) * NRQ_ROW;
+    const uint32_t b2 = pl_aux_lvbase(c)[group + 1u], n2 = (pl_aux_lvbase(c)[group + 2u] - b2) * NRQ_ROW;
     if (n2 <= PL_OPQ_WORDS) {
       pf_n = n2;
-      const uint32_t *src = gops + (size_t)pl_aux_lvbase(c)[group + 1u] * NRQ_ROW;
 #pragma unroll
       for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT_MIN; q++)
-        if (q < PL_OPQ_WORDS / nt) pf[q] = (tid + q * nt) < n2 ? src[tid + q * nt] : 0u /* a padding op */;
+        if (q < PL_OPQ_WORDS / nt) {
+          const uint32_t e = tid + q * nt;
+          pf[q] = e < n2 ? gops[NRQ_OP_INDEX(b2 + e / NRQ_ROW, e % NRQ_ROW)] : 0u /* a padding op */;
+        }
     }
   }
   if (wpr <= 8u) {
@@ -1031,7 +1065,7 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
 #pragma unroll
       for (uint32_t q = 0; q < 8; q++) {
         const uint32_t e = e0 + q * ngrp;
-        op[q] = e < nops ? ops[e] : 0u;
+        op[q] = e < nops ? op_at(e) : 0u;
       }
 #pragma unroll
       for (uint32_t q = 0; q < 8; q++) {
@@ -1051,7 +1085,7 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
 #pragma unroll
       for (uint32_t q = 0; q < OB; q++) {
         const uint32_t e = e0 + q * ngrp;
-        op[q] = e < nops ? ops[e] : 0u;
+        op[q] = e < nops ? op_at(e) : 0u;
       }
 #pragma unroll
       for (uint32_t q = 0; q < OB; q++) {
@@ -1193,15 +1227,32 @@ SB_HD uint32_t pl_group_span(uint32_t l, uint32_t nf, uint32_t n) {
   const uint32_t need = pl_group_rows(nf) + (NRQ_PIPE - 1u), have = pl_group_rows(n);
   return have > need ? have : need;
 }
+/* rows of group l: with the class counters, what the lane placement needs (plan.h); else pl_group_span */
+SB_HD uint32_t pl_group_span_of(const PlanCtx &c, uint32_t l, uint32_t *n_out, uint32_t *nf_out) {
+  uint32_t nf, n;
+  uint32_t span;
+  if (const uint32_t *cls = pl_cls(c)) {
+    uint32_t cf[NRQ_LANE_CLASSES], ct[NRQ_LANE_CLASSES];
+    n = pl_cls_counts(cls, l, cf, ct, &nf);
+    span = l ? nrq_group_span(n, cf) : 0u;
+    for (uint32_t d = 0; d < NRQ_LANE_CLASSES; d++) /* (a 16-bit counter that came near its end: do not trust the block) */
+      if (ct[d] >= 0x7FFFu) (c.sh->fail_site = __LINE__, c.sh->status = PL_FAIL_CAPACITY);
+  } else {
+    nf = n = pl_lev_ctr(c, 0)[l];
+    span = pl_group_span(l, nf, n);
+  }
+  *n_out = n; *nf_out = nf;
+  return span;
+}
 /* per group: op counts to the workspace, rows to LDS (the frontier queues are free by now) for the prefix sums of
  * pl_ops_layout -- when the groups are too many for that, pl_ops_layout walks them alone */
 template <int Z> SB_HD void pl_ops_layout_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
-  const uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lds_lev(c) ? pl_lev_ctr(c, 1) : nullptr;
   const bool in_lds = sh->nlev + 1u <= 2u * c.qcap;
   uint16_t *rowq = c.queue(0u);
   for (uint32_t l = tid; l <= sh->nlev; l += nt) {
-    const uint32_t nf = cntF[l], n = nf + (cntN ? cntN[l] : 0u), span = pl_group_span(l, nf, n);
+    uint32_t n, nf;
+    const uint32_t span = pl_group_span_of(c, l, &n, &nf);
     c.lev_ops[l] = n;
     c.lev_fin[l] = nf;
     if (in_lds) {
@@ -1212,28 +1263,27 @@ template <int Z> SB_HD void pl_ops_layout_a(PlanCtx &c, uint32_t tid, uint32_t n
 }
 template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
-  /* row base of every group (1..nlev-1: pivot levels, nlev: leftover rows); the stream starts with the NRQ_RING
-   * lead rows */
+  /* row base of every group (1..nlev-1: pivot levels, nlev: leftover rows); lev_base[nlev + 1] = the first row behind them */
   const bool in_lds = sh->nlev + 1u <= 2u * c.qcap;
   if (in_lds)
-    for (uint32_t l = tid; l <= sh->nlev; l += nt) c.lev_base[l] = NRQ_RING + pl_deg_prefix(c, l);
+    for (uint32_t l = tid; l <= sh->nlev + 1u; l += nt) c.lev_base[l] = pl_deg_prefix(c, l);
   if (tid != 0) return;
-  uint32_t rows = NRQ_RING;
+  uint32_t rows = 0;
   if (in_lds) rows += pl_deg_prefix(c, sh->nlev + 1u);
   else {
-    const uint32_t *cntF = pl_lev_ctr(c, 0), *cntN = pl_lds_lev(c) ? pl_lev_ctr(c, 1) : nullptr;
     for (uint32_t l = 0; l <= sh->nlev; l++) {
-      const uint32_t nf = cntF[l], n = nf + (cntN ? cntN[l] : 0u);
+      uint32_t n, nf;
       c.lev_base[l] = rows;
-      rows += pl_group_span(l, nf, n);
+      rows += pl_group_span_of(c, l, &n, &nf); /* (lev_ops / lev_fin were written by pl_ops_layout_a) */
     }
+    c.lev_base[sh->nlev + 1u] = rows;
   }
   sh->spare_base = rows; /* rows reserved for constraint rows added later */
   rows += PL_SPARE_ROWS + (NRQ_PIPE - 1u);
   sh->tmp0 = rows; /* rows so far; the GF(2) combination group follows after the elimination */
   /* ops region: generous bound for the combination group (nlow ones per reduced row at most) */
   uint32_t bin_bound = ((sh->nlow + PL_EXTRA_ROWS) * (sh->nlow + PL_EXTRA_ROWS) + NRQ_ROW - 1u) / NRQ_ROW + 1u;
-  uint32_t total_rows = rows + bin_bound + NRQ_PAD_ROWS;
+  uint32_t total_rows = NRQ_STREAM_ROWS(rows + bin_bound + NRQ_PAD_ROWS);
   sh->off_ops = pl_r16(c.fixed_end);
   sh->arena_top = pl_r16(sh->off_ops + total_rows * NRQ_ROW * 4u);
   sh->opbase = total_rows;
@@ -1244,8 +1294,10 @@ template <int Z> SB_HD void pl_ops_clear(PlanCtx &c, uint32_t tid, uint32_t nt) 
   if (sh->status) return;
   uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
   const uint32_t nw = sh->opbase * NRQ_ROW;
-  for (uint32_t k = tid; k < nw; k += nt) ops[k] = NRQ_NOP_AT(k);
+  for (uint32_t k = tid; k < nw; k += nt) ops[k] = NRQ_NOP_AT(NRQ_OP_LANE_OF_INDEX(k)); /* (the stream is quad-interleaved) */
 }
+/* the op word at place `pos` (row-major: 64 lanes per row) counted from stream row `row0` */
+SB_HD uint32_t *pl_op_at(uint32_t *ops, uint32_t row0, uint32_t pos) { return ops + NRQ_OP_INDEX(row0 + pos / NRQ_ROW, pos % NRQ_ROW); }
 /* position of the i-th op of a run starting at `pos` inside a group of n ops: a multiplicative shuffle
  * keeps the ops of one row apart so that the lanes of a wave rarely hit the same target slot */
 SB_HD uint32_t pl_spread(uint32_t pos, uint32_t n) {
@@ -1257,57 +1309,45 @@ SB_HD uint32_t pl_spread(uint32_t pos, uint32_t n) {
     if (n % mult[q]) m = mult[q];
   return (uint32_t)(((uint64_t)pos * m) % n);
 }
-/* The lanes that walk ONE constraint row take consecutive places of a group's counter; 64 consecutive places are one
- * row of the op stream, i.e. one wave instruction of LDS atomics on the same target slot.  A bijection of [0, n)
- * that keeps the lane (place mod 64) and shifts the stream row by it sends consecutive places to different rows. */
-SB_HD uint32_t pl_shear(uint32_t idx, uint32_t n) {
-  const uint32_t R = n / NRQ_ROW; /* whole rows; the ragged tail stays where it is */
-  if (idx >= R * NRQ_ROW || R < 2u) return idx;
-  const uint32_t b = idx % NRQ_ROW;
-  uint32_t a = idx / NRQ_ROW + b;
-  while (a >= R) a -= R;
-  return a * NRQ_ROW + b;
-}
 /* the ops of constraint row r (dst; on level `lev`), each into its group (pl_op_group): finishing ops fill the
  * group from the front, early ops follow them; the place inside either part is whatever the counter hands out,
  * which also keeps the ops of one row apart */
 SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t lev, uint32_t deg) {
   uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + c.sh->off_ops);
-  uint32_t *fillF = pl_lev_ctr(c, 2), *fillN = pl_lds_lev(c) ? pl_lev_ctr(c, 3) : nullptr;
-  const uint16_t *collev = pl_col_level(c);
+  uint32_t *fillF = pl_lev_ctr(c, 2);
   const uint16_t *cols;
   const uint32_t m = pl_row(c, r, &cols);
-  /* without LDS counters: one run of `deg` places in the row's own group, shuffled (pl_spread) */
-  uint32_t run = collev ? 0u : PL_ATOM_ADD(&fillF[lev], deg);
+  /* (without the class counters only:) one run of `deg` places in the row's own group, shuffled (pl_spread) */
+  uint32_t run = PL_ATOM_ADD(&fillF[lev], deg);
   for (uint32_t k = 0; k < m; k++) {
     const uint32_t col = cols[k], info = c.colinfo[col];
     if ((info >> 30) != PL_ST_PIVOT || col == own) continue;
-    const uint32_t g = pl_op_group(collev, lev, r, col);
-    const uint32_t pos = !collev ? pl_spread(run++, c.lev_ops[lev])
-                         : g == lev ? PL_ATOM_ADD(&fillF[g], 1u) : c.lev_fin[g] + PL_ATOM_ADD(&fillN[g], 1u);
-    ops[(size_t)c.lev_base[g] * NRQ_ROW + pos] = NRQ_OP(r, c.pivslot[info & 0x3FFFFFFFu]);
+    *pl_op_at(ops, c.lev_base[lev], pl_spread(run++, c.lev_ops[lev])) = NRQ_OP(r, c.pivslot[info & 0x3FFFFFFFu]);
   }
 }
 template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
-  if (pl_col_level(c)) { /* the ops were recorded with their place: finishing ops from the front of the group, early ops behind them */
+  if (const uint32_t *cls = pl_cls(c)) { /* the ops were recorded with group, class and rank: their lanes follow (plan.h "lane placement") */
     uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
     const uint32_t nrec = sh->nrec;
     for (uint32_t i0 = tid; i0 < nrec; i0 += PL_WU * nt) { /* PL_WU records in flight per thread */
-      uint32_t m[PL_WU], g[PL_WU], w[PL_WU], nf[PL_WU], n[PL_WU], base[PL_WU];
+      uint32_t m[PL_WU], g[PL_WU], w[PL_WU], base[PL_WU], next[PL_WU];
 #pragma unroll
       for (uint32_t j = 0; j < PL_WU; j++) {
         const uint32_t i = i0 + j * nt < nrec ? i0 + j * nt : i0;
         m[j] = c.rec_idx[i]; g[j] = c.rec_g[i]; w[j] = c.rec_word[i];
       }
 #pragma unroll
-      for (uint32_t j = 0; j < PL_WU; j++) { nf[j] = c.lev_fin[g[j]]; n[j] = c.lev_ops[g[j]]; base[j] = c.lev_base[g[j]]; }
+      for (uint32_t j = 0; j < PL_WU; j++) { base[j] = c.lev_base[g[j]]; next[j] = c.lev_base[g[j] + 1u]; }
 #pragma unroll
       for (uint32_t j = 0; j < PL_WU; j++) {
         if (i0 + j * nt >= nrec) continue;
-        const uint32_t pos = (m[j] >> 31) ? nf[j] + pl_shear(m[j] & 0x7FFFFFFFu, n[j] - nf[j]) : pl_shear(m[j], nf[j]);
-        ops[(size_t)base[j] * NRQ_ROW + pos] = w[j];
+        uint32_t cf[NRQ_LANE_CLASSES], ct[NRQ_LANE_CLASSES], nf;
+        pl_cls_counts(cls, g[j], cf, ct, &nf);
+        const uint32_t d = nrq_op_class(w[j]);
+        const uint32_t rank = (m[j] >> 31) ? cf[d] + (m[j] & 0x7FFFFFFFu) : m[j]; /* early ops rank behind the finishing ones */
+        *pl_op_at(ops, base[j], nrq_lane_place(next[j] - base[j], ct, d, rank)) = w[j];
       }
     }
     return;
@@ -1319,6 +1359,23 @@ template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
   for (uint32_t j = tid; j < sh->nlow; j += nt) pl_emit_row(c, c.lowslot[j], PL_NONE, sh->nlev, c.lowdeg[j]);
 }
 
+#ifdef NRQ_PLAN_SELFCHECK
+/* debugging aid (-DNRQ_PLAN_SELFCHECK): every recorded op must have reached the stream (two ops on one place would lose
+ * one); a mismatch is reported as capacity failure at "line" 70000 + the number of ops missing */
+template <int Z> SB_HD void pl_ops_check_a(PlanCtx &c, uint32_t tid, uint32_t nt) { if (tid == 0) c.sh->tmp1 = 0; }
+template <int Z> SB_HD void pl_ops_check_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (sh->status || !pl_cls(c)) return;
+  const uint32_t *ops = reinterpret_cast<const uint32_t *>(c.arena + sh->off_ops);
+  uint32_t n = 0;
+  for (uint32_t k = tid; k < NRQ_STREAM_ROWS(sh->spare_base) * NRQ_ROW; k += nt) n += NRQ_OP_IS_NOP(ops[k]) ? 0u : 1u; /* (quad-interleaved: whole quads) */
+  if (n) PL_ATOM_ADD(&sh->tmp1, n);
+}
+template <int Z> SB_HD void pl_ops_check_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (tid == 0 && !sh->status && pl_cls(c) && sh->tmp1 != sh->nrec) { sh->fail_site = 70000u + (sh->nrec - sh->tmp1); sh->status = PL_FAIL_CAPACITY; }
+}
+#endif
 /* =============================== phase 5: HDPC rows over the inactive columns ================= */
 /* MhT[x] = G_U[:,x] ^ SUM_k W[k][x] * G[:, pivcol k]  (16 bytes per inactive column x, in LDS).  The pivots
  * are streamed through LDS in tiles: their HDPC columns (16 bytes each, kconst GT) and their W rows. */
@@ -1491,11 +1548,15 @@ template <int Z> SB_HD void pl_bin_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (tid != 0) return;
+  /* the ops of reduced row q (target: scratch row M + q) rank among those of the target's lane class (plan.h "lane placement") */
   uint32_t run = 0;
-  for (uint32_t q = 0; q < sh->r2; q++) { uint32_t n = c.pivdeg[q]; c.pivdeg[q] = run; run += n; }
+  for (uint32_t d = 0; d < NRQ_LANE_CLASSES; d++) sh->bin_ct[d] = 0;
+  for (uint32_t q = 0; q < sh->r2; q++) {
+    const uint32_t n = c.pivdeg[q], d = nrq_op_class(NRQ_OP(sh->M + q, 0u));
+    c.pivdeg[q] = sh->bin_ct[d]; sh->bin_ct[d] += n; run += n;
+  }
   const uint32_t g = sh->nlev + 1u;
   c.lev_ops[g] = run;
-  c.lev_base[g] = sh->tmp0;
   sh->nrows = sh->tmp0 + pl_group_rows(run);
   if ((sh->nrows + NRQ_PAD_ROWS > sh->opbase || sh->M + sh->r2 + NRQ_SCRATCH > 65535u) && sh->status == 0)
     (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* op fields are 16 bits */
@@ -1503,8 +1564,10 @@ template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
 template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
-  const uint32_t g = sh->nlev + 1u, n = c.lev_ops[g];
-  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops) + (size_t)c.lev_base[g] * NRQ_ROW;
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
+  const uint32_t row0 = sh->tmp0, span = sh->nrows - sh->tmp0;
+  uint32_t ct[NRQ_LANE_CLASSES];
+  for (uint32_t d = 0; d < NRQ_LANE_CLASSES; d++) ct[d] = sh->bin_ct[d];
   const uint32_t *Mb = pl_mb(c);
   for (uint32_t q = tid; q < sh->r2; q += nt) {
     const uint32_t *aug = Mb + (size_t)c.red_row[q] * sh->rowlen + sh->wpr;
@@ -1514,7 +1577,8 @@ template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
       while (bits) {
         const uint32_t j = w * 32u + (uint32_t)__builtin_ctz(bits);
         bits &= bits - 1u;
-        ops[pl_spread(i, n)] = NRQ_OP(sh->M + q, c.lowslot[j]);
+        const uint32_t word = NRQ_OP(sh->M + q, c.lowslot[j]);
+        *pl_op_at(ops, row0, nrq_lane_place(span, ct, nrq_op_class(word), i)) = word;
         i++;
       }
     }
@@ -1625,13 +1689,13 @@ template <int Z> SB_HD void pl_extra_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   uint32_t cols[RQ_MAX_LT_COLS];
   const uint32_t n = rq_lt_columns(&p, esi + (p.Kp - p.K), cols);
   uint16_t *dst = c.patch_cols + (size_t)i * PL_PATCH_STRIDE;
-  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops) + (size_t)sh->spare_base * NRQ_ROW;
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
   for (uint32_t k = 0; k < n; k++) {
     dst[k] = (uint16_t)cols[k];
     const uint32_t info = c.colinfo[cols[k]];
     if ((info >> 30) == PL_ST_PIVOT) {
       if (sh->spare_fill >= PL_SPARE_ROWS * NRQ_ROW) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); return; }
-      ops[sh->spare_fill++] = NRQ_OP(row, c.pivslot[info & 0x3FFFFFFFu]);
+      *pl_op_at(ops, sh->spare_base, sh->spare_fill++) = NRQ_OP(row, c.pivslot[info & 0x3FFFFFFFu]);
     }
   }
   c.patch_len[i] = (uint8_t)n;

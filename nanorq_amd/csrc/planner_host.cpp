@@ -364,31 +364,28 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   std::vector<uint32_t> ops;
   uint32_t n_real_ops = 0;
   auto pad_rows = [&](uint32_t nrows_) { for (uint32_t k = 0; k < nrows_ * NRQ_ROW; k++) ops.push_back(NRQ_NOP_AT(ops.size())); };
-  pad_rows(NRQ_RING); /* lead rows: the initial content of the kernel's op-word ring */
   /* place one group (plan.h): `fin` ops that complete rows other groups may read next, then `early` ops whose
    * targets are read later; the last NRQ_PIPE-1 rows of a group hold no finishing op */
-  auto spread = [](std::vector<uint32_t> &v) { /* keep the ops of one row apart: a multiplicative shuffle */
-    const size_t n = v.size();
-    if (n < 128) return;
-    static const uint32_t mult[6] = {61u, 67u, 71u, 73u, 79u, 83u};
-    uint32_t m = 1;
-    for (int q = 5; q >= 0; q--)
-      if (n % mult[q]) m = mult[q];
-    std::vector<uint32_t> w(n);
-    for (size_t i = 0; i < n; i++) w[(i * m) % n] = v[i];
-    v.swap(w);
-  };
+  /* Lanes inside a group are chosen for the LDS banks (plan.h "lane placement"): of every 16 consecutive lanes, two per
+   * class of the target slot (slot mod 8).  An op of class d with rank r among the group's ops of that class -- finishing
+   * ops first -- takes lane 2d + (r & 1) of 16-lane block r >> 1; what a class has beyond two per block fills the lanes
+   * other classes leave empty, class by class. */
   auto place_group = [&](std::vector<uint32_t> &fin, std::vector<uint32_t> &early) {
     /* (an empty group still takes its NRQ_PIPE-1 rows: early ops in the group before it may complete rows that the
      * group after it reads) */
-    spread(fin); spread(early);
     n_real_ops += (uint32_t)(fin.size() + early.size());
-    const size_t r0 = ops.size() / NRQ_ROW;
-    ops.insert(ops.end(), fin.begin(), fin.end());
-    const size_t fin_rows = (fin.size() + NRQ_ROW - 1) / NRQ_ROW;
-    ops.insert(ops.end(), early.begin(), early.end());
-    while (ops.size() % NRQ_ROW) ops.push_back(NRQ_NOP_AT(ops.size()));
-    while (ops.size() / NRQ_ROW < r0 + fin_rows + (NRQ_PIPE - 1u)) pad_rows(1);
+    uint32_t cf[NRQ_LANE_CLASSES] = {0}, ct[NRQ_LANE_CLASSES] = {0};
+    for (uint32_t w : fin) { cf[nrq_op_class(w)]++; ct[nrq_op_class(w)]++; }
+    for (uint32_t w : early) ct[nrq_op_class(w)]++;
+    const uint32_t span = nrq_group_span((uint32_t)(fin.size() + early.size()), cf);
+    const size_t at = ops.size();
+    pad_rows(span);
+    uint32_t rank[NRQ_LANE_CLASSES] = {0};
+    for (int part = 0; part < 2; part++)
+      for (uint32_t w : part ? early : fin) {
+        const uint32_t d = nrq_op_class(w);
+        ops[at + nrq_lane_place(span, ct, d, rank[d]++)] = w;
+      }
   };
   {
     /* group of an op dst <- src: the dst's level if src sits on the level right below (a "finishing" op), else any
@@ -551,8 +548,12 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   hd.nrows = op_rows; hd.pipe = NRQ_PIPE; hd.wpr = wpr;
   hd.npiv_pad = (npiv + 63u) & ~63u;
   hd.n_xor_ops = n_real_ops;
-  hd.off_ops = A.reserve((uint32_t)(ops.size() * 4));
-  memcpy(A.at<uint8_t>(hd.off_ops), ops.data(), ops.size() * 4);
+  { /* the stream goes out quad-interleaved (plan.h: NRQ_OP_INDEX), whole quads of rows */
+    while ((ops.size() / NRQ_ROW) % 4u) pad_rows(1);
+    hd.off_ops = A.reserve((uint32_t)(ops.size() * 4));
+    uint32_t *out = A.at<uint32_t>(hd.off_ops);
+    for (size_t i = 0; i < ops.size(); i++) out[NRQ_OP_INDEX(i / NRQ_ROW, i % NRQ_ROW)] = ops[i];
+  }
   hd.off_pivslot = A.reserve(npiv * 2);
   memcpy(A.at<uint8_t>(hd.off_pivslot), pivslot.data(), (size_t)npiv * 2);
   hd.off_pivcol = A.reserve(npiv * 2);

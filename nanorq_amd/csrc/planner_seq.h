@@ -11,8 +11,12 @@
  *                         on 2-byte strips of the bit rows, a workgroup per strip), the HDPC fold over the pivots and the
  *                         transposition of W are parallel work and take 40 % of a one-workgroup planner at K'=56403, so many
  *                         workgroups do them between the two parts (pl_shared travels through the block's workspace)
- * and provides `PlanCtx c`.  Every value that steers control flow is read from workgroup-shared state
- * right after a barrier, so all threads take the same path.
+ *     PL_STEER_SYNC       a workgroup barrier (nothing in the emulator)
+ * and provides `PlanCtx c`.  Every value that steers control flow is read from workgroup-shared state right after a
+ * barrier -- and where the phase that follows may CHANGE that value (peeling counts, `best`, `status`), every thread
+ * reads it into a local first and PL_STEER_SYNC separates the reads from that phase: without it a wave that is late
+ * to the read sees what an early wave has already written, takes the other branch, and the workgroup's barriers pair
+ * up across different phases from there on (seen as rare corrupt plans with four waves, every fifth plan with sixteen).
  */
 {
   pl_shared *sh_ = c.sh;
@@ -30,6 +34,7 @@
     for (;;) {
       /* (one LDS round trip for the three words, not one per test: a round is a chain of such trips) */
       const uint32_t st_ = sh_->status, nv_ = sh_->nV, nq_ = sh_->nq[rd_ & 1u];
+      PL_STEER_SYNC; /* (pl_round_claim lowers nV and may raise status) */
       if (st_ != 0 || nv_ == 0 || rd_ >= guard_max) break;
       if (nq_ > 0) {
         PL_PHASE1(pl_round_claim, rd_);
@@ -44,12 +49,18 @@
           while (!pl_peel_in_lds(c)) {
             PL_PHASE1(pl_inact_find, a_);
             PL_PHASE1(pl_inact_find_c, a_);
-            if (sh_->best != PL_NONE || sh_->ncand[0] == 0u) break;
+            const bool found_ = sh_->best != PL_NONE || sh_->ncand[0] == 0u;
+            PL_STEER_SYNC; /* (the next search writes best) */
+            if (found_) break;
           }
-          if (sh_->best == PL_NONE) PL_PHASE1(pl_inact_find_b, a_);
+          const bool scan_ = sh_->best == PL_NONE;
+          PL_STEER_SYNC; /* (pl_inact_find_b writes best) */
+          if (scan_) PL_PHASE1(pl_inact_find_b, a_);
           PL_PHASE1(pl_inact_apply_a, a_);
           PL_PHASE1(pl_inact_apply_b, a_);
-          if (sh_->tmp1 || sh_->status != 0 || sh_->nV == 0) break;
+          const bool last_ = sh_->tmp1 || sh_->status != 0 || sh_->nV == 0;
+          PL_STEER_SYNC;
+          if (last_) break;
         }
       }
       rd_++;
@@ -57,13 +68,17 @@
   }
   PL_PHASE(pl_lev_0);
   PL_PHASE(pl_lev_a);
-  if (sh_->status == 0 && sh_->nV == 0) {
+  const bool peeled_ = sh_->status == 0 && sh_->nV == 0;
+  PL_STEER_SYNC; /* (later phases raise status when a capacity is exceeded) */
+  if (peeled_) {
     PL_PHASE(pl_lev_b);
     PL_PHASE(pl_low_a);
     PL_PHASE(pl_low_b);
   }
   } /* PL_SEG != 2 */
-  if (sh_->status == 0 && sh_->nV == 0) {
+  const uint32_t st2_ = sh_->status, nv2_ = sh_->nV;
+  PL_STEER_SYNC;
+  if (st2_ == 0 && nv2_ == 0) {
     if (PL_SEG != 2) {
     PL_PHASE(pl_w_init);
     PL_PHASE(pl_w_init_b);
@@ -71,11 +86,17 @@
     PL_PHASE(pl_ops_layout);
     PL_PHASE(pl_ops_clear);
     PL_PHASE(pl_ops_emit);
+#ifdef NRQ_PLAN_SELFCHECK
+    PL_PHASE(pl_ops_check_a);
+    PL_PHASE(pl_ops_check_b);
+    PL_PHASE(pl_ops_check_c);
+#endif
     /* W = X^-1 * A_U and the leftover rows' reduced coefficients: the op stream run on bit rows -- on strips of
      * them in LDS by the solve kernel's row pipeline (PL_WFAST_RUN: wave 0 only; defined by the includer),
      * or, when no strip width fits, level by level on the HBM rows */
     if (PL_SEG == 0) { /* (a segmented run leaves the W pass to nrq_wpass_kernel: one workgroup per 2-byte strip of the W rows) */
       const uint32_t wb_ = sh_->status == 0 ? pl_wfast_wb(c) : 0u;
+      PL_STEER_SYNC;
       if (wb_) {
         PL_PHASE(pl_wfast_spill);
         const uint32_t ns_ = (sh_->wpr * 4u + wb_ - 1u) / wb_;
@@ -114,21 +135,28 @@
     for (uint32_t try_ = 0; try_ <= PL_EXTRA_ROWS + 1u; try_++) {
       PL_PHASE(pl_dense_a);
       PL_PHASE(pl_dense_b);
-      if (sh_->status == 0 && sh_->dense_ok) {
-        const uint32_t nf_ = sh_->nfree;
+      const bool solve_ = sh_->status == 0 && sh_->dense_ok;
+      const uint32_t nf_ = sh_->nfree;
+      PL_STEER_SYNC;
+      if (solve_) {
         for (uint32_t f_ = 0; f_ < nf_; f_++) {
           PL_PHASE1(pl_dense_step_a, f_);
           PL_PHASE1(pl_dense_step_b, f_);
         }
       }
-      if (sh_->status != 0 || sh_->dense_ok) break;
+      const bool done_ = sh_->status != 0 || sh_->dense_ok;
+      PL_STEER_SYNC; /* (pl_extra_a may raise status) */
+      if (done_) break;
       PL_PHASE(pl_extra_a);
-      if (sh_->status != 0) break;
+      const bool stop_ = sh_->status != 0;
+      PL_STEER_SYNC;
+      if (stop_) break;
       PL_PHASE(pl_extra_b);
       PL_PHASE(pl_extra_c);
       PL_PHASE(pl_extra_d);
-      if (sh_->xcol != PL_NONE) {
-        const uint32_t xc_ = sh_->xcol;
+      const uint32_t xc_ = sh_->xcol;
+      PL_STEER_SYNC;
+      if (xc_ != PL_NONE) {
         PL_PHASE1(pl_gj_a, xc_);
         PL_PHASE1(pl_gj_b, xc_);
       }
@@ -141,7 +169,7 @@
     PL_PHASE(pl_final_b);
     PL_PHASE(pl_final_c);
     } /* PL_SEG != 1 */
-  } else if (sh_->status == 0 && PL_SEG != 1) {
+  } else if (st2_ == 0 && PL_SEG != 1) {
     PL_PHASE(pl_mark_failed); /* peeling did not terminate: report the block as undecodable */
   }
   if (PL_SEG != 1) {

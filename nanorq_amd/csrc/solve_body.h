@@ -350,46 +350,102 @@ template <int WB> struct GroupSrc { /* where the rows of one line group of one b
   uint32_t lsub;                  /* log2 of the strips the group has (a whole line: 128/WB; fewer when work is scarce) */
 };
 /* (G > 1: a unit is moved by the G lanes of a virtual thread p of np; `sub` is the lane's 16-byte column of the wide strip) */
-template <int WB, int G = 1> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
+template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
                                        uint32_t p, uint32_t np, uint32_t sub = 0) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u; /* unit u = (row u >> lsub, piece u & pmask) */
 #ifndef NRQ_GATHER_PB
 #define NRQ_GATHER_PB 4
 #endif
-  constexpr int PB = NRQ_GATHER_PB; /* requests in flight per thread: few -- a deep queue of gather requests in the CU's
+  constexpr int PB = NRQ_GATHER_PB; /* requests in flight per thread and stage: few -- a deep queue of gather requests in the CU's
                                      * memory pipeline delays the op words wave 0 is waiting for */
+  if constexpr (!PIPELINED) { /* the register-lean form (the 256- and 64-thread workgroups: 96-128 registers per thread) */
   for (uint32_t base = u0 + p; base < u1; base += PB * np) {
-    uint32_t s[PB];
-    SV<WB> v[PB];
-#pragma unroll
-    for (int q = 0; q < PB; q++) {
-      const uint32_t u = base + (uint32_t)q * np;
-      s[q] = u < u1 ? g.rowsrc[u >> lsub] : NRQ_ROW_ZERO;
-    }
-#pragma unroll
-    for (int q = 0; q < PB; q++) {
-      const uint32_t u = base + (uint32_t)q * np, strip = g.strip0 + (u & pmask);
-      v[q] = sv_zero<WB>();
-      if (s[q] != NRQ_ROW_ZERO && strip < g.nstrips) {
-        const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? g.rep + (size_t)(s[q] & 0x7FFFFFFFu) * g.T : g.src + (size_t)s[q] * g.T;
-        if constexpr (G == 1) {
-          const uint32_t rem = g.T - strip * WB;
-          v[q] = g_get_stream<WB>(b + (size_t)strip * WB, rem < (uint32_t)WB ? rem : (uint32_t)WB);
-        } else {
-          const uint32_t at = strip * (WB * G) + sub * WB, rem = at < g.T ? g.T - at : 0u;
-          if (rem) v[q] = g_get_stream<WB>(b + at, rem < (uint32_t)WB ? rem : (uint32_t)WB);
+      uint32_t s[PB];
+      SV<WB> v[PB];
+  #pragma unroll
+      for (int q = 0; q < PB; q++) {
+        const uint32_t u = base + (uint32_t)q * np;
+        s[q] = u < u1 ? g.rowsrc[u >> lsub] : NRQ_ROW_ZERO;
+      }
+  #pragma unroll
+      for (int q = 0; q < PB; q++) {
+        const uint32_t u = base + (uint32_t)q * np, strip = g.strip0 + (u & pmask);
+        v[q] = sv_zero<WB>();
+        if (s[q] != NRQ_ROW_ZERO && strip < g.nstrips) {
+          const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? g.rep + (size_t)(s[q] & 0x7FFFFFFFu) * g.T : g.src + (size_t)s[q] * g.T;
+          if constexpr (G == 1) {
+            const uint32_t rem = g.T - strip * WB;
+            v[q] = g_get_stream<WB>(b + (size_t)strip * WB, rem < (uint32_t)WB ? rem : (uint32_t)WB);
+          } else {
+            const uint32_t at = strip * (WB * G) + sub * WB, rem = at < g.T ? g.T - at : 0u;
+            if (rem) v[q] = g_get_stream<WB>(b + at, rem < (uint32_t)WB ? rem : (uint32_t)WB);
+          }
         }
+      }
+  #pragma unroll
+      for (int q = 0; q < PB; q++) {
+        const uint32_t u = base + (uint32_t)q * np;
+        if (u < u1) g_put_stream<WB>(stage + (size_t)(u & pmask) * stage_stride + (size_t)(u >> lsub) * (WB * G) + sub * WB, WB, v[q]);
+      }
+    }
+    return;
+  }
+  /* Three stages, each a trip to memory (row map -> symbol piece -> staging buffer), run as a software pipeline: the row
+   * map entries of trip t + 1 and the pieces of trip t are requested before the pieces of trip t - 1 are stored, so a trip
+   * costs one memory latency, not three in a row (vector memory operations of a wave complete in order: waiting for a
+   * trip's loads right after its stores waits for the stores too). */
+  auto unit_of = [&](uint32_t base, int q) { return base + (uint32_t)q * np; };
+  auto fetch = [&](uint32_t u, uint32_t src) {
+    const uint32_t strip = g.strip0 + (u & pmask);
+    SV<WB> v = sv_zero<WB>();
+    if (u < u1 && src != NRQ_ROW_ZERO && strip < g.nstrips) {
+      const NRQ_GAS uint8_t *b = (src & NRQ_ROW_REP) ? g.rep + (size_t)(src & 0x7FFFFFFFu) * g.T : g.src + (size_t)src * g.T;
+      if constexpr (G == 1) {
+        const uint32_t rem = g.T - strip * WB;
+        v = g_get_stream<WB>(b + (size_t)strip * WB, rem < (uint32_t)WB ? rem : (uint32_t)WB);
+      } else {
+        const uint32_t at = strip * (WB * G) + sub * WB, rem = at < g.T ? g.T - at : 0u;
+        if (rem) v = g_get_stream<WB>(b + at, rem < (uint32_t)WB ? rem : (uint32_t)WB);
+      }
+    }
+    return v;
+  };
+  const uint32_t first = u0 + p, step = (uint32_t)PB * np;
+  if (first >= u1) return;
+  uint32_t s_cur[PB], s_nxt[PB];
+  SV<WB> v_prev[PB], v_cur[PB];
+#pragma unroll
+  for (int q = 0; q < PB; q++) { const uint32_t u = unit_of(first, q); s_cur[q] = u < u1 ? g.rowsrc[u >> lsub] : NRQ_ROW_ZERO; }
+  uint32_t prev = 0; /* base of the trip whose pieces are in v_prev (none yet) */
+  bool have_prev = false;
+  for (uint32_t base = first; base < u1; base += step) {
+#pragma unroll
+    for (int q = 0; q < PB; q++) { const uint32_t u = unit_of(base + step, q); s_nxt[q] = u < u1 ? g.rowsrc[u >> lsub] : NRQ_ROW_ZERO; }
+#pragma unroll
+    for (int q = 0; q < PB; q++) v_cur[q] = fetch(unit_of(base, q), s_cur[q]);
+    if (have_prev) {
+#pragma unroll
+      for (int q = 0; q < PB; q++) {
+        const uint32_t u = unit_of(prev, q);
+        if (u < u1) g_put_stream<WB>(stage + (size_t)(u & pmask) * stage_stride + (size_t)(u >> lsub) * (WB * G) + sub * WB, WB, v_prev[q]);
       }
     }
 #pragma unroll
-    for (int q = 0; q < PB; q++) {
-      const uint32_t u = base + (uint32_t)q * np;
-      if (u < u1) g_put_stream<WB>(stage + (size_t)(u & pmask) * stage_stride + (size_t)(u >> lsub) * (WB * G) + sub * WB, WB, v[q]);
-    }
+    for (int q = 0; q < PB; q++) { v_prev[q] = v_cur[q]; s_cur[q] = s_nxt[q]; }
+    prev = base;
+    have_prev = true;
+  }
+#pragma unroll
+  for (int q = 0; q < PB; q++) {
+    const uint32_t u = unit_of(prev, q);
+    if (u < u1) g_put_stream<WB>(stage + (size_t)(u & pmask) * stage_stride + (size_t)(u >> lsub) * (WB * G) + sub * WB, WB, v_prev[q]);
   }
 }
+#ifndef NRQ_COMMIT_PB
+#define NRQ_COMMIT_PB 4
+#endif
 template <int WB, int G = 1> SB_HD void pf_commit(const StripCtx<WB, G> &c, const NRQ_GAS uint8_t *stage, uint32_t r0, uint32_t tid, uint32_t nt) {
-  constexpr int PB = 4;
+  constexpr int PB = NRQ_COMMIT_PB;
   const uint32_t M = c.h->M;
   for (uint32_t base = r0 + tid; base < M; base += PB * nt) {
     SV<WB> v[PB];
@@ -452,87 +508,84 @@ template <int WB> __device__ __forceinline__ typename RowVal<WB>::type ph_row_re
   if constexpr (WB == 2) return *NRQ_LDSP(uint16_t, a);
   else return *NRQ_LDSP(typename RowVal<WB>::type, a);
 }
-template <int WB> __device__ __forceinline__ void ph_row_apply(const StripCtx<WB> &, uint32_t op, typename RowVal<WB>::type v) {
-  const uint32_t a = row_addr_lo<WB>(op);
-  if constexpr (WB == 16) {
+template <int WB, class V> __device__ __forceinline__ void row_apply_at(uint32_t a, V v) { /* LDS bytes at a ^= v (V: the whole strip, or half of it) */
+  if constexpr (sizeof(V) == 16) {
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
     const u2 lo = {v.x, v.y}, hi = {v.z, v.w};
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a + 8u), __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else if constexpr (WB == 8) {
+  } else if constexpr (sizeof(V) == 8) {
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else if constexpr (WB == 4) {
+  } else if constexpr (WB >= 4) {
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else {
+  } else { /* 2-byte slots: the halfword inside its dword */
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a & ~3u), v << ((a & 2u) * 8u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
+template <int WB> __device__ __forceinline__ void ph_row_apply(const StripCtx<WB> &, uint32_t op, typename RowVal<WB>::type v) {
+  row_apply_at<WB, typename RowVal<WB>::type>(row_addr_lo<WB>(op), v);
+}
 template <int WB> __device__ __forceinline__ typename RowVal<WB>::type row_zero() { typename RowVal<WB>::type z = {}; return z; }
 /* The row pipeline itself, run by ONE wave (lane = 0..63) on the LDS image that starts at LDS address 0: step q
- * applies row q-NRQ_PIPE and then reads the sources of row q.  Op words live in a ring of NRQ_RING fixed
- * registers, each reloaded (NRQ_RING rows ahead) right after its row has been applied -- no hand-over between
- * registers, so the loads stay outstanding across the LDS work.  The ring starts as the NRQ_RING all-NOP rows the
- * stream begins with; the stream is padded (NRQ_PAD_ROWS) so that every fetch is in bounds.  Used by the solve
- * kernel on symbol strips and by the planner kernel on strips of the W bit rows. */
-template <int WB> __device__ __forceinline__ void fwd_rows(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
-  constexpr uint32_t P = NRQ_PIPE, NS = NRQ_PIPE + 1u, U = NRQ_RING;
-  static_assert(U % NS == 0, "ring must be a multiple of the value sets");
-  const StripCtx<WB> none{};
-  const NRQ_GAS uint32_t *nxt = ops + lane;
-  uint32_t o[U];
-  typename RowVal<WB>::type v[NS];
-#pragma unroll
-  for (uint32_t k = 0; k < U; k++) o[k] = NRQ_NOP_AT(lane);
-#pragma unroll
-  for (uint32_t k = 0; k < NS; k++) v[k] = row_zero<WB>();
-  for (uint32_t base = 0; base < nrows + P; base += U, nxt += U * NRQ_ROW) {
-#pragma unroll
-    for (uint32_t k = 0; k < U; k++) {
-      const uint32_t j = (k + U - P) % U; /* ring slot of row q - P */
-      ph_row_apply<WB>(none, o[j], v[(k + NS - P) % NS]);
-      o[j] = nxt[(k + U - P) * NRQ_ROW];
-      v[k % NS] = ph_row_read<WB>(none, o[k]);
-    }
-  }
-}
-/* The same pipeline on HALF of the strip width (bytes [OFF, OFF + WB/2) of every slot): the solve kernel runs two of
- * them on two waves -- byte columns are independent, so the two never need to meet -- because a row costs a single
- * wave ~63 clocks of instruction issue against ~44 of LDS time. */
-template <int WB> struct HalfVal;
-template <> struct HalfVal<16> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
-template <> struct HalfVal<8> { typedef uint32_t type; };
-template <int WB, int OFF> __device__ __forceinline__ void fwd_rows_half(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
-  static_assert(WB == 16 || WB == 8, "half-width pipeline: 16- and 8-byte strips only");
-  constexpr uint32_t P = NRQ_PIPE, NS = NRQ_PIPE + 1u, U = NRQ_RING;
-  typedef typename HalfVal<WB>::type V;
-  const NRQ_GAS uint32_t *nxt = ops + lane;
+ * applies row q-NRQ_PIPE and then reads the sources of row q.  Op words live in a ring of U fixed registers, a quad of
+ * four rows per 16-byte load (plan.h: the stream is quad-interleaved), each quad reloaded (U rows ahead) right after its
+ * last row has been applied -- no hand-over between registers, so the loads stay outstanding across the LDS work.  The
+ * ring is primed with the stream's first U-4 rows; its last quad starts as padding (what the steady state has there at
+ * the top of a trip: rows already read, about to be applied and replaced).  The stream is padded (NRQ_PAD_ROWS) so that
+ * every fetch is in bounds.  Used by the solve kernel on symbol strips and by the planner kernels on strips of the W bit rows. */
+typedef uint32_t OpQuad __attribute__((ext_vector_type(4)));
+template <int WB, int OFF, class V, uint32_t U> __device__ __forceinline__ void fwd_rows_impl(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
+  constexpr uint32_t P = NRQ_PIPE, NS = NRQ_PIPE + 1u, NQ = U / 4u;
+  static_assert(U % NS == 0 && U % 4u == 0 && P <= 4u && U <= NRQ_RING_MAX, "ring: whole quads, whole value sets");
+  const NRQ_GAS OpQuad *nxt = reinterpret_cast<const NRQ_GAS OpQuad *>(ops) + lane; /* quad g of this lane: nxt[g * NRQ_ROW] */
   uint32_t o[U];
   V v[NS];
 #pragma unroll
-  for (uint32_t k = 0; k < U; k++) o[k] = NRQ_NOP_AT(lane);
+  for (uint32_t g = 0; g + 1u < NQ; g++) {
+    const OpQuad w = nxt[g * NRQ_ROW];
+    o[4u * g] = w.x; o[4u * g + 1u] = w.y; o[4u * g + 2u] = w.z; o[4u * g + 3u] = w.w;
+  }
+#pragma unroll
+  for (uint32_t k = U - 4u; k < U; k++) o[k] = NRQ_NOP_AT(lane);
 #pragma unroll
   for (uint32_t k = 0; k < NS; k++) { V z = {}; v[k] = z; }
-  for (uint32_t base = 0; base < nrows + P; base += U, nxt += U * NRQ_ROW) {
+  for (uint32_t base = 0; base < nrows + P; base += U, nxt += NQ * NRQ_ROW) {
 #pragma unroll
     for (uint32_t k = 0; k < U; k++) {
-      const uint32_t j = (k + U - P) % U;
-      {
-        const uint32_t a = row_addr_lo<WB>(o[j]) + (uint32_t)OFF;
-        const V x = v[(k + NS - P) % NS];
-        if constexpr (WB == 16)
-          __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else
-          __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t j = (k + U - P) % U; /* ring slot of row q - P */
+      /* both LDS addresses of the step are formed BEFORE the step waits for the LDS data it applies: a lone wave issues
+       * in order, and an address instruction between the wait and the LDS instruction that needs it puts its latency on
+       * the critical path of every row (tools/microbench/fwd_loop.hip: 51 -> 44 clocks per row) */
+      const uint32_t a_dst = row_addr_lo<WB>(o[j]) + (uint32_t)OFF, a_src = row_addr_hi<WB>(o[k]) + (uint32_t)OFF;
+      NRQ_SCHED_FENCE();
+      row_apply_at<WB, V>(a_dst, v[(k + NS - P) % NS]);
+      if constexpr (sizeof(V) == 4 && WB == 2 && OFF == 0) v[k % NS] = *NRQ_LDSP(uint16_t, a_src);
+      else v[k % NS] = *NRQ_LDSP(V, a_src);
+      if (j % 4u == 3u) { /* the quad's last row has been applied: the rows it holds next (this trip's if still ahead, k < P) */
+        const OpQuad w = nxt[(j / 4u + (j < k ? NQ : 0u)) * NRQ_ROW];
+        o[j - 3u] = w.x; o[j - 2u] = w.y; o[j - 1u] = w.z; o[j] = w.w;
       }
-      o[j] = nxt[(k + U - P) * NRQ_ROW];
-      v[k % NS] = *NRQ_LDSP(V, row_addr_hi<WB>(o[k]) + (uint32_t)OFF);
+      NRQ_SCHED_FENCE();
     }
   }
+}
+template <int WB, uint32_t U = NRQ_RING> __device__ __forceinline__ void fwd_rows(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
+  fwd_rows_impl<WB, 0, typename RowVal<WB>::type, U>(ops, nrows, lane);
+}
+/* The same pipeline on HALF of the strip width (bytes [OFF, OFF + WB/2) of every slot): the solve kernel runs two of
+ * them on two waves -- byte columns are independent, so the two never need to meet -- because a row costs a single
+ * wave ~45 clocks of instruction issue and LDS round trip against ~25 of LDS time. */
+template <int WB> struct HalfVal;
+template <> struct HalfVal<16> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct HalfVal<8> { typedef uint32_t type; };
+template <int WB, int OFF, uint32_t U = NRQ_RING> __device__ __forceinline__ void fwd_rows_half(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
+  static_assert(WB == 16 || WB == 8, "half-width pipeline: 16- and 8-byte strips only");
+  fwd_rows_impl<WB, OFF, typename HalfVal<WB>::type, U>(ops, nrows, lane);
 }
 /* The forward passes on a WIDE strip (G lanes per op, 16 bytes each; lane = op * G + sub): a row of 64 op slots is G
  * wave instructions of 64 / G ops.  Ops of one row never read what the row writes (plan.h), so a row is: fetch the G
  * source pieces, then the G XORs; instructions whose 64 / G ops are all padding are skipped (the planners fill a row from
- * the front, so a thin level costs one or two instructions, not a row), and so are the NRQ_RING lead rows.  For small
+ * the front, so a thin level costs one or two instructions, not a row).  For small
  * blocks: their levels hold a dozen ops, which leaves most of a 64-op row's lanes empty on a 16-byte strip. */
 template <int G> __device__ __forceinline__ void fwd_rows_wide(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
   constexpr uint32_t NV = NRQ_ROW / G, SH = G == 8 ? 7u : G == 4 ? 6u : G == 2 ? 5u : 4u; /* log2(16 * G) */
@@ -544,11 +597,12 @@ template <int G> __device__ __forceinline__ void fwd_rows_wide(const NRQ_GAS uin
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   const uint32_t vl = lane / G, subofs = (lane % G) * 16u;
-  const NRQ_GAS uint32_t *p = ops + vl;
-  const uint32_t s0 = (NRQ_RING < nrows ? NRQ_RING : nrows) * G, S = nrows * G; /* instructions; the lead rows are all padding */
+  /* instruction s = sub-instruction s % G of row s / G: the ops of lanes [(s % G) * NV, +NV) of the (quad-interleaved) stream */
+  auto word = [&](uint32_t sidx) { return ops[NRQ_OP_INDEX(sidx / G, (sidx % G) * NV + vl)]; };
+  const uint32_t s0 = 0u, S = nrows * G;
   uint32_t o[R];
 #pragma unroll
-  for (uint32_t k = 0; k < R; k++) o[k] = p[(size_t)(s0 + k) * NV];
+  for (uint32_t k = 0; k < R; k++) o[k] = word(s0 + k);
   /* software pipeline, one row deep: the sources of row r + 1 are fetched before row r is applied (rows that follow
    * each other never depend on each other, plan.h), so an LDS round trip is not exposed per row */
   bool live[2][G];
@@ -578,7 +632,7 @@ template <int G> __device__ __forceinline__ void fwd_rows_wide(const NRQ_GAS uin
           __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a + 8u), __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         oa[s] = o[g0 + s];
-        o[g0 + s] = p[(size_t)(base + g0 + s + R) * NV]; /* (the stream is padded by NRQ_PAD_ROWS: in bounds) */
+        o[g0 + s] = word(base + g0 + s + R); /* (the stream is padded by NRQ_PAD_ROWS: in bounds) */
       }
     }
   }
@@ -593,8 +647,8 @@ template <int WB> SB_HD void ph_row_apply(const StripCtx<WB> &c, uint32_t op, co
 template <int WB> SB_HD SV<WB> row_zero() { return sv_zero<WB>(); }
 /* host compilation pass of the kernels only: the row pipeline exists on the device (the CPU emulators have
  * their own row loops over ph_row_read / ph_row_apply) */
-template <int WB> SB_HD void fwd_rows(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
-template <int WB, int OFF> SB_HD void fwd_rows_half(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
+template <int WB, uint32_t U = NRQ_RING> SB_HD void fwd_rows(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
+template <int WB, int OFF, uint32_t U = NRQ_RING> SB_HD void fwd_rows_half(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
 #endif
 
 /* phase 3: HDPC right-hand sides R_h = SUM_c HDPC[h][c] * Y(c) over the peeled columns, through
@@ -977,22 +1031,62 @@ template <int WB> struct GroupDst {
   uint32_t lsub;
 };
 /* units [u0, u1) of the scatter, unit = (staged element, piece of the line): whole lines to the symbol rows */
-template <int WB, int G = 1> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
+template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
                                         uint32_t u1, uint32_t p, uint32_t np, uint32_t sub = 0) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u;
 #ifndef NRQ_SCATTER_PB
 #define NRQ_SCATTER_PB 4
 #endif
+#ifndef NRQ_SCATTER_PUT
+#define NRQ_SCATTER_PUT g_put
+#endif
   constexpr int PB = NRQ_SCATTER_PB;
+  if constexpr (!PIPELINED) {
   for (uint32_t base = u0 + p; base < u1; base += PB * np) {
-    SV<WB> v[PB];
-    uint32_t row[PB];
+      SV<WB> v[PB];
+      uint32_t row[PB];
+  #pragma unroll
+      for (int q = 0; q < PB; q++) {
+        const uint32_t u = base + (uint32_t)q * np, i = u >> lsub;
+        row[q] = (u < u1 && i >= g.ni) ? g.orow[i - g.ni] : i;
+        v[q] = u < u1 ? g_get_l2<WB>(ostage + (size_t)(u & pmask) * stage_stride + (size_t)i * (WB * G) + sub * WB) : sv_zero<WB>();
+      }
+  #pragma unroll
+      for (int q = 0; q < PB; q++) {
+        const uint32_t u = base + (uint32_t)q * np, i = u >> lsub, strip = g.strip0 + (u & pmask);
+        if (u >= u1 || strip >= g.nstrips) continue;
+        if constexpr (G == 1) {
+          const uint32_t rem = g.T - strip * WB;
+          NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB;
+          NRQ_SCATTER_PUT<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
+        } else {
+          const uint32_t at = strip * (WB * G) + sub * WB;
+          if (at >= g.T) continue;
+          const uint32_t rem = g.T - at;
+          NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + at;
+          NRQ_SCATTER_PUT<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
+        }
+      }
+    }
+    return;
+  }
+  /* two stages (staged element and its row number -> symbol row), pipelined like pf_gather: the loads of trip t + 1 are on
+   * their way before trip t is stored */
+  const uint32_t first = u0 + p, step = (uint32_t)PB * np;
+  if (first >= u1) return;
+  SV<WB> v[PB], vn[PB];
+  uint32_t row[PB], rown[PB];
+  auto load = [&](uint32_t base, SV<WB> (&vv)[PB], uint32_t (&rr)[PB]) {
 #pragma unroll
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np, i = u >> lsub;
-      row[q] = (u < u1 && i >= g.ni) ? g.orow[i - g.ni] : i;
-      v[q] = u < u1 ? g_get_l2<WB>(ostage + (size_t)(u & pmask) * stage_stride + (size_t)i * (WB * G) + sub * WB) : sv_zero<WB>();
+      rr[q] = (u < u1 && i >= g.ni) ? g.orow[i - g.ni] : i;
+      vv[q] = u < u1 ? g_get_l2<WB>(ostage + (size_t)(u & pmask) * stage_stride + (size_t)i * (WB * G) + sub * WB) : sv_zero<WB>();
     }
+  };
+  load(first, v, row);
+  for (uint32_t base = first; base < u1; base += step) {
+    if (base + step < u1) load(base + step, vn, rown);
 #pragma unroll
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np, i = u >> lsub, strip = g.strip0 + (u & pmask);
@@ -1000,15 +1094,17 @@ template <int WB, int G = 1> SB_HD void pf_scatter(const GroupDst<WB> &g, const 
       if constexpr (G == 1) {
         const uint32_t rem = g.T - strip * WB;
         NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB;
-        g_put<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
+        NRQ_SCATTER_PUT<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
       } else {
         const uint32_t at = strip * (WB * G) + sub * WB;
         if (at >= g.T) continue;
         const uint32_t rem = g.T - at;
         NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + at;
-        g_put<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
+        NRQ_SCATTER_PUT<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
       }
     }
+#pragma unroll
+    for (int q = 0; q < PB; q++) { v[q] = vn[q]; row[q] = rown[q]; }
   }
 }
 

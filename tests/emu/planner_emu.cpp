@@ -26,16 +26,14 @@ static void emu_wfast_run(PlanCtx &c, uint32_t wb) {
   std::vector<uint32_t> v((size_t)(P + 1) * NRQ_ROW * wpl);
   for (uint32_t q = 0; q < nrows + P; q++) {
     if (q >= P) {
-      const uint32_t *row = ops + (size_t)(q - P) * NRQ_ROW;
       const uint32_t *vr = &v[(size_t)((q - P) % (P + 1)) * NRQ_ROW * wpl];
       for (uint32_t l = 0; l < NRQ_ROW; l++)
-        for (uint32_t k = 0; k < wpl; k++) img[(size_t)(row[l] & 0xFFFFu) * wpl + k] ^= vr[l * wpl + k];
+        for (uint32_t k = 0; k < wpl; k++) img[(size_t)(ops[NRQ_OP_INDEX(q - P, l)] & 0xFFFFu) * wpl + k] ^= vr[l * wpl + k];
     }
     if (q < nrows) {
-      const uint32_t *row = ops + (size_t)q * NRQ_ROW;
       uint32_t *vr = &v[(size_t)(q % (P + 1)) * NRQ_ROW * wpl];
       for (uint32_t l = 0; l < NRQ_ROW; l++)
-        for (uint32_t k = 0; k < wpl; k++) vr[l * wpl + k] = img[(size_t)(row[l] >> 16) * wpl + k];
+        for (uint32_t k = 0; k < wpl; k++) vr[l * wpl + k] = img[(size_t)(ops[NRQ_OP_INDEX(q, l)] >> 16) * wpl + k];
     }
   }
 }
@@ -53,8 +51,8 @@ static void emu_wpass_strips(PlanCtx &c) {
     for (uint32_t e = 0; e < M + NRQ_SCRATCH; e++) img[e] = e >= NRQ_SCRATCH ? rows16[(size_t)(e - NRQ_SCRATCH) * wpr * 2u + strip] : 0;
     for (uint32_t r = 0; r < nrows; r++) {
       uint16_t v[NRQ_ROW];
-      for (uint32_t l = 0; l < NRQ_ROW; l++) v[l] = img[ops[(size_t)r * NRQ_ROW + l] >> 16];
-      for (uint32_t l = 0; l < NRQ_ROW; l++) img[ops[(size_t)r * NRQ_ROW + l] & 0xFFFFu] ^= v[l];
+      for (uint32_t l = 0; l < NRQ_ROW; l++) v[l] = img[ops[NRQ_OP_INDEX(r, l)] >> 16];
+      for (uint32_t l = 0; l < NRQ_ROW; l++) img[ops[NRQ_OP_INDEX(r, l)] & 0xFFFFu] ^= v[l];
     }
     for (uint32_t r = 0; r < M; r++) rows16[(size_t)r * wpr * 2u + strip] = img[r + NRQ_SCRATCH];
   }
@@ -94,6 +92,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
 #define PL_PHASE1(fn, a) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, (a), t_, PL_NT); } while (0)
 #define PL_WFAST_RUN(wb) emu_wfast_run(c, (wb))
 #define PL_SEG g_seg
+#define PL_STEER_SYNC do { } while (0)
   for (uint32_t pass_ = 0; pass_ < (g_split ? 2u : 1u); pass_++) {
     const uint32_t g_seg = g_split ? pass_ + 1u : 0u;
     if (g_seg == 2u) { /* what the helper kernels do between the parts */
@@ -112,6 +111,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
     if (g_seg == 1u) { PL_PHASE(pl_mh_ext_clear); PL_PHASE(pl_sh_save); memset(sh, 0xEE, shb); }
   }
 #undef PL_SEG
+#undef PL_STEER_SYNC
   if (g_split) pl_wt_fill(arena, reinterpret_cast<const uint32_t *>(work.data() + wl.wrows), 0u, 1u); /* = nrq_wt_kernel */
 #undef PL_PHASE
 #undef PL_PHASE1

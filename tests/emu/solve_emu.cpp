@@ -28,14 +28,12 @@ template <int WB> static bool emu_forward(const StripCtx<WB> &c) {
   std::vector<SV<WB>> v((size_t)(P + 1) * NRQ_ROW);
   for (uint32_t q = 0; q < nrows + P; q++) {
     if (q >= P) {
-      const uint32_t *row = ops + (size_t)(q - P) * NRQ_ROW;
       const SV<WB> *vr = &v[(size_t)((q - P) % (P + 1)) * NRQ_ROW];
-      for (uint32_t l = 0; l < NRQ_ROW; l++) ph_row_apply<WB>(c, row[l], vr[l]);
+      for (uint32_t l = 0; l < NRQ_ROW; l++) ph_row_apply<WB>(c, ops[NRQ_OP_INDEX(q - P, l)], vr[l]);
     }
     if (q < nrows) {
-      const uint32_t *row = ops + (size_t)q * NRQ_ROW;
       SV<WB> *vr = &v[(size_t)(q % (P + 1)) * NRQ_ROW];
-      for (uint32_t l = 0; l < NRQ_ROW; l++) vr[l] = ph_row_read<WB>(c, row[l]);
+      for (uint32_t l = 0; l < NRQ_ROW; l++) vr[l] = ph_row_read<WB>(c, ops[NRQ_OP_INDEX(q, l)]);
     }
   }
   return true;
@@ -67,7 +65,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
     g.M = c.h->M; g.T = T; g.strip0 = (strip / SPL) * SPL; g.nstrips = (T + WB - 1) / WB; g.lsub = __builtin_ctz(SPL);
     const uint32_t np = NT - NRQ_ROW, units = g.M * SPL, half = units / 2;
     for (uint32_t p = 0; p < np; p++) pf_gather<WB>(g, stage.data(), stride, 0, half, p, np);   /* in two portions, */
-    for (uint32_t p = 0; p < np; p++) pf_gather<WB>(g, stage.data(), stride, half, units, p, np); /* as the kernel does */
+    for (uint32_t p = 0; p < np; p++) pf_gather<WB, 1, true>(g, stage.data(), stride, half, units, p, np); /* as the kernel does */
     for (uint32_t t = 0; t < NT; t++) pf_commit<WB>(c, stage.data() + (size_t)(strip % SPL) * stride, 0u, t, NT);
     PHASE(ph_clear);
   }
@@ -93,7 +91,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
       g.ni = c.job->inter ? c.h->L : 0u; g.nout = c.job->nout; g.T = T; g.strip0 = (strip / SPL) * SPL; g.nstrips = nstrips; g.lsub = __builtin_ctz(SPL);
       const uint32_t np = NT - NRQ_ROW, units = ne * SPL, cut = units / 3;
       for (uint32_t p = 0; p < np; p++) pf_scatter<WB>(g, ostage.data(), ostride, 0, cut, p, np);
-      for (uint32_t p = 0; p < np; p++) pf_scatter<WB>(g, ostage.data(), ostride, cut, units, p, np);
+      for (uint32_t p = 0; p < np; p++) pf_scatter<WB, 1, true>(g, ostage.data(), ostride, cut, units, p, np);
     }
   }
 #undef PHASE

@@ -405,6 +405,27 @@ def test_wide_strips(G, orc, g):
         c.set_option("wide_g", 0)
 
 
+def test_five_workgroups_per_cu_variant(G, orc):
+    """The 256-thread solve workgroup also exists compiled for five per CU (96 registers per thread; option "small_waves4"
+    = 0 selects it where five strip images fit): same bytes as the oracle."""
+    c = G.ctx()
+    c.set_option("small_waves4", 0)
+    try:
+        for K, T, nblk, p in [(1000, 1280, 6, 0.06), (700, 333, 5, 0.1)]:
+            src = np.stack([payload(K * T, seed=K + 3, block=b).reshape(K, T) for b in range(nblk)])
+            esis = np.array([K, K + 1, K + 9, K + 500], np.uint32)
+            rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+            assert c.stats()["wg_waves_per_simd"] == 5
+            for b in (0, nblk - 1):
+                r_rep, r_int, _ = orc.encode_block(src[b], K, T, esis, want_inter=True)
+                assert np.array_equal(inter[b], r_int) and np.array_equal(rep[b], r_rep), (K, T, b)
+            st, out, src2 = _roundtrip(G, K, T, nblk, p, 0, seed=K + 11)
+            for b in range(nblk):
+                assert not st[b] or np.array_equal(out[b], src2[b]), (K, T, b)
+    finally:
+        c.set_option("small_waves4", 1)
+
+
 def test_segmented_planner_at_small_sizes(G, orc):
     """Big blocks are planned in two kernel parts with helper kernels between and after (W pass on 2-byte strips, HDPC
     fold, W transposition; planner_seq.h).  Forced here for sizes the oracle checks quickly: decoded data against the

@@ -33,8 +33,9 @@ template <int LAYOUT> __global__ __launch_bounds__(256) void k(const uint32_t *_
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const uint32_t ss = slots[(q * 2) * 64 + lane], dd = slots[(q * 2 + 1) * 64 + lane]; // both waves: the same ops
-    s[q] = LAYOUT == 0 ? ss * 16u + 8u * (h & 1u) : (h & 1u) * NSLOT * 8u + ss * 8u;
-    d[q] = LAYOUT == 0 ? dd * 16u + 8u * (h & 1u) : (h & 1u) * NSLOT * 8u + dd * 8u;
+    // LAYOUT 2: 16-byte slots whose halves are swapped when bit 4 of the slot number is set
+    s[q] = LAYOUT == 0 ? ss * 16u + 8u * (h & 1u) : LAYOUT == 1 ? (h & 1u) * NSLOT * 8u + ss * 8u : ss * 16u + 8u * ((h ^ (ss >> 4)) & 1u);
+    d[q] = LAYOUT == 0 ? dd * 16u + 8u * (h & 1u) : LAYOUT == 1 ? (h & 1u) * NSLOT * 8u + dd * 8u : dd * 16u + 8u * ((h ^ (dd >> 4)) & 1u);
   }
   unsigned long long t0 = clock64();
   unsigned long long v0 = rd(s[0]), v1 = rd(s[1]);
@@ -57,7 +58,7 @@ template <int LAYOUT> __global__ __launch_bounds__(256) void k(const uint32_t *_
 int main() {
   std::vector<uint32_t> hs(16 * 64);
   uint32_t x = 12345;
-  for (int conf = 0; conf < 7; conf++) {
+  for (int conf = 0; conf < 10; conf++) {
     for (size_t i = 0; i < hs.size(); i++) {
       x = x * 1664525u + 1013904223u;
       const uint32_t lane = i % 64, q = i / 64;
@@ -67,6 +68,13 @@ int main() {
       // 5: residues mod 32 distinct within each half of the wave; 6: at most two lanes per residue mod 64
       const uint32_t spread32 = ((x >> 8) % (NSLOT / 32)) * 32 + ((lane * 13 + q) & 31);
       const uint32_t pair2 = ((x >> 8) % (NSLOT / 64)) * 64 + (((lane >> 1) * 37 + q) & 63);
+      // 7: targets: every 16-lane group holds each residue mod 8 twice (sources random); 8: targets: every 16-lane group holds
+      // 16 different (residue mod 8, bit 4) classes; 9: as 8, and the sources of every 32-lane half hold 32 different residues mod 32
+      const uint32_t blk = (x >> 8) % (NSLOT / 32);
+      const uint32_t d7 = blk * 32 + ((x >> 3) & 3u) * 8 + (((lane & 15u) >> 1) + q) % 8;
+      const uint32_t d8 = blk * 32 + ((lane + q) & 7u) + 8u * ((x >> 5) & 1u) + 16u * (((lane >> 3) + q) & 1u);
+      const uint32_t s9 = blk * 32 + ((lane * 5 + q) & 31u);
+      if (conf >= 7) { hs[i] = conf == 7 ? (is_dst ? d7 : rnd) : conf == 8 ? (is_dst ? d8 : rnd) : (is_dst ? d8 : s9); continue; }
       hs[i] = conf == 0 ? rnd : conf == 1 ? (lane + q * 97) % NSLOT : conf == 2 ? spread : conf == 3 ? (is_dst ? spread : rnd)
               : conf == 4 ? (is_dst ? rnd : spread) : conf == 5 ? spread32 : pair2;
     }
@@ -74,12 +82,12 @@ int main() {
     hipMalloc(&d_s, hs.size() * 4); hipMalloc(&d_out, 64);
     hipMemcpy(d_s, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
     const uint32_t iters = 4000;
-    const char *cn[] = {"random", "linear", "spread", "dst-spr", "src-spr", "mod32", "2-way"};
+    const char *cn[] = {"random", "linear", "spread", "dst-spr", "src-spr", "mod32", "2-way", "dst8x2", "dst16", "d16+s32"};
 #define RUN(L, NW) do { hipFuncSetAttribute((const void *)k<L>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
     hipLaunchKernelGGL(k<L>, dim3(1), dim3(256), LDS_BYTES, 0, d_s, iters, d_out, NW); hipDeviceSynchronize(); \
     unsigned long long o[4]; hipMemcpy(o, d_out, 32, hipMemcpyDeviceToHost); \
-    printf("%-7s layout %s waves=%d  %6.1f clk per row\n", cn[conf], L ? "B (two 8-byte planes)" : "A (16-byte slots)   ", NW, (double)o[0] / iters / 8.0); } while (0)
-    RUN(0, 1); RUN(1, 1); RUN(0, 2); RUN(1, 2);
+    printf("%-7s layout %s waves=%d  %6.1f clk per row\n", cn[conf], L == 1 ? "B (two 8-byte planes)" : L == 2 ? "C (halves swapped by bit 4)" : "A (16-byte slots)   ", NW, (double)o[0] / iters / 8.0); } while (0)
+    RUN(0, 1); RUN(0, 2); RUN(2, 2);
     hipFree(d_s); hipFree(d_out);
   }
   return 0;
