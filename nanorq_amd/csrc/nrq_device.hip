@@ -1558,6 +1558,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "no_plan_split") t.no_plan_split = value != 0;
   else if (n == "plan_split_force") t.plan_split_force = value != 0;
   else if (n == "plan_small_state") t.plan_small_state = value != 0;
+  else if (n == "plan_big_wg") t.plan_big_wg = value != 0;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "solve_grid") t.solve_grid = (uint64_t)value;
   else if (n == "big_wg") t.big_wg = value != 0;

@@ -746,23 +746,33 @@ template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t t
  * per row, not per op, and lanes handed out in counter order. */
 SB_HD uint32_t pl_lev_words(const PlanCtx &c) { return c.sh->nlev + 2u; }
 #define PL_CLS_BYTES (2u * NRQ_LANE_CLASSES * 2u) /* per group: [part 0 = finishing, 1 = early][class] x u16 */
-/* where the class counters go: the dense stage's region when the peeling state has its own place in LDS (that region is
- * idle until the HDPC fold), else behind the column levels at the end of the aux region */
+/* Where the class counters go: the dense stage's region when the peeling state has its own place in LDS (that region is
+ * idle until the HDPC fold), else the aux region -- behind the column levels if those fit there too.  Big blocks (peeling
+ * state in the workspace, L * 2 bytes of levels beyond the LDS) keep the column levels in HBM: in the stack of open rows,
+ * dead once peeling is over -- a trip to L2 per entry, with PL_WU entries in flight, instead of the row walks and
+ * same-address global atomics of the path without counters. */
+SB_HD bool pl_collev_in_lds(const PlanCtx &c) {
+  const uint32_t bytes = pl_r16(pl_lev_words(c) * PL_CLS_BYTES), lv = pl_r16(c.p.L * 2u);
+  if (!c.aux_lds || lv > c.aux_bytes) return false;
+  if (c.dense_lds != c.aux_lds && bytes <= c.dense_bytes) return true; /* (the counters are elsewhere) */
+  return lv + bytes <= c.aux_bytes;
+}
 SB_HD uint8_t *pl_cls_place(const PlanCtx &c) {
   const uint32_t bytes = pl_r16(pl_lev_words(c) * PL_CLS_BYTES);
   if (!c.aux_lds) return nullptr;
   if (c.dense_lds != c.aux_lds && bytes <= c.dense_bytes) return c.dense_lds;
-  if (pl_r16(c.p.L * 2u) + bytes <= c.aux_bytes) return c.aux_lds + c.aux_bytes - bytes;
+  if (bytes <= c.aux_bytes) return c.aux_lds + c.aux_bytes - bytes; /* (the levels, if they are here too, lie at the start: pl_collev_in_lds) */
   return nullptr;
 }
 SB_HD uint16_t *pl_col_level(const PlanCtx &c) {
-  if (!c.aux_lds || pl_r16(c.p.L * 2u) > c.aux_bytes || !pl_cls_place(c)) return nullptr; /* (the level-by-level W pass stages its tables in the aux region later) */
-  return reinterpret_cast<uint16_t *>(c.aux_lds);
+  if (!pl_cls_place(c)) return nullptr;
+  if (pl_collev_in_lds(c)) return reinterpret_cast<uint16_t *>(c.aux_lds); /* (the level-by-level W pass stages its tables in the aux region later) */
+  return c.cand; /* Mcap >= L entries */
 }
 /* the class counters (nullptr: the HBM counters are in use) */
 SB_HD uint32_t *pl_cls(const PlanCtx &c) {
-  if (!pl_col_level(c)) return nullptr;
   uint32_t *q = reinterpret_cast<uint32_t *>(pl_cls_place(c));
+  if (!q) return nullptr;
   PL_ASSUME_LDS(q);
   return q;
 }

@@ -405,6 +405,23 @@ def test_wide_strips(G, orc, g):
         c.set_option("wide_g", 0)
 
 
+def test_planner_waves_stay_in_step(G):
+    """The planner chooses its next phase from workgroup-shared values; a wave that reads such a value after another wave has
+    already changed it (in the phase that follows) would take the other branch and the workgroup's barriers pair up across
+    different phases (planner_seq.h PL_STEER_SYNC).  Sixteen waves on small blocks made that happen in every fifth plan: here
+    600 plans with the 1024-thread planner forced -- every block planned on the device, decoded, equal to its source."""
+    c = G.ctx()
+    c.set_option("plan_big_wg", 1)
+    try:
+        K, T, nblk = 1024, 64, 600
+        st, out, src = _roundtrip(G, K, T, nblk, 0.05, 3, seed=808)
+        assert c.stats()["host_planned"] == 0
+        assert st.all()
+        assert np.array_equal(out, src)
+    finally:
+        c.set_option("plan_big_wg", 0)
+
+
 def test_five_workgroups_per_cu_variant(G, orc):
     """The 256-thread solve workgroup also exists compiled for five per CU (96 registers per thread; option "small_waves4"
     = 0 selects it where five strip images fit): same bytes as the oracle."""
