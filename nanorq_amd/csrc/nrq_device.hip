@@ -354,6 +354,12 @@ enum {
   pl_tag_pl_mh_load = 11,
   pl_tag_pl_mh_acc = 11,
   pl_tag_pl_gj_a = 12,
+  pl_tag_pl_gjp_init = 12,
+  pl_tag_pl_gjp_bid = 12,
+  pl_tag_pl_gjp_step = 12,
+  pl_tag_pl_gjp_comb = 12,
+  pl_tag_pl_gjp_stage = 12,
+  pl_tag_pl_gjp_apply = 12,
   pl_tag_pl_gj_b = 12,
   pl_tag_pl_bin_a = 13,
   pl_tag_pl_bin_b = 13,
@@ -409,11 +415,13 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
     __syncthreads(); PL_ACC(2); } while (0)
 #define PL_SEG seg
 #define PL_STEER_SYNC __syncthreads()
+#define PL_NT_ ((uint32_t)NT)
   if (seg == 2u) PL_PHASE(pl_sh_restore);
 #include "planner_seq.h"
   if (seg == 1u) { PL_PHASE(pl_mh_ext_clear); PL_PHASE(pl_sh_save); }
 #undef PL_SEG
 #undef PL_STEER_SYNC
+#undef PL_NT_
 #undef PL_PHASE
 #undef PL_PHASE1
 #undef PL_WFAST_RUN

@@ -132,6 +132,8 @@ typedef struct pl_shared {
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
   uint32_t pad_to_16[3];
   uint32_t bin_ct[NRQ_LANE_CLASSES]; /* ops of the GF(2) combination group per lane class of the target */
+  uint32_t gj_A[32];   /* blocked Gauss-Jordan: pivot row b at its pivot step = XOR of the panel-start rows gj_pr[k], k in gj_A[b] */
+  uint16_t gj_pr[32];  /* pivot row of bit b of the current panel (PL_NONE16: the column is free) */
   /* The arrays whose size depends on the launch follow the struct in LDS (pl_tail_*): frontier queues queue[2][qcap],
    * claim lists claim_l[qcap] / claim_c[qcap] (columns claimed this round: level + 1 of the pivot, column),
    * partial[nt] (per-thread scratch), gj_flag[lowcap] / gj_used[lowcap] (Gauss-Jordan: bit of the current column /
@@ -1538,6 +1540,117 @@ template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t xarg, uint32_t tid, uin
       c.red_x[sh->r2] = x;
       sh->r2++;
     }
+  }
+}
+
+/* ---- the same elimination, a panel of 32 columns (one word of every row) at a time ----
+ * A step of the loop above is a pass over the whole matrix and a barrier per column: 16 k clocks at K'=56403 (650 rows of
+ * 41 words), 634 columns.  Per panel w instead: (1) the 32 columns are eliminated on the panel word of every row alone
+ * (pl_gjp_bid / pl_gjp_step: same pivot rule, one word per row), while a mask per row records which pivots it absorbed;
+ * (2) pivot row b at its pivot step is a GF(2) combination gj_A[b] of the pivot rows as they were when the panel began
+ * (pl_gjp_comb), so every row ends as itself plus the panel-start pivot rows named by M_j = XOR of gj_A[s] over its mask;
+ * (3) those 32 rows are copied aside (HBM, a dead array; pl_gjp_stage) and ONE pass applies them to every other word of
+ * every row (pl_gjp_apply).  Same pivots, same result, one full pass per 32 columns.  Masks live in the frontier queues
+ * (idle since peeling).  The single-column steps above stay for the column a late extra row may add (planner_seq.h). */
+#define PL_NONE16 0xFFFFu
+#ifndef PL_GJ_BLOCK_MIN
+#define PL_GJ_BLOCK_MIN 4u /* words of the matrix per thread from which the panel form is used */
+#endif
+SB_HD uint32_t *pl_gj_mask(const PlanCtx &c) { uint32_t *q = reinterpret_cast<uint32_t *>(c.qmem); PL_ASSUME_LDS(q); return q; } /* [2 * qcap] words */
+/* (worth it when a pass over the matrix is more than a few words per thread: measured at K=8192 -- 216 rows of 15 words on
+ * 1024 threads -- the column-at-a-time loop with its single barrier per column is faster: 0.8 M against 1.2 M clocks) */
+SB_HD bool pl_gj_blocked(const PlanCtx &c, uint32_t nt) {
+  return c.sh->nlow * c.sh->rowlen >= PL_GJ_BLOCK_MIN * nt && c.sh->nlow + PL_EXTRA_ROWS <= 2u * c.qcap && 32u * c.sh->rowlen <= c.reccap;
+}
+template <int Z> SB_HD void pl_gjp_init(PlanCtx &c, uint32_t w, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  uint32_t *m = pl_gj_mask(c);
+  for (uint32_t j = tid; j < sh->nlow; j += nt) m[j] = 0;
+  if (tid < 32u) { sh->gj_pr[tid] = PL_NONE16; sh->gj_A[tid] = 0; }
+  if (tid == 0) sh->cand[0] = sh->cand[1] = PL_NONE;
+}
+/* column x = 32 w + b: the unused row with the lowest index that has it bids */
+template <int Z> SB_HD void pl_gjp_bid(PlanCtx &c, uint32_t x, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint32_t *Mb = pl_mb(c);
+  const uint32_t rowlen = sh->rowlen, w = x >> 5, b = x & 31u;
+  uint32_t best = PL_NONE; /* (one atomic per wave: hundreds of bids on one LDS word are served one after the other) */
+  for (uint32_t j = tid; j < sh->nlow; j += nt)
+    if (((Mb[(size_t)j * rowlen + w] >> b) & 1u) && !c.gj_used()[j] && j < best) best = j;
+  best = PL_WAVE_MIN(best);
+  if (best != PL_NONE && PL_WAVE_LEADER(tid)) PL_ATOM_MIN(&sh->cand[x & 1u], best);
+}
+/* ... and the column leaves the panel word of every other row that has it; one thread keeps the books (the bids of the
+ * next column go to the other slot, cleared here) */
+template <int Z> SB_HD void pl_gjp_step(PlanCtx &c, uint32_t x, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  uint32_t *Mb = pl_mb(c);
+  uint32_t *m = pl_gj_mask(c);
+  const uint32_t rowlen = sh->rowlen, w = x >> 5, b = x & 31u, pr = sh->cand[x & 1u];
+  if (pr != PL_NONE) {
+    const uint32_t pw = Mb[(size_t)pr * rowlen + w]; /* (the pivot row's own word does not change in this step) */
+    for (uint32_t j = tid; j < sh->nlow; j += nt) {
+      if (j == pr) continue;
+      const uint32_t v = Mb[(size_t)j * rowlen + w];
+      if ((v >> b) & 1u) { Mb[(size_t)j * rowlen + w] = v ^ pw; m[j] |= 1u << b; }
+    }
+  }
+  if (tid != 0) return;
+  sh->cand[(x & 1u) ^ 1u] = PL_NONE;
+  if (pr == PL_NONE) {
+    if (sh->nfree < NRQ_MAX_FREE) sh->freex[sh->nfree] = x;
+    sh->nfree++;
+  } else {
+    c.gj_used()[pr] = 1;
+    c.red_row[sh->r2] = pr;
+    c.red_x[sh->r2] = x;
+    sh->r2++;
+    sh->gj_pr[b] = (uint16_t)pr;
+  }
+}
+/* pivot row b when it was used = the panel-start pivot rows named by gj_A[b]: itself and what it had absorbed before */
+template <int Z> SB_HD void pl_gjp_comb(PlanCtx &c, uint32_t w, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (tid != 0) return;
+  const uint32_t *m = pl_gj_mask(c);
+  for (uint32_t b = 0; b < 32u; b++) {
+    if (sh->gj_pr[b] == PL_NONE16) continue;
+    uint32_t a = 1u << b, before = m[sh->gj_pr[b]] & ((1u << b) - 1u);
+    while (before) { const uint32_t s = (uint32_t)__builtin_ctz(before); before &= before - 1u; a ^= sh->gj_A[s]; }
+    sh->gj_A[b] = a;
+  }
+}
+/* the 32 panel-start pivot rows aside (words other than the panel's: those are final), every row's mask in terms of them */
+template <int Z> SB_HD void pl_gjp_stage(PlanCtx &c, uint32_t w, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint32_t *Mb = pl_mb(c);
+  uint32_t *m = pl_gj_mask(c);
+  const uint32_t rowlen = sh->rowlen;
+  uint32_t *P = c.rec_word; /* (dead since the op stream was emitted; 32 * rowlen <= 32 * 64 words) */
+  for (uint32_t e = tid; e < 32u * rowlen; e += nt) {
+    const uint32_t b = e / rowlen, wd = e - b * rowlen, pr = sh->gj_pr[b];
+    P[e] = pr == PL_NONE16 ? 0u : Mb[(size_t)pr * rowlen + wd];
+  }
+  for (uint32_t j = tid; j < sh->nlow; j += nt) {
+    uint32_t mj = m[j], M = 0;
+    while (mj) { const uint32_t s = (uint32_t)__builtin_ctz(mj); mj &= mj - 1u; M ^= sh->gj_A[s]; }
+    m[j] = M;
+  }
+}
+template <int Z> SB_HD void pl_gjp_apply(PlanCtx &c, uint32_t w, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  uint32_t *Mb = pl_mb(c);
+  const uint32_t *m = pl_gj_mask(c);
+  const uint32_t *P = c.rec_word;
+  const uint32_t rowlen = sh->rowlen, total = sh->nlow * rowlen;
+  const uint32_t inv = 0xFFFFFFFFu / rowlen + 1u; /* e / rowlen == mulhi(e, inv) for e < 2^16 * rowlen */
+  for (uint32_t e = tid; e < total; e += nt) {
+    const uint32_t j = (uint32_t)(((uint64_t)e * inv) >> 32), wd = e - j * rowlen;
+    uint32_t M = m[j];
+    if (wd == w || !M) continue;
+    uint32_t v = Mb[e];
+    while (M) { const uint32_t s = (uint32_t)__builtin_ctz(M); M &= M - 1u; v ^= P[s * rowlen + wd]; }
+    Mb[e] = v;
   }
 }
 

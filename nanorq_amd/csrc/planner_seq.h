@@ -12,6 +12,7 @@
  *                         transposition of W are parallel work and take 40 % of a one-workgroup planner at K'=56403, so many
  *                         workgroups do them between the two parts (pl_shared travels through the block's workspace)
  *     PL_STEER_SYNC       a workgroup barrier (nothing in the emulator)
+ *     PL_NT_              threads of the workgroup
  * and provides `PlanCtx c`.  Every value that steers control flow is read from workgroup-shared state right after a
  * barrier -- and where the phase that follows may CHANGE that value (peeling counts, `best`, `status`), every thread
  * reads it into a local first and PL_STEER_SYNC separates the reads from that phase: without it a wave that is late
@@ -125,10 +126,23 @@
     PL_PHASE(pl_low_c); /* (after the fold: Mb takes the place of the fold's tiles) */
     {
       const uint32_t u_ = c.p.L - sh_->npiv;
+      if (pl_gj_blocked(c, PL_NT_)) { /* a panel of 32 columns at a time: one pass over the matrix per panel, not per column */
+        for (uint32_t w_ = 0; w_ * 32u < u_; w_++) {
+          PL_PHASE1(pl_gjp_init, w_);
+          for (uint32_t x_ = w_ * 32u; x_ < u_ && x_ < w_ * 32u + 32u; x_++) {
+            PL_PHASE1(pl_gjp_bid, x_);
+            PL_PHASE1(pl_gjp_step, x_);
+          }
+          PL_PHASE1(pl_gjp_comb, w_);
+          PL_PHASE1(pl_gjp_stage, w_);
+          PL_PHASE1(pl_gjp_apply, w_);
+        }
+      } else {
       if (u_) PL_PHASE1(pl_gj_a, 0u);
       for (uint32_t x_ = 0; x_ < u_; x_++) {
         const uint32_t a_ = x_ | (x_ + 1u < u_ ? 0x80000000u : 0u); /* step B also prepares the next column */
         PL_PHASE1(pl_gj_b, a_);
+      }
       }
     }
     /* the free columns over GF(256); while that fails and the caller holds further symbols, add one row */

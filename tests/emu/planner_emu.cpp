@@ -9,6 +9,9 @@
 #include <cstring>
 #include <vector>
 
+static uint32_t g_gj_block_min = 4; /* words of the GF(2) matrix per thread from which the Gauss-Jordan runs in panels (kernel: 4) */
+#define PL_GJ_BLOCK_MIN g_gj_block_min
+extern "C" void emu_plan_set_gj_block_min(uint32_t v) { g_gj_block_min = v; }
 #include "../../nanorq_amd/csrc/planner_body.h"
 
 extern "C" uint32_t emu_plan_arena_bound(uint32_t K, const uint8_t *kc, uint32_t overhead_cap, uint32_t nlost_cap) {
@@ -93,6 +96,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
 #define PL_WFAST_RUN(wb) emu_wfast_run(c, (wb))
 #define PL_SEG g_seg
 #define PL_STEER_SYNC do { } while (0)
+#define PL_NT_ PL_NT
   for (uint32_t pass_ = 0; pass_ < (g_split ? 2u : 1u); pass_++) {
     const uint32_t g_seg = g_split ? pass_ + 1u : 0u;
     if (g_seg == 2u) { /* what the helper kernels do between the parts */
@@ -112,6 +116,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   }
 #undef PL_SEG
 #undef PL_STEER_SYNC
+#undef PL_NT_
   if (g_split) pl_wt_fill(arena, reinterpret_cast<const uint32_t *>(work.data() + wl.wrows), 0u, 1u); /* = nrq_wt_kernel */
 #undef PL_PHASE
 #undef PL_PHASE1

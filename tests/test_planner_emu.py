@@ -298,6 +298,27 @@ def test_device_planner_builds_encode_plans(orc, K, T, wb, lds):
     assert emu_device_plan(K, kc, [], [])[1]["status"] == 1
 
 
+@pytest.mark.parametrize("K,p,oh", [(300, 0.3, 0), (1024, 0.12, 0), (1024, 0.12, 2), (4000, 0.2, 0)])
+def test_blocked_gauss_jordan_gives_the_same_plan(K, p, oh):
+    """Big matrices run the GF(2) Gauss-Jordan a panel of 32 columns at a time (planner_body.h pl_gjp_*): same pivot rule, so
+    the plan must be the one the column-at-a-time loop produces, byte for byte -- forced here for sizes the CPU tier affords
+    (rank-deficient blocks included: they take spare symbols through the single-column steps afterwards)."""
+    from emu_support import pemu
+    kc = nanorq_amd.host_kconst(K)
+    for seed in range(3):
+        lost = loss_pattern(K, p, seed + 40)
+        rep_esis = np.arange(K, K + len(lost) + oh + 3, dtype=np.uint32)
+        pemu().emu_plan_set_gj_block_min(1 << 30)
+        try:
+            ref, ref_hdr = emu_device_plan(K, kc, lost, rep_esis, use=len(lost) + oh)
+            pemu().emu_plan_set_gj_block_min(0)
+            blk, blk_hdr = emu_device_plan(K, kc, lost, rep_esis, use=len(lost) + oh)
+        finally:
+            pemu().emu_plan_set_gj_block_min(4)
+        assert ref_hdr["status"] == blk_hdr["status"]
+        assert ref == blk
+
+
 def test_small_planner_state_reports_overflow(orc):
     """Capacities of the arrays behind pl_shared are the launch's choice; a block that does not fit them must come back
     as a capacity failure (the host planner then takes it), never as a wrong plan."""
