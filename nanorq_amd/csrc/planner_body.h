@@ -78,7 +78,20 @@ typedef struct nrq_planjob {
 #define PL_WAVE_MIN(v) __reduce_min_sync(~0ull, (unsigned int)(v))
 #define PL_WAVE_MAX(v) __reduce_max_sync(~0ull, (unsigned int)(v))
 #define PL_WAVE_LEADER(tid) (((tid) & 63u) == 0u)
+/* `take` of the wave's lanes each want the next value of the counter *p: one atomic for all of them (every lane must call it;
+ * lanes without `take` get garbage) -- thousands of single increments of one LDS word are served one after the other */
+__device__ __forceinline__ uint32_t pl_wave_take(uint32_t *p, bool take) {
+  const unsigned long long m = __ballot(take);
+  if (!m) return 0u;
+  const uint32_t lane = __lane_id(), leader = (uint32_t)__ffsll((long long)m) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(p, (uint32_t)__popcll(m));
+  base = __shfl(base, (int)leader);
+  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+#define PL_WAVE_TAKE(p, take) pl_wave_take((p), (take))
 #else
+#define PL_WAVE_TAKE(p, take) ((take) ? pl_add_((p), 1u) : 0u)
 #define PL_WAVE_MIN(v) (v)
 #define PL_WAVE_MAX(v) (v)
 #define PL_WAVE_LEADER(tid) true
@@ -859,7 +872,10 @@ SB_HD void pl_record_op(PlanCtx &c, uint32_t *cls, const uint16_t *collev, uint3
  * Ordinary rows: 8 lanes per row, sharing its entries.  The long LDPC rows (r < S): 64 lanes each (pl_w_init_b). */
 /* one entry (row r, column col) of the constraint matrix: an inactive column toggles its bit of the row's W row,
  * a pivot column other than the row's own is a row op */
-#define PL_WU 4u /* entries a thread has in flight: every step below is a trip to L2 or beyond (the planner's working
+#ifndef PL_WU
+#define PL_WU 4u
+#endif
+/* PL_WU: entries a thread has in flight: every step below is a trip to L2 or beyond (the planner's working
                    set, ~2 MB per block, does not stay in the 4 MB of L2 that 32 blocks share) */
 SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cls, const uint16_t *collev, const uint32_t (&r)[PL_WU],
                         const uint32_t (&col)[PL_WU], const bool (&use)[PL_WU], bool base) {
@@ -876,21 +892,21 @@ SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cls, const uint16_t *collev, const
     src[j] = (on[j] && (info[j] >> 30) == PL_ST_PIVOT) ? c.pivslot[info[j] & 0x3FFFFFFFu] : PL_NONE;
 #pragma unroll
   for (uint32_t j = 0; j < PL_WU; j++) {
-    if (!on[j]) continue;
     const uint32_t idx = info[j] & 0x3FFFFFFFu;
-    if ((info[j] >> 30) == PL_ST_INACT) PL_ATOM_XOR(&c.wrows[(size_t)r[j] * c.sh->wpr + (idx >> 5)], 1u << (idx & 31u));
-    else if (src[j] != r[j]) { /* (== : the row's own pivot column) */
-      const uint32_t lev = (rinfo[j] & PL_UNASSIGNED) ? c.sh->nlev : (rinfo[j] & PL_LEVEL_MASK);
-      const uint32_t g = pl_op_group(collev, lev, r[j], col[j]);
-      const uint32_t early = g == lev ? 0u : 0x80000000u;
-      const uint32_t word = NRQ_OP(r[j], src[j]);
-      const uint32_t at = pl_cls_take(cls, g, early ? 1u : 0u, nrq_op_class(word));
-      const uint32_t i = PL_ATOM_ADD(&c.sh->nrec, 1u);
-      if (i >= c.reccap) { (c.sh->fail_site = __LINE__, c.sh->status = PL_FAIL_CAPACITY); continue; }
-      c.rec_word[i] = word;
-      c.rec_idx[i] = early | at;
-      c.rec_g[i] = (uint16_t)g;
-    }
+    const bool inact = on[j] && (info[j] >> 30) == PL_ST_INACT;
+    const bool op = on[j] && !inact && src[j] != r[j]; /* (== : the row's own pivot column) */
+    if (inact) PL_ATOM_XOR(&c.wrows[(size_t)r[j] * c.sh->wpr + (idx >> 5)], 1u << (idx & 31u));
+    const uint32_t i = PL_WAVE_TAKE(&c.sh->nrec, op); /* (by the whole wave: see there) */
+    if (!op) continue;
+    const uint32_t lev = (rinfo[j] & PL_UNASSIGNED) ? c.sh->nlev : (rinfo[j] & PL_LEVEL_MASK);
+    const uint32_t g = pl_op_group(collev, lev, r[j], col[j]);
+    const uint32_t early = g == lev ? 0u : 0x80000000u;
+    const uint32_t word = NRQ_OP(r[j], src[j]);
+    const uint32_t at = pl_cls_take(cls, g, early ? 1u : 0u, nrq_op_class(word));
+    if (i >= c.reccap) { (c.sh->fail_site = __LINE__, c.sh->status = PL_FAIL_CAPACITY); continue; }
+    c.rec_word[i] = word;
+    c.rec_idx[i] = early | at;
+    c.rec_g[i] = (uint16_t)g;
   }
 }
 template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
