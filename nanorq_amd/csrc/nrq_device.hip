@@ -121,7 +121,13 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
                      NGW = NMV >= 6u ? NRQ_MOVER_WAVES : NMV >= 3u ? 2u : 1u, NSW = NMV >= 6u ? NRQ_MOVER_WAVES : NMV - NGW;
   static_assert(NMV >= 2u || NT == 64, "workgroup too small for the data movers");
   /* op-word ring of the forward wave(s), in rows: what the variant's register budget holds without spilling */
-  constexpr bool MPIPE = NT >= 512; /* software-pipelined data movers: where the registers allow (168 per thread) */
+#ifndef NRQ_PIPE_SMALL
+#define NRQ_PIPE_SMALL 1
+#endif
+  /* software-pipelined data movers where the registers allow: the 768-thread workgroup (168 per thread) and the 256-thread one
+   * built for four per CU (128; measured: K=1000 977 -> 1031 Gbit/s, K=2000 1085 -> 1174, K=3000 1034 -> 1137; the single-wave
+   * variant loses with them: K=100 340 -> 328) */
+  constexpr bool MPIPE = NT >= 512 || (NRQ_PIPE_SMALL && NT == 256 && WV == 4);
   constexpr uint32_t RU = NT >= 512 ? NRQ_BIG_RING : WV >= 5 ? NRQ_RING_5W : NRQ_RING;
   /* NT == 64: ONE wave solves the strip on its own (no mover waves: it gathers and scatters its portions itself after
    * the forward passes; barriers are free).  For images of a few KB -- K up to ~400 -- where a strip is a chain of
