@@ -955,6 +955,9 @@ template <int WB, int G = 1> SB_HD void ph_park(const StripCtx<WB, G> &c, uint32
  * (element i < L: intermediate symbol i, if the job wants them; then the nout generated symbols).  Results leave
  * for their rows in HBM a line group at a time (pf_scatter): written strip by strip, every 16-byte piece would be a
  * partial-line write of its own (measured: 3.7x the bytes at the HBM interface). */
+#ifndef NRQ_STORE_CHUNK
+#define NRQ_STORE_CHUNK 32u
+#endif
 template <int WB, int G = 1> SB_HD uint32_t out_elems(const nrq_job *job, const nrq_plan_hdr *h) { return (job->inter ? h->L : 0u) + job->nout; }
 template <int WB, int G = 1> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
   constexpr int STB = 8;
@@ -975,31 +978,29 @@ template <int WB, int G = 1> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_G
   }
   const NRQ_GAS uint32_t *cptr = gptr<uint32_t>(c.job->out_cptr);
   const NRQ_GAS uint16_t *osl = gptr<uint16_t>(c.job->out_slots);
-  /* two generated symbols per thread and trip (each step is a dependent trip to L2: list bounds, then the slot
-   * numbers 8 at a time, then the 8 strips from LDS) */
+  /* a generated symbol per thread and pass: list bounds, then ALL slot numbers of the list in one trip (an LT list has at most
+   * 30 + 3 entries: a chunk of NRQ_STORE_CHUNK covers it; eight at a time it was a chain of up to four dependent trips to L2
+   * per symbol, and a wave waited for its longest list), then the strips from LDS.  The bounds of the thread's next symbol
+   * are fetched meanwhile. */
   const uint32_t nout = c.job->nout;
-  for (uint32_t q0 = tid; q0 < nout; q0 += 2u * nt) {
-    const uint32_t q1 = q0 + nt;
-    const bool two = q1 < nout;
-    uint32_t e[2] = {cptr[q0], two ? cptr[q1] : 0u};
-    const uint32_t end[2] = {cptr[q0 + 1], two ? cptr[q1 + 1] : 0u};
-    SV<WB> acc[2] = {sv_zero<WB>(), sv_zero<WB>()};
-    while (e[0] < end[0] || e[1] < end[1]) {
-      uint32_t sl[2][8];
+  constexpr uint32_t CH = NRQ_STORE_CHUNK;
+  uint32_t e_n = 0, end_n = 0;
+  if (tid < nout) { e_n = cptr[tid]; end_n = cptr[tid + 1]; }
+  for (uint32_t q = tid; q < nout; q += nt) {
+    uint32_t e = e_n;
+    const uint32_t end = end_n;
+    if (q + nt < nout) { e_n = cptr[q + nt]; end_n = cptr[q + nt + 1]; }
+    SV<WB> acc = sv_zero<WB>();
+    while (e < end) {
+      uint32_t sl[CH];
 #pragma unroll
-      for (uint32_t j = 0; j < 2; j++)
+      for (uint32_t k = 0; k < CH; k++) sl[k] = e + k < end ? (uint32_t)osl[e + k] : NRQ_NOSLOT;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) sl[j][k] = e[j] + k < end[j] ? (uint32_t)osl[e[j] + k] : NRQ_NOSLOT;
-#pragma unroll
-      for (uint32_t j = 0; j < 2; j++) {
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++)
-          if (sl[j][k] != NRQ_NOSLOT) sv_xor<WB>(acc[j], lds_get<WB, G>(c.slots(), sl[j][k]));
-        e[j] += 8u;
-      }
+      for (uint32_t k = 0; k < CH; k++)
+        if (sl[k] != NRQ_NOSLOT) sv_xor<WB>(acc, lds_get<WB, G>(c.slots(), sl[k]));
+      e += CH;
     }
-    g_put_stream<WB>(ostage + (size_t)(ni + q0) * (WB * G), WB, acc[0]);
-    if (two) g_put_stream<WB>(ostage + (size_t)(ni + q1) * (WB * G), WB, acc[1]);
+    g_put_stream<WB>(ostage + (size_t)(ni + q) * (WB * G), WB, acc);
   }
 }
 /* phase 6b for the SPLIT solve of narrow strips (big blocks, nrq_device.hip): instead of back-substitution and results,
