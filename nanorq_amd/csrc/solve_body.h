@@ -677,6 +677,11 @@ template <int WB, int G = 1> SB_HD void ph_hdpc_reduce(const StripCtx<WB, G> &c,
   }
   if (any) lds_xor<WB, G>(c.slots(), c.h->S + hq, acc);
 }
+#ifndef NRQ_HDPC_COEF_ALL_NT
+#define NRQ_HDPC_COEF_ALL_NT 256u /* from this workgroup size on the H coefficients of the closing fold are loaded together (the 256-thread
+                                     * variant built for four per CU has the registers: K=1000 1062 -> 1102 Gbit/s, K=2000 1210 -> 1242;
+                                     * the single-wave variant gains nothing) */
+#endif
 template <int WB, int G = 1> SB_HD void ph_hdpc(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(c.kc);
   const NRQ_GAS uint8_t *Gm = gptr<uint8_t>(c.kc + kh->off_g); /* the HDPC block */
@@ -729,8 +734,8 @@ template <int WB, int G = 1> SB_HD void ph_hdpc(const StripCtx<WB, G> &c, uint32
     pw[0] = sv_xtime<WB>(g);
 #pragma unroll
     for (int k = 1; k < 8; k++) pw[k] = sv_xtime<WB>(pw[k - 1]);
-    if (nt >= 512u) { /* the big workgroup (168 registers per thread): the H coefficients loaded together, one trip to
-                       * L2 instead of one per HDPC row; the 256-thread variants have no registers to spare for it */
+    if (nt >= NRQ_HDPC_COEF_ALL_NT) { /* the H coefficients loaded together: one trip to L2 instead of one per HDPC row (the compiler may not
+                                       * move the next load above the LDS atomic of the term before) */
       uint32_t coef[16]; /* (H <= 16) */
 #pragma unroll
       for (uint32_t h = 0; h < 16; h++) coef[h] = h < H ? Gm[(size_t)h * n + b] : 0u;
