@@ -128,7 +128,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
    * built for four per CU (128; measured: K=1000 977 -> 1031 Gbit/s, K=2000 1085 -> 1174, K=3000 1034 -> 1137; the single-wave
    * variant loses with them: K=100 340 -> 328) */
   constexpr bool MPIPE = NT >= 512 || (NRQ_PIPE_SMALL && NT == 256 && WV == 4);
-  constexpr uint32_t RU = NT >= 512 ? NRQ_BIG_RING : WV >= 5 ? NRQ_RING_5W : NRQ_RING;
+#ifndef NRQ_RING_4W
+#define NRQ_RING_4W NRQ_RING
+#endif
+  constexpr uint32_t RU = NT >= 512 ? NRQ_BIG_RING : WV >= 5 ? NRQ_RING_5W : NRQ_RING_4W;
   /* NT == 64: ONE wave solves the strip on its own (no mover waves: it gathers and scatters its portions itself after
    * the forward passes; barriers are free).  For images of a few KB -- K up to ~400 -- where a strip is a chain of
    * short phases with little parallel work: 19-20 such workgroups share a CU instead of five 256-thread ones, i.e.
