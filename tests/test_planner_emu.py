@@ -319,6 +319,37 @@ def test_blocked_gauss_jordan_gives_the_same_plan(K, p, oh):
         assert ref == blk
 
 
+def _atomic_cycles_per_row(plan):
+    """LDS cycles of a row's 64-lane atomic under the bank model of plan.h "lane placement": four blocks of 16 contiguous lanes,
+    a block costs as many cycles as its busiest class (target slot mod 8) has different slots."""
+    ops = nanorq_amd.plan_ops(plan)
+    dst = (ops & 0xFFFF).astype(np.int64)
+    live = ((ops & 0xFFFF) >= 64).any(axis=1)
+    cost = []
+    for row in dst[live]:
+        c = 0
+        for g in range(4):
+            s = np.unique(row[16 * g:16 * g + 16])
+            c += np.bincount(s % 8, minlength=8).max()
+        cost.append(c)
+    return float(np.mean(cost))
+
+
+def test_lanes_are_placed_by_bank_class():
+    """Both planners place the ops of a level group two per bank class and 16-lane block (8 cycles per row at best; lanes in
+    arrival order cost ~16): host plan and emulated device plan of a decode."""
+    K = 3000
+    kc = nanorq_amd.host_kconst(K)
+    p = nanorq_amd.params(K)
+    host = nanorq_amd.host_plan(K, np.arange(p["Kp"], dtype=np.uint32), kc)
+    assert _atomic_cycles_per_row(host) < 11.0
+    lost = loss_pattern(K, 0.1, 77)
+    rep_esis = np.arange(K, K + len(lost) + 3, dtype=np.uint32)
+    dev, hdr = emu_device_plan(K, kc, lost, rep_esis, use=len(lost))
+    assert hdr["status"] == 0
+    assert _atomic_cycles_per_row(dev) < 11.0
+
+
 def test_small_planner_state_reports_overflow(orc):
     """Capacities of the arrays behind pl_shared are the launch's choice; a block that does not fit them must come back
     as a capacity failure (the host planner then takes it), never as a wrong plan."""
