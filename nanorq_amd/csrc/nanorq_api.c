@@ -192,6 +192,12 @@ static void mask_set(struct blockst *b, size_t id) {
   if (id < b->K && !((b->mask[w] >> (id % 32)) & 1u)) b->have++;
   b->mask[w] |= 1u << (id % 32);
 }
+static void mask_clear(struct blockst *b, size_t id) {
+  const size_t w = id / 32;
+  if (w >= b->mask_words || !((b->mask[w] >> (id % 32)) & 1u)) return;
+  b->mask[w] &= ~(1u << (id % 32));
+  if (id < b->K) b->have--;
+}
 static size_t mask_gaps(const struct blockst *b, size_t until) { /* zero bits below `until` (bitmask_gaps, bitmask.c:47-77) */
   if (until == b->K) return b->K - b->have;
   size_t set = 0, full = until / 32;
@@ -377,6 +383,7 @@ void nanorq_encoder_reset(nanorq *rq, uint8_t sbn) { /* nanorq.c:453-469 */
   b->nrep = 0;
   b->win_n = 0;
   b->have = 0;
+  if (b->dev) drop_device(b); /* a device-resident decoder block: its rows go back to the pool (the next packet batch allocates anew) */
   b->dev = b->dirty = false;
   if (b->mask) memset(b->mask, 0, b->mask_words * sizeof(uint32_t));
 }
@@ -566,7 +573,7 @@ static bool dev_put_row(nanorq *rq, struct blockst *b, void *d_row, const void *
   gpu_unlock();
   return ok;
 }
-static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, void **old_out); /* (below) */
+static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, size_t keep, void **old_out); /* (below) */
 
 int nanorq_decoder_add_symbol(nanorq *rq, void *data, uint32_t tag, struct ioctx *io) { /* nanorq.c:478-509 */
   uint8_t sbn = (uint8_t)(tag >> 24);
@@ -588,7 +595,7 @@ int nanorq_decoder_add_symbol(nanorq *rq, void *data, uint32_t tag, struct ioctx
     if (!rep_reserve_host(rq, b)) return NANORQ_SYM_ERR;
     if (b->dev) {
       void *old = NULL;
-      if (!dev_rep_reserve(rq, b, b->nrep + 1, &old)) return NANORQ_SYM_ERR;
+      if (!dev_rep_reserve(rq, b, b->nrep + 1, b->nrep, &old)) return NANORQ_SYM_ERR;
       const bool ok = dev_put_row(rq, b, (uint8_t *)b->d_rep + b->nrep * T, data); /* (waits for the upload stream: `old` is idle then) */
       if (old) { gpu_lock(); nrq_dev_free(ctx(), old); gpu_unlock(); }
       if (!ok) return NANORQ_SYM_ERR;
@@ -854,8 +861,8 @@ size_t nanorq_encode_range(nanorq *rq, void *data, uint32_t esi0, uint32_t n, ui
 }
 
 /* room for `need` repair symbols in a device-resident block's d_rep; an outgrown buffer is handed back through *old_out
- * (the caller frees it once the copy out of it -- enqueued on the upload stream -- is done) */
-static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, void **old_out) {
+ * (the caller frees it once the copy of its first `keep` symbols -- enqueued on the upload stream -- is done) */
+static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, size_t keep, void **old_out) {
   nrq_ctx *c = ctx();
   *old_out = NULL;
   if (need <= b->d_rep_cap) return true;
@@ -864,9 +871,9 @@ static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, void **o
   void *p = NULL;
   gpu_lock();
   bool ok = nrq_dev_alloc(c, nc * rq->T, &p) == 0;
-  if (ok && b->d_rep && b->nrep) ok = nrq_copy_on(c, 1, p, b->d_rep, b->nrep * rq->T) == 0;
+  if (ok && b->d_rep && keep) ok = nrq_copy_on(c, 1, p, b->d_rep, keep * rq->T) == 0;
   gpu_unlock();
-  if (!ok) return false;
+  if (!ok) { if (p) { gpu_lock(); nrq_dev_free(c, p); gpu_unlock(); } return false; }
   *old_out = b->d_rep;
   b->d_rep = p;
   b->d_rep_cap = nc;
@@ -895,15 +902,35 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
     }
     return added;
   }
+  /* Bookkeeping first, addresses afterwards: a repair symbol is recorded as (block, index in the block's repair rows) while
+   * the loop runs, and only when the batch's final repair count of every block is known is the block's d_rep grown -- ONCE,
+   * keeping the rows it held before the batch -- and the index turned into an address.  (Growing inside the loop left the
+   * addresses of the batch's earlier symbols pointing into the outgrown buffer.) */
   void *olds[NRQ_Z_MAX];
   unsigned nold = 0;
   uint32_t nput = 0;
+  size_t nrep0[NRQ_Z_MAX];                 /* repair symbols a touched block held before this batch */
+  uint8_t touched[NRQ_Z_MAX], newdev[NRQ_Z_MAX];
+  uint32_t *rix = malloc((size_t)n * sizeof(uint32_t)); /* per symbol: index of its repair row, or RIX_* */
+  enum { RIX_NONE = 0xFFFFFFFFu, RIX_SRC = 0xFFFFFFFEu };
+  if (!rix) { free(dst); dst = NULL; }
+  if (!dst) {
+    for (uint32_t k = 0; k < n; k++) {
+      const int r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * T), tags[k], io);
+      if (results) results[k] = r;
+      if (r == NANORQ_SYM_ADDED) added++;
+    }
+    return added;
+  }
+  memset(touched, 0, sizeof(touched));
+  memset(newdev, 0, sizeof(newdev));
   gpu_lock();
   for (uint32_t k = 0; k < n; k++) {
     const uint8_t sbn = (uint8_t)(tags[k] >> 24);
     const uint32_t esi = tags[k] & 0x00ffffffu;
     struct blockst *b = get_block(rq, sbn);
     int r = NANORQ_SYM_ADDED;
+    rix[k] = RIX_NONE;
     if (!b || esi > rq->max_esi) r = NANORQ_SYM_ERR;
     else if (mask_gaps(b, b->K) == 0) r = NANORQ_SYM_IGN;
     else if (mask_get(b, esi)) r = NANORQ_SYM_DUP;
@@ -912,19 +939,17 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
       r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * T), tags[k], io);
     } else {
       if (!b->dev) { /* first symbol of the block: it becomes device-resident */
-        if (nrq_dev_alloc(c, (size_t)b->K * T, &b->d_src) != 0 || nrq_memset_on(c, 1, b->d_src, 0, (size_t)b->K * T) != 0) r = NANORQ_SYM_ERR;
-        else b->dev = true;
+        if (!b->d_src && nrq_dev_alloc(c, (size_t)b->K * T, &b->d_src) != 0) r = NANORQ_SYM_ERR;
+        else if (nrq_memset_on(c, 1, b->d_src, 0, (size_t)b->K * T) != 0) r = NANORQ_SYM_ERR;
+        else { b->dev = true; newdev[sbn] = 1; }
       }
+      if (r == NANORQ_SYM_ADDED && !touched[sbn]) { touched[sbn] = 1; nrep0[sbn] = b->nrep; }
       if (r == NANORQ_SYM_ADDED && esi < b->K) {
-        dst[k] = (uint64_t)(uintptr_t)((uint8_t *)b->d_src + (size_t)esi * T);
-        b->dirty = true;
+        rix[k] = RIX_SRC;
       } else if (r == NANORQ_SYM_ADDED) {
-        void *old = NULL;
-        if (!rep_reserve_host(rq, b) || !dev_rep_reserve(rq, b, b->nrep + 1, &old)) r = NANORQ_SYM_ERR;
+        if (!rep_reserve_host(rq, b)) r = NANORQ_SYM_ERR;
         else {
-          if (old && nold < NRQ_Z_MAX) olds[nold++] = old;
-          else if (old) { nrq_stream_sync(c, 1); nrq_dev_free(c, old); }
-          dst[k] = (uint64_t)(uintptr_t)((uint8_t *)b->d_rep + b->nrep * T);
+          rix[k] = (uint32_t)b->nrep;
           b->rep_esi[b->nrep++] = esi;
         }
       }
@@ -933,21 +958,57 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
     if (results) results[k] = r;
     if (r == NANORQ_SYM_ADDED) added++;
   }
-  if (nput) {
+  bool ok = true;
+  /* every touched block's repair rows to their final size, then the addresses */
+  for (unsigned sbn = 0; sbn < NRQ_Z_MAX && ok; sbn++) {
+    struct blockst *b = touched[sbn] ? rq->blocks[sbn] : NULL;
+    if (!b || b->nrep == nrep0[sbn]) continue;
+    void *old = NULL;
+    ok = dev_rep_reserve(rq, b, b->nrep, nrep0[sbn], &old);
+    if (old) olds[nold++] = old; /* (at most one per block: nold <= NRQ_Z_MAX) */
+  }
+  if (ok)
+    for (uint32_t k = 0; k < n; k++) {
+      if (rix[k] == RIX_NONE) continue;
+      struct blockst *b = rq->blocks[(uint8_t)(tags[k] >> 24)];
+      dst[k] = rix[k] == RIX_SRC ? (uint64_t)(uintptr_t)((uint8_t *)b->d_src + (size_t)(tags[k] & 0x00ffffffu) * T)
+                                 : (uint64_t)(uintptr_t)((uint8_t *)b->d_rep + (size_t)rix[k] * T);
+    }
+  if (nput && ok) {
     /* packets up in pieces, each sorted into its rows as soon as it has landed (same stream: the order is the stream's) */
     void *d_blob = NULL;
     const uint32_t piece = (uint32_t)((CHUNK_BYTES / T) ? (CHUNK_BYTES / T) : 1);
-    bool ok = nrq_dev_alloc(c, (size_t)(n < piece ? n : piece) * T, &d_blob) == 0;
+    ok = nrq_dev_alloc(c, (size_t)(n < piece ? n : piece) * T, &d_blob) == 0;
     for (uint32_t k0 = 0; k0 < n && ok; k0 += piece) {
       const uint32_t m = n - k0 < piece ? n - k0 : piece;
       ok = nrq_copy_on(c, 1, d_blob, p + (size_t)k0 * T, (size_t)m * T) == 0 && nrq_scatter_symbols(c, 1, d_blob, m, (uint32_t)T, dst + k0) == 0;
     }
     ok = nrq_stream_sync(c, 1) == 0 && ok;
     if (d_blob) nrq_dev_free(c, d_blob);
-    if (!ok) added = 0; /* the device state is unusable; nothing better to report through this signature */
   } else {
-    nrq_stream_sync(c, 1);
+    ok = nrq_stream_sync(c, 1) == 0 && ok;
   }
+  if (!ok) {
+    /* The bytes did not reach the device rows: take the batch's bookkeeping back, so that the decoder does not believe in
+     * symbols it does not hold (they can be sent again), and say so symbol by symbol. */
+    for (uint32_t k = 0; k < n; k++) {
+      if (rix[k] == RIX_NONE) continue;
+      struct blockst *b = rq->blocks[(uint8_t)(tags[k] >> 24)];
+      mask_clear(b, tags[k] & 0x00ffffffu);
+      if (results) results[k] = NANORQ_SYM_ERR;
+      added--;
+    }
+    for (unsigned sbn = 0; sbn < NRQ_Z_MAX; sbn++) {
+      struct blockst *b = touched[sbn] ? rq->blocks[sbn] : NULL;
+      if (!b) continue;
+      b->nrep = nrep0[sbn];
+      if (newdev[sbn]) { b->dev = false; b->dirty = false; } /* (d_src stays allocated for the next attempt) */
+    }
+  } else {
+    for (uint32_t k = 0; k < n; k++)
+      if (rix[k] == RIX_SRC) rq->blocks[(uint8_t)(tags[k] >> 24)]->dirty = true;
+  }
+  free(rix);
   for (unsigned i = 0; i < nold; i++) nrq_dev_free(c, olds[i]);
   gpu_unlock();
   free(dst);

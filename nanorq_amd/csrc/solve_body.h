@@ -107,6 +107,21 @@ SB_HD uint32_t xtime32(uint32_t x) {
   const uint32_t hi = x & 0x80808080u;
   return ((x ^ hi) << 1) ^ ((hi - (hi >> 7)) & 0x1d1d1d1du);
 }
+/* three-input logic in one instruction (gfx950: v_bitop3_b32, truth table over a = 0xF0, b = 0xCC, c = 0xAA) */
+SB_HD uint32_t nrq_xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+SB_HD uint32_t nrq_xor_and(uint32_t a, uint32_t b, uint32_t c) { /* a ^ (b & c) */
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x78);
+#else
+  return a ^ (b & c);
+#endif
+}
 template <int WB> SB_HD SV<WB> sv_xtime(const SV<WB> &a) {
   SV<WB> r;
 #pragma unroll
@@ -200,7 +215,10 @@ template <int WB> SB_HD SV<WB> g_get(const NRQ_GAS uint8_t *p, uint32_t valid) {
       r.w[0] = *reinterpret_cast<const NRQ_GAS uint16_t *>(p);
     }
   } else {
-    for (uint32_t k = 0; k < valid; k++) r.w[k >> 2] |= (uint32_t)p[k] << ((k & 3u) * 8u);
+    /* (constant indices: a run-time index into r.w would move every SV the caller holds into scratch memory) */
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)WB; k++)
+      if (k < valid) r.w[k >> 2] |= (uint32_t)p[k] << ((k & 3u) * 8u);
   }
   return r;
 }
@@ -241,7 +259,23 @@ template <int WB> SB_HD void g_put(NRQ_GAS uint8_t *p, uint32_t valid, const SV<
       *reinterpret_cast<NRQ_GAS uint16_t *>(p) = (uint16_t)v.w[0];
     }
   } else {
-    for (uint32_t k = 0; k < valid; k++) p[k] = (uint8_t)(v.w[k >> 2] >> ((k & 3u) * 8u));
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)WB; k++)
+      if (k < valid) p[k] = (uint8_t)(v.w[k >> 2] >> ((k & 3u) * 8u));
+  }
+}
+
+template <int WB> SB_HD void g_put_al(NRQ_GAS uint8_t *p, const SV<WB> &v) { /* a whole, aligned strip element */
+  if constexpr (WB == 16) {
+    uint4 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2]; t.w = v.w[3];
+    *reinterpret_cast<NRQ_GAS uint4 *>(p) = t;
+  } else if constexpr (WB == 8) {
+    uint2 t; t.x = v.w[0]; t.y = v.w[1];
+    *reinterpret_cast<NRQ_GAS uint2 *>(p) = t;
+  } else if constexpr (WB == 4) {
+    *reinterpret_cast<NRQ_GAS uint32_t *>(p) = v.w[0];
+  } else {
+    *reinterpret_cast<NRQ_GAS uint16_t *>(p) = (uint16_t)v.w[0];
   }
 }
 
@@ -350,8 +384,11 @@ template <int WB> struct GroupSrc { /* where the rows of one line group of one b
   uint32_t lsub;                  /* log2 of the strips the group has (a whole line: 128/WB; fewer when work is scarce) */
 };
 /* (G > 1: a unit is moved by the G lanes of a virtual thread p of np; `sub` is the lane's 16-byte column of the wide strip) */
-template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
-                                       uint32_t p, uint32_t np, uint32_t sub = 0) {
+/* AL: every piece is a whole, aligned strip element (T a multiple of the strip width, rows aligned): the loop then holds no
+ * byte-wise path at all -- with one in it, the compiler waits for ALL outstanding loads wherever the paths join, and the
+ * pieces of a trip, meant to be in flight together, are fetched one memory latency after the other */
+template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_gather_impl(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
+                                       uint32_t p, uint32_t np, uint32_t sub) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u; /* unit u = (row u >> lsub, piece u & pmask) */
 #ifndef NRQ_GATHER_PB
 #define NRQ_GATHER_PB 4
@@ -373,7 +410,9 @@ template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_gather(const 
         v[q] = sv_zero<WB>();
         if (s[q] != NRQ_ROW_ZERO && strip < g.nstrips) {
           const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? g.rep + (size_t)(s[q] & 0x7FFFFFFFu) * g.T : g.src + (size_t)s[q] * g.T;
-          if constexpr (G == 1) {
+          if constexpr (AL) {
+            v[q] = g_get_l2<WB>(b + (size_t)strip * WB);
+          } else if constexpr (G == 1) {
             const uint32_t rem = g.T - strip * WB;
             v[q] = g_get_stream<WB>(b + (size_t)strip * WB, rem < (uint32_t)WB ? rem : (uint32_t)WB);
           } else {
@@ -400,7 +439,9 @@ template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_gather(const 
     SV<WB> v = sv_zero<WB>();
     if (u < u1 && src != NRQ_ROW_ZERO && strip < g.nstrips) {
       const NRQ_GAS uint8_t *b = (src & NRQ_ROW_REP) ? g.rep + (size_t)(src & 0x7FFFFFFFu) * g.T : g.src + (size_t)src * g.T;
-      if constexpr (G == 1) {
+      if constexpr (AL) {
+        v = g_get_l2<WB>(b + (size_t)strip * WB);
+      } else if constexpr (G == 1) {
         const uint32_t rem = g.T - strip * WB;
         v = g_get_stream<WB>(b + (size_t)strip * WB, rem < (uint32_t)WB ? rem : (uint32_t)WB);
       } else {
@@ -440,6 +481,14 @@ template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_gather(const 
     const uint32_t u = unit_of(prev, q);
     if (u < u1) g_put_stream<WB>(stage + (size_t)(u & pmask) * stage_stride + (size_t)(u >> lsub) * (WB * G) + sub * WB, WB, v_prev[q]);
   }
+}
+template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
+                                       uint32_t p, uint32_t np, uint32_t sub = 0) {
+  if constexpr (G == 1 && WB >= 4) {
+    const bool al = g.T % (uint32_t)WB == 0u && ((reinterpret_cast<uintptr_t>(g.src) | reinterpret_cast<uintptr_t>(g.rep)) & (uintptr_t)(WB - 1)) == 0;
+    if (al) { pf_gather_impl<WB, G, PIPELINED, true>(g, stage, stage_stride, u0, u1, p, np, sub); return; }
+  }
+  pf_gather_impl<WB, G, PIPELINED, false>(g, stage, stage_stride, u0, u1, p, np, sub);
 }
 #ifndef NRQ_COMMIT_PB
 #define NRQ_COMMIT_PB 4
@@ -879,13 +928,18 @@ SB_HD void backsub_one(const StripCtx<WB, G> &c, const uint8_t *t4, uint32_t slo
        * instead of at most 16, and the phase becomes LDS-bandwidth bound at 1.6x the time. */
       uint32_t odd = bits & 0xF0F0F0F0u, even = (bits << 4) & 0xF0F0F0F0u;
       asm volatile("" : "+v"(odd), "+v"(even)); /* keep the packed form */
-      const uint32_t tb = (uint32_t)(uintptr_t)t4;
+      /* all eight lookups of the word in flight together, each address one byte-select add with the table's offset in the
+       * instruction's immediate field, then the 32 dwords folded three at a time (v_bitop3_b32: a ^ b ^ c).  As it was -- four
+       * lookups in flight, then four one by one, each a full LDS round trip the wave waited for, and three VALU operations per
+       * address -- the phase was bound by those round trips (47 k clocks per strip at K=8192 against 33 k of LDS time). */
+      const uint32_t tbw = (uint32_t)(uintptr_t)t4 + w * 2048u; /* (the word's tables; the lookup's own offset q * 256 is an immediate) */
+      uint4 d[8];
 #pragma unroll
-      for (uint32_t q = 0; q < 8; q++) {
-        const uint32_t a = t4_addr(tb, (q & 1u) ? odd : even, q >> 1) + (w * 8u + q) * 256u;
-        const uint4 v = *NRQ_LDSP(uint4, a);
-        acc.w[0] ^= v.x; acc.w[1] ^= v.y; acc.w[2] ^= v.z; acc.w[3] ^= v.w;
-        if (q == 3) NRQ_SCHED_FENCE();
+      for (uint32_t q = 0; q < 8; q++) d[q] = *NRQ_LDSP(uint4, t4_addr(tbw, (q & 1u) ? odd : even, q >> 1) + q * 256u);
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q += 2) {
+        acc.w[0] = nrq_xor3(acc.w[0], d[q].x, d[q + 1].x); acc.w[1] = nrq_xor3(acc.w[1], d[q].y, d[q + 1].y);
+        acc.w[2] = nrq_xor3(acc.w[2], d[q].z, d[q + 1].z); acc.w[3] = nrq_xor3(acc.w[3], d[q].w, d[q + 1].w);
       }
       NRQ_SCHED_FENCE();
       continue;
@@ -908,16 +962,28 @@ template <int WB, int NW, int G = 1> SB_HD void backsub_fixed(const StripCtx<WB,
   const NRQ_GAS uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
   const uint32_t wpr = c.h->wpr, stride = c.h->npiv_pad, npiv = c.h->npiv;
   const uint8_t *t4 = c.t4();
-  for (uint32_t k = tid; k < npiv; k += 2 * nt) {
-    const uint32_t k2 = k + nt;
-    uint32_t a[NW], b[NW];
-    const uint32_t sa = pivslot[k];
-    const uint32_t sb = k2 < npiv ? pivslot[k2] : 0u;
+  /* two register sets, filled alternately: the W words of the NEXT pivot are requested before the current one starts its
+   * table lookups, so a trip to L2 is never waited for with nothing else to do (it was: both sets loaded, then both used) */
+  uint32_t a[NW], b[NW], sa = 0, sb = 0;
+  uint32_t k = tid;
+  if (k < npiv) {
+    sa = pivslot[k];
 #pragma unroll
     for (uint32_t w = 0; w < (uint32_t)NW; w++) a[w] = w < wpr ? wt[(size_t)w * stride + k] : 0u;
+  }
+  for (; k < npiv; k += 2 * nt) {
+    const uint32_t k2 = k + nt, k3 = k + 2 * nt;
+    if (k2 < npiv) {
+      sb = pivslot[k2];
 #pragma unroll
-    for (uint32_t w = 0; w < (uint32_t)NW; w++) b[w] = (w < wpr && k2 < npiv) ? wt[(size_t)w * stride + k2] : 0u;
+      for (uint32_t w = 0; w < (uint32_t)NW; w++) b[w] = w < wpr ? wt[(size_t)w * stride + k2] : 0u;
+    }
     backsub_one<WB, NW, G>(c, t4, sa, a, wpr);
+    if (k3 < npiv) {
+      sa = pivslot[k3];
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)NW; w++) a[w] = w < wpr ? wt[(size_t)w * stride + k3] : 0u;
+    }
     if (k2 < npiv) backsub_one<WB, NW, G>(c, t4, sb, b, wpr);
   }
 }
@@ -1037,8 +1103,8 @@ template <int WB> struct GroupDst {
   uint32_t lsub;
 };
 /* units [u0, u1) of the scatter, unit = (staged element, piece of the line): whole lines to the symbol rows */
-template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
-                                        uint32_t u1, uint32_t p, uint32_t np, uint32_t sub = 0) {
+template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_scatter_impl(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
+                                        uint32_t u1, uint32_t p, uint32_t np, uint32_t sub) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u;
 #ifndef NRQ_SCATTER_PB
 #define NRQ_SCATTER_PB 4
@@ -1061,7 +1127,9 @@ template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_scatter(const
       for (int q = 0; q < PB; q++) {
         const uint32_t u = base + (uint32_t)q * np, i = u >> lsub, strip = g.strip0 + (u & pmask);
         if (u >= u1 || strip >= g.nstrips) continue;
-        if constexpr (G == 1) {
+        if constexpr (AL) {
+          g_put_al<WB>((i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB, v[q]);
+        } else if constexpr (G == 1) {
           const uint32_t rem = g.T - strip * WB;
           NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB;
           NRQ_SCATTER_PUT<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
@@ -1097,7 +1165,9 @@ template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_scatter(const
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np, i = u >> lsub, strip = g.strip0 + (u & pmask);
       if (u >= u1 || strip >= g.nstrips) continue;
-      if constexpr (G == 1) {
+      if constexpr (AL) {
+        g_put_al<WB>((i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB, v[q]);
+      } else if constexpr (G == 1) {
         const uint32_t rem = g.T - strip * WB;
         NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB;
         NRQ_SCATTER_PUT<WB>(dst, rem < (uint32_t)WB ? rem : (uint32_t)WB, v[q]);
@@ -1112,6 +1182,15 @@ template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_scatter(const
 #pragma unroll
     for (int q = 0; q < PB; q++) { v[q] = vn[q]; row[q] = rown[q]; }
   }
+}
+
+template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
+                                        uint32_t u1, uint32_t p, uint32_t np, uint32_t sub = 0) {
+  if constexpr (G == 1 && WB >= 4) {
+    const bool al = g.T % (uint32_t)WB == 0u && ((reinterpret_cast<uintptr_t>(g.inter) | reinterpret_cast<uintptr_t>(g.out)) & (uintptr_t)(WB - 1)) == 0;
+    if (al) { pf_scatter_impl<WB, G, PIPELINED, true>(g, ostage, stage_stride, u0, u1, p, np, sub); return; }
+  }
+  pf_scatter_impl<WB, G, PIPELINED, false>(g, ostage, stage_stride, u0, u1, p, np, sub);
 }
 
 #endif /* NRQ_SOLVE_BODY_H */
