@@ -82,7 +82,8 @@ def lib():
 PARAM_NAMES = ("Kp", "J", "S", "H", "W", "L", "P", "P1", "U", "B")
 PLAN_FIELDS = ("magic status K Kp J S H W L P P1 B M npiv u nlow r2 nfree nlev nrows pipe wpr "
                "npiv_pad n_xor_ops off_ops off_pivslot off_pivcol off_wt off_lowslot off_pivx off_fbits "
-               "off_mh off_freex off_hinv off_colslot off_pivof off_uslot total_bytes").split()
+               "off_mh off_freex off_hinv off_colslot off_pivof off_uslot total_bytes reserved0 reserved1 fail_site "
+               "off_augt lpr aug_stride").split()
 
 
 def params(K):

@@ -276,6 +276,16 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       ph_hdpc_reduce<WB, G>(c, vt, VNT);
       __syncthreads();
       NRQ_STAMP(3);
+      /* the GF(2) combinations E_p of the dense stage: tables over the leftover rows in region X (zero again after the
+       * reduce above), as many words of the bit rows at a time as it holds */
+      for (uint32_t w0 = 0; w0 < c.h->lpr; w0 += low_table_words<WB, G>(c)) {
+        ph_low_tables<WB, G>(c, w0, vt, VNT);
+        __syncthreads();
+        ph_combine<WB, G>(c, w0, vt, VNT);
+        __syncthreads();
+      }
+      ph_clear_x<WB, G>(c, vt, VNT);
+      __syncthreads();
       NRQ_STAMP(4);
       ph_dense_fold<WB, G>(c, vt, VNT);
       __syncthreads();

@@ -118,14 +118,14 @@ typedef struct nrq_plan_hdr {
   uint32_t r2;      /* GF(2) rank reached on the u inactive columns with those rows */
   uint32_t nfree;   /* u - r2: columns that need the HDPC rows */
   uint32_t nlev;    /* dependency depth of the peeled block */
-  uint32_t nrows;   /* rows of the op stream (pivot levels, leftover rows, GF(2) combinations) */
+  uint32_t nrows;   /* rows of the op stream (pivot levels, leftover rows, spare rows) */
   uint32_t pipe;    /* NRQ_PIPE the stream was laid out for */
   uint32_t wpr;     /* 32-bit words per W row: ceil(u/32) */
   uint32_t npiv_pad;/* stride (in pivots) of the transposed W image, multiple of 64 */
   uint32_t n_xor_ops; /* real (non-padding) ops in both passes, for statistics */
 
-  uint32_t off_ops;     /* u32[(nrows+NRQ_PAD_ROWS)*NRQ_ROW]: op words (above), padding = NRQ_NOP_AT.  Slots >= M are
-                         * the r2 scratch rows E_p (slot M+p) of the dense stage: E_p = XOR of leftover rows */
+  uint32_t off_ops;     /* u32[(nrows+NRQ_PAD_ROWS)*NRQ_ROW]: op words (above), padding = NRQ_NOP_AT.  (Slots >= M are
+                         * the r2 scratch rows E_p, slot M+p, of the dense stage: see off_augt) */
   uint32_t off_pivslot; /* u16[npiv]: slot of pivot k */
   uint32_t off_pivcol;  /* u16[npiv]: column of pivot k */
   uint32_t off_wt;      /* u32[wpr*npiv_pad]: word w of W row k at [w*npiv_pad + k] */
@@ -141,6 +141,13 @@ typedef struct nrq_plan_hdr {
   uint32_t total_bytes;
   uint32_t reserved[2]; /* device planner: [0] = PL_FAIL_* reason, [1] = repair symbols taken beyond the initial ones */
   uint32_t fail_site;   /* device planner: planner_body.h line that raised a capacity failure (diagnostics) */
+  /* The GF(2) combinations of the dense stage, E_p = XOR of the leftover rows named by the augmented part of reduced row p
+   * (slot M+p), as a bit matrix: bit j of the row = leftover row j (slot lowslot[j]) takes part.  The solve kernel applies it
+   * with 16-entry XOR tables over groups of four leftover rows (solve_body.h ph_low_tables / ph_combine) -- as ops of the
+   * stream these ~r2 * nlow / 2 terms were a quarter of all row operations, run by the single forward wave. */
+  uint32_t off_augt;    /* u32[lpr * aug_stride]: word w of reduced row p at [w * aug_stride + p] */
+  uint32_t lpr;         /* words per row: ceil(nlow / 32) */
+  uint32_t aug_stride;  /* >= r2, multiple of 4 */
 } nrq_plan_hdr;
 
 /* Per-K' constants shared by every plan of that K': the HDPC block (RFC 6330 section 5.3.3.3) and the

@@ -143,7 +143,7 @@ typedef struct pl_shared {
   uint32_t lv_in_lds, opq_group[2];
   uint32_t tmp_mhoff; /* byte offset of Mb inside the dense LDS region, behind MhT (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
-  uint32_t pad_to_16[3];
+  uint32_t off_augt, aug_stride, pad_to_16[1];
   uint32_t bin_ct[NRQ_LANE_CLASSES]; /* ops of the GF(2) combination group per lane class of the target */
   uint32_t gj_A[32];   /* blocked Gauss-Jordan: pivot row b at its pivot step = XOR of the panel-start rows gj_pr[k], k in gj_A[b] */
   uint16_t gj_pr[32];  /* pivot row of bit b of the current panel (PL_NONE16: the column is free) */
@@ -208,7 +208,8 @@ SB_HD uint32_t pl_arena_bound(uint32_t L, uint32_t Mcap, uint32_t ucap, uint32_t
   const uint32_t wprcap = (ucap + 31u) / 32u, npad = (L + 63u) & ~63u;
   /* op stream: the ops themselves, one partly filled row plus NRQ_PIPE-1 spacer rows per level, the spare and
    * the lead/padding rows */
-  uint32_t ops = (2u * nnz + nnz / 2u + 2u * ucap * 64u) + NRQ_ROW * (NRQ_PIPE * (L / 2u + 8u) + PL_SPARE_ROWS + NRQ_PAD_ROWS + 4u);
+  uint32_t ops = (2u * nnz + nnz / 2u) + NRQ_ROW * (NRQ_PIPE * (L / 2u + 8u) + PL_SPARE_ROWS + NRQ_PAD_ROWS + 4u);
+  ops += ((ucap + 3u) & ~3u) * ((PL_LOWCAP + 31u) / 32u) + 16u; /* (words of the bit matrix of the GF(2) combinations) */
   uint32_t b = 256u + L * 2u * 3u + (L + 16u) * 2u + ucap * 2u * 4u + ucap * 4u * 2u + PL_MAXH * ucap +
                NRQ_MAX_FREE * PL_MAXH + wprcap * npad * 4u + ops * 4u +
                Mcap * 4u + (nlost_cap + 1u) * 8u + nlost_cap * PL_PATCH_STRIDE * 2u + 1024u;
@@ -1308,10 +1309,8 @@ template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt)
   }
   sh->spare_base = rows; /* rows reserved for constraint rows added later */
   rows += PL_SPARE_ROWS + (NRQ_PIPE - 1u);
-  sh->tmp0 = rows; /* rows so far; the GF(2) combination group follows after the elimination */
-  /* ops region: generous bound for the combination group (nlow ones per reduced row at most) */
-  uint32_t bin_bound = ((sh->nlow + PL_EXTRA_ROWS) * (sh->nlow + PL_EXTRA_ROWS) + NRQ_ROW - 1u) / NRQ_ROW + 1u;
-  uint32_t total_rows = NRQ_STREAM_ROWS(rows + bin_bound + NRQ_PAD_ROWS);
+  sh->tmp0 = rows; /* rows of the stream */
+  uint32_t total_rows = NRQ_STREAM_ROWS(rows + NRQ_PAD_ROWS);
   sh->off_ops = pl_r16(c.fixed_end);
   sh->arena_top = pl_r16(sh->off_ops + total_rows * NRQ_ROW * 4u);
   sh->opbase = total_rows;
@@ -1670,58 +1669,39 @@ template <int Z> SB_HD void pl_gjp_apply(PlanCtx &c, uint32_t w, uint32_t tid, u
   }
 }
 
-/* the GF(2) combinations E_q (slot M+q) as one more accumulate-only group of XOR ops */
+/* the GF(2) combinations E_q (slot M+q) = XOR of the leftover rows named by the augmented part of reduced row q: handed to
+ * the solve kernel as a bit matrix, word w of row q at [w * aug_stride + q] (plan.h off_augt), behind the op stream */
 template <int Z> SB_HD void pl_bin_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (tid == 0) {
     sh->tmp1 = 0;
-  }
-  const uint32_t *Mb = pl_mb(c);
-  for (uint32_t q = tid; q < sh->r2; q += nt) {
-    const uint32_t *aug = Mb + (size_t)c.red_row[q] * sh->rowlen + sh->wpr;
-    uint32_t n = 0;
-    for (uint32_t w = 0; w < sh->lpr; w++) n += (uint32_t)__builtin_popcount(aug[w]);
-    c.pivdeg[q] = n; /* reuse */
+    sh->aug_stride = (sh->r2 + 3u) & ~3u;
+    if (sh->aug_stride < 4u) sh->aug_stride = 4u;
+    sh->off_augt = sh->arena_top;
+    sh->arena_top = pl_r16(sh->off_augt + sh->lpr * sh->aug_stride * 4u);
+    sh->nrows = sh->tmp0; /* rows of the stream: the level groups and the spare rows */
+    if ((sh->arena_top > c.job.arena_cap || sh->nrows + NRQ_PAD_ROWS > sh->opbase || sh->M + sh->r2 + NRQ_SCRATCH > 65535u) && sh->status == 0)
+      (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* (op fields and slot numbers are 16 bits) */
   }
 }
 template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
-  if (tid != 0) return;
-  /* the ops of reduced row q (target: scratch row M + q) rank among those of the target's lane class (plan.h "lane placement") */
-  uint32_t run = 0;
-  for (uint32_t d = 0; d < NRQ_LANE_CLASSES; d++) sh->bin_ct[d] = 0;
-  for (uint32_t q = 0; q < sh->r2; q++) {
-    const uint32_t n = c.pivdeg[q], d = nrq_op_class(NRQ_OP(sh->M + q, 0u));
-    c.pivdeg[q] = sh->bin_ct[d]; sh->bin_ct[d] += n; run += n;
+  if (sh->status) return;
+  const uint32_t *Mb = pl_mb(c);
+  uint32_t *augt = reinterpret_cast<uint32_t *>(c.arena + sh->off_augt);
+  const uint32_t lpr = sh->lpr, stride = sh->aug_stride;
+  uint32_t n = 0;
+  for (uint32_t e = tid; e < lpr * stride; e += nt) {
+    const uint32_t w = e / stride, q = e - w * stride;
+    const uint32_t v = q < sh->r2 ? Mb[(size_t)c.red_row[q] * sh->rowlen + sh->wpr + w] : 0u;
+    augt[e] = v;
+    n += (uint32_t)__builtin_popcount(v);
   }
-  const uint32_t g = sh->nlev + 1u;
-  c.lev_ops[g] = run;
-  sh->nrows = sh->tmp0 + pl_group_rows(run);
-  if ((sh->nrows + NRQ_PAD_ROWS > sh->opbase || sh->M + sh->r2 + NRQ_SCRATCH > 65535u) && sh->status == 0)
-    (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* op fields are 16 bits */
+  if (n) PL_ATOM_ADD(&sh->tmp1, n); /* terms, for the statistics */
 }
 template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
-  if (sh->status) return;
-  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
-  const uint32_t row0 = sh->tmp0, span = sh->nrows - sh->tmp0;
-  uint32_t ct[NRQ_LANE_CLASSES];
-  for (uint32_t d = 0; d < NRQ_LANE_CLASSES; d++) ct[d] = sh->bin_ct[d];
-  const uint32_t *Mb = pl_mb(c);
-  for (uint32_t q = tid; q < sh->r2; q += nt) {
-    const uint32_t *aug = Mb + (size_t)c.red_row[q] * sh->rowlen + sh->wpr;
-    uint32_t i = c.pivdeg[q];
-    for (uint32_t w = 0; w < sh->lpr; w++) {
-      uint32_t bits = aug[w];
-      while (bits) {
-        const uint32_t j = w * 32u + (uint32_t)__builtin_ctz(bits);
-        bits &= bits - 1u;
-        const uint32_t word = NRQ_OP(sh->M + q, c.lowslot[j]);
-        *pl_op_at(ops, row0, nrq_lane_place(span, ct, nrq_op_class(word), i)) = word;
-        i++;
-      }
-    }
-  }
+  if (tid == 0) c.lev_ops[sh->nlev + 1u] = sh->status ? 0u : sh->tmp1;
 }
 
 /* =============================== phase 7: the free columns over GF(256) ====================== */
@@ -2001,6 +1981,7 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   h.off_lowslot = c.off_lowslot; h.off_pivx = c.off_pivx; h.off_fbits = c.off_fbits; h.off_mh = c.off_mh;
   h.off_freex = c.off_freex; h.off_hinv = c.off_hinv; h.off_colslot = c.off_colslot; h.off_pivof = c.off_pivof;
   h.off_uslot = c.off_uslot; h.total_bytes = sh->arena_top;
+  h.off_augt = sh->off_augt; h.lpr = sh->lpr; h.aug_stride = sh->aug_stride;
   if (!sh->status) {
     const uint32_t nl = c.job.nlost;
     uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + c.part()[2]);

@@ -808,6 +808,65 @@ template <int WB, int G = 1> SB_HD void ph_hdpc(const StripCtx<WB, G> &c, uint32
   }
 }
 
+/* phase 4a: the GF(2) combinations of the dense stage, E_p (slot M+p, zeroed by ph_clear) = XOR of the leftover rows that
+ * the bit matrix of the plan names (plan.h off_augt).  Method of four Russians, like the back-substitution: region X --
+ * idle and zero between ph_hdpc_reduce and the dense fold -- takes 16-entry XOR tables over groups of four leftover rows
+ * (words [w0, w0 + nw) of the bit rows at a time, as many as region X holds), then every reduced row looks its nibbles up.
+ * Threads share a row word by word and add their parts with LDS atomics.  ph_clear_x hands region X back zeroed.
+ * (As ops of the stream these terms -- r2 * nlow / 2, a quarter of all row operations at K=8192 -- cost the forward wave
+ * 300 of its 1400 rows: 16 k clocks per strip against 3 k here.) */
+template <int WB, int G = 1> SB_HD uint32_t low_table_words(const StripCtx<WB, G> &c) { /* words of the bit rows region X has tables for */
+  const uint32_t groups = (c.lay.total - c.lay.off_x) / (16u * WB * G);
+  return groups / 8u;
+}
+template <int WB, int G = 1> SB_HD void ph_low_tables(const StripCtx<WB, G> &c, uint32_t w0, uint32_t tid, uint32_t nt) {
+  const NRQ_GAS uint16_t *lowslot = c.template arr<uint16_t>(c.h->off_lowslot);
+  const uint32_t nlow = c.h->nlow, lpr = c.h->lpr, cap = low_table_words<WB, G>(c);
+  const uint32_t nw = lpr - w0 < cap ? lpr - w0 : cap;
+  for (uint32_t e = tid; e < nw * 8u * 16u; e += nt) {
+    const uint32_t grp = e >> 4, nib = e & 15u, j0 = w0 * 32u + grp * 4u;
+    uint32_t sl[4];
+#pragma unroll
+    for (uint32_t bq = 0; bq < 4; bq++) sl[bq] = (((nib >> bq) & 1u) && j0 + bq < nlow) ? (uint32_t)lowslot[j0 + bq] : NRQ_NOSLOT;
+    SV<WB> v = sv_zero<WB>();
+#pragma unroll
+    for (uint32_t bq = 0; bq < 4; bq++)
+      if (sl[bq] != NRQ_NOSLOT) sv_xor<WB>(v, lds_get<WB, G>(c.slots(), sl[bq]));
+    lds_put<WB, G>(c.t4(), e, v);
+  }
+}
+template <int WB, int G = 1> SB_HD void ph_combine(const StripCtx<WB, G> &c, uint32_t w0, uint32_t tid, uint32_t nt) {
+  const NRQ_GAS uint32_t *augt = c.template arr<uint32_t>(c.h->off_augt);
+  const uint32_t r2 = c.h->r2, lpr = c.h->lpr, stride = c.h->aug_stride, cap = low_table_words<WB, G>(c);
+  const uint32_t nw = lpr - w0 < cap ? lpr - w0 : cap;
+  if (!r2) return;
+  uint32_t nparts = nt / r2; /* threads per reduced row: they take its words in turn */
+  if (nparts < 1u) nparts = 1u;
+  if (nparts > nw) nparts = nw;
+  for (uint32_t i = tid; i < r2 * nparts; i += nt) {
+    const uint32_t p = i % r2, part = i / r2;
+    constexpr uint32_t WU = 4; /* words of the row in flight */
+    SV<WB> acc = sv_zero<WB>();
+    for (uint32_t wa = part; wa < nw; wa += WU * nparts) {
+      uint32_t bits[WU];
+#pragma unroll
+      for (uint32_t k = 0; k < WU; k++) bits[k] = wa + k * nparts < nw ? augt[(size_t)(w0 + wa + k * nparts) * stride + p] : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < WU; k++) {
+        if (!bits[k]) continue;
+        const uint32_t w = wa + k * nparts;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) sv_xor<WB>(acc, lds_get<WB, G>(c.t4(), (w * 8u + q) * 16u + ((bits[k] >> (4u * q)) & 15u)));
+      }
+    }
+    lds_xor<WB, G>(c.slots(), c.h->M + p, acc);
+  }
+}
+template <int WB, int G = 1> SB_HD void ph_clear_x(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+  const uint32_t nx = (c.lay.total - c.lay.off_x) / (WB * G);
+  for (uint32_t f = tid; f < nx; f += nt) lds_put<WB, G>(c.cf(), f, sv_zero<WB>());
+}
+
 /* phase 4b: fold the columns resolved by binary rows out of the HDPC rows: R_h ^= mh[h][p]*E_p.
  * Big workgroups (dense_fold_shared): one thread per E_p -- its 8 multiples by alpha^k once, then every one of the H
  * products is a masked XOR per set coefficient bit (a general GF(256) multiply per (h, p) pair is 3.4x the

@@ -60,8 +60,15 @@ int orc_plan_exec(const uint8_t *plan, uint8_t *Din, uint32_t T, uint8_t *C) {
   for (uint32_t k = 0; k < h->npiv; k++)
     for (uint32_t q = 0; q < H; q++) fma_row(ROW(h->S + q), ROW(pivslot[k]), T, G[(size_t)q * n_hd + pivcol[k]]);
   free(G);
-  /* 4: the binary combinations E_p were accumulated by the op stream into rows M+p */
+  /* 4: the binary combinations E_p (rows M+p) = XOR of the leftover rows the bit matrix names */
   uint8_t *E = D + (size_t)h->M * T;
+  {
+    const uint32_t *augt = (const uint32_t *)(plan + h->off_augt);
+    const uint16_t *lowslot = (const uint16_t *)(plan + h->off_lowslot);
+    for (uint32_t p = 0; p < h->r2; p++)
+      for (uint32_t j = 0; j < h->nlow; j++)
+        if ((augt[(size_t)(j >> 5) * h->aug_stride + p] >> (j & 31)) & 1u) xor_row(E + (size_t)p * T, ROW(lowslot[j]), T);
+  }
   /* 5: fold the resolved columns out of the HDPC rows */
   for (uint32_t q = 0; q < H; q++)
     for (uint32_t p = 0; p < h->r2; p++) fma_row(ROW(h->S + q), E + (size_t)p * T, T, mh[(size_t)q * h->r2 + p]);

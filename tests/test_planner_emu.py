@@ -342,12 +342,12 @@ def test_lanes_are_placed_by_bank_class():
     kc = nanorq_amd.host_kconst(K)
     p = nanorq_amd.params(K)
     host = nanorq_amd.host_plan(K, np.arange(p["Kp"], dtype=np.uint32), kc)
-    assert _atomic_cycles_per_row(host) < 11.0
-    lost = loss_pattern(K, 0.1, 77)
+    assert _atomic_cycles_per_row(host) < 11.5   # (the thin level groups: the wide, well-filled group of the GF(2)
+    lost = loss_pattern(K, 0.1, 77)              #  combinations left the stream for the table phase)
     rep_esis = np.arange(K, K + len(lost) + 3, dtype=np.uint32)
     dev, hdr = emu_device_plan(K, kc, lost, rep_esis, use=len(lost))
     assert hdr["status"] == 0
-    assert _atomic_cycles_per_row(dev) < 11.0
+    assert _atomic_cycles_per_row(dev) < 11.5
 
 
 def test_small_planner_state_reports_overflow(orc):
