@@ -65,6 +65,12 @@ typedef struct nrq_job {
   uint32_t pad;
 } nrq_job;
 
+/* true in every lane of the wave if the condition holds in one (the CPU emulation runs a thread at a time: the thread's own) */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NRQ_WAVE_ANY(x) (__ballot(x) != 0ull)
+#else
+#define NRQ_WAVE_ANY(x) (x)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NRQ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -1086,7 +1092,10 @@ template <int WB, int G = 1> SB_HD void ph_park(const StripCtx<WB, G> &c, uint32
  * for their rows in HBM a line group at a time (pf_scatter): written strip by strip, every 16-byte piece would be a
  * partial-line write of its own (measured: 3.7x the bytes at the HBM interface). */
 #ifndef NRQ_STORE_CHUNK
-#define NRQ_STORE_CHUNK 32u
+#define NRQ_STORE_CHUNK 8u /* (even) */
+#endif
+#ifndef NRQ_STORE_TRIP
+#define NRQ_STORE_TRIP 32u /* (a multiple of the chunk) */
 #endif
 template <int WB, int G = 1> SB_HD uint32_t out_elems(const nrq_job *job, const nrq_plan_hdr *h) { return (job->inter ? h->L : 0u) + job->nout; }
 template <int WB, int G = 1> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
@@ -1108,29 +1117,45 @@ template <int WB, int G = 1> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_G
   }
   const NRQ_GAS uint32_t *cptr = gptr<uint32_t>(c.job->out_cptr);
   const NRQ_GAS uint16_t *osl = gptr<uint16_t>(c.job->out_slots);
-  /* a generated symbol per thread and pass: list bounds, then ALL slot numbers of the list in one trip (an LT list has at most
-   * 30 + 3 entries: a chunk of NRQ_STORE_CHUNK covers it; eight at a time it was a chain of up to four dependent trips to L2
-   * per symbol, and a wave waited for its longest list), then the strips from LDS.  The bounds of the thread's next symbol
-   * are fetched meanwhile. */
+  /* A generated symbol per thread and pass: its list bounds (fetched a pass ahead), then the slot numbers NRQ_STORE_CHUNK at a
+   * time in one trip, then the strips from LDS -- ALL of the chunk's, unconditionally: an entry beyond the end of the list reads
+   * the lane's scratch slot, which holds zeros (ph_clear; the padding ops of the stream XOR it into itself), so the loop body
+   * has no branch and its LDS reads are in flight together.  (With a test per entry every read was waited for on its own: 14 k
+   * clocks for the 860 symbols of a decode strip.)  The waves of a pass go on as long as one lane has entries left; an LT list
+   * has 7 entries on average and 33 at most. */
   const uint32_t nout = c.job->nout;
   constexpr uint32_t CH = NRQ_STORE_CHUNK;
+  const uint32_t zero_at = tid & (NRQ_SCRATCH - 1u); /* (element index from the start of the image) */
   uint32_t e_n = 0, end_n = 0;
   if (tid < nout) { e_n = cptr[tid]; end_n = cptr[tid + 1]; }
-  for (uint32_t q = tid; q < nout; q += nt) {
+  const uint32_t npass = (nout + nt - 1u) / nt;
+  for (uint32_t pass = 0, q = tid; pass < npass; pass++, q += nt) {
     uint32_t e = e_n;
     const uint32_t end = end_n;
+    e_n = end_n = 0;
     if (q + nt < nout) { e_n = cptr[q + nt]; end_n = cptr[q + nt + 1]; }
     SV<WB> acc = sv_zero<WB>();
-    while (e < end) {
-      uint32_t sl[CH];
+    while (NRQ_WAVE_ANY(e < end)) {
+      /* one trip to L2 for the next NRQ_STORE_TRIP entries of every lane's list (nearly always all that is left), then the
+       * strips, a chunk of entries at a time while a lane of the wave still has some */
+      constexpr uint32_t TR = NRQ_STORE_TRIP;
+      uint32_t sl[TR];
 #pragma unroll
-      for (uint32_t k = 0; k < CH; k++) sl[k] = e + k < end ? (uint32_t)osl[e + k] : NRQ_NOSLOT;
+      for (uint32_t k = 0; k < TR; k++) sl[k] = e + k < end ? (uint32_t)osl[e + k] + NRQ_SCRATCH : zero_at;
 #pragma unroll
-      for (uint32_t k = 0; k < CH; k++)
-        if (sl[k] != NRQ_NOSLOT) sv_xor<WB>(acc, lds_get<WB, G>(c.slots(), sl[k]));
-      e += CH;
+      for (uint32_t k0 = 0; k0 < TR; k0 += CH) {
+        if (k0 && !NRQ_WAVE_ANY(e + k0 < end)) break;
+        SV<WB> v[CH];
+#pragma unroll
+        for (uint32_t k = 0; k < CH; k++) v[k] = lds_get<WB, G>(c.lds, sl[k0 + k]);
+#pragma unroll
+        for (uint32_t k = 0; k + 1u < CH; k += 2u)
+#pragma unroll
+          for (int i = 0; i < SV<WB>::ND; i++) acc.w[i] = nrq_xor3(acc.w[i], v[k].w[i], v[k + 1u].w[i]);
+      }
+      e += TR;
     }
-    g_put_stream<WB>(ostage + (size_t)(ni + q) * (WB * G), WB, acc);
+    if (q < nout) g_put_stream<WB>(ostage + (size_t)(ni + q) * (WB * G), WB, acc);
   }
 }
 /* phase 6b for the SPLIT solve of narrow strips (big blocks, nrq_device.hip): instead of back-substitution and results,
