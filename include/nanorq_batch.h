@@ -26,6 +26,11 @@ size_t nanorq_generate_symbols_all(nanorq *rq, struct ioctx *io);
  * block `sbn`; `data` receives n * nanorq_symbol_size(rq) bytes.  Returns the bytes written (0 on failure). */
 size_t nanorq_encode_range(nanorq *rq, void *data, uint32_t esi0, uint32_t n, uint8_t sbn, struct ioctx *io);
 
+/* Encoder: the n consecutive REPAIR symbols esi0 .. esi0+n-1 (esi0 >= the symbols of every block) of ALL blocks: `data`
+ * receives, block after block, n * nanorq_symbol_size(rq) bytes each (solving what is not solved yet).  One download per
+ * device instead of a launch, a wait and a download per block.  Returns the bytes written (0 on failure). */
+size_t nanorq_encode_range_all(nanorq *rq, void *data, uint32_t esi0, uint32_t n, struct ioctx *io);
+
 /* Decoder: nanorq_decoder_add_symbol (reference lib/nanorq.c:478-509) for n symbols: symbol k is the T bytes at
  * data + k*T with tag tags[k].  results[k] (may be NULL) receives the NANORQ_SYM_* code of symbol k.  Returns the
  * number of symbols stored (NANORQ_SYM_ADDED). */
@@ -57,6 +62,15 @@ void nanorq_pinned_free(void *p);
 /* Decoder: write the received source symbols that have not reached `io` yet (blocks fed through the page-locked path
  * and not repaired since).  Returns the number of blocks written. */
 size_t nanorq_decoder_flush(nanorq *rq, struct ioctx *io);
+
+
+/* ---- devices ----
+ * NANORQ_HIP_DEVICES=0,1,... (read once, at the first call that needs a GPU) names the GPUs of the process; source blocks
+ * share nothing (reference lib/nanorq.c:97-112), so block sbn of every object lives on device number sbn mod N and the
+ * batched calls above run one host thread per device.  The packets and symbols produced do not depend on N. */
+size_t nanorq_devices(void); /* contexts in use (0: no GPU could be opened -- every call that needs one fails) */
+/* give back the page-locked host rows and device pool blocks cached from freed objects */
+void nanorq_trim(void);
 
 #ifdef __cplusplus
 }

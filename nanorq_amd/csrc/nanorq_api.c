@@ -17,8 +17,13 @@
  * object's memory and the GPU by DMA with no copy on the host at all, and a decoder fed from a page-locked
  * packet buffer keeps its received symbols on the device ("device-resident" blocks below).
  *
+ * Devices.  NANORQ_HIP_DEVICES=0,1,... names the GPUs of the process (default: NANORQ_HIP_DEVICE or
+ * device 0); each gets a context of its own -- streams, pools, plan caches -- and a lock.  Source blocks share nothing
+ * (reference get_source_block, lib/nanorq.c:97-112), so block sbn of every object lives on device sbn mod N, and the batched
+ * calls run one host thread per device over that device's blocks.  A device may be named twice (two contexts on one GPU).
+ *
  * Threads: distinct nanorq objects may be used from different threads (as with the reference, which has no
- * globals); the one GPU context of the process behind them is guarded by a lock.  One object is not thread-safe.
+ * globals); the GPU contexts behind them are guarded by a lock each.  One object is not thread-safe.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -43,6 +48,7 @@ struct part { /* RFC 6330 section 4.4.1.2 Partition[I, J] */
 };
 
 struct blockst {
+  int di;             /* the device (index into g_dev) the block lives on: sbn mod the number of devices */
   uint32_t K, Kp, L;  /* source symbols; the table row the block is coded with and its L (block 0's unless NANORQ_EXT_PER_BLOCK_KP) */
   bool loaded, inverted;
   uint8_t *src;       /* K x T: source symbols (encoder) / received source symbols (decoder); allocated on first use */
@@ -80,28 +86,58 @@ struct nanorq {
   struct blockst *blocks[NRQ_Z_MAX];
 };
 
-/* ---------------------------------------------------------------- GPU context (process-wide) ---- */
-static nrq_ctx *g_ctx;
+/* --------------------------------------------------------------- GPU contexts (process-wide) ---- */
+#define NRQ_MAX_DEV 16
+struct devctx {
+  nrq_ctx *c;
+  int device;
+  pthread_mutex_t lock; /* recursive: every entry point that touches the context holds it */
+};
+static struct devctx g_dev[NRQ_MAX_DEV];
+static int g_ndev;
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
-static pthread_mutex_t g_lock; /* recursive: every entry point that touches g_ctx holds it */
+static pthread_mutex_t g_io_lock = PTHREAD_MUTEX_INITIALIZER; /* an ioctx has one cursor: the device threads of a batched call take turns */
 
 static void ctx_init(void) {
-  int dev = 0;
-  const char *e = getenv("NANORQ_HIP_DEVICE");
-  if (e && *e) dev = atoi(e);
+  int devs[NRQ_MAX_DEV], n = 0;
+  const char *e = getenv("NANORQ_HIP_DEVICES");
+  if (e && *e) {
+    while (*e && n < NRQ_MAX_DEV) {
+      char *end = NULL;
+      const long v = strtol(e, &end, 10);
+      if (end == e) break;
+      if (v >= 0) devs[n++] = (int)v;
+      e = end;
+      while (*e == ',' || *e == ' ') e++;
+    }
+  }
+  if (n == 0) {
+    e = getenv("NANORQ_HIP_DEVICE");
+    devs[n++] = (e && *e) ? atoi(e) : 0;
+  }
   pthread_mutexattr_t a;
   pthread_mutexattr_init(&a);
   pthread_mutexattr_settype(&a, PTHREAD_MUTEX_RECURSIVE);
-  pthread_mutex_init(&g_lock, &a);
+  for (int i = 0; i < n; i++) {
+    nrq_ctx *c = NULL;
+    if (nrq_ctx_create(devs[i], NULL, &c) != 0 || !c) continue; /* a device that cannot be opened is left out */
+    g_dev[g_ndev].c = c;
+    g_dev[g_ndev].device = devs[i];
+    pthread_mutex_init(&g_dev[g_ndev].lock, &a);
+    g_ndev++;
+  }
   pthread_mutexattr_destroy(&a);
-  if (nrq_ctx_create(dev, NULL, &g_ctx) != 0) g_ctx = NULL;
 }
-static nrq_ctx *ctx(void) {
+static int ndev(void) {
   pthread_once(&g_once, ctx_init);
-  return g_ctx;
+  return g_ndev;
 }
-static void gpu_lock(void) { pthread_once(&g_once, ctx_init); pthread_mutex_lock(&g_lock); }
-static void gpu_unlock(void) { pthread_mutex_unlock(&g_lock); }
+static nrq_ctx *ctx(void) { return ndev() ? g_dev[0].c : NULL; } /* "is there a GPU at all" */
+static nrq_ctx *dctx(int di) { return di < ndev() ? g_dev[di].c : NULL; }
+static void gpu_lock(int di) { pthread_mutex_lock(&g_dev[di].lock); }
+static void gpu_unlock(int di) { pthread_mutex_unlock(&g_dev[di].lock); }
+size_t nanorq_devices(void) { return (size_t)ndev(); }
+void nanorq_trim(void); /* (below) */
 
 /* -------------------------------------------------------------------------- small helpers ---- */
 static size_t ceil_div(size_t a, size_t b) { return a / b + (a % b ? 1 : 0); }
@@ -330,6 +366,7 @@ static struct blockst *get_block(nanorq *rq, uint8_t sbn) { /* nanorq.c:130-146 
   struct blockst *b = calloc(1, sizeof(*b));
   if (!b) return NULL;
   b->K = (uint32_t)nanorq_block_symbols(rq, sbn);
+  b->di = ndev() ? (int)(sbn % (unsigned)ndev()) : 0;
   b->Kp = rq->Kp;
   b->L = rq->L;
   if ((rq->flags & NANORQ_EXT_PER_BLOCK_KP) && b->K) {
@@ -353,13 +390,13 @@ static bool ensure_src(nanorq *rq, struct blockst *b) {
 }
 
 static void drop_device(struct blockst *b) {
-  nrq_ctx *c = g_ctx;
+  nrq_ctx *c = g_ndev ? g_dev[b->di].c : NULL;
   if (c) {
-    gpu_lock();
+    gpu_lock(b->di);
     if (b->d_src) nrq_dev_free(c, b->d_src);
     if (b->d_inter) nrq_dev_free(c, b->d_inter);
     if (b->d_rep) nrq_dev_free(c, b->d_rep);
-    gpu_unlock();
+    gpu_unlock(b->di);
   }
   b->d_src = b->d_inter = b->d_rep = NULL;
   b->d_rep_cap = 0;
@@ -466,12 +503,15 @@ static bool load_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct ioctx 
 
 /* ------------------------------------------------------------------------- encoding ---- */
 bool nanorq_precalculate(nanorq *rq) { /* nanorq.c:393-401 */
-  nrq_ctx *c = ctx();
   size_t k0 = nanorq_block_symbols(rq, 0);
-  if (!c || k0 == 0) return false;
-  gpu_lock();
-  const bool ok = nrq_precalculate(c, (uint32_t)k0, rq->Kp) == 0;
-  gpu_unlock();
+  if (!ndev() || k0 == 0) return false;
+  bool ok = true;
+  const size_t Z = nanorq_blocks(rq);
+  for (int d = 0; d < g_ndev && (size_t)d < (Z ? Z : 1); d++) { /* (every device that will hold a block keeps its own plan cache) */
+    gpu_lock(d);
+    ok = nrq_precalculate(g_dev[d].c, (uint32_t)k0, rq->Kp) == 0 && ok;
+    gpu_unlock(d);
+  }
   if (ok) rq->precalc = true;
   return ok;
 }
@@ -482,11 +522,11 @@ bool nanorq_generate_symbols(nanorq *rq, uint8_t sbn, struct ioctx *io) { /* nan
   if (b->inverted) return true;
   if (!b->loaded) b->loaded = load_block(rq, sbn, b, io);
   if (!b->loaded || b->K == 0) return false;
-  nrq_ctx *c = ctx();
+  nrq_ctx *c = dctx(b->di);
   if (!c) return false; /* no GPU: no solve */
   const size_t T = rq->T, bytes = (size_t)b->K * T;
   bool ok = false;
-  gpu_lock();
+  gpu_lock(b->di);
   /* every block of an object is coded with block 0's K' (nanorq.c:289); a short block just has more padding */
   if (!b->d_src && nrq_dev_alloc(c, bytes, &b->d_src) != 0) goto out;
   if (!b->d_inter && nrq_dev_alloc(c, (size_t)b->L * T, &b->d_inter) != 0) goto out;
@@ -495,7 +535,7 @@ bool nanorq_generate_symbols(nanorq *rq, uint8_t sbn, struct ioctx *io) { /* nan
   if (nrq_ctx_sync(c) != 0) goto out;
   ok = true;
 out:
-  gpu_unlock();
+  gpu_unlock(b->di);
   if (ok) { b->win_n = 0; b->inverted = true; }
   return ok;
 }
@@ -504,18 +544,18 @@ out:
 static bool fetch_symbol(nanorq *rq, struct blockst *b, uint32_t isi, uint8_t *out) {
   const size_t T = rq->T;
   if (!(b->win_n && isi >= b->win_isi0 && isi < b->win_isi0 + b->win_n)) {
-    nrq_ctx *c = ctx();
+    nrq_ctx *c = dctx(b->di);
     if (!c || !b->d_inter) return false;
     if (!b->win && !(b->win = malloc((size_t)ENC_WINDOW * T))) return false;
     uint32_t isis[ENC_WINDOW], n = ENC_WINDOW;
     for (uint32_t k = 0; k < n; k++) isis[k] = isi + k;
     void *d_out = NULL;
-    gpu_lock();
+    gpu_lock(b->di);
     bool ok = nrq_dev_alloc(c, (size_t)n * T, &d_out) == 0 &&
               nrq_gen_symbols(c, b->K, b->Kp, (uint32_t)T, 1, b->d_inter, (size_t)b->L * T, n, isis, d_out, (size_t)n * T) == 0 &&
               nrq_dev_download(c, b->win, d_out, (size_t)n * T) == 0;
     if (d_out) nrq_dev_free(c, d_out);
-    gpu_unlock();
+    gpu_unlock(b->di);
     if (!ok) return false;
     b->win_isi0 = isi;
     b->win_n = n;
@@ -565,12 +605,11 @@ static bool rep_reserve_host(nanorq *rq, struct blockst *b) { /* room for one mo
 
 /* one symbol of a device-resident block arriving through the per-symbol call: straight to its device row */
 static bool dev_put_row(nanorq *rq, struct blockst *b, void *d_row, const void *data) {
-  nrq_ctx *c = ctx();
-  (void)b;
+  nrq_ctx *c = dctx(b->di);
   if (!c) return false;
-  gpu_lock();
+  gpu_lock(b->di);
   const bool ok = nrq_copy_on(c, 1, d_row, data, rq->T) == 0 && nrq_stream_sync(c, 1) == 0;
-  gpu_unlock();
+  gpu_unlock(b->di);
   return ok;
 }
 static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, size_t keep, void **old_out); /* (below) */
@@ -597,7 +636,7 @@ int nanorq_decoder_add_symbol(nanorq *rq, void *data, uint32_t tag, struct ioctx
       void *old = NULL;
       if (!dev_rep_reserve(rq, b, b->nrep + 1, b->nrep, &old)) return NANORQ_SYM_ERR;
       const bool ok = dev_put_row(rq, b, (uint8_t *)b->d_rep + b->nrep * T, data); /* (waits for the upload stream: `old` is idle then) */
-      if (old) { gpu_lock(); nrq_dev_free(ctx(), old); gpu_unlock(); }
+      if (old) { gpu_lock(b->di); nrq_dev_free(dctx(b->di), old); gpu_unlock(b->di); }
       if (!ok) return NANORQ_SYM_ERR;
     } else {
       memcpy(b->rep_data + b->nrep * T, data, T);
@@ -643,7 +682,7 @@ static uint32_t rep_upfront(size_t gaps, size_t nrep) { return (uint32_t)(nrep -
  * complete (`all`), otherwise the runs of received rows only.  Enqueues on the download stream when `io` is a
  * page-locked context (the caller waits), else goes through the block's host rows. */
 static bool flush_dev_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct ioctx *io, bool all) {
-  nrq_ctx *c = ctx();
+  nrq_ctx *c = dctx(b->di);
   if (!c || !io || !b->d_src) return false;
   const size_t T = rq->T;
   uint8_t *base;
@@ -651,8 +690,10 @@ static bool flush_dev_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct i
   const bool dma = ioctx_dma_region(io, &base, &rlen) && block_extent(rq, sbn, b->K, &off, &len) && off + len <= rlen;
   if (!dma) {
     if (!ensure_src(rq, b) || nrq_copy_on(c, 2, b->src, b->d_src, (size_t)b->K * T) != 0 || nrq_stream_sync(c, 2) != 0) return false;
+    pthread_mutex_lock(&g_io_lock);
     for (uint32_t e = 0; e < b->K; e++)
       if (all || mask_get(b, e)) transfer_symbol(rq, sbn, e, b->K, b->src + (size_t)e * T, io, 1);
+    pthread_mutex_unlock(&g_io_lock);
     return true;
   }
   if (all) return nrq_copy_on(c, 2, base + off, b->d_src, len) == 0;
@@ -671,12 +712,12 @@ bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.
   struct blockst *b = get_block(rq, sbn);
   if (!b) return false;
   const size_t gaps = mask_gaps(b, b->K);
-  nrq_ctx *c = ctx();
+  nrq_ctx *c = dctx(b->di);
   if (gaps == 0) {
     if (b->dev && b->dirty && io && c) { /* received through the page-locked path and not written yet */
-      gpu_lock();
+      gpu_lock(b->di);
       if (flush_dev_block(rq, sbn, b, io, true) && nrq_stream_sync(c, 2) == 0) b->dirty = false;
-      gpu_unlock();
+      gpu_unlock(b->di);
     }
     return true;
   }
@@ -692,7 +733,7 @@ bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.
   void *d_rep = NULL;
   uint32_t nlost = (uint32_t)gaps, nuse = rep_upfront(gaps, b->nrep), navail = (uint32_t)b->nrep, used = 0;
   int status = 0;
-  gpu_lock();
+  gpu_lock(b->di);
   if (b->dev) {
     const uint64_t sv = (uint64_t)(uintptr_t)b->d_src, rv = (uint64_t)(uintptr_t)b->d_rep;
     if (nrq_decode_blocks_v(c, b->K, b->Kp, (uint32_t)T, 1, &sv, lost, &nlost, nlost, b->rep_esi, &nuse, &navail, navail, &rv, &status, &used) != 0) goto out;
@@ -723,7 +764,7 @@ bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.
   ok = mask_gaps(b, b->K) == 0;
 out:
   if (d_rep) { nrq_ctx_sync(c); nrq_dev_free(c, d_rep); }
-  gpu_unlock();
+  gpu_unlock(b->di);
   free(lost);
   return ok;
 }
@@ -739,26 +780,65 @@ void *nanorq_pinned_alloc(size_t bytes) {
 }
 void nanorq_pinned_free(void *p) { nrq_host_free_pinned(p); }
 
-/* Encoder, all blocks: a pipeline of chunks of blocks -- chunk n+1 goes up (upload stream; straight out of a page-locked
- * context, or out of the blocks' page-locked host rows) while chunk n is solved (the context's stream).  Every block
- * keeps its intermediate symbols on the device, like after nanorq_generate_symbols. */
-size_t nanorq_generate_symbols_all(nanorq *rq, struct ioctx *io) {
-  nrq_ctx *c = ctx();
+/* the batched calls run one host thread per device over that device's blocks */
+struct all_job {
+  nanorq *rq;
+  struct ioctx *io;
+  int di;
+  bool dma;
+  uint8_t *base;
+  size_t rlen;
+  /* nanorq_decoder_add_symbols */
+  const uint8_t *pk;
+  const uint32_t *tags;
+  const uint32_t *rix;
+  uint32_t n;
+  const size_t *nrep0;
+  const uint8_t *touched;
+  bool ok;
+  /* nanorq_encode_range_all */
+  uint8_t *out;
+  uint32_t esi0;
+};
+static void for_devices(void *(*fn)(void *), struct all_job *tmpl, int nd) {
+  struct all_job jobs[NRQ_MAX_DEV];
+  pthread_t th[NRQ_MAX_DEV];
+  bool started[NRQ_MAX_DEV];
+  for (int d = 0; d < nd; d++) { jobs[d] = *tmpl; jobs[d].di = d; jobs[d].ok = true; started[d] = false; }
+  for (int d = 1; d < nd; d++) started[d] = pthread_create(&th[d], NULL, fn, &jobs[d]) == 0;
+  fn(&jobs[0]);
+  for (int d = 1; d < nd; d++) {
+    if (started[d]) pthread_join(th[d], NULL);
+    else fn(&jobs[d]); /* (no thread to be had: one after the other) */
+  }
+  tmpl->ok = true;
+  for (int d = 0; d < nd; d++) tmpl->ok = tmpl->ok && jobs[d].ok;
+}
+static int devices_for(nanorq *rq) { /* devices that hold blocks of this object */
+  const size_t Z = nanorq_blocks(rq);
+  return (size_t)ndev() < Z ? ndev() : (int)Z;
+}
+
+/* Encoder, all blocks: per device a pipeline of chunks of blocks -- chunk n+1 goes up (upload stream; straight out of a
+ * page-locked context, or out of the blocks' page-locked host rows) while chunk n is solved (the context's stream).  Every
+ * block keeps its intermediate symbols on the device, like after nanorq_generate_symbols. */
+static void *gen_all_worker(void *arg) {
+  struct all_job *j = arg;
+  nanorq *rq = j->rq;
+  const int di = j->di;
+  nrq_ctx *c = g_dev[di].c;
   const size_t Z = nanorq_blocks(rq), T = rq->T;
-  if (!c || !io) return 0;
-  uint8_t *base = NULL;
-  size_t rlen = 0;
-  const bool dma = ioctx_dma_region(io, &base, &rlen) && rq->N == 1 && rlen >= rq->F;
-  gpu_lock();
+  const bool dma = j->dma;
+  uint8_t *base = j->base;
+  gpu_lock(di);
   for (uint32_t cls = 0; cls < 2; cls++) {
-    /* the blocks of this size that still need the solve */
+    /* the blocks of this size on this device that still need the solve */
     unsigned todo[NRQ_Z_MAX], n = 0;
     uint32_t K = 0, Kp = 0, L = 0;
     for (unsigned sbn = 0; sbn < Z; sbn++) {
       if (class_of(rq, sbn) != cls) continue;
-      struct blockst *b = get_block(rq, (uint8_t)sbn);
-      if (!b || b->K == 0 || b->inverted) continue;
-      if (!dma && !b->loaded) b->loaded = load_block(rq, (uint8_t)sbn, b, io);
+      struct blockst *b = rq->blocks[sbn];
+      if (!b || b->di != di || b->K == 0 || b->inverted) continue;
       if (!dma && !b->loaded) continue;
       K = b->K; Kp = b->Kp; L = b->L;
       todo[n++] = sbn;
@@ -822,11 +902,84 @@ size_t nanorq_generate_symbols_all(nanorq *rq, struct ioctx *io) {
       nrq_event_free(solved[i]);
     }
   }
-  gpu_unlock();
+  gpu_unlock(di);
+  return NULL;
+}
+size_t nanorq_generate_symbols_all(nanorq *rq, struct ioctx *io) {
+  const size_t Z = nanorq_blocks(rq);
+  if (!ndev() || !io) return 0;
+  struct all_job j;
+  memset(&j, 0, sizeof(j));
+  j.rq = rq; j.io = io;
+  j.dma = ioctx_dma_region(io, &j.base, &j.rlen) && rq->N == 1 && j.rlen >= rq->F;
+  /* the blocks' state (and, without a page-locked context, their source rows: the context has ONE cursor) before the
+   * device threads start */
+  for (unsigned sbn = 0; sbn < Z; sbn++) {
+    struct blockst *b = get_block(rq, (uint8_t)sbn);
+    if (!b || b->K == 0 || b->inverted) continue;
+    if (!j.dma && !b->loaded) b->loaded = load_block(rq, (uint8_t)sbn, b, io);
+  }
+  for_devices(gen_all_worker, &j, devices_for(rq));
   size_t done = 0;
   for (unsigned sbn = 0; sbn < Z; sbn++)
     if (rq->blocks[sbn] && rq->blocks[sbn]->inverted) done++;
   return done;
+}
+
+/* Encoder: the repair symbols esi0 .. esi0+n-1 (esi0 >= K of every block) of ALL blocks in one go: `data` receives, block
+ * after block, n * T bytes each.  One generation launch per block, queued without waiting, and one download per device
+ * instead of a launch, a wait and a download per block (nanorq_encode_range). */
+static void *range_all_worker(void *arg) {
+  struct all_job *j = arg;
+  nanorq *rq = j->rq;
+  const int di = j->di;
+  nrq_ctx *c = g_dev[di].c;
+  const size_t Z = nanorq_blocks(rq), T = rq->T, per = (size_t)j->n * T;
+  uint32_t *isis = malloc((size_t)j->n * sizeof(uint32_t));
+  if (!isis) { j->ok = false; return NULL; }
+  gpu_lock(di);
+  /* device staging for a batch of blocks at a time */
+  unsigned mine[NRQ_Z_MAX], nm = 0;
+  for (unsigned sbn = 0; sbn < Z; sbn++)
+    if (rq->blocks[sbn] && rq->blocks[sbn]->di == di) mine[nm++] = sbn;
+  unsigned B = (unsigned)(((size_t)256 << 20) / (per ? per : 1));
+  if (B < 1) B = 1;
+  if (B > nm) B = nm;
+  void *d_out = NULL;
+  bool ok = nm == 0 || nrq_dev_alloc(c, per * B, &d_out) == 0;
+  for (unsigned b0 = 0; b0 < nm && ok; b0 += B) {
+    const unsigned m = nm - b0 < B ? nm - b0 : B;
+    for (unsigned k = 0; k < m && ok; k++) {
+      struct blockst *b = rq->blocks[mine[b0 + k]];
+      for (uint32_t q = 0; q < j->n; q++) isis[q] = j->esi0 + q + (b->Kp - b->K);
+      ok = nrq_gen_symbols(c, b->K, b->Kp, (uint32_t)T, 1, b->d_inter, (size_t)b->L * T, j->n, isis, (uint8_t *)d_out + per * k, per) == 0;
+    }
+    if (!ok) break;
+    /* blocks of one device are every N-th of the object: their pieces of `data` are apart, one copy each (download stream) */
+    ok = nrq_ctx_sync(c) == 0;
+    for (unsigned k = 0; k < m && ok; k++)
+      ok = nrq_copy_on(c, 2, j->out + per * mine[b0 + k], (uint8_t *)d_out + per * k, per) == 0;
+    ok = nrq_stream_sync(c, 2) == 0 && ok;
+  }
+  if (d_out) nrq_dev_free(c, d_out);
+  gpu_unlock(di);
+  free(isis);
+  j->ok = ok;
+  return NULL;
+}
+size_t nanorq_encode_range_all(nanorq *rq, void *data, uint32_t esi0, uint32_t n, struct ioctx *io) {
+  const size_t Z = nanorq_blocks(rq), T = rq->T;
+  if (!ndev() || !n || (uint64_t)esi0 + n > (1u << 24)) return 0;
+  for (unsigned sbn = 0; sbn < Z; sbn++) {
+    struct blockst *b = get_block(rq, (uint8_t)sbn);
+    if (!b || esi0 < b->K) return 0; /* repair symbols only */
+  }
+  if (nanorq_generate_symbols_all(rq, io) != Z) return 0;
+  struct all_job j;
+  memset(&j, 0, sizeof(j));
+  j.rq = rq; j.io = io; j.out = data; j.esi0 = esi0; j.n = n;
+  for_devices(range_all_worker, &j, devices_for(rq));
+  return j.ok ? Z * (size_t)n * T : 0;
 }
 
 size_t nanorq_encode_range(nanorq *rq, void *data, uint32_t esi0, uint32_t n, uint8_t sbn, struct ioctx *io) {
@@ -842,12 +995,12 @@ size_t nanorq_encode_range(nanorq *rq, void *data, uint32_t esi0, uint32_t n, ui
   }
   if (!left) return (size_t)n * T;
   if (!b->inverted) b->inverted = nanorq_generate_symbols(rq, sbn, io);
-  nrq_ctx *c = ctx();
+  nrq_ctx *c = dctx(b->di);
   if (!b->inverted || !c) return 0;
   /* repair symbols: generated on the device in one go, one download */
   uint32_t *isis = malloc((size_t)left * sizeof(uint32_t));
   void *d_out = NULL;
-  gpu_lock();
+  gpu_lock(b->di);
   bool ok = isis && nrq_dev_alloc(c, (size_t)left * T, &d_out) == 0;
   if (ok) {
     for (uint32_t k = 0; k < left; k++) isis[k] = esi + k + (b->Kp - b->K);
@@ -855,7 +1008,7 @@ size_t nanorq_encode_range(nanorq *rq, void *data, uint32_t esi0, uint32_t n, ui
          nrq_dev_download(c, out, d_out, (size_t)left * T) == 0;
   }
   if (d_out) nrq_dev_free(c, d_out);
-  gpu_unlock();
+  gpu_unlock(b->di);
   free(isis);
   return ok ? (size_t)n * T : 0;
 }
@@ -863,17 +1016,18 @@ size_t nanorq_encode_range(nanorq *rq, void *data, uint32_t esi0, uint32_t n, ui
 /* room for `need` repair symbols in a device-resident block's d_rep; an outgrown buffer is handed back through *old_out
  * (the caller frees it once the copy of its first `keep` symbols -- enqueued on the upload stream -- is done) */
 static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, size_t keep, void **old_out) {
-  nrq_ctx *c = ctx();
+  nrq_ctx *c = dctx(b->di);
   *old_out = NULL;
   if (need <= b->d_rep_cap) return true;
   size_t nc = b->d_rep_cap ? b->d_rep_cap * 2 : (b->K / 8 > 64 ? b->K / 8 : 64);
   while (nc < need) nc *= 2;
   void *p = NULL;
-  gpu_lock();
+  gpu_lock(b->di);
   bool ok = nrq_dev_alloc(c, nc * rq->T, &p) == 0;
   if (ok && b->d_rep && keep) ok = nrq_copy_on(c, 1, p, b->d_rep, keep * rq->T) == 0;
-  gpu_unlock();
-  if (!ok) { if (p) { gpu_lock(); nrq_dev_free(c, p); gpu_unlock(); } return false; }
+  if (!ok && p) nrq_dev_free(c, p);
+  gpu_unlock(b->di);
+  if (!ok) return false;
   *old_out = b->d_rep;
   b->d_rep = p;
   b->d_rep_cap = nc;
@@ -883,17 +1037,72 @@ static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, size_t k
 /* Decoder, many symbols.  With a page-locked packet buffer (and a page-locked or no output context, no sub-blocking)
  * the packets go to the GPU in one DMA copy and a kernel sorts them into their rows (nrq_scatter_symbols); the host
  * does the bookkeeping of nanorq_decoder_add_symbol (nanorq.c:478-509) and touches no symbol byte.  Otherwise: the
- * per-symbol call in a loop. */
+ * per-symbol call in a loop.  With several devices every device uploads the buffer and keeps the symbols of its own blocks. */
+enum { RIX_NONE = 0xFFFFFFFFu, RIX_SRC = 0xFFFFFFFEu };
+static void *add_all_worker(void *arg) {
+  struct all_job *j = arg;
+  nanorq *rq = j->rq;
+  const int di = j->di;
+  nrq_ctx *c = g_dev[di].c;
+  const size_t T = rq->T;
+  const uint32_t n = j->n;
+  uint64_t *dst = calloc(n ? n : 1, sizeof(uint64_t));
+  void *olds[NRQ_Z_MAX];
+  unsigned nold = 0;
+  bool ok = dst != NULL, any = false;
+  gpu_lock(di);
+  /* every touched block's repair rows to their final size (ONCE, keeping the rows held before the batch), then addresses */
+  for (unsigned sbn = 0; sbn < NRQ_Z_MAX && ok; sbn++) {
+    struct blockst *b = j->touched[sbn] ? rq->blocks[sbn] : NULL;
+    if (!b || b->di != di || b->nrep == j->nrep0[sbn]) continue;
+    void *old = NULL;
+    ok = dev_rep_reserve(rq, b, b->nrep, j->nrep0[sbn], &old);
+    if (old) olds[nold++] = old; /* (at most one per block) */
+  }
+  uint32_t k_lo = n, k_hi = 0; /* the stretch of the buffer that holds this device's symbols */
+  if (ok)
+    for (uint32_t k = 0; k < n; k++) {
+      if (j->rix[k] == RIX_NONE) continue;
+      struct blockst *b = rq->blocks[(uint8_t)(j->tags[k] >> 24)];
+      if (b->di != di) continue;
+      dst[k] = j->rix[k] == RIX_SRC ? (uint64_t)(uintptr_t)((uint8_t *)b->d_src + (size_t)(j->tags[k] & 0x00ffffffu) * T)
+                                    : (uint64_t)(uintptr_t)((uint8_t *)b->d_rep + (size_t)j->rix[k] * T);
+      if (k < k_lo) k_lo = k;
+      k_hi = k + 1u;
+      any = true;
+    }
+  if (any && ok) {
+    /* packets up in pieces, each sorted into its rows as soon as it has landed (same stream: the order is the stream's) */
+    void *d_blob = NULL;
+    const uint32_t piece = (uint32_t)((CHUNK_BYTES / T) ? (CHUNK_BYTES / T) : 1), span = k_hi - k_lo;
+    ok = nrq_dev_alloc(c, (size_t)(span < piece ? span : piece) * T, &d_blob) == 0;
+    for (uint32_t k0 = k_lo; k0 < k_hi && ok; k0 += piece) {
+      const uint32_t m = k_hi - k0 < piece ? k_hi - k0 : piece;
+      ok = nrq_copy_on(c, 1, d_blob, j->pk + (size_t)k0 * T, (size_t)m * T) == 0 && nrq_scatter_symbols(c, 1, d_blob, m, (uint32_t)T, dst + k0) == 0;
+    }
+    ok = nrq_stream_sync(c, 1) == 0 && ok;
+    if (d_blob) nrq_dev_free(c, d_blob);
+  } else {
+    ok = nrq_stream_sync(c, 1) == 0 && ok;
+  }
+  for (unsigned i = 0; i < nold; i++) nrq_dev_free(c, olds[i]);
+  gpu_unlock(di);
+  free(dst);
+  j->ok = ok;
+  return NULL;
+}
 size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io) {
   size_t added = 0;
   const uint8_t *p = data;
   const size_t T = rq->T;
-  nrq_ctx *c = ctx();
   uint8_t *obase;
   size_t olen;
-  const bool dma = c && n >= 16 && rq->N == 1 && nrq_host_is_pinned(data) && (!io || (ioctx_dma_region(io, &obase, &olen) && olen >= rq->F));
-  uint64_t *dst = dma ? calloc(n, sizeof(uint64_t)) : NULL;
-  if (!dst) {
+  const bool dma = ndev() && n >= 16 && rq->N == 1 && nrq_host_is_pinned(data) && (!io || (ioctx_dma_region(io, &obase, &olen) && olen >= rq->F));
+  /* Bookkeeping first, addresses afterwards: a repair symbol is recorded as (block, index in the block's repair rows) while
+   * the loop runs; only when the batch's final repair count of every block is known are the blocks' device rows grown and
+   * the indices turned into addresses (add_all_worker). */
+  uint32_t *rix = dma ? malloc((size_t)n * sizeof(uint32_t)) : NULL; /* per symbol: index of its repair row, or RIX_* */
+  if (!rix) {
     for (uint32_t k = 0; k < n; k++) {
       /* (add_symbol copies; the const is cast away only because the per-symbol signature of the reference is void *) */
       const int r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * T), tags[k], io);
@@ -902,29 +1111,11 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
     }
     return added;
   }
-  /* Bookkeeping first, addresses afterwards: a repair symbol is recorded as (block, index in the block's repair rows) while
-   * the loop runs, and only when the batch's final repair count of every block is known is the block's d_rep grown -- ONCE,
-   * keeping the rows it held before the batch -- and the index turned into an address.  (Growing inside the loop left the
-   * addresses of the batch's earlier symbols pointing into the outgrown buffer.) */
-  void *olds[NRQ_Z_MAX];
-  unsigned nold = 0;
-  uint32_t nput = 0;
   size_t nrep0[NRQ_Z_MAX];                 /* repair symbols a touched block held before this batch */
   uint8_t touched[NRQ_Z_MAX], newdev[NRQ_Z_MAX];
-  uint32_t *rix = malloc((size_t)n * sizeof(uint32_t)); /* per symbol: index of its repair row, or RIX_* */
-  enum { RIX_NONE = 0xFFFFFFFFu, RIX_SRC = 0xFFFFFFFEu };
-  if (!rix) { free(dst); dst = NULL; }
-  if (!dst) {
-    for (uint32_t k = 0; k < n; k++) {
-      const int r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * T), tags[k], io);
-      if (results) results[k] = r;
-      if (r == NANORQ_SYM_ADDED) added++;
-    }
-    return added;
-  }
   memset(touched, 0, sizeof(touched));
   memset(newdev, 0, sizeof(newdev));
-  gpu_lock();
+  uint32_t nput = 0;
   for (uint32_t k = 0; k < n; k++) {
     const uint8_t sbn = (uint8_t)(tags[k] >> 24);
     const uint32_t esi = tags[k] & 0x00ffffffu;
@@ -939,9 +1130,12 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
       r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * T), tags[k], io);
     } else {
       if (!b->dev) { /* first symbol of the block: it becomes device-resident */
+        nrq_ctx *c = dctx(b->di);
+        gpu_lock(b->di);
         if (!b->d_src && nrq_dev_alloc(c, (size_t)b->K * T, &b->d_src) != 0) r = NANORQ_SYM_ERR;
         else if (nrq_memset_on(c, 1, b->d_src, 0, (size_t)b->K * T) != 0) r = NANORQ_SYM_ERR;
         else { b->dev = true; newdev[sbn] = 1; }
+        gpu_unlock(b->di);
       }
       if (r == NANORQ_SYM_ADDED && !touched[sbn]) { touched[sbn] = 1; nrep0[sbn] = b->nrep; }
       if (r == NANORQ_SYM_ADDED && esi < b->K) {
@@ -958,37 +1152,12 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
     if (results) results[k] = r;
     if (r == NANORQ_SYM_ADDED) added++;
   }
-  bool ok = true;
-  /* every touched block's repair rows to their final size, then the addresses */
-  for (unsigned sbn = 0; sbn < NRQ_Z_MAX && ok; sbn++) {
-    struct blockst *b = touched[sbn] ? rq->blocks[sbn] : NULL;
-    if (!b || b->nrep == nrep0[sbn]) continue;
-    void *old = NULL;
-    ok = dev_rep_reserve(rq, b, b->nrep, nrep0[sbn], &old);
-    if (old) olds[nold++] = old; /* (at most one per block: nold <= NRQ_Z_MAX) */
-  }
-  if (ok)
-    for (uint32_t k = 0; k < n; k++) {
-      if (rix[k] == RIX_NONE) continue;
-      struct blockst *b = rq->blocks[(uint8_t)(tags[k] >> 24)];
-      dst[k] = rix[k] == RIX_SRC ? (uint64_t)(uintptr_t)((uint8_t *)b->d_src + (size_t)(tags[k] & 0x00ffffffu) * T)
-                                 : (uint64_t)(uintptr_t)((uint8_t *)b->d_rep + (size_t)rix[k] * T);
-    }
-  if (nput && ok) {
-    /* packets up in pieces, each sorted into its rows as soon as it has landed (same stream: the order is the stream's) */
-    void *d_blob = NULL;
-    const uint32_t piece = (uint32_t)((CHUNK_BYTES / T) ? (CHUNK_BYTES / T) : 1);
-    ok = nrq_dev_alloc(c, (size_t)(n < piece ? n : piece) * T, &d_blob) == 0;
-    for (uint32_t k0 = 0; k0 < n && ok; k0 += piece) {
-      const uint32_t m = n - k0 < piece ? n - k0 : piece;
-      ok = nrq_copy_on(c, 1, d_blob, p + (size_t)k0 * T, (size_t)m * T) == 0 && nrq_scatter_symbols(c, 1, d_blob, m, (uint32_t)T, dst + k0) == 0;
-    }
-    ok = nrq_stream_sync(c, 1) == 0 && ok;
-    if (d_blob) nrq_dev_free(c, d_blob);
-  } else {
-    ok = nrq_stream_sync(c, 1) == 0 && ok;
-  }
-  if (!ok) {
+  struct all_job j;
+  memset(&j, 0, sizeof(j));
+  j.rq = rq; j.io = io; j.pk = p; j.tags = tags; j.rix = rix; j.n = n; j.nrep0 = nrep0; j.touched = touched;
+  (void)nput;
+  for_devices(add_all_worker, &j, ndev()); /* (also with nothing to put: the memsets of new blocks are waited for) */
+  if (!j.ok) {
     /* The bytes did not reach the device rows: take the batch's bookkeeping back, so that the decoder does not believe in
      * symbols it does not hold (they can be sent again), and say so symbol by symbol. */
     for (uint32_t k = 0; k < n; k++) {
@@ -1009,122 +1178,133 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
       if (rix[k] == RIX_SRC) rq->blocks[(uint8_t)(tags[k] >> 24)]->dirty = true;
   }
   free(rix);
-  for (unsigned i = 0; i < nold; i++) nrq_dev_free(c, olds[i]);
-  gpu_unlock();
-  free(dst);
   return added;
 }
 
-/* Decoder, all blocks that can be repaired: per block size a pipeline of chunks -- host-resident blocks go up chunk by
- * chunk (upload stream), the chunk is decoded (the context's stream), the decoded blocks come down (download stream)
+/* Decoder, all blocks that can be repaired: per device and block size a pipeline of chunks -- host-resident blocks go up chunk
+ * by chunk (upload stream), the chunk is decoded (the context's stream), the decoded blocks come down (download stream)
  * beside the next chunk's decode; device-resident blocks skip the upload.  What comes down: whole blocks into a
  * page-locked output context, else the blocks' host rows and the repaired symbols from there through the context. */
-size_t nanorq_repair_all(nanorq *rq, struct ioctx *io) {
-  nrq_ctx *c = ctx();
+static void *repair_all_worker(void *arg) {
+  struct all_job *j = arg;
+  nanorq *rq = j->rq;
+  struct ioctx *io = j->io;
+  const int di = j->di;
+  nrq_ctx *c = g_dev[di].c;
   const size_t Z = nanorq_blocks(rq), T = rq->T;
-  if (c) {
-    gpu_lock();
-    for (uint32_t cls = 0; cls < 2; cls++) {
-      unsigned todo[NRQ_Z_MAX], n = 0;
-      uint32_t K = 0, Kp = 0;
-      size_t lost_cap = 0, rep_cap = 0;
-      for (unsigned sbn = 0; sbn < Z; sbn++) {
-        if (class_of(rq, sbn) != cls) continue;
-        struct blockst *b = rq->blocks[sbn];
-        if (!b || b->K == 0) continue;
-        const size_t gaps = mask_gaps(b, b->K);
-        if (gaps == 0) { /* complete; a device-resident block may still owe the output its received symbols */
-          if (b->dev && b->dirty && io && flush_dev_block(rq, (uint8_t)sbn, b, io, true)) b->dirty = false; /* (the sync is at the end) */
+  gpu_lock(di);
+  for (uint32_t cls = 0; cls < 2; cls++) {
+    unsigned todo[NRQ_Z_MAX], n = 0;
+    uint32_t K = 0, Kp = 0;
+    size_t lost_cap = 0, rep_cap = 0;
+    for (unsigned sbn = 0; sbn < Z; sbn++) {
+      if (class_of(rq, sbn) != cls) continue;
+      struct blockst *b = rq->blocks[sbn];
+      if (!b || b->di != di || b->K == 0) continue;
+      const size_t gaps = mask_gaps(b, b->K);
+      if (gaps == 0) { /* complete; a device-resident block may still owe the output its received symbols */
+        if (b->dev && b->dirty && io && flush_dev_block(rq, (uint8_t)sbn, b, io, true)) b->dirty = false; /* (the sync is at the end) */
+        continue;
+      }
+      if (b->nrep < gaps || b->nrep - gaps > b->spare) continue; /* as nanorq_repair_block */
+      K = b->K; Kp = b->Kp;
+      if (gaps > lost_cap) lost_cap = gaps;
+      if (b->nrep > rep_cap) rep_cap = b->nrep;
+      todo[n++] = sbn;
+    }
+    if (!n) continue;
+    const size_t sbytes = (size_t)K * T;
+    /* chunks: each costs a planner launch the host waits for (~3 ms whatever the number of blocks) before its solve
+     * can go, and only the download of the chunk BEFORE runs beside it: few, big chunks (two to four) */
+    unsigned C = (unsigned)(REPAIR_CHUNK_BYTES / sbytes);
+    if (C < 1) C = 1;
+    if (C > n) C = n;
+    if (C == n && n >= 8 && (size_t)n * sbytes >= ((size_t)128 << 20)) C = (n + 1) / 2; /* at least two, so that something overlaps */
+    uint32_t *lost = calloc((size_t)C * lost_cap, sizeof(uint32_t)), *nlost = calloc(C, sizeof(uint32_t));
+    uint32_t *resi = calloc((size_t)C * rep_cap, sizeof(uint32_t)), *nuse = calloc(C, sizeof(uint32_t)), *navail = calloc(C, sizeof(uint32_t));
+    int *status = calloc(C, sizeof(int));
+    uint64_t *sv = calloc(C, sizeof(uint64_t)), *rv = calloc(C, sizeof(uint64_t));
+    void *ev_up = NULL, *ev_dec = NULL;
+    void *tmp_rep[NRQ_Z_MAX]; /* device copies of host-resident blocks' repair symbols (freed at the end) */
+    unsigned ntmp = 0;
+    bool ok = lost && nlost && resi && nuse && navail && status && sv && rv && nrq_event_new(c, &ev_up) == 0 && nrq_event_new(c, &ev_dec) == 0;
+    for (unsigned c0 = 0; c0 < n && ok; c0 += C) {
+      const unsigned m = n - c0 < C ? n - c0 : C;
+      bool any_up = false;
+      for (unsigned k = 0; k < m && ok; k++) {
+        struct blockst *b = rq->blocks[todo[c0 + k]];
+        nlost[k] = list_lost(b, lost + (size_t)k * lost_cap);
+        nuse[k] = rep_upfront(nlost[k], b->nrep);
+        navail[k] = (uint32_t)b->nrep;
+        memcpy(resi + (size_t)k * rep_cap, b->rep_esi, b->nrep * sizeof(uint32_t));
+        if (!b->dev) { /* host-resident: rows and repair symbols go up now */
+          void *d_rep = NULL;
+          ok = ensure_src(rq, b) && (b->d_src || nrq_dev_alloc(c, sbytes, &b->d_src) == 0) && nrq_dev_alloc(c, b->nrep * T, &d_rep) == 0 &&
+               nrq_copy_on(c, 1, b->d_src, b->src, sbytes) == 0 && nrq_copy_on(c, 1, d_rep, b->rep_data, b->nrep * T) == 0;
+          if (d_rep) tmp_rep[ntmp++] = d_rep;
+          rv[k] = (uint64_t)(uintptr_t)d_rep;
+          any_up = true;
+        } else {
+          rv[k] = (uint64_t)(uintptr_t)b->d_rep;
+        }
+        sv[k] = (uint64_t)(uintptr_t)b->d_src;
+      }
+      if (any_up) ok = ok && nrq_event_record(c, ev_up, 1) == 0 && nrq_stream_wait(c, 0, ev_up) == 0;
+      ok = ok && nrq_decode_blocks_v(c, K, Kp, (uint32_t)T, m, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv,
+                                     status, NULL) == 0 &&
+           nrq_event_record(c, ev_dec, 0) == 0 && nrq_stream_wait(c, 2, ev_dec) == 0;
+      for (unsigned k = 0; k < m && ok; k++) { /* the decoded blocks come down beside the next chunk's decode */
+        struct blockst *b = rq->blocks[todo[c0 + k]];
+        const uint8_t sbn = (uint8_t)todo[c0 + k];
+        if (!status[k]) { /* rank deficient: retry after more symbols (nanorq.c:620-623); what was received is written */
+          if (b->dev && b->dirty && io && flush_dev_block(rq, sbn, b, io, false)) b->dirty = false;
           continue;
         }
-        if (b->nrep < gaps || b->nrep - gaps > b->spare) continue; /* as nanorq_repair_block */
-        K = b->K; Kp = b->Kp;
-        if (gaps > lost_cap) lost_cap = gaps;
-        if (b->nrep > rep_cap) rep_cap = b->nrep;
-        todo[n++] = sbn;
+        if (b->dev) {
+          if (io) ok = flush_dev_block(rq, sbn, b, io, true);
+          for (uint32_t q = 0; q < nlost[k]; q++) mask_set(b, lost[(size_t)k * lost_cap + q]);
+          if (io && ok) b->dirty = false;
+        } else {
+          ok = nrq_copy_on(c, 2, b->src, b->d_src, sbytes) == 0;
+        }
       }
-      if (!n) continue;
-      const size_t sbytes = (size_t)K * T;
-      /* chunks: each costs a planner launch the host waits for (~3 ms whatever the number of blocks) before its solve
-       * can go, and only the download of the chunk BEFORE runs beside it: few, big chunks (two to four) */
-      unsigned C = (unsigned)(REPAIR_CHUNK_BYTES / sbytes);
-      if (C < 1) C = 1;
-      if (C > n) C = n;
-      if (C == n && n >= 8 && (size_t)n * sbytes >= ((size_t)128 << 20)) C = (n + 1) / 2; /* at least two, so that something overlaps */
-      uint32_t *lost = calloc((size_t)C * lost_cap, sizeof(uint32_t)), *nlost = calloc(C, sizeof(uint32_t));
-      uint32_t *resi = calloc((size_t)C * rep_cap, sizeof(uint32_t)), *nuse = calloc(C, sizeof(uint32_t)), *navail = calloc(C, sizeof(uint32_t));
-      int *status = calloc(C, sizeof(int));
-      uint64_t *sv = calloc(C, sizeof(uint64_t)), *rv = calloc(C, sizeof(uint64_t));
-      void *ev_up = NULL, *ev_dec = NULL;
-      void *tmp_rep[NRQ_Z_MAX]; /* device copies of host-resident blocks' repair symbols (freed at the end) */
-      unsigned ntmp = 0;
-      bool ok = lost && nlost && resi && nuse && navail && status && sv && rv && nrq_event_new(c, &ev_up) == 0 && nrq_event_new(c, &ev_dec) == 0;
-      for (unsigned c0 = 0; c0 < n && ok; c0 += C) {
-        const unsigned m = n - c0 < C ? n - c0 : C;
-        bool any_up = false;
+      /* host-resident blocks: their repaired symbols go through the context once the rows are down */
+      bool any_host = false;
+      for (unsigned k = 0; k < m; k++) any_host = any_host || (status[k] && !rq->blocks[todo[c0 + k]]->dev);
+      if (any_host && ok) {
+        ok = nrq_stream_sync(c, 2) == 0;
+        pthread_mutex_lock(&g_io_lock);
         for (unsigned k = 0; k < m && ok; k++) {
           struct blockst *b = rq->blocks[todo[c0 + k]];
-          nlost[k] = list_lost(b, lost + (size_t)k * lost_cap);
-          nuse[k] = rep_upfront(nlost[k], b->nrep);
-          navail[k] = (uint32_t)b->nrep;
-          memcpy(resi + (size_t)k * rep_cap, b->rep_esi, b->nrep * sizeof(uint32_t));
-          if (!b->dev) { /* host-resident: rows and repair symbols go up now */
-            void *d_rep = NULL;
-            ok = ensure_src(rq, b) && (b->d_src || nrq_dev_alloc(c, sbytes, &b->d_src) == 0) && nrq_dev_alloc(c, b->nrep * T, &d_rep) == 0 &&
-                 nrq_copy_on(c, 1, b->d_src, b->src, sbytes) == 0 && nrq_copy_on(c, 1, d_rep, b->rep_data, b->nrep * T) == 0;
-            if (d_rep) tmp_rep[ntmp++] = d_rep;
-            rv[k] = (uint64_t)(uintptr_t)d_rep;
-            any_up = true;
-          } else {
-            rv[k] = (uint64_t)(uintptr_t)b->d_rep;
-          }
-          sv[k] = (uint64_t)(uintptr_t)b->d_src;
-        }
-        if (any_up) ok = ok && nrq_event_record(c, ev_up, 1) == 0 && nrq_stream_wait(c, 0, ev_up) == 0;
-        ok = ok && nrq_decode_blocks_v(c, K, Kp, (uint32_t)T, m, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv,
-                                       status, NULL) == 0 &&
-             nrq_event_record(c, ev_dec, 0) == 0 && nrq_stream_wait(c, 2, ev_dec) == 0;
-        for (unsigned k = 0; k < m && ok; k++) { /* the decoded blocks come down beside the next chunk's decode */
-          struct blockst *b = rq->blocks[todo[c0 + k]];
-          const uint8_t sbn = (uint8_t)todo[c0 + k];
-          if (!status[k]) { /* rank deficient: retry after more symbols (nanorq.c:620-623); what was received is written */
-            if (b->dev && b->dirty && io && flush_dev_block(rq, sbn, b, io, false)) b->dirty = false;
-            continue;
-          }
-          if (b->dev) {
-            if (io) ok = flush_dev_block(rq, sbn, b, io, true);
-            for (uint32_t j = 0; j < nlost[k]; j++) mask_set(b, lost[(size_t)k * lost_cap + j]);
-            if (io && ok) b->dirty = false;
-          } else {
-            ok = nrq_copy_on(c, 2, b->src, b->d_src, sbytes) == 0;
+          if (!status[k] || b->dev) continue;
+          for (uint32_t q = 0; q < nlost[k]; q++) {
+            const uint32_t e = lost[(size_t)k * lost_cap + q];
+            if (io) transfer_symbol(rq, (uint8_t)todo[c0 + k], e, b->K, b->src + (size_t)e * T, io, 1);
+            mask_set(b, e);
           }
         }
-        /* host-resident blocks: their repaired symbols go through the context once the rows are down */
-        bool any_host = false;
-        for (unsigned k = 0; k < m; k++) any_host = any_host || (status[k] && !rq->blocks[todo[c0 + k]]->dev);
-        if (any_host && ok) {
-          ok = nrq_stream_sync(c, 2) == 0;
-          for (unsigned k = 0; k < m && ok; k++) {
-            struct blockst *b = rq->blocks[todo[c0 + k]];
-            if (!status[k] || b->dev) continue;
-            for (uint32_t j = 0; j < nlost[k]; j++) {
-              const uint32_t e = lost[(size_t)k * lost_cap + j];
-              if (io) transfer_symbol(rq, (uint8_t)todo[c0 + k], e, b->K, b->src + (size_t)e * T, io, 1);
-              mask_set(b, e);
-            }
-          }
-        }
+        pthread_mutex_unlock(&g_io_lock);
       }
-      nrq_ctx_sync(c);
-      nrq_stream_sync(c, 1);
-      nrq_stream_sync(c, 2);
-      for (unsigned i = 0; i < ntmp; i++) nrq_dev_free(c, tmp_rep[i]);
-      nrq_event_free(ev_up);
-      nrq_event_free(ev_dec);
-      free(lost); free(nlost); free(resi); free(nuse); free(navail); free(status); free(sv); free(rv);
     }
+    nrq_ctx_sync(c);
+    nrq_stream_sync(c, 1);
     nrq_stream_sync(c, 2);
-    gpu_unlock();
+    for (unsigned i = 0; i < ntmp; i++) nrq_dev_free(c, tmp_rep[i]);
+    nrq_event_free(ev_up);
+    nrq_event_free(ev_dec);
+    free(lost); free(nlost); free(resi); free(nuse); free(navail); free(status); free(sv); free(rv);
+  }
+  nrq_stream_sync(c, 2);
+  gpu_unlock(di);
+  return NULL;
+}
+size_t nanorq_repair_all(nanorq *rq, struct ioctx *io) {
+  const size_t Z = nanorq_blocks(rq);
+  if (ndev()) {
+    struct all_job j;
+    memset(&j, 0, sizeof(j));
+    j.rq = rq; j.io = io;
+    for_devices(repair_all_worker, &j, devices_for(rq));
   }
   size_t complete = 0;
   for (unsigned sbn = 0; sbn < Z; sbn++) {
@@ -1135,16 +1315,38 @@ size_t nanorq_repair_all(nanorq *rq, struct ioctx *io) {
 }
 
 size_t nanorq_decoder_flush(nanorq *rq, struct ioctx *io) {
-  nrq_ctx *c = ctx();
-  if (!c || !io) return 0;
+  if (!ndev() || !io) return 0;
   size_t nflushed = 0;
-  gpu_lock();
   for (unsigned sbn = 0; sbn < NRQ_Z_MAX; sbn++) {
     struct blockst *b = rq->blocks[sbn];
     if (!b || !b->dev || !b->dirty) continue;
+    gpu_lock(b->di);
     if (flush_dev_block(rq, (uint8_t)sbn, b, io, mask_gaps(b, b->K) == 0)) { b->dirty = false; nflushed++; }
+    gpu_unlock(b->di);
   }
-  nrq_stream_sync(c, 2);
-  gpu_unlock();
+  for (int d = 0; d < g_ndev; d++) {
+    gpu_lock(d);
+    nrq_stream_sync(g_dev[d].c, 2);
+    gpu_unlock(d);
+  }
   return nflushed;
+}
+
+/* Give back what the layer caches between objects: the page-locked host rows of freed objects (up to 8 GiB) and the
+ * device pools of every context (up to 24 GiB each).  For long-lived processes after a large object. */
+void nanorq_trim(void) {
+  pthread_mutex_lock(&g_pin_lock);
+  for (int i = 0; i < PIN_CACHE_SLOTS; i++)
+    if (g_pin_cache[i].p) {
+      nrq_host_free_pinned((uint8_t *)g_pin_cache[i].p - 64);
+      g_pin_cache[i].p = NULL;
+      g_pin_cache[i].cap = 0;
+    }
+  g_pin_cached = 0;
+  pthread_mutex_unlock(&g_pin_lock);
+  for (int d = 0; d < ndev(); d++) {
+    gpu_lock(d);
+    nrq_dev_trim(g_dev[d].c);
+    gpu_unlock(d);
+  }
 }

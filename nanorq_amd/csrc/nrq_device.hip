@@ -1081,6 +1081,9 @@ int encplan_device_launch(nrq_ctx *ctx, const rq_params &p, uint32_t K, KConst *
   int rc;
   if ((rc = ensure_encbuf(ctx, ep, buf, dev_total))) return rc;
   if ((rc = ensure_dev(ctx, ctx->encplan_work, wl.total))) return rc;
+  /* (the pinned image may still be the source of a host-built plan's asynchronous upload: encplan_host_build after a failed
+   * device build -- wait for it before the job record is written over its first bytes) */
+  HIPCHK(ctx, hipEventSynchronize(ctx->encplan_uploaded));
   if (ep.pin_cap < pin_total) {
     if (ep.pin) HIPCHK(ctx, hipHostFree(ep.pin));
     ep.pin = nullptr;
@@ -1557,6 +1560,7 @@ const char *nrq_ctx_error(nrq_ctx *ctx) { return ctx ? ctx->err.c_str() : "no co
 
 int nrq_ctx_sync(nrq_ctx *ctx) {
   if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -2139,12 +2143,12 @@ int nrq_dev_trim(nrq_ctx *ctx) {
 int nrq_host_alloc_pinned(size_t bytes, void **out) {
   if (!out) return -1;
   *out = nullptr;
-  return hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? 0 : -10;
+  return hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocPortable) == hipSuccess ? 0 : -10; /* (every device of the process may DMA it) */
 }
 void nrq_host_free_pinned(void *p) {
   if (p) (void)hipHostFree(p);
 }
-int nrq_host_register(void *p, size_t bytes) { return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? 0 : -10; }
+int nrq_host_register(void *p, size_t bytes) { return hipHostRegister(p, bytes, hipHostRegisterPortable) == hipSuccess ? 0 : -10; }
 void nrq_host_unregister(void *p) {
   if (p) (void)hipHostUnregister(p);
 }
@@ -2174,6 +2178,7 @@ int nrq_memset_on(nrq_ctx *ctx, int stream, void *d_dst, int value, size_t bytes
 int nrq_event_new(nrq_ctx *ctx, void **out) {
   if (!ctx || !out) return -1;
   hipEvent_t e;
+  HIPCHK(ctx, hipSetDevice(ctx->device)); /* (an event belongs to the device that is current when it is created) */
   HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *out = e;
   return 0;
@@ -2183,11 +2188,13 @@ void nrq_event_free(void *ev) {
 }
 int nrq_event_record(nrq_ctx *ctx, void *ev, int stream) {
   if (!ctx || !ev) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipEventRecord((hipEvent_t)ev, sel_stream(ctx, stream)));
   return 0;
 }
 int nrq_stream_wait(nrq_ctx *ctx, int stream, void *ev) {
   if (!ctx || !ev) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamWaitEvent(sel_stream(ctx, stream), (hipEvent_t)ev, 0));
   return 0;
 }

@@ -50,6 +50,7 @@ def lib():
         L.orc_decode_block_kp.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u8p, u8p,
                                           C.POINTER(Stats)]
         L.orc_plan_probe.argtypes = [C.c_uint32, C.c_uint32, u32p, C.POINTER(Stats)]
+        L.orc_encode_block_cached.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.c_uint32, u32p, u8p]
         _LIB = L
     return _LIB
 
@@ -126,6 +127,17 @@ def encode_block(src, K, T, repair_esis=(), want_inter=False, Kp=0):
     if not ok:
         raise RuntimeError("oracle encode failed")
     return rep[:len(esis)], inter, st.as_dict()
+
+
+def encode_block_cached(src, K, T, repair_esis=(), Kp=0):
+    """encode_block with the schedule kept from the previous call of the same (K, K') -- the reference's precalculated
+    encoder (nanorq_precalculate).  Returns repair[nrep, T]."""
+    src = np.ascontiguousarray(src, dtype=np.uint8).reshape(K, T)
+    esis = np.ascontiguousarray(repair_esis, dtype=np.uint32)
+    rep = np.zeros((max(len(esis), 1), T), np.uint8)
+    if not lib().orc_encode_block_cached(K, Kp, T, _u8(src), len(esis), _u32(esis) if len(esis) else None, _u8(rep)):
+        raise RuntimeError("oracle encode failed")
+    return rep[:len(esis)]
 
 
 def decode_block(esis, syms, K, T, Kp=0):

@@ -739,6 +739,33 @@ int orc_encode_block(uint32_t K, uint32_t T, const uint8_t *src, uint8_t *inter,
   return orc_encode_block_kp(K, 0, T, src, inter, nrep, esis, rep, st);
 }
 
+/* Encode with a kept schedule: the reference's nanorq_precalculate (nanorq.c:393-401) builds the schedule of the encoding
+ * matrix once per object and nanorq_generate_symbols replays it for every block (nanorq.c:216-224).  One schedule is kept
+ * here, for the last (K, K') asked for (not thread safe: bench.py's single-core "precalc" baseline is its only caller). */
+int orc_encode_block_cached(uint32_t K, uint32_t Kp, uint32_t T, const uint8_t *src, uint32_t nrep, const uint32_t *esis,
+                            uint8_t *rep) {
+  static plan_t *kept;
+  static uint32_t kept_K, kept_Kp;
+  orc_params_t p;
+  gf_init();
+  if (!derive_params_kp(K, Kp, &p) || T == 0) return 0;
+  if (!kept || kept_K != K || kept_Kp != p.Kp) {
+    if (kept) plan_free(kept);
+    kept = make_plan(&p, build_constraints(&p, 0));
+    kept_K = K; kept_Kp = p.Kp;
+    if (!kept) return 0;
+  }
+  size_t ld = ((size_t)T + 31u) & ~(size_t)31u;
+  uint8_t *D = (uint8_t *)aligned_alloc(64, (size_t)p.L * ld);
+  uint8_t *C = (uint8_t *)aligned_alloc(64, (size_t)p.L * ld);
+  memset(D, 0, (size_t)p.L * ld);
+  for (uint32_t e = 0; e < K; e++) memcpy(D + (size_t)(p.S + p.H + e) * ld, src + (size_t)e * T, T);
+  replay_plan(&p, kept, D, ld, T, C, ld, NULL);
+  for (uint32_t k = 0; k < nrep; k++) lt_symbol(&p, C, ld, T, esis[k] + (p.Kp - K), rep + (size_t)k * T);
+  free(D); free(C);
+  return 1;
+}
+
 /* Decode one source block from received symbols in ARRIVAL order
  * (reference nanorq.c:478-509 add_symbol, :527-631 repair_block).
  *   esis[n], syms[n*T]; out: K*T bytes (received source symbols are written through, recovered

@@ -90,6 +90,12 @@ def api():
         L.nanorq_pinned_free.argtypes = [vp]
         L.nanorq_decoder_flush.restype = C.c_size_t
         L.nanorq_decoder_flush.argtypes = [vp, iop]
+        L.nanorq_encode_range_all.restype = C.c_size_t
+        L.nanorq_encode_range_all.argtypes = [vp, vp, C.c_uint32, C.c_uint32, iop]
+        L.nanorq_devices.restype = C.c_size_t
+        L.nanorq_devices.argtypes = []
+        L.nanorq_trim.restype = None
+        L.nanorq_trim.argtypes = []
         L.nanorq_encoder_new_ext.restype = vp
         L.nanorq_encoder_new_ext.argtypes = [C.c_size_t, C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint8, C.c_uint32]
         L.nanorq_decoder_new_ext.restype = vp

@@ -2,6 +2,8 @@
 decode.c / benchmark.c do, through the same calls, with the solve on the GPU."""
 import ctypes as C
 import hashlib
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -463,3 +465,38 @@ def test_sub_blocking(orc, N, T, F):
     assert want[0].tobytes() == rep[0][1]
     src = [(t & 0xffffff, p) for t, p in pk if (t >> 24) == 0 and (t & 0xffffff) < k0]
     assert src[0][1] == sym[src[0][0]].tobytes()
+
+
+def _devices_run(env_devices, K, T, Z, loss):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("NANORQ_HIP_DEVICES", None)
+    if env_devices:
+        env["NANORQ_HIP_DEVICES"] = env_devices
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "devices_worker.py"),
+                        str(K), str(T), str(Z), str(loss)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().split("\n")[-1])
+
+
+def test_object_spread_over_two_contexts_gives_the_same_packets():
+    """NANORQ_HIP_DEVICES names the GPUs; block sbn lives on device sbn mod N and the batched calls run one host
+    thread per device.  Two contexts on GPU 0 (the box has one GPU) against the single-context run: same packets, same
+    recovered object (reference: blocks share nothing, lib/nanorq.c:97-112)."""
+    one = _devices_run("", 600, 320, 7, 0.1)
+    two = _devices_run("0,0", 600, 320, 7, 0.1)
+    three = _devices_run("0,0,0", 600, 320, 7, 0.1)
+    assert one["devices"] == 1 and two["devices"] == 2 and three["devices"] == 3
+    assert one["ok"] and two["ok"] and three["ok"]
+    assert one["packets"] == two["packets"] == three["packets"]
+    assert one["object"] == two["object"] == three["object"]
+
+
+def test_one_batch_with_many_repair_symbols_per_block():
+    """A single nanorq_decoder_add_symbols batch that carries more repair symbols for a block than its device rows hold at
+    first (max(K/8, 64)): the rows are grown once, after the batch's bookkeeping, and every symbol of the batch lands in the
+    grown buffer (was: the earlier ones were scattered into the outgrown buffer and the block decoded from garbage)."""
+    r = _devices_run("", 1000, 256, 3, 0.2)
+    assert r["max_repair_per_block"] > 1000 // 8
+    assert r["ok"], r

@@ -3,7 +3,7 @@
 # the reference's chart) through bench.py, one JSON line each into gpurun_out/cfg/ -- copy what is to be judged to profiles/.
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/bench_configs.sh [tag]'
 REPO=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=$REPO/gpurun_out/cfg
 mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
@@ -25,6 +25,10 @@ run cfg1_K100_T1024      100  1024 8192 0.06 0
 run cfg2_K1024_T1280    1024  1280 2048 0.05 0
 run cfg4_K27000_T65504 27000 65504    1 0.10 0 0
 run cfg5_K56403_T1280  56403  1280    8 0.20 0 1
+# the XOR-only path (overhead >= H: no GF(256) work, reference precode.c:362-363) and the small-overhead variants of SURVEY 8(d)
+run cfg2_K1024_oh52     1024  1280 2048 0.06 52
+run cfg3_K8192_oh2      8192  1280  256 0.10 2
+run cfg5_K56403_oh16   56403  1280    8 0.20 16 1
 run K1000_T1280         1000  1280 2048 0.06 0
 run K500_T1280           500  1280 4096 0.06 0
 run K5000_T1280         5000  1280  512 0.06 0

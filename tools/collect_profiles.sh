@@ -2,10 +2,10 @@
 # Runs ON THE GPU BOX (through gpurun): the default bench line (with its own live PMC passes), the rocprofv3 kernel trace
 # of the same command, the PMC passes again as a stand-alone file, and the other BASELINE configs -- all into
 # gpurun_out/prof/ (copy what you want judged into profiles/).
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r2'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r3'
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=$REPO/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
