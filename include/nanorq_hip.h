@@ -57,7 +57,8 @@ int nrq_ctx_set_planner(nrq_ctx *ctx, int device_planner);
 /* Tuning / test knobs of the launch path (the NRQ_* environment variables read at nrq_ctx_create set the same
  * fields): "max_wb" widest column strip considered (16/8/4/2), "no_split", "no_balance", "no_plan_stream",
  * "reserve_cus", "solve_grid", "big_wg", "map_spread", "no_tiny", "tiny_div", "wide_g", "small_waves4", "no_plan_split",
- * "plan_split_force", "plan_small_state", "plan_big_wg", "encplan_dev_min_l".  Results never depend on them, only speed. */
+ * "plan_split_force", "plan_small_state", "plan_big_wg", "encplan_dev_min_l", "plan_ucap" (inactive columns the device
+ * planner has room for; a block that needs more is re-planned on the host).  Results never depend on them, only speed. */
 int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value);
 /* threads used for host-side planning (0 = hardware concurrency) */
 int nrq_ctx_set_threads(nrq_ctx *ctx, int n);

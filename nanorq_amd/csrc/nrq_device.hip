@@ -781,6 +781,8 @@ struct Tuning {
   bool plan_split_force = false; /* "plan_split_force": every block planned in two parts + helper kernels (tests) */
   bool no_plan_split = false;  /* NRQ_NO_PLAN_SPLIT: big blocks planned by one kernel (no helper kernels for the HDPC fold / W transposition) */
   bool no_plan_stream = false; /* NRQ_NO_PLAN_STREAM: planner kernel on the caller's stream (no overlap with the solve before it) */
+  uint32_t plan_ucap = 0;      /* "plan_ucap": inactive-column capacity of the device planner (0 = P + 768, at most 1280); tests lower it
+                                * to send blocks through the capacity fallback (host re-plan) */
   void read() {
     auto flag = [](const char *n) { const char *e = getenv(n); return e != nullptr; };
     auto num = [](const char *n, long long d) { const char *e = getenv(n); return (e && *e) ? atoll(e) : d; };
@@ -1596,6 +1598,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "small_waves4") t.small_waves4 = value != 0;
   else if (n == "map_spread") t.map_spread = value != 0;
   else if (n == "encplan_dev_min_l") t.encplan_dev_min_l = (uint32_t)value;
+  else if (n == "plan_ucap") t.plan_ucap = (uint32_t)value;
   else return fail(ctx, -1, "unknown option %s", name);
   return 0;
 }
@@ -1885,6 +1888,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   }
   uint32_t ucap = p.P + 768u;
   if (ucap > 1280u) ucap = 1280u; /* 40 words per W row at most */
+  if (ctx->tune.plan_ucap && ctx->tune.plan_ucap < ucap) ucap = ctx->tune.plan_ucap;
   if (ucap < p.P + 32u) return fail(ctx, -5, "K'=%u has too many permanently inactive columns for the device planner", p.Kp);
   const uint32_t Mcap = p.L + max_oh + PL_EXTRA_ROWS + 8u, npcap = max_nrep + PL_EXTRA_ROWS + 8u;
   const pl_work_layout wl = pl_work_plan(p.L, Mcap, npcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE);

@@ -484,3 +484,50 @@ def test_segmented_planner_at_small_sizes(G, orc):
         c.set_option("plan_split_force", 0)
         c.set_option("encplan_dev_min_l", 12000)
         c.clear_plan_cache()
+
+
+@pytest.mark.parametrize("K,T,nblk,loss", [(1000, 64, 24, 0.3), (8192, 32, 6, 0.4)])
+def test_capacity_fallback_replans_on_the_host(G, orc, K, T, nblk, loss):
+    """A block whose plan exceeds a capacity of the device planner (here: inactive columns, lowered through "plan_ucap") is
+    reported PL_FAIL_CAPACITY and re-planned by planner_host.cpp inside the same call (nrq_device.hip decode_device).  With
+    the capacity set between the smallest and the largest u of the batch, device-planned and host-planned blocks are solved
+    by ONE launch: the verdicts and the recovered bytes are the oracle's either way (reference precode.c:287-315: its
+    solver has no such capacity)."""
+    c = G.ctx()
+    P = nanorq_amd.params(K)["P"]
+    rng = np.random.default_rng(K)
+    src = rng.integers(0, 256, (nblk, K, T), dtype=np.uint8)
+    lost = [loss_pattern(K, loss * (0.5 + b / nblk), seed=3, block=b) for b in range(nblk)]   # heavier loss towards the end
+    nrep = max(len(x) for x in lost) + 2
+    esis = np.arange(K, K + nrep, dtype=np.uint32)
+    rep, _ = G.gpu_encode(src, K, T, esis)
+    work = src.copy()
+    for b in range(nblk):
+        work[b][lost[b]] = 0xEE
+
+    def decode():
+        st, out, _ = G.gpu_decode(work, K, T, lost, [esis[:len(l) + 1] for l in lost], [rep[b][:len(lost[b]) + 1] for b in range(nblk)])
+        return st, out, c.stats()["host_planned"]
+
+    st0, out0, hp0 = decode()
+    assert hp0 == 0
+    u = []
+    for b in range(nblk):   # the verdict of the reference algorithm, and how many inactive columns our planners end up with
+        ok, ref, _ = orc.decode_block(np.concatenate([np.setdiff1d(np.arange(K, dtype=np.uint32), lost[b]), esis[:len(lost[b]) + 1]]),
+                                      np.concatenate([src[b][np.setdiff1d(np.arange(K), lost[b])], rep[b][:len(lost[b]) + 1]]), K, T)
+        assert bool(st0[b]) == ok, b
+        if ok:
+            assert np.array_equal(out0[b], ref) and np.array_equal(ref, src[b])
+    mixed = False
+    try:
+        for extra in (40, 56, 72, 88, 104, 136, 168):
+            c.set_option("plan_ucap", P + extra)
+            st, out, hp = decode()
+            assert np.array_equal(st, st0), extra
+            assert np.array_equal(out[st0 != 0], out0[st0 != 0]), extra
+            mixed = mixed or 0 < hp < nblk
+            if extra == 40:
+                assert hp > 0          # nothing fits so few inactive columns: every block went to the host planner
+    finally:
+        c.set_option("plan_ucap", 0)
+    assert mixed, "no capacity setting split the batch between the device and the host planner"
