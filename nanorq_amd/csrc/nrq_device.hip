@@ -148,10 +148,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
     uint32_t blk, grp;
     nrq_map_group(q, nblk, gpb, by_block != 0u, &blk, &grp);
     const nrq_job *j = jobs + blk;
-    g.rowsrc = gptr<uint32_t>(j->rowsrc); g.src = gptr<uint8_t>(j->src); g.rep = gptr<uint8_t>(j->rep);
-    g.M = reinterpret_cast<const nrq_plan_hdr *>(j->plan)->M;
-    g.T = T; g.strip0 = grp * sub; g.nstrips = nstrips; g.lsub = lsub;
-    *blk_out = blk;
+    g.rowsrc = nrq_uniform_ptr(gptr<uint32_t>(j->rowsrc)); g.src = nrq_uniform_ptr(gptr<uint8_t>(j->src)); g.rep = nrq_uniform_ptr(gptr<uint8_t>(j->rep));
+    g.M = nrq_uniform(reinterpret_cast<const nrq_plan_hdr *>(j->plan)->M);
+    g.T = nrq_uniform(T); g.strip0 = nrq_uniform(grp * sub); g.nstrips = nrq_uniform(nstrips); g.lsub = nrq_uniform(lsub);
+    *blk_out = nrq_uniform(blk);
   };
   auto group_dst = [&](uint32_t q, GroupDst<WB> &g) -> uint32_t { /* returns the staged elements per strip */
     uint32_t blk, grp;
@@ -159,13 +159,16 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
     const nrq_job *j = jobs + blk;
     g.inter = gptr_w<uint8_t>(j->inter); g.out = gptr_w<uint8_t>(j->out); g.orow = gptr<uint32_t>(j->out_row);
     g.ni = j->inter ? reinterpret_cast<const nrq_plan_hdr *>(j->plan)->L : 0u;
-    g.nout = j->nout; g.T = T; g.strip0 = grp * sub; g.nstrips = nstrips; g.lsub = lsub;
+    g.nout = j->nout; g.T = nrq_uniform(T); g.strip0 = nrq_uniform(grp * sub); g.nstrips = nrq_uniform(nstrips); g.lsub = nrq_uniform(lsub);
+    g.orow = nrq_uniform_ptr(g.orow);
     if (ybuf) { /* split solve: the slot image and C_u go to rows [0, M + u) of the block's work buffer */
       const nrq_plan_hdr *h = reinterpret_cast<const nrq_plan_hdr *>(j->plan);
       g.inter = gptr_w<uint8_t>((uint64_t)(uintptr_t)(ybuf + (size_t)blk * ybuf_stride));
       g.ni = h->M + h->u;
       g.nout = 0u;
     }
+    g.inter = nrq_uniform_ptr(g.inter); g.out = nrq_uniform_ptr(g.out);
+    g.ni = nrq_uniform(g.ni); g.nout = nrq_uniform(g.nout);
     return g.ni + g.nout;
   };
   uint32_t q = nrq_next_group(blockIdx.x, nslots, jobs, nblk, gpb, by_block != 0u);

@@ -71,6 +71,19 @@ typedef struct nrq_job {
 #else
 #define NRQ_WAVE_ANY(x) (x)
 #endif
+/* A value that is the same in every lane of the wave, said so: it then lives in a scalar register (the descriptors of the
+ * group being gathered / scattered are such values, live across all phases of a strip). */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t nrq_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+template <class P> __device__ __forceinline__ P nrq_uniform_ptr(P p) {
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint64_t u = (uint64_t)nrq_uniform((uint32_t)v) | ((uint64_t)nrq_uniform((uint32_t)(v >> 32)) << 32);
+  return (P)(uintptr_t)u;
+}
+#else
+SB_HD uint32_t nrq_uniform(uint32_t x) { return x; }
+template <class P> SB_HD P nrq_uniform_ptr(P p) { return p; }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NRQ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
