@@ -122,6 +122,17 @@ int nrq_decode_blocks_v(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint3
                         const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi, const uint32_t *h_nrep,
                         const uint32_t *h_nrep_avail, uint32_t rep_cap, const uint64_t *d_rep_v, int *h_status, uint32_t *h_used);
 
+/* nrq_decode_blocks_v with ONE planner run for all blocks and the solve in chunks of `chunk_blocks` blocks, in order: after
+ * chunk i has been solved the event chunk_done[i] (nrq_event_new; ceil(nblk / chunk_blocks) of them) is recorded on the
+ * context's stream, so that a caller can start moving the first blocks (nrq_stream_wait on a copy stream) while the later
+ * ones are still being solved -- the planner's fixed cost (a launch the host waits for, ~3 ms) is paid once, not per chunk.
+ * upload_done (nullable): events the solve of chunk i waits for before it reads the chunk's symbols (their upload).
+ * Replaces nanorq_repair_block per block (reference lib/nanorq.c:591-631). */
+int nrq_decode_blocks_vc(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const uint64_t *d_src_v, const uint32_t *h_lost,
+                         const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi, const uint32_t *h_nrep,
+                         const uint32_t *h_nrep_avail, uint32_t rep_cap, const uint64_t *d_rep_v, int *h_status, uint32_t *h_used,
+                         uint32_t chunk_blocks, void *const *chunk_done, void *const *upload_done);
+
 /* Generate encoding symbols from intermediate symbols already in HBM (after encode/decode with
  * d_inter != NULL): symbol q of block b = LT(C_b, isi[q]) -> d_out + b*out_stride + q*T.
  * h_isi are INTERNAL symbol ids (esi for esi < K, esi + K' - K for repair symbols). */

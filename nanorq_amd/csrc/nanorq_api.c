@@ -41,7 +41,7 @@
 #define ENC_WINDOW 512u /* repair symbols fetched from the device per miss of the encode cache */
 #define PIN_MIN ((size_t)64 << 10)        /* host buffers from this size on are page-locked */
 #define CHUNK_BYTES ((size_t)192 << 20)   /* source bytes per pipeline step of the batched calls */
-#define REPAIR_CHUNK_BYTES ((size_t)384 << 20)
+#define REPAIR_CHUNK_BYTES ((size_t)128 << 20) /* source bytes per solve launch of nanorq_repair_all (one planner run for all) */
 
 struct part { /* RFC 6330 section 4.4.1.2 Partition[I, J] */
   size_t IL, IS, JL, JS;
@@ -1214,25 +1214,27 @@ static void *repair_all_worker(void *arg) {
     }
     if (!n) continue;
     const size_t sbytes = (size_t)K * T;
-    /* chunks: each costs a planner launch the host waits for (~3 ms whatever the number of blocks) before its solve
-     * can go, and only the download of the chunk BEFORE runs beside it: few, big chunks (two to four) */
+    /* ONE planner run for all blocks of the class (its fixed cost -- a launch the host waits for, ~3 ms whatever the number of
+     * blocks -- is paid once), then the solve in chunks (nrq_decode_blocks_vc): the decoded blocks of chunk i come down while
+     * the chunks behind it are still being solved, and host-resident blocks of chunk i+1 go up meanwhile */
     unsigned C = (unsigned)(REPAIR_CHUNK_BYTES / sbytes);
     if (C < 1) C = 1;
     if (C > n) C = n;
-    if (C == n && n >= 8 && (size_t)n * sbytes >= ((size_t)128 << 20)) C = (n + 1) / 2; /* at least two, so that something overlaps */
-    uint32_t *lost = calloc((size_t)C * lost_cap, sizeof(uint32_t)), *nlost = calloc(C, sizeof(uint32_t));
-    uint32_t *resi = calloc((size_t)C * rep_cap, sizeof(uint32_t)), *nuse = calloc(C, sizeof(uint32_t)), *navail = calloc(C, sizeof(uint32_t));
-    int *status = calloc(C, sizeof(int));
-    uint64_t *sv = calloc(C, sizeof(uint64_t)), *rv = calloc(C, sizeof(uint64_t));
-    void *ev_up = NULL, *ev_dec = NULL;
+    const unsigned nch = (n + C - 1) / C;
+    uint32_t *lost = calloc((size_t)n * lost_cap, sizeof(uint32_t)), *nlost = calloc(n, sizeof(uint32_t));
+    uint32_t *resi = calloc((size_t)n * rep_cap, sizeof(uint32_t)), *nuse = calloc(n, sizeof(uint32_t)), *navail = calloc(n, sizeof(uint32_t));
+    int *status = calloc(n, sizeof(int));
+    uint64_t *sv = calloc(n, sizeof(uint64_t)), *rv = calloc(n, sizeof(uint64_t));
+    void **ev_done = calloc(nch, sizeof(void *)), **ev_up = calloc(nch, sizeof(void *)), **ev_dl = calloc(nch, sizeof(void *));
     void *tmp_rep[NRQ_Z_MAX]; /* device copies of host-resident blocks' repair symbols (freed at the end) */
     unsigned ntmp = 0;
-    bool ok = lost && nlost && resi && nuse && navail && status && sv && rv && nrq_event_new(c, &ev_up) == 0 && nrq_event_new(c, &ev_dec) == 0;
-    for (unsigned c0 = 0; c0 < n && ok; c0 += C) {
+    bool ok = lost && nlost && resi && nuse && navail && status && sv && rv && ev_done && ev_up && ev_dl;
+    for (unsigned ci = 0; ci < nch && ok; ci++) ok = nrq_event_new(c, &ev_done[ci]) == 0 && nrq_event_new(c, &ev_dl[ci]) == 0;
+    for (unsigned c0 = 0, ci = 0; c0 < n && ok; c0 += C, ci++) { /* lists, and what has to go up, chunk by chunk */
       const unsigned m = n - c0 < C ? n - c0 : C;
       bool any_up = false;
-      for (unsigned k = 0; k < m && ok; k++) {
-        struct blockst *b = rq->blocks[todo[c0 + k]];
+      for (unsigned k = c0; k < c0 + m && ok; k++) {
+        struct blockst *b = rq->blocks[todo[k]];
         nlost[k] = list_lost(b, lost + (size_t)k * lost_cap);
         nuse[k] = rep_upfront(nlost[k], b->nrep);
         navail[k] = (uint32_t)b->nrep;
@@ -1249,13 +1251,17 @@ static void *repair_all_worker(void *arg) {
         }
         sv[k] = (uint64_t)(uintptr_t)b->d_src;
       }
-      if (any_up) ok = ok && nrq_event_record(c, ev_up, 1) == 0 && nrq_stream_wait(c, 0, ev_up) == 0;
-      ok = ok && nrq_decode_blocks_v(c, K, Kp, (uint32_t)T, m, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv,
-                                     status, NULL) == 0 &&
-           nrq_event_record(c, ev_dec, 0) == 0 && nrq_stream_wait(c, 2, ev_dec) == 0;
-      for (unsigned k = 0; k < m && ok; k++) { /* the decoded blocks come down beside the next chunk's decode */
-        struct blockst *b = rq->blocks[todo[c0 + k]];
-        const uint8_t sbn = (uint8_t)todo[c0 + k];
+      if (any_up && ok) ok = nrq_event_new(c, &ev_up[ci]) == 0 && nrq_event_record(c, ev_up[ci], 1) == 0;
+    }
+    ok = ok && nrq_decode_blocks_vc(c, K, Kp, (uint32_t)T, n, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv, status,
+                                    NULL, C, ev_done, ev_up) == 0;
+    bool any_host = false;
+    for (unsigned c0 = 0, ci = 0; c0 < n && ok; c0 += C, ci++) { /* the downloads, each chunk behind its solve */
+      const unsigned m = n - c0 < C ? n - c0 : C;
+      ok = nrq_stream_wait(c, 2, ev_done[ci]) == 0;
+      for (unsigned k = c0; k < c0 + m && ok; k++) {
+        struct blockst *b = rq->blocks[todo[k]];
+        const uint8_t sbn = (uint8_t)todo[k];
         if (!status[k]) { /* rank deficient: retry after more symbols (nanorq.c:620-623); what was received is written */
           if (b->dev && b->dirty && io && flush_dev_block(rq, sbn, b, io, false)) b->dirty = false;
           continue;
@@ -1266,32 +1272,37 @@ static void *repair_all_worker(void *arg) {
           if (io && ok) b->dirty = false;
         } else {
           ok = nrq_copy_on(c, 2, b->src, b->d_src, sbytes) == 0;
+          any_host = true;
         }
       }
-      /* host-resident blocks: their repaired symbols go through the context once the rows are down */
-      bool any_host = false;
-      for (unsigned k = 0; k < m; k++) any_host = any_host || (status[k] && !rq->blocks[todo[c0 + k]]->dev);
-      if (any_host && ok) {
-        ok = nrq_stream_sync(c, 2) == 0;
-        pthread_mutex_lock(&g_io_lock);
-        for (unsigned k = 0; k < m && ok; k++) {
-          struct blockst *b = rq->blocks[todo[c0 + k]];
-          if (!status[k] || b->dev) continue;
-          for (uint32_t q = 0; q < nlost[k]; q++) {
-            const uint32_t e = lost[(size_t)k * lost_cap + q];
-            if (io) transfer_symbol(rq, (uint8_t)todo[c0 + k], e, b->K, b->src + (size_t)e * T, io, 1);
-            mask_set(b, e);
-          }
+      ok = ok && nrq_event_record(c, ev_dl[ci], 2) == 0;
+    }
+    /* host-resident blocks: their repaired symbols go through the context once their rows are down */
+    for (unsigned c0 = 0, ci = 0; c0 < n && ok && any_host; c0 += C, ci++) {
+      const unsigned m = n - c0 < C ? n - c0 : C;
+      ok = nrq_event_sync(c, ev_dl[ci]) == 0;
+      pthread_mutex_lock(&g_io_lock);
+      for (unsigned k = c0; k < c0 + m && ok; k++) {
+        struct blockst *b = rq->blocks[todo[k]];
+        if (!status[k] || b->dev) continue;
+        for (uint32_t q = 0; q < nlost[k]; q++) {
+          const uint32_t e = lost[(size_t)k * lost_cap + q];
+          if (io) transfer_symbol(rq, (uint8_t)todo[k], e, b->K, b->src + (size_t)e * T, io, 1);
+          mask_set(b, e);
         }
-        pthread_mutex_unlock(&g_io_lock);
       }
+      pthread_mutex_unlock(&g_io_lock);
     }
     nrq_ctx_sync(c);
     nrq_stream_sync(c, 1);
     nrq_stream_sync(c, 2);
     for (unsigned i = 0; i < ntmp; i++) nrq_dev_free(c, tmp_rep[i]);
-    nrq_event_free(ev_up);
-    nrq_event_free(ev_dec);
+    for (unsigned ci = 0; ci < nch; ci++) {
+      if (ev_done) nrq_event_free(ev_done[ci]);
+      if (ev_up) nrq_event_free(ev_up[ci]);
+      if (ev_dl) nrq_event_free(ev_dl[ci]);
+    }
+    free(ev_done); free(ev_up); free(ev_dl);
     free(lost); free(nlost); free(resi); free(nuse); free(navail); free(status); free(sv); free(rv);
   }
   nrq_stream_sync(c, 2);

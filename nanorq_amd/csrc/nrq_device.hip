@@ -220,6 +220,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       c.strip = strip;
       const uint32_t at = strip * WBE + subl * WB, rem = at < T ? T - at : 0u;
       c.valid = rem < (uint32_t)WB ? rem : (uint32_t)WB;
+      const uint32_t lpr_ = c.h->lpr; /* (fetched here, with the header fields the first phases need: not a trip of its own later) */
       /* NRQ_PROF=1 debugging aid: shader-clock stamps at phase boundaries, the 10th strip of every 16th workgroup */
       unsigned long long *stamp = nullptr;
       const bool sampled = prof && (blockIdx.x & 15u) == 0 && done == 9u;
@@ -281,14 +282,16 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       NRQ_STAMP(3);
       /* the GF(2) combinations E_p of the dense stage: tables over the leftover rows in region X (zero again after the
        * reduce above), as many words of the bit rows at a time as it holds */
-      for (uint32_t w0 = 0; w0 < c.h->lpr; w0 += low_table_words<WB, G>(c)) {
+      for (uint32_t w0 = 0; w0 < lpr_; w0 += low_table_words<WB, G>(c)) {
         ph_low_tables<WB, G>(c, w0, vt, VNT);
         __syncthreads();
         ph_combine<WB, G>(c, w0, vt, VNT);
         __syncthreads();
       }
-      ph_clear_x<WB, G>(c, vt, VNT);
-      __syncthreads();
+      if (lpr_) { /* (0: the combinations were ops of the stream -- small blocks) */
+        ph_clear_x<WB, G>(c, vt, VNT);
+        __syncthreads();
+      }
       NRQ_STAMP(4);
       ph_dense_fold<WB, G>(c, vt, VNT);
       __syncthreads();
@@ -309,11 +312,11 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
         ph_tables<WB, G>(c, vt, VNT);
         __syncthreads();
         NRQ_STAMP(6);
-        ph_backsub<WB, G>(c, vt, VNT);
+        ph_backsub<WB, G, (NT >= 512)>(c, vt, VNT);
         ph_park<WB, G>(c, vt, VNT);
         __syncthreads();
         NRQ_STAMP(7);
-        ph_store<WB, G>(c, ostage_cur + (size_t)sidx * ostage_stride + subl * WB, vt, VNT);
+        ph_store<WB, G, (NT >= 512)>(c, ostage_cur + (size_t)sidx * ostage_stride + subl * WB, vt, VNT);
       }
       __syncthreads();
       NRQ_STAMP(8);
@@ -839,6 +842,8 @@ struct nrq_ctx {
    * streams before it frees. */
   const uint64_t *vec_inter = nullptr; /* nrq_encode_blocks_v: per-block addresses of the intermediate symbols */
   const uint64_t *vec_src = nullptr, *vec_rep = nullptr; /* nrq_decode_blocks_v: per-block buffer addresses instead of base + stride */
+  uint32_t chunk_blocks = 0;            /* nrq_decode_blocks_vc: blocks per solve launch (0: one launch for all) */
+  void *const *chunk_done = nullptr, *const *chunk_up = nullptr;
   std::multimap<size_t, void *> pool_free;
   std::map<void *, size_t> pool_size;
   size_t pool_cached = 0;
@@ -2012,7 +2017,23 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     }
   }
   int result = 0;
-  if (!hdrs.empty()) {
+  if (ctx->chunk_blocks) {
+    /* one planner run, the solve chunk by chunk (nrq_decode_blocks_vc): an event per chunk for the caller's copy streams */
+    if (ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->planned, 0));
+    const uint32_t cb = ctx->chunk_blocks;
+    for (uint32_t c0 = 0, ci = 0; c0 < nblk && !result; c0 += cb, ci++) {
+      const uint32_t m = nblk - c0 < cb ? nblk - c0 : cb;
+      std::vector<const nrq_plan_hdr *> hc;
+      for (uint32_t b = c0; b < c0 + m; b++)
+        if (h_nlost[b] != 0 && hd[b].magic == NRQ_PLAN_MAGIC && hd[b].status == 0) hc.push_back(&hd[b]);
+      if (ctx->chunk_up && ctx->chunk_up[ci]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)ctx->chunk_up[ci], 0));
+      if (!hc.empty())
+        result = pick_and_launch(ctx, hc, reinterpret_cast<const nrq_job *>(ctx->plan_jobs.p) + c0, m, T, kc->dev, (d_inter ? p.L : 0u) + max_nl);
+      if (ctx->chunk_done && ctx->chunk_done[ci]) HIPCHK(ctx, hipEventRecord((hipEvent_t)ctx->chunk_done[ci], ctx->stream));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->arena_free, ctx->stream));
+    ctx->arena_busy = true;
+  } else if (!hdrs.empty()) {
     if (ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->planned, 0));
     result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ctx->plan_jobs.p), nblk, T, kc->dev,
                              (d_inter ? p.L : 0u) + max_nl);
@@ -2067,6 +2088,29 @@ int nrq_decode_blocks_v(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint3
   const int rc = nrq_decode_blocks_lazy(ctx, K, Kp, T, nblk, (void *)(uintptr_t)16, 0, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, h_nrep_avail,
                                         rep_cap, (const void *)(uintptr_t)16, 0, nullptr, 0, h_status, h_used);
   ctx->vec_src = ctx->vec_rep = nullptr;
+  return rc;
+}
+
+int nrq_decode_blocks_vc(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const uint64_t *d_src_v, const uint32_t *h_lost,
+                         const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi, const uint32_t *h_nrep,
+                         const uint32_t *h_nrep_avail, uint32_t rep_cap, const uint64_t *d_rep_v, int *h_status, uint32_t *h_used,
+                         uint32_t chunk_blocks, void *const *chunk_done, void *const *upload_done) {
+  if (!ctx || !chunk_blocks || !chunk_done) return -1;
+  const uint32_t nchunks = (nblk + chunk_blocks - 1u) / chunk_blocks;
+  if (!ctx->planner) {
+    /* host planner: no chunks -- everything is solved by one launch, after all uploads; every event is recorded behind it */
+    for (uint32_t i = 0; upload_done && i < nchunks; i++)
+      if (upload_done[i]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)upload_done[i], 0));
+  } else {
+    ctx->chunk_blocks = chunk_blocks; ctx->chunk_done = chunk_done; ctx->chunk_up = upload_done;
+  }
+  const int rc = nrq_decode_blocks_v(ctx, K, Kp, T, nblk, d_src_v, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, h_nrep_avail, rep_cap, d_rep_v,
+                                     h_status, h_used);
+  const bool chunked = ctx->chunk_blocks != 0 && ctx->stats.host_planned == 0;
+  ctx->chunk_blocks = 0; ctx->chunk_done = ctx->chunk_up = nullptr;
+  if (!chunked) /* (also when blocks were re-planned on the host and solved by a later launch: the events say "all done") */
+    for (uint32_t i = 0; i < nchunks; i++)
+      if (chunk_done[i]) HIPCHK(ctx, hipEventRecord((hipEvent_t)chunk_done[i], ctx->stream));
   return rc;
 }
 

@@ -107,6 +107,12 @@ NRQ_PLAN_FN uint32_t nrq_lane_place(uint32_t span, const uint32_t *ct, uint32_t 
 #define NRQ_MULTI_INACT 6u
 #endif
 
+/* From this many intermediate symbols on the GF(2) combinations of the dense stage are a bit matrix (off_augt), below it ops
+ * of the stream: the table phase costs a strip ~7 k clocks of trips and barriers whatever the size, the ops r2 * nlow / 2 / 64
+ * rows of the forward wave (measured: 16 k clocks at K=8192, 1 k at K=1000, where four 256-thread workgroups share a CU). */
+#ifndef NRQ_AUG_MATRIX_MIN_L
+#define NRQ_AUG_MATRIX_MIN_L 5000u
+#endif
 typedef struct nrq_plan_hdr {
   uint32_t magic;
   uint32_t status; /* 0 = solvable, 1 = rank(A) < L (decode must fail, nanorq.c:620-623) */
@@ -146,7 +152,7 @@ typedef struct nrq_plan_hdr {
    * with 16-entry XOR tables over groups of four leftover rows (solve_body.h ph_low_tables / ph_combine) -- as ops of the
    * stream these ~r2 * nlow / 2 terms were a quarter of all row operations, run by the single forward wave. */
   uint32_t off_augt;    /* u32[lpr * aug_stride]: word w of reduced row p at [w * aug_stride + p] */
-  uint32_t lpr;         /* words per row: ceil(nlow / 32) */
+  uint32_t lpr;         /* words per row: ceil(nlow / 32); 0: the combinations are ops of the stream (blocks of L < NRQ_AUG_MATRIX_MIN_L) */
   uint32_t aug_stride;  /* >= r2, multiple of 4 */
 } nrq_plan_hdr;
 

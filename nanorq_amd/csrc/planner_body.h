@@ -162,6 +162,8 @@ SB_HD uint32_t pl_shared_bytes(uint32_t qcap, uint32_t lowcap, uint32_t nt) {
   return pl_r16((uint32_t)sizeof(pl_shared)) + pl_r16(qcap * 8u) + pl_r16(nt * 4u) + pl_r16(lowcap * 2u);
 }
 
+SB_HD bool pl_bin_in_stream(uint32_t L) { return L < NRQ_AUG_MATRIX_MIN_L; } /* (plan.h: the GF(2) combinations as ops of the stream) */
+
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
   uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, ucol, wrows,
@@ -209,7 +211,8 @@ SB_HD uint32_t pl_arena_bound(uint32_t L, uint32_t Mcap, uint32_t ucap, uint32_t
   /* op stream: the ops themselves, one partly filled row plus NRQ_PIPE-1 spacer rows per level, the spare and
    * the lead/padding rows */
   uint32_t ops = (2u * nnz + nnz / 2u) + NRQ_ROW * (NRQ_PIPE * (L / 2u + 8u) + PL_SPARE_ROWS + NRQ_PAD_ROWS + 4u);
-  ops += ((ucap + 3u) & ~3u) * ((PL_LOWCAP + 31u) / 32u) + 16u; /* (words of the bit matrix of the GF(2) combinations) */
+  if (pl_bin_in_stream(L)) ops += 2u * ucap * 64u;             /* (the GF(2) combinations as ops of the stream) */
+  else ops += ((ucap + 3u) & ~3u) * ((PL_LOWCAP + 31u) / 32u) + 16u; /* (or as words of a bit matrix) */
   uint32_t b = 256u + L * 2u * 3u + (L + 16u) * 2u + ucap * 2u * 4u + ucap * 4u * 2u + PL_MAXH * ucap +
                NRQ_MAX_FREE * PL_MAXH + wprcap * npad * 4u + ops * 4u +
                Mcap * 4u + (nlost_cap + 1u) * 8u + nlost_cap * PL_PATCH_STRIDE * 2u + 1024u;
@@ -1310,7 +1313,9 @@ template <int Z> SB_HD void pl_ops_layout(PlanCtx &c, uint32_t tid, uint32_t nt)
   sh->spare_base = rows; /* rows reserved for constraint rows added later */
   rows += PL_SPARE_ROWS + (NRQ_PIPE - 1u);
   sh->tmp0 = rows; /* rows of the stream */
-  uint32_t total_rows = NRQ_STREAM_ROWS(rows + NRQ_PAD_ROWS);
+  /* (in-stream form: generous bound for the combination group, nlow ones per reduced row at most) */
+  const uint32_t bin_bound = pl_bin_in_stream(c.p.L) ? ((sh->nlow + PL_EXTRA_ROWS) * (sh->nlow + PL_EXTRA_ROWS) + NRQ_ROW - 1u) / NRQ_ROW + 1u : 0u;
+  uint32_t total_rows = NRQ_STREAM_ROWS(rows + bin_bound + NRQ_PAD_ROWS);
   sh->off_ops = pl_r16(c.fixed_end);
   sh->arena_top = pl_r16(sh->off_ops + total_rows * NRQ_ROW * 4u);
   sh->opbase = total_rows;
@@ -1669,10 +1674,69 @@ template <int Z> SB_HD void pl_gjp_apply(PlanCtx &c, uint32_t w, uint32_t tid, u
   }
 }
 
+/* The GF(2) combinations E_q (slot M+q) = XOR of the leftover rows named by the augmented part of reduced row q, in one of
+ * two forms (plan.h off_augt): small blocks (pl_bin_in_stream) keep them as one more accumulate-only group of the op stream
+ * -- a few rows of the forward wave -- big blocks hand them over as a bit matrix that the solve kernel applies with XOR
+ * tables by the whole workgroup (a fixed ~7 k clocks of trips and barriers per strip, against r2 * nlow / 2 ops). */
+/* the GF(2) combinations E_q (slot M+q) as one more accumulate-only group of XOR ops */
+SB_HD void pl_binops_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (tid == 0) {
+    sh->tmp1 = 0;
+  }
+  const uint32_t *Mb = pl_mb(c);
+  for (uint32_t q = tid; q < sh->r2; q += nt) {
+    const uint32_t *aug = Mb + (size_t)c.red_row[q] * sh->rowlen + sh->wpr;
+    uint32_t n = 0;
+    for (uint32_t w = 0; w < sh->lpr; w++) n += (uint32_t)__builtin_popcount(aug[w]);
+    c.pivdeg[q] = n; /* reuse */
+  }
+}
+SB_HD void pl_binops_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (tid != 0) return;
+  /* the ops of reduced row q (target: scratch row M + q) rank among those of the target's lane class (plan.h "lane placement") */
+  uint32_t run = 0;
+  for (uint32_t d = 0; d < NRQ_LANE_CLASSES; d++) sh->bin_ct[d] = 0;
+  for (uint32_t q = 0; q < sh->r2; q++) {
+    const uint32_t n = c.pivdeg[q], d = nrq_op_class(NRQ_OP(sh->M + q, 0u));
+    c.pivdeg[q] = sh->bin_ct[d]; sh->bin_ct[d] += n; run += n;
+  }
+  const uint32_t g = sh->nlev + 1u;
+  c.lev_ops[g] = run;
+  sh->nrows = sh->tmp0 + pl_group_rows(run);
+  if ((sh->nrows + NRQ_PAD_ROWS > sh->opbase || sh->M + sh->r2 + NRQ_SCRATCH > 65535u) && sh->status == 0)
+    (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* op fields are 16 bits */
+}
+SB_HD void pl_binops_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (sh->status) return;
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
+  const uint32_t row0 = sh->tmp0, span = sh->nrows - sh->tmp0;
+  uint32_t ct[NRQ_LANE_CLASSES];
+  for (uint32_t d = 0; d < NRQ_LANE_CLASSES; d++) ct[d] = sh->bin_ct[d];
+  const uint32_t *Mb = pl_mb(c);
+  for (uint32_t q = tid; q < sh->r2; q += nt) {
+    const uint32_t *aug = Mb + (size_t)c.red_row[q] * sh->rowlen + sh->wpr;
+    uint32_t i = c.pivdeg[q];
+    for (uint32_t w = 0; w < sh->lpr; w++) {
+      uint32_t bits = aug[w];
+      while (bits) {
+        const uint32_t j = w * 32u + (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1u;
+        const uint32_t word = NRQ_OP(sh->M + q, c.lowslot[j]);
+        *pl_op_at(ops, row0, nrq_lane_place(span, ct, nrq_op_class(word), i)) = word;
+        i++;
+      }
+    }
+  }
+}
+
 /* the GF(2) combinations E_q (slot M+q) = XOR of the leftover rows named by the augmented part of reduced row q: handed to
  * the solve kernel as a bit matrix, word w of row q at [w * aug_stride + q] (plan.h off_augt), behind the op stream */
 template <int Z> SB_HD void pl_bin_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (pl_bin_in_stream(c.p.L)) { if (tid == 0) { sh->off_augt = 0; sh->aug_stride = 0; } pl_binops_a(c, tid, nt); return; }
   if (tid == 0) {
     sh->tmp1 = 0;
     sh->aug_stride = (sh->r2 + 3u) & ~3u;
@@ -1686,6 +1750,7 @@ template <int Z> SB_HD void pl_bin_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (pl_bin_in_stream(c.p.L)) { pl_binops_b(c, tid, nt); return; }
   if (sh->status) return;
   const uint32_t *Mb = pl_mb(c);
   uint32_t *augt = reinterpret_cast<uint32_t *>(c.arena + sh->off_augt);
@@ -1701,6 +1766,7 @@ template <int Z> SB_HD void pl_bin_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
 }
 template <int Z> SB_HD void pl_bin_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (pl_bin_in_stream(c.p.L)) { pl_binops_c(c, tid, nt); return; }
   if (tid == 0) c.lev_ops[sh->nlev + 1u] = sh->status ? 0u : sh->tmp1;
 }
 
@@ -1981,7 +2047,7 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   h.off_lowslot = c.off_lowslot; h.off_pivx = c.off_pivx; h.off_fbits = c.off_fbits; h.off_mh = c.off_mh;
   h.off_freex = c.off_freex; h.off_hinv = c.off_hinv; h.off_colslot = c.off_colslot; h.off_pivof = c.off_pivof;
   h.off_uslot = c.off_uslot; h.total_bytes = sh->arena_top;
-  h.off_augt = sh->off_augt; h.lpr = sh->lpr; h.aug_stride = sh->aug_stride;
+  h.off_augt = sh->off_augt; h.lpr = pl_bin_in_stream(p.L) ? 0u : sh->lpr; h.aug_stride = sh->aug_stride;
   if (!sh->status) {
     const uint32_t nl = c.job.nlost;
     uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + c.part()[2]);

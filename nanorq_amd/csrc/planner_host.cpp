@@ -451,16 +451,37 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
     red_x.push_back(x);
   }
   const uint32_t r2 = (uint32_t)red_row.size(), nfree = (uint32_t)freex.size();
-  /* GF(2) combinations E_p (slot M+p) = XOR of the leftover rows named by the augmented part of
-   * reduced row p: handed over as a bit matrix (plan.h off_augt), not as ops of the stream */
+  /* GF(2) combinations E_p (slot M+p) = XOR of the leftover rows named by the augmented part of reduced row p: ops of the
+   * stream for small blocks, a bit matrix for big ones (plan.h NRQ_AUG_MATRIX_MIN_L) */
   if (M + r2 + NRQ_SCRATCH > 65535u) return -3;
+  const bool aug_in_stream = L < NRQ_AUG_MATRIX_MIN_L;
   const uint32_t aug_stride = std::max(4u, (r2 + 3u) & ~3u);
-  std::vector<uint32_t> augt((size_t)lpr * aug_stride, 0);
-  for (uint32_t q = 0; q < r2; q++) {
-    const uint32_t *aug = &Mb[(size_t)red_row[q] * rowlen + wpr];
-    for (uint32_t w = 0; w < lpr; w++) {
-      augt[(size_t)w * aug_stride + q] = aug[w];
-      n_real_ops += (uint32_t)__builtin_popcount(aug[w]);
+  std::vector<uint32_t> augt(aug_in_stream ? 0 : (size_t)lpr * aug_stride, 0);
+  if (aug_in_stream) {
+    /* round-robin over p so that neighbouring ops hit different targets */
+    std::vector<uint32_t> g, curj(r2, 0);
+    bool any = r2 > 0;
+    while (any) {
+      any = false;
+      for (uint32_t q = 0; q < r2; q++) {
+        const uint32_t *aug = &Mb[(size_t)red_row[q] * rowlen + wpr];
+        uint32_t &j = curj[q];
+        while (j < nlow && !bit(aug, j)) j++;
+        if (j < nlow) {
+          g.push_back(NRQ_OP(M + q, lowslot[j]));
+          j++; any = true;
+        }
+      }
+    }
+    std::vector<uint32_t> none;
+    place_group(g, none);
+  } else {
+    for (uint32_t q = 0; q < r2; q++) {
+      const uint32_t *aug = &Mb[(size_t)red_row[q] * rowlen + wpr];
+      for (uint32_t w = 0; w < lpr; w++) {
+        augt[(size_t)w * aug_stride + q] = aug[w];
+        n_real_ops += (uint32_t)__builtin_popcount(aug[w]);
+      }
     }
   }
   const uint32_t op_rows = (uint32_t)(ops.size() / NRQ_ROW);
@@ -572,9 +593,9 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   memcpy(A.at<uint8_t>(hd.off_pivof), pivof.data(), (size_t)n_hd * 2);
   hd.off_uslot = A.reserve(std::max(1u, u) * 2);
   if (u) memcpy(A.at<uint8_t>(hd.off_uslot), uslot.data(), (size_t)u * 2);
-  hd.lpr = lpr; hd.aug_stride = aug_stride;
-  hd.off_augt = A.reserve((uint32_t)(augt.size() * 4));
-  memcpy(A.at<uint8_t>(hd.off_augt), augt.data(), augt.size() * 4);
+  hd.lpr = aug_in_stream ? 0u : lpr; hd.aug_stride = aug_stride;
+  hd.off_augt = A.reserve((uint32_t)(augt.size() * 4 + 16));
+  if (!augt.empty()) memcpy(A.at<uint8_t>(hd.off_augt), augt.data(), augt.size() * 4);
   hd.total_bytes = align16((uint32_t)A.buf.size());
   A.buf.resize(hd.total_bytes, 0);
   memcpy(A.buf.data(), &hd, sizeof(hd));

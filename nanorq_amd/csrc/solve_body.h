@@ -74,7 +74,11 @@ typedef struct nrq_job {
 /* A value that is the same in every lane of the wave, said so: it then lives in a scalar register (the descriptors of the
  * group being gathered / scattered are such values, live across all phases of a strip). */
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef NRQ_NO_UNIFORM
+__device__ __forceinline__ uint32_t nrq_uniform(uint32_t x) { return x; }
+#else
 __device__ __forceinline__ uint32_t nrq_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+#endif
 template <class P> __device__ __forceinline__ P nrq_uniform_ptr(P p) {
   const uint64_t v = (uint64_t)(uintptr_t)p;
   const uint64_t u = (uint64_t)nrq_uniform((uint32_t)v) | ((uint64_t)nrq_uniform((uint32_t)(v >> 32)) << 32);
@@ -503,10 +507,12 @@ template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_gather_impl(cons
 }
 template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_gather(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
                                        uint32_t p, uint32_t np, uint32_t sub = 0) {
+#ifndef NRQ_NO_AL
   if constexpr (G == 1 && WB >= 4) {
     const bool al = g.T % (uint32_t)WB == 0u && ((reinterpret_cast<uintptr_t>(g.src) | reinterpret_cast<uintptr_t>(g.rep)) & (uintptr_t)(WB - 1)) == 0;
     if (al) { pf_gather_impl<WB, G, PIPELINED, true>(g, stage, stage_stride, u0, u1, p, np, sub); return; }
   }
+#endif
   pf_gather_impl<WB, G, PIPELINED, false>(g, stage, stage_stride, u0, u1, p, np, sub);
 }
 #ifndef NRQ_COMMIT_PB
@@ -989,7 +995,7 @@ template <int WB, int G = 1> SB_HD void ph_tables(const StripCtx<WB, G> &c, uint
 /* phase 5b: back substitution C(pivot k) = Y_k ^ W_k * C_u.  Two pivots per trip with separate
  * register sets: the W words of the second are in flight while the first does its table lookups
  * (no register hand-over between trips, so the compiler can leave the loads outstanding). */
-template <int WB, int NW, int G = 1>
+template <int WB, int NW, int G = 1, bool FAST = true>
 SB_HD void backsub_one(const StripCtx<WB, G> &c, const uint8_t *t4, uint32_t slot, const uint32_t (&bitsw)[NW],
                        uint32_t wpr) {
   SV<WB> acc = lds_get<WB, G>(c.slots(), slot);
@@ -1010,6 +1016,7 @@ SB_HD void backsub_one(const StripCtx<WB, G> &c, const uint8_t *t4, uint32_t slo
        * instruction's immediate field, then the 32 dwords folded three at a time (v_bitop3_b32: a ^ b ^ c).  As it was -- four
        * lookups in flight, then four one by one, each a full LDS round trip the wave waited for, and three VALU operations per
        * address -- the phase was bound by those round trips (47 k clocks per strip at K=8192 against 33 k of LDS time). */
+      if constexpr (FAST) {
       const uint32_t tbw = (uint32_t)(uintptr_t)t4 + w * 2048u; /* (the word's tables; the lookup's own offset q * 256 is an immediate) */
       uint4 d[8];
 #pragma unroll
@@ -1018,6 +1025,32 @@ SB_HD void backsub_one(const StripCtx<WB, G> &c, const uint8_t *t4, uint32_t slo
       for (uint32_t q = 0; q < 8; q += 2) {
         acc.w[0] = nrq_xor3(acc.w[0], d[q].x, d[q + 1].x); acc.w[1] = nrq_xor3(acc.w[1], d[q].y, d[q + 1].y);
         acc.w[2] = nrq_xor3(acc.w[2], d[q].z, d[q + 1].z); acc.w[3] = nrq_xor3(acc.w[3], d[q].w, d[q + 1].w);
+      }
+      } else { /* (the register-lean form of the small workgroups) */
+        const uint32_t tb = (uint32_t)(uintptr_t)t4;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) {
+        const uint32_t a = t4_addr(tb, (q & 1u) ? odd : even, q >> 1) + (w * 8u + q) * 256u;
+        const uint4 v = *NRQ_LDSP(uint4, a);
+        acc.w[0] ^= v.x; acc.w[1] ^= v.y; acc.w[2] ^= v.z; acc.w[3] ^= v.w;
+        if (q == 3) NRQ_SCHED_FENCE();
+      }
+      }
+      NRQ_SCHED_FENCE();
+      continue;
+    }
+    if constexpr (WB == 8 && G == 1) {
+      /* the same for 8-byte strips (blocks whose 16-byte image does not fit the LDS: K from ~9800 on): table entries of 8
+       * bytes, so a nibble is brought to "8 * nibble" in place and a word's tables are 1 KB */
+      uint32_t odd = (bits >> 1) & 0x78787878u, even = (bits << 3) & 0x78787878u;
+      asm volatile("" : "+v"(odd), "+v"(even));
+      const uint32_t tbw = (uint32_t)(uintptr_t)t4 + w * 1024u;
+      uint2 d[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) d[q] = *NRQ_LDSP(uint2, t4_addr(tbw, (q & 1u) ? odd : even, q >> 1) + q * 128u);
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q += 2) {
+        acc.w[0] = nrq_xor3(acc.w[0], d[q].x, d[q + 1].x); acc.w[1] = nrq_xor3(acc.w[1], d[q].y, d[q + 1].y);
       }
       NRQ_SCHED_FENCE();
       continue;
@@ -1035,7 +1068,27 @@ SB_HD void backsub_one(const StripCtx<WB, G> &c, const uint8_t *t4, uint32_t slo
   lds_put<WB, G>(c.slots(), slot, acc);
 }
 
-template <int WB, int NW, int G = 1> SB_HD void backsub_fixed(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int NW, int G = 1, bool FAST = true> SB_HD void backsub_fixed(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+  if constexpr (!FAST) { /* the small workgroups: both register sets loaded, then both used (fewer live registers) */
+
+  const NRQ_GAS uint16_t *pivslot = c.template arr<uint16_t>(c.h->off_pivslot);
+  const NRQ_GAS uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
+  const uint32_t wpr = c.h->wpr, stride = c.h->npiv_pad, npiv = c.h->npiv;
+  const uint8_t *t4 = c.t4();
+  for (uint32_t k = tid; k < npiv; k += 2 * nt) {
+    const uint32_t k2 = k + nt;
+    uint32_t a[NW], b[NW];
+    const uint32_t sa = pivslot[k];
+    const uint32_t sb = k2 < npiv ? pivslot[k2] : 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)NW; w++) a[w] = w < wpr ? wt[(size_t)w * stride + k] : 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)NW; w++) b[w] = (w < wpr && k2 < npiv) ? wt[(size_t)w * stride + k2] : 0u;
+    backsub_one<WB, NW, G, false>(c, t4, sa, a, wpr);
+    if (k2 < npiv) backsub_one<WB, NW, G, false>(c, t4, sb, b, wpr);
+  }
+    return;
+  }
   const NRQ_GAS uint16_t *pivslot = c.template arr<uint16_t>(c.h->off_pivslot);
   const NRQ_GAS uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
   const uint32_t wpr = c.h->wpr, stride = c.h->npiv_pad, npiv = c.h->npiv;
@@ -1056,22 +1109,22 @@ template <int WB, int NW, int G = 1> SB_HD void backsub_fixed(const StripCtx<WB,
 #pragma unroll
       for (uint32_t w = 0; w < (uint32_t)NW; w++) b[w] = w < wpr ? wt[(size_t)w * stride + k2] : 0u;
     }
-    backsub_one<WB, NW, G>(c, t4, sa, a, wpr);
+    backsub_one<WB, NW, G, FAST>(c, t4, sa, a, wpr);
     if (k3 < npiv) {
       sa = pivslot[k3];
 #pragma unroll
       for (uint32_t w = 0; w < (uint32_t)NW; w++) a[w] = w < wpr ? wt[(size_t)w * stride + k3] : 0u;
     }
-    if (k2 < npiv) backsub_one<WB, NW, G>(c, t4, sb, b, wpr);
+    if (k2 < npiv) backsub_one<WB, NW, G, FAST>(c, t4, sb, b, wpr);
   }
 }
 
-template <int WB, int G = 1> SB_HD void ph_backsub(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1, bool FAST = true> SB_HD void ph_backsub(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const uint32_t wpr = c.h->wpr;
-  if (wpr <= 4) backsub_fixed<WB, 4, G>(c, tid, nt);
-  else if (wpr <= 8) backsub_fixed<WB, 8, G>(c, tid, nt);
-  else if (wpr <= 12) backsub_fixed<WB, 12, G>(c, tid, nt);
-  else if (wpr <= 24) backsub_fixed<WB, 24, G>(c, tid, nt);
+  if (wpr <= 4) backsub_fixed<WB, 4, G, FAST>(c, tid, nt);
+  else if (wpr <= 8) backsub_fixed<WB, 8, G, FAST>(c, tid, nt);
+  else if (wpr <= 12) backsub_fixed<WB, 12, G, FAST>(c, tid, nt);
+  else if (wpr <= 24) backsub_fixed<WB, 24, G, FAST>(c, tid, nt);
   else {
     const NRQ_GAS uint16_t *pivslot = c.template arr<uint16_t>(c.h->off_pivslot);
     const NRQ_GAS uint32_t *wt = c.template arr<uint32_t>(c.h->off_wt);
@@ -1111,7 +1164,9 @@ template <int WB, int G = 1> SB_HD void ph_park(const StripCtx<WB, G> &c, uint32
 #define NRQ_STORE_TRIP 32u /* (a multiple of the chunk) */
 #endif
 template <int WB, int G = 1> SB_HD uint32_t out_elems(const nrq_job *job, const nrq_plan_hdr *h) { return (job->inter ? h->L : 0u) + job->nout; }
-template <int WB, int G = 1> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
+/* FAST: the form for the big workgroup (168 registers per thread); the 256- and 64-thread variants, built for 96-128 registers,
+ * keep the lean loop (measured at K=1000: store phase 20 k -> 31 k clocks with the fast form there) */
+template <int WB, int G = 1, bool FAST = true> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
   constexpr int STB = 8;
   const NRQ_GAS uint16_t *colslot = c.template arr<uint16_t>(c.h->off_colslot);
   const uint32_t L = c.h->L, ni = c.job->inter ? L : 0u;
@@ -1130,6 +1185,7 @@ template <int WB, int G = 1> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_G
   }
   const NRQ_GAS uint32_t *cptr = gptr<uint32_t>(c.job->out_cptr);
   const NRQ_GAS uint16_t *osl = gptr<uint16_t>(c.job->out_slots);
+  if constexpr (FAST) {
   /* A generated symbol per thread and pass: its list bounds (fetched a pass ahead), then the slot numbers NRQ_STORE_CHUNK at a
    * time in one trip, then the strips from LDS -- ALL of the chunk's, unconditionally: an entry beyond the end of the list reads
    * the lane's scratch slot, which holds zeros (ph_clear; the padding ops of the stream XOR it into itself), so the loop body
@@ -1169,6 +1225,32 @@ template <int WB, int G = 1> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_G
       e += TR;
     }
     if (q < nout) g_put_stream<WB>(ostage + (size_t)(ni + q) * (WB * G), WB, acc);
+  }
+  } else {
+  /* a generated symbol per thread and pass: list bounds, then ALL slot numbers of the list in one trip (an LT list has at most
+   * 30 + 3 entries: a chunk of NRQ_STORE_CHUNK covers it; eight at a time it was a chain of up to four dependent trips to L2
+   * per symbol, and a wave waited for its longest list), then the strips from LDS.  The bounds of the thread's next symbol
+   * are fetched meanwhile. */
+  const uint32_t nout = c.job->nout;
+  constexpr uint32_t CH = 32u;
+  uint32_t e_n = 0, end_n = 0;
+  if (tid < nout) { e_n = cptr[tid]; end_n = cptr[tid + 1]; }
+  for (uint32_t q = tid; q < nout; q += nt) {
+    uint32_t e = e_n;
+    const uint32_t end = end_n;
+    if (q + nt < nout) { e_n = cptr[q + nt]; end_n = cptr[q + nt + 1]; }
+    SV<WB> acc = sv_zero<WB>();
+    while (e < end) {
+      uint32_t sl[CH];
+#pragma unroll
+      for (uint32_t k = 0; k < CH; k++) sl[k] = e + k < end ? (uint32_t)osl[e + k] : NRQ_NOSLOT;
+#pragma unroll
+      for (uint32_t k = 0; k < CH; k++)
+        if (sl[k] != NRQ_NOSLOT) sv_xor<WB>(acc, lds_get<WB, G>(c.slots(), sl[k]));
+      e += CH;
+    }
+    g_put_stream<WB>(ostage + (size_t)(ni + q) * (WB * G), WB, acc);
+  }
   }
 }
 /* phase 6b for the SPLIT solve of narrow strips (big blocks, nrq_device.hip): instead of back-substitution and results,
@@ -1283,10 +1365,12 @@ template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_scatter_impl(con
 
 template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_scatter(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
                                         uint32_t u1, uint32_t p, uint32_t np, uint32_t sub = 0) {
+#ifndef NRQ_NO_AL
   if constexpr (G == 1 && WB >= 4) {
     const bool al = g.T % (uint32_t)WB == 0u && ((reinterpret_cast<uintptr_t>(g.inter) | reinterpret_cast<uintptr_t>(g.out)) & (uintptr_t)(WB - 1)) == 0;
     if (al) { pf_scatter_impl<WB, G, PIPELINED, true>(g, ostage, stage_stride, u0, u1, p, np, sub); return; }
   }
+#endif
   pf_scatter_impl<WB, G, PIPELINED, false>(g, ostage, stage_stride, u0, u1, p, np, sub);
 }
 

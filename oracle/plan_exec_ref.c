@@ -60,9 +60,10 @@ int orc_plan_exec(const uint8_t *plan, uint8_t *Din, uint32_t T, uint8_t *C) {
   for (uint32_t k = 0; k < h->npiv; k++)
     for (uint32_t q = 0; q < H; q++) fma_row(ROW(h->S + q), ROW(pivslot[k]), T, G[(size_t)q * n_hd + pivcol[k]]);
   free(G);
-  /* 4: the binary combinations E_p (rows M+p) = XOR of the leftover rows the bit matrix names */
+  /* 4: the binary combinations E_p (rows M+p) = XOR of the leftover rows the bit matrix names (lpr == 0: they were
+   * ops of the stream, accumulated into rows M+p above) */
   uint8_t *E = D + (size_t)h->M * T;
-  {
+  if (h->lpr) {
     const uint32_t *augt = (const uint32_t *)(plan + h->off_augt);
     const uint16_t *lowslot = (const uint16_t *)(plan + h->off_lowslot);
     for (uint32_t p = 0; p < h->r2; p++)

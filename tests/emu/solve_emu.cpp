@@ -76,7 +76,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
     for (uint32_t t = 0; t < NT; t++) ph_low_tables<WB>(c, w0, t, NT);
     for (uint32_t t = 0; t < NT; t++) ph_combine<WB>(c, w0, t, NT);
   }
-  PHASE(ph_clear_x);
+  if (c.h->lpr) PHASE(ph_clear_x);
   PHASE(ph_dense_fold);
   if (dense_fold_shared(NT)) PHASE(ph_hdpc_reduce);
   PHASE(ph_dense_free);
