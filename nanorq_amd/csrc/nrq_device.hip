@@ -283,9 +283,11 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       /* the GF(2) combinations E_p of the dense stage: tables over the leftover rows in region X (zero again after the
        * reduce above), as many words of the bit rows at a time as it holds */
       for (uint32_t w0 = 0; w0 < lpr_; w0 += low_table_words<WB, G>(c)) {
+        uint32_t cb_[NRQ_COMBINE_WU];
         ph_low_tables<WB, G>(c, w0, vt, VNT);
+        ph_combine_fetch<WB, G>(c, w0, vt, VNT, cb_);
         __syncthreads();
-        ph_combine<WB, G>(c, w0, vt, VNT);
+        ph_combine<WB, G>(c, w0, vt, VNT, cb_);
         __syncthreads();
       }
       if (lpr_) { /* (0: the combinations were ops of the stream -- small blocks) */

@@ -860,7 +860,25 @@ template <int WB, int G = 1> SB_HD void ph_low_tables(const StripCtx<WB, G> &c, 
     lds_put<WB, G>(c.t4(), e, v);
   }
 }
-template <int WB, int G = 1> SB_HD void ph_combine(const StripCtx<WB, G> &c, uint32_t w0, uint32_t tid, uint32_t nt) {
+/* (the words of the bit rows a thread will use are fetched BEFORE the barrier that ends the table build -- ph_combine_fetch --
+ * so that the trip to L2 runs beside it; NRQ_COMBINE_WU words per thread at most, the rest is fetched in ph_combine itself) */
+#define NRQ_COMBINE_WU 4u
+template <int WB, int G = 1> SB_HD void ph_combine_fetch(const StripCtx<WB, G> &c, uint32_t w0, uint32_t tid, uint32_t nt, uint32_t (&bits)[NRQ_COMBINE_WU]) {
+  const NRQ_GAS uint32_t *augt = c.template arr<uint32_t>(c.h->off_augt);
+  const uint32_t r2 = c.h->r2, lpr = c.h->lpr, stride = c.h->aug_stride, cap = low_table_words<WB, G>(c);
+  const uint32_t nw = lpr - w0 < cap ? lpr - w0 : cap;
+#pragma unroll
+  for (uint32_t k = 0; k < NRQ_COMBINE_WU; k++) bits[k] = 0u;
+  if (!r2) return;
+  uint32_t nparts = nt / r2;
+  if (nparts < 1u) nparts = 1u;
+  if (nparts > nw) nparts = nw;
+  if (tid >= r2 * nparts) return;
+  const uint32_t p = tid % r2, part = tid / r2;
+#pragma unroll
+  for (uint32_t k = 0; k < NRQ_COMBINE_WU; k++) bits[k] = part + k * nparts < nw ? augt[(size_t)(w0 + part + k * nparts) * stride + p] : 0u;
+}
+template <int WB, int G = 1> SB_HD void ph_combine(const StripCtx<WB, G> &c, uint32_t w0, uint32_t tid, uint32_t nt, const uint32_t (&first)[NRQ_COMBINE_WU]) {
   const NRQ_GAS uint32_t *augt = c.template arr<uint32_t>(c.h->off_augt);
   const uint32_t r2 = c.h->r2, lpr = c.h->lpr, stride = c.h->aug_stride, cap = low_table_words<WB, G>(c);
   const uint32_t nw = lpr - w0 < cap ? lpr - w0 : cap;
@@ -870,12 +888,13 @@ template <int WB, int G = 1> SB_HD void ph_combine(const StripCtx<WB, G> &c, uin
   if (nparts > nw) nparts = nw;
   for (uint32_t i = tid; i < r2 * nparts; i += nt) {
     const uint32_t p = i % r2, part = i / r2;
-    constexpr uint32_t WU = 4; /* words of the row in flight */
+    constexpr uint32_t WU = NRQ_COMBINE_WU; /* words of the row in flight */
     SV<WB> acc = sv_zero<WB>();
     for (uint32_t wa = part; wa < nw; wa += WU * nparts) {
       uint32_t bits[WU];
 #pragma unroll
-      for (uint32_t k = 0; k < WU; k++) bits[k] = wa + k * nparts < nw ? augt[(size_t)(w0 + wa + k * nparts) * stride + p] : 0u;
+      for (uint32_t k = 0; k < WU; k++)
+        bits[k] = (i == tid && wa == part) ? first[k] : (wa + k * nparts < nw ? augt[(size_t)(w0 + wa + k * nparts) * stride + p] : 0u);
 #pragma unroll
       for (uint32_t k = 0; k < WU; k++) {
         if (!bits[k]) continue;

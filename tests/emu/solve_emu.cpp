@@ -74,7 +74,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
   PHASE(ph_hdpc_reduce);
   for (uint32_t w0 = 0; w0 < c.h->lpr; w0 += low_table_words<WB>(c)) {
     for (uint32_t t = 0; t < NT; t++) ph_low_tables<WB>(c, w0, t, NT);
-    for (uint32_t t = 0; t < NT; t++) ph_combine<WB>(c, w0, t, NT);
+    for (uint32_t t = 0; t < NT; t++) { uint32_t cb[NRQ_COMBINE_WU]; ph_combine_fetch<WB>(c, w0, t, NT, cb); ph_combine<WB>(c, w0, t, NT, cb); }
   }
   if (c.h->lpr) PHASE(ph_clear_x);
   PHASE(ph_dense_fold);

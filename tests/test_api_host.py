@@ -55,6 +55,12 @@ def test_no_gpu_means_failure_not_fallback():
     buf = (C.c_uint8 * 8)()
     assert L.nanorq_encode(rq, buf, 3, 0, io) == 8 and bytes(buf) == data[24:32].tobytes()  # plain copy works
     assert L.nanorq_encode(rq, buf, 10, 0, io) == 0  # repair symbol: needs the GPU
+    # the batched / multi-device layer (nanorq_batch.h): no context could be opened -- nothing is solved, nothing crashes
+    assert L.nanorq_devices() == 0
+    assert L.nanorq_generate_symbols_all(rq, io) == 0
+    rep = np.zeros(8 * 3, np.uint8)
+    assert L.nanorq_encode_range_all(rq, rep.ctypes.data_as(C.c_void_p), 10, 3, io) == 0
+    L.nanorq_trim()
     L.nanorq_free(rq)
     io.contents.destroy(io)
 
