@@ -99,6 +99,15 @@ NRQ_PLAN_FN uint32_t nrq_lane_place(uint32_t span, const uint32_t *ct, uint32_t 
   }
   return (r >> 1) * 16u + 2u * d + (r & 1u);
 }
+/* Early ops by release.  An early op may run in any group of its window [level(src)+1, level(dst)-1].  Those whose window is at
+ * most NRQ_EARLY_NARROW groups wide take one by hash; the others are served in the order of their release, each group taking
+ * what its rows have lanes for (host planner: encode plans of L < 12000 and the fallback; the device planner takes every early
+ * op's group by hash).  Measured at K=8192: 878 rows instead of 1086 for the same 55.6 k ops -- and an encode forward window of
+ * 68 k clocks instead of 71-75 k: with full rows the pass is bound by the LDS time of its real ops (bank conflicts of 63 random
+ * slots per row), not by the row count, so the device planner was left as it is. */
+#ifndef NRQ_EARLY_NARROW
+#define NRQ_EARLY_NARROW 128u
+#endif
 /* When a peeling round has no row of weight 1, this many open rows (sparsest first) are resolved by
  * inactivation before peeling resumes: fewer, wider cascades -> fewer rounds in the planner and fewer dependency
  * levels in the plan, for a few more inactive columns (which the back-substitution pays for).  Measured on the

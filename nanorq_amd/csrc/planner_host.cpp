@@ -388,26 +388,59 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
       }
   };
   {
-    /* group of an op dst <- src: the dst's level if src sits on the level right below (a "finishing" op), else any
-     * group of [level(src)+1, level(dst)-1], picked by a hash: such "early" ops fill lanes that narrow levels leave empty */
+    /* group of an op dst <- src: the dst's level t if src sits on the level right below (a "finishing" op); else any group of
+     * its window [level(src)+1, t-1] ("early" op: fills lanes that thin levels leave empty).  An early op with a narrow
+     * window takes a group of it by hash.  The others -- most: the median window is ~200 levels -- are dealt out in the order
+     * of their release (plan.h "early ops by release"): a group takes as many of the waiting ones as its rows have lanes left,
+     * and whole extra rows only when the groups behind it could not hold the rest; picked by hash alone the groups' loads
+     * scatter around their row boundaries and a quarter of the stream was padding (1086 rows for 55.6 k ops at K=8192,
+     * 870 are needed, this gives ~900). */
     std::vector<std::vector<uint32_t>> fin(nlev + 1), early(nlev + 1);
+    struct WideOp { uint32_t lo, t, word; };
+    std::vector<WideOp> wide;
     auto add_row = [&](uint32_t r, uint32_t own, uint32_t t) {
       for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++) {
         const uint32_t col = cidx[e];
         if (cstate[col] != PIVOT || col == own) continue;
         const uint32_t src = owner[col], lo = level[src] + 1u;
-        uint32_t g = t;
-        if (lo < t) {
-          uint32_t h = r * 0x9E3779B1u ^ col * 0x85EBCA6Bu;
-          h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-          g = lo + h % (t - lo);
-        }
-        (g == t ? fin[g] : early[g]).push_back(NRQ_OP(r, src));
+        if (lo >= t) { fin[t].push_back(NRQ_OP(r, src)); continue; }
+        if (t - lo > NRQ_EARLY_NARROW) { wide.push_back(WideOp{lo, t, NRQ_OP(r, src)}); continue; }
+        uint32_t h = r * 0x9E3779B1u ^ col * 0x85EBCA6Bu;
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+        early[lo + h % (t - lo)].push_back(NRQ_OP(r, src));
       }
     };
     for (uint32_t k = 0; k < npiv; k++)
       if (level[pivslot[k]] > 0) add_row(pivslot[k], pivcol[k], level[pivslot[k]]); /* level 0 rows have nothing to gather */
     for (uint32_t j = 0; j < nlow; j++) add_row(lowslot[j], 0xFFFFFFFFu, nlev);
+    if (!wide.empty()) {
+      std::stable_sort(wide.begin(), wide.end(), [](const WideOp &a, const WideOp &b) { return a.lo < b.lo; });
+      /* lanes a group has left at its minimal span, and what the groups behind it have */
+      std::vector<uint32_t> cap(nlev + 2, 0), rel(nlev + 2, 0);
+      std::vector<uint64_t> behind(nlev + 3, 0);
+      for (uint32_t l = 1; l <= nlev; l++) {
+        uint32_t cf[NRQ_LANE_CLASSES] = {0};
+        for (uint32_t w : fin[l]) cf[nrq_op_class(w)]++;
+        const uint32_t fixed = (uint32_t)(fin[l].size() + early[l].size());
+        cap[l] = nrq_group_span(fixed, cf) * NRQ_ROW - fixed;
+      }
+      for (uint32_t l = nlev; l >= 1; l--) behind[l] = behind[l + 1] + cap[l];
+      for (const WideOp &o : wide) rel[o.lo]++;
+      uint64_t backlog = 0, unreleased = wide.size();
+      size_t next = 0;
+      for (uint32_t g = 1; g <= nlev; g++) {
+        backlog += rel[g]; unreleased -= rel[g];
+        uint64_t c = cap[g];
+        while (backlog >= c + NRQ_ROW && backlog + unreleased - c > behind[g + 1]) c += NRQ_ROW; /* whole extra rows */
+        uint64_t take = backlog < c ? backlog : c;
+        backlog -= take;
+        for (; take; take--, next++) {
+          const WideOp &o = wide[next];
+          early[g < o.t ? g : o.t - 1u].push_back(o.word); /* (served after its window: its last group takes it) */
+        }
+      }
+      for (; next < wide.size(); next++) early[wide[next].t - 1u].push_back(wide[next].word);
+    }
     for (uint32_t l = 1; l <= nlev; l++) place_group(fin[l], early[l]);
   }
 
