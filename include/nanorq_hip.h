@@ -41,6 +41,8 @@ typedef struct nrq_call_stats {
   uint32_t strips_per_slot; /* strips a work slot holds (a whole 128-byte line group unless work is scarce) */
   uint32_t wg_waves_per_simd; /* register budget of the solve kernel variant launched: waves per SIMD it was compiled for */
   uint32_t host_planned; /* decode blocks whose plan exceeded a device-planner capacity and was rebuilt on the host */
+  uint32_t movers_aligned; /* 1: the solve kernel variant without byte-wise paths in its movers (all rows aligned, T a multiple of the strip) */
+  uint32_t reserved_;
 } nrq_call_stats;
 
 /* One context per GPU (one process per GPU: no cross-device state).  `stream` is a hipStream_t the

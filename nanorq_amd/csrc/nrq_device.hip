@@ -97,7 +97,11 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
  * workgroups, 5 (96 registers, a few more spills).  Left to itself the compiler took 207 registers: 2 workgroups. */
 /* G > 1: WIDE strips -- an element is G adjacent 16-byte columns, one lane each (solve_body.h): thread t is lane t % G of
  * virtual thread t / G, and every phase runs on the NT / G virtual threads.  For small blocks. */
-template <int WB, int NT, int WV, int G = 1>
+/* AL: every symbol row of the launch is aligned to the strip width and T is a multiple of it (the host checks): the movers are
+ * then compiled WITHOUT their byte-wise forms -- with both forms at every call site the kernels were half as large again
+ * (persistent workgroups in different phases share the instruction cache), and a byte-wise path inside a mover loop makes the
+ * compiler wait for all loads in flight where the paths join. */
+template <int WB, int NT, int WV, int G = 1, bool AL = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WV)))
 void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
                                                        uint32_t T, uint32_t nstrips, uint32_t by_block, uint32_t nslots,
@@ -111,6 +115,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
    * big enough to spare a second SIMD); the waves on the other SIMDs move data meanwhile: NGW gather, NSW scatter */
   static_assert(G == 1 || WB == 16, "wide strips are made of 16-byte lanes");
   constexpr uint32_t WBE = (uint32_t)WB * G; /* bytes of a strip */
+  constexpr bool ALX = AL && G == 1 && WB >= 4;
   const uint32_t vt = tid / G, subl = tid % G; /* virtual thread, lane inside it */
   constexpr uint32_t VNT = NT / G;
   constexpr uint32_t SPL = WBE >= 128u ? 1u : 128u / WBE, NFW = (G == 1 && WB >= 8 && NT >= 512) ? 2u : 1u,
@@ -122,11 +127,12 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
   static_assert(NMV >= 2u || NT == 64, "workgroup too small for the data movers");
   /* op-word ring of the forward wave(s), in rows: what the variant's register budget holds without spilling */
 #ifndef NRQ_PIPE_SMALL
-#define NRQ_PIPE_SMALL 1
+#define NRQ_PIPE_SMALL 0 /* (round 3: with the movers' aligned-only form the software-pipelined loops of the 256-thread variant keep so many
+                          * requests in flight that its forward wave waits for its op words: K=1000 9.7 / 8.6 ms with them, 8.2 / 7.7 without;
+                          * K=500 14.6 / 13.4 vs 12.4 / 11.8; K=2000 8.5 / 7.3 vs 7.2 / 6.5) */
 #endif
-  /* software-pipelined data movers where the registers allow: the 768-thread workgroup (168 per thread) and the 256-thread one
-   * built for four per CU (128; measured: K=1000 977 -> 1031 Gbit/s, K=2000 1085 -> 1174, K=3000 1034 -> 1137; the single-wave
-   * variant loses with them: K=100 340 -> 328) */
+  /* software-pipelined data movers in the 768-thread workgroup (168 registers per thread); the 256-thread variant had them in
+   * round 2 (K=1000 977 -> 1031 Gbit/s with the loops as they were then), see NRQ_PIPE_SMALL */
   constexpr bool MPIPE = NT >= 512 || (NRQ_PIPE_SMALL && NT == 256 && WV == 4);
 #ifndef NRQ_RING_4W
 #define NRQ_RING_4W NRQ_RING
@@ -178,7 +184,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
     GroupSrc<WB> g0;
     uint32_t b0;
     group_src(q, g0, &b0);
-    pf_gather<WB, G, MPIPE>(g0, stage0, stage_stride, 0u, g0.M << lsub, (tid) / G, (NT) / G, subl); /* the first group: nothing to overlap it with */
+    pf_gather_impl<WB, G, MPIPE, ALX>(g0, stage0, stage_stride, 0u, g0.M << lsub, (tid) / G, (NT) / G, subl); /* the first group: nothing to overlap it with */
     __syncthreads();
   }
   while (q < nslots) {
@@ -205,8 +211,8 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       const uint32_t sm = NT > NRQ_HDPC_NT_ ? s1 - (uint32_t)((uint64_t)(s1 - s0) * NRQ_SCATTER_LATE_PCT / 100u) : s1;
       const uint32_t strip = strip0 + sidx;
       if (strip >= nstrips) { /* no such strip: everybody moves this portion */
-        if (u1 > u0) pf_gather<WB, G, MPIPE>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (NT) / G, subl);
-        if (s1 > s0) pf_scatter<WB, G, MPIPE>(gp, ostage_prv, ostage_stride, s0, s1, (tid) / G, (NT) / G, subl);
+        if (u1 > u0) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (NT) / G, subl);
+        if (s1 > s0) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, s0, s1, (tid) / G, (NT) / G, subl);
         continue;
       }
       StripCtx<WB, G> c;
@@ -242,8 +248,8 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       if constexpr (NT == 64) {
         if constexpr (G > 1) fwd_rows_wide<G>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
         else fwd_rows<WB, RU>(c.template arr<uint32_t>(c.h->off_ops), c.h->nrows, tid);
-        if (u1 > u0) pf_gather<WB, G, MPIPE>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (64u) / G, subl);
-        if (sm > s0) pf_scatter<WB, G, MPIPE>(gp, ostage_prv, ostage_stride, s0, sm, (tid) / G, (64u) / G, subl);
+        if (u1 > u0) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (64u) / G, subl);
+        if (sm > s0) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, s0, sm, (tid) / G, (64u) / G, subl);
       } else if (wv < NFW) {
         __builtin_amdgcn_s_setprio(3); /* the critical waves: ahead of the others at instruction issue */
         const NRQ_GAS uint32_t *ops_ = c.template arr<uint32_t>(c.h->off_ops);
@@ -261,10 +267,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       } else if ((wv & 3u) >= NFW) { /* the waves that do not share a SIMD with the forward waves; index among them: */
         const uint32_t mv = (wv >> 2) * (4u - NFW) + (wv & 3u) - NFW;
         if (mv < NGW) {
-          if (u1 > u0) pf_gather<WB, G, MPIPE>(gn, stage_nxt, stage_stride, u0, u1, (mv * 64u + (tid & 63u)) / G, (NGW * 64u) / G, subl);
+          if (u1 > u0) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, u0, u1, (mv * 64u + (tid & 63u)) / G, (NGW * 64u) / G, subl);
           NRQ_MARK_MAX(c, 2);
         } else if (mv < NGW + NSW) {
-          if (sm > s0) pf_scatter<WB, G, MPIPE>(gp, ostage_prv, ostage_stride, s0, sm, ((mv - NGW) * 64u + (tid & 63u)) / G, (NSW * 64u) / G, subl);
+          if (sm > s0) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, s0, sm, ((mv - NGW) * 64u + (tid & 63u)) / G, (NSW * 64u) / G, subl);
           NRQ_MARK_MAX(c, 3);
         }
       }
@@ -274,7 +280,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       {
         constexpr uint32_t HNT = NT < NRQ_HDPC_NT_ ? NT : NRQ_HDPC_NT_;
         if (tid < HNT) ph_hdpc<WB, G>(c, tid / G, HNT / G);
-        else if (s1 > sm) pf_scatter<WB, G, MPIPE>(gp, ostage_prv, ostage_stride, sm, s1, (tid - HNT) / G, (NT - HNT) / G, subl); /* the waves HDPC leaves idle */
+        else if (s1 > sm) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, sm, s1, (tid - HNT) / G, (NT - HNT) / G, subl); /* the waves HDPC leaves idle */
       }
       __syncthreads();
       ph_hdpc_reduce<WB, G>(c, vt, VNT);
@@ -333,7 +339,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
   if (qp < nslots) {
     GroupDst<WB> gp;
     const uint32_t units_p = group_dst(qp, gp) << lsub;
-    pf_scatter<WB, G, MPIPE>(gp, ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride, ostage_stride, 0u, units_p, (tid) / G, (NT) / G, subl);
+    pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage0 + (size_t)(buf ^ 1u) * SPL * ostage_stride, ostage_stride, 0u, units_p, (tid) / G, (NT) / G, subl);
   }
 }
 
@@ -844,6 +850,7 @@ struct nrq_ctx {
    * streams before it frees. */
   const uint64_t *vec_inter = nullptr; /* nrq_encode_blocks_v: per-block addresses of the intermediate symbols */
   const uint64_t *vec_src = nullptr, *vec_rep = nullptr; /* nrq_decode_blocks_v: per-block buffer addresses instead of base + stride */
+  bool io_aligned = false;              /* set by the entry points: every symbol row of the call is 16-byte aligned (base addresses and strides) */
   uint32_t chunk_blocks = 0;            /* nrq_decode_blocks_vc: blocks per solve launch (0: one launch for all) */
   void *const *chunk_done = nullptr, *const *chunk_up = nullptr;
   std::multimap<size_t, void *> pool_free;
@@ -1298,14 +1305,14 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_backsub_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, NRQ_WG, 1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 256, 4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 256, 5>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<WB, 64, 5>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+#define NRQ_SET_LDS_ATTR(...)                                                                                                              \
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)NRQ_LDS_MAX))
+    NRQ_SET_LDS_ATTR(WB, NRQ_WG, 1, 1, false); NRQ_SET_LDS_ATTR(WB, NRQ_WG, 1, 1, true);
+    NRQ_SET_LDS_ATTR(WB, 256, 4, 1, false);    NRQ_SET_LDS_ATTR(WB, 256, 4, 1, true);
+    NRQ_SET_LDS_ATTR(WB, 256, 5, 1, false);    NRQ_SET_LDS_ATTR(WB, 256, 5, 1, true);
+    NRQ_SET_LDS_ATTR(WB, 64, 5, 1, false);     NRQ_SET_LDS_ATTR(WB, 64, 5, 1, true);
+#undef NRQ_SET_LDS_ATTR
     if constexpr (WB == 16) {
       HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<16, 256, 4, 2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
@@ -1342,18 +1349,19 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   if (WB == 16 && G == 8) { if constexpr (WB == 16) NRQ_LAUNCH_WIDE(8); }
   else if (WB == 16 && G == 4) { if constexpr (WB == 16) NRQ_LAUNCH_WIDE(4); }
   else if (WB == 16 && G == 2) { if constexpr (WB == 16) NRQ_LAUNCH_WIDE(2); }
-  else if (tiny)
-    hipLaunchKernelGGL((nrq_solve_kernel<WB, 64, 5>), dim3((uint32_t)grid), dim3(64), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
-                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
-  else if (five)
-    hipLaunchKernelGGL((nrq_solve_kernel<WB, 256, 5>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
-                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
-  else if (small)
-    hipLaunchKernelGGL((nrq_solve_kernel<WB, 256, 4>), dim3((uint32_t)grid), dim3(256), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
-                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
-  else
-    hipLaunchKernelGGL((nrq_solve_kernel<WB, NRQ_WG, 1>), dim3((uint32_t)grid), dim3(NRQ_WG), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips,
-                       by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf, ybuf_stride);
+  else {
+    const bool al = ctx->io_aligned && G == 1 && WB >= 4 && T % (uint32_t)WB == 0u; /* (the movers' aligned-only form) */
+#define NRQ_LAUNCH(NTT, WVV, ALL)                                                                                                        \
+  hipLaunchKernelGGL((nrq_solve_kernel<WB, NTT, WVV, 1, ALL>), dim3((uint32_t)grid), dim3(NTT), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips, \
+                     by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf,   \
+                     ybuf_stride)
+    if (tiny) { if (al) NRQ_LAUNCH(64, 5, true); else NRQ_LAUNCH(64, 5, false); }
+    else if (five) { if (al) NRQ_LAUNCH(256, 5, true); else NRQ_LAUNCH(256, 5, false); }
+    else if (small) { if (al) NRQ_LAUNCH(256, 4, true); else NRQ_LAUNCH(256, 4, false); }
+    else { if (al) NRQ_LAUNCH(NRQ_WG, 1, true); else NRQ_LAUNCH(NRQ_WG, 1, false); }
+#undef NRQ_LAUNCH
+    ctx->stats.movers_aligned = al ? 1u : 0u;
+  }
   HIPCHK(ctx, hipGetLastError());
   if (split) {
     /* 32-byte strips while the tables (4 KiB per W word) leave room for two workgroups per CU, 16-byte strips beyond */
@@ -1411,6 +1419,17 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   ctx->stats.strips_per_slot = 1u << lsub;
   ctx->stats.wg_waves_per_simd = (five || tiny) ? 5u : small ? 4u : 1u;
   return 0;
+}
+
+/* every row of a base + b * stride array of T-byte rows starts 16-byte aligned */
+inline bool rows_aligned(const void *base, size_t stride, uint32_t T) {
+  return ((reinterpret_cast<uintptr_t>(base) | (uintptr_t)stride | (uintptr_t)T) & 15u) == 0;
+}
+inline bool vec_aligned(const uint64_t *v, uint32_t n, uint32_t T) {
+  if (T & 15u) return false;
+  for (uint32_t b = 0; b < n; b++)
+    if (v[b] & 15u) return false;
+  return true;
 }
 
 /* widest strip whose LDS image fits for every plan header in hdrs */
@@ -1638,6 +1657,8 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   if (rc) return rc;
   for (uint32_t q = 0; q < nrep; q++)
     if (h_esis[q] < K || h_esis[q] >= (1u << 24)) return fail(ctx, -1, "repair ESI %u out of range", h_esis[q]);
+  ctx->io_aligned = rows_aligned(d_src, src_stride, T) && (!nrep || rows_aligned(d_rep, rep_stride, T)) &&
+                    (ctx->vec_inter ? vec_aligned(ctx->vec_inter, nblk, T) : (!d_inter || rows_aligned(d_inter, inter_stride, T)));
   KConst *kc;
   rc = get_kconst(ctx, p.Kp, &kc);
   if (rc) return rc;
@@ -2055,6 +2076,9 @@ int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, ui
   if (!ctx) return -1;
   if (!d_src || T == 0 || nblk == 0 || !h_nlost || !h_nrep || !h_status) return fail(ctx, -1, "bad arguments");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->io_aligned = (ctx->vec_src ? vec_aligned(ctx->vec_src, nblk, T) : rows_aligned(d_src, src_stride, T)) &&
+                    (ctx->vec_rep ? vec_aligned(ctx->vec_rep, nblk, T) : rows_aligned(d_rep, rep_stride, T)) &&
+                    (!d_inter || rows_aligned(d_inter, inter_stride, T));
   if (!ctx->planner)
     return decode_host(ctx, nullptr, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
                        h_nrep_avail, h_used, rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);
