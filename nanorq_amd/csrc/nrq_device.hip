@@ -133,7 +133,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
 #endif
   /* software-pipelined data movers in the 768-thread workgroup (168 registers per thread); the 256-thread variant had them in
    * round 2 (K=1000 977 -> 1031 Gbit/s with the loops as they were then), see NRQ_PIPE_SMALL */
-  constexpr bool MPIPE = NT >= 512 || (NRQ_PIPE_SMALL && NT == 256 && WV == 4);
+#ifndef NRQ_PIPE_BIG
+#define NRQ_PIPE_BIG 1
+#endif
+  constexpr bool MPIPE = (NRQ_PIPE_BIG && NT >= 512) || (NRQ_PIPE_SMALL && NT == 256 && WV == 4);
 #ifndef NRQ_RING_4W
 #define NRQ_RING_4W NRQ_RING
 #endif

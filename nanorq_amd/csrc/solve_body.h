@@ -765,12 +765,45 @@ template <int WB, int G = 1> SB_HD void ph_hdpc(const StripCtx<WB, G> &c, uint32
   const uint32_t mine = (tid & (hdpc_nsets<WB, G>(c) - 1u)) * H; /* this lane's copy of the H accumulators */
   /* chunks of whole 8-column groups, as equal as possible; the threads that take one group more are the FIRST
    * ones, so that a single wave (not one lane of every wave) runs the longer loop */
-  const uint32_t groups = (n + 7u) / 8u, base = groups / nt, extra = groups - base * nt;
-  const uint32_t a = 8u * (tid * base + (tid < extra ? tid : extra));
+  /* (small blocks: groups of 4 or 2 columns while there are fewer groups than threads -- the closing fold below costs a wave the
+   * same instructions whether its lanes close 8 columns or 2, the recurrence costs it per column of its longest lane: K=100 on
+   * a single wave is 15 lanes x 8 columns as groups of 8, 59 lanes x 2 as groups of 2) */
+  const uint32_t gsz = (n + 1u) / 2u <= nt ? 2u : (n + 3u) / 4u <= nt ? 4u : 8u; /* (smaller than 8: at most one group per thread) */
+  const uint32_t groups = (n + gsz - 1u) / gsz, base = groups / nt, extra = groups - base * nt;
+  const uint32_t a = gsz * (tid * base + (tid < extra ? tid : extra));
   if (a >= n || (base == 0u && tid >= extra)) return;
-  const uint32_t len = 8u * (base + (tid < extra ? 1u : 0u));
+  const uint32_t len = gsz * (base + (tid < extra ? 1u : 0u));
   const uint32_t b = (a + len < n) ? a + len : n;
   SV<WB> g = sv_zero<WB>();
+  if (gsz < 8u) { /* one group of at most 4 columns per thread (groups < nt): slot numbers and MT rows column by column, in flight together */
+    uint32_t sl4[4], e4[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+      const uint32_t col = a + q < b ? a + q : a;
+      sl4[q] = pivof[col];
+      e4[q] = b12[col];
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+      const uint32_t col = a + q;
+      if (col >= b) break;
+      g = sv_xtime<WB>(g);
+      if (sl4[q] != NRQ_NOSLOT) {
+        SV<WB> y = lds_get<WB, G>(c.slots(), sl4[q]);
+        sv_xor<WB>(g, y);
+      }
+      if (col + 1 < n) {
+        lds_xor<WB, G>(c.cf(), mine + (e4[q] & 15u), g);
+        lds_xor<WB, G>(c.cf(), mine + (e4[q] >> 4), g);
+      } else { /* last column of MT is alpha^h */
+        SV<WB> v = g;
+        for (uint32_t h = 0; h < H; h++) {
+          lds_xor<WB, G>(c.cf(), mine + h, v);
+          v = sv_xtime<WB>(v);
+        }
+      }
+    }
+  } else
   /* 8 columns per step: their slot indices and MT rows come in two vector loads (the arrays are
    * 16-byte aligned and padded, a is a multiple of 8) */
   for (uint32_t c0 = a; c0 < b; c0 += 8) {
