@@ -361,3 +361,20 @@ def test_small_planner_state_reports_overflow(orc):
     _, ok_hdr = emu_device_plan(K, kc, lost, rep_esis)
     _, hdr = emu_device_plan(K, kc, lost, rep_esis, caps=(64, 16))
     assert ok_hdr["status"] == 0 and hdr["status"] == 1
+
+
+def test_host_planner_fills_the_rows_of_the_stream():
+    """plan.h "early ops by release": the host planner deals the early ops with wide windows out in the order of their release,
+    so that a group takes what its rows have lanes for -- the stream's rows are nearly full (by hash alone a quarter of it was
+    padding: ~50 real ops per row of 64), and the forward passes still come out right (the emulated pipeline is sensitive to
+    row spacing: test_emulated_forward_pass_is_sensitive_to_row_spacing)."""
+    K = 8192   # (55.6 k ops on 343 levels: 870 rows are needed; small blocks are bound by two rows per level instead)
+    kc = nanorq_amd.host_kconst(K)
+    p = nanorq_amd.params(K)
+    plan = nanorq_amd.host_plan(K, np.arange(p["Kp"], dtype=np.uint32), kc)
+    ops = nanorq_amd.plan_ops(plan)
+    real = ((ops & 0xFFFF) >= 64).sum(1)
+    h = nanorq_amd.plan_header(plan)
+    rows = real[:h["nrows"]]
+    assert rows.sum() / max(1, (rows > 0).sum()) > 60.0, "stream rows are not filled"
+    assert h["nrows"] < 950
