@@ -209,9 +209,18 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       const uint32_t s0 = (uint32_t)(((uint64_t)units_p * sidx) >> lsub), s1 = (uint32_t)(((uint64_t)units_p * (sidx + 1u)) >> lsub);
       /* part of the scatter portion is left to the waves that the HDPC phase does not use (when there are any) */
 #ifndef NRQ_SCATTER_LATE_PCT
-#define NRQ_SCATTER_LATE_PCT 35u
+#define NRQ_SCATTER_LATE_PCT 20u
 #endif
       const uint32_t sm = NT > NRQ_HDPC_NT_ ? s1 - (uint32_t)((uint64_t)(s1 - s0) * NRQ_SCATTER_LATE_PCT / 100u) : s1;
+      /* ... and part of the gather portion: the gather of an encode strip is bound by its bytes in flight against the memory
+       * latency and ends with the forward waves (more of it in flight there would delay their op words); in the HDPC window
+       * nobody waits for op words.  K=8192 T=1280, encode / decode solve kernel in ms at gather % / scatter %: 0/35 7.09 / 6.28,
+       * 40/20 6.61 / 6.30, 35/35 6.79 / 6.25, 50/25 6.82 / 6.37, 60/35 7.02 / 6.34 (beyond 40 % the HDPC window grows by more
+       * than the forward window shrinks) */
+#ifndef NRQ_GATHER_LATE_PCT
+#define NRQ_GATHER_LATE_PCT 40u
+#endif
+      const uint32_t um = NT > NRQ_HDPC_NT_ ? u1 - (uint32_t)((uint64_t)(u1 - u0) * NRQ_GATHER_LATE_PCT / 100u) : u1;
       const uint32_t strip = strip0 + sidx;
       if (strip >= nstrips) { /* no such strip: everybody moves this portion */
         if (u1 > u0) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (NT) / G, subl);
@@ -270,7 +279,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       } else if ((wv & 3u) >= NFW) { /* the waves that do not share a SIMD with the forward waves; index among them: */
         const uint32_t mv = (wv >> 2) * (4u - NFW) + (wv & 3u) - NFW;
         if (mv < NGW) {
-          if (u1 > u0) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, u0, u1, (mv * 64u + (tid & 63u)) / G, (NGW * 64u) / G, subl);
+          if (um > u0) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, u0, um, (mv * 64u + (tid & 63u)) / G, (NGW * 64u) / G, subl);
           NRQ_MARK_MAX(c, 2);
         } else if (mv < NGW + NSW) {
           if (sm > s0) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, s0, sm, ((mv - NGW) * 64u + (tid & 63u)) / G, (NSW * 64u) / G, subl);
@@ -283,7 +292,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       {
         constexpr uint32_t HNT = NT < NRQ_HDPC_NT_ ? NT : NRQ_HDPC_NT_;
         if (tid < HNT) ph_hdpc<WB, G>(c, tid / G, HNT / G);
-        else if (s1 > sm) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, sm, s1, (tid - HNT) / G, (NT - HNT) / G, subl); /* the waves HDPC leaves idle */
+        else { /* the waves HDPC leaves idle */
+          if (u1 > um) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, um, u1, (tid - HNT) / G, (NT - HNT) / G, subl);
+          if (s1 > sm) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, sm, s1, (tid - HNT) / G, (NT - HNT) / G, subl);
+        }
       }
       __syncthreads();
       ph_hdpc_reduce<WB, G>(c, vt, VNT);
