@@ -1218,6 +1218,31 @@ template <int WB, int G = 1> SB_HD void ph_park(const StripCtx<WB, G> &c, uint32
 template <int WB, int G = 1> SB_HD uint32_t out_elems(const nrq_job *job, const nrq_plan_hdr *h) { return (job->inter ? h->L : 0u) + job->nout; }
 /* FAST: the form for the big workgroup (168 registers per thread); the 256- and 64-thread variants, built for 96-128 registers,
  * keep the lean loop (measured at K=1000: store phase 20 k -> 31 k clocks with the fast form there) */
+/* The NRQ_STORE_TRIP slot numbers from entry e on, two per word, as 16-byte loads from a 2-byte-aligned address (the memory
+ * path takes them).  With a 16-bit load per entry under `e + k < end` the compiler made a branch per entry and waited for each
+ * load inside it: 32 trips to L2 one after the other, 15 k clocks for the 820 symbols of a decode strip.  The loads run past the
+ * end of the list, the last list's past the end of the array: out_slots[] is followed by NRQ_STORE_TRIP * 2 bytes that may be
+ * read (nrq_device.hip, planner_body.h). */
+SB_HD void store_trip(const NRQ_GAS uint16_t *osl, uint32_t e, uint32_t end, uint32_t (&raw)[NRQ_STORE_TRIP / 2u]) {
+  (void)end;
+#ifdef __HIP_DEVICE_COMPILE__
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef u4 u4a __attribute__((aligned(2)));
+#pragma unroll
+  for (uint32_t k = 0; k < NRQ_STORE_TRIP / 8u; k++) {
+    const u4 w = *reinterpret_cast<const NRQ_GAS u4a *>(osl + e + 8u * k);
+    raw[4u * k] = w.x; raw[4u * k + 1u] = w.y; raw[4u * k + 2u] = w.z; raw[4u * k + 3u] = w.w;
+  }
+#else
+#pragma unroll
+  for (uint32_t k = 0; k < NRQ_STORE_TRIP / 2u; k++) /* (the emulator's arrays have no slack: stay inside the list) */
+    raw[k] = (e + 2u * k < end ? (uint32_t)osl[e + 2u * k] : 0u) | (e + 2u * k + 1u < end ? (uint32_t)osl[e + 2u * k + 1u] : 0u) << 16;
+#endif
+}
+/* entry e + k of the list as an element of the image: its slot, or (past the end of the list) the lane's scratch slot */
+SB_HD uint32_t store_slot(const uint32_t (&raw)[NRQ_STORE_TRIP / 2u], uint32_t k, uint32_t e, uint32_t end, uint32_t zero_at) {
+  return e + k < end ? ((raw[k / 2u] >> (16u * (k & 1u))) & 0xFFFFu) + NRQ_SCRATCH : zero_at;
+}
 template <int WB, int G = 1, bool FAST = true> SB_HD void ph_store(const StripCtx<WB, G> &c, NRQ_GAS uint8_t *ostage, uint32_t tid, uint32_t nt) {
   constexpr int STB = 8;
   const NRQ_GAS uint16_t *colslot = c.template arr<uint16_t>(c.h->off_colslot);
@@ -1260,15 +1285,14 @@ template <int WB, int G = 1, bool FAST = true> SB_HD void ph_store(const StripCt
       /* one trip to L2 for the next NRQ_STORE_TRIP entries of every lane's list (nearly always all that is left), then the
        * strips, a chunk of entries at a time while a lane of the wave still has some */
       constexpr uint32_t TR = NRQ_STORE_TRIP;
-      uint32_t sl[TR];
-#pragma unroll
-      for (uint32_t k = 0; k < TR; k++) sl[k] = e + k < end ? (uint32_t)osl[e + k] + NRQ_SCRATCH : zero_at;
+      uint32_t raw[TR / 2u];
+      store_trip(osl, e, end, raw);
 #pragma unroll
       for (uint32_t k0 = 0; k0 < TR; k0 += CH) {
         if (k0 && !NRQ_WAVE_ANY(e + k0 < end)) break;
         SV<WB> v[CH];
 #pragma unroll
-        for (uint32_t k = 0; k < CH; k++) v[k] = lds_get<WB, G>(c.lds, sl[k0 + k]);
+        for (uint32_t k = 0; k < CH; k++) v[k] = lds_get<WB, G>(c.lds, store_slot(raw, k0 + k, e, end, zero_at));
 #pragma unroll
         for (uint32_t k = 0; k + 1u < CH; k += 2u)
 #pragma unroll
