@@ -318,12 +318,15 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       NRQ_STAMP(4);
       ph_dense_fold<WB, G>(c, vt, VNT);
       __syncthreads();
+      NRQ_MARK(c, 4);
       if (dense_fold_shared(VNT) || G > 1) { /* (then the fold leaves its products in the accumulator copies) */
         ph_hdpc_reduce<WB, G>(c, vt, VNT);
         __syncthreads();
       }
+      NRQ_MARK(c, 5);
       ph_dense_free<WB, G>(c, vt, VNT);
       __syncthreads();
+      NRQ_MARK(c, 6);
       ph_dense_cu<WB, G>(c, vt, VNT);
       __syncthreads();
       NRQ_STAMP(5);
