@@ -211,7 +211,6 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
 #ifndef NRQ_SCATTER_LATE_PCT
 #define NRQ_SCATTER_LATE_PCT 20u
 #endif
-      const uint32_t sm = NT > NRQ_HDPC_NT_ ? s1 - (uint32_t)((uint64_t)(s1 - s0) * NRQ_SCATTER_LATE_PCT / 100u) : s1;
       /* ... and part of the gather portion: the gather of an encode strip is bound by its bytes in flight against the memory
        * latency and ends with the forward waves (more of it in flight there would delay their op words); in the HDPC window
        * nobody waits for op words.  K=8192 T=1280, encode / decode solve kernel in ms at gather % / scatter %: 0/35 7.09 / 6.28,
@@ -220,7 +219,15 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
 #ifndef NRQ_GATHER_LATE_PCT
 #define NRQ_GATHER_LATE_PCT 40u
 #endif
-      const uint32_t um = NT > NRQ_HDPC_NT_ ? u1 - (uint32_t)((uint64_t)(u1 - u0) * NRQ_GATHER_LATE_PCT / 100u) : u1;
+#ifndef NRQ_SCATTER_LATE_PCT_NARROW
+#define NRQ_SCATTER_LATE_PCT_NARROW 10u
+#endif
+#ifndef NRQ_GATHER_LATE_PCT_NARROW
+#define NRQ_GATHER_LATE_PCT_NARROW 15u
+#endif
+      constexpr uint32_t SLATE = WB >= 8 ? NRQ_SCATTER_LATE_PCT : NRQ_SCATTER_LATE_PCT_NARROW, GLATE = WB >= 8 ? NRQ_GATHER_LATE_PCT : NRQ_GATHER_LATE_PCT_NARROW;
+      const uint32_t sm = NT > NRQ_HDPC_NT_ ? s1 - (uint32_t)((uint64_t)(s1 - s0) * SLATE / 100u) : s1;
+      const uint32_t um = NT > NRQ_HDPC_NT_ ? u1 - (uint32_t)((uint64_t)(u1 - u0) * GLATE / 100u) : u1;
       const uint32_t strip = strip0 + sidx;
       if (strip >= nstrips) { /* no such strip: everybody moves this portion */
         if (u1 > u0) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, u0, u1, (tid) / G, (NT) / G, subl);
@@ -291,7 +298,12 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
 
       {
         constexpr uint32_t HNT = NT < NRQ_HDPC_NT_ ? NT : NRQ_HDPC_NT_;
-        if (tid < HNT) ph_hdpc<WB, G>(c, tid / G, HNT / G);
+        /* (narrow strips: the H sums in registers -- on 16-byte strips that form is slower, 24 k against 17.5 k clocks for the
+         * recurrence: 4 x H operations per column instead of four LDS atomics) */
+#ifndef NRQ_HDPC_REGS_MAX_WB
+#define NRQ_HDPC_REGS_MAX_WB 4
+#endif
+        if (tid < HNT) { ph_hdpc<WB, G, (NT >= 512 && G == 1 && WB <= NRQ_HDPC_REGS_MAX_WB)>(c, tid / G, HNT / G); }
         else { /* the waves HDPC leaves idle */
           if (u1 > um) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, um, u1, (tid - HNT) / G, (NT - HNT) / G, subl);
           if (s1 > sm) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, sm, s1, (tid - HNT) / G, (NT - HNT) / G, subl);

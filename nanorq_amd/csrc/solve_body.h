@@ -95,7 +95,7 @@ template <class P> SB_HD P nrq_uniform_ptr(P p) { return p; }
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NRQ_MARK(c, i) do { if ((c).dbg && (c).dbg_t0) (c).dbg[i] = (unsigned long long)clock64(); } while (0)
-#define NRQ_MARK_MAX(c, i) do { if ((c).dbg) atomicMax(&(c).dbg[i], (unsigned long long)clock64()); } while (0)
+#define NRQ_MARK_MAX(c, i) do { if ((c).dbg) atomicMax(&(c).dbg[i], (unsigned long long)clock64()); } while (0) /* (costs the marked waves: 768 atomics on one address are ~20 k clocks) */
 #else
 #define NRQ_MARK(c, i) do { } while (0)
 #define NRQ_MARK_MAX(c, i) do { } while (0)
@@ -268,6 +268,30 @@ template <int WB> SB_HD SV<WB> g_get_l2(const NRQ_GAS uint8_t *p) {
   return g_get<WB>(p, WB);
 #endif
 }
+/* CB bytes of a symbol row from an address aligned to the strip width only (declared 2-byte aligned; the memory path takes
+ * unaligned vector loads) */
+template <int CB, int AL> SB_HD SV<CB> g_get_chunk(const NRQ_GAS uint8_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  SV<CB> r = sv_zero<CB>();
+  if constexpr (CB == 16) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef u4 u4a __attribute__((aligned(2)));
+    const u4 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u4a *>(p));
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  } else if constexpr (CB == 8) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    typedef u2 u2a __attribute__((aligned(2)));
+    const u2 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u2a *>(p));
+    r.w[0] = v.x; r.w[1] = v.y;
+  } else {
+    typedef uint32_t u1a __attribute__((aligned(2)));
+    r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u1a *>(p));
+  }
+  return r;
+#else
+  return g_get<CB>(p, CB);
+#endif
+}
 template <int WB> SB_HD void g_put(NRQ_GAS uint8_t *p, uint32_t valid, const SV<WB> &v) {
   if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
     if constexpr (WB == 16) {
@@ -410,9 +434,98 @@ template <int WB> struct GroupSrc { /* where the rows of one line group of one b
 /* AL: every piece is a whole, aligned strip element (T a multiple of the strip width, rows aligned): the loop then holds no
  * byte-wise path at all -- with one in it, the compiler waits for ALL outstanding loads wherever the paths join, and the
  * pieces of a trip, meant to be in flight together, are fetched one memory latency after the other */
+/* Narrow strips (2, 4, 8 bytes): a request per strip piece moves 2-8 bytes, and the gather is bound by its requests in flight
+ * against the memory latency -- at K=27000 (4-byte strips) and K'=56403 (2-byte strips) the movers, not the forward waves or
+ * the HDPC phase, bounded both of their windows.  The strips of a line group are neighbours in the symbol row, so one load
+ * of CB = 4, 8 or 16 bytes brings NP = CB / WB of them; the pieces then go to their strips' staging buffers.  Needs
+ * every chunk of a row whole (T a multiple of CB) and rows that start on a strip boundary.  A range [u0, u1) of pieces owns
+ * the chunks whose first piece it holds: consecutive ranges tile the chunks as they tile the pieces. */
+template <int WB, int CB> SB_HD SV<WB> chunk_piece(const SV<CB> &v, int j) {
+  SV<WB> r = sv_zero<WB>();
+  if constexpr (WB == 8) { r.w[0] = v.w[2 * j]; r.w[1] = v.w[2 * j + 1]; }
+  else if constexpr (WB == 4) r.w[0] = v.w[j];
+  else r.w[0] = (v.w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+  return r;
+}
+template <int WB, int CB, bool PIPELINED> SB_HD void pf_gather_chunks(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0,
+                                                                      uint32_t u1, uint32_t p, uint32_t np) {
+  constexpr int NP = CB / WB, LNP = NP == 8 ? 3 : NP == 4 ? 2 : 1, PB = 4;
+  const uint32_t lc = g.lsub - (uint32_t)LNP, cmask = (1u << lc) - 1u; /* chunk unit c = (row c >> lc, chunk c & cmask) */
+  const uint32_t c0 = (u0 + NP - 1u) >> LNP, c1 = (u1 + NP - 1u) >> LNP;
+  auto fetch = [&](uint32_t cu, uint32_t src) {
+    const uint32_t strip = g.strip0 + ((cu & cmask) << LNP);
+    SV<CB> v = sv_zero<CB>();
+    if (cu < c1 && src != NRQ_ROW_ZERO && strip < g.nstrips) {
+      const NRQ_GAS uint8_t *b = (src & NRQ_ROW_REP) ? g.rep + (size_t)(src & 0x7FFFFFFFu) * g.T : g.src + (size_t)src * g.T;
+      v = g_get_chunk<CB, WB>(b + (size_t)strip * WB);
+    }
+    return v;
+  };
+  auto put = [&](uint32_t cu, const SV<CB> &v) {
+    if (cu >= c1) return;
+    NRQ_GAS uint8_t *d = stage + (size_t)((cu & cmask) << LNP) * stage_stride + (size_t)(cu >> lc) * WB;
+#pragma unroll
+    for (int j = 0; j < NP; j++) g_put_stream<WB>(d + (size_t)j * stage_stride, WB, chunk_piece<WB, CB>(v, j));
+  };
+  const uint32_t first = c0 + p, step = (uint32_t)PB * np;
+  if (first >= c1) return;
+  if constexpr (!PIPELINED) {
+    for (uint32_t base = first; base < c1; base += step) {
+      uint32_t sr[PB];
+      SV<CB> v[PB];
+#pragma unroll
+      for (int q = 0; q < PB; q++) { const uint32_t cu = base + (uint32_t)q * np; sr[q] = cu < c1 ? g.rowsrc[cu >> lc] : NRQ_ROW_ZERO; }
+#pragma unroll
+      for (int q = 0; q < PB; q++) v[q] = fetch(base + (uint32_t)q * np, sr[q]);
+#pragma unroll
+      for (int q = 0; q < PB; q++) put(base + (uint32_t)q * np, v[q]);
+    }
+    return;
+  }
+  uint32_t s_cur[PB], s_nxt[PB];
+  SV<CB> v_prev[PB], v_cur[PB];
+#pragma unroll
+  for (int q = 0; q < PB; q++) { const uint32_t cu = first + (uint32_t)q * np; s_cur[q] = cu < c1 ? g.rowsrc[cu >> lc] : NRQ_ROW_ZERO; }
+  uint32_t prev = 0;
+  bool have_prev = false;
+  for (uint32_t base = first; base < c1; base += step) {
+#pragma unroll
+    for (int q = 0; q < PB; q++) { const uint32_t cu = base + step + (uint32_t)q * np; s_nxt[q] = cu < c1 ? g.rowsrc[cu >> lc] : NRQ_ROW_ZERO; }
+#pragma unroll
+    for (int q = 0; q < PB; q++) v_cur[q] = fetch(base + (uint32_t)q * np, s_cur[q]);
+    if (have_prev) {
+#pragma unroll
+      for (int q = 0; q < PB; q++) put(prev + (uint32_t)q * np, v_prev[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < PB; q++) { v_prev[q] = v_cur[q]; s_cur[q] = s_nxt[q]; }
+    prev = base;
+    have_prev = true;
+  }
+#pragma unroll
+  for (int q = 0; q < PB; q++) put(prev + (uint32_t)q * np, v_prev[q]);
+}
+#ifndef NRQ_GATHER_CHUNKS
+#define NRQ_GATHER_CHUNKS 1
+#endif
 template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_gather_impl(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
                                        uint32_t p, uint32_t np, uint32_t sub) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u; /* unit u = (row u >> lsub, piece u & pmask) */
+#if NRQ_GATHER_CHUNKS
+  if constexpr (G == 1 && WB < 16) {
+    const uint32_t span = (uint32_t)WB << lsub, cb = span >= 16u ? 16u : span; /* bytes of a row that a line group holds; of a chunk */
+    const bool whole = cb > (uint32_t)WB && g.T % cb == 0u &&
+                       ((reinterpret_cast<uintptr_t>(g.src) | reinterpret_cast<uintptr_t>(g.rep)) & (uintptr_t)(WB - 1)) == 0;
+    if (whole) {
+      if (cb == 16u) pf_gather_chunks<WB, 16, PIPELINED>(g, stage, stage_stride, u0, u1, p, np);
+      else if constexpr (WB < 8) {
+        if (cb == 8u) pf_gather_chunks<WB, 8, PIPELINED>(g, stage, stage_stride, u0, u1, p, np);
+        else if constexpr (WB < 4) pf_gather_chunks<WB, 4, PIPELINED>(g, stage, stage_stride, u0, u1, p, np);
+      }
+      return;
+    }
+  }
+#endif
 #ifndef NRQ_GATHER_PB
 #define NRQ_GATHER_PB 4
 #endif
@@ -756,7 +869,93 @@ template <int WB, int G = 1> SB_HD void ph_hdpc_reduce(const StripCtx<WB, G> &c,
                                      * variant built for four per CU has the registers: K=1000 1062 -> 1102 Gbit/s, K=2000 1210 -> 1242;
                                      * the single-wave variant gains nothing) */
 #endif
-template <int WB, int G = 1> SB_HD void ph_hdpc(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+/* all ones if bit h of x is set (one v_bfe_i32) */
+SB_HD uint32_t nrq_bit_mask(uint32_t x, uint32_t h) { return (uint32_t)((int32_t)(x << (31u - h)) >> 31); }
+/* REGS form of a thread's chunk [a, b) (whole groups of 8 columns): the H sums live in REGISTERS while the thread walks its
+ * columns -- a column adds g to two of them, chosen by a two-bit mask over the H rows (one bit-field extract and one
+ * a ^ (b & m) per row and dword) -- and reach the thread's LDS copy once, at the end.  With LDS atomics per column (four
+ * ds_xor_b64 on 16-byte strips, their 64 lanes on 16 bank pairs) the recurrence was bound by the LDS pipeline: 17.5 k clocks for
+ * the 24 columns of the longest thread at K=8192, and the same count of atomics per column whatever the strip width (72 k
+ * clocks on 4-byte strips at K=27000, 211 k on 2-byte strips at K'=56403).  Needs 4 * H registers on 16-byte strips: the big
+ * workgroup's variant only. */
+#define NRQ_MIN_H 10u /* RFC 6330 table 2: 10 <= H <= 16 */
+template <int WB, int G> SB_HD void hdpc_chunk_regs(const StripCtx<WB, G> &c, uint32_t a, uint32_t b, uint32_t n, uint32_t H, uint32_t mine,
+                                                    uint32_t zero_at, const NRQ_GAS uint16_t *pivof, const NRQ_GAS uint8_t *b12,
+                                                    const NRQ_GAS uint8_t *Gm) {
+  constexpr int ND = SV<WB>::ND;
+  SV<WB> acc[16]; /* (H <= 16) */
+#pragma unroll
+  for (uint32_t h = 0; h < 16; h++) acc[h] = sv_zero<WB>();
+  SV<WB> g = sv_zero<WB>();
+  for (uint32_t c0 = a; c0 < b; c0 += 8) {
+    const uint4 sl = *reinterpret_cast<const NRQ_GAS uint4 *>(pivof + c0);
+    const uint2 bb = *reinterpret_cast<const NRQ_GAS uint2 *>(b12 + c0);
+    const uint32_t slw[4] = {sl.x, sl.y, sl.z, sl.w};
+    const uint32_t bbw[2] = {bb.x, bb.y};
+    /* the eight strips first, unconditionally (a column without a slot, or beyond the chunk, reads the lane's zero scratch
+     * slot): nothing between them that the LDS would have to keep in order */
+    SV<WB> y[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+      const uint32_t sq = (slw[q >> 1] >> ((q & 1u) * 16u)) & 0xFFFFu;
+      y[q] = lds_get<WB, G>(c.lds, (c0 + q < b && sq != NRQ_NOSLOT) ? sq + NRQ_SCRATCH : zero_at);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+      const uint32_t col = c0 + q;
+      if (col >= b) break;
+      g = sv_xtime<WB>(g);
+      sv_xor<WB>(g, y[q]);
+      if (col + 1 < n) {
+        const uint32_t e = (bbw[q >> 2] >> ((q & 3u) * 8u)) & 0xFFu;
+        const uint32_t bits = (1u << (e & 15u)) ^ (1u << (e >> 4));
+#pragma unroll
+        for (uint32_t h = 0; h < 16; h++) {
+          if (h < NRQ_MIN_H || h < H) { /* (no `break`: the loop must unroll completely, or acc[] is an array in scratch memory) */
+            const uint32_t m = nrq_bit_mask(bits, h);
+#pragma unroll
+            for (int i = 0; i < ND; i++) acc[h].w[i] = nrq_xor_and(acc[h].w[i], g.w[i], m);
+          }
+        }
+      } else { /* last column of MT is alpha^h */
+        SV<WB> v = g;
+#pragma unroll
+        for (uint32_t h = 0; h < 16; h++) {
+          if (h < H) {
+            sv_xor<WB>(acc[h], v);
+            v = sv_xtime<WB>(v);
+          }
+        }
+      }
+    }
+  }
+  NRQ_MARK(c, 0);
+  if (b < n) { /* what the chunk owes to the columns beyond b: G[.][b] * alpha * g */
+    SV<WB> pw[8];
+    pw[0] = sv_xtime<WB>(g);
+#pragma unroll
+    for (int k = 1; k < 8; k++) pw[k] = sv_xtime<WB>(pw[k - 1]);
+    uint32_t coef[16];
+#pragma unroll
+    for (uint32_t h = 0; h < 16; h++) coef[h] = h < H ? Gm[(size_t)h * n + b] : 0u;
+#pragma unroll
+    for (uint32_t h = 0; h < 16; h++) {
+      if (h < NRQ_MIN_H || h < H) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const uint32_t m = nrq_bit_mask(coef[h], (uint32_t)k);
+#pragma unroll
+          for (int i = 0; i < ND; i++) acc[h].w[i] = nrq_xor_and(acc[h].w[i], pw[k].w[i], m);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (uint32_t h = 0; h < 16; h++) {
+    if (h < H) lds_xor<WB, G>(c.cf(), mine + h, acc[h]);
+  }
+}
+template <int WB, int G = 1, bool REGS = false> SB_HD void ph_hdpc(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(c.kc);
   const NRQ_GAS uint8_t *Gm = gptr<uint8_t>(c.kc + kh->off_g); /* the HDPC block */
   const NRQ_GAS uint8_t *b12 = gptr<uint8_t>(c.kc + kh->off_b12);
@@ -774,6 +973,12 @@ template <int WB, int G = 1> SB_HD void ph_hdpc(const StripCtx<WB, G> &c, uint32
   if (a >= n || (base == 0u && tid >= extra)) return;
   const uint32_t len = gsz * (base + (tid < extra ? 1u : 0u));
   const uint32_t b = (a + len < n) ? a + len : n;
+  if constexpr (REGS && G == 1) {
+    if (gsz == 8u) {
+      hdpc_chunk_regs<WB, G>(c, a, b, n, H, mine, tid & (NRQ_SCRATCH - 1u), pivof, b12, Gm);
+      return;
+    }
+  }
   SV<WB> g = sv_zero<WB>();
   if (gsz < 8u) { /* one group of at most 4 columns per thread (groups < nt): slot numbers and MT rows column by column, in flight together */
     uint32_t sl4[4], e4[4];

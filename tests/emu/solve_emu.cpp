@@ -17,6 +17,8 @@ static uint32_t g_dense_shared_min_nt = 512; /* workgroup size from which the de
 #define NRQ_DENSE_SHARED_MIN_NT g_dense_shared_min_nt
 #include "../../nanorq_amd/csrc/solve_body.h"
 extern "C" void emu_set_dense_shared_min_nt(uint32_t v) { g_dense_shared_min_nt = v; }
+static int g_hdpc_regs = 0; /* 1: the HDPC phase in the form of the big workgroup (register accumulators) */
+extern "C" void emu_set_hdpc_regs(int v) { g_hdpc_regs = v; }
 
 /* The forward passes in the order the kernel's wave 0 issues them (plan.h): step q applies row q-NRQ_PIPE,
  * then reads the sources of row q -- so a plan that puts dependent rows closer than NRQ_PIPE rows apart
@@ -70,7 +72,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
     PHASE(ph_clear);
   }
   if (!emu_forward<WB>(c)) return -7;
-  PHASE(ph_hdpc);
+  if (g_hdpc_regs) { for (uint32_t t = 0; t < NT; t++) ph_hdpc<WB, 1, true>(c, t, NT); } else PHASE(ph_hdpc);
   PHASE(ph_hdpc_reduce);
   for (uint32_t w0 = 0; w0 < c.h->lpr; w0 += low_table_words<WB>(c)) {
     for (uint32_t t = 0; t < NT; t++) ph_low_tables<WB>(c, w0, t, NT);

@@ -27,6 +27,7 @@ def emu():
         L.emu_lds_bytes.argtypes = [C.c_void_p, C.c_uint32]
         L.emu_lds_bytes.restype = C.c_uint32
         L.emu_set_dense_shared_min_nt.argtypes = [C.c_uint32]
+        L.emu_set_hdpc_regs.argtypes = [C.c_int]
         _EMU = L
     return _EMU
 

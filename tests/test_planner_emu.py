@@ -34,7 +34,9 @@ def _encode_case(orc, K, T, wb, nrep=7):
 
 
 @pytest.mark.parametrize("K,T,wb", [(10, 8, 16), (10, 8, 4), (10, 24, 16), (100, 64, 16), (100, 36, 8), (100, 10, 4),
-                                    (100, 6, 2), (1024, 32, 16), (1024, 20, 8), (8192, 16, 16)])
+                                    (100, 6, 2), (1024, 32, 16), (1024, 20, 8), (8192, 16, 16),
+                                    # T a multiple of 16: narrow strips gathered as 16-byte chunks of their line group (pf_gather_chunks)
+                                    (100, 32, 8), (100, 16, 2), (1024, 48, 4), (300, 160, 2)])
 def test_encode_emulated_matches_oracle(orc, K, T, wb):
     _encode_case(orc, K, T, wb)
 
@@ -79,6 +81,20 @@ def test_dense_fold_with_shared_multiples(orc, K, T, wb):
     try:
         _encode_case(orc, K, T, wb)
     finally:
+        emu().emu_set_dense_shared_min_nt(512)
+
+
+@pytest.mark.parametrize("K,T,wb", [(1024, 32, 16), (1024, 20, 8), (1024, 12, 4), (2000, 6, 2), (8192, 16, 16)])
+def test_hdpc_with_register_accumulators(orc, K, T, wb):
+    """The big-workgroup form of the HDPC phase (hdpc_chunk_regs: the H sums in registers over a thread's columns, one LDS
+    update per thread) on the emulator's 256-thread workgroup, with the dense fold of that workgroup."""
+    from emu_support import emu
+    emu().emu_set_hdpc_regs(1)
+    emu().emu_set_dense_shared_min_nt(1)
+    try:
+        _encode_case(orc, K, T, wb)
+    finally:
+        emu().emu_set_hdpc_regs(0)
         emu().emu_set_dense_shared_min_nt(512)
 
 
