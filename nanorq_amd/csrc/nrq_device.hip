@@ -328,7 +328,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
         __syncthreads();
       }
       NRQ_STAMP(4);
-      ph_dense_fold<WB, G>(c, vt, VNT);
+      ph_dense_fold<WB, G, (NT == 64)>(c, vt, VNT);
       __syncthreads();
       NRQ_MARK(c, 4);
       if (dense_fold_shared(VNT) || G > 1) { /* (then the fold leaves its products in the accumulator copies) */
@@ -336,10 +336,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
         __syncthreads();
       }
       NRQ_MARK(c, 5);
-      ph_dense_free<WB, G>(c, vt, VNT);
+      ph_dense_free<WB, G, (NT == 64)>(c, vt, VNT);
       __syncthreads();
       NRQ_MARK(c, 6);
-      ph_dense_cu<WB, G>(c, vt, VNT);
+      ph_dense_cu<WB, G, (NT == 64)>(c, vt, VNT);
       __syncthreads();
       NRQ_STAMP(5);
       if (ybuf) { /* split solve (narrow strips): back-substitution and results are nrq_backsub_kernel / nrq_collect_kernel */

@@ -1162,18 +1162,38 @@ template <int WB, int G = 1> SB_HD void ph_clear_x(const StripCtx<WB, G> &c, uin
 /* (a single-wave workgroup, nt == 64, also shares the multiples: with one wave the few (h, p) pairs of a small block
  * leave most lanes idle either way, and the general multiply is 3.4x the instructions of the shared form) */
 SB_HD bool dense_fold_shared(uint32_t nt) { return nt >= NRQ_DENSE_SHARED_MIN_NT || nt == 64u; }
-template <int WB, int G = 1> SB_HD void ph_dense_fold(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+/* BATCH (the single-wave variant): the coefficients of a thread's terms are asked for eight at a time before the first
+ * is used -- one after the other each was a trip to L2 in front of ~230 instructions (K=1000: 5 terms per thread, fold 12 k clocks
+ * of a 110 k strip; K=100: free columns 14 k of 140 k).  K=100: dense stage 45 k -> 38 k clocks, solve 7.58 / 7.16 -> 7.24 / 6.84 ms; the 256-thread
+ * variant LOSES 2-4 % with it (K=500, 1000, 2000: its fold is bound by the multiplications of four waves per SIMD, and the unrolled
+ * form costs it 12 more spills), so it keeps the loop. */
+template <int WB, int G = 1, bool BATCH = false> SB_HD void ph_dense_fold(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint8_t *mh = c.template arr<uint8_t>(c.h->off_mh);
   const uint32_t H = c.h->H, r2 = c.h->r2, M = c.h->M;
   if (!dense_fold_shared(nt) && G == 1) {
     const uint32_t hq = tid & 15u, part = tid >> 4, nparts = nt >> 4;
     if (hq >= H) return;
     SV<WB> acc = sv_zero<WB>();
+    if constexpr (BATCH) {
+      for (uint32_t p0 = part; p0 < r2; p0 += 8u * nparts) {
+        uint32_t coef[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) coef[i] = mh[(size_t)hq * r2 + (p0 + i * nparts < r2 ? p0 + i * nparts : p0)];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+          const uint32_t p = p0 + i * nparts;
+          if (p >= r2 || !coef[i]) continue;
+          SV<WB> t = sv_mul<WB>(lds_get<WB, G>(c.slots(), M + p), coef[i]);
+          sv_xor<WB>(acc, t);
+        }
+      }
+    } else {
     for (uint32_t p = part; p < r2; p += nparts) {
       uint32_t coef = mh[(size_t)hq * r2 + p];
       if (!coef) continue;
       SV<WB> t = sv_mul<WB>(lds_get<WB, G>(c.slots(), M + p), coef);
       sv_xor<WB>(acc, t);
+    }
     }
     lds_xor<WB, G>(c.slots(), c.h->S + hq, acc);
     return;
@@ -1199,11 +1219,28 @@ template <int WB, int G = 1> SB_HD void ph_dense_fold(const StripCtx<WB, G> &c, 
 }
 
 /* phase 4c: free columns C_f = SUM_h hinv[f][h] * R_h */
-template <int WB, int G = 1> SB_HD void ph_dense_free(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1, bool BATCH = false> SB_HD void ph_dense_free(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint8_t *hinv = c.template arr<uint8_t>(c.h->off_hinv);
   const uint32_t H = c.h->H, nfree = c.h->nfree;
   const uint32_t hq = tid & 15u;
   if (hq >= H) return;
+  if constexpr (BATCH) {
+    const uint32_t nparts = nt >> 4;
+    for (uint32_t f0 = tid >> 4; f0 < nfree; f0 += 8u * nparts) {
+      uint32_t coef[8];
+#pragma unroll
+      for (uint32_t i = 0; i < 8; i++) coef[i] = hinv[(size_t)(f0 + i * nparts < nfree ? f0 + i * nparts : f0) * H + hq];
+      const SV<WB> r = lds_get<WB, G>(c.slots(), c.h->S + hq);
+#pragma unroll
+      for (uint32_t i = 0; i < 8; i++) {
+        const uint32_t f = f0 + i * nparts;
+        if (f >= nfree || !coef[i]) continue;
+        SV<WB> t = sv_mul<WB>(r, coef[i]);
+        lds_xor<WB, G>(c.cf(), f, t);
+      }
+    }
+    return;
+  }
   for (uint32_t f = tid >> 4; f < nfree; f += nt >> 4) {
     uint32_t coef = hinv[(size_t)f * H + hq];
     if (!coef) continue;
@@ -1213,10 +1250,15 @@ template <int WB, int G = 1> SB_HD void ph_dense_free(const StripCtx<WB, G> &c, 
 }
 
 /* phase 4d: values of all u inactive columns */
-template <int WB, int G = 1> SB_HD void ph_dense_cu(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1, bool BATCH = false> SB_HD void ph_dense_cu(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint16_t *pivx = c.template arr<uint16_t>(c.h->off_pivx);
   const NRQ_GAS uint32_t *fbits = c.template arr<uint32_t>(c.h->off_fbits);
   const NRQ_GAS uint16_t *freex = c.template arr<uint16_t>(c.h->off_freex);
+  uint32_t fx0 = 0, px0 = 0;
+  if constexpr (BATCH) { /* (the map entries of both loops' first trips in flight together) */
+    if (tid < c.h->nfree) fx0 = freex[tid];
+    if (tid < c.h->r2) px0 = pivx[tid];
+  }
   for (uint32_t p = tid; p < c.h->r2; p += nt) {
     SV<WB> v = lds_get<WB, G>(c.slots(), c.h->M + p);
     uint32_t fb = fbits[p];
@@ -1226,9 +1268,9 @@ template <int WB, int G = 1> SB_HD void ph_dense_cu(const StripCtx<WB, G> &c, ui
       SV<WB> t = lds_get<WB, G>(c.cf(), f);
       sv_xor<WB>(v, t);
     }
-    lds_put<WB, G>(c.cu(), pivx[p], v);
+    lds_put<WB, G>(c.cu(), (BATCH && p == tid) ? px0 : (uint32_t)pivx[p], v);
   }
-  for (uint32_t f = tid; f < c.h->nfree; f += nt) lds_put<WB, G>(c.cu(), freex[f], lds_get<WB, G>(c.cf(), f));
+  for (uint32_t f = tid; f < c.h->nfree; f += nt) lds_put<WB, G>(c.cu(), (BATCH && f == tid) ? fx0 : (uint32_t)freex[f], lds_get<WB, G>(c.cf(), f));
 }
 
 /* phase 5a: 16-entry XOR tables over groups of 4 inactive columns (region X is reused) */

@@ -91,13 +91,16 @@ if __name__ == "__main__" and sys.argv[1] != "timeline":
 def timeline(path, last=40):
     """the last `last` kernel dispatches with start offsets: where the gaps between kernels are"""
     db = sqlite3.connect(path)
-    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    try:
+        rows = db.execute("select name, start, end, grid_x, queue_id from kernels order by start").fetchall()
+    except sqlite3.Error:
+        rows = [r + (0, 0) for r in db.execute("select name, start, end from kernels order by start").fetchall()]
     rows = rows[-last:]
     t0 = rows[0][1]
     prev_end = t0
-    print("# start_us  gap_before_us  dur_us  kernel")
-    for name, s, e in rows:
-        print("%10.1f %10.1f %10.1f  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, short(name)))
+    print("# start_us  gap_before_us  dur_us  end_us  grid_x  queue  kernel")
+    for name, s, e, gx, qid in rows:
+        print("%10.1f %10.1f %10.1f %10.1f %9s %6s  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, (e - t0) / 1e3, gx, qid, short(name)))
         prev_end = max(prev_end, e)
 
 
