@@ -14,7 +14,7 @@ cd /tmp
 timeout 900 python $REPO/bench.py > "$OUT/${TAG}_bench_1gpu.json" 2> "$OUT/bench_1gpu.err"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 python $REPO/tools/rocprof_summary.py stats $(find "$OUT/trace" -name '*.db' | head -1) > "$OUT/${TAG}_kernel_stats.txt"
-python $REPO/tools/rocprof_summary.py timeline $(find "$OUT/trace" -name '*.db' | head -1) 24 > "$OUT/${TAG}_kernel_timeline.txt"
+python $REPO/tools/rocprof_summary.py timeline $(find "$OUT/trace" -name "*.db" | head -1) -1 > "$OUT/${TAG}_kernel_timeline.txt"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum"; do

@@ -89,13 +89,19 @@ if __name__ == "__main__" and sys.argv[1] != "timeline":
 
 
 def timeline(path, last=40):
-    """the last `last` kernel dispatches with start offsets: where the gaps between kernels are"""
+    """the last `last` kernel dispatches with start offsets: where the gaps between kernels are (last < 0: the last two steps of a
+    bench run, found by their solve kernels)"""
     db = sqlite3.connect(path)
     try:
         rows = db.execute("select name, start, end, grid_x, queue_id from kernels order by start").fetchall()
     except sqlite3.Error:
         rows = [r + (0, 0) for r in db.execute("select name, start, end from kernels order by start").fetchall()]
-    rows = rows[-last:]
+    solves = [i for i, r in enumerate(rows) if "nrq_solve_kernel" in r[0]]
+    if last < 0 and len(solves) >= 5:
+        # the last two steps of the run: from the fourth-last solve launch (an encode) to the end of the last one, with what ran before it
+        rows = rows[max(0, solves[-4] - 8):solves[-1] + 4]
+    else:
+        rows = rows[-abs(last):]
     t0 = rows[0][1]
     prev_end = t0
     print("# start_us  gap_before_us  dur_us  end_us  grid_x  queue  kernel")
