@@ -887,9 +887,17 @@ template <int WB, int G> SB_HD void hdpc_chunk_regs(const StripCtx<WB, G> &c, ui
 #pragma unroll
   for (uint32_t h = 0; h < 16; h++) acc[h] = sv_zero<WB>();
   SV<WB> g = sv_zero<WB>();
+  /* (the slot numbers and MT rows of the NEXT group are asked for before this group's strips: a trip to L2 per group of eight
+   * columns otherwise stands in front of ~350 instructions -- 14 groups per thread at K'=56403) */
+  uint4 sl_n = *reinterpret_cast<const NRQ_GAS uint4 *>(pivof + a);
+  uint2 bb_n = *reinterpret_cast<const NRQ_GAS uint2 *>(b12 + a);
   for (uint32_t c0 = a; c0 < b; c0 += 8) {
-    const uint4 sl = *reinterpret_cast<const NRQ_GAS uint4 *>(pivof + c0);
-    const uint2 bb = *reinterpret_cast<const NRQ_GAS uint2 *>(b12 + c0);
+    const uint4 sl = sl_n;
+    const uint2 bb = bb_n;
+    if (c0 + 8u < b) {
+      sl_n = *reinterpret_cast<const NRQ_GAS uint4 *>(pivof + c0 + 8u);
+      bb_n = *reinterpret_cast<const NRQ_GAS uint2 *>(b12 + c0 + 8u);
+    }
     const uint32_t slw[4] = {sl.x, sl.y, sl.z, sl.w};
     const uint32_t bbw[2] = {bb.x, bb.y};
     /* the eight strips first, unconditionally (a column without a slot, or beyond the chunk, reads the lane's zero scratch
