@@ -618,17 +618,39 @@ __global__ __launch_bounds__(256) void nrq_backsub_kernel(const nrq_job *__restr
       store(Y + (size_t)uslot[x] * T + col0, t);
     }
   const uint32_t k0 = (uint32_t)(((uint64_t)npiv * chunk) / nchunks), k1 = (uint32_t)(((uint64_t)npiv * (chunk + 1u)) / nchunks);
-  for (uint32_t k = k0 + tid; k < k1; k += 256u) {
-    const uint32_t slot = pivslot[k];
+  /* A pivot per thread and trip: Y(slot) ^= W_k * C_u through the tables.  Everything a pivot needs from memory -- its slot, its
+   * row, its first WCH words of W -- is asked for while the pivot BEFORE it does its lookups (all loads unconditional: a word
+   * beyond wpr re-reads the last one and is not used): before, a pivot was a chain of seven trips (slot, row, five groups of four
+   * W words: 12 us per pivot at K'=56403, 1.8 ms per launch, 3.3 ms at K=27000 T=65504). */
+  constexpr uint32_t WCH = 20u;
+  auto words = [&](uint32_t k, uint32_t w0, uint32_t (&b)[WCH]) {
+#pragma unroll
+    for (uint32_t j = 0; j < WCH; j++) b[j] = wt[(size_t)(w0 + j < wpr ? w0 + j : wpr - 1u) * stride + k];
+  };
+  uint32_t k = k0 + tid;
+  if (k >= k1) return;
+  uint32_t bits_n[WCH];
+  SV<16> acc_n[NQ];
+  NRQ_GAS uint8_t *row_n = Y + (size_t)pivslot[k] * T + col0;
+  load(row_n, acc_n);
+  words(k, 0u, bits_n);
+  for (; k < k1; k += 256u) {
     SV<16> acc[NQ];
-    NRQ_GAS uint8_t *row = Y + (size_t)slot * T + col0;
-    load(row, acc);
-    for (uint32_t w0 = 0; w0 < wpr; w0 += 4u) { /* four W words in flight */
-      uint32_t bits[4];
+    uint32_t bits[WCH];
+    NRQ_GAS uint8_t *row = row_n;
 #pragma unroll
-      for (uint32_t j = 0; j < 4; j++) bits[j] = w0 + j < wpr ? wt[(size_t)(w0 + j) * stride + k] : 0u;
+    for (int z = 0; z < NQ; z++) acc[z] = acc_n[z];
 #pragma unroll
-      for (uint32_t j = 0; j < 4; j++) {
+    for (uint32_t j = 0; j < WCH; j++) bits[j] = bits_n[j];
+    const uint32_t kn = k + 256u;
+    if (kn < k1) {
+      row_n = Y + (size_t)pivslot[kn] * T + col0;
+      load(row_n, acc_n);
+      words(kn, 0u, bits_n);
+    }
+    for (uint32_t w0 = 0;;) {
+#pragma unroll
+      for (uint32_t j = 0; j < WCH; j++) {
         if (w0 + j >= wpr) break;
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
@@ -637,6 +659,9 @@ __global__ __launch_bounds__(256) void nrq_backsub_kernel(const nrq_job *__restr
           for (int z = 0; z < NQ; z++) sv_xor<16>(acc[z], lds_get<16>(smem, e * NQ + z));
         }
       }
+      w0 += WCH;
+      if (w0 >= wpr) break;
+      words(k, w0, bits); /* (more than WCH words: u > 640) */
     }
     store(row, acc);
   }
