@@ -564,7 +564,20 @@ template <int SB>
 __global__ __launch_bounds__(256) void nrq_backsub_kernel(const nrq_job *__restrict__ jobs, uint32_t T, uint8_t *__restrict__ ybuf,
                                                           size_t ybuf_stride, uint32_t nchunks) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const uint32_t tid = threadIdx.x, strip = blockIdx.x, chunk = blockIdx.y, blk = blockIdx.z;
+  const uint32_t tid = threadIdx.x, chunk = blockIdx.y, blk = blockIdx.z;
+  /* Workgroup i runs on XCD i % 8 (round-robin dispatch).  The strips that share a 128-byte line of every row -- 128 / SB
+   * neighbours -- are given to workgroups i, i + 8, i + 16 ... : same XCD, dispatched together, walking the pivots in step, so
+   * a line fetched for one of them is in that XCD's L2 for the others (with strip = i the neighbours sat on different XCDs and
+   * every one of them fetched the line from HBM: the kernel is bound by its scattered 32-byte row accesses). */
+  uint32_t strip = blockIdx.x;
+  {
+    constexpr uint32_t NB_ = 128u / SB, PER = 8u * NB_;
+    const uint32_t i = blockIdx.x, full = (gridDim.x / PER) * PER;
+    if (i < full) {
+      const uint32_t r = i % PER, g = (i / PER) * 8u + (r & 7u), j = r >> 3;
+      strip = g * NB_ + j;
+    }
+  }
   const uint8_t *plan = reinterpret_cast<const uint8_t *>(jobs[blk].plan);
   const nrq_plan_hdr *h = reinterpret_cast<const nrq_plan_hdr *>(plan);
   if (h->status) return;
