@@ -255,7 +255,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       c.dbg_t0 = tid == 0;
       done++;
       NRQ_STAMP(0);
-      pf_commit<WB, G>(c, stage_cur + (size_t)sidx * stage_stride + subl * WB, 0u, vt, VNT);
+      pf_commit<WB, G, (NT == 64 ? 4 : 8)>(c, stage_cur + (size_t)sidx * stage_stride + subl * WB, 0u, vt, VNT);
       ph_clear<WB, G>(c, vt, VNT);
       __syncthreads();
       NRQ_STAMP(1);

@@ -631,8 +631,10 @@ template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_gather(const 
 #ifndef NRQ_COMMIT_PB
 #define NRQ_COMMIT_PB 4
 #endif
-template <int WB, int G = 1> SB_HD void pf_commit(const StripCtx<WB, G> &c, const NRQ_GAS uint8_t *stage, uint32_t r0, uint32_t tid, uint32_t nt) {
-  constexpr int PB = NRQ_COMMIT_PB;
+/* PB: loads in flight per thread (8 in the multi-wave workgroups: the 8.4 k rows of a K=8192 image are two trips of a 768-thread
+ * workgroup instead of three -- solve 6.38-6.54 / 5.99-6.02 -> 6.36-6.37 / 5.93 ms, K=1000 8.43 / 7.85 -> 8.17 / 7.76; the single-wave
+ * variant, 18 workgroups per CU, is 2 % slower with 8 and keeps 4) */
+template <int WB, int G = 1, int PB = NRQ_COMMIT_PB> SB_HD void pf_commit(const StripCtx<WB, G> &c, const NRQ_GAS uint8_t *stage, uint32_t r0, uint32_t tid, uint32_t nt) {
   const uint32_t M = c.h->M;
   for (uint32_t base = r0 + tid; base < M; base += PB * nt) {
     SV<WB> v[PB];
