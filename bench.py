@@ -16,10 +16,12 @@ already resident in HBM when the timed region starts.  Blocks shard across GPUs 
 collective (weak scaling); rank 0 prints ONE JSON line.
 
 `value` = 8 * (payload bytes encoded and decoded) / wall time, whole job.
-Proof of work: every step leaves a digest of two sampled blocks' repair + intermediate symbols (poisoned
-before the encode) and of their decoded rows (damaged before the decode); all digests must equal the
-digest of the oracle's results for those blocks, and after the last step every block must equal its
-source.  A step that did nothing fails the run.
+Proof of work: every step destroys the lost rows of every block's receiver copy over their FULL width, poisons a few
+full-width rows of EVERY block's repair and intermediate symbols (which rows changes with the step) and leaves a
+column-weighted digest of them and of sampled decoded rows of every block.  After the timed region every block is verified
+in full on the device (decoded block == source; source symbols regenerated from the intermediate symbols == source; repair
+symbols regenerated == the encode's), two blocks are compared with the oracle byte for byte, and every step's digest must
+equal the digest of that verified state.  An encode or decode that skips a block, or a column strip of one, fails the run.
 `roofline`: the solve kernel (nrq_solve_kernel) --
   achieved/peak/frac  the ALGORITHMIC bytes of SURVEY.md section 8(d) (the row traffic the reference CPU path
                       performs for the same blocks, counted by the oracle on the sampled blocks) over the kernel's
@@ -152,9 +154,12 @@ def cpu_baseline(args, src_np, lost_np, nrep_enc):
             b = j % n
             rep_, _, _ = oracle.encode_block(src_np[b], K, T, esis)
             keep_ = np.setdiff1d(np.arange(K, dtype=np.uint32), lost_np[b])
-            nr_ = len(lost_np[b]) + args.overhead + 2   # +2: never singular, keeps the parallel leg simple
-            ok_, _, _ = oracle.decode_block(np.concatenate([keep_, esis[:nr_]]), np.concatenate([src_np[b][keep_], rep_[:nr_]]),
-                                            K, T)
+            nr_ = len(lost_np[b]) + args.overhead   # the same workload as the 1-core leg: a rank-deficient block takes one more
+            ok_ = False
+            while not ok_ and nr_ <= len(esis):
+                ok_, _, _ = oracle.decode_block(np.concatenate([keep_, esis[:nr_]]), np.concatenate([src_np[b][keep_], rep_[:nr_]]),
+                                                K, T)
+                nr_ += 1
             return ok_
 
         t0 = time.perf_counter()
@@ -273,6 +278,7 @@ def binding_model(c, avg_ms, ncu):
             out["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
     if "SQ_INSTS_VALU" in c:
         out["issue_frac"] = c["SQ_INSTS_VALU"] * VALU_CYCLES / (cu_cycles * SIMD_PER_CU)
+        out["issue_frac_at_4_cycles"] = c["SQ_INSTS_VALU"] * 4.0 / (cu_cycles * SIMD_PER_CU)   # a wave64 instruction as 4 passes of a 16-lane SIMD
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
         out["waves_waiting_share"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
     for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"):
@@ -337,7 +343,7 @@ def main():
     # rows (block * K + esi) the channel destroyed: overwritten again at the start of EVERY step
     lost_rows = torch.from_numpy(np.concatenate([b * K + lost[b].astype(np.int64) for b in range(NB)])).to(dev)
     work_rows = work.view(NB * K, T)
-    damage = work_rows.narrow(1, 0, min(T, 32))   # the first 32 bytes of a lost row are enough to lose it
+    damage = work_rows   # the WHOLE lost row is destroyed: a decode that skips any column strip leaves 0xEE behind
     lost_arr = np.zeros((NB, max_lost + 1), np.uint32)
     for b in range(NB):
         lost_arr[b, :len(lost[b])] = lost[b]
@@ -348,11 +354,26 @@ def main():
     nr_first = (nlost + args.overhead).astype(np.uint32)
     nr_avail = (nlost + args.overhead + spare).astype(np.uint32)
 
-    # proof of work: blocks whose results are poisoned before and digested after every step
+    # proof of work.  (1) oracle: `chk` blocks are compared with the oracle byte for byte after the timed region.  (2) every
+    # step, EVERY block: a few full-width rows of its repair and intermediate symbols (which rows: a function of the step's
+    # phase) are poisoned before the encode, and a digest of those rows and of sampled lost rows of every block's receiver
+    # copy (destroyed over their full width before the decode) is left behind -- an encode that skips a block or a column
+    # strip of one, or a decode that does, leaves poison in the digest.  (3) after the timed region every block is verified in
+    # full (systematic property and repair symbols regenerated from the intermediate symbols, all on the device), and the
+    # digests are compared with the ones formed from that verified state.
     chk = sorted(set([0, NB - 1][:max(0, args.check_blocks)]))[:args.check_blocks] if args.check_blocks > 0 else []
-    chk_t = torch.tensor(chk, dtype=torch.int64, device=dev) if chk else None
     nchk_rep = int(min(nr_first[chk].min(), nrep)) if chk else 0   # repair symbols every reception of theirs uses
     digests = []
+    NPHASE, REP_S, INT_S, WRK_S = 8, 2, 8, 8
+    rng = np.random.default_rng(4242)
+    ph_rep, ph_int, ph_wrk = [], [], []
+    if args.check_blocks > 0:
+        for _ in range(NPHASE):
+            ph_rep.append(torch.from_numpy(np.concatenate([b * nrep + rng.integers(0, int(nr_first[b]), REP_S) for b in range(NB)])).to(dev))
+            ph_int.append(torch.from_numpy(np.concatenate([b * L + rng.integers(0, L, INT_S) for b in range(NB)])).to(dev))
+            ph_wrk.append(torch.from_numpy(np.concatenate([b * K + lost[b][rng.integers(0, len(lost[b]), WRK_S)].astype(np.int64)
+                                                           for b in range(NB) if len(lost[b])])).to(dev))
+    wcol = (torch.arange(T, device=dev, dtype=torch.int64) % 251 + 1).view(1, T)   # column weights: the far end of T counts
 
     # block ranges of the stream groups
     bounds = [(NB * g_) // nstreams for g_ in range(nstreams + 1)]
@@ -360,30 +381,26 @@ def main():
 
     replan_early = L >= 12000   # (the library's threshold for device-built encode plans, NRQ_ENCPLAN_DEV_MIN_L)
 
-    # (a sample of each checked block's rows: the digest costs microseconds, not a pass over the block)
-    rep_rows = torch.arange(0, min(16, nchk_rep), device=dev) if chk else None
-    int_rows = torch.arange(0, L, 32, device=dev)
-    wrk_rows = (torch.from_numpy(np.concatenate([b * K + lost[b][:64].astype(np.int64) for b in chk])).to(dev) if chk else None)
-    rep_v, int_v = rep.view(NB, nrep, T), inter.view(NB, L, T)
+    rep_rows_all, int_rows_all = rep.view(NB * nrep, T), inter.view(NB * L, T)
+    step_no = 0
 
-    def poison():
-        for b in chk:
-            rep_v[b].index_fill_(0, rep_rows, 0xCD)
-            int_v[b].index_fill_(0, int_rows, 0xCD)
+    def poison(ph):
+        rep_rows_all.index_fill_(0, ph_rep[ph], 0xCD)
+        int_rows_all.index_fill_(0, ph_int[ph], 0xCD)
 
-    def digest():
-        # sums are enough: the sampled rows are poisoned with constants before the step, the expected values come from the oracle
-        return torch.stack([torch.stack([rep_v[b].index_select(0, rep_rows).sum(dtype=torch.int64) for b in chk]).sum(),
-                            torch.stack([int_v[b].index_select(0, int_rows).sum(dtype=torch.int64) for b in chk]).sum(),
-                            work_rows.index_select(0, wrk_rows).sum(dtype=torch.int64)])
+    def digest_of(ph, wrows):
+        return torch.stack([(t.index_select(0, ix).to(torch.int64) * wcol).sum()
+                            for t, ix in ((rep_rows_all, ph_rep[ph]), (int_rows_all, ph_int[ph]), (wrows, ph_wrk[ph]))])
 
     def step():
-        nonlocal retries
+        nonlocal retries, step_no
         enc_stats = dec_stats = None
-        # the channel: the receiver's copy loses its rows again (one small kernel; part of the step)
+        ph = step_no % NPHASE
+        step_no += 1
+        # the channel: the receiver's copy loses its rows again, over their full width (part of the step)
         damage.index_fill_(0, lost_rows, 0xEE)
-        if chk:
-            poison()
+        if ph_rep:
+            poison(ph)
         for (lo, hi), c_ in zip(groups, ctxs):
             n_ = hi - lo
             c_.encode_blocks(K, T, n_, src[lo].data_ptr(), K * T, rep[lo].data_ptr(), nrep * T, esis, inter[lo].data_ptr(),
@@ -406,8 +423,8 @@ def main():
             if not st.all():
                 raise RuntimeError("decode failed for %d blocks" % int((st == 0).sum()))
             retries += int((used - nr_first[lo:hi]).sum())
-        if chk and nstreams == 1:
-            digests.append(digest())
+        if ph_rep and nstreams == 1:
+            digests.append((ph, digest_of(ph, work_rows)))
         if not args.no_replan and not replan_early:
             # one encode plan per step (= per 256-block object, like nanorq_precalculate): the plan for the NEXT step's
             # encode is rebuilt on the host here (once per context), while the GPU runs this step's solve
@@ -425,6 +442,7 @@ def main():
     barrier()
     retries = 0
     digests.clear()
+    step_no = 0
     for c_ in ctxs:
         c_.ktime_enable(True)
     t0 = time.perf_counter()
@@ -445,22 +463,43 @@ def main():
 
     # ---- correctness of what was timed ----
     assert torch.equal(work, src), "decoded blocks differ from the source blocks"
-    check = {"blocks": chk, "steps_digested": len(digests), "oracle": False}
-    if digests:
-        d0 = digests[0]
-        for d in digests[1:]:
-            assert torch.equal(d, d0), "a timed step produced different results than the first one"
+    check = {"blocks": chk, "steps_digested": len(digests), "oracle": False, "all_blocks_verified": False,
+             "rows_per_block_per_step": {"repair": REP_S, "intermediate": INT_S, "decoded": WRK_S} if ph_rep else None}
+    if ph_rep:
+        # every block in full, on the device: the source symbols regenerated from the block's intermediate symbols must be
+        # the block (systematic property, RFC 6330 5.3.3.4.2), and its repair symbols regenerated must be the ones the
+        # encode left.  (The decode's output was compared with `src` above.)
+        Kp = prm["Kp"]
+        vb = max(1, min(NB, (256 << 20) // (K * T)))
+        tmp = torch.empty((vb, K, T), dtype=torch.uint8, device=dev)
+        tmp_r = torch.empty((vb, nrep, T), dtype=torch.uint8, device=dev)
+        src_isis = np.arange(K, dtype=np.uint32)
+        rep_isis = (esis + (Kp - K)).astype(np.uint32)
+        for b0 in range(0, NB, vb):
+            n_ = min(vb, NB - b0)
+            tmp.fill_(0x5A)
+            tmp_r.fill_(0x5A)
+            ctx.gen_symbols(K, T, n_, inter[b0].data_ptr(), L * T, src_isis, tmp.data_ptr(), K * T)
+            ctx.gen_symbols(K, T, n_, inter[b0].data_ptr(), L * T, rep_isis, tmp_r.data_ptr(), nrep * T)
+            ctx.sync()
+            assert torch.equal(tmp[:n_], src[b0:b0 + n_]), "systematic property fails for a block in %d..%d" % (b0, b0 + n_)
+            assert torch.equal(tmp_r[:n_], rep[b0:b0 + n_]), "repair symbols of a block in %d..%d are not LT(intermediate)" % (b0, b0 + n_)
+        del tmp, tmp_r
+        check["all_blocks_verified"] = True
+        # the digests every timed step left behind against the ones of the verified state
+        src_rows = src.view(NB * K, T)
+        expect = {}
+        for ph, d in digests:
+            if ph not in expect:
+                expect[ph] = digest_of(ph, src_rows)
+            assert torch.equal(d, expect[ph]), "a timed step left poisoned or wrong rows behind (phase %d)" % ph
+    if chk:
         import oracle
-        exp_rep = exp_int = 0
         for b in chk:   # the oracle's repair + intermediate symbols of the checked blocks, byte for byte
             sb = src[b].cpu().numpy()
             r_rep, r_int, _ = oracle.encode_block(sb, K, T, esis[:nchk_rep], want_inter=True)
             assert np.array_equal(rep[b, :nchk_rep].cpu().numpy(), r_rep), "repair symbols of block %d differ from the oracle" % b
             assert np.array_equal(inter[b].cpu().numpy(), r_int), "intermediate symbols of block %d differ from the oracle" % b
-            exp_rep += int(r_rep[:len(rep_rows)].sum(dtype=np.int64))
-            exp_int += int(r_int[::32].sum(dtype=np.int64))
-        exp_work = int(src.view(NB * K, T).index_select(0, wrk_rows).sum(dtype=torch.int64))   # (rows still holding 0xEE would not sum to this)
-        assert [int(x) for x in d0] == [exp_rep, exp_int, exp_work], "step digests differ from the oracle's results"
         check["oracle"] = True
     if args.digest_out:
         import hashlib
@@ -593,8 +632,9 @@ def main():
                                    "host, %d threads/rank" % threads),
                        "host_planned_blocks": dec_stats.get("host_planned", 0),
                        "decode_retries": retries_total, "spare_symbols_taken": retries_total,
-                       "in_step": "damage of the receiver's copy (lost rows overwritten on the device), poisoning and digest of the "
-                                  "checked blocks"},
+                       "in_step": "damage of the receiver's copy (every lost row overwritten over its full width: %.0f MB of writes), "
+                                  "poisoning of %d repair + %d intermediate rows of EVERY block and a digest of them and of %d decoded "
+                                  "rows per block (~0.1 ms per step together)" % (float(nlost.sum()) * T / 1e6, REP_S, INT_S, WRK_S)},
             "check": check,
             "roofline": roof, "e2e": e2e, "cpu_baseline": cpu,
             "detail": {"solve_kernel_ms_sum_per_step": sum(ktimes) / args.steps,

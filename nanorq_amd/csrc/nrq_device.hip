@@ -29,6 +29,7 @@
 #include "rq_math.h"
 #include "solve_body.h"
 #include "planner_body.h"
+static_assert(RQ_LT_COLS_MAX_REAL <= NRQ_LT_LIST_MAX, "solve_body.h sizes the slack behind out_slots[] for the longest LT list");
 
 #define NRQ_LDS_MAX 163840u /* 160 KiB per workgroup on gfx950 */
 #ifndef NRQ_WG
@@ -1751,7 +1752,7 @@ int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_
   const size_t off_cptr = r16(off_jobs + (size_t)nblk * sizeof(nrq_job));
   const size_t off_row = r16(off_cptr + (size_t)(nrep + 1) * 4);
   const size_t off_cols = r16(off_row + (size_t)(nrep ? nrep : 1) * 4);
-  const size_t total = r16(off_cols + cols.size() * 2 + 16 + NRQ_STORE_TRIP * 2u); /* (ph_store reads a whole trip from a list's start) */
+  const size_t total = r16(off_cols + cols.size() * 2 + NRQ_STORE_SLACK); /* (ph_store reads a whole trip from a list's start) */
   const int f = ctx->flip;
   ctx->flip ^= 1;
   HIPCHK(ctx, hipEventSynchronize(ctx->staged[f]));
@@ -1898,7 +1899,7 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
     pr.off_rowsrc = off; off = r16(off + pr.rowsrc.size() * 4);
     pr.off_cptr = off;   off = r16(off + pr.cptr.size() * 4);
     pr.off_row = off;    off = r16(off + pr.orow.size() * 4);
-    pr.off_cols = off;   off = r16(off + pr.cols.size() * 2 + 16 + NRQ_STORE_TRIP * 2u);
+    pr.off_cols = off;   off = r16(off + pr.cols.size() * 2 + NRQ_STORE_SLACK);
   }
   const size_t total = off;
   int result = 0;

@@ -1981,7 +1981,7 @@ template <int Z> SB_HD void pl_final_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
     c.part()[1] = o; o = pl_r16(o + sh->M * 4u);                       /* rowsrc */
     c.part()[2] = o; o = pl_r16(o + (nl + 1u) * 4u);                   /* out_cptr */
     c.part()[3] = o; o = pl_r16(o + nl * 4u + 4u);                     /* out_row */
-    c.part()[4] = o; o = pl_r16(o + nl * PL_PATCH_STRIDE * 2u + 16u + NRQ_STORE_TRIP * 2u);  /* out_slots (+ what ph_store reads past a list) */
+    c.part()[4] = o; o = pl_r16(o + nl * PL_PATCH_STRIDE * 2u + NRQ_STORE_SLACK);  /* out_slots (+ what ph_store reads past a list) */
     sh->arena_top = o;
     if (o > c.job.arena_cap) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     (void)p;

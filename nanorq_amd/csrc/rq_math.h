@@ -28,7 +28,8 @@ typedef struct rq_tuple {
   uint32_t d, a, b, d1, a1, b1;
 } rq_tuple;
 
-#define RQ_MAX_LT_COLS 40 /* d <= 30, d1 <= 3 */
+#define RQ_MAX_LT_COLS 40 /* capacity of column-list arrays */
+#define RQ_LT_COLS_MAX_REAL 33 /* longest list RFC 6330 5.3.5.2-4 can give: d <= 30 and d1 <= 3 (d1 = 3 only with d < 4, so really 32) */
 
 /* ---- tables: host copy always; device copy (constant memory) only in HIP translation units ---- */
 static const uint32_t rq_host_V[4 * 256] = {RQ_V_WORDS};

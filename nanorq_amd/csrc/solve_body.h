@@ -1472,13 +1472,18 @@ template <int WB, int G = 1> SB_HD void ph_park(const StripCtx<WB, G> &c, uint32
 #ifndef NRQ_STORE_TRIP
 #define NRQ_STORE_TRIP 32u /* (a multiple of the chunk) */
 #endif
+/* bytes that may be read behind out_slots[]: a trip from the last list's start, and a second one if a list were longer than one
+ * trip (RFC 6330 lists are at most 32 entries = one trip; the slack covers RQ_LT_COLS_MAX_REAL) */
+#define NRQ_STORE_SLACK (16u + NRQ_STORE_TRIP * 4u)
+#define NRQ_LT_LIST_MAX 33u /* (= RQ_LT_COLS_MAX_REAL of rq_math.h; nrq_device.hip checks the two against each other) */
+static_assert(NRQ_LT_LIST_MAX <= 2u * NRQ_STORE_TRIP, "ph_store reads at most two trips of a list; out_slots[] slack is sized for that");
 template <int WB, int G = 1> SB_HD uint32_t out_elems(const nrq_job *job, const nrq_plan_hdr *h) { return (job->inter ? h->L : 0u) + job->nout; }
 /* FAST: the form for the big workgroup (168 registers per thread); the 256- and 64-thread variants, built for 96-128 registers,
  * keep the lean loop (measured at K=1000: store phase 20 k -> 31 k clocks with the fast form there) */
 /* The NRQ_STORE_TRIP slot numbers from entry e on, two per word, as 16-byte loads from a 2-byte-aligned address (the memory
  * path takes them).  With a 16-bit load per entry under `e + k < end` the compiler made a branch per entry and waited for each
  * load inside it: 32 trips to L2 one after the other, 15 k clocks for the 820 symbols of a decode strip.  The loads run past the
- * end of the list, the last list's past the end of the array: out_slots[] is followed by NRQ_STORE_TRIP * 2 bytes that may be
+ * end of the list, the last list's past the end of the array: out_slots[] is followed by NRQ_STORE_SLACK bytes that may be
  * read (nrq_device.hip, planner_body.h). */
 SB_HD void store_trip(const NRQ_GAS uint16_t *osl, uint32_t e, uint32_t end, uint32_t (&raw)[NRQ_STORE_TRIP / 2u]) {
   (void)end;

@@ -42,13 +42,12 @@
 #include <immintrin.h>
 #endif
 
-#include "../nanorq_amd/csrc/rfc6330_tables.h" /* RFC 6330 constants (data only) */
+#include "orc_tables.h" /* RFC 6330 constants: the oracle's OWN generated copy (tools/gen_oracle_tables.py), not the product's header */
 
 /* ------------------------------------------------------------------------------------------
  * RFC 6330 constants
  * ---------------------------------------------------------------------------------------- */
-static const struct { uint16_t kp, j, s, h, w; } T2[RQ_TABLE2_COUNT] = {RQ_TABLE2_ROWS};
-static const uint32_t VT[4][256] = {RQ_V_WORDS};
+#define VT ORC_V
 
 /* degree distribution, RFC 6330 section 5.3.5.2 (reference tuple.c:4-8) */
 static const uint32_t DEG_F[31] = {
@@ -70,10 +69,10 @@ static int is_prime_u32(uint32_t n) {
 /* reference params.c:21-45 */
 static int derive_params(uint32_t K, orc_params_t *p) {
   int found = -1;
-  for (int r = 0; r < RQ_TABLE2_COUNT; r++)
-    if (K <= T2[r].kp) { found = r; break; }
+  for (int r = 0; r < ORC_TABLE2_COUNT; r++)
+    if (K <= ORC_KP[r]) { found = r; break; }
   if (found < 0 || K == 0) return 0;
-  p->Kp = T2[found].kp; p->J = T2[found].j; p->S = T2[found].s; p->H = T2[found].h; p->W = T2[found].w;
+  p->Kp = ORC_KP[found]; p->J = ORC_J[found]; p->S = ORC_S[found]; p->H = ORC_H[found]; p->W = ORC_W[found];
   p->L = p->Kp + p->S + p->H;
   p->P = p->L - p->W;
   p->U = p->P - p->H;
