@@ -87,6 +87,12 @@ def parse():
                     help="auto: at 1 GPU, collect HBM / LDS / issue counters of the solve kernel with rocprofv3 passes of this "
                          "command after the timed run (falls back to the committed profiles/ file); off: skip")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffers-to-host-buffers leg")
+    ap.add_argument("--one-object", choices=("auto", "on", "off"), default="auto",
+                    help="ONE object over all N GPUs from rank 0's process (NANORQ_HIP_DEVICES=0..N-1, a host thread per device: "
+                         "SURVEY 8(e)'s placement for cfg4 / cfg5) next to the process-sharded line; auto = when N > 1")
+    ap.add_argument("--one-object-K", type=int, default=56403, help="block size of that object (cfg5: 56403, 8 blocks per GPU)")
+    ap.add_argument("--one-object-T", type=int, default=1280)
+    ap.add_argument("--one-object-blocks", type=int, default=0, help="blocks of that object (0 = 8 per GPU)")
     ap.add_argument("--check-blocks", type=int, default=2, help="blocks whose results are digested every step and compared with the oracle")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=-1,
@@ -535,6 +541,26 @@ def main():
                        "of the bench line."}
         del h_obj
 
+    # ---- ONE object over the N GPUs of one process (the other placement of SURVEY 8(e)); rank 0 runs it in a process of its
+    # own (the object layer reads its device list once) while the other ranks wait at the closing barrier ----
+    one_object = None
+    if rank == 0 and (args.one_object == "on" or (args.one_object == "auto" and world > 1)) and args.force_device < 0:
+        for c_ in ctxs:
+            c_.sync()
+        torch.cuda.empty_cache()
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_one_object.py"), "--devices", ",".join(str(d) for d in range(world)),
+               "--K", str(args.one_object_K), "--T", str(args.one_object_T), "--blocks", str(args.one_object_blocks),
+               "--loss", "0.2" if args.one_object_K == 56403 else str(args.loss)]
+        env1 = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NANORQ_HIP_DEVICE"):
+            env1.pop(k, None)
+        try:
+            r = subprocess.run(cmd, env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            one_object = (json.loads(r.stdout.decode().strip().split("\n")[-1]) if r.returncode == 0 else
+                          {"error": "rc %d: %s" % (r.returncode, r.stderr.decode()[-300:])})
+        except Exception as e:  # noqa: BLE001 -- the bench line must still come out
+            one_object = {"error": repr(e)}
+
     if rank == 0:
         payload_step = world * NB * K * T
         value = 8.0 * payload_step * args.steps / elapsed / 1e9
@@ -636,7 +662,7 @@ def main():
                                   "poisoning of %d repair + %d intermediate rows of EVERY block and a digest of them and of %d decoded "
                                   "rows per block (~0.1 ms per step together)" % (float(nlost.sum()) * T / 1e6, REP_S, INT_S, WRK_S)},
             "check": check,
-            "roofline": roof, "e2e": e2e, "cpu_baseline": cpu,
+            "roofline": roof, "e2e": e2e, "one_object": one_object, "cpu_baseline": cpu,
             "detail": {"solve_kernel_ms_sum_per_step": sum(ktimes) / args.steps,
                        "planner_ms": (sum(ptimes) / len(ptimes)) if ptimes else None,
                        # the solve launches of a step are [encode, decode] per stream group, in that order

@@ -56,21 +56,30 @@ def build_lib(force=False, verbose=False, out=None, extra=()):
     objs = []
     common = ["-O3", "-fPIC", "-Wno-pass-failed", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     common += list(extra)
+    # an object is rebuilt when its source or any header is newer than it (the .hip takes ~100 s, the rest seconds)
+    headers = [f for f in _deps() if f.endswith(".h")]
+
+    def stale(o, src):
+        return force or out is not None or _newer(o, [src] + headers)
+
     for s in HIP_SOURCES:
         o = os.path.join(objdir, s + ".o")
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", *common, "-c", os.path.join(CSRC, s), "-o", o],
-                       check=True)
+        if stale(o, os.path.join(CSRC, s)):
+            subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", *common, "-c", os.path.join(CSRC, s), "-o", o],
+                           check=True)
         objs.append(o)
     for s in CXX_SOURCES:
         o = os.path.join(objdir, s + ".o")
-        subprocess.run(["g++", "-std=c++17", "-Wall", *common, "-c", os.path.join(CSRC, s), "-o", o], check=True)
+        if stale(o, os.path.join(CSRC, s)):
+            subprocess.run(["g++", "-std=c++17", "-Wall", *common, "-c", os.path.join(CSRC, s), "-o", o], check=True)
         objs.append(o)
     for s in C_SOURCES:
         src = os.path.join(CSRC, s)
         if not os.path.exists(src):
             continue
         o = os.path.join(objdir, s + ".o")
-        subprocess.run(["gcc", "-std=gnu11", "-Wall", "-D_FILE_OFFSET_BITS=64", *common, "-c", src, "-o", o], check=True)
+        if stale(o, src):
+            subprocess.run(["gcc", "-std=gnu11", "-Wall", "-D_FILE_OFFSET_BITS=64", *common, "-c", src, "-o", o], check=True)
         objs.append(o)
     target = out or LIB
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target, *objs, "-lpthread"], check=True)

@@ -55,7 +55,7 @@ struct ioctx *ioctx_from_file(const char *fn, int t) {
 }
 
 /* --------------------------------------------------------------------------- caller memory ---- */
-struct mem_io { struct ioctx io; uint8_t *base; size_t pos, len; int pinned; /* 0 = caller memory, 1 = page-locked and owned, 2 = caller memory registered */ };
+struct mem_io { struct ioctx io; uint8_t *base; size_t pos, len; int pinned; /* 0 = caller memory, 1 = page-locked and owned, 2 = caller memory registered, 3 = registered on first use by the object layer (ioctx_dma_region_auto), -1 = that was tried and refused */ };
 
 static size_t m_clip(struct mem_io *m, size_t len) { return (m->pos + len > m->len) ? m->len - m->pos : len; }
 static size_t m_read(struct ioctx *io, uint8_t *buf, size_t len) {
@@ -80,7 +80,11 @@ static bool m_seek(struct ioctx *io, const size_t off) {
 }
 static long m_tell(struct ioctx *io) { return (long)((struct mem_io *)io)->pos; }
 static size_t m_size(struct ioctx *io) { return ((struct mem_io *)io)->len; }
-static void m_destroy(struct ioctx *io) { free(io); }
+static void m_destroy(struct ioctx *io) {
+  struct mem_io *m = (struct mem_io *)io;
+  if (m->pinned == 3) nrq_host_unregister(m->base); /* (the page lock the object layer took; the memory stays the caller's) */
+  free(io);
+}
 
 struct ioctx *ioctx_from_mem(const uint8_t *ptr, size_t sz) {
   struct mem_io *m = calloc(1, sizeof(*m));
@@ -127,7 +131,24 @@ uint8_t *ioctx_mem_base(struct ioctx *io) {
 bool ioctx_dma_region(struct ioctx *io, uint8_t **base, size_t *len) {
   if (!io || io->read != m_read || io->write != m_write) return false; /* (a caller that replaced the vtable gets the generic path) */
   struct mem_io *m = (struct mem_io *)io;
-  if (!m->pinned) return false;
+  if (m->pinned <= 0) return false;
+  *base = m->base;
+  *len = m->len;
+  return true;
+}
+
+/* An ordinary memory context (ioctx_from_mem, the only kind the reference's callers make) whose blocks the per-block calls
+ * move: the first use page-locks the caller's region in place, so that nanorq_generate_symbols can hand the block's bytes to
+ * the copy engine instead of copying them into a staging buffer first (reference load_symbol_matrix, lib/nanorq.c:175-182).
+ * The lock is dropped in destroy(); NANORQ_HIP_AUTOPIN=0 switches this off; regions below 1 MiB are not worth the call. */
+bool ioctx_dma_region_auto(struct ioctx *io, uint8_t **base, size_t *len) {
+  if (ioctx_dma_region(io, base, len)) return true;
+  if (!io || io->read != m_read || io->write != m_write || io->destroy != m_destroy) return false;
+  struct mem_io *m = (struct mem_io *)io;
+  if (m->pinned != 0 || m->len < ((size_t)1 << 20)) return false;
+  const char *e = getenv("NANORQ_HIP_AUTOPIN");
+  if ((e && *e == '0') || nrq_host_register(m->base, m->len) != 0) { m->pinned = -1; return false; }
+  m->pinned = 3;
   *base = m->base;
   *len = m->len;
   return true;

@@ -55,6 +55,14 @@ struct blockst {
   bool src_pinned;
   void *d_src;        /* device copy (K x T) */
   void *d_inter;      /* device: L x T intermediate symbols once solved */
+  /* deferred encode of the per-block call (nanorq_generate_symbols): the upload goes into one of two device copies in turn,
+   * so that the next block's bytes travel while this one is being solved; the solve is only enqueued */
+  void *d_src2;       /* the other device copy */
+  void *ev_up;        /* the upload of the current call */
+  void *ev_read[2];   /* behind the solve that read d_src / d_src2 */
+  bool ev_read_set[2];
+  int cur;            /* which copy the solve in flight (or the last one) read: 0 = d_src, 1 = d_src2 */
+  bool pending;       /* work of this block may still be in flight on the context's streams */
   /* decoder side */
   uint32_t *mask;     /* received-ESI bitmap */
   size_t mask_words;
@@ -281,6 +289,21 @@ size_t nanorq_block_kprime(nanorq *rq, uint8_t sbn) {
 }
 
 /* ---------------------------------------------------------------------- construction ---- */
+/* What the first block of an object would otherwise pay inside its first timed call: context creation, the code object, the
+ * per-K' constants and (encoder) the encode plan -- on every device that will hold a block.  Failures are ignored here: the
+ * calls that need the GPU report them.  NANORQ_HIP_LAZY=1 leaves all of it to first use. */
+static void warm(nanorq *rq, int encoder) {
+  const char *e = getenv("NANORQ_HIP_LAZY");
+  if (e && *e == '1') return;
+  const size_t k0 = nanorq_block_symbols(rq, 0), Z = nanorq_blocks(rq);
+  if (!ndev() || k0 == 0) return;
+  for (int d = 0; d < g_ndev && (size_t)d < (Z ? Z : 1); d++) {
+    gpu_lock(d);
+    (void)nrq_warm(g_dev[d].c, (uint32_t)k0, rq->Kp, encoder);
+    gpu_unlock(d);
+  }
+}
+
 nanorq *nanorq_encoder_new_ext(size_t len, uint16_t T16, uint16_t K, uint16_t Z16, uint16_t N16, uint8_t Al8, uint32_t flags) {
   /* nanorq.c:241-296 */
   static const uint8_t aligns[4] = {8, 4, 2, 1};
@@ -318,6 +341,7 @@ nanorq *nanorq_encoder_new_ext(size_t len, uint16_t T16, uint16_t K, uint16_t Z1
   rq->src_part = partition(Kt, Z);
   rq->sub_part = partition(T / Al, rq->N);
   if (!set_block_params(rq)) { free(rq); return NULL; }
+  warm(rq, 1);
   return rq;
 }
 nanorq *nanorq_encoder_new_ex(size_t len, uint16_t T, uint16_t K, uint16_t Z, uint8_t Al) {
@@ -350,6 +374,7 @@ nanorq *nanorq_decoder_new_ext(uint64_t common, uint32_t specific, uint32_t flag
   rq->sub_part = partition(T / Al, N);
   if (!set_block_params(rq)) { free(rq); return NULL; }
   rq->max_esi = 2 * rq->Kp;
+  warm(rq, 0);
   return rq;
 }
 nanorq *nanorq_decoder_new(uint64_t common, uint32_t specific) { return nanorq_decoder_new_ext(common, specific, 0); }
@@ -393,12 +418,15 @@ static void drop_device(struct blockst *b) {
   nrq_ctx *c = g_ndev ? g_dev[b->di].c : NULL;
   if (c) {
     gpu_lock(b->di);
+    if (b->pending) { nrq_stream_sync(c, 1); nrq_ctx_sync(c); } /* (a freed pool block may be handed out again at once) */
     if (b->d_src) nrq_dev_free(c, b->d_src);
+    if (b->d_src2) nrq_dev_free(c, b->d_src2);
     if (b->d_inter) nrq_dev_free(c, b->d_inter);
     if (b->d_rep) nrq_dev_free(c, b->d_rep);
     gpu_unlock(b->di);
   }
-  b->d_src = b->d_inter = b->d_rep = NULL;
+  b->pending = false;
+  b->d_src = b->d_src2 = b->d_inter = b->d_rep = NULL;
   b->d_rep_cap = 0;
 }
 
@@ -406,6 +434,7 @@ void nanorq_encoder_cleanup(nanorq *rq, uint8_t sbn) { /* nanorq.c:437-451 */
   struct blockst *b = rq->blocks[sbn];
   if (!b) return;
   drop_device(b);
+  nrq_event_free(b->ev_up); nrq_event_free(b->ev_read[0]); nrq_event_free(b->ev_read[1]);
   host_free(b->src, b->src_pinned);
   host_free(b->rep_data, b->rep_pinned);
   free(b->mask); free(b->rep_esi); free(b->win); free(b);
@@ -415,8 +444,11 @@ void nanorq_encoder_cleanup(nanorq *rq, uint8_t sbn) { /* nanorq.c:437-451 */
 void nanorq_encoder_reset(nanorq *rq, uint8_t sbn) { /* nanorq.c:453-469 */
   struct blockst *b = rq->blocks[sbn];
   if (!b) return;
+  /* The reference zeroes D here (nanorq.c:460).  Nothing reads a row of this block before it has been written again:
+   * load_block fills every row (and zeroes what the object does not cover), the decoder's rows are written by add_symbol
+   * and the rows that stay missing are named to the solver, never read -- so the host rows are left as they are (12.8 MB
+   * of memset per call at K=10000), and the device copies stay allocated for the next use. */
   b->loaded = b->inverted = false;
-  if (b->src) memset(b->src, 0, (size_t)(b->K ? b->K : 1) * rq->T);
   b->nrep = 0;
   b->win_n = 0;
   b->have = 0;
@@ -516,25 +548,61 @@ bool nanorq_precalculate(nanorq *rq) { /* nanorq.c:393-401 */
   return ok;
 }
 
+/* the rows of block sbn as one stretch of a page-locked memory context (ordinary memory contexts are page-locked on first
+ * use, io.c): the copy engine can read them where they are */
+static bool io_dma_block(nanorq *rq, uint8_t sbn, uint32_t K, struct ioctx *io, uint8_t **p, size_t *len) {
+  uint8_t *base;
+  size_t rlen, off;
+  if (!io || !ioctx_dma_region_auto(io, &base, &rlen)) return false;
+  if (!block_extent(rq, sbn, K, &off, len) || off + *len > rlen) return false;
+  *p = base + off;
+  return true;
+}
+
+/* Deferred: the block's bytes are handed to the upload stream (straight from the caller's memory when that can be page-locked,
+ * else from the block's page-locked host rows), the solve is enqueued behind them, and the call returns when the UPLOAD is
+ * done -- the caller's bytes have been consumed, as in the reference, but nobody waits for the solve: the next call's upload
+ * goes into the block's second device copy and runs beside it.  The results are waited for where bytes leave the library
+ * (nanorq_encode -> fetch_symbol downloads on the context's stream, behind the solve; cleanup and free synchronise).
+ * A solve cannot fail for mathematical reasons (the encode matrix is always invertible); a HIP error surfaces at those calls. */
 bool nanorq_generate_symbols(nanorq *rq, uint8_t sbn, struct ioctx *io) { /* nanorq.c:206-232 */
   struct blockst *b = get_block(rq, sbn);
   if (!b) return false;
   if (b->inverted) return true;
-  if (!b->loaded) b->loaded = load_block(rq, sbn, b, io);
-  if (!b->loaded || b->K == 0) return false;
+  if (b->K == 0) return false;
   nrq_ctx *c = dctx(b->di);
   if (!c) return false; /* no GPU: no solve */
   const size_t T = rq->T, bytes = (size_t)b->K * T;
+  uint8_t *hp = NULL;
+  size_t hlen = 0;
+  if (b->loaded || !io_dma_block(rq, sbn, b->K, io, &hp, &hlen)) {
+    if (!b->loaded) b->loaded = load_block(rq, sbn, b, io);
+    if (!b->loaded) return false;
+    hp = b->src;
+    hlen = bytes;
+  }
   bool ok = false;
   gpu_lock(b->di);
   /* every block of an object is coded with block 0's K' (nanorq.c:289); a short block just has more padding */
-  if (!b->d_src && nrq_dev_alloc(c, bytes, &b->d_src) != 0) goto out;
+  const int w = b->pending ? b->cur ^ 1 : 0; /* the copy the solve in flight is not reading */
+  void **dp = w ? &b->d_src2 : &b->d_src;
+  if (!*dp && nrq_dev_alloc(c, bytes, dp) != 0) goto out;
   if (!b->d_inter && nrq_dev_alloc(c, (size_t)b->L * T, &b->d_inter) != 0) goto out;
-  if (nrq_dev_upload_async(c, b->d_src, b->src, bytes) != 0) goto out;
-  if (nrq_encode_blocks(c, b->K, b->Kp, (uint32_t)T, 1, b->d_src, bytes, b->d_inter, (size_t)b->L * T, 0, NULL, NULL, 0) != 0) goto out;
-  if (nrq_ctx_sync(c) != 0) goto out;
+  if (!b->ev_up && nrq_event_new(c, &b->ev_up) != 0) goto out;
+  if (!b->ev_read[w] && nrq_event_new(c, &b->ev_read[w]) != 0) goto out;
+  if (b->ev_read_set[w] && nrq_stream_wait(c, 1, b->ev_read[w]) != 0) goto out; /* (the solve two calls ago read this copy) */
+  if (nrq_copy_on(c, 1, *dp, hp, hlen) != 0) goto out;
+  if (hlen < bytes && nrq_memset_on(c, 1, (uint8_t *)*dp + hlen, 0, bytes - hlen) != 0) goto out; /* beyond F: zero */
+  if (nrq_event_record(c, b->ev_up, 1) != 0 || nrq_stream_wait(c, 0, b->ev_up) != 0) goto out;
+  b->pending = true;
+  if (nrq_encode_blocks(c, b->K, b->Kp, (uint32_t)T, 1, *dp, bytes, b->d_inter, (size_t)b->L * T, 0, NULL, NULL, 0) != 0) goto out;
+  if (nrq_event_record(c, b->ev_read[w], 0) != 0) goto out;
+  b->ev_read_set[w] = true;
+  b->cur = w;
+  if (nrq_event_sync(c, b->ev_up) != 0) goto out; /* the source bytes are on the device: the caller may reuse them */
   ok = true;
 out:
+  if (!ok && b->pending) { nrq_stream_sync(c, 1); nrq_ctx_sync(c); b->pending = false; }
   gpu_unlock(b->di);
   if (ok) { b->win_n = 0; b->inverted = true; }
   return ok;
@@ -557,6 +625,7 @@ static bool fetch_symbol(nanorq *rq, struct blockst *b, uint32_t isi, uint8_t *o
     if (d_out) nrq_dev_free(c, d_out);
     gpu_unlock(b->di);
     if (!ok) return false;
+    b->pending = false; /* (the download waited for the context's stream: the solve before it is done) */
     b->win_isi0 = isi;
     b->win_n = n;
   }

@@ -995,6 +995,21 @@ int block_params(nrq_ctx *ctx, uint32_t K, uint32_t Kp, rq_params *p) {
   return 0;
 }
 
+/* the planner kernels may own the whole LDS of a CU (also the first touch of the code object: the runtime loads it here) */
+static int plan_attr_once(nrq_ctx *ctx) {
+  if (ctx->plan_attr) return 0;
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT_MIN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_mh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)NRQ_LDS_MAX));
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_wpass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)NRQ_LDS_MAX));
+  ctx->plan_attr = true;
+  return 0;
+}
+
 int get_kconst(nrq_ctx *ctx, uint32_t K, KConst **out) {
   rq_params p;
   if (!rq_params_init(K, &p)) return fail(ctx, -1, "K=%u out of range", K);
@@ -1058,17 +1073,7 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     qcap = PL_QCAP; lowcap = PL_LOWCAP; sh_bytes = pl_shared_bytes(qcap, lowcap, PL_NT);
   }
   const uint32_t mh_dyn = 72u * 1024u; /* nrq_mh_kernel: MhT (16 B x u <= 20 KB) + the tiles (4 KB + 256 x wpr words <= 40 KB) */
-  if (!ctx->plan_attr) {
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT_MIN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_mh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)NRQ_LDS_MAX));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_wpass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)NRQ_LDS_MAX));
-    ctx->plan_attr = true;
-  }
+  { int rc_ = plan_attr_once(ctx); if (rc_) return rc_; }
   for (uint32_t part = seg ? 1u : 0u; part <= (seg ? 2u : 0u); part++) {
     if (small_wg)
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
@@ -1712,6 +1717,22 @@ int nrq_precalculate(nrq_ctx *ctx, uint32_t K, uint32_t Kp) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   EncPlan *ep;
   return get_encplan(ctx, K, Kp, &ep, /*finish=*/false); /* a device build is only enqueued; the encode that needs it waits */
+}
+
+int nrq_warm(nrq_ctx *ctx, uint32_t K, uint32_t Kp, int encode_plan) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = plan_attr_once(ctx);
+  if (rc) return rc;
+  rq_params p;
+  if ((rc = block_params(ctx, K, Kp, &p))) return rc;
+  KConst *kc;
+  if ((rc = get_kconst(ctx, p.Kp, &kc))) return rc;
+  if (encode_plan) {
+    EncPlan *ep;
+    rc = get_encplan(ctx, K, Kp, &ep, /*finish=*/false);
+  }
+  return rc;
 }
 
 int nrq_encode_blocks(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,

@@ -500,3 +500,87 @@ def test_one_batch_with_many_repair_symbols_per_block():
     r = _devices_run("", 1000, 256, 3, 0.2)
     assert r["max_repair_per_block"] > 1000 // 8
     assert r["ok"], r
+
+
+@pytest.mark.parametrize("K,T", [(300, 64), (2000, 1280)])
+def test_deferred_generate_symbols_in_a_reset_loop(orc, K, T):
+    """The loop of reference benchmark.c:101-109 -- nanorq_generate_symbols + nanorq_encoder_reset over and over, each call
+    only enqueueing its solve (and, for a memory context of >= 1 MiB, reading the caller's memory by DMA after page-locking
+    it in place) -- with DIFFERENT bytes in the caller's buffer every time: the bytes are consumed when the call returns
+    (the buffer is scribbled over right after), and the repair symbols fetched at the end are the oracle's for the LAST
+    contents."""
+    L = api()
+    data = np.zeros(K * T, np.uint8)
+    rq = L.nanorq_encoder_new_ex(K * T, T, K, 0, 8)
+    io = mem_io(data)
+    last = None
+    for it in range(5):
+        last = payload(K * T, seed=77 + it)
+        data[:] = last
+        assert L.nanorq_generate_symbols(rq, 0, io)
+        data[:] = 0xEE                      # the call has returned: the library may not read these bytes any more
+        if it < 4:
+            L.nanorq_encoder_reset(rq, 0)
+    esis = np.arange(K, K + 40, dtype=np.uint32)
+    want, _, _ = orc.encode_block(last.reshape(K, T), K, T, esis)
+    buf = (C.c_uint8 * T)()
+    for q, esi in enumerate(esis):
+        assert L.nanorq_encode(rq, buf, int(esi), 0, io) == T
+        assert bytes(buf) == want[q].tobytes(), (it, esi)
+    # a source symbol after the solve: the reference regenerates it from the intermediate symbols; here the row is
+    # read from the caller's context on first use -- which now holds the scribble, so put the block back first
+    data[:] = last
+    assert L.nanorq_encode(rq, buf, 3, 0, io) == T and bytes(buf) == last[3 * T:4 * T].tobytes()
+    L.nanorq_free(rq)
+    io.contents.destroy(io)
+
+
+def test_page_locking_on_first_use_gives_the_same_packets():
+    """NANORQ_HIP_AUTOPIN=0 NANORQ_HIP_LAZY=1 (no page lock on the caller's memory, nothing prepared by the constructors):
+    same packets, same recovered object -- compared across two processes of the per-block API"""
+    import subprocess
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, 'tests'); "
+            "from capi import encode_object, decode_object; from util import payload; "
+            "d = payload(1200 * 1280, seed=5); c, s, p = encode_object(d, 1280, K=1200, loss=0.06, overhead=3, seed=2); "
+            "ok, out = decode_object(c, s, p, len(d)); assert ok and np.array_equal(out, d); "
+            "print(hashlib.sha256(b''.join(x for _, x in p)).hexdigest(), c, s)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"NANORQ_HIP_AUTOPIN": "0", "NANORQ_HIP_LAZY": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        outs.append(r.stdout.decode().split())
+    assert outs[0] == outs[1]
+
+
+def test_object_spread_over_distinct_gpus_gives_the_same_packets():
+    """The same on PHYSICALLY different devices (skipped on a one-GPU box): NANORQ_HIP_DEVICES=0,1 against the one-device run --
+    same packets, same recovered object; and tools/bench_one_object.py (what bench.py --one-object runs) decodes its object."""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    one = _devices_run("", 600, 320, 7, 0.1)
+    two = _devices_run("0,1", 600, 320, 7, 0.1)
+    assert one["devices"] == 1 and two["devices"] == 2 and one["ok"] and two["ok"]
+    assert one["packets"] == two["packets"] and one["object"] == two["object"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_one_object.py"), "--devices", "0,1", "--K", "2000", "--T", "256",
+                        "--blocks", "6", "--loss", "0.1", "--reps", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rec = json.loads(r.stdout.strip().split("\n")[-1])
+    assert rec["ok"] and rec["devices"] == 2 and rec["blocks"] == 6
+
+
+def test_bench_one_object_tool_on_one_gpu():
+    """tools/bench_one_object.py with two contexts on GPU 0: the placement bench.py reports as `one_object`"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_one_object.py"), "--devices", "0,0", "--K", "1500", "--T", "256",
+                        "--blocks", "5", "--loss", "0.1", "--reps", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rec = json.loads(r.stdout.strip().split("\n")[-1])
+    assert rec["ok"] and rec["devices"] == 2 and rec["blocks"] == 5 and rec["value"] > 0
