@@ -51,6 +51,12 @@ import sys
 import tempfile
 import time
 
+# The library runs up to six streams beside the caller's (two planner streams, the encode-plan stream, the object layer's two
+# copy streams).  The HIP runtime multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4): with
+# more streams than queues, two of them share a queue and run one after the other -- seen as the encode-plan build (14 ms at
+# K'=56403) serialised into the solve stream.  Must be set before the runtime initialises (torch import).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
@@ -86,6 +92,11 @@ def parse():
     ap.add_argument("--pmc", choices=("auto", "off"), default="auto",
                     help="auto: at 1 GPU, collect HBM / LDS / issue counters of the solve kernel with rocprofv3 passes of this "
                          "command after the timed run (falls back to the committed profiles/ file); off: skip")
+    ap.add_argument("--plan-ahead-depth", type=int, default=2, help="planner runs kept in flight ahead of their decode (1 or 2)")
+    ap.add_argument("--plan-ahead", choices=("auto", "on", "off"), default="auto",
+                    help="issue the decode planner run of the NEXT step while this step's decode is being solved (the symbolic stage "
+                         "needs the reception pattern only): nrq_decode_plan_ahead.  auto = for big blocks (few of them per GPU, a "
+                         "planner workgroup per block: L >= 12000), where the planner's latency is the step's critical path")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffers-to-host-buffers leg")
     ap.add_argument("--one-object", choices=("auto", "on", "off"), default="auto",
                     help="ONE object over all N GPUs from rank 0's process (NANORQ_HIP_DEVICES=0..N-1, a host thread per device: "
@@ -386,6 +397,9 @@ def main():
     groups = [(bounds[g_], bounds[g_ + 1]) for g_ in range(nstreams)]
 
     replan_early = L >= 12000   # (the library's threshold for device-built encode plans, NRQ_ENCPLAN_DEV_MIN_L)
+    plan_ahead = nstreams == 1 and (args.plan_ahead == "on" or (args.plan_ahead == "auto" and replan_early))
+    ahead_depth = max(1, min(2, args.plan_ahead_depth))
+    ahead_out = 0   # planner runs issued ahead and not consumed yet
 
     rep_rows_all, int_rows_all = rep.view(NB * nrep, T), inter.view(NB * L, T)
     step_no = 0
@@ -399,7 +413,7 @@ def main():
                             for t, ix in ((rep_rows_all, ph_rep[ph]), (int_rows_all, ph_int[ph]), (wrows, ph_wrk[ph]))])
 
     def step():
-        nonlocal retries, step_no
+        nonlocal retries, step_no, ahead_out
         enc_stats = dec_stats = None
         ph = step_no % NPHASE
         step_no += 1
@@ -429,6 +443,15 @@ def main():
             if not st.all():
                 raise RuntimeError("decode failed for %d blocks" % int((st == 0).sum()))
             retries += int((used - nr_first[lo:hi]).sum())
+            if plan_ahead:
+                # the decode plans of the NEXT steps (same reception pattern every step in this bench; a planner run per step
+                # all the same): enqueued now, they run beside this step's decode solve and the next steps' solves
+                if c_.stats().get("plan_ahead"):
+                    ahead_out -= 1
+                while ahead_out < ahead_depth:
+                    c_.decode_plan_ahead(K, T, n_, work[lo].data_ptr(), K * T, lost_arr[lo:hi], nlost[lo:hi], resi[lo:hi],
+                                         nr_first[lo:hi], nr_avail[lo:hi], rep[lo].data_ptr(), nrep * T)
+                    ahead_out += 1
         if ph_rep and nstreams == 1:
             digests.append((ph, digest_of(ph, work_rows)))
         if not args.no_replan and not replan_early:
@@ -657,6 +680,10 @@ def main():
                        "planner": ("device (nrq_plan_kernel, one workgroup per block)" if dec_stats["planner"] else
                                    "host, %d threads/rank" % threads),
                        "host_planned_blocks": dec_stats.get("host_planned", 0),
+                       "decode_plan": ("issued %d step(s) ahead (nrq_decode_plan_ahead): every step runs one planner pass per block, "
+                                       "beside the solves of the steps before it" % ahead_depth if plan_ahead else
+                                       "inside the decode call"),
+                       "decode_found_plan_ahead": bool(dec_stats.get("plan_ahead", 0)),
                        "decode_retries": retries_total, "spare_symbols_taken": retries_total,
                        "in_step": "damage of the receiver's copy (every lost row overwritten over its full width: %.0f MB of writes), "
                                   "poisoning of %d repair + %d intermediate rows of EVERY block and a digest of them and of %d decoded "

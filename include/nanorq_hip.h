@@ -42,7 +42,7 @@ typedef struct nrq_call_stats {
   uint32_t wg_waves_per_simd; /* register budget of the solve kernel variant launched: waves per SIMD it was compiled for */
   uint32_t host_planned; /* decode blocks whose plan exceeded a device-planner capacity and was rebuilt on the host */
   uint32_t movers_aligned; /* 1: the solve kernel variant without byte-wise paths in its movers (all rows aligned, T a multiple of the strip) */
-  uint32_t reserved_;
+  uint32_t plan_ahead;  /* 1: the decode found its planner run already issued (nrq_decode_plan_ahead) */
 } nrq_call_stats;
 
 /* One context per GPU (one process per GPU: no cross-device state).  `stream` is a hipStream_t the
@@ -119,6 +119,19 @@ int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, ui
                            const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
                            const uint32_t *h_nrep, const uint32_t *h_nrep_avail, uint32_t rep_cap, const void *d_rep,
                            size_t rep_stride, void *d_inter, size_t inter_stride, int *h_status, uint32_t *h_used);
+
+/* Issue the planner run of a later nrq_decode_blocks / nrq_decode_blocks_lazy call now (same arguments, without the result
+ * arrays): the symbolic stage (reference precode_matrix_invert's planning half, lib/precode.c:347-377) needs the reception
+ * pattern only, not the symbols, so it can run on the planner stream while earlier batches are still being solved.  The
+ * decode call with identical arguments then only waits for it (nrq_call_stats::plan_ahead = 1).  Up to two runs may be waiting
+ * (-6 beyond that); they are consumed in the order they were issued, and a decode call the oldest one was not issued for
+ * discards them all.  Two runs issued back to back execute side by side (two planner streams, two workspaces, three sets of
+ * plan arenas): a planner workgroup is latency bound on one compute unit, so a pipeline that keeps two batches' plans in
+ * flight gets them at twice the rate.  Not for the per-block-address variants (_v, _vc). */
+int nrq_decode_plan_ahead(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                          const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                          const uint32_t *h_nrep, const uint32_t *h_nrep_avail, uint32_t rep_cap, const void *d_rep, size_t rep_stride,
+                          void *d_inter, size_t inter_stride);
 
 /* nrq_encode_blocks (no repair symbols) with block b's intermediate symbols going to device address d_inter_v[b]. */
 int nrq_encode_blocks_v(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_src, size_t src_stride,

@@ -18,7 +18,7 @@ class CallStats(C.Structure):
                 ("plan_bytes", C.c_uint64), ("xor_ops", C.c_uint64), ("npiv", C.c_uint32), ("u", C.c_uint32),
                 ("nlev", C.c_uint32), ("nfree", C.c_uint32), ("wg_threads", C.c_uint32), ("strips_per_slot", C.c_uint32),
                 ("wg_waves_per_simd", C.c_uint32), ("host_planned", C.c_uint32), ("movers_aligned", C.c_uint32),
-                ("reserved_", C.c_uint32)]
+                ("plan_ahead", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -59,6 +59,8 @@ def lib():
                                     u32p, C.c_uint32, vp, sz, vp, sz, ip]
     L.nrq_decode_blocks_lazy.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, u32p, u32p, C.c_uint32,
                                          u32p, u32p, u32p, C.c_uint32, vp, sz, vp, sz, ip, u32p]
+    L.nrq_decode_plan_ahead.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, u32p, u32p, C.c_uint32,
+                                        u32p, u32p, u32p, C.c_uint32, vp, sz, vp, sz]
     L.nrq_gen_symbols.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, sz, C.c_uint32, u32p, vp, sz]
     L.nrq_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.nrq_dev_free.argtypes = [vp, vp]
@@ -241,6 +243,20 @@ class Context:
                                                  C.c_void_p(d_inter or 0), inter_stride,
                                                  status.ctypes.data_as(C.POINTER(C.c_int)), _u32(used)))
         return status, used
+
+    def decode_plan_ahead(self, K, T, nblk, d_src, src_stride, lost, nlost, rep_esi, nrep, nrep_avail, d_rep, rep_stride,
+                          d_inter=0, inter_stride=0, Kp=0):
+        """Issue the planner run of the decode_blocks_lazy (nrep_avail given) / decode_blocks (None) call with the same
+        arguments now; that call then only waits for it."""
+        lost = np.ascontiguousarray(lost, dtype=np.uint32).reshape(nblk, -1)
+        rep_esi = np.ascontiguousarray(rep_esi, dtype=np.uint32).reshape(nblk, -1)
+        nlost = np.ascontiguousarray(nlost, dtype=np.uint32)
+        nrep = np.ascontiguousarray(nrep, dtype=np.uint32)
+        av = None if nrep_avail is None else np.ascontiguousarray(nrep_avail, dtype=np.uint32)
+        self._chk(self._L.nrq_decode_plan_ahead(self._h, K, Kp, T, nblk, C.c_void_p(d_src), src_stride, _u32(lost), _u32(nlost),
+                                                lost.shape[1], _u32(rep_esi), _u32(nrep), None if av is None else _u32(av),
+                                                rep_esi.shape[1], C.c_void_p(d_rep or 0), rep_stride, C.c_void_p(d_inter or 0),
+                                                inter_stride))
 
     def gen_symbols(self, K, T, nblk, d_inter, inter_stride, isis, d_out, out_stride, Kp=0):
         isis = np.ascontiguousarray(isis, dtype=np.uint32)

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <thread>
@@ -883,6 +884,9 @@ struct Tuning {
   }
 };
 
+#define NRQ_PLAN_AHEAD_MAX 2u
+struct PlanRun;
+static void plan_ahead_drop(struct nrq_ctx *ctx);
 struct nrq_ctx {
   int device = 0;
   Tuning tune;
@@ -910,7 +914,13 @@ struct nrq_ctx {
   unsigned long long *prof = nullptr; /* NRQ_PROF=1 */
   /* device planner */
   int planner = 1; /* 1 = device planner for decode (default), 0 = host planner */
-  DevBuf plan_work, plan_arena, plan_jobs;
+  /* Planner runs may be issued AHEAD of their decode call (nrq_decode_plan_ahead), up to NRQ_PLAN_AHEAD_MAX of them: plan
+   * arenas / job records come in three sets in turn (one being read by the solve in flight, two being written), the planner
+   * workspace and the planner stream in two (two runs side by side: a planner workgroup is latency bound on ONE compute unit,
+   * so two batches' planners on twice the compute units take the time of one), the input / header staging in four. */
+  DevBuf plan_work[2], plan_arena[3], plan_jobs[3];
+  uint32_t prun = 0; /* planner runs launched so far (chooses stream and workspace) */
+  uint32_t ahead_hint = 0; /* most planner runs that were waiting at once since the last discard: sizes the CU reserve of big-block launches */
   DevBuf stage; /* solve kernel: staging buffers of the persistent workgroups */
   DevBuf ybuf;  /* split solve of narrow strips: per block, (M + u) full-width rows (slot image + inactive columns) */
   /* nrq_dev_alloc / nrq_dev_free: a caching pool (the object API allocates per call; hipMalloc / hipFree are
@@ -937,13 +947,16 @@ struct nrq_ctx {
    * ordered behind it); `arena_free`: the solve that reads the plan arenas / job records has finished -- the next
    * planner launch overwrites them and waits for it. */
   hipStream_t plan_stream = nullptr;
-  hipEvent_t planned = nullptr, arena_free = nullptr;
-  bool arena_busy = false;
+  hipStream_t plan_stream_b = nullptr; /* the second planner stream (runs issued ahead alternate) */
+  hipEvent_t planned[3] = {nullptr, nullptr, nullptr}, arena_free[3] = {nullptr, nullptr, nullptr};
+  bool arena_busy[3] = {false, false, false};
+  int aflip = 0;
+  std::deque<struct PlanRun *> ahead; /* planner runs issued by nrq_decode_plan_ahead and not yet consumed, oldest first */
   hipStream_t plan_stream2 = nullptr; /* encode plans built on the device (encplan_device_launch): beside both of the above */
   DevBuf encplan_work;                /* planner workspace of that build */
-  DevBuf pscratch[2]; /* planner inputs: buffers of their own (the per-call arrays above belong to the caller's stream) */
-  PinBuf pstaging[2];
-  hipEvent_t pstaged[2] = {nullptr, nullptr};
+  DevBuf pscratch[4]; /* planner inputs: buffers of their own (the per-call arrays above belong to the caller's stream) */
+  PinBuf pstaging[4];
+  hipEvent_t pstaged[4] = {nullptr, nullptr, nullptr, nullptr};
   int pflip = 0;
 };
 
@@ -1326,7 +1339,11 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
    * they are all done.  ~3 % of the solve's throughput for 8 blocks; the planner (one workgroup per block, latency
    * bound: 12 ms at K=27000, 36 ms at K'=56403) then hides behind the encode solve. */
   if (!small && occ == 1u) {
-    uint32_t reserve = ctx->tune.reserve_cus >= 0 ? (uint32_t)ctx->tune.reserve_cus : (nblk <= 16u ? (nblk + 7u) / 8u * 8u : 0u);
+    /* (with planner runs issued ahead -- nrq_decode_plan_ahead -- up to `ahead_hint` batches' planner workgroups are resident at
+     * once, and the encode plan of a big block is built by one more workgroup on a stream of its own: without a compute unit
+     * for each of them one waits until this launch's persistent workgroups are through, and its 20-30 ms start from there) */
+    const uint32_t runs = ctx->ahead_hint > 1u ? ctx->ahead_hint : 1u;
+    uint32_t reserve = ctx->tune.reserve_cus >= 0 ? (uint32_t)ctx->tune.reserve_cus : (nblk <= 16u ? (nblk * runs + 1u + 7u) / 8u * 8u : 0u);
     if (reserve + 64u <= grid) grid -= reserve / 8u * 8u;
   }
   if (ctx->tune.solve_grid) grid = ctx->tune.solve_grid / 8 * 8;
@@ -1554,6 +1571,10 @@ int nrq_params(uint32_t K, uint32_t out[10]) {
 }
 
 int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
+  /* (the runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues, 4 by default; a context runs up to six
+   * streams beside the caller's, and two streams on one queue execute one after the other.  Only effective when this is the
+   * process's first HIP call; a host that initialises the runtime itself sets the variable itself, as bench.py does.) */
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   if (!out) return -1;
   *out = nullptr;
   int ndev = 0;
@@ -1571,15 +1592,22 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
   if (getenv("NRQ_HOST_PLANNER")) ctx->planner = 0;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->plan_stream_b, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->plan_stream2, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->aux[0], hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->aux[1], hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->scat_ev[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->scat_ev[1], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->planned, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->arena_free, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->planned[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->planned[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->planned[2], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->arena_free[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->arena_free[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->arena_free[2], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->pstaged[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->pstaged[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->pstaged[2], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->pstaged[3], hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->encplan_uploaded, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->staged[0], hipEventDisableTiming) != hipSuccess ||
@@ -1620,7 +1648,9 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
     if (kv.second.dev) (void)hipFree(kv.second.dev);
     nrq_host_free(kv.second.host);
   }
+  plan_ahead_drop(ctx);
   if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
+  if (ctx->plan_stream_b) { (void)hipStreamSynchronize(ctx->plan_stream_b); (void)hipStreamDestroy(ctx->plan_stream_b); }
   if (ctx->plan_stream2) { (void)hipStreamSynchronize(ctx->plan_stream2); (void)hipStreamDestroy(ctx->plan_stream2); }
   if (ctx->encplan_work.p) (void)hipFree(ctx->encplan_work.p);
   for (int i = 0; i < 2; i++) {
@@ -1631,11 +1661,19 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
   }
   for (auto &kv : ctx->pool_size) (void)hipFree(kv.first);
   ctx->pool_size.clear(); ctx->pool_free.clear();
-  if (ctx->planned) (void)hipEventDestroy(ctx->planned);
-  if (ctx->arena_free) (void)hipEventDestroy(ctx->arena_free);
-  if (ctx->plan_work.p) (void)hipFree(ctx->plan_work.p);
-  if (ctx->plan_arena.p) (void)hipFree(ctx->plan_arena.p);
-  if (ctx->plan_jobs.p) (void)hipFree(ctx->plan_jobs.p);
+  for (int i = 0; i < 3; i++) {
+    if (ctx->planned[i]) (void)hipEventDestroy(ctx->planned[i]);
+    if (ctx->arena_free[i]) (void)hipEventDestroy(ctx->arena_free[i]);
+    if (ctx->plan_arena[i].p) (void)hipFree(ctx->plan_arena[i].p);
+    if (ctx->plan_jobs[i].p) (void)hipFree(ctx->plan_jobs[i].p);
+  }
+  for (int i = 0; i < 2; i++)
+    if (ctx->plan_work[i].p) (void)hipFree(ctx->plan_work[i].p);
+  for (int i = 2; i < 4; i++) {
+    if (ctx->pscratch[i].p) (void)hipFree(ctx->pscratch[i].p);
+    if (ctx->pstaging[i].p) (void)hipHostFree(ctx->pstaging[i].p);
+    if (ctx->pstaged[i]) (void)hipEventDestroy(ctx->pstaged[i]);
+  }
   if (ctx->stage.p) (void)hipFree(ctx->stage.p);
   if (ctx->ybuf.p) (void)hipFree(ctx->ybuf.p);
   for (int i = 0; i < 2; i++) {
@@ -1981,22 +2019,48 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
 }
 
 
-/* decode with the symbolic stage on the GPU: one planner workgroup per block, then the solve */
-static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
-                         const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
-                         const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
-                         size_t inter_stride, int *h_status, std::vector<uint8_t> *fallback, const uint32_t *h_avail,
-                         uint32_t *h_used) {
-  const double t_begin = now_ms();
+/* One planner run of a batch of decode blocks: what its launch leaves for the half that waits for it and launches the solve.
+ * Kept in the context between nrq_decode_plan_ahead and the decode call it was issued for (`key_*`: that call's arguments). */
+struct PlanRun {
   rq_params p;
+  KConst *kc = nullptr;
+  uint32_t K = 0, Kp = 0, T = 0, nblk = 0, lost_cap = 0, rep_cap = 0;
+  uint32_t ucap = 0, Mcap = 0, npcap = 0, arena_cap = 0, max_nl = 0;
+  size_t off_hdrs = 0;
+  int f = 0, ab = 0; /* staging set, arena set */
+  hipStream_t ps = nullptr;
+  double t_begin = 0;
+  /* the call this run was issued for */
+  const void *d_src = nullptr, *d_rep = nullptr, *d_inter = nullptr;
+  size_t src_stride = 0, rep_stride = 0, inter_stride = 0;
+  bool has_avail = false;
+  std::vector<uint32_t> lost, nlost, resi, nrep, avail;
+};
+
+static void plan_ahead_drop(nrq_ctx *ctx) {
+  for (PlanRun *r : ctx->ahead) {
+    (void)hipEventSynchronize(ctx->planned[r->ab]); /* (its arena set is free again once it has run) */
+    delete r;
+  }
+  ctx->ahead.clear();
+  ctx->ahead_hint = 0;
+}
+
+/* first half: inputs down, planner kernels and the headers' way back enqueued on the planner stream */
+static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                       const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                       const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
+                       size_t inter_stride, const uint32_t *h_avail) {
+  r.t_begin = now_ms();
+  rq_params &p = r.p;
   int rc = block_params(ctx, K, Kp, &p);
   if (rc) return rc;
   KConst *kc;
   rc = get_kconst(ctx, p.Kp, &kc);
   if (rc) return rc;
+  r.kc = kc;
+  r.K = K; r.Kp = Kp; r.T = T; r.nblk = nblk; r.lost_cap = lost_cap; r.rep_cap = rep_cap;
   const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(kc->host);
-  memset(&ctx->stats, 0, sizeof(ctx->stats));
-  ctx->stats.planner = 1;
   uint32_t max_oh = 0, max_nrep = 0, max_nl = 0;
   for (uint32_t b = 0; b < nblk; b++) {
     const uint32_t nl = h_nlost[b];
@@ -2007,6 +2071,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     if (nr > max_nrep) max_nrep = nr;
     if (nl > max_nl) max_nl = nl;
   }
+  r.max_nl = max_nl;
   uint32_t ucap = p.P + 768u;
   if (ucap > 1280u) ucap = 1280u; /* 40 words per W row at most */
   if (ctx->tune.plan_ucap && ctx->tune.plan_ucap < ucap) ucap = ctx->tune.plan_ucap;
@@ -2014,9 +2079,22 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   const uint32_t Mcap = p.L + max_oh + PL_EXTRA_ROWS + 8u, npcap = max_nrep + PL_EXTRA_ROWS + 8u;
   const pl_work_layout wl = pl_work_plan(p.L, Mcap, npcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE);
   const uint32_t arena_cap = pl_arena_bound(p.L, Mcap, ucap, kh->nnz + npcap * PL_PATCH_STRIDE, max_nl + 8u);
-  if ((rc = ensure_dev(ctx, ctx->plan_work, (size_t)nblk * wl.total))) return rc;
-  if ((rc = ensure_dev(ctx, ctx->plan_arena, (size_t)nblk * arena_cap))) return rc;
-  if ((rc = ensure_dev(ctx, ctx->plan_jobs, (size_t)nblk * sizeof(nrq_job)))) return rc;
+  r.ucap = ucap; r.Mcap = Mcap; r.npcap = npcap; r.arena_cap = arena_cap;
+  const int ab = ctx->aflip;
+  ctx->aflip = (ctx->aflip + 1) % 3;
+  r.ab = ab;
+  const uint32_t run_no = ctx->prun++;
+  DevBuf &work = ctx->plan_work[run_no & 1u];
+  /* (growing a buffer frees the old one: nothing may still be running in it) */
+  if (work.cap < (size_t)nblk * wl.total || ctx->plan_arena[ab].cap < (size_t)nblk * arena_cap ||
+      ctx->plan_jobs[ab].cap < (size_t)nblk * sizeof(nrq_job)) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->plan_stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->plan_stream_b));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if ((rc = ensure_dev(ctx, work, (size_t)nblk * wl.total))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->plan_arena[ab], (size_t)nblk * arena_cap))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->plan_jobs[ab], (size_t)nblk * sizeof(nrq_job)))) return rc;
 
   /* inputs of the planner: [planjobs][lost lists][repair ESI lists]; headers come back after them */
   const size_t off_pj = 0;
@@ -2025,18 +2103,23 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   const size_t in_bytes = r16(off_resi + (size_t)nblk * rep_cap * 4);
   const size_t off_hdrs = in_bytes;
   const size_t total = r16(off_hdrs + (size_t)nblk * sizeof(nrq_plan_hdr));
+  r.off_hdrs = off_hdrs;
   /* everything up to the headers' way back runs on the planner stream (see nrq_ctx::plan_stream) */
   /* (only while the planner workgroups leave at least half of the CUs alone: with one per CU the two kernels just take
    * turns, and planner workgroups that get in first delay the persistent workgroups of the solve -- measured at 256
    * blocks of K=8192: encode solve 7.6 -> 10.4 ms, step +0.4 ms; at 64 blocks of K=20000 the overlap is worth 10 %) */
-  hipStream_t ps = (ctx->tune.no_plan_stream || nblk * 2u > (uint32_t)ctx->ncu) ? ctx->stream : ctx->plan_stream;
+  hipStream_t ps = (ctx->tune.no_plan_stream || nblk * 2u > (uint32_t)ctx->ncu) ? ctx->stream
+                   : (run_no & 1u)                                                 ? ctx->plan_stream_b
+                                                                                   : ctx->plan_stream;
+  r.ps = ps;
   const int f = ctx->pflip;
-  ctx->pflip ^= 1;
+  ctx->pflip = (ctx->pflip + 1) & 3;
+  r.f = f;
   HIPCHK(ctx, hipEventSynchronize(ctx->pstaged[f]));
   if ((rc = ensure_pin(ctx, ctx->pstaging[f], total))) return rc;
   if ((rc = ensure_dev(ctx, ctx->pscratch[f], in_bytes))) return rc;
   uint8_t *hs = ctx->pstaging[f].p, *ds = ctx->pscratch[f].p;
-  if (ctx->arena_busy && ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ps, ctx->arena_free, 0));
+  if (ctx->arena_busy[ab] && ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ps, ctx->arena_free[ab], 0));
   memcpy(hs + off_lost, h_lost, (size_t)nblk * lost_cap * 4);
   memcpy(hs + off_resi, h_rep_esi, (size_t)nblk * rep_cap * 4);
   nrq_planjob *pj = reinterpret_cast<nrq_planjob *>(hs + off_pj);
@@ -2046,8 +2129,8 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     const bool sane = h_nlost[b] <= lost_cap && h_nrep[b] <= rep_cap;
     j.lost = (uint64_t)(uintptr_t)(ds + off_lost + (size_t)b * lost_cap * 4);
     j.rep_esi = (uint64_t)(uintptr_t)(ds + off_resi + (size_t)b * rep_cap * 4);
-    j.work = (uint64_t)(uintptr_t)(ctx->plan_work.p + (size_t)b * wl.total);
-    j.arena = (uint64_t)(uintptr_t)(ctx->plan_arena.p + (size_t)b * arena_cap);
+    j.work = (uint64_t)(uintptr_t)(work.p + (size_t)b * wl.total);
+    j.arena = (uint64_t)(uintptr_t)(ctx->plan_arena[ab].p + (size_t)b * arena_cap);
     j.src = (ctx->vec_src ? ctx->vec_src[b] : (uint64_t)(uintptr_t)((uint8_t *)d_src + (size_t)b * src_stride));
     j.rep = (ctx->vec_rep ? ctx->vec_rep[b] : (uint64_t)(uintptr_t)((const uint8_t *)d_rep + (size_t)b * rep_stride));
     j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
@@ -2078,7 +2161,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     HIPCHK(ctx, hipEventRecord(pe0, ps));
   }
   if ((rc = launch_plan_kernel(ctx, ps, p, kc->dev, reinterpret_cast<const nrq_planjob *>(ds + off_pj),
-                               reinterpret_cast<nrq_job *>(ctx->plan_jobs.p), nblk, Mcap, npcap, ucap, pprof,
+                               reinterpret_cast<nrq_job *>(ctx->plan_jobs[ab].p), nblk, Mcap, npcap, ucap, pprof,
                                kh->nnz + npcap * PL_PATCH_STRIDE)))
     return rc;
   if (pe1) HIPCHK(ctx, hipEventRecord(pe1, ps));
@@ -2095,12 +2178,66 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
     fprintf(stderr, "\n");
     (void)hipFree(pprof);
   }
-  HIPCHK(ctx, hipMemcpy2DAsync(hs + off_hdrs, sizeof(nrq_plan_hdr), ctx->plan_arena.p, arena_cap, sizeof(nrq_plan_hdr), nblk,
+  HIPCHK(ctx, hipMemcpy2DAsync(hs + off_hdrs, sizeof(nrq_plan_hdr), ctx->plan_arena[ab].p, arena_cap, sizeof(nrq_plan_hdr), nblk,
                                hipMemcpyDeviceToHost, ps));
   HIPCHK(ctx, hipEventRecord(ctx->pstaged[f], ps));
-  HIPCHK(ctx, hipEventRecord(ctx->planned, ps));
-  HIPCHK(ctx, hipEventSynchronize(ctx->planned));
+  HIPCHK(ctx, hipEventRecord(ctx->planned[ab], ps));
+  return 0;
+}
+
+/* was this run issued for exactly this call? */
+static bool plan_run_matches(const nrq_ctx *ctx, const PlanRun &r, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_src,
+                             size_t src_stride, const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap,
+                             const uint32_t *h_rep_esi, const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride,
+                             const void *d_inter, size_t inter_stride, const uint32_t *h_avail) {
+  if (ctx->vec_src || ctx->vec_rep || ctx->chunk_blocks) return false;
+  if (r.K != K || r.Kp != Kp || r.T != T || r.nblk != nblk || r.lost_cap != lost_cap || r.rep_cap != rep_cap) return false;
+  if (r.d_src != d_src || r.src_stride != src_stride || r.d_rep != d_rep || r.rep_stride != rep_stride || r.d_inter != d_inter ||
+      r.inter_stride != inter_stride || r.has_avail != (h_avail != nullptr))
+    return false;
+  return memcmp(r.nlost.data(), h_nlost, (size_t)nblk * 4) == 0 && memcmp(r.nrep.data(), h_nrep, (size_t)nblk * 4) == 0 &&
+         (!h_avail || memcmp(r.avail.data(), h_avail, (size_t)nblk * 4) == 0) &&
+         memcmp(r.lost.data(), h_lost, (size_t)nblk * lost_cap * 4) == 0 && memcmp(r.resi.data(), h_rep_esi, (size_t)nblk * rep_cap * 4) == 0;
+}
+
+/* decode with the symbolic stage on the GPU: one planner workgroup per block, then the solve */
+static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                         const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                         const uint32_t *h_nrep, uint32_t rep_cap, const void *d_rep, size_t rep_stride, void *d_inter,
+                         size_t inter_stride, int *h_status, std::vector<uint8_t> *fallback, const uint32_t *h_avail,
+                         uint32_t *h_used) {
+  const double t_begin = now_ms();
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  ctx->stats.planner = 1;
+  PlanRun local, *run = &local;
+  bool ahead = false;
+  if (!ctx->ahead.empty()) {
+    if (plan_run_matches(ctx, *ctx->ahead.front(), K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap,
+                         d_rep, rep_stride, d_inter, inter_stride, h_avail)) {
+      run = ctx->ahead.front(); /* the planner run of this very call is already on its way (or done) */
+      ctx->ahead.pop_front();
+      ahead = true;
+    } else {
+      plan_ahead_drop(ctx); /* (runs are consumed in the order they were issued: a call they were not issued for ends them all) */
+    }
+  }
+  struct Owner { PlanRun *r; ~Owner() { delete r; } } owner{ahead ? run : nullptr};
+  if (!ahead) {
+    const int rc0 = plan_launch(ctx, *run, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap, d_rep,
+                                rep_stride, d_inter, inter_stride, h_avail);
+    if (rc0) return rc0;
+  }
+  const rq_params &p = run->p;
+  KConst *kc = run->kc;
+  const int ab = run->ab;
+  const uint32_t arena_cap = run->arena_cap, max_nl = run->max_nl;
+  hipStream_t ps = run->ps;
+  uint8_t *hs = ctx->pstaging[run->f].p;
+  const size_t off_hdrs = run->off_hdrs;
+  (void)arena_cap;
+  HIPCHK(ctx, hipEventSynchronize(ctx->planned[ab]));
   ctx->stats.plan_ms = now_ms() - t_begin;
+  ctx->stats.plan_ahead = ahead ? 1 : 0;
   const nrq_plan_hdr *hd = reinterpret_cast<const nrq_plan_hdr *>(hs + off_hdrs);
   std::vector<const nrq_plan_hdr *> hdrs;
   bool need_fallback = false;
@@ -2132,7 +2269,7 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   int result = 0;
   if (ctx->chunk_blocks) {
     /* one planner run, the solve chunk by chunk (nrq_decode_blocks_vc): an event per chunk for the caller's copy streams */
-    if (ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->planned, 0));
+    if (ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->planned[ab], 0));
     const uint32_t cb = ctx->chunk_blocks;
     for (uint32_t c0 = 0, ci = 0; c0 < nblk && !result; c0 += cb, ci++) {
       const uint32_t m = nblk - c0 < cb ? nblk - c0 : cb;
@@ -2141,22 +2278,51 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
         if (h_nlost[b] != 0 && hd[b].magic == NRQ_PLAN_MAGIC && hd[b].status == 0) hc.push_back(&hd[b]);
       if (ctx->chunk_up && ctx->chunk_up[ci]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)ctx->chunk_up[ci], 0));
       if (!hc.empty())
-        result = pick_and_launch(ctx, hc, reinterpret_cast<const nrq_job *>(ctx->plan_jobs.p) + c0, m, T, kc->dev, (d_inter ? p.L : 0u) + max_nl);
+        result = pick_and_launch(ctx, hc, reinterpret_cast<const nrq_job *>(ctx->plan_jobs[ab].p) + c0, m, T, kc->dev, (d_inter ? p.L : 0u) + max_nl);
       if (ctx->chunk_done && ctx->chunk_done[ci]) HIPCHK(ctx, hipEventRecord((hipEvent_t)ctx->chunk_done[ci], ctx->stream));
     }
-    HIPCHK(ctx, hipEventRecord(ctx->arena_free, ctx->stream));
-    ctx->arena_busy = true;
+    HIPCHK(ctx, hipEventRecord(ctx->arena_free[ab], ctx->stream));
+    ctx->arena_busy[ab] = true;
   } else if (!hdrs.empty()) {
-    if (ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->planned, 0));
-    result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ctx->plan_jobs.p), nblk, T, kc->dev,
+    if (ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->planned[ab], 0));
+    result = pick_and_launch(ctx, hdrs, reinterpret_cast<const nrq_job *>(ctx->plan_jobs[ab].p), nblk, T, kc->dev,
                              (d_inter ? p.L : 0u) + max_nl);
-    /* the launch reads the plan arenas and job records: the next planner run may not overwrite them before it is done */
-    HIPCHK(ctx, hipEventRecord(ctx->arena_free, ctx->stream));
-    ctx->arena_busy = true;
+    /* the launch reads the plan arenas and job records: a later planner run may not overwrite this set before it is done */
+    HIPCHK(ctx, hipEventRecord(ctx->arena_free[ab], ctx->stream));
+    ctx->arena_busy[ab] = true;
   }
   ctx->stats.host_ms = now_ms() - t_begin;
   if (result) return result;
   return need_fallback ? 1 : 0;
+}
+
+/* Issue the planner run of a decode call AHEAD of the call: the symbolic stage needs the reception pattern only, not the
+ * symbols -- a receiver that knows which symbols of a batch of blocks it holds (or a pipeline that decodes batch after batch)
+ * can have the plan built while earlier work is still being solved; the nrq_decode_blocks / _lazy call with the same arguments
+ * then only waits for it.  A call with other arguments discards it. */
+int nrq_decode_plan_ahead(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
+                          const uint32_t *h_lost, const uint32_t *h_nlost, uint32_t lost_cap, const uint32_t *h_rep_esi,
+                          const uint32_t *h_nrep, const uint32_t *h_nrep_avail, uint32_t rep_cap, const void *d_rep, size_t rep_stride,
+                          void *d_inter, size_t inter_stride) {
+  if (!ctx) return -1;
+  if (!d_src || T == 0 || nblk == 0 || !h_nlost || !h_nrep || !h_lost || !h_rep_esi) return fail(ctx, -1, "bad arguments");
+  if (!ctx->planner) return 0; /* host planner: nothing to issue ahead */
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->ahead.size() >= NRQ_PLAN_AHEAD_MAX) return fail(ctx, -6, "nrq_decode_plan_ahead: %u runs are already waiting for their decode calls", (unsigned)NRQ_PLAN_AHEAD_MAX);
+  PlanRun *r = new PlanRun();
+  const int rc = plan_launch(ctx, *r, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap, d_rep,
+                             rep_stride, d_inter, inter_stride, h_nrep_avail);
+  if (rc) { delete r; return rc; }
+  r->d_src = d_src; r->src_stride = src_stride; r->d_rep = d_rep; r->rep_stride = rep_stride; r->d_inter = d_inter; r->inter_stride = inter_stride;
+  r->has_avail = h_nrep_avail != nullptr;
+  r->lost.assign(h_lost, h_lost + (size_t)nblk * lost_cap);
+  r->resi.assign(h_rep_esi, h_rep_esi + (size_t)nblk * rep_cap);
+  r->nlost.assign(h_nlost, h_nlost + nblk);
+  r->nrep.assign(h_nrep, h_nrep + nblk);
+  if (h_nrep_avail) r->avail.assign(h_nrep_avail, h_nrep_avail + nblk);
+  ctx->ahead.push_back(r);
+  if (ctx->ahead.size() > ctx->ahead_hint) ctx->ahead_hint = (uint32_t)ctx->ahead.size();
+  return 0;
 }
 
 int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,
@@ -2465,6 +2631,7 @@ int nrq_ptime_read(nrq_ctx *ctx, float *ms_out, uint32_t cap, uint32_t *count) {
   if (!ctx || !count) return -1;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->plan_stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->plan_stream_b));
   uint32_t n = (uint32_t)ctx->ptime_used;
   for (uint32_t k = 0; k < n && k < cap; k++)
     HIPCHK(ctx, hipEventElapsedTime(&ms_out[k], ctx->ptime_pool[k].first, ctx->ptime_pool[k].second));

@@ -531,3 +531,86 @@ def test_capacity_fallback_replans_on_the_host(G, orc, K, T, nblk, loss):
     finally:
         c.set_option("plan_ucap", 0)
     assert mixed, "no capacity setting split the batch between the device and the host planner"
+
+
+def test_decode_plan_issued_ahead(G, orc):
+    """nrq_decode_plan_ahead: the planner run of a decode call issued before the call (the symbolic stage needs the reception
+    pattern only) -- the decode with the same arguments finds it (stats.plan_ahead), a decode with OTHER arguments discards it
+    and plans for itself, and a pipeline of several batches with the next batch's plan always in flight (two arena sets in
+    turn) decodes every batch like the plain call: bytes equal to the source, which the oracle's decode also returns."""
+    K, T, nblk = 600, 64, 6
+    c = G.ctx()
+    src = np.stack([payload(K * T, seed=50 + b).reshape(K, T) for b in range(nblk)])
+    esis = np.arange(K, K + 90, dtype=np.uint32)
+    rep, _ = G.gpu_encode(src, K, T, esis)
+
+    def batch(seed):
+        lost = np.zeros((nblk, 80), np.uint32); nlost = np.zeros(nblk, np.uint32)
+        work = src.copy()
+        for b in range(nblk):
+            lo = loss_pattern(K, 0.1, seed=seed, block=b)[:80]
+            lost[b, :len(lo)] = lo; nlost[b] = len(lo)
+            work[b][lo] = 0x77
+        return lost, nlost, work
+
+    resi = np.tile(esis, (nblk, 1))
+    d_src = c.alloc(src.nbytes); d_rep = c.alloc(rep.nbytes)
+    try:
+        c.upload(d_rep, rep)
+        # 1. same arguments: found
+        lost, nlost, work = batch(1)
+        c.upload(d_src, work)
+        c.decode_plan_ahead(K, T, nblk, d_src, K * T, lost, nlost, resi, nlost + 2, nlost + 5, d_rep, 90 * T)
+        st, used = c.decode_blocks_lazy(K, T, nblk, d_src, K * T, lost, nlost, resi, nlost + 2, nlost + 5, d_rep, 90 * T)
+        assert c.stats()["plan_ahead"] == 1 and st.all()
+        c.sync()
+        assert np.array_equal(c.download(d_src, src.nbytes).reshape(src.shape), src)
+        ok, ref, _ = orc.decode_block(np.concatenate([np.setdiff1d(np.arange(K, dtype=np.uint32), lost[0, :nlost[0]]), esis[:nlost[0] + 2]]),
+                                      np.concatenate([src[0][np.setdiff1d(np.arange(K), lost[0, :nlost[0]])], rep[0][:nlost[0] + 2]]), K, T)
+        assert ok and np.array_equal(ref, src[0])
+        # 2. other arguments (another reception pattern): discarded, the call plans for itself
+        lost2, nlost2, work2 = batch(2)
+        c.upload(d_src, work2)
+        c.decode_plan_ahead(K, T, nblk, d_src, K * T, lost, nlost, resi, nlost + 2, nlost + 5, d_rep, 90 * T)
+        st, used = c.decode_blocks_lazy(K, T, nblk, d_src, K * T, lost2, nlost2, resi, nlost2 + 2, nlost2 + 5, d_rep, 90 * T)
+        assert c.stats()["plan_ahead"] == 0 and st.all()
+        c.sync()
+        assert np.array_equal(c.download(d_src, src.nbytes).reshape(src.shape), src)
+        # 3. a pipeline: batch i + 1's plan is issued right after batch i's decode call returned (its solve still queued)
+        batches = [batch(10 + i) for i in range(5)]
+        bufs = [c.alloc(src.nbytes) for _ in batches]
+        for (lo_, nl_, wk_), d in zip(batches, bufs):
+            c.upload(d, wk_)
+        lo_, nl_, _ = batches[0]
+        c.decode_plan_ahead(K, T, nblk, bufs[0], K * T, lo_, nl_, resi, nl_ + 2, nl_ + 5, d_rep, 90 * T)
+        for i, ((lo_, nl_, _), d) in enumerate(zip(batches, bufs)):
+            st, used = c.decode_blocks_lazy(K, T, nblk, d, K * T, lo_, nl_, resi, nl_ + 2, nl_ + 5, d_rep, 90 * T)
+            assert c.stats()["plan_ahead"] == 1 and st.all(), i
+            if i + 1 < len(batches):
+                ln, nn, _ = batches[i + 1]
+                c.decode_plan_ahead(K, T, nblk, bufs[i + 1], K * T, ln, nn, resi, nn + 2, nn + 5, d_rep, 90 * T)
+        c.sync()
+        for d in bufs:
+            assert np.array_equal(c.download(d, src.nbytes).reshape(src.shape), src)
+        # 4. the same with TWO runs in flight (they execute side by side: two planner streams, three arena sets); a third one
+        # is refused while two are waiting
+        for (lo_, nl_, wk_), d in zip(batches, bufs):
+            c.upload(d, wk_)
+
+        def ahead(i):
+            ln, nn, _ = batches[i]
+            c.decode_plan_ahead(K, T, nblk, bufs[i], K * T, ln, nn, resi, nn + 2, nn + 5, d_rep, 90 * T)
+        ahead(0); ahead(1)
+        with pytest.raises(nanorq_amd.NrqError):
+            ahead(2)
+        for i, ((lo_, nl_, _), d) in enumerate(zip(batches, bufs)):
+            st, used = c.decode_blocks_lazy(K, T, nblk, d, K * T, lo_, nl_, resi, nl_ + 2, nl_ + 5, d_rep, 90 * T)
+            assert c.stats()["plan_ahead"] == 1 and st.all(), i
+            if i + 2 < len(batches):
+                ahead(i + 2)
+        c.sync()
+        for d in bufs:
+            assert np.array_equal(c.download(d, src.nbytes).reshape(src.shape), src)
+            c.free(d)
+    finally:
+        c.free(d_src); c.free(d_rep)
