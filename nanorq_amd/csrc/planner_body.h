@@ -90,7 +90,24 @@ __device__ __forceinline__ uint32_t pl_wave_take(uint32_t *p, bool take) {
   return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 #define PL_WAVE_TAKE(p, take) pl_wave_take((p), (take))
+/* compact peeling state (below): updates of the HBM copies that nobody waits for -- GLOBAL instructions without a return value
+ * (a FLAT one would also count against the LDS counter of the wave and every LDS result would wait for it) -- and loads
+ * that must see what other waves' atomics left in L2 */
+#define PL_G32(p) ((__attribute__((address_space(1))) uint32_t *)(p))
+/* (WORKGROUP scope: one workgroup owns a block's peeling state from the first to the last round, so its atomics may be
+ * performed in the XCD's L2; at device scope -- the default of atomicSub() and friends -- gfx950 sends them past the L2) */
+#ifndef PL_PEEL_SCOPE
+#define PL_PEEL_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+#define PL_GSUB_NR(p, v) ((void)__hip_atomic_fetch_sub(PL_G32(p), (v), __ATOMIC_RELAXED, PL_PEEL_SCOPE))
+#define PL_GMAX_NR(p, v) ((void)__hip_atomic_fetch_max(PL_G32(p), (v), __ATOMIC_RELAXED, PL_PEEL_SCOPE))
+#define PL_GLOAD(p) __hip_atomic_load(PL_G32(p), __ATOMIC_RELAXED, PL_PEEL_SCOPE)
+#define PL_GSTORE(p, v) (*PL_G32(p) = (v))
 #else
+#define PL_GSUB_NR(p, v) ((void)pl_sub_((p), (v)))
+#define PL_GMAX_NR(p, v) ((void)pl_max_((p), (v)))
+#define PL_GLOAD(p) (*(p))
+#define PL_GSTORE(p, v) (*(p) = (v))
 #define PL_WAVE_TAKE(p, take) ((take) ? pl_add_((p), 1u) : 0u)
 #define PL_WAVE_MIN(v) (v)
 #define PL_WAVE_MAX(v) (v)
@@ -252,6 +269,11 @@ struct PlanCtx {
   pl_work_layout wl;
   uint8_t *work;
   uint32_t *rowstate, *rowinfo, *colinfo;
+  /* compact peeling state in LDS (big blocks, whose three arrays above stay in HBM): what a peeling round DECIDES on --
+   * the number of V columns of every row (a byte), "row has no pivot yet", "row was replaced by this block", "column has
+   * left V" (a bit each): 79 KB at K'=56403.  The HBM arrays are kept up to date by stores and atomics nobody waits for
+   * (later phases read them); a round then waits for three trips to memory instead of six (pl_round_claim_k). */
+  uint32_t *pk_cnt, *pk_un, *pk_pa, *pk_vb;
   uint16_t *patch_of, *patch_cols, *pc_rows, *ucol;
   uint8_t *patch_len;
   uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *lev_fin, *red_row,
@@ -326,6 +348,15 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
       c.dense_lds = lds_dyn + need;
       c.dense_bytes = lds_dyn_bytes - need;
       c.aux_bytes = pl_r16(Mcap * 4u); /* the rowstate image, dead once peeling is over */
+    }
+    c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
+    const uint32_t pk_cnt_b = pl_r16(Mcap + 4u), pk_row_b = pl_r16((Mcap + 31u) / 32u * 4u), pk_col_b = pl_r16((c.p.L + 31u) / 32u * 4u);
+    if (lds_dyn && c.rowstate != reinterpret_cast<uint32_t *>(lds_dyn) && pk_cnt_b + 2u * pk_row_b + pk_col_b <= lds_dyn_bytes) {
+      /* (the dynamic region is idle during peeling when the state is not in it: the dense stage and the level tables come later) */
+      c.pk_cnt = reinterpret_cast<uint32_t *>(lds_dyn);
+      c.pk_un = reinterpret_cast<uint32_t *>(lds_dyn + pk_cnt_b);
+      c.pk_pa = reinterpret_cast<uint32_t *>(lds_dyn + pk_cnt_b + pk_row_b);
+      c.pk_vb = reinterpret_cast<uint32_t *>(lds_dyn + pk_cnt_b + 2u * pk_row_b);
     }
   }
   c.patch_of = reinterpret_cast<uint16_t *>(w + c.wl.patch_of);
@@ -444,6 +475,23 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   }
   for (uint32_t x = tid; x < p.P; x += nt) c.ucol[x] = (uint16_t)(p.W + x);
   for (uint32_t j = tid; j < c.lowcap; j += nt) c.gj_used()[j] = 0;
+  if (c.pk_cnt) {
+    uint32_t *cnt = c.pk_cnt, *un = c.pk_un, *pa = c.pk_pa, *vb = c.pk_vb;
+    PL_ASSUME_LDS(cnt); PL_ASSUME_LDS(un); PL_ASSUME_LDS(pa); PL_ASSUME_LDS(vb);
+    for (uint32_t w = tid; w * 4u < c.Mcap; w += nt) { /* four rows' counts per word */
+      uint32_t v = 0;
+      for (uint32_t q = 0; q < 4u; q++) {
+        const uint32_t r = w * 4u + q;
+        if (r < L) v |= (c.b_state[r] >> 24) << (8u * q);
+      }
+      cnt[w] = v;
+    }
+    for (uint32_t w = tid; w * 32u < c.Mcap; w += nt) { un[w] = 0xFFFFFFFFu; pa[w] = 0u; }
+    for (uint32_t w = tid; w * 32u < L; w += nt) { /* bit set = the column is not (or no longer) in V */
+      const uint32_t lo = w * 32u;
+      vb[w] = lo >= p.W ? 0xFFFFFFFFu : (lo + 32u <= p.W ? 0u : ~((1u << (p.W - lo)) - 1u));
+    }
+  }
 }
 
 /* validate the inputs and expand the patched rows (thread per received repair symbol) */
@@ -476,6 +524,13 @@ template <int Z> SB_HD void pl_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
     c.patch_of[row] = (uint16_t)i;
     c.rowstate[row] = (cnt << 24) | sum;
     c.rowinfo[row] = PL_UNASSIGNED | PL_PATCHED;
+    if (c.pk_cnt) { /* (pl_init_a wrote the base row's count: replace the byte) */
+      uint32_t *pc = c.pk_cnt, *pa = c.pk_pa;
+      PL_ASSUME_LDS(pc); PL_ASSUME_LDS(pa);
+      const uint32_t sh8 = (row & 3u) * 8u, old = (pc[row >> 2] >> sh8) & 0xFFu;
+      PL_ATOM_ADD(&pc[row >> 2], (cnt - old) << sh8); /* (wraps inside the byte's lane of the sum: cnt - old may be negative) */
+      PL_ATOM_OR(&pa[row >> 5], 1u << (row & 31u));
+    }
   }
 }
 
@@ -535,6 +590,17 @@ template <bool LDS> SB_HD PlPeel pl_peel_state(const PlanCtx &c) {
   return s;
 }
 #define PL_PEEL_DISPATCH(fn, ...) do { if (pl_peel_in_lds(c)) fn<true>(__VA_ARGS__); else fn<false>(__VA_ARGS__); } while (0)
+/* three ways: the state in LDS | the compact state in LDS with the HBM arrays kept up to date (fn##k) | the HBM arrays alone */
+#define PL_PEEL_DISPATCH3(fn, ...) do { if (pl_peel_in_lds(c)) fn##t<true>(__VA_ARGS__); else if (c.pk_cnt) fn##k(__VA_ARGS__); \
+                                        else fn##t<false>(__VA_ARGS__); } while (0)
+struct PlPk { uint32_t *cnt, *un, *pa, *vb; };
+SB_HD PlPk pl_pk(const PlanCtx &c) {
+  PlPk k{c.pk_cnt, c.pk_un, c.pk_pa, c.pk_vb};
+  PL_ASSUME_LDS(k.cnt); PL_ASSUME_LDS(k.un); PL_ASSUME_LDS(k.pa); PL_ASSUME_LDS(k.vb);
+  return k;
+}
+SB_HD uint32_t pk_count(const PlPk &k, uint32_t r) { return (k.cnt[r >> 2] >> ((r & 3u) * 8u)) & 0xFFu; }
+SB_HD bool pk_bit(const uint32_t *b, uint32_t i) { return ((b[i >> 5] >> (i & 31u)) & 1u) != 0u; }
 
 /* column `col` leaves V: one atomic subtract per row that contains it; rows that drop to a single V
  * column join the next frontier (queue of parity `np`).  `lvl1` (pivot level + 1) is folded into the
@@ -556,6 +622,34 @@ template <bool LDS> SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint3
       const uint32_t j = PL_ATOM_ADD(&sh->nq[np], 1u);
       if (j < c.qcap) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     } else if (!LDS && (old >> 24) == 3u && (info & PL_UNASSIGNED)) { /* two V columns left: a candidate of the next inactivation */
+      const uint32_t j = PL_ATOM_ADD(&sh->ncand[0], 1u);
+      if (j < c.Mcap) c.cand[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    }
+  }
+}
+
+/* the same on the compact state: after the two trips for the column's row list everything the round waits for is in LDS --
+ * the count (a byte of a word: the atomic subtracts 1 in the byte's place; a count never goes below zero, so nothing is
+ * borrowed from the neighbour), the two flags; the HBM row state and level follow by atomics without a return value */
+SB_HD void pl_drop_column_k(PlanCtx &c, const PlPk &k, uint32_t col, uint32_t lvl1, uint32_t np, uint32_t lane0, uint32_t lanes) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint32_t dec = (1u << 24) | col;
+  uint16_t *nextq = c.queue(np);
+  const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a;
+  const uint32_t pa = c.pc_ptr[col], npc = c.pc_ptr[col + 1] - pa;
+  for (uint32_t e = lane0; e < nb + npc; e += lanes) {
+    const bool base = e < nb;
+    const uint32_t r = base ? c.b_ridx[a + e] : c.pc_rows[pa + (e - nb)];
+    const bool patched = pk_bit(k.pa, r), open = pk_bit(k.un, r); /* flags change in other phases only: stable here */
+    if (base && patched) continue; /* base entry of a row this block replaced */
+    if (lvl1 && open) PL_GMAX_NR(&c.rowinfo[r], PL_UNASSIGNED | (patched ? PL_PATCHED : 0u) | lvl1);
+    PL_GSUB_NR(&c.rowstate[r], dec);
+    const uint32_t sh8 = (r & 3u) * 8u;
+    const uint32_t old = (PL_ATOM_SUB(&k.cnt[r >> 2], 1u << sh8) >> sh8) & 0xFFu;
+    if (old == 2u && open) {
+      const uint32_t j = PL_ATOM_ADD(&sh->nq[np], 1u);
+      if (j < c.qcap) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    } else if (old == 3u && open) { /* two V columns left: a candidate of the next inactivation */
       const uint32_t j = PL_ATOM_ADD(&sh->ncand[0], 1u);
       if (j < c.Mcap) c.cand[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     }
@@ -590,8 +684,36 @@ template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_
   }
   if (tid == 0) { sh->nq[pq ^ 1u] = 0; sh->best = PL_NONE; }
 }
+/* compact state: whether a frontier row still has exactly one V column and no pivot is in LDS; WHICH column that is, is the
+ * sum left in the HBM row state (all of last round's subtractions have arrived: the barrier waited for them) -- one trip,
+ * together with the row's level so far; the claim itself is a bit in LDS */
+SB_HD void pl_round_claim_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const PlPk k = pl_pk(c);
+  const uint32_t pq = rd & 1u;
+  const uint16_t *fq = c.queue(pq);
+  const uint32_t nf = sh->nq[pq] < c.qcap ? sh->nq[pq] : c.qcap;
+  for (uint32_t t = tid; t < nf; t += nt) {
+    const uint32_t r = fq[t];
+    if (pk_count(k, r) != 1u || !pk_bit(k.un, r)) continue;
+    const uint32_t st = PL_GLOAD(&c.rowstate[r]), info = PL_GLOAD(&c.rowinfo[r]);
+    const uint32_t col = st & 0xFFFFFFu, cbit = 1u << (col & 31u);
+    if (PL_ATOM_OR(&k.vb[col >> 5], cbit) & cbit) continue; /* another row of this round took the column */
+    const uint32_t lv = info & PL_LEVEL_MASK;
+    const uint32_t kk = PL_ATOM_ADD(&sh->npiv, 1u);
+    const uint32_t i = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
+    PL_ATOM_XOR(&k.un[r >> 5], 1u << (r & 31u)); /* assigned (the bit was set: only this thread clears it) */
+    PL_GSTORE(&c.rowinfo[r], (info & PL_PATCHED) | lv);
+    PL_GSTORE(&c.colinfo[col], (PL_ST_PIVOT << 30) | kk);
+    PL_ATOM_SUB(&sh->nV, 1u);
+    if (i < c.qcap) { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    c.pivslot[kk] = (uint16_t)r; /* (HBM; read after peeling) */
+    c.pivcol[kk] = (uint16_t)col;
+  }
+  if (tid == 0) { sh->nq[pq ^ 1u] = 0; sh->best = PL_NONE; }
+}
 template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
-  PL_PEEL_DISPATCH(pl_round_claim_t, c, rd, tid, nt);
+  PL_PEEL_DISPATCH3(pl_round_claim_, c, rd, tid, nt);
 }
 /* B: the claimed columns leave V.  A group of 8..64 lanes per column -- as many as the round's claim count leaves
  * (most rounds claim a dozen columns; each trip over a column's row list is a dependent HBM/L2 round trip) */
@@ -608,8 +730,19 @@ template <bool LDS> SB_HD void pl_round_drop_t(PlanCtx &c, uint32_t rd, uint32_t
   }
   if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
 }
+SB_HD void pl_round_drop_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const PlPk k = pl_pk(c);
+  const uint32_t pq = rd & 1u;
+  const uint32_t nc = sh->nclaim[pq] < c.qcap ? sh->nclaim[pq] : c.qcap;
+  uint32_t lg = 3;
+  while (lg < 6u && (nc << (lg + 1u)) <= nt) lg++;
+  const uint32_t grp = tid >> lg, lane = tid & ((1u << lg) - 1u), ngrp = nt >> lg;
+  for (uint32_t i = grp; i < nc; i += ngrp) pl_drop_column_k(c, k, c.claim_c()[i], c.claim_l()[i], pq ^ 1u, lane, 1u << lg);
+  if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
+}
 template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
-  PL_PEEL_DISPATCH(pl_round_drop_t, c, rd, tid, nt);
+  PL_PEEL_DISPATCH3(pl_round_drop_, c, rd, tid, nt);
 }
 /* No claimant in the frontier: find an open row with the fewest V columns.  Almost always that is a row with two; those
  * are kept on a stack as they come up (pl_drop_column pushes a row when its count drops to two; rows that start with
@@ -633,8 +766,23 @@ template <bool LDS> SB_HD void pl_inact_find_t(PlanCtx &c, uint32_t rdrep, uint3
   if (best != PL_NONE && PL_WAVE_LEADER(tid)) { PL_ATOM_MIN(&sh->best, best); PL_ATOM_MAX(&sh->ncand[1], hi); }
   if (tid == 0 && rep == 0) { sh->nq[(rd & 1u) ^ 1u] = 0; sh->nclaim[rd & 1u] = 0; }
 }
+SB_HD void pl_inact_find_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const PlPk k = pl_pk(c);
+  const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
+  const uint32_t n = sh->ncand[0], lo = n > nt ? n - nt : 0u, i = lo + tid;
+  uint32_t best = PL_NONE, hi = 0;
+  if (i < n) {
+    const uint32_t r = c.cand[i];
+    if (pk_bit(k.un, r) && pk_count(k, r) == 2u) { best = (2u << 16) | r; hi = i + 1u; }
+  }
+  best = PL_WAVE_MIN(best);
+  hi = PL_WAVE_MAX(hi);
+  if (best != PL_NONE && PL_WAVE_LEADER(tid)) { PL_ATOM_MIN(&sh->best, best); PL_ATOM_MAX(&sh->ncand[1], hi); }
+  if (tid == 0 && rep == 0) { sh->nq[(rd & 1u) ^ 1u] = 0; sh->nclaim[rd & 1u] = 0; }
+}
 template <int Z> SB_HD void pl_inact_find(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  PL_PEEL_DISPATCH(pl_inact_find_t, c, rdrep, tid, nt);
+  PL_PEEL_DISPATCH3(pl_inact_find_, c, rdrep, tid, nt);
 }
 /* pop what the search found invalid: everything above the highest valid entry, or the whole chunk */
 template <int Z> SB_HD void pl_inact_find_c(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
@@ -663,8 +811,24 @@ template <bool LDS> SB_HD void pl_inact_find_b_t(PlanCtx &c, uint32_t rdrep, uin
   if (best != PL_NONE && PL_WAVE_LEADER(tid)) PL_ATOM_MIN(&sh->best, best);
   (void)rdrep;
 }
+SB_HD void pl_inact_find_b_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const PlPk k = pl_pk(c);
+  uint32_t best = PL_NONE;
+  for (uint32_t r = tid; r < sh->M; r += nt) {
+    if (!pk_bit(k.un, r)) continue;
+    const uint32_t cnt = pk_count(k, r);
+    if (cnt >= 2u) {
+      const uint32_t key = (cnt << 16) | r;
+      if (key < best) best = key;
+    }
+  }
+  best = PL_WAVE_MIN(best);
+  if (best != PL_NONE && PL_WAVE_LEADER(tid)) PL_ATOM_MIN(&sh->best, best);
+  (void)rdrep;
+}
 template <int Z> SB_HD void pl_inact_find_b(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  PL_PEEL_DISPATCH(pl_inact_find_b_t, c, rdrep, tid, nt);
+  PL_PEEL_DISPATCH3(pl_inact_find_b_, c, rdrep, tid, nt);
 }
 /* inactivate all but one V column of that row (or every remaining V column if no row is left) */
 template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
@@ -726,8 +890,62 @@ template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, ui
   sh->nclaim[rd & 1u] = m; /* "columns to drop" */
   sh->nV -= m;
 }
+SB_HD void pl_inact_apply_a_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const PlPk k = pl_pk(c);
+  const rq_params &p = c.p;
+  const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
+  if (sh->best == PL_NONE) {
+    if (rep != 0) return; /* later rows of an event: nothing left to take, peeling resumes */
+    for (uint32_t col = tid; col < p.W; col += nt) {
+      if (!pk_bit(k.vb, col)) {
+        const uint32_t x = p.P + PL_ATOM_ADD(&sh->ninact, 1u);
+        if (x < c.ucap) { PL_ATOM_OR(&k.vb[col >> 5], 1u << (col & 31u)); c.colinfo[col] = (PL_ST_INACT << 30) | x; c.ucol[x] = (uint16_t)col; }
+        else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+      }
+    }
+    return;
+  }
+  if (tid != 0) return;
+  /* list the row's V columns; keep the one with the fewest entries (heuristic), inactivate the others */
+  const uint32_t r = sh->best & 0xFFFFu;
+  const uint16_t *cols;
+  const uint32_t n = pl_row(c, r, &cols);
+  uint32_t keep = PL_NONE, keepdeg = PL_NONE, m = 0;
+  constexpr uint32_t CB = 8;
+  for (uint32_t k0 = 0; k0 < n; k0 += CB) {
+    uint32_t col[CB], dg[CB];
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++)
+      dg[q] = (c.b_cptr[col[q] + 1] - c.b_cptr[col[q]]) + (c.pc_ptr[col[q] + 1] - c.pc_ptr[col[q]]);
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++)
+      if (k0 + q < n && !pk_bit(k.vb, col[q]) && dg[q] < keepdeg) { keepdeg = dg[q]; keep = col[q]; }
+  }
+  bool full = false;
+  for (uint32_t k0 = 0; k0 < n && !full; k0 += CB) {
+    uint32_t col[CB];
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) {
+      if (k0 + q >= n || pk_bit(k.vb, col[q]) || col[q] == keep || full) continue;
+      const uint32_t x = p.P + sh->ninact;
+      if (x >= c.ucap || m >= c.qcap) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); full = true; continue; }
+      sh->ninact++;
+      k.vb[col[q] >> 5] |= 1u << (col[q] & 31u); /* (one thread; also keeps a column listed twice from being taken twice) */
+      c.colinfo[col[q]] = (PL_ST_INACT << 30) | x;
+      c.ucol[x] = (uint16_t)col[q];
+      c.claim_c()[m++] = (uint16_t)col[q];
+    }
+  }
+  sh->nclaim[rd & 1u] = m; /* "columns to drop" */
+  sh->nV -= m;
+}
 template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  PL_PEEL_DISPATCH(pl_inact_apply_a_t, c, rdrep, tid, nt);
+  PL_PEEL_DISPATCH3(pl_inact_apply_a_, c, rdrep, tid, nt);
 }
 template <bool LDS> SB_HD void pl_inact_apply_b_t(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
@@ -743,8 +961,22 @@ template <bool LDS> SB_HD void pl_inact_apply_b_t(PlanCtx &c, uint32_t rdrep, ui
   for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column<LDS>(c, s, c.claim_c()[i], 0u, pq ^ 1u, lane, 32u);
   if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; }
 }
+SB_HD void pl_inact_apply_b_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const PlPk k = pl_pk(c);
+  const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
+  const uint32_t pq = rd & 1u;
+  if (sh->best == PL_NONE) {
+    if (tid == 0 && rep == 0) sh->nV = 0;
+    if (tid == 0) sh->tmp1 = 1u; /* event over */
+    return;
+  }
+  const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
+  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column_k(c, k, c.claim_c()[i], 0u, pq ^ 1u, lane, 32u);
+  if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; }
+}
 template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
-  PL_PEEL_DISPATCH(pl_inact_apply_b_t, c, rdrep, tid, nt);
+  PL_PEEL_DISPATCH3(pl_inact_apply_b_, c, rdrep, tid, nt);
 }
 /* between two rows of one event: forget the previous choice */
 template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {

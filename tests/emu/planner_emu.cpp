@@ -65,7 +65,8 @@ static uint32_t g_mode = 0; /* nrq_planjob::mode of the next emu_plan call (1 = 
 static uint32_t g_qcap = PL_QCAP, g_lowcap = PL_LOWCAP; /* capacities of the arrays behind pl_shared (small blocks get small ones) */
 extern "C" void emu_plan_set_caps(uint32_t qcap, uint32_t lowcap) { g_qcap = qcap ? qcap : PL_QCAP; g_lowcap = lowcap ? lowcap : PL_LOWCAP; }
 static uint32_t g_split = 0; /* run the phase sequence in its two parts (what big blocks do on the GPU) */
-extern "C" void emu_plan_set_mode(uint32_t mode) { g_mode = mode & 0xFFu; g_split = (mode >> 8) & 1u; }
+static uint32_t g_nopk = 0;  /* keep the peeling state in the workspace alone (no compact copy in LDS) when it does not fit the LDS */
+extern "C" void emu_plan_set_mode(uint32_t mode) { g_mode = mode & 0xFFu; g_split = (mode >> 8) & 1u; g_nopk = (mode >> 9) & 1u; }
 extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const uint32_t *lost, uint32_t nlost,
                         const uint32_t *rep_esi, uint32_t nrep, uint32_t nrep_avail, uint8_t *arena,
                         uint32_t arena_cap, uint32_t lds_dyn_bytes, nrq_job *job_out) {
@@ -91,6 +92,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   job.mode = g_mode | (g_split << 8);
   PlanCtx c;
   pl_ctx_setup(c, p, kc, job, sh, lds_dyn_bytes ? dyn.data() : nullptr, lds_dyn_bytes, Mcap, npcap, ucap, job_out, g_qcap, g_lowcap, PL_NT);
+  if (g_nopk) c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
 #define PL_PHASE(fn) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, t_, PL_NT); } while (0)
 #define PL_PHASE1(fn, a) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, (a), t_, PL_NT); } while (0)
 #define PL_WFAST_RUN(wb) emu_wfast_run(c, (wb))

@@ -219,6 +219,10 @@ def test_device_planner_emulated_matches_oracle(orc, K, T, wb, p, oh, lds):
         if not ok:
             continue
         assert plan2 == plan, "the segmented run built a different plan"
+        if lds < 140:   # the peeling state is out of LDS: by default its counts and flags are mirrored there (compact state,
+            # big blocks on the GPU); without the mirror the same plan must come out
+            plan4, hdr4 = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=lds * 1024, compact=False)
+            assert plan4 == plan, "the compact peeling state built a different plan"
         if K <= 1024:   # small blocks run with small queues / claim lists / Gauss-Jordan flags behind pl_shared
             plan3, hdr3 = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=lds * 1024, caps=(512, 384))
             assert plan3 == plan
