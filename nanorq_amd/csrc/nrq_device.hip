@@ -448,7 +448,9 @@ enum {
 
 /* The symbolic stage of one decode block per workgroup (phases in planner_body.h, order in
  * planner_seq.h): reception pattern -> device plan + the block's solve job. */
-template <int NT>
+/* PK = 1: the instance for blocks whose peeling state does not fit the LDS -- it carries the compact form of that state
+ * (planner_body.h "compact peeling state"); the others are compiled without it */
+template <int NT, int PK = 0>
 __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
                                                          const nrq_planjob *__restrict__ pjobs,
                                                          nrq_job *__restrict__ jobs_out, uint32_t nblk, uint32_t Mcap,
@@ -464,12 +466,22 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
   pl_shared *sh = reinterpret_cast<pl_shared *>(smem + lds_dyn_bytes);
   PlanCtx c;
   pl_ctx_setup(c, p, kc, pjobs[b], sh, dyn, lds_dyn_bytes, Mcap, npcap, ucap, jobs_out + b, qcap, lowcap, (uint32_t)NT);
+  if (!PK) c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
   /* NRQ_PROF=1: thread 0 of block 0 accumulates shader clocks per phase family (index = PL_TAG) */
   unsigned long long t_prev = prof ? (unsigned long long)clock64() : 0ull;
 #define PL_ACC(tag) do { if (prof && b == 0 && tid == 0) { unsigned long long t_ = (unsigned long long)clock64(); \
                                                           prof[tag] += t_ - t_prev; prof[16 + tag] += 1; t_prev = t_; } } while (0)
-#define PL_PHASE(fn) do { fn<0>(c, tid, (uint32_t)NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
-#define PL_PHASE1(fn, a) do { fn<0>(c, (a), tid, (uint32_t)NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
+#define PL_PHASE(fn) do { fn<PK>(c, tid, (uint32_t)NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
+#define PL_PHASE1(fn, a) do { fn<PK>(c, (a), tid, (uint32_t)NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
+#ifndef PL_CLAIM_FULL_BARRIER
+#define PL_CLAIM_FULL_BARRIER 0
+#endif
+/* (the claim phase: with the peeling decisions in LDS its global stores -- pivot lists, the HBM copies of row / column
+ * state -- are read after peeling only, or by nobody before the next full barrier: the barrier waits for the LDS alone, not
+ * for the stores' way to memory and back, a trip per round) */
+#define PL_PHASE1_CLAIM(fn, a) do { fn<PK>(c, (a), tid, (uint32_t)NT); \
+    if (!PL_CLAIM_FULL_BARRIER && (pl_peel_in_lds(c) || c.pk_cnt)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads(); \
+    PL_ACC(pl_tag_##fn); } while (0)
 #define PL_WFAST_RUN(wb) do { \
     if (tid < NRQ_ROW) { \
       const NRQ_GAS uint32_t *ops_ = gptr<uint32_t>(c.arena + c.sh->off_ops); \
@@ -489,6 +501,7 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
 #undef PL_NT_
 #undef PL_PHASE
 #undef PL_PHASE1
+#undef PL_PHASE1_CLAIM
 #undef PL_WFAST_RUN
 #undef PL_ACC
 }
@@ -1013,6 +1026,8 @@ static int plan_attr_once(nrq_ctx *ctx) {
   if (ctx->plan_attr) return 0;
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT_MIN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_mh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1091,6 +1106,9 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     if (small_wg)
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
                          nblk, Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
+    else if (2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L) > dyn_bytes) /* (pl_ctx_setup's rule: the state stays in HBM) */
+      hipLaunchKernelGGL((nrq_plan_kernel<(int)PL_NT, 1>), dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
+                         Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
     else
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
                          Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);

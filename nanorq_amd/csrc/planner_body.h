@@ -103,7 +103,13 @@ __device__ __forceinline__ uint32_t pl_wave_take(uint32_t *p, bool take) {
 #define PL_GMAX_NR(p, v) ((void)__hip_atomic_fetch_max(PL_G32(p), (v), __ATOMIC_RELAXED, PL_PEEL_SCOPE))
 #define PL_GLOAD(p) __hip_atomic_load(PL_G32(p), __ATOMIC_RELAXED, PL_PEEL_SCOPE)
 #define PL_GSTORE(p, v) (*PL_G32(p) = (v))
+/* two words from two places in one trip (as atomic loads the compiler waits for the first before it asks for the second) */
+__device__ __forceinline__ void pl_gload2(const uint32_t *a, const uint32_t *b, uint32_t &va, uint32_t &vb) {
+  asm volatile("global_load_dword %0, %2, off sc0\n\tglobal_load_dword %1, %3, off sc0\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(va), "=&v"(vb) : "v"(a), "v"(b) : "memory");
+}
 #else
+static inline void pl_gload2(const uint32_t *a, const uint32_t *b, uint32_t &va, uint32_t &vb) { va = *a; vb = *b; }
 #define PL_GSUB_NR(p, v) ((void)pl_sub_((p), (v)))
 #define PL_GMAX_NR(p, v) ((void)pl_max_((p), (v)))
 #define PL_GLOAD(p) (*(p))
@@ -351,7 +357,10 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
     }
     c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
     const uint32_t pk_cnt_b = pl_r16(Mcap + 4u), pk_row_b = pl_r16((Mcap + 31u) / 32u * 4u), pk_col_b = pl_r16((c.p.L + 31u) / 32u * 4u);
-    if (lds_dyn && c.rowstate != reinterpret_cast<uint32_t *>(lds_dyn) && pk_cnt_b + 2u * pk_row_b + pk_col_b <= lds_dyn_bytes) {
+#ifndef PL_NO_COMPACT
+#define PL_NO_COMPACT 0
+#endif
+    if (!PL_NO_COMPACT && lds_dyn && c.rowstate != reinterpret_cast<uint32_t *>(lds_dyn) && pk_cnt_b + 2u * pk_row_b + pk_col_b <= lds_dyn_bytes) {
       /* (the dynamic region is idle during peeling when the state is not in it: the dense stage and the level tables come later) */
       c.pk_cnt = reinterpret_cast<uint32_t *>(lds_dyn);
       c.pk_un = reinterpret_cast<uint32_t *>(lds_dyn + pk_cnt_b);
@@ -475,7 +484,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   }
   for (uint32_t x = tid; x < p.P; x += nt) c.ucol[x] = (uint16_t)(p.W + x);
   for (uint32_t j = tid; j < c.lowcap; j += nt) c.gj_used()[j] = 0;
-  if (c.pk_cnt) {
+  if (Z != 0 && c.pk_cnt) {
     uint32_t *cnt = c.pk_cnt, *un = c.pk_un, *pa = c.pk_pa, *vb = c.pk_vb;
     PL_ASSUME_LDS(cnt); PL_ASSUME_LDS(un); PL_ASSUME_LDS(pa); PL_ASSUME_LDS(vb);
     for (uint32_t w = tid; w * 4u < c.Mcap; w += nt) { /* four rows' counts per word */
@@ -524,7 +533,7 @@ template <int Z> SB_HD void pl_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
     c.patch_of[row] = (uint16_t)i;
     c.rowstate[row] = (cnt << 24) | sum;
     c.rowinfo[row] = PL_UNASSIGNED | PL_PATCHED;
-    if (c.pk_cnt) { /* (pl_init_a wrote the base row's count: replace the byte) */
+    if (Z != 0 && c.pk_cnt) { /* (pl_init_a wrote the base row's count: replace the byte) */
       uint32_t *pc = c.pk_cnt, *pa = c.pk_pa;
       PL_ASSUME_LDS(pc); PL_ASSUME_LDS(pa);
       const uint32_t sh8 = (row & 3u) * 8u, old = (pc[row >> 2] >> sh8) & 0xFFu;
@@ -590,8 +599,10 @@ template <bool LDS> SB_HD PlPeel pl_peel_state(const PlanCtx &c) {
   return s;
 }
 #define PL_PEEL_DISPATCH(fn, ...) do { if (pl_peel_in_lds(c)) fn<true>(__VA_ARGS__); else fn<false>(__VA_ARGS__); } while (0)
-/* three ways: the state in LDS | the compact state in LDS with the HBM arrays kept up to date (fn##k) | the HBM arrays alone */
-#define PL_PEEL_DISPATCH3(fn, ...) do { if (pl_peel_in_lds(c)) fn##t<true>(__VA_ARGS__); else if (c.pk_cnt) fn##k(__VA_ARGS__); \
+/* three ways: the state in LDS | the compact state in LDS with the HBM arrays kept up to date (fn##k) | the HBM arrays alone.
+ * Z: template argument of the phase functions -- 0 compiles the compact form out (the kernel instance for blocks whose state
+ * fits the LDS: with the extra code in it that instance ran 11 % slower, 3.19 -> 3.55 ms per 256 blocks of K=8192) */
+#define PL_PEEL_DISPATCH3(fn, ...) do { if (pl_peel_in_lds(c)) fn##t<true>(__VA_ARGS__); else if (Z != 0 && c.pk_cnt) fn##k(__VA_ARGS__); \
                                         else fn##t<false>(__VA_ARGS__); } while (0)
 struct PlPk { uint32_t *cnt, *un, *pa, *vb; };
 SB_HD PlPk pl_pk(const PlanCtx &c) {
@@ -696,7 +707,8 @@ SB_HD void pl_round_claim_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) 
   for (uint32_t t = tid; t < nf; t += nt) {
     const uint32_t r = fq[t];
     if (pk_count(k, r) != 1u || !pk_bit(k.un, r)) continue;
-    const uint32_t st = PL_GLOAD(&c.rowstate[r]), info = PL_GLOAD(&c.rowinfo[r]);
+    uint32_t st, info;
+    pl_gload2(&c.rowstate[r], &c.rowinfo[r], st, info);
     const uint32_t col = st & 0xFFFFFFu, cbit = 1u << (col & 31u);
     if (PL_ATOM_OR(&k.vb[col >> 5], cbit) & cbit) continue; /* another row of this round took the column */
     const uint32_t lv = info & PL_LEVEL_MASK;

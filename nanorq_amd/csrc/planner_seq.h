@@ -11,6 +11,8 @@
  *                         on 2-byte strips of the bit rows, a workgroup per strip), the HDPC fold over the pivots and the
  *                         transposition of W are parallel work and take 40 % of a one-workgroup planner at K'=56403, so many
  *                         workgroups do them between the two parts (pl_shared travels through the block's workspace)
+ *     PL_PHASE1_CLAIM(fn, a)  PL_PHASE1 for pl_round_claim: what that phase writes to HBM is read after peeling only (when the
+ *                         peeling decisions are taken in LDS), so the barrier behind it need not wait for those stores
  *     PL_STEER_SYNC       a workgroup barrier (nothing in the emulator)
  *     PL_NT_              threads of the workgroup
  * and provides `PlanCtx c`.  Every value that steers control flow is read from workgroup-shared state right after a
@@ -38,7 +40,7 @@
       PL_STEER_SYNC; /* (pl_round_claim lowers nV and may raise status) */
       if (st_ != 0 || nv_ == 0 || rd_ >= guard_max) break;
       if (nq_ > 0) {
-        PL_PHASE1(pl_round_claim, rd_);
+        PL_PHASE1_CLAIM(pl_round_claim, rd_);
         PL_PHASE1(pl_round_drop, rd_);
       } else {
         /* one inactivation event: up to NRQ_MULTI_INACT open rows, sparsest first */

@@ -93,8 +93,9 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   PlanCtx c;
   pl_ctx_setup(c, p, kc, job, sh, lds_dyn_bytes ? dyn.data() : nullptr, lds_dyn_bytes, Mcap, npcap, ucap, job_out, g_qcap, g_lowcap, PL_NT);
   if (g_nopk) c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
-#define PL_PHASE(fn) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, t_, PL_NT); } while (0)
-#define PL_PHASE1(fn, a) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<0>(c, (a), t_, PL_NT); } while (0)
+#define PL_PHASE(fn) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<1>(c, t_, PL_NT); } while (0)
+#define PL_PHASE1(fn, a) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<1>(c, (a), t_, PL_NT); } while (0)
+#define PL_PHASE1_CLAIM(fn, a) PL_PHASE1(fn, a)
 #define PL_WFAST_RUN(wb) emu_wfast_run(c, (wb))
 #define PL_SEG g_seg
 #define PL_STEER_SYNC do { } while (0)
@@ -122,6 +123,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   if (g_split) pl_wt_fill(arena, reinterpret_cast<const uint32_t *>(work.data() + wl.wrows), 0u, 1u); /* = nrq_wt_kernel */
 #undef PL_PHASE
 #undef PL_PHASE1
+#undef PL_PHASE1_CLAIM
 #undef PL_WFAST_RUN
   return 0;
 }
