@@ -36,6 +36,15 @@ size_t nanorq_encode_range_all(nanorq *rq, void *data, uint32_t esi0, uint32_t n
  * number of symbols stored (NANORQ_SYM_ADDED). */
 size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io);
 
+/* Decoder: nanorq_decoder_add_symbols that only ENQUEUES the way of the bytes to the GPU (page-locked packet buffer; with any
+ * other buffer it is the call above).  Bookkeeping and result codes are final on return -- they are those of
+ * nanorq_decoder_add_symbol (reference lib/nanorq.c:478-509) -- but `data` must stay untouched until nanorq_repair_all,
+ * nanorq_decoder_flush, nanorq_repair_block of a block the batch feeds, or nanorq_free has returned.  The receiver's two
+ * stations then overlap: nanorq_repair_all plans at once (the symbolic stage needs the reception pattern, not the symbols),
+ * every chunk of blocks is solved as soon as the upload piece that completes it has landed, and decoded blocks travel
+ * back while later pieces still travel up. */
+size_t nanorq_decoder_add_symbols_async(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io);
+
 /* Decoder: nanorq_repair_block (reference lib/nanorq.c:591-631) for every block that misses source symbols and holds
  * at least as many repair symbols as it misses, in one device batch per block size.  Returns the number of blocks of
  * the object that are complete afterwards; blocks whose system is rank deficient stay incomplete and retryable. */

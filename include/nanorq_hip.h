@@ -196,6 +196,12 @@ int nrq_stream_sync(nrq_ctx *ctx, int stream);
 /* Symbol ingestion on the device: symbol k (T bytes at d_blob + k*T, device memory) is copied to device address
  * h_dst[k] (0 = skip) -- received packets go up in one piece and are put into their rows by a kernel. */
 int nrq_scatter_symbols(nrq_ctx *ctx, int stream, const void *d_blob, uint32_t n, uint32_t T, const uint64_t *h_dst);
+/* Control data (KBs to a few MB, a multiple of 16 bytes, both ends 16-byte aligned) from page-locked host memory into a device
+ * buffer by a kernel that reads the host memory itself: unlike a copy it does not queue behind the bulk uploads the copy
+ * engine is busy with.  stream selector as in nrq_copy_on, plus 3 = the stream of the sorting kernels. */
+int nrq_ctl_copy(nrq_ctx *ctx, int stream, void *d_dst, const void *h_pinned, size_t bytes);
+/* the same with the destination addresses already on the device (enqueue only: no staging of the list, nothing waited for) */
+int nrq_scatter_symbols_dev(nrq_ctx *ctx, int stream, const void *d_blob, uint32_t n, uint32_t T, const uint64_t *d_dst);
 
 /* Per-launch duration of the solve kernel, measured with HIP events recorded on the launch stream
  * immediately around each launch (bench.py's roofline leg).  enable(1) starts collecting; read()

@@ -42,6 +42,10 @@
 #define PIN_MIN ((size_t)64 << 10)        /* host buffers from this size on are page-locked */
 #define CHUNK_BYTES ((size_t)192 << 20)   /* source bytes per pipeline step of the batched calls */
 #define REPAIR_CHUNK_BYTES ((size_t)128 << 20) /* source bytes per solve launch of nanorq_repair_all (one planner run for all) */
+#define UP_PIECE_BYTES ((size_t)48 << 20)      /* packet bytes per upload piece of the deferred ingestion */
+#define NRQ_UP_EV 256
+#define NRQ_UP_BLOB 16
+#define NRQ_MAX_DEV 16
 
 struct part { /* RFC 6330 section 4.4.1.2 Partition[I, J] */
   size_t IL, IS, JL, JS;
@@ -78,6 +82,8 @@ struct blockst {
   void *d_rep;        /* device: repair symbols in arrival order, capacity d_rep_cap symbols */
   size_t d_rep_cap;
   bool dirty;         /* received source symbols have not reached the output context yet */
+  uint32_t up_seq;    /* deferred ingestion: 1 + index (in the object's list for the block's device) of the last upload piece that
+                       * carries symbols of this block; 0 = none in flight */
   /* encoder side: window of generated symbols */
   uint8_t *win;
   uint32_t win_isi0, win_n;
@@ -92,10 +98,21 @@ struct nanorq {
   uint32_t flags;          /* NANORQ_EXT_* */
   bool precalc;
   struct blockst *blocks[NRQ_Z_MAX];
+  /* deferred ingestion (nanorq_decoder_add_symbols_async), per device: the events behind the upload pieces still in
+   * flight (a piece = copy of a stretch of the packet buffer + the kernel that sorts it into rows, on the upload stream)
+   * and the staging buffers they go through; released by settle_uploads() */
+  struct upstate {
+    void *ev[NRQ_UP_EV];
+    unsigned nev;
+    void *blob[NRQ_UP_BLOB];
+    unsigned nblob;
+    void *pin[NRQ_UP_BLOB]; /* page-locked host arrays (destination addresses) the pieces' copies read */
+    bool pin_cached[NRQ_UP_BLOB]; /* from host_alloc (goes back to its cache) rather than nrq_host_alloc_pinned */
+    unsigned npin;
+  } up[NRQ_MAX_DEV];
 };
 
 /* --------------------------------------------------------------- GPU contexts (process-wide) ---- */
-#define NRQ_MAX_DEV 16
 struct devctx {
   nrq_ctx *c;
   int device;
@@ -385,6 +402,30 @@ bool nanorq_set_max_esi(nanorq *rq, uint32_t max_esi) { /* nanorq.c:471-476 */
   return true;
 }
 
+/* deferred ingestion: wait for device di's upload pieces and release what they used */
+static void settle_uploads(nanorq *rq, int di) {
+  struct upstate *u = &rq->up[di];
+  if (!u->nev && !u->nblob && !u->npin) return;
+  nrq_ctx *c = dctx(di);
+  if (c) {
+    gpu_lock(di);
+    nrq_stream_sync(c, 1);
+    nrq_stream_sync(c, 3);
+    for (unsigned i = 0; i < u->nblob; i++) nrq_dev_free(c, u->blob[i]);
+    gpu_unlock(di);
+  }
+  for (unsigned i = 0; i < u->npin; i++) {
+    if (u->pin_cached[i]) host_free(u->pin[i], true); else nrq_host_free_pinned(u->pin[i]);
+  }
+  for (unsigned i = 0; i < u->nev; i++) nrq_event_free(u->ev[i]);
+  u->nev = u->nblob = u->npin = 0;
+  for (unsigned sbn = 0; sbn < NRQ_Z_MAX; sbn++)
+    if (rq->blocks[sbn] && rq->blocks[sbn]->di == di) rq->blocks[sbn]->up_seq = 0;
+}
+static void settle_all_uploads(nanorq *rq) {
+  for (int d = 0; d < g_ndev; d++) settle_uploads(rq, d);
+}
+
 /* -------------------------------------------------------------------- per-block state ---- */
 static struct blockst *get_block(nanorq *rq, uint8_t sbn) { /* nanorq.c:130-146 */
   if (rq->blocks[sbn]) return rq->blocks[sbn];
@@ -433,6 +474,7 @@ static void drop_device(struct blockst *b) {
 void nanorq_encoder_cleanup(nanorq *rq, uint8_t sbn) { /* nanorq.c:437-451 */
   struct blockst *b = rq->blocks[sbn];
   if (!b) return;
+  if (b->up_seq) settle_uploads(rq, b->di);
   drop_device(b);
   nrq_event_free(b->ev_up); nrq_event_free(b->ev_read[0]); nrq_event_free(b->ev_read[1]);
   host_free(b->src, b->src_pinned);
@@ -452,6 +494,7 @@ void nanorq_encoder_reset(nanorq *rq, uint8_t sbn) { /* nanorq.c:453-469 */
   b->nrep = 0;
   b->win_n = 0;
   b->have = 0;
+  if (b->dev && b->up_seq) settle_uploads(rq, b->di);
   if (b->dev) drop_device(b); /* a device-resident decoder block: its rows go back to the pool (the next packet batch allocates anew) */
   b->dev = b->dirty = false;
   if (b->mask) memset(b->mask, 0, b->mask_words * sizeof(uint32_t));
@@ -459,6 +502,7 @@ void nanorq_encoder_reset(nanorq *rq, uint8_t sbn) { /* nanorq.c:453-469 */
 
 void nanorq_free(nanorq *rq) { /* nanorq.c:298-307 */
   if (!rq) return;
+  settle_all_uploads(rq);
   for (unsigned sbn = 0; sbn < NRQ_Z_MAX; sbn++) nanorq_encoder_cleanup(rq, (uint8_t)sbn);
   free(rq);
 }
@@ -691,6 +735,7 @@ int nanorq_decoder_add_symbol(nanorq *rq, void *data, uint32_t tag, struct ioctx
   if (mask_gaps(b, b->K) == 0) return NANORQ_SYM_IGN;
   if (mask_get(b, esi)) return NANORQ_SYM_DUP;
   const size_t T = rq->T;
+  if (b->dev && b->up_seq) settle_uploads(rq, b->di); /* (a deferred batch is still being sorted into this block's rows) */
   if (esi < b->K) {
     if (b->dev) {
       if (!dev_put_row(rq, b, (uint8_t *)b->d_src + (size_t)esi * T, data)) return NANORQ_SYM_ERR;
@@ -780,6 +825,7 @@ static bool flush_dev_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct i
 bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.c:591-631 */
   struct blockst *b = get_block(rq, sbn);
   if (!b) return false;
+  if (b->up_seq) settle_uploads(rq, b->di); /* (symbols of a deferred batch still on their way) */
   const size_t gaps = mask_gaps(b, b->K);
   nrq_ctx *c = dctx(b->di);
   if (gaps == 0) {
@@ -864,6 +910,10 @@ struct all_job {
   uint32_t n;
   const size_t *nrep0;
   const uint8_t *touched;
+  bool deferred; /* nanorq_decoder_add_symbols_async: enqueue only */
+  void *early_blob;     /* ... and the packet buffer is already on its way into this device buffer, in pieces of early_piece */
+  uint32_t early_piece; /* symbols, their copies' events at rq->up[di].ev[early_ev0 ...] */
+  unsigned early_ev0;
   bool ok;
   /* nanorq_encode_range_all */
   uint8_t *out;
@@ -1115,10 +1165,15 @@ static void *add_all_worker(void *arg) {
   nrq_ctx *c = g_dev[di].c;
   const size_t T = rq->T;
   const uint32_t n = j->n;
-  uint64_t *dst = calloc(n ? n : 1, sizeof(uint64_t));
+  /* (deferred ingestion with the packets already on their way: the address list is built where the GPU will read it) */
+  const size_t lbytes = ((size_t)n * 8u + 15u) & ~(size_t)15u;
+  bool dst_pinned = false;
+  uint64_t *dst = j->early_blob ? host_alloc(lbytes >= PIN_MIN ? lbytes : PIN_MIN, &dst_pinned) : calloc(n ? n : 1, sizeof(uint64_t));
   void *olds[NRQ_Z_MAX];
   unsigned nold = 0;
-  bool ok = dst != NULL, any = false;
+  bool ok = dst != NULL && (!j->early_blob || dst_pinned), any = false;
+  uint32_t last_k[NRQ_Z_MAX]; /* per block: the last symbol of the batch that is the block's */
+  memset(last_k, 0xFF, sizeof(last_k));
   gpu_lock(di);
   /* every touched block's repair rows to their final size (ONCE, keeping the rows held before the batch), then addresses */
   for (unsigned sbn = 0; sbn < NRQ_Z_MAX && ok; sbn++) {
@@ -1138,20 +1193,98 @@ static void *add_all_worker(void *arg) {
                                     : (uint64_t)(uintptr_t)((uint8_t *)b->d_rep + (size_t)j->rix[k] * T);
       if (k < k_lo) k_lo = k;
       k_hi = k + 1u;
+      last_k[(uint8_t)(j->tags[k] >> 24)] = k;
       any = true;
     }
+  struct upstate *u = &rq->up[di];
+  if (j->early_blob) {
+    /* The packets have been travelling since the call began (add_symbols_impl): what is left is to tell the GPU where every
+     * symbol goes and to sort each piece into rows when its copy has landed -- kernels on a stream of their own, the address
+     * list brought down by a kernel too (a copy would queue behind the packets). */
+    const uint32_t piece = j->early_piece;
+    void *d_dst = NULL;
+    ok = ok && nrq_dev_alloc(c, lbytes, &d_dst) == 0 && nrq_ctl_copy(c, 3, d_dst, dst, lbytes) == 0;
+    const unsigned ev_first = u->nev; /* the event behind the sort of piece i: u->ev[ev_first + i] */
+    unsigned pi = 0;
+    for (uint32_t k0 = 0; k0 < n && ok; k0 += piece, pi++) {
+      const uint32_t m = n - k0 < piece ? n - k0 : piece;
+      void *ev = NULL;
+      ok = nrq_stream_wait(c, 3, u->ev[j->early_ev0 + pi]) == 0 &&
+           nrq_scatter_symbols_dev(c, 3, (const uint8_t *)j->early_blob + (size_t)k0 * T, m, (uint32_t)T, (const uint64_t *)d_dst + k0) == 0 &&
+           nrq_event_new(c, &ev) == 0 && nrq_event_record(c, ev, 3) == 0;
+      if (ev) u->ev[u->nev++] = ev;
+    }
+    for (unsigned sbn = 0; sbn < NRQ_Z_MAX && ok; sbn++)
+      if (last_k[sbn] != 0xFFFFFFFFu && rq->blocks[sbn]) rq->blocks[sbn]->up_seq = ev_first + last_k[sbn] / piece + 1u;
+    u->blob[u->nblob++] = j->early_blob;
+    if (d_dst) u->blob[u->nblob++] = d_dst;
+    if (dst && dst_pinned) {
+      u->pin_cached[u->npin] = true;
+      u->pin[u->npin++] = dst; /* (read by the kernel above: released by settle_uploads) */
+    } else {
+      host_free(dst, dst_pinned);
+    }
+    if (!ok || nold) { /* (replaced repair rows are freed below: nothing may still be copying out of them) */
+      nrq_stream_sync(c, 1);
+      nrq_stream_sync(c, 3);
+      settle_uploads(rq, di);
+    }
+    for (unsigned i = 0; i < nold; i++) nrq_dev_free(c, olds[i]);
+    gpu_unlock(di);
+    j->ok = ok;
+    return NULL;
+  }
+  /* deferred: nothing is waited for -- every piece leaves an event on the upload stream, every block remembers its last
+   * piece, and nanorq_repair_all lets the solve of a chunk of blocks wait for that piece only (the pieces behind it travel
+   * while the chunk is solved and comes down).  Falls back to the waiting form when a block's repair rows had to be
+   * replaced (the old rows are freed below) or the event / staging lists are full. */
+  const uint32_t dpiece = (uint32_t)((UP_PIECE_BYTES / T) ? (UP_PIECE_BYTES / T) : 1);
+  const bool deferred = j->deferred && nold == 0 && any && u->nblob + 2u <= NRQ_UP_BLOB && u->npin < NRQ_UP_BLOB &&
+                        u->nev + (k_hi - k_lo + dpiece - 1u) / dpiece <= NRQ_UP_EV;
   if (any && ok) {
     /* packets up in pieces, each sorted into its rows as soon as it has landed (same stream: the order is the stream's) */
     void *d_blob = NULL;
-    const uint32_t piece = (uint32_t)((CHUNK_BYTES / T) ? (CHUNK_BYTES / T) : 1), span = k_hi - k_lo;
+    const uint32_t piece = deferred ? dpiece : (uint32_t)((CHUNK_BYTES / T) ? (CHUNK_BYTES / T) : 1), span = k_hi - k_lo;
+    /* (deferred: two staging buffers in turn would let piece i+1 travel while piece i is sorted; the sort takes a fraction
+     * of the copy's time, so one buffer and the stream's order are kept) */
     ok = nrq_dev_alloc(c, (size_t)(span < piece ? span : piece) * T, &d_blob) == 0;
+    void *d_dst = NULL, *h_dst = NULL;
+    if (deferred && ok) {
+      /* the destination addresses of the whole stretch go down ONCE, from a page-locked copy (nrq_scatter_symbols stages a
+       * list per call through two buffers and waits for the call before last: with the pieces' copies queued in front of
+       * them that wait is the upload itself) */
+      ok = nrq_host_alloc_pinned((size_t)span * 8u, &h_dst) == 0 && nrq_dev_alloc(c, (size_t)span * 8u, &d_dst) == 0;
+      if (ok) {
+        memcpy(h_dst, dst + k_lo, (size_t)span * 8u);
+        ok = nrq_copy_on(c, 1, d_dst, h_dst, (size_t)span * 8u) == 0;
+      }
+    }
     for (uint32_t k0 = k_lo; k0 < k_hi && ok; k0 += piece) {
       const uint32_t m = k_hi - k0 < piece ? k_hi - k0 : piece;
-      ok = nrq_copy_on(c, 1, d_blob, j->pk + (size_t)k0 * T, (size_t)m * T) == 0 && nrq_scatter_symbols(c, 1, d_blob, m, (uint32_t)T, dst + k0) == 0;
+      ok = nrq_copy_on(c, 1, d_blob, j->pk + (size_t)k0 * T, (size_t)m * T) == 0 &&
+           (deferred ? nrq_scatter_symbols_dev(c, 1, d_blob, m, (uint32_t)T, (const uint64_t *)d_dst + (k0 - k_lo))
+                     : nrq_scatter_symbols(c, 1, d_blob, m, (uint32_t)T, dst + k0)) == 0;
+      if (deferred && ok) {
+        void *ev = NULL;
+        ok = nrq_event_new(c, &ev) == 0 && nrq_event_record(c, ev, 1) == 0;
+        if (ev) u->ev[u->nev++] = ev;
+        for (uint32_t k = k0; k < k0 + m && ok; k++)
+          if (j->rix[k] != RIX_NONE && rq->blocks[(uint8_t)(j->tags[k] >> 24)]->di == di) rq->blocks[(uint8_t)(j->tags[k] >> 24)]->up_seq = u->nev;
+      }
     }
-    ok = nrq_stream_sync(c, 1) == 0 && ok;
-    if (d_blob) nrq_dev_free(c, d_blob);
-  } else {
+    if (deferred && ok) {
+      u->blob[u->nblob++] = d_blob; /* released by settle_uploads */
+      u->blob[u->nblob++] = d_dst;
+      u->pin_cached[u->npin] = false;
+      u->pin[u->npin++] = h_dst;
+    } else {
+      ok = nrq_stream_sync(c, 1) == 0 && ok;
+      if (d_blob) nrq_dev_free(c, d_blob);
+      if (d_dst) nrq_dev_free(c, d_dst);
+      if (h_dst) nrq_host_free_pinned(h_dst);
+      if (j->deferred) settle_uploads(rq, di);
+    }
+  } else if (!j->deferred) {
     ok = nrq_stream_sync(c, 1) == 0 && ok;
   }
   for (unsigned i = 0; i < nold; i++) nrq_dev_free(c, olds[i]);
@@ -1160,7 +1293,7 @@ static void *add_all_worker(void *arg) {
   j->ok = ok;
   return NULL;
 }
-size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io) {
+static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io, bool deferred) {
   size_t added = 0;
   const uint8_t *p = data;
   const size_t T = rq->T;
@@ -1179,6 +1312,36 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
       if (r == NANORQ_SYM_ADDED) added++;
     }
     return added;
+  }
+  /* Deferred ingestion on one device: the packet buffer starts its way up NOW, piece by piece into one device buffer -- the
+   * bookkeeping below (a million symbols: ~9 ms) runs beside the copies instead of in front of them. */
+  void *early_blob = NULL;
+  uint32_t early_piece = 0;
+  unsigned early_ev0 = 0;
+  if (deferred && g_ndev == 1) {
+    struct upstate *u = &rq->up[0];
+    const uint32_t piece = (uint32_t)((UP_PIECE_BYTES / T) ? (UP_PIECE_BYTES / T) : 1), np = (n + piece - 1u) / piece;
+    nrq_ctx *c = dctx(0);
+    if (c && u->nblob + 2u <= NRQ_UP_BLOB && u->npin < NRQ_UP_BLOB && u->nev + 2u * np <= NRQ_UP_EV) {
+      gpu_lock(0);
+      bool ok = nrq_dev_alloc(c, (size_t)n * T, &early_blob) == 0;
+      early_ev0 = u->nev;
+      for (uint32_t k0 = 0; k0 < n && ok; k0 += piece) {
+        const uint32_t m = n - k0 < piece ? n - k0 : piece;
+        void *ev = NULL;
+        ok = nrq_copy_on(c, 1, (uint8_t *)early_blob + (size_t)k0 * T, p + (size_t)k0 * T, (size_t)m * T) == 0 && nrq_event_new(c, &ev) == 0 &&
+             nrq_event_record(c, ev, 1) == 0;
+        if (ev) u->ev[u->nev++] = ev;
+      }
+      if (!ok) { /* back to the staged path: what was enqueued is waited for and dropped */
+        nrq_stream_sync(c, 1);
+        if (early_blob) nrq_dev_free(c, early_blob);
+        early_blob = NULL;
+      } else {
+        early_piece = piece;
+      }
+      gpu_unlock(0);
+    }
   }
   size_t nrep0[NRQ_Z_MAX];                 /* repair symbols a touched block held before this batch */
   uint8_t touched[NRQ_Z_MAX], newdev[NRQ_Z_MAX];
@@ -1202,7 +1365,7 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
         nrq_ctx *c = dctx(b->di);
         gpu_lock(b->di);
         if (!b->d_src && nrq_dev_alloc(c, (size_t)b->K * T, &b->d_src) != 0) r = NANORQ_SYM_ERR;
-        else if (nrq_memset_on(c, 1, b->d_src, 0, (size_t)b->K * T) != 0) r = NANORQ_SYM_ERR;
+        else if (nrq_memset_on(c, early_blob ? 3 : 1, b->d_src, 0, (size_t)b->K * T) != 0) r = NANORQ_SYM_ERR; /* (in front of the sort into rows) */
         else { b->dev = true; newdev[sbn] = 1; }
         gpu_unlock(b->di);
       }
@@ -1223,7 +1386,8 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
   }
   struct all_job j;
   memset(&j, 0, sizeof(j));
-  j.rq = rq; j.io = io; j.pk = p; j.tags = tags; j.rix = rix; j.n = n; j.nrep0 = nrep0; j.touched = touched;
+  j.rq = rq; j.io = io; j.pk = p; j.tags = tags; j.rix = rix; j.n = n; j.nrep0 = nrep0; j.touched = touched; j.deferred = deferred;
+  j.early_blob = early_blob; j.early_piece = early_piece; j.early_ev0 = early_ev0;
   (void)nput;
   for_devices(add_all_worker, &j, ndev()); /* (also with nothing to put: the memsets of new blocks are waited for) */
   if (!j.ok) {
@@ -1250,6 +1414,19 @@ size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *
   return added;
 }
 
+size_t nanorq_decoder_add_symbols(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io) {
+  settle_all_uploads(rq); /* (a deferred batch before this one: this call's contract is "the buffer is free on return") */
+  return add_symbols_impl(rq, data, tags, n, results, io, false);
+}
+/* The same, enqueue only (page-locked packet buffer; otherwise identical to the call above): bookkeeping and result codes
+ * are final on return, the BYTES travel afterwards -- `data` must stay untouched until nanorq_repair_all,
+ * nanorq_decoder_flush, nanorq_repair_block of a block it feeds, or nanorq_free has returned.  nanorq_repair_all starts its
+ * planner run at once (it needs the reception pattern, not the symbols) and lets the solve of every chunk of blocks wait
+ * for the upload piece that completes the chunk: ingest, solve and the way back of the decoded blocks overlap. */
+size_t nanorq_decoder_add_symbols_async(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io) {
+  return add_symbols_impl(rq, data, tags, n, results, io, true);
+}
+
 /* Decoder, all blocks that can be repaired: per device and block size a pipeline of chunks -- host-resident blocks go up chunk
  * by chunk (upload stream), the chunk is decoded (the context's stream), the decoded blocks come down (download stream)
  * beside the next chunk's decode; device-resident blocks skip the upload.  What comes down: whole blocks into a
@@ -1272,7 +1449,10 @@ static void *repair_all_worker(void *arg) {
       if (!b || b->di != di || b->K == 0) continue;
       const size_t gaps = mask_gaps(b, b->K);
       if (gaps == 0) { /* complete; a device-resident block may still owe the output its received symbols */
-        if (b->dev && b->dirty && io && flush_dev_block(rq, (uint8_t)sbn, b, io, true)) b->dirty = false; /* (the sync is at the end) */
+        if (b->dev && b->dirty && io) {
+          if (b->up_seq && b->up_seq <= rq->up[di].nev) nrq_stream_wait(c, 2, rq->up[di].ev[b->up_seq - 1u]); /* (still on their way up) */
+          if (flush_dev_block(rq, (uint8_t)sbn, b, io, true)) b->dirty = false; /* (the sync is at the end) */
+        }
         continue;
       }
       if (b->nrep < gaps || b->nrep - gaps > b->spare) continue; /* as nanorq_repair_block */
@@ -1295,9 +1475,10 @@ static void *repair_all_worker(void *arg) {
     int *status = calloc(n, sizeof(int));
     uint64_t *sv = calloc(n, sizeof(uint64_t)), *rv = calloc(n, sizeof(uint64_t));
     void **ev_done = calloc(nch, sizeof(void *)), **ev_up = calloc(nch, sizeof(void *)), **ev_dl = calloc(nch, sizeof(void *));
+    bool *ev_up_borrowed = calloc(nch, sizeof(bool)); /* (an event of the deferred ingestion: released by settle_uploads) */
     void *tmp_rep[NRQ_Z_MAX]; /* device copies of host-resident blocks' repair symbols (freed at the end) */
     unsigned ntmp = 0;
-    bool ok = lost && nlost && resi && nuse && navail && status && sv && rv && ev_done && ev_up && ev_dl;
+    bool ok = lost && nlost && resi && nuse && navail && status && sv && rv && ev_done && ev_up && ev_dl && ev_up_borrowed;
     for (unsigned ci = 0; ci < nch && ok; ci++) ok = nrq_event_new(c, &ev_done[ci]) == 0 && nrq_event_new(c, &ev_dl[ci]) == 0;
     for (unsigned c0 = 0, ci = 0; c0 < n && ok; c0 += C, ci++) { /* lists, and what has to go up, chunk by chunk */
       const unsigned m = n - c0 < C ? n - c0 : C;
@@ -1320,7 +1501,13 @@ static void *repair_all_worker(void *arg) {
         }
         sv[k] = (uint64_t)(uintptr_t)b->d_src;
       }
-      if (any_up && ok) ok = nrq_event_new(c, &ev_up[ci]) == 0 && nrq_event_record(c, ev_up[ci], 1) == 0;
+      if (any_up && ok) ok = nrq_event_new(c, &ev_up[ci]) == 0 && nrq_event_record(c, ev_up[ci], 1) == 0; /* (behind every earlier piece too) */
+      else if (ok) { /* device-resident blocks fed by a deferred batch: the chunk waits for the last piece any of them is in */
+        uint32_t seq = 0;
+        for (unsigned k = c0; k < c0 + m; k++)
+          if (rq->blocks[todo[k]]->up_seq > seq) seq = rq->blocks[todo[k]]->up_seq;
+        if (seq && seq <= rq->up[di].nev) { ev_up[ci] = rq->up[di].ev[seq - 1u]; ev_up_borrowed[ci] = true; }
+      }
     }
     ok = ok && nrq_decode_blocks_vc(c, K, Kp, (uint32_t)T, n, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv, status,
                                     NULL, C, ev_done, ev_up) == 0;
@@ -1368,13 +1555,14 @@ static void *repair_all_worker(void *arg) {
     for (unsigned i = 0; i < ntmp; i++) nrq_dev_free(c, tmp_rep[i]);
     for (unsigned ci = 0; ci < nch; ci++) {
       if (ev_done) nrq_event_free(ev_done[ci]);
-      if (ev_up) nrq_event_free(ev_up[ci]);
+      if (ev_up && !(ev_up_borrowed && ev_up_borrowed[ci])) nrq_event_free(ev_up[ci]);
       if (ev_dl) nrq_event_free(ev_dl[ci]);
     }
-    free(ev_done); free(ev_up); free(ev_dl);
+    free(ev_done); free(ev_up); free(ev_dl); free(ev_up_borrowed);
     free(lost); free(nlost); free(resi); free(nuse); free(navail); free(status); free(sv); free(rv);
   }
   nrq_stream_sync(c, 2);
+  settle_uploads(rq, di); /* (whatever a deferred batch still had in flight: the blocks that waited for it are done) */
   gpu_unlock(di);
   return NULL;
 }
@@ -1396,6 +1584,7 @@ size_t nanorq_repair_all(nanorq *rq, struct ioctx *io) {
 
 size_t nanorq_decoder_flush(nanorq *rq, struct ioctx *io) {
   if (!ndev() || !io) return 0;
+  settle_all_uploads(rq);
   size_t nflushed = 0;
   for (unsigned sbn = 0; sbn < NRQ_Z_MAX; sbn++) {
     struct blockst *b = rq->blocks[sbn];

@@ -743,6 +743,14 @@ __global__ __launch_bounds__(256) void nrq_collect_kernel(const nrq_job *__restr
 
 /* Symbol ingestion on the device (nrq_scatter_symbols): symbol k of a contiguous packet buffer goes to the row its
  * tag names -- dst[k] is the row's device address (0 = drop).  One workgroup per symbol. */
+/* Control data (job records, lists of lost / received ESIs: KBs) from page-locked host memory into a device buffer by a
+ * KERNEL that reads the host memory directly: a hipMemcpyAsync of it is served by the host-to-device copy engine in the order
+ * of submission, i.e. behind every bulk upload queued before it on ANY stream -- the planner of nanorq_repair_all then
+ * started when the last packet of a deferred ingestion had landed (24 ms for 128 blocks of K=8192) instead of at once. */
+__global__ __launch_bounds__(256) void nrq_ctl_copy_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint32_t n16) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(128) void nrq_scatter_kernel(const uint8_t *__restrict__ blob, uint32_t T, const uint64_t *__restrict__ dst,
                                                           uint32_t n) {
   const uint32_t k = blockIdx.x;
@@ -948,7 +956,8 @@ struct nrq_ctx {
   std::multimap<size_t, void *> pool_free;
   std::map<void *, size_t> pool_size;
   size_t pool_cached = 0;
-  hipStream_t aux[2] = {nullptr, nullptr}; /* copy streams of the object layer: [0] host -> device, [1] device -> host */
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr}; /* streams of the object layer: [0] host -> device copies, [1] device -> host copies,
+                                                     * [2] kernels that sort uploaded packets into rows beside both */
   DevBuf scat_dev[2];
   PinBuf scat_pin[2];
   hipEvent_t scat_ev[2] = {nullptr, nullptr};
@@ -1614,6 +1623,7 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
       hipStreamCreateWithFlags(&ctx->plan_stream2, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->aux[0], hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->aux[1], hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->aux[2], hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->scat_ev[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->scat_ev[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->planned[0], hipEventDisableTiming) != hipSuccess ||
@@ -1673,6 +1683,7 @@ void nrq_ctx_destroy(nrq_ctx *ctx) {
   if (ctx->encplan_work.p) (void)hipFree(ctx->encplan_work.p);
   for (int i = 0; i < 2; i++) {
     if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
+    if (i == 0 && ctx->aux[2]) { (void)hipStreamSynchronize(ctx->aux[2]); (void)hipStreamDestroy(ctx->aux[2]); }
     if (ctx->scat_dev[i].p) (void)hipFree(ctx->scat_dev[i].p);
     if (ctx->scat_pin[i].p) (void)hipHostFree(ctx->scat_pin[i].p);
     if (ctx->scat_ev[i]) (void)hipEventDestroy(ctx->scat_ev[i]);
@@ -2159,7 +2170,13 @@ static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32
     j.arena_cap = arena_cap;
     j.mode = plan_is_segmented(ctx, p, Mcap) ? 0x100u : 0u;
   }
-  HIPCHK(ctx, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ps));
+  { /* (in_bytes is a multiple of 16; both buffers are 16-byte aligned allocations) */
+    const uint32_t n16 = (uint32_t)(in_bytes / 16u);
+    uint32_t g = (n16 + 255u) / 256u;
+    if (g > 64u) g = 64u;
+    hipLaunchKernelGGL(nrq_ctl_copy_kernel, dim3(g ? g : 1u), dim3(256), 0, ps, reinterpret_cast<uint4 *>(ds), reinterpret_cast<const uint4 *>(hs), n16);
+    HIPCHK(ctx, hipGetLastError());
+  }
   unsigned long long *pprof = nullptr;
   if (ctx->tune.prof) {
     HIPCHK(ctx, hipMalloc((void **)&pprof, 32 * 8));
@@ -2511,7 +2528,21 @@ int nrq_host_is_pinned(const void *p) {
 
 /* streams and events of the object layer's copy pipeline; stream selector: 0 = the context's stream, 1 = upload
  * stream, 2 = download stream */
-static hipStream_t sel_stream(nrq_ctx *ctx, int which) { return which == 1 ? ctx->aux[0] : which == 2 ? ctx->aux[1] : ctx->stream; }
+static hipStream_t sel_stream(nrq_ctx *ctx, int which) {
+  return which == 1 ? ctx->aux[0] : which == 2 ? ctx->aux[1] : which == 3 ? ctx->aux[2] : ctx->stream;
+}
+int nrq_ctl_copy(nrq_ctx *ctx, int stream, void *d_dst, const void *h_pinned, size_t bytes) {
+  if (!ctx || !d_dst || !h_pinned || (bytes & 15u) || (((uintptr_t)d_dst | (uintptr_t)h_pinned) & 15u)) return -1;
+  if (!bytes) return 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint32_t n16 = (uint32_t)(bytes / 16u);
+  uint32_t g = (n16 + 255u) / 256u;
+  if (g > 256u) g = 256u;
+  hipLaunchKernelGGL(nrq_ctl_copy_kernel, dim3(g), dim3(256), 0, sel_stream(ctx, stream), reinterpret_cast<uint4 *>(d_dst),
+                     reinterpret_cast<const uint4 *>(h_pinned), n16);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
 int nrq_copy_on(nrq_ctx *ctx, int stream, void *dst, const void *src, size_t bytes) {
   if (!ctx) return -1;
   if (!bytes) return 0;
@@ -2575,6 +2606,15 @@ int nrq_scatter_symbols(nrq_ctx *ctx, int stream, const void *d_blob, uint32_t n
   HIPCHK(ctx, hipMemcpyAsync(ctx->scat_dev[f].p, ctx->scat_pin[f].p, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(ctx, hipEventRecord(ctx->scat_ev[f], st));
   hipLaunchKernelGGL(nrq_scatter_kernel, dim3(n), dim3(128), 0, st, (const uint8_t *)d_blob, T, (const uint64_t *)ctx->scat_dev[f].p, n);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+int nrq_scatter_symbols_dev(nrq_ctx *ctx, int stream, const void *d_blob, uint32_t n, uint32_t T, const uint64_t *d_dst) {
+  if (!ctx || !d_blob || !d_dst || T == 0) return -1;
+  if (n == 0) return 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(nrq_scatter_kernel, dim3(n), dim3(128), 0, sel_stream(ctx, stream), (const uint8_t *)d_blob, T, d_dst, n);
   HIPCHK(ctx, hipGetLastError());
   return 0;
 }

@@ -75,6 +75,8 @@ def api():
         L.nanorq_encode_range.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, iop]
         L.nanorq_decoder_add_symbols.restype = C.c_size_t
         L.nanorq_decoder_add_symbols.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int), iop]
+        L.nanorq_decoder_add_symbols_async.restype = C.c_size_t
+        L.nanorq_decoder_add_symbols_async.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int), iop]
         L.nanorq_repair_all.restype = C.c_size_t
         L.nanorq_repair_all.argtypes = [vp, iop]
         # include/nanorq_batch.h: page-locked memory; include/nanorq_ext.h: RFC 6330 options

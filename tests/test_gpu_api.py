@@ -584,3 +584,58 @@ def test_bench_one_object_tool_on_one_gpu():
     assert r.returncode == 0, r.stderr[-1500:]
     rec = json.loads(r.stdout.strip().split("\n")[-1])
     assert rec["ok"] and rec["devices"] == 2 and rec["blocks"] == 5 and rec["value"] > 0
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_deferred_ingestion_gives_the_same_object(shuffle):
+    """nanorq_decoder_add_symbols_async: result codes and counts final on return, the bytes travel afterwards in pieces;
+    nanorq_repair_all lets every chunk of blocks wait for its last piece only.  Against the waiting call: same codes, same
+    recovered object -- packets in block order and shuffled (then every block's last piece is the last one), in TWO batches,
+    a block completed by per-symbol calls in between, one block left undecodable (flushed as received)."""
+    from capi import SYM_ADDED, pinned_array, pinned_io
+    L = api()
+    K, T, Z = 900, 1280, 40           # 46 MB of packets: the deferred path moves them in pieces of 48 MB / several batches
+    F = K * T * Z - 333
+    data = payload(F, seed=91)
+    c, s, packets = encode_object_batched(data, T, K=K, loss=0.08, overhead=3, seed=4)
+    # block 7 loses all its repair symbols: it stays incomplete
+    packets = [(t, p) for t, p in packets if not ((t >> 24) == 7 and (t & 0xffffff) >= K)]
+    if shuffle:
+        rng = np.random.default_rng(5)
+        packets = [packets[i] for i in rng.permutation(len(packets))]
+    Tsz = T
+    half = len(packets) // 2
+    outs = []
+    for mode in ("sync", "async"):
+        dq = L.nanorq_decoder_new(c, s)
+        oio, out = pinned_io(F)
+        out[:] = 0
+        addrs, codes = [], []
+        for lo, hi in ((0, half), (half, len(packets))):
+            tags = np.array([t for t, _ in packets[lo:hi]], np.uint32)
+            addr, blob = pinned_array(len(tags) * Tsz)
+            blob[:] = np.frombuffer(b"".join(p for _, p in packets[lo:hi]), np.uint8)
+            res = np.zeros(len(tags), np.int32)
+            add = L.nanorq_decoder_add_symbols_async if mode == "async" else L.nanorq_decoder_add_symbols
+            n = add(dq, C.c_void_p(addr), tags.ctypes.data_as(C.POINTER(C.c_uint32)), len(tags), res.ctypes.data_as(C.POINTER(C.c_int)), oio)
+            assert n == int((res == SYM_ADDED).sum())
+            codes.append(res.copy()); addrs.append(addr)
+            if lo == 0:   # between the batches: a per-symbol call on a device-resident block (a duplicate) and a per-block repair
+                t0, p0 = packets[0]
+                assert L.nanorq_decoder_add_symbol(dq, (C.c_uint8 * Tsz).from_buffer_copy(p0), t0, oio) in (1, 2)
+                L.nanorq_repair_block(dq, oio, 3)   # may or may not have enough symbols yet; must not disturb the batch in flight
+        done = L.nanorq_repair_all(dq, oio)
+        assert L.nanorq_decoder_flush(dq, oio) >= 0
+        outs.append((done, [x.tolist() for x in codes], out.copy(), [L.nanorq_num_missing(dq, b) for b in range(Z)]))
+        L.nanorq_free(dq)
+        oio.contents.destroy(oio)
+        for a in addrs:
+            L.nanorq_pinned_free(a)
+    assert outs[0][0] == outs[1][0] == Z - 1 and outs[0][1] == outs[1][1] and outs[0][3] == outs[1][3]
+    assert np.array_equal(outs[0][2], outs[1][2])
+    got = outs[1][2].reshape(-1)
+    per = K * T
+    for b in range(Z):
+        if b == 7:
+            continue
+        assert np.array_equal(got[b * per:min(F, (b + 1) * per)], data[b * per:min(F, (b + 1) * per)]), b

@@ -11,7 +11,10 @@ import numpy as np
 from capi import api, pinned_array, pinned_io
 
 
-def run_pinned(K, T, Z, lost, data=None, spare=2, reps=1):
+def run_pinned(K, T, Z, lost, data=None, spare=2, reps=1, async_ingest=False):
+    """async_ingest: the packets go in through nanorq_decoder_add_symbols_async (enqueue only): `add` is then the host's
+    bookkeeping alone and `repair` contains the wait for the bytes -- only receiver_gbps (= payload / (add + repair)) compares
+    with the serial form."""
     L = api()
     F = K * T * Z
     if data is None:
@@ -55,7 +58,8 @@ def run_pinned(K, T, Z, lost, data=None, spare=2, reps=1):
             tags[at + m:at + m + nrep[b]] = (b << 24) | (K + np.arange(nrep[b], dtype=np.uint32))
             at += m + nrep[b]
         t3 = time.perf_counter()
-        added = L.nanorq_decoder_add_symbols(dq, blob.ctypes.data_as(C.c_void_p), tags.ctypes.data_as(C.POINTER(C.c_uint32)), n, None, oio)
+        add = L.nanorq_decoder_add_symbols_async if async_ingest else L.nanorq_decoder_add_symbols
+        added = add(dq, blob.ctypes.data_as(C.c_void_p), tags.ctypes.data_as(C.POINTER(C.c_uint32)), n, None, oio)
         t4 = time.perf_counter()
         done = L.nanorq_repair_all(dq, oio)
         t5 = time.perf_counter()
