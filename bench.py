@@ -386,11 +386,14 @@ def main():
     ph_rep, ph_int, ph_wrk = [], [], []
     if args.check_blocks > 0:
         for _ in range(NPHASE):
-            ph_rep.append(torch.from_numpy(np.concatenate([b * nrep + rng.integers(0, int(nr_first[b]), REP_S) for b in range(NB)])).to(dev))
+            ph_rep.append(torch.from_numpy(np.concatenate([b * nrep + rng.integers(0, nrep, REP_S) for b in range(NB)])).to(dev))
             ph_int.append(torch.from_numpy(np.concatenate([b * L + rng.integers(0, L, INT_S) for b in range(NB)])).to(dev))
             ph_wrk.append(torch.from_numpy(np.concatenate([b * K + lost[b][rng.integers(0, len(lost[b]), WRK_S)].astype(np.int64)
                                                            for b in range(NB) if len(lost[b])])).to(dev))
-    wcol = (torch.arange(T, device=dev, dtype=torch.int64) % 251 + 1).view(1, T)   # column weights: the far end of T counts
+    # column weights (the far end of T counts); rows are read as 8-byte words: no widened copy of the sampled rows (with 8192
+    # blocks of K=100 that copy was 1.2 GB per step)
+    W8 = T // 8
+    wcol = (torch.arange(max(1, W8), device=dev, dtype=torch.int64) % 251 + 1).view(1, -1)
 
     # block ranges of the stream groups
     bounds = [(NB * g_) // nstreams for g_ in range(nstreams + 1)]
@@ -409,8 +412,12 @@ def main():
         int_rows_all.index_fill_(0, ph_int[ph], 0xCD)
 
     def digest_of(ph, wrows):
-        return torch.stack([(t.index_select(0, ix).to(torch.int64) * wcol).sum()
-                            for t, ix in ((rep_rows_all, ph_rep[ph]), (int_rows_all, ph_int[ph]), (wrows, ph_wrk[ph]))])
+        def dg(t, ix):
+            r = t.index_select(0, ix)
+            if T % 8 == 0:
+                return (r.view(torch.int64) * wcol).sum()     # (wraps: a checksum)
+            return r.sum(dtype=torch.int64)
+        return torch.stack([dg(t, ix) for t, ix in ((rep_rows_all, ph_rep[ph]), (int_rows_all, ph_int[ph]), (wrows, ph_wrk[ph]))])
 
     def step():
         nonlocal retries, step_no, ahead_out

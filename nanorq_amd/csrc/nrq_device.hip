@@ -103,6 +103,17 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
  * then compiled WITHOUT their byte-wise forms -- with both forms at every call site the kernels were half as large again
  * (persistent workgroups in different phases share the instruction cache), and a byte-wise path inside a mover loop makes the
  * compiler wait for all loads in flight where the paths join. */
+#ifndef NRQ_TINY_WV
+#define NRQ_TINY_WV 3   /* the single-wave variant: waves per SIMD it is built for (170 registers), */
+#endif
+#ifndef NRQ_TINY_OCC
+#define NRQ_TINY_OCC 12u /* and workgroups per compute unit it runs with.  Round 4, K=100 T=1024 x 8192 blocks: 5 / 18 (96 registers,
+                          * 151 of them spilled: every phase reloads its pointers from scratch) 370 Gbit/s, 4 / 16 ~385, 3 / 12 419,
+                          * 2 / 8 358; K=256 527 / 547 / 569 / 533 */
+#endif
+#ifndef NRQ_SMALL_WV
+#define NRQ_SMALL_WV 4   /* the 256-thread variant: workgroups per compute unit = waves per SIMD it is built for */
+#endif
 template <int WB, int NT, int WV, int G = 1, bool AL = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WV)))
 void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
@@ -878,7 +889,9 @@ struct Tuning {
                               * the device planner, asynchronously (the host planner takes 25 ms at K=27000, 95 ms at K'=56403) */
   uint32_t wide_g = 0;       /* NRQ_WIDE_G: wide strips of G = 2, 4, 8 lanes per element where two such images fit a CU */
   bool no_tiny = false;      /* NRQ_NO_TINY: no single-wave workgroups for tiny strip images */
-  uint32_t tiny_div = 12;    /* NRQ_TINY_DIV: LDS images per CU from which the single-wave variant is used */
+  uint32_t tiny_div = 12;    /* NRQ_TINY_DIV: LDS images per CU from which the single-wave variant is used (launches with ONE plan: encode) */
+  uint32_t tiny_div_dec = 6; /* NRQ_TINY_DIV_DEC: the same for launches with a plan per block (decode): every strip walks a plan of its own
+                              * through L2 / HBM, and more independent strips in flight hide more of those trips */
   bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
   bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
   int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
@@ -898,7 +911,7 @@ struct Tuning {
     encplan_dev_min_l = (uint32_t)num("NRQ_ENCPLAN_DEV_MIN_L", 12000);
     wide_g = (uint32_t)num("NRQ_WIDE_G", 0);
     if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
-    no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12);
+    no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 6);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
     plan_small_state = !flag("NRQ_PLAN_BIG_STATE");
@@ -1346,17 +1359,18 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
    * when two or more fit */
   const bool small = lds_bytes * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg;
   /* single-wave workgroups when 12 or more images fit a CU (see the kernel; K=256: +26 % over five 256-thread workgroups) */
-  const bool tiny = G == 1 && small && (uint64_t)lds_bytes * ctx->tune.tiny_div <= NRQ_LDS_MAX && !ctx->tune.no_tiny;
+  const uint32_t tdiv = hdrs.size() > 1u ? ctx->tune.tiny_div_dec : ctx->tune.tiny_div;
+  const bool tiny = G == 1 && small && (uint64_t)lds_bytes * tdiv <= NRQ_LDS_MAX && !ctx->tune.no_tiny;
   const uint32_t nt = tiny ? 64u : small ? 256u : (uint32_t)NRQ_WG;
   uint32_t occ = NRQ_LDS_MAX / (lds_bytes ? lds_bytes : 1u);
   if (occ > 2048u / nt) occ = 2048u / nt;
   /* registers: the 256-thread variant (one wave per SIMD) is compiled for NRQ_SMALL_WAVES waves per SIMD.  More
    * workgroups than are resident at once would run as a second, thinner round of a statically partitioned job. */
   const bool five = G == 1 && small && !tiny && occ >= 5u && !ctx->tune.small_waves4;
-  if (tiny) { if (occ > 18u) occ = 18u; } /* one wave per workgroup, compiled for 5 waves per SIMD; 20 per CU by the LDS sum, but
+  if (tiny) { if (occ > NRQ_TINY_OCC) occ = NRQ_TINY_OCC; } /* one wave per workgroup, compiled for 5 waves per SIMD; 20 per CU by the LDS sum, but
                                               * measured: with 20 x 256 workgroups not all are resident and the rest runs as a second
                                               * round (10.4 ms against 8.7 ms with 18 x 256 at K=100, T=1024, 8192 blocks) */
-  else if (small && occ > (five ? 5u : 4u)) occ = five ? 5u : 4u;
+  else if (small && occ > (five ? 5u : (uint32_t)NRQ_SMALL_WV)) occ = five ? 5u : (uint32_t)NRQ_SMALL_WV;
   if (occ < 1u) occ = 1u;
   /* persistent workgroups fill the device; a multiple of 8 keeps a workgroup's slots on its XCD */
   uint64_t grid = (uint64_t)(ctx->ncu / 8) * 8 * occ;
@@ -1427,9 +1441,9 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)NRQ_LDS_MAX))
     NRQ_SET_LDS_ATTR(WB, NRQ_WG, 1, 1, false); NRQ_SET_LDS_ATTR(WB, NRQ_WG, 1, 1, true);
-    NRQ_SET_LDS_ATTR(WB, 256, 4, 1, false);    NRQ_SET_LDS_ATTR(WB, 256, 4, 1, true);
+    NRQ_SET_LDS_ATTR(WB, 256, NRQ_SMALL_WV, 1, false);    NRQ_SET_LDS_ATTR(WB, 256, NRQ_SMALL_WV, 1, true);
     NRQ_SET_LDS_ATTR(WB, 256, 5, 1, false);    NRQ_SET_LDS_ATTR(WB, 256, 5, 1, true);
-    NRQ_SET_LDS_ATTR(WB, 64, 5, 1, false);     NRQ_SET_LDS_ATTR(WB, 64, 5, 1, true);
+    NRQ_SET_LDS_ATTR(WB, 64, NRQ_TINY_WV, 1, false);     NRQ_SET_LDS_ATTR(WB, 64, NRQ_TINY_WV, 1, true);
 #undef NRQ_SET_LDS_ATTR
     if constexpr (WB == 16) {
       HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<16, 256, 4, 2>),
@@ -1473,9 +1487,9 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   hipLaunchKernelGGL((nrq_solve_kernel<WB, NTT, WVV, 1, ALL>), dim3((uint32_t)grid), dim3(NTT), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips, \
                      by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf,   \
                      ybuf_stride)
-    if (tiny) { if (al) NRQ_LAUNCH(64, 5, true); else NRQ_LAUNCH(64, 5, false); }
+    if (tiny) { if (al) NRQ_LAUNCH(64, NRQ_TINY_WV, true); else NRQ_LAUNCH(64, NRQ_TINY_WV, false); }
     else if (five) { if (al) NRQ_LAUNCH(256, 5, true); else NRQ_LAUNCH(256, 5, false); }
-    else if (small) { if (al) NRQ_LAUNCH(256, 4, true); else NRQ_LAUNCH(256, 4, false); }
+    else if (small) { if (al) NRQ_LAUNCH(256, NRQ_SMALL_WV, true); else NRQ_LAUNCH(256, NRQ_SMALL_WV, false); }
     else { if (al) NRQ_LAUNCH(NRQ_WG, 1, true); else NRQ_LAUNCH(NRQ_WG, 1, false); }
 #undef NRQ_LAUNCH
     ctx->stats.movers_aligned = al ? 1u : 0u;
@@ -1535,7 +1549,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   ctx->stats.grid = (uint32_t)grid;
   ctx->stats.wg_threads = nt;
   ctx->stats.strips_per_slot = 1u << lsub;
-  ctx->stats.wg_waves_per_simd = (five || tiny) ? 5u : small ? 4u : 1u;
+  ctx->stats.wg_waves_per_simd = tiny ? (uint32_t)NRQ_TINY_WV : five ? 5u : small ? (uint32_t)NRQ_SMALL_WV : 1u;
   return 0;
 }
 
@@ -1756,6 +1770,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "no_tiny") t.no_tiny = value != 0;
   else if (n == "wide_g") t.wide_g = (value == 2 || value == 4 || value == 8) ? (uint32_t)value : 0u;
   else if (n == "tiny_div") t.tiny_div = (uint32_t)value;
+  else if (n == "tiny_div_dec") t.tiny_div_dec = (uint32_t)value;
   else if (n == "no_balance") t.no_balance = value != 0;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
   else if (n == "no_plan_split") t.no_plan_split = value != 0;
