@@ -579,6 +579,7 @@ def main():
     # ---- ONE object over the N GPUs of one process (the other placement of SURVEY 8(e)); rank 0 runs it in a process of its
     # own (the object layer reads its device list once) while the other ranks wait at the closing barrier ----
     one_object = None
+    shard.finalize(world)   # (the last collective is behind us: the other ranks leave, rank 0 may take its time)
     if rank == 0 and (args.one_object == "on" or (args.one_object == "auto" and world > 1)) and args.force_device < 0:
         for c_ in ctxs:
             c_.sync()

@@ -146,6 +146,9 @@ int nrq_decode_blocks_v(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint3
  * chunk i has been solved the event chunk_done[i] (nrq_event_new; ceil(nblk / chunk_blocks) of them) is recorded on the
  * context's stream, so that a caller can start moving the first blocks (nrq_stream_wait on a copy stream) while the later
  * ones are still being solved -- the planner's fixed cost (a launch the host waits for, ~3 ms) is paid once, not per chunk.
+ * The events are valid once the call has RETURNED (the caller enqueues its waits afterwards): with the host planner, or when
+ * blocks had to be re-planned on the host, all chunks are solved by one later launch and every event is recorded behind that;
+ * on a negative return value the events are undefined.
  * upload_done (nullable): events the solve of chunk i waits for before it reads the chunk's symbols (their upload).
  * Replaces nanorq_repair_block per block (reference lib/nanorq.c:591-631). */
 int nrq_decode_blocks_vc(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const uint64_t *d_src_v, const uint32_t *h_lost,

@@ -1394,7 +1394,13 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
     /* The bytes did not reach the device rows: take the batch's bookkeeping back, so that the decoder does not believe in
      * symbols it does not hold (they can be sent again), and say so symbol by symbol. */
     for (uint32_t k = 0; k < n; k++) {
-      if (rix[k] == RIX_NONE) continue;
+      if (rix[k] == RIX_NONE) {
+        /* a symbol reported DUP / IGN because an EARLIER symbol of this batch set its bit or completed its block: that
+         * earlier symbol is taken back below, so the decoder holds neither copy -- say so */
+        if (results && touched[(uint8_t)(tags[k] >> 24)] && (results[k] == NANORQ_SYM_DUP || results[k] == NANORQ_SYM_IGN))
+          results[k] = NANORQ_SYM_ERR;
+        continue;
+      }
       struct blockst *b = rq->blocks[(uint8_t)(tags[k] >> 24)];
       mask_clear(b, tags[k] & 0x00ffffffu);
       if (results) results[k] = NANORQ_SYM_ERR;

@@ -3,7 +3,7 @@
 # the reference's chart) through bench.py, one JSON line each into gpurun_out/cfg/ -- copy what is to be judged to profiles/.
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/bench_configs.sh [tag]'
 REPO=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=$REPO/gpurun_out/cfg
 mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
@@ -30,6 +30,7 @@ run cfg2_K1024_oh52     1024  1280 2048 0.06 52
 run cfg3_K8192_oh2      8192  1280  256 0.10 2
 run cfg5_K56403_oh16   56403  1280    8 0.20 16 1
 run K1000_T1280         1000  1280 2048 0.06 0
+run K256_T1280           256  1280 8192 0.06 0
 run K500_T1280           500  1280 4096 0.06 0
 run K5000_T1280         5000  1280  512 0.06 0
 run K10000_T1280       10000  1280  256 0.06 0

@@ -5,7 +5,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r3'
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=$REPO/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -14,6 +14,7 @@ cd /tmp
 timeout 900 python $REPO/bench.py > "$OUT/${TAG}_bench_1gpu.json" 2> "$OUT/bench_1gpu.err"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 python $REPO/tools/rocprof_summary.py stats $(find "$OUT/trace" -name '*.db' | head -1) > "$OUT/${TAG}_kernel_stats.txt"
+echo "# (averages over ALL launches of the run: 1 warm-up step + 3 timed steps, i.e. they include the cold first launch -- the max column; the steady-state durations are in ${TAG}_kernel_timeline.txt and in roofline.avg_launch_ms of ${TAG}_bench_1gpu.json)" >> "$OUT/${TAG}_kernel_stats.txt"
 python $REPO/tools/rocprof_summary.py timeline $(find "$OUT/trace" -name "*.db" | head -1) -1 > "$OUT/${TAG}_kernel_timeline.txt"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES" \
@@ -32,6 +33,9 @@ find "$OUT" -name "*.db" -delete
 rm -rf "$OUT"/trace "$OUT"/pmc? "$OUT"/tr_*/
 bash $REPO/tools/bench_configs.sh $TAG > "$OUT/${TAG}_configs_summary.txt" 2>&1
 cp $REPO/gpurun_out/cfg/${TAG}_bench_*.json "$OUT/" 2>/dev/null
+bash $REPO/tools/reference_benchmark.sh > "$OUT/${TAG}_reference_benchmark.txt" 2> "$OUT/refbench.err"
+python $REPO/tools/bench_receiver.py 8192 1280 128 0.1 > "$OUT/${TAG}_receiver_K8192.json" 2> "$OUT/recv.err"
+python $REPO/tools/bench_one_object.py --devices 0 --blocks 8 > "$OUT/${TAG}_one_object_cfg5_8blocks_1gpu.json" 2> "$OUT/oneobj.err"
 python $REPO/tools/bench_object_api.py 8192 1280 64 --json > "$OUT/${TAG}_object_api_K8192.json" 2> "$OUT/obj.err"
 python $REPO/tools/bench_object_api.py 1000 1280 64 --json > "$OUT/${TAG}_object_api_K1000.json" 2>> "$OUT/obj.err"
 ls -la "$OUT"
