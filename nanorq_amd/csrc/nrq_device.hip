@@ -452,6 +452,8 @@ enum {
   pl_tag_pl_final_a = 15,
   pl_tag_pl_final_b = 15,
   pl_tag_pl_final_c = 15,
+  pl_tag_pl_final_c2 = 15,
+  pl_tag_pl_final_c3 = 15,
   pl_tag_pl_final_d = 15,
   pl_tag_pl_final_e = 15,
   pl_tag_pl_mark_failed = 15,

@@ -135,6 +135,21 @@ static inline uint32_t pl_cas_(uint32_t *p, uint32_t c, uint32_t v) { uint32_t o
 #endif
 
 SB_HD uint32_t pl_r16(uint32_t x) { return (x + 15u) & ~15u; }
+/* for (i = tid; i < n; i += nt) store(i, load(i)) with the loads of PL_BATCH items in flight together.  Written the plain way
+ * such a loop is a chain: the compiler may not move item i+1's load above item i's store (they could alias), so every item
+ * pays its own trip to L2 / HBM -- 56 trips per thread and loop at K'=56403 (init and final phases: 6 M clocks per block). */
+#ifndef PL_BATCH
+#define PL_BATCH 8u
+#endif
+template <class LOAD, class STORE> SB_HD void pl_for_batched(uint32_t tid, uint32_t nt, uint32_t n, LOAD load, STORE store) {
+  for (uint32_t i0 = tid; i0 < n; i0 += PL_BATCH * nt) {
+    decltype(load(0u)) v[PL_BATCH];
+#pragma unroll
+    for (uint32_t j = 0; j < PL_BATCH; j++) { const uint32_t i = i0 + j * nt; v[j] = load(i < n ? i : i0); } /* (beyond the end: item i0 again, unused) */
+#pragma unroll
+    for (uint32_t j = 0; j < PL_BATCH; j++) { const uint32_t i = i0 + j * nt; if (i < n) store(i, v[j]); }
+  }
+}
 
 /* A pointer held in PlanCtx is generic as far as the compiler can tell, and every access through it a FLAT instruction:
  * slower than a DS one, and ordered (vmcnt) behind the phase's outstanding global stores.  The workgroup state
@@ -473,11 +488,8 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->gf_log[0] = 0;
   }
   const uint32_t L = p.L;
-  for (uint32_t r = tid; r < c.Mcap; r += nt) {
-    c.rowstate[r] = r < L ? c.b_state[r] : 0u;
-    c.rowinfo[r] = PL_UNASSIGNED;
-    c.patch_of[r] = 0xFFFFu;
-  }
+  pl_for_batched(tid, nt, c.Mcap, [&](uint32_t r) { return r < L ? c.b_state[r] : 0u; },
+                 [&](uint32_t r, uint32_t st) { c.rowstate[r] = st; c.rowinfo[r] = PL_UNASSIGNED; c.patch_of[r] = 0xFFFFu; });
   for (uint32_t col = tid; col < L; col += nt) {
     c.colinfo[col] = col < p.W ? 0u : ((PL_ST_INACT << 30) | (col - p.W));
     c.pc_fill[col] = 0;
@@ -559,7 +571,14 @@ template <int Z> SB_HD void pl_scan_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
 template <int Z> SB_HD void pl_scan_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t L = c.p.L, per = (L + nt - 1) / nt;
   uint32_t a = tid * per, b = a + per < L ? a + per : L, run = c.part()[tid];
-  for (uint32_t k = a; k < b; k++) { uint32_t v = c.pc_fill[k]; c.pc_ptr[k] = run; run += v; c.pc_fill[k] = 0; }
+  for (uint32_t k0 = a; k0 < b; k0 += PL_BATCH) { /* (the counts of a batch first, then the running sum over them) */
+    uint32_t v[PL_BATCH];
+#pragma unroll
+    for (uint32_t j = 0; j < PL_BATCH; j++) v[j] = c.pc_fill[k0 + j < b ? k0 + j : k0];
+#pragma unroll
+    for (uint32_t j = 0; j < PL_BATCH; j++)
+      if (k0 + j < b) { c.pc_ptr[k0 + j] = run; run += v[j]; c.pc_fill[k0 + j] = 0; }
+  }
 }
 SB_HD bool pl_peel_in_lds(const PlanCtx &c);
 /* fill the patch CSC; seed the first frontier with the rows that already have one V column */
@@ -577,15 +596,14 @@ template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) 
       c.pc_rows[c.pc_ptr[col] + pos] = (uint16_t)row;
     }
   }
-  for (uint32_t r = tid; r < sh->M; r += nt) {
-    const uint32_t cnt = c.rowstate[r] >> 24;
+  pl_for_batched(tid, nt, sh->M, [&](uint32_t r) { return c.rowstate[r] >> 24; }, [&](uint32_t r, uint32_t cnt) {
     if (cnt == 1u) {
       uint32_t j = PL_ATOM_ADD(&sh->nq[0], 1u);
       if (j < c.qcap) c.queue(0u)[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     } else if (cnt == 2u && !pl_peel_in_lds(c)) {
       c.cand[PL_ATOM_ADD(&sh->ncand[0], 1u)] = (uint16_t)r; /* (a row enters the stack once: at most M entries) */
     }
-  }
+  });
 }
 
 /* The peeling state (rowstate / rowinfo / colinfo) lives in LDS when it fits and in the block's HBM workspace
@@ -1072,10 +1090,8 @@ SB_HD uint32_t pl_op_group(const uint16_t *collev, uint32_t t, uint32_t r, uint3
 template <int Z> SB_HD void pl_lev_0(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   uint32_t m = 0;
-  for (uint32_t k = tid; k < sh->npiv; k += nt) {
-    const uint32_t lv = (c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK) + 1u;
-    if (lv > m) m = lv;
-  }
+  pl_for_batched(tid, nt, sh->npiv, [&](uint32_t k) { return (c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK) + 1u; },
+                 [&](uint32_t, uint32_t lv) { if (lv > m) m = lv; });
   m = PL_WAVE_MAX(m);
   if (m && PL_WAVE_LEADER(tid)) PL_ATOM_MAX(&sh->nlev, m);
 }
@@ -1093,7 +1109,9 @@ template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (uint32_t *l = pl_cls(c)) { /* nlev is final now */
     for (uint32_t k = tid; k < pl_lev_words(c) * (PL_CLS_BYTES / 4u); k += nt) l[k] = 0;
     uint16_t *collev = pl_col_level(c);
-    for (uint32_t k = tid; k < sh->npiv; k += nt) collev[c.pivcol[k]] = (uint16_t)(c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK);
+    struct CL { uint32_t col, lev; };
+    pl_for_batched(tid, nt, sh->npiv, [&](uint32_t k) { return CL{c.pivcol[k], c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK}; },
+                   [&](uint32_t, CL v) { collev[v.col] = (uint16_t)v.lev; });
   }
   /* W rows are accumulated with XORs: start from zero */
   for (uint32_t e = tid; e < sh->M * sh->wpr; e += nt) c.wrows[e] = 0;
@@ -2204,19 +2222,18 @@ template <int Z> SB_HD void pl_final_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->tmp0 = (sh->npiv + 63u) & ~63u; /* npiv_pad */
   }
   /* homes of the inactive columns: the rows that did not become pivots, any one-to-one assignment */
-  for (uint32_t r = tid; r < sh->M; r += nt) {
-    if (!(c.rowinfo[r] & PL_UNASSIGNED)) continue;
+  pl_for_batched(tid, nt, sh->M, [&](uint32_t r) { return c.rowinfo[r]; }, [&](uint32_t r, uint32_t info) {
+    if (!(info & PL_UNASSIGNED)) return;
     uint32_t x = PL_ATOM_ADD(&sh->uslot_fill, 1u);
     if (x < u) { c.uslot[x] = (uint16_t)r; c.colslot[c.ucol[x]] = (uint16_t)r; }
-  }
+  });
 }
 template <int Z> SB_HD void pl_final_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
-  for (uint32_t k = tid; k < sh->npiv; k += nt) {
-    c.colslot[c.pivcol[k]] = c.pivslot[k];
-    c.pivof[c.pivcol[k]] = c.pivslot[k];
-  }
+  struct CS { uint32_t col, slot; };
+  pl_for_batched(tid, nt, sh->npiv, [&](uint32_t k) { return CS{c.pivcol[k], c.pivslot[k]}; },
+                 [&](uint32_t, CS v) { c.colslot[v.col] = (uint16_t)v.slot; c.pivof[v.col] = (uint16_t)v.slot; });
   if (tid == 0) {
     const rq_params &p = c.p;
     const uint32_t nl = c.job.nlost;
@@ -2228,6 +2245,7 @@ template <int Z> SB_HD void pl_final_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
     c.part()[4] = o; o = pl_r16(o + nl * PL_PATCH_STRIDE * 2u + NRQ_STORE_SLACK);  /* out_slots (+ what ph_store reads past a list) */
     sh->arena_top = o;
     if (o > c.job.arena_cap) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    sh->tmp1 = 0; /* (sum of the level groups' op counts: pl_final_c) */
     (void)p;
   }
 }
@@ -2243,13 +2261,12 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
       wt[e] = k < sh->npiv ? c.wrows[(size_t)c.pivslot[k] * wpr + w] : 0u;
     }
   uint32_t *rowsrc = reinterpret_cast<uint32_t *>(c.arena + c.part()[1]);
-  for (uint32_t r = tid; r < sh->M; r += nt) {
+  pl_for_batched(tid, nt, sh->M, [&](uint32_t r) { return (uint32_t)c.patch_of[r]; }, [&](uint32_t r, uint32_t pi) {
     uint32_t v = NRQ_ROW_ZERO;
-    const uint32_t pi = c.patch_of[r];
     if (pi != 0xFFFFu) v = NRQ_ROW_REP | pi;
     else if (r >= p.S + p.H && r < p.S + p.H + p.K) v = r - p.S - p.H;
     rowsrc[r] = v;
-  }
+  });
   /* the missing source symbols as LT combinations of slots (ISI of a source symbol = its ESI) */
   uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + c.part()[2]);
   uint32_t *orow = reinterpret_cast<uint32_t *>(c.arena + c.part()[3]);
@@ -2258,13 +2275,39 @@ template <int Z> SB_HD void pl_final_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
    * running sum in pl_final_d -- one thread -- does not walk an array in HBM */
   uint16_t *degq = c.queue(0u);
   const bool in_lds = nl <= 2u * c.qcap;
-  for (uint32_t g = tid; g < nl; g += nt) {
-    const uint32_t e = c.lost[g];
-    const uint32_t dg = c.b_rptr[p.S + p.H + e + 1] - c.b_rptr[p.S + p.H + e];
-    if (in_lds) degq[g] = (uint16_t)dg; else c.pivdeg[g] = dg;
-    orow[g] = e;
-  }
+  struct ED { uint32_t e, dg; };
+  pl_for_batched(tid, nt, nl, [&](uint32_t g) { const uint32_t e = c.lost[g]; return ED{e, c.b_rptr[p.S + p.H + e + 1] - c.b_rptr[p.S + p.H + e]}; },
+                 [&](uint32_t g, ED v) { if (in_lds) degq[g] = (uint16_t)v.dg; else c.pivdeg[g] = v.dg; orow[g] = v.e; });
   (void)cptr; (void)osl;
+  /* ops of the stream, summed by everybody (one thread walking nlev + 2 words of HBM: a trip each, 1.5 M clocks at K'=56403) */
+  uint32_t ops = 0;
+  pl_for_batched(tid, nt, sh->nlev + 2u, [&](uint32_t l) { return c.lev_ops[l]; }, [&](uint32_t, uint32_t v) { ops += v; });
+  if (ops) PL_ATOM_ADD(&sh->tmp1, ops);
+}
+/* many missing symbols (more than the frontier queues hold lengths of): the list offsets by a three-step scan over pivdeg[]
+ * instead of a running sum by one thread */
+template <int Z> SB_HD void pl_final_c2(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint32_t nl = c.job.nlost;
+  if (sh->status || nl <= 2u * c.qcap) return;
+  const uint32_t per = (nl + nt - 1u) / nt, a = tid * per < nl ? tid * per : nl, b = a + per < nl ? a + per : nl;
+  uint32_t sum = 0;
+  for (uint32_t g0 = a; g0 < b; g0 += PL_BATCH) {
+    uint32_t v[PL_BATCH];
+#pragma unroll
+    for (uint32_t j = 0; j < PL_BATCH; j++) v[j] = c.pivdeg[g0 + j < b ? g0 + j : g0];
+#pragma unroll
+    for (uint32_t j = 0; j < PL_BATCH; j++) if (g0 + j < b) sum += v[j];
+  }
+  reinterpret_cast<uint32_t *>(c.queue(0u))[tid] = sum; /* (the frontier queues are free by now; part()[0..4] hold the arena offsets) */
+}
+template <int Z> SB_HD void pl_final_c3(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (sh->status || c.job.nlost <= 2u * c.qcap || tid != 0) return;
+  uint32_t *ps = reinterpret_cast<uint32_t *>(c.queue(0u));
+  uint32_t run = 0;
+  for (uint32_t t = 0; t < nt; t++) { const uint32_t v = ps[t]; ps[t] = run; run += v; }
+  ps[nt] = run; /* the sum of all list lengths */
 }
 template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
@@ -2274,6 +2317,19 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
      * stores in between) -- a running sum by one thread is a chain of LDS round trips, one per entry */
     uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + c.part()[2]);
     for (uint32_t g = tid; g <= c.job.nlost; g += nt) cptr[g] = pl_deg_prefix(c, g);
+  } else if (!sh->status) { /* (pl_final_c2 / c3 left every thread's starting offset in the queues) */
+    const uint32_t nl = c.job.nlost, per = (nl + nt - 1u) / nt, a = tid * per < nl ? tid * per : nl, b = a + per < nl ? a + per : nl;
+    const uint32_t *ps = reinterpret_cast<const uint32_t *>(c.queue(0u));
+    uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + c.part()[2]);
+    uint32_t run = ps[tid];
+    for (uint32_t g0 = a; g0 < b; g0 += PL_BATCH) {
+      uint32_t v[PL_BATCH];
+#pragma unroll
+      for (uint32_t j = 0; j < PL_BATCH; j++) v[j] = c.pivdeg[g0 + j < b ? g0 + j : g0];
+#pragma unroll
+      for (uint32_t j = 0; j < PL_BATCH; j++) if (g0 + j < b) { cptr[g0 + j] = run; run += v[j]; }
+    }
+    if (tid == 0) cptr[nl] = ps[nt];
   }
   if (tid != 0) return;
   nrq_plan_hdr h;
@@ -2297,12 +2353,9 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
     uint32_t *cptr = reinterpret_cast<uint32_t *>(c.arena + c.part()[2]);
     uint32_t run = 0;
     if (nl <= 2u * c.qcap) run = pl_deg_prefix(c, nl);
-    else {
-      for (uint32_t g = 0; g < nl; g++) { cptr[g] = run; run += c.pivdeg[g]; }
-      cptr[nl] = run;
-    }
-    h.n_xor_ops = c.lev_ops[sh->nlev + 1u] + run + sh->spare_fill;
-    for (uint32_t l = 0; l <= sh->nlev; l++) h.n_xor_ops += c.lev_ops[l];
+    else run = reinterpret_cast<const uint32_t *>(c.queue(0u))[nt];
+    (void)cptr;
+    h.n_xor_ops = sh->tmp1 + run + sh->spare_fill; /* (tmp1: the level groups' ops, summed in pl_final_c) */
   }
   *c.hdr = h;
   if (c.jobout) {

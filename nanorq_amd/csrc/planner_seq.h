@@ -184,6 +184,8 @@
     PL_PHASE(pl_final_a);
     PL_PHASE(pl_final_b);
     PL_PHASE(pl_final_c);
+    PL_PHASE(pl_final_c2);
+    PL_PHASE(pl_final_c3);
     } /* PL_SEG != 1 */
   } else if (st2_ == 0 && PL_SEG != 1) {
     PL_PHASE(pl_mark_failed); /* peeling did not terminate: report the block as undecodable */

@@ -192,7 +192,8 @@ def test_lds_budget_of_headline_config(orc):
 @pytest.mark.parametrize("K,T,wb,p,oh,lds", [(10, 16, 16, 0.3, 0, 140), (10, 16, 16, 0.3, 4, 140), (100, 32, 16, 0.06, 0, 140),
                                              (100, 8, 8, 0.4, 25, 140), (1024, 16, 16, 0.05, 0, 140),
                                              (1024, 16, 16, 0.06, 52, 24), (8192, 16, 16, 0.1, 0, 140),
-                                             (8192, 16, 16, 0.1, 2, 60)])
+                                             (8192, 16, 16, 0.1, 2, 60),
+                                             (8192, 16, 16, 0.55, 3, 60)])   # > 4096 missing symbols: the list offsets by the scan phases
 def test_device_planner_emulated_matches_oracle(orc, K, T, wb, p, oh, lds):
     """The GPU planner's phase code (planner_body.h), emulated, then the emulated solve: decoded data must be
     the oracle's; `lds` (KiB) small enough forces the peeling state out of LDS into the HBM workspace.  Every case
