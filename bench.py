@@ -306,6 +306,37 @@ def binding_model(c, avg_ms, ncu):
     return out
 
 
+def e2e_leg(args):
+    """host buffers -> host buffers (PCIe both ways) through the object API's page-locked path, in a process of its own and
+    BEFORE this process touches the GPU: one object of up to 128 of the step's blocks through include/nanorq_batch.h --
+    nanorq_generate_symbols_all, nanorq_encode_range_all, nanorq_decoder_add_symbols(_async), nanorq_repair_all; same loss
+    patterns as the timed region.  (In this process, or beside it once it holds a GPU context, the object layer's six streams
+    share hardware queues / the GPU's process scheduling with the bench context's and torch's: the receiver pipeline's
+    upload, sorting and download streams then took turns -- repair 44-46 ms against 31 ms alone.)"""
+    K, T, Z = args.K, args.T, min(args.blocks, 128)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_receiver.py"), str(K), str(T), str(Z), str(args.loss), "--legs"]
+    env1 = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env1.pop(k, None)
+    r = subprocess.run(cmd, env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, "end-to-end leg failed: %s" % r.stderr.decode()[-400:]
+    rec = json.loads(r.stdout.decode().strip().split("\n")[-1])
+    legs, legs_p = rec["serial"], rec["pipeline"]
+    assert legs["ok"] and legs_p["ok"], "end-to-end leg: the decoded object differs from the source"
+    return {"value": legs["value"], "unit": "Gbit/s", "blocks": Z, "ms_total": legs["total_ms"],
+            "generate_gbps": legs["generate_gbps"], "ingest_gbps": legs["add_gbps"], "repair_gbps": legs["repair_gbps"],
+            "repair_symbols_ms": legs["repair_symbols_ms"], "received_symbols": legs["received_symbols"],
+            "sender_gbps": legs["sender_gbps"], "receiver_gbps": legs_p["receiver_gbps"], "receiver_gbps_serial": legs["receiver_gbps"],
+            "receiver_pipeline_ms": {"add": 8e-6 * Z * K * T / legs_p["add_gbps"], "repair": 8e-6 * Z * K * T / legs_p["repair_gbps"]},
+            "what": "object API on page-locked memory (nanorq_batch.h): value = payload / (generate + repair symbols to host + "
+                    "ingest + repair) with the four legs one after the other on ONE GPU; sender_gbps = payload / (generate + "
+                    "repair symbols), receiver_gbps = payload / (ingest + repair) are the two stations of a transfer -- receiver_gbps "
+                    "with the packets enqueued by nanorq_decoder_add_symbols_async (ingest, plan, solve and the way back overlap), "
+                    "receiver_gbps_serial and the per-leg rates with the waiting call; run in a process of its own before the timed "
+                    "region.  Each leg crosses PCIe once: the per-leg rates stand against ~440 Gbit/s of link per direction.  Never "
+                    "`value` of the bench line."}
+
+
 def main():
     args = parse()
     import torch
@@ -316,6 +347,7 @@ def main():
     rank, world, local = shard.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    e2e = e2e_leg(args) if (rank == 0 and world == 1 and not args.no_e2e and args.streams <= 1) else None
     if args.force_device >= 0:
         local = args.force_device
     torch.cuda.set_device(local)
@@ -542,39 +574,6 @@ def main():
         with open(args.digest_out, "w") as f:
             json.dump({str(gb): hashlib.sha256(rep[b, :int(nr_first[b])].cpu().numpy().tobytes()).hexdigest()
                        for b, gb in enumerate(my_blocks)}, f)
-
-    # ---- host buffers -> host buffers (PCIe both ways), rank 0 / 1 GPU only: the object API's page-locked path ----
-    e2e = None
-    if rank == 0 and world == 1 and not args.no_e2e and nstreams == 1:
-        # One object of up to 128 of the step's blocks through include/nanorq_batch.h: nanorq_generate_symbols_all (object ->
-        # GPU -> intermediate symbols), nanorq_encode_range (repair symbols -> host), nanorq_decoder_add_symbols (received
-        # packets -> GPU rows), nanorq_repair_all (decode -> recovered object in host memory); upload, solve and download are
-        # overlapped inside the library (three streams).  Same loss patterns as the timed region.
-        for c_ in ctxs:
-            c_.sync()
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from object_api_legs import run_pinned
-        Z = min(NB, 128)
-        h_obj = src[:Z].cpu().numpy().reshape(-1)
-        torch.cuda.empty_cache()
-        run_pinned(K, T, min(Z, 16), lost, data=h_obj[:min(Z, 16) * K * T])   # warm-up: library context, plan cache, pools
-        legs = run_pinned(K, T, Z, lost, data=h_obj, reps=2)
-        assert legs["ok"], "end-to-end leg: the decoded object differs from the source"
-        # the receiver as a pipeline: the packets only ENQUEUED (nanorq_decoder_add_symbols_async), nanorq_repair_all plans at
-        # once and solves every chunk of blocks when the upload piece that completes it has landed
-        legs_p = run_pinned(K, T, Z, lost, data=h_obj, reps=2, async_ingest=True)
-        assert legs_p["ok"], "end-to-end leg (deferred ingestion): the decoded object differs from the source"
-        e2e = {"value": legs["value"], "unit": "Gbit/s", "blocks": Z, "ms_total": legs["total_ms"],
-               "generate_gbps": legs["generate_gbps"], "ingest_gbps": legs["add_gbps"], "repair_gbps": legs["repair_gbps"],
-               "repair_symbols_ms": legs["repair_symbols_ms"], "received_symbols": legs["received_symbols"],
-               "sender_gbps": legs["sender_gbps"], "receiver_gbps": legs_p["receiver_gbps"], "receiver_gbps_serial": legs["receiver_gbps"],
-               "receiver_pipeline_ms": {"add": 8e-6 * Z * K * T / legs_p["add_gbps"], "repair": 8e-6 * Z * K * T / legs_p["repair_gbps"]},
-               "what": "object API on page-locked memory (nanorq_batch.h): value = payload / (generate + repair symbols to host + "
-                       "ingest + repair) with the four legs one after the other on ONE GPU; sender_gbps = payload / (generate + "
-                       "repair symbols), receiver_gbps = payload / (ingest + repair) are the two stations of a transfer.  Each "
-                       "leg crosses PCIe once: the per-leg rates stand against ~440 Gbit/s of link per direction.  Never `value` "
-                       "of the bench line."}
-        del h_obj
 
     # ---- ONE object over the N GPUs of one process (the other placement of SURVEY 8(e)); rank 0 runs it in a process of its
     # own (the object layer reads its device list once) while the other ranks wait at the closing barrier ----

@@ -11,7 +11,7 @@ import numpy as np
 from capi import api, pinned_array, pinned_io
 
 
-def run_pinned(K, T, Z, lost, data=None, spare=2, reps=1, async_ingest=False):
+def run_pinned(K, T, Z, lost, data=None, spare=2, reps=1, async_ingest=False, key="value"):
     """async_ingest: the packets go in through nanorq_decoder_add_symbols_async (enqueue only): `add` is then the host's
     bookkeeping alone and `repair` contains the wait for the bytes -- only receiver_gbps (= payload / (add + repair)) compares
     with the serial form."""
@@ -72,6 +72,6 @@ def run_pinned(K, T, Z, lost, data=None, spare=2, reps=1, async_ingest=False):
                 "repair_gbps": gbit / (t5 - t4), "total_ms": ((t2 - t0) + (t5 - t3)) * 1e3,
                 "value": gbit / ((t2 - t0) + (t5 - t3)), "sender_gbps": gbit / (t2 - t0), "receiver_gbps": gbit / (t5 - t3),
                 "ok": bool(ok), "received_symbols": int(n)}
-        if best is None or legs["value"] > best["value"]:
+        if best is None or legs[key] > best[key]:
             best = legs
     return best
