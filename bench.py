@@ -392,7 +392,11 @@ def main():
     # rows (block * K + esi) the channel destroyed: overwritten again at the start of EVERY step
     lost_rows = torch.from_numpy(np.concatenate([b * K + lost[b].astype(np.int64) for b in range(NB)])).to(dev)
     work_rows = work.view(NB * K, T)
-    damage = work_rows   # the WHOLE lost row is destroyed: a decode that skips any column strip leaves 0xEE behind
+    # the WHOLE lost row is destroyed (a decode that skips any column strip leaves 0xEE behind) -- written as 8-byte words:
+    # torch's index_fill moves one element per thread, and byte elements made it 0.34 ms per step for 268 MB
+    damage, damage_value = work_rows, 0xEE
+    if T % 8 == 0:
+        damage, damage_value = work.view(torch.int64).view(NB * K, T // 8), -0x1111111111111112   # = 0xEEEEEEEEEEEEEEEE
     lost_arr = np.zeros((NB, max_lost + 1), np.uint32)
     for b in range(NB):
         lost_arr[b, :len(lost[b])] = lost[b]
@@ -457,7 +461,7 @@ def main():
         ph = step_no % NPHASE
         step_no += 1
         # the channel: the receiver's copy loses its rows again, over their full width (part of the step)
-        damage.index_fill_(0, lost_rows, 0xEE)
+        damage.index_fill_(0, lost_rows, damage_value)
         if ph_rep:
             poison(ph)
         for (lo, hi), c_ in zip(groups, ctxs):
