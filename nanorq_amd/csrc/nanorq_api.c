@@ -1241,6 +1241,46 @@ static void *add_all_worker(void *arg) {
   const uint32_t dpiece = (uint32_t)((UP_PIECE_BYTES / T) ? (UP_PIECE_BYTES / T) : 1);
   const bool deferred = j->deferred && nold == 0 && any && u->nblob + 2u <= NRQ_UP_BLOB && u->npin < NRQ_UP_BLOB &&
                         u->nev + (k_hi - k_lo + dpiece - 1u) / dpiece <= NRQ_UP_EV;
+  /* Several devices: a device takes up ITS packets only.  Runs of consecutive packets of its blocks (a transfer whose packets
+   * arrive block after block has one per block) are copied one by one into a compact staging buffer; with the whole stretch
+   * uploaded by every device the host-to-device traffic was N times the batch.  Packets interleaved finer than that (more
+   * than 4096 runs) keep the whole-stretch form. */
+  if (any && ok && g_ndev > 1) {
+    uint32_t nmine = 0, nruns = 0;
+    for (uint32_t k = k_lo; k < k_hi; k++)
+      if (dst[k]) { nmine++; if (k == k_lo || !dst[k - 1u]) nruns++; }
+    if (nmine < k_hi - k_lo && nruns <= 4096u) {
+      const uint32_t cap0 = (uint32_t)((CHUNK_BYTES / T) ? (CHUNK_BYTES / T) : 1), cap = nmine < cap0 ? nmine : cap0;
+      uint64_t *cdst = malloc((size_t)cap * sizeof(uint64_t));
+      void *d_blob = NULL;
+      ok = cdst && nrq_dev_alloc(c, (size_t)cap * T, &d_blob) == 0;
+      uint32_t fill = 0;
+      for (uint32_t k = k_lo; k < k_hi && ok;) {
+        if (!dst[k]) { k++; continue; }
+        uint32_t k1 = k;
+        while (k1 < k_hi && dst[k1]) k1++;
+        while (k < k1 && ok) {
+          const uint32_t take = k1 - k < cap - fill ? k1 - k : cap - fill;
+          ok = nrq_copy_on(c, 1, (uint8_t *)d_blob + (size_t)fill * T, j->pk + (size_t)k * T, (size_t)take * T) == 0;
+          memcpy(cdst + fill, dst + k, (size_t)take * sizeof(uint64_t));
+          fill += take;
+          k += take;
+          if (fill == cap && ok) { ok = nrq_scatter_symbols(c, 1, d_blob, fill, (uint32_t)T, cdst) == 0; fill = 0; }
+        }
+      }
+      if (fill && ok) ok = nrq_scatter_symbols(c, 1, d_blob, fill, (uint32_t)T, cdst) == 0;
+      ok = nrq_stream_sync(c, 1) == 0 && ok;
+      if (d_blob) nrq_dev_free(c, d_blob);
+      free(cdst);
+      if (j->deferred) settle_uploads(rq, di);
+      any = false; /* done */
+      for (unsigned i = 0; i < nold; i++) nrq_dev_free(c, olds[i]);
+      gpu_unlock(di);
+      free(dst);
+      j->ok = ok;
+      return NULL;
+    }
+  }
   if (any && ok) {
     /* packets up in pieces, each sorted into its rows as soon as it has landed (same stream: the order is the stream's) */
     void *d_blob = NULL;
