@@ -27,12 +27,12 @@ def run_pinned(K, T, Z, lost, data=None, spare=2, reps=1, async_ingest=False, ke
         io, mem = pinned_io(F)
         mem[:] = data
         L.nanorq_precalculate(rq)
+        nrep = [len(lost[b]) + spare for b in range(Z)]
+        nmax = max(nrep)
+        raddr, rbuf = pinned_array(Z * nmax * T)       # (page-locked target of the repair symbols: allocated outside the timed legs)
         t0 = time.perf_counter()
         assert L.nanorq_generate_symbols_all(rq, io) == Z
         t1 = time.perf_counter()
-        nrep = [len(lost[b]) + spare for b in range(Z)]
-        nmax = max(nrep)
-        raddr, rbuf = pinned_array(Z * nmax * T)       # the repair symbols of all blocks in one call, into page-locked memory
         assert L.nanorq_encode_range_all(rq, C.c_void_p(raddr), K, nmax, io) == Z * nmax * T
         rep = [rbuf.reshape(Z, nmax, T)[b, :nrep[b]] for b in range(Z)]
         t2 = time.perf_counter()
