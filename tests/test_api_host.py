@@ -233,3 +233,29 @@ def test_rfc_options_host_logic():
         assert bytes(buf) == want, esi
     L.nanorq_free(rq)
     io.contents.destroy(io)
+
+
+def test_batched_add_calls_without_a_gpu_are_the_per_symbol_call():
+    """nanorq_decoder_add_symbols and its enqueue-only form (nanorq_decoder_add_symbols_async) on ordinary memory -- and on any
+    machine without a GPU -- are nanorq_decoder_add_symbol in a loop: same result codes, source symbols written through,
+    a block without missing symbols complete (reference lib/nanorq.c:478-509, :605-606)."""
+    L = api()
+    K, T = 30, 16
+    src = np.arange(K * T, dtype=np.uint8)
+    enc = L.nanorq_encoder_new_ex(K * T, T, K, 0, 8)
+    oti = (L.nanorq_oti_common(enc), L.nanorq_oti_scheme_specific(enc))
+    tags = np.array([L.nanorq_tag(0, e) for e in list(range(K)) + [3, K + 2]], np.uint32)     # all source symbols, a duplicate, a late repair symbol
+    blob = np.concatenate([src, src[3 * T:4 * T], np.zeros(T, np.uint8)])
+    for name in ("nanorq_decoder_add_symbols", "nanorq_decoder_add_symbols_async"):
+        dq = L.nanorq_decoder_new(*oti)
+        out = np.zeros(K * T, np.uint8)
+        io = mem_io(out)
+        res = np.full(len(tags), 99, np.int32)
+        n = getattr(L, name)(dq, blob.ctypes.data_as(C.c_void_p), tags.ctypes.data_as(C.POINTER(C.c_uint32)), len(tags),
+                             res.ctypes.data_as(C.POINTER(C.c_int)), io)
+        assert n == K and list(res[:K]) == [SYM_ADDED] * K and list(res[K:]) == [1, 1], (name, list(res))   # complete block: IGN, IGN
+        assert np.array_equal(out, src) and L.nanorq_num_missing(dq, 0) == 0
+        assert L.nanorq_repair_block(dq, io, 0)            # nothing missing: true without a solve
+        L.nanorq_free(dq)
+        io.contents.destroy(io)
+    L.nanorq_free(enc)
