@@ -406,6 +406,7 @@ enum {
   pl_tag_pl_lev_b = 7,
   pl_tag_pl_w_init = 8,
   pl_tag_pl_w_init_b = 8,
+  pl_tag_pl_cls_fetch = 8,
   pl_tag_pl_w_group = 8,
   pl_tag_pl_w_stage = 8,
   pl_tag_pl_wfast_spill = 4,
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
   PlanCtx c;
   pl_ctx_setup(c, p, kc, pjobs[b], sh, dyn, lds_dyn_bytes, Mcap, npcap, ucap, jobs_out + b, qcap, lowcap, (uint32_t)NT);
   if (!PK) c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
+  if (seg == 3u) c.cls_glob = reinterpret_cast<uint32_t *>(c.work + c.wl.cls_g); /* (pl_lev_b zeroes the counters nrq_wentry_kernel counts into) */
   /* NRQ_PROF=1: thread 0 of block 0 accumulates shader clocks per phase family (index = PL_TAG) */
   unsigned long long t_prev = prof ? (unsigned long long)clock64() : 0ull;
 #define PL_ACC(tag) do { if (prof && b == 0 && tid == 0) { unsigned long long t_ = (unsigned long long)clock64(); \
@@ -506,9 +508,10 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
 #define PL_SEG seg
 #define PL_STEER_SYNC __syncthreads()
 #define PL_NT_ ((uint32_t)NT)
-  if (seg == 2u) PL_PHASE(pl_sh_restore);
+  if (seg == 2u || seg == 4u) PL_PHASE(pl_sh_restore);
 #include "planner_seq.h"
-  if (seg == 1u) { PL_PHASE(pl_mh_ext_clear); PL_PHASE(pl_sh_save); }
+  if (seg == 1u || seg == 4u) PL_PHASE(pl_mh_ext_clear);
+  if (seg == 1u || seg == 3u || seg == 4u) PL_PHASE(pl_sh_save);
 #undef PL_SEG
 #undef PL_STEER_SYNC
 #undef PL_NT_
@@ -517,6 +520,29 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
 #undef PL_PHASE1_CLAIM
 #undef PL_WFAST_RUN
 #undef PL_ACC
+}
+
+/* Between parts 3 and 4 of a segmented planner run: the entry pass over the constraint matrix (pl_w_init: every entry either
+ * toggles a bit of its row's W row or becomes a row op, counted in its level group and lane class and recorded) by `nparts`
+ * workgroups per block.  One workgroup is bound by its CU's rate of scattered accesses there -- three per entry, 571 k entries at
+ * K'=56403: 4.7 M clocks, a fifth of the plan.  Counters and the record counter are the workspace's for the duration. */
+__global__ __launch_bounds__(1024) void nrq_wentry_kernel(rq_params p, const uint8_t *__restrict__ kc, const nrq_planjob *__restrict__ pjobs,
+                                                          uint32_t Mcap, uint32_t npcap, uint32_t ucap, uint32_t lds_dyn_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t part = blockIdx.x, nparts = gridDim.x, b = blockIdx.y, tid = threadIdx.x;
+  pl_shared *sh = reinterpret_cast<pl_shared *>(smem);
+  PlanCtx c;
+  /* (lds_dyn_bytes: what the planner workgroup has -- pl_cls_place / pl_col_level decide by it; nothing of it is touched here) */
+  pl_ctx_setup(c, p, kc, pjobs[b], sh, nullptr, 0u, Mcap, npcap, ucap, nullptr, PL_QCAP, PL_LOWCAP, PL_NT);
+  c.aux_lds = reinterpret_cast<uint8_t *>(smem); c.aux_bytes = lds_dyn_bytes; c.dense_lds = c.aux_lds; c.dense_bytes = lds_dyn_bytes; /* (as the planner sees them: only their sizes matter) */
+  pl_sh_restore<0>(c, tid, 1024u);
+  __syncthreads();
+  if (sh->status != 0 || sh->nV != 0) return;
+  c.cls_glob = reinterpret_cast<uint32_t *>(c.work + c.wl.cls_g);
+  c.nrec_ptr = &c.wentry[0];
+  pl_w_init_part<0>(c, part, nparts, tid, 1024u);
+  __syncthreads();
+  pl_wentry_report<0>(c, tid, 1024u);
 }
 
 /* Between the two parts of a segmented planner run (planner_seq.h): the HDPC fold over the pivots,
@@ -890,6 +916,7 @@ struct Tuning {
   uint32_t encplan_dev_min_l = 12000; /* NRQ_ENCPLAN_DEV_MIN_L: from this many intermediate symbols on, encode plans are built by
                               * the device planner, asynchronously (the host planner takes 25 ms at K=27000, 95 ms at K'=56403) */
   uint32_t wide_g = 0;       /* NRQ_WIDE_G: wide strips of G = 2, 4, 8 lanes per element where two such images fit a CU */
+  bool no_wentry = false;    /* NRQ_NO_WENTRY: big blocks' entry pass by the planner workgroup itself, not by nrq_wentry_kernel */
   bool no_tiny = false;      /* NRQ_NO_TINY: no single-wave workgroups for tiny strip images */
   uint32_t tiny_div = 12;    /* NRQ_TINY_DIV: LDS images per CU from which the single-wave variant is used (launches with ONE plan: encode) */
   uint32_t tiny_div_dec = 6; /* NRQ_TINY_DIV_DEC: the same for launches with a plan per block (decode): every strip walks a plan of its own
@@ -913,7 +940,7 @@ struct Tuning {
     encplan_dev_min_l = (uint32_t)num("NRQ_ENCPLAN_DEV_MIN_L", 12000);
     wide_g = (uint32_t)num("NRQ_WIDE_G", 0);
     if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
-    no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 6);
+    no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 6);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
     plan_small_state = !flag("NRQ_PLAN_BIG_STATE");
@@ -1126,7 +1153,12 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
   }
   const uint32_t mh_dyn = 72u * 1024u; /* nrq_mh_kernel: MhT (16 B x u <= 20 KB) + the tiles (4 KB + 256 x wpr words <= 40 KB) */
   { int rc_ = plan_attr_once(ctx); if (rc_) return rc_; }
-  for (uint32_t part = seg ? 1u : 0u; part <= (seg ? 2u : 0u); part++) {
+  /* parts of the run: everything | 3, (entry pass), 4, (W pass, HDPC fold), 2 */
+  const bool wentry = seg && !ctx->tune.no_wentry;
+  const uint32_t parts_seg[3] = {wentry ? 3u : 1u, wentry ? 4u : 2u, 2u};
+  const uint32_t nparts_run = !seg ? 1u : wentry ? 3u : 2u;
+  for (uint32_t pi = 0; pi < nparts_run; pi++) {
+    const uint32_t part = seg ? parts_seg[pi] : 0u;
     if (small_wg)
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
                          nblk, Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
@@ -1137,7 +1169,14 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT>, dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
                          Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
     HIPCHK(ctx, hipGetLastError());
-    if (part == 1u) {
+    if (part == 3u) {
+      uint32_t nw = 64u / (nblk ? nblk : 1u); /* workgroups per block: what a batch of few big blocks finds free beside the solves */
+      if (nw < 2u) nw = 2u;
+      if (nw > 8u) nw = 8u;
+      hipLaunchKernelGGL(nrq_wentry_kernel, dim3(nw, nblk), dim3(1024), sh_bytes, ps, p, d_kc, d_pj, Mcap, npcap, ucap, dyn_bytes);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    if (part == 1u || part == 4u) {
       const uint32_t wp_lds = (Mcap + NRQ_SCRATCH) * 2u + 64u;
       hipLaunchKernelGGL(nrq_wpass_kernel, dim3(((ucap + 31u) / 32u) * 2u, nblk), dim3(256), wp_lds, ps, p, d_kc, d_pj, Mcap, npcap, ucap);
       HIPCHK(ctx, hipGetLastError());
@@ -1248,7 +1287,7 @@ int encplan_device_launch(nrq_ctx *ctx, const rq_params &p, uint32_t K, KConst *
   pj->work = (uint64_t)(uintptr_t)ctx->encplan_work.p;
   pj->arena = (uint64_t)(uintptr_t)ep.devbuf[buf];
   pj->arena_cap = arena_cap;
-  pj->mode = 1u | (plan_is_segmented(ctx, p, Mcap) ? 0x100u : 0u);
+  pj->mode = 1u | (plan_is_segmented(ctx, p, Mcap) ? (ctx->tune.no_wentry ? 0x100u : 0x300u) : 0u);
   HIPCHK(ctx, hipMemcpyAsync(ep.devbuf[buf] + off_pj, pj, sizeof(*pj), hipMemcpyHostToDevice, ps));
   rq_params pk = p;
   pk.K = K;
@@ -1770,6 +1809,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   if (n == "max_wb") t.max_wb = (uint32_t)value;
   else if (n == "no_split") t.no_split = value != 0;
   else if (n == "no_tiny") t.no_tiny = value != 0;
+  else if (n == "no_wentry") t.no_wentry = value != 0;
   else if (n == "wide_g") t.wide_g = (value == 2 || value == 4 || value == 8) ? (uint32_t)value : 0u;
   else if (n == "tiny_div") t.tiny_div = (uint32_t)value;
   else if (n == "tiny_div_dec") t.tiny_div_dec = (uint32_t)value;
@@ -2185,7 +2225,7 @@ static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32
     j.nrep_avail = j.nrep;
     if (sane && h_avail && h_avail[b] > j.nrep) j.nrep_avail = h_avail[b] < rep_cap ? h_avail[b] : rep_cap;
     j.arena_cap = arena_cap;
-    j.mode = plan_is_segmented(ctx, p, Mcap) ? 0x100u : 0u;
+    j.mode = plan_is_segmented(ctx, p, Mcap) ? (ctx->tune.no_wentry ? 0x100u : 0x300u) : 0u; /* bit 8: segmented run, bit 9: entry pass by nrq_wentry_kernel */
   }
   { /* (in_bytes is a multiple of 16; both buffers are 16-byte aligned allocations) */
     const uint32_t n16 = (uint32_t)(in_bytes / 16u);

@@ -205,7 +205,7 @@ SB_HD bool pl_bin_in_stream(uint32_t L) { return L < NRQ_AUG_MATRIX_MIN_L; } /* 
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
   uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, ucol, wrows,
-      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, sh_save, mh_ext, total;
+      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, sh_save, mh_ext, cls_g, wentry, total;
 } pl_work_layout;
 
 /* nnzcap: entries of the base structure plus the patch rows (bounds the number of row ops) */
@@ -239,6 +239,8 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.cand = o;       o = pl_r16(o + Mcap * 2u); /* stack of open rows with exactly two V columns (pl_inact_find) */
   w.sh_save = o;    o = pl_r16(o + pl_shared_bytes(PL_QCAP, PL_LOWCAP, PL_NT)); /* pl_shared (with its arrays) between the parts of a segmented run (planner_seq.h) */
   w.mh_ext = o;     o = pl_r16(o + ucap * PL_MAXH);               /* MhT as nrq_mh_kernel leaves it (16 bytes per inactive column) */
+  w.cls_g = o;      o = pl_r16(o + (L + 2u) * 32u);               /* the class counters (PL_CLS_BYTES per level group) while nrq_wentry_kernel's workgroups count into them */
+  w.wentry = o;     o = pl_r16(o + 16u);                           /* ... and their record counter / failure report */
   w.total = o;
   return w;
 }
@@ -295,6 +297,12 @@ struct PlanCtx {
    * left V" (a bit each): 79 KB at K'=56403.  The HBM arrays are kept up to date by stores and atomics nobody waits for
    * (later phases read them); a round then waits for three trips to memory instead of six (pl_round_claim_k). */
   uint32_t *pk_cnt, *pk_un, *pk_pa, *pk_vb;
+  /* the entry pass on many workgroups (nrq_wentry_kernel, big blocks; job.mode bit 9): the column levels stay in HBM whatever the
+   * LDS would hold, and while the helper's workgroups count, the class counters and the record counter are the workspace's */
+  bool collev_hbm;
+  uint32_t *cls_glob;  /* non-null: pl_cls() is this array in HBM */
+  uint32_t *nrec_ptr;  /* the record counter: &sh->nrec, or the workspace's */
+  uint32_t *wentry;    /* workspace: [0] records, [1] status, [2] fail site */
   uint16_t *patch_of, *patch_cols, *pc_rows, *ucol;
   uint8_t *patch_len;
   uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *lev_fin, *red_row,
@@ -370,6 +378,10 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
       c.dense_bytes = lds_dyn_bytes - need;
       c.aux_bytes = pl_r16(Mcap * 4u); /* the rowstate image, dead once peeling is over */
     }
+    c.collev_hbm = (job.mode & 0x200u) != 0u;
+    c.cls_glob = nullptr;
+    c.nrec_ptr = &sh->nrec;
+    c.wentry = reinterpret_cast<uint32_t *>(w + c.wl.wentry);
     c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
     const uint32_t pk_cnt_b = pl_r16(Mcap + 4u), pk_row_b = pl_r16((Mcap + 31u) / 32u * 4u), pk_col_b = pl_r16((c.p.L + 31u) / 32u * 4u);
 #ifndef PL_NO_COMPACT
@@ -1027,12 +1039,14 @@ template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t t
  * per row, not per op, and lanes handed out in counter order. */
 SB_HD uint32_t pl_lev_words(const PlanCtx &c) { return c.sh->nlev + 2u; }
 #define PL_CLS_BYTES (2u * NRQ_LANE_CLASSES * 2u) /* per group: [part 0 = finishing, 1 = early][class] x u16 */
+static_assert(PL_CLS_BYTES == 32u, "pl_work_plan sizes the workspace copy of the class counters with 32 bytes per group");
 /* Where the class counters go: the dense stage's region when the peeling state has its own place in LDS (that region is
  * idle until the HDPC fold), else the aux region -- behind the column levels if those fit there too.  Big blocks (peeling
  * state in the workspace, L * 2 bytes of levels beyond the LDS) keep the column levels in HBM: in the stack of open rows,
  * dead once peeling is over -- a trip to L2 per entry, with PL_WU entries in flight, instead of the row walks and
  * same-address global atomics of the path without counters. */
 SB_HD bool pl_collev_in_lds(const PlanCtx &c) {
+  if (c.collev_hbm) return false;
   const uint32_t bytes = pl_r16(pl_lev_words(c) * PL_CLS_BYTES), lv = pl_r16(c.p.L * 2u);
   if (!c.aux_lds || lv > c.aux_bytes) return false;
   if (c.dense_lds != c.aux_lds && bytes <= c.dense_bytes) return true; /* (the counters are elsewhere) */
@@ -1052,6 +1066,7 @@ SB_HD uint16_t *pl_col_level(const PlanCtx &c) {
 }
 /* the class counters (nullptr: the HBM counters are in use) */
 SB_HD uint32_t *pl_cls(const PlanCtx &c) {
+  if (c.cls_glob) return pl_cls_place(c) ? c.cls_glob : nullptr;
   uint32_t *q = reinterpret_cast<uint32_t *>(pl_cls_place(c));
   if (!q) return nullptr;
   PL_ASSUME_LDS(q);
@@ -1108,6 +1123,7 @@ template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (uint32_t *l = pl_cls(c)) { /* nlev is final now */
     for (uint32_t k = tid; k < pl_lev_words(c) * (PL_CLS_BYTES / 4u); k += nt) l[k] = 0;
+    if (c.cls_glob && tid < 4u) c.wentry[tid] = 0u;
     uint16_t *collev = pl_col_level(c);
     struct CL { uint32_t col, lev; };
     pl_for_batched(tid, nt, sh->npiv, [&](uint32_t k) { return CL{c.pivcol[k], c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK}; },
@@ -1162,7 +1178,7 @@ SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cls, const uint16_t *collev, const
     const bool inact = on[j] && (info[j] >> 30) == PL_ST_INACT;
     const bool op = on[j] && !inact && src[j] != r[j]; /* (== : the row's own pivot column) */
     if (inact) PL_ATOM_XOR(&c.wrows[(size_t)r[j] * c.sh->wpr + (idx >> 5)], 1u << (idx & 31u));
-    const uint32_t i = PL_WAVE_TAKE(&c.sh->nrec, op); /* (by the whole wave: see there) */
+    const uint32_t i = PL_WAVE_TAKE(c.nrec_ptr, op); /* (by the whole wave: see there) */
     if (!op) continue;
     const uint32_t lev = (rinfo[j] & PL_UNASSIGNED) ? c.sh->nlev : (rinfo[j] & PL_LEVEL_MASK);
     const uint32_t g = pl_op_group(collev, lev, r[j], col[j]);
@@ -1175,7 +1191,10 @@ SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cls, const uint16_t *collev, const
     c.rec_g[i] = (uint16_t)g;
   }
 }
-template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
+/* `part` of `nparts`: the entries (collev path) are dealt out over nparts workgroups -- nrq_wentry_kernel; one workgroup: 0 of 1 */
+template <int Z> SB_HD void pl_w_init_part(PlanCtx &c, uint32_t part, uint32_t nparts, uint32_t tid, uint32_t nt);
+template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) { pl_w_init_part<Z>(c, 0u, 1u, tid, nt); }
+template <int Z> SB_HD void pl_w_init_part(PlanCtx &c, uint32_t part, uint32_t nparts, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   const uint32_t grp = tid >> 3, w8 = tid & 7u, ngrp = nt >> 3, wpr = sh->wpr, S = c.p.S;
@@ -1186,24 +1205,25 @@ template <int Z> SB_HD void pl_w_init(PlanCtx &c, uint32_t tid, uint32_t nt) {
     /* with the group counters in LDS every entry stands for itself: one pass over the entries of the base structure
      * (rows this block patched excepted) and of the patch rows -- coalesced, no walk from row to row */
     const uint32_t nnz = c.kh->nnz, nl = c.job.nlost, npq = sh->npatch * PL_PATCH_STRIDE;
-    for (uint32_t e0 = tid; e0 < nnz; e0 += PL_WU * nt) {
+    const uint32_t vt = part * nt + tid, vnt = nparts * nt; /* thread and thread count over all parts */
+    for (uint32_t e0 = vt; e0 < nnz; e0 += PL_WU * vnt) {
       uint32_t r[PL_WU], col[PL_WU];
       bool use[PL_WU];
 #pragma unroll
       for (uint32_t j = 0; j < PL_WU; j++) {
-        const uint32_t e = e0 + j * nt;
+        const uint32_t e = e0 + j * vnt;
         use[j] = e < nnz;
         r[j] = use[j] ? c.b_erow[e] : 0u;
         col[j] = use[j] ? c.b_cidx[e] : 0u;
       }
       pl_w_entries(c, cls, collev, r, col, use, true);
     }
-    for (uint32_t q0 = tid; q0 < npq; q0 += PL_WU * nt) {
+    for (uint32_t q0 = vt; q0 < npq; q0 += PL_WU * vnt) {
       uint32_t r[PL_WU], col[PL_WU];
       bool use[PL_WU];
 #pragma unroll
       for (uint32_t j = 0; j < PL_WU; j++) {
-        const uint32_t q = q0 + j * nt, i = q / PL_PATCH_STRIDE, k = q - i * PL_PATCH_STRIDE;
+        const uint32_t q = q0 + j * vnt, i = q / PL_PATCH_STRIDE, k = q - i * PL_PATCH_STRIDE;
         use[j] = q < npq && k < c.patch_len[i];
         r[j] = !use[j] ? 0u : i < nl ? c.p.S + c.p.H + c.lost[i] : c.p.L + (i - nl);
         col[j] = use[j] ? c.patch_cols[q] : 0u;
@@ -1738,6 +1758,22 @@ template <int Z> SB_HD void pl_sh_save(PlanCtx &c, uint32_t tid, uint32_t nt) {
   uint32_t *dst = reinterpret_cast<uint32_t *>(c.work + c.wl.sh_save);
   const uint32_t *src = reinterpret_cast<const uint32_t *>(c.sh);
   for (uint32_t k = tid; k < c.sh_bytes / 4u; k += nt) dst[k] = src[k];
+}
+/* after nrq_wentry_kernel: its counters into this workgroup's LDS, its record count and verdict into pl_shared */
+template <int Z> SB_HD void pl_cls_fetch(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint32_t *g = reinterpret_cast<const uint32_t *>(c.work + c.wl.cls_g);
+  if (uint32_t *l = pl_cls(c)) /* (cls_glob is off in this part: the LDS place) */
+    for (uint32_t k = tid; k < pl_lev_words(c) * (PL_CLS_BYTES / 4u); k += nt) l[k] = g[k];
+  if (tid == 0) {
+    sh->nrec = c.wentry[0];
+    if (c.wentry[1] && !sh->status) { sh->status = c.wentry[1]; sh->fail_site = c.wentry[2]; }
+  }
+}
+/* a helper workgroup's capacity failure, for the planner workgroup to find */
+template <int Z> SB_HD void pl_wentry_report(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  (void)nt;
+  if (tid == 0 && c.sh->status) { c.wentry[2] = c.sh->fail_site; c.wentry[1] = c.sh->status; }
 }
 template <int Z> SB_HD void pl_sh_restore(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t *src = reinterpret_cast<const uint32_t *>(c.work + c.wl.sh_save);

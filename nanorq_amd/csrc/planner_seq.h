@@ -6,7 +6,9 @@
  *     PL_WFAST_RUN(wb)    run the op-stream rows [0, pl_wfast_rows(c)) on the wb-byte slot image at the start of
  *                         the dynamic LDS region (one wave), then barrier
  *     PL_SEG              which part to run: 0 = everything (small and medium blocks, the emulator);
- *                         1 = up to the op stream, 2 = from the leftover rows' coefficients on.  Big blocks (peeling state
+ *                         1 = up to the op stream, 2 = from the leftover rows' coefficients on; 3 + 4 = part 1 cut once more, in
+ *                         front of the entry pass over the constraint matrix (pl_w_init), which nrq_wentry_kernel then runs on
+ *                         several workgroups: 3 | nrq_wentry_kernel | 4 | nrq_wpass_kernel | nrq_mh_kernel | 2 | nrq_wt_kernel.  Big blocks (peeling state
  *                         in HBM) run as 1 | nrq_wpass_kernel | nrq_mh_kernel | 2 | nrq_wt_kernel: the W pass (the op stream
  *                         on 2-byte strips of the bit rows, a workgroup per strip), the HDPC fold over the pivots and the
  *                         transposition of W are parallel work and take 40 % of a one-workgroup planner at K'=56403, so many
@@ -23,7 +25,7 @@
  */
 {
   pl_shared *sh_ = c.sh;
-  if (PL_SEG != 2) {
+  if (PL_SEG != 2 && PL_SEG != 4) {
   PL_PHASE(pl_init_a);
   PL_PHASE(pl_init_b);
   PL_PHASE(pl_scan_a);
@@ -78,12 +80,13 @@
     PL_PHASE(pl_low_a);
     PL_PHASE(pl_low_b);
   }
-  } /* PL_SEG != 2 */
+  } /* PL_SEG != 2, 4 */
   const uint32_t st2_ = sh_->status, nv2_ = sh_->nV;
   PL_STEER_SYNC;
   if (st2_ == 0 && nv2_ == 0) {
-    if (PL_SEG != 2) {
-    PL_PHASE(pl_w_init);
+    if (PL_SEG != 2 && PL_SEG != 3) {
+    if (PL_SEG == 4) PL_PHASE(pl_cls_fetch); /* (nrq_wentry_kernel ran the entry pass) */
+    else PL_PHASE(pl_w_init);
     PL_PHASE(pl_w_init_b);
     PL_PHASE(pl_ops_layout_a);
     PL_PHASE(pl_ops_layout);
@@ -114,8 +117,8 @@
         for (uint32_t lv_ = 1; lv_ <= sh_->nlev; lv_++) PL_PHASE1(pl_w_group, lv_);
       }
     }
-    } /* PL_SEG != 2 */
-    if (PL_SEG != 1) {
+    } /* PL_SEG != 2, 3 */
+    if (PL_SEG != 1 && PL_SEG != 3 && PL_SEG != 4) {
     if (PL_SEG == 0) {
       PL_PHASE(pl_mh_init);
       for (uint32_t tl_ = 0; tl_ * PL_MH_TILE < sh_->npiv; tl_++) {
@@ -187,10 +190,10 @@
     PL_PHASE(pl_final_c2);
     PL_PHASE(pl_final_c3);
     } /* PL_SEG != 1 */
-  } else if (st2_ == 0 && PL_SEG != 1) {
+  } else if (st2_ == 0 && PL_SEG != 1 && PL_SEG != 3 && PL_SEG != 4) {
     PL_PHASE(pl_mark_failed); /* peeling did not terminate: report the block as undecodable */
   }
-  if (PL_SEG != 1) {
+  if (PL_SEG != 1 && PL_SEG != 3 && PL_SEG != 4) {
     PL_PHASE(pl_final_d);
     PL_PHASE(pl_final_e);
   }

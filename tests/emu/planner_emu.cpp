@@ -66,7 +66,8 @@ static uint32_t g_qcap = PL_QCAP, g_lowcap = PL_LOWCAP; /* capacities of the arr
 extern "C" void emu_plan_set_caps(uint32_t qcap, uint32_t lowcap) { g_qcap = qcap ? qcap : PL_QCAP; g_lowcap = lowcap ? lowcap : PL_LOWCAP; }
 static uint32_t g_split = 0; /* run the phase sequence in its two parts (what big blocks do on the GPU) */
 static uint32_t g_nopk = 0;  /* keep the peeling state in the workspace alone (no compact copy in LDS) when it does not fit the LDS */
-extern "C" void emu_plan_set_mode(uint32_t mode) { g_mode = mode & 0xFFu; g_split = (mode >> 8) & 1u; g_nopk = (mode >> 9) & 1u; }
+static uint32_t g_went = 0;  /* with g_split: part 1 cut once more, the entry pass by two "workgroups" in between (nrq_wentry_kernel) */
+extern "C" void emu_plan_set_mode(uint32_t mode) { g_mode = mode & 0xFFu; g_split = (mode >> 8) & 1u; g_nopk = (mode >> 9) & 1u; g_went = (mode >> 10) & 1u; }
 extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const uint32_t *lost, uint32_t nlost,
                         const uint32_t *rep_esi, uint32_t nrep, uint32_t nrep_avail, uint8_t *arena,
                         uint32_t arena_cap, uint32_t lds_dyn_bytes, nrq_job *job_out) {
@@ -89,7 +90,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
   job.work = (uint64_t)(uintptr_t)work.data();
   job.arena = (uint64_t)(uintptr_t)arena;
   job.nlost = nlost; job.nrep = nrep; job.arena_cap = arena_cap; job.nrep_avail = nrep_avail;
-  job.mode = g_mode | (g_split << 8);
+  job.mode = g_mode | (g_split << 8) | ((g_split && g_went) ? 0x200u : 0u);
   PlanCtx c;
   pl_ctx_setup(c, p, kc, job, sh, lds_dyn_bytes ? dyn.data() : nullptr, lds_dyn_bytes, Mcap, npcap, ucap, job_out, g_qcap, g_lowcap, PL_NT);
   if (g_nopk) c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
@@ -100,8 +101,24 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
 #define PL_SEG g_seg
 #define PL_STEER_SYNC do { } while (0)
 #define PL_NT_ PL_NT
-  for (uint32_t pass_ = 0; pass_ < (g_split ? 2u : 1u); pass_++) {
-    const uint32_t g_seg = g_split ? pass_ + 1u : 0u;
+  const uint32_t segs_[3] = {(g_split && g_went) ? 3u : 1u, (g_split && g_went) ? 4u : 2u, 2u};
+  for (uint32_t pass_ = 0; pass_ < (!g_split ? 1u : g_went ? 3u : 2u); pass_++) {
+    const uint32_t g_seg = g_split ? segs_[pass_] : 0u;
+    c.cls_glob = g_seg == 3u ? reinterpret_cast<uint32_t *>(c.work + c.wl.cls_g) : nullptr;
+    if (g_seg == 4u) { /* nrq_wentry_kernel: the entry pass dealt out over two workgroups, counters in the workspace */
+      PL_PHASE(pl_sh_restore);
+      if (sh->status == 0 && sh->nV == 0) {
+        c.cls_glob = reinterpret_cast<uint32_t *>(c.work + c.wl.cls_g);
+        c.nrec_ptr = &c.wentry[0];
+        for (uint32_t part = 0; part < 2u; part++)
+          for (uint32_t t_ = 0; t_ < PL_NT; t_++) pl_w_init_part<1>(c, part, 2u, t_, PL_NT);
+        PL_PHASE(pl_wentry_report);
+        c.cls_glob = nullptr;
+        c.nrec_ptr = &sh->nrec;
+      }
+      memset(sh, 0xEE, shb);
+      PL_PHASE(pl_sh_restore);
+    }
     if (g_seg == 2u) { /* what the helper kernels do between the parts */
       PL_PHASE(pl_sh_restore);
       if (sh->status == 0 && sh->nV == 0) {
@@ -115,7 +132,8 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
       }
     }
 #include "../../nanorq_amd/csrc/planner_seq.h"
-    if (g_seg == 1u) { PL_PHASE(pl_mh_ext_clear); PL_PHASE(pl_sh_save); memset(sh, 0xEE, shb); }
+    if (g_seg == 1u || g_seg == 4u) PL_PHASE(pl_mh_ext_clear);
+    if (g_seg == 1u || g_seg == 3u || g_seg == 4u) { PL_PHASE(pl_sh_save); memset(sh, 0xEE, shb); }
   }
 #undef PL_SEG
 #undef PL_STEER_SYNC

@@ -103,7 +103,7 @@ def pemu():
 
 
 def emu_device_plan(K, kconst, lost, rep_esis, lds_bytes=140 * 1024, Kp=0, use=None, encode=False, split=False, caps=None,
-                    compact=True):
+                    compact=True, wentry=False):
     """Run the GPU planner's phase code on the CPU. Returns (plan arena bytes, header).  `use` = number of repair
     symbols to use up front (default all); the rest may be taken one at a time if the system is rank deficient."""
     L_ = pemu()
@@ -117,7 +117,8 @@ def emu_device_plan(K, kconst, lost, rep_esis, lds_bytes=140 * 1024, Kp=0, use=N
     L_.emu_plan_set_caps(*(caps or (0, 0)))  # capacities of the arrays behind pl_shared (0 = the big-block ones)
     # encode plan: a job without missing symbols; split: the phase sequence in its two parts; compact=False: a peeling state
     # that does not fit the LDS lives in the workspace ALONE (no compact copy of counts and flags in LDS)
-    L_.emu_plan_set_mode((1 if encode else 0) | (0x100 if split else 0) | (0 if compact else 0x200))
+    # wentry (with split): part 1 cut once more, the entry pass over the matrix by two "workgroups" in between (nrq_wentry_kernel)
+    L_.emu_plan_set_mode((1 if encode else 0) | (0x100 if split else 0) | (0 if compact else 0x200) | (0x400 if wentry else 0))
     try:
         rc = L_.emu_plan(K, Kp, C.addressof(kcb), lost.ctypes.data_as(C.POINTER(C.c_uint32)), len(lost),
                          rep_esis.ctypes.data_as(C.POINTER(C.c_uint32)), use, len(rep_esis), arena.ctypes.data, cap, lds_bytes,

@@ -233,6 +233,15 @@ def test_device_planner_emulated_matches_oracle(orc, K, T, wb, p, oh, lds):
         lists = lt_lists(orc, K, lost, plan)
         r, inter = emu_solve(plan, kc, rowsrc, work, rep, T, prm["L"], lists, lost, work, wb)
         assert r == 1 and np.array_equal(work, src)
+        # the segmented run with the entry pass over the matrix dealt out over two "workgroups" (nrq_wentry_kernel: counters in
+        # the workspace, column levels in HBM): ops land in other lanes of their groups, so the plan differs byte for byte --
+        # it must solve the block all the same
+        plan5, hdr5 = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=lds * 1024, split=True, wentry=True)
+        assert hdr5["status"] == 0 and [hdr5[k] for k in ("npiv", "u", "nlev", "n_xor_ops")] == [hdr[k] for k in ("npiv", "u", "nlev", "n_xor_ops")]
+        work5 = src.copy()
+        work5[lost] = 0x55
+        r5, _ = emu_solve(plan5, kc, rowsrc, work5, rep, T, prm["L"], lt_lists(orc, K, lost, plan5), lost, work5, wb)
+        assert r5 == 1 and np.array_equal(work5, src)
         done += 1
     assert done >= 1
 
