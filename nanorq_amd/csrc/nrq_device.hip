@@ -387,12 +387,21 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
 }
 
 enum {
+#ifdef NRQ_PROF_INIT /* diagnostic build: the init phases one by one, in the slots big blocks leave empty (Wrun, Wmove, mh) */
+  pl_tag_pl_init_a = 0,
+  pl_tag_pl_init_b = 2,
+  pl_tag_pl_scan_a = 4,
+  pl_tag_pl_scan_b = 4,
+  pl_tag_pl_scan_c = 4,
+  pl_tag_pl_pcsc_fill = 11,
+#else
   pl_tag_pl_init_a = 0,
   pl_tag_pl_init_b = 0,
   pl_tag_pl_scan_a = 0,
   pl_tag_pl_scan_b = 0,
   pl_tag_pl_scan_c = 0,
   pl_tag_pl_pcsc_fill = 0,
+#endif
   pl_tag_pl_round_claim = 1,
   pl_tag_pl_round_drop = 3,
   pl_tag_pl_inact_find = 5,
