@@ -602,18 +602,31 @@ template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) 
   for (uint32_t i = tid; i < sh->npatch; i += nt) {
     uint32_t row = i < nl ? p.S + p.H + c.lost[i] : p.L + (i - nl);
     const uint16_t *cols = c.patch_cols + (size_t)i * PL_PATCH_STRIDE;
-    for (uint32_t k = 0; k < c.patch_len[i]; k++) {
-      uint32_t col = cols[k];
-      uint32_t pos = PL_ATOM_ADD(&c.pc_fill[col], 1u);
-      c.pc_rows[c.pc_ptr[col] + pos] = (uint16_t)row;
+    const uint32_t n = c.patch_len[i];
+    for (uint32_t k0 = 0; k0 < n; k0 += PL_BATCH) { /* (a batch's places asked for together: entry by entry each was a trip of its own) */
+      uint32_t col[PL_BATCH], base[PL_BATCH], pos[PL_BATCH];
+#pragma unroll
+      for (uint32_t j = 0; j < PL_BATCH; j++) col[j] = cols[k0 + j < n ? k0 + j : k0];
+#pragma unroll
+      for (uint32_t j = 0; j < PL_BATCH; j++) base[j] = c.pc_ptr[col[j]];
+#pragma unroll
+      for (uint32_t j = 0; j < PL_BATCH; j++) pos[j] = k0 + j < n ? PL_ATOM_ADD(&c.pc_fill[col[j]], 1u) : 0u;
+#pragma unroll
+      for (uint32_t j = 0; j < PL_BATCH; j++)
+        if (k0 + j < n) c.pc_rows[base[j] + pos[j]] = (uint16_t)row;
     }
   }
+  const bool stack2 = !pl_peel_in_lds(c);
   pl_for_batched(tid, nt, sh->M, [&](uint32_t r) { return c.rowstate[r] >> 24; }, [&](uint32_t r, uint32_t cnt) {
+    /* (half of all rows start with two V columns: their places on the stack are taken a wave at a time -- 28 k single
+     * increments of ONE LDS word were 0.8 M clocks at K'=56403) */
+    const bool two = cnt == 2u && stack2;
+    const uint32_t at = PL_WAVE_TAKE(&sh->ncand[0], two);
     if (cnt == 1u) {
       uint32_t j = PL_ATOM_ADD(&sh->nq[0], 1u);
       if (j < c.qcap) c.queue(0u)[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
-    } else if (cnt == 2u && !pl_peel_in_lds(c)) {
-      c.cand[PL_ATOM_ADD(&sh->ncand[0], 1u)] = (uint16_t)r; /* (a row enters the stack once: at most M entries) */
+    } else if (two) {
+      c.cand[at] = (uint16_t)r; /* (a row enters the stack once: at most M entries) */
     }
   });
 }
