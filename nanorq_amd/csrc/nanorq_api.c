@@ -97,6 +97,8 @@ struct nanorq {
   uint32_t max_esi;
   uint32_t flags;          /* NANORQ_EXT_* */
   bool precalc;
+  pthread_mutex_t io_lock; /* an ioctx has one cursor: the device threads of a batched call on THIS object take turns at it
+                            * (was process-wide: unrelated objects' output waited for each other) */
   struct blockst *blocks[NRQ_Z_MAX];
   /* deferred ingestion (nanorq_decoder_add_symbols_async), per device: the events behind the upload pieces still in
    * flight (a piece = copy of a stretch of the packet buffer + the kernel that sorts it into rows, on the upload stream)
@@ -121,7 +123,6 @@ struct devctx {
 static struct devctx g_dev[NRQ_MAX_DEV];
 static int g_ndev;
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
-static pthread_mutex_t g_io_lock = PTHREAD_MUTEX_INITIALIZER; /* an ioctx has one cursor: the device threads of a batched call take turns */
 
 static void ctx_init(void) {
   int devs[NRQ_MAX_DEV], n = 0;
@@ -354,6 +355,7 @@ nanorq *nanorq_encoder_new_ext(size_t len, uint16_t T16, uint16_t K, uint16_t Z1
   if ((flags & NANORQ_EXT_RFC_OTI) && (Z > 255 || T > 0xffff)) return NULL;
   nanorq *rq = calloc(1, sizeof(nanorq));
   if (!rq) return NULL;
+  pthread_mutex_init(&rq->io_lock, NULL);
   rq->F = len; rq->T = T; rq->Al = Al; rq->Z = Z; rq->N = N; rq->Kt = Kt; rq->flags = flags;
   rq->src_part = partition(Kt, Z);
   rq->sub_part = partition(T / Al, rq->N);
@@ -386,6 +388,7 @@ nanorq *nanorq_decoder_new_ext(uint64_t common, uint32_t specific, uint32_t flag
   if (ceil_div(Kt, Z) > NRQ_K_MAX) return NULL;
   nanorq *rq = calloc(1, sizeof(nanorq));
   if (!rq) return NULL;
+  pthread_mutex_init(&rq->io_lock, NULL);
   rq->F = F; rq->T = T; rq->Al = Al; rq->Z = Z; rq->N = N; rq->Kt = Kt; rq->flags = flags;
   rq->src_part = partition(Kt, Z);
   rq->sub_part = partition(T / Al, N);
@@ -504,6 +507,7 @@ void nanorq_free(nanorq *rq) { /* nanorq.c:298-307 */
   if (!rq) return;
   settle_all_uploads(rq);
   for (unsigned sbn = 0; sbn < NRQ_Z_MAX; sbn++) nanorq_encoder_cleanup(rq, (uint8_t)sbn);
+  pthread_mutex_destroy(&rq->io_lock);
   free(rq);
 }
 
@@ -804,10 +808,10 @@ static bool flush_dev_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct i
   const bool dma = ioctx_dma_region(io, &base, &rlen) && block_extent(rq, sbn, b->K, &off, &len) && off + len <= rlen;
   if (!dma) {
     if (!ensure_src(rq, b) || nrq_copy_on(c, 2, b->src, b->d_src, (size_t)b->K * T) != 0 || nrq_stream_sync(c, 2) != 0) return false;
-    pthread_mutex_lock(&g_io_lock);
+    pthread_mutex_lock(&rq->io_lock);
     for (uint32_t e = 0; e < b->K; e++)
       if (all || mask_get(b, e)) transfer_symbol(rq, sbn, e, b->K, b->src + (size_t)e * T, io, 1);
-    pthread_mutex_unlock(&g_io_lock);
+    pthread_mutex_unlock(&rq->io_lock);
     return true;
   }
   if (all) return nrq_copy_on(c, 2, base + off, b->d_src, len) == 0;
@@ -1583,7 +1587,7 @@ static void *repair_all_worker(void *arg) {
     for (unsigned c0 = 0, ci = 0; c0 < n && ok && any_host; c0 += C, ci++) {
       const unsigned m = n - c0 < C ? n - c0 : C;
       ok = nrq_event_sync(c, ev_dl[ci]) == 0;
-      pthread_mutex_lock(&g_io_lock);
+      pthread_mutex_lock(&rq->io_lock);
       for (unsigned k = c0; k < c0 + m && ok; k++) {
         struct blockst *b = rq->blocks[todo[k]];
         if (!status[k] || b->dev) continue;
@@ -1593,7 +1597,7 @@ static void *repair_all_worker(void *arg) {
           mask_set(b, e);
         }
       }
-      pthread_mutex_unlock(&g_io_lock);
+      pthread_mutex_unlock(&rq->io_lock);
     }
     nrq_ctx_sync(c);
     nrq_stream_sync(c, 1);
