@@ -30,7 +30,9 @@
 #include "rq_math.h"
 #include "solve_body.h"
 
+#ifndef PL_NT
 #define PL_NT 1024u     /* threads of a planner workgroup: big blocks */
+#endif
 #define PL_NT_MIN 256u  /* small blocks (several workgroups per CU) */
 #define PL_QCAP 2048u          /* frontier / claim queue capacity */
 #define PL_UNASSIGNED 0x80000000u /* rowinfo bit 31: row has no pivot column (yet) */
