@@ -124,8 +124,8 @@ int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, ui
  * arrays): the symbolic stage (reference precode_matrix_invert's planning half, lib/precode.c:347-377) needs the reception
  * pattern only, not the symbols, so it can run on the planner stream while earlier batches are still being solved.  The
  * decode call with identical arguments then only waits for it (nrq_call_stats::plan_ahead = 1).  Up to two runs may be waiting
- * (-6 beyond that); they are consumed in the order they were issued, and a decode call the oldest one was not issued for
- * discards them all.  Two runs issued back to back execute side by side (two planner streams, two workspaces, three sets of
+ * (-6 beyond that); they are consumed in the order they were issued: a decode call discards the runs in front of the one
+ * issued for it (and all of them if none was).  Two runs issued back to back execute side by side (two planner streams, two workspaces, three sets of
  * plan arenas): a planner workgroup is latency bound on one compute unit, so a pipeline that keeps two batches' plans in
  * flight gets them at twice the rate.  Not for the per-block-address variants (_v, _vc). */
 int nrq_decode_plan_ahead(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, void *d_src, size_t src_stride,

@@ -2312,15 +2312,20 @@ static int decode_device(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
   ctx->stats.planner = 1;
   PlanRun local, *run = &local;
   bool ahead = false;
-  if (!ctx->ahead.empty()) {
-    if (plan_run_matches(ctx, *ctx->ahead.front(), K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap,
-                         d_rep, rep_stride, d_inter, inter_stride, h_avail)) {
-      run = ctx->ahead.front(); /* the planner run of this very call is already on its way (or done) */
-      ctx->ahead.pop_front();
+  while (!ctx->ahead.empty()) {
+    PlanRun *f = ctx->ahead.front();
+    ctx->ahead.pop_front();
+    if (plan_run_matches(ctx, *f, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap, d_rep, rep_stride,
+                         d_inter, inter_stride, h_avail)) {
+      run = f; /* the planner run of this very call is already on its way (or done) */
       ahead = true;
-    } else {
-      plan_ahead_drop(ctx); /* (runs are consumed in the order they were issued: a call they were not issued for ends them all) */
+      break;
     }
+    /* runs are consumed in the order they were issued: one this call was not issued for is over (its arena set is free again
+     * once it has run); a later one may still be this call's (a caller that issued a run per reception state) */
+    (void)hipEventSynchronize(ctx->planned[f->ab]);
+    delete f;
+    if (ctx->ahead.empty()) ctx->ahead_hint = 0;
   }
   struct Owner { PlanRun *r; ~Owner() { delete r; } } owner{ahead ? run : nullptr};
   if (!ahead) {
