@@ -76,8 +76,8 @@ int nrq_params(uint32_t K, uint32_t out[10]);
  * nanorq_precalculate (lib/nanorq.c:393-401).  Implied by nrq_encode_blocks. */
 int nrq_precalculate(nrq_ctx *ctx, uint32_t K, uint32_t Kp);
 /* First-use costs of blocks of (K, K') paid now instead of inside the first encode / decode: the code object is loaded, the
- * per-K' constants are built and uploaded, and with encode_plan != 0 the encode plan is built (enqueued, for big K') as by
- * nrq_precalculate.  The object layer calls it from nanorq_encoder_new* / nanorq_decoder_new* -- the reference pays nothing
+ * per-K' constants are built and uploaded, and with encode_plan != 0 the encode plan is built (1: enqueued, for big K', as by
+ * nrq_precalculate; 2: waited for).  The object layer calls it from nanorq_encoder_new* / nanorq_decoder_new* -- the reference pays nothing
  * comparable (its tables are static), so the constructors are where a drop-in can put it without a timed call seeing it. */
 int nrq_warm(nrq_ctx *ctx, uint32_t K, uint32_t Kp, int encode_plan);
 /* drop cached encode plans (so that a benchmark can time plan generation) */

@@ -317,7 +317,7 @@ static void warm(nanorq *rq, int encoder) {
   if (!ndev() || k0 == 0) return;
   for (int d = 0; d < g_ndev && (size_t)d < (Z ? Z : 1); d++) {
     gpu_lock(d);
-    (void)nrq_warm(g_dev[d].c, (uint32_t)k0, rq->Kp, encoder);
+    (void)nrq_warm(g_dev[d].c, (uint32_t)k0, rq->Kp, encoder ? 2 : 0); /* (the encode plan of a big block is built on the device: waited for) */
     gpu_unlock(d);
   }
 }

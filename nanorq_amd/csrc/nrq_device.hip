@@ -1863,7 +1863,7 @@ int nrq_warm(nrq_ctx *ctx, uint32_t K, uint32_t Kp, int encode_plan) {
   if ((rc = get_kconst(ctx, p.Kp, &kc))) return rc;
   if (encode_plan) {
     EncPlan *ep;
-    rc = get_encplan(ctx, K, Kp, &ep, /*finish=*/false);
+    rc = get_encplan(ctx, K, Kp, &ep, /*finish=*/encode_plan > 1); /* (2: also wait for a device build of the plan) */
   }
   return rc;
 }
