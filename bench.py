@@ -95,8 +95,7 @@ def parse():
     ap.add_argument("--plan-ahead-depth", type=int, default=2, help="planner runs kept in flight ahead of their decode (1 or 2)")
     ap.add_argument("--plan-ahead", choices=("auto", "on", "off"), default="auto",
                     help="issue the decode planner run of the NEXT step while this step's decode is being solved (the symbolic stage "
-                         "needs the reception pattern only): nrq_decode_plan_ahead.  auto = for big blocks (few of them per GPU, a "
-                         "planner workgroup per block: L >= 12000), where the planner's latency is the step's critical path")
+                         "needs the reception pattern only): nrq_decode_plan_ahead.  auto = on")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffers-to-host-buffers leg")
     ap.add_argument("--one-object", choices=("auto", "on", "off"), default="auto",
                     help="ONE object over all N GPUs from rank 0's process (NANORQ_HIP_DEVICES=0..N-1, a host thread per device: "
@@ -436,7 +435,11 @@ def main():
     groups = [(bounds[g_], bounds[g_ + 1]) for g_ in range(nstreams)]
 
     replan_early = L >= 12000   # (the library's threshold for device-built encode plans, NRQ_ENCPLAN_DEV_MIN_L)
-    plan_ahead = nstreams == 1 and (args.plan_ahead == "on" or (args.plan_ahead == "auto" and replan_early))
+    # auto = always.  Big blocks: the planner's latency leaves the critical path (two steps' runs side by side).  Many small
+    # blocks (the planner stays on the solve stream): what goes is the host's wait for the planner in the MIDDLE of the step and
+    # its work behind it (2048 plan headers, the solve launch) with the GPU idle -- K=1000: 18.5 -> 18.1 ms on a quiet host,
+    # 28.8 -> 18.1 ms on a busy one; the headline 15.87 -> 15.74.
+    plan_ahead = nstreams == 1 and args.plan_ahead in ("on", "auto")
     ahead_depth = max(1, min(2, args.plan_ahead_depth))
     ahead_out = 0   # planner runs issued ahead and not consumed yet
 
