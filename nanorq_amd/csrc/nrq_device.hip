@@ -482,6 +482,7 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
                                                          uint32_t lowcap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
+#define PL_SEG_ (PK == 0 ? 0u : seg) /* (blocks whose peeling state fits the LDS run in one part: launch_plan_kernel) */
   if (b >= nblk) return;
   /* the dynamic region comes first (LDS address 0: the W strip image is addressed like the solve kernel's), the
    * fixed workgroup state after it */
@@ -490,11 +491,15 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
   PlanCtx c;
   pl_ctx_setup(c, p, kc, pjobs[b], sh, dyn, lds_dyn_bytes, Mcap, npcap, ucap, jobs_out + b, qcap, lowcap, (uint32_t)NT);
   if (!PK) c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
-  if (seg == 3u) c.cls_glob = reinterpret_cast<uint32_t *>(c.work + c.wl.cls_g); /* (pl_lev_b zeroes the counters nrq_wentry_kernel counts into) */
+  if (PL_SEG_ == 3u) c.cls_glob = reinterpret_cast<uint32_t *>(c.work + c.wl.cls_g); /* (pl_lev_b zeroes the counters nrq_wentry_kernel counts into) */
   /* NRQ_PROF=1: thread 0 of block 0 accumulates shader clocks per phase family (index = PL_TAG) */
   unsigned long long t_prev = prof ? (unsigned long long)clock64() : 0ull;
-#define PL_ACC(tag) do { if (prof && b == 0 && tid == 0) { unsigned long long t_ = (unsigned long long)clock64(); \
+#ifdef PL_STAMP
+#define PL_ACC(tag) ((void)0) /* (the stamps alone: the per-phase clocks' stores to memory would be what the stamped loads wait for) */
+#else
+#define PL_ACC(tag) do { if (__builtin_expect(prof && b == 0 && tid == 0, 0)) { unsigned long long t_ = (unsigned long long)clock64(); \
                                                           prof[tag] += t_ - t_prev; prof[16 + tag] += 1; t_prev = t_; } } while (0)
+#endif
 #define PL_PHASE(fn) do { fn<PK>(c, tid, (uint32_t)NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
 #define PL_PHASE1(fn, a) do { fn<PK>(c, (a), tid, (uint32_t)NT); __syncthreads(); PL_ACC(pl_tag_##fn); } while (0)
 #ifndef PL_CLAIM_FULL_BARRIER
@@ -503,7 +508,10 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
 /* (the claim phase: with the peeling decisions in LDS its global stores -- pivot lists, the HBM copies of row / column
  * state -- are read after peeling only, or by nobody before the next full barrier: the barrier waits for the LDS alone, not
  * for the stores' way to memory and back, a trip per round) */
-#define PL_PHASE1_CLAIM(fn, a) do { fn<PK>(c, (a), tid, (uint32_t)NT); \
+#ifndef PL_CLAIM_SKIP_IDLE
+#define PL_CLAIM_SKIP_IDLE 1
+#endif
+#define PL_PHASE1_CLAIM(fn, a) do { if (!PL_CLAIM_SKIP_IDLE || (tid & ~63u) < nq_) fn<PK>(c, (a), tid, (uint32_t)NT); \
     if (!PL_CLAIM_FULL_BARRIER && (pl_peel_in_lds(c) || c.pk_cnt)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads(); \
     PL_ACC(pl_tag_##fn); } while (0)
 #define PL_WFAST_RUN(wb) do { \
@@ -514,14 +522,23 @@ __global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t
       else fwd_rows<4>(ops_, pl_wfast_rows(c), tid); \
     } \
     __syncthreads(); PL_ACC(2); } while (0)
-#define PL_SEG seg
+#define PL_SEG PL_SEG_ /* (blocks whose peeling state fits the LDS run in one part: launch_plan_kernel) */
 #define PL_STEER_SYNC __syncthreads()
 #define PL_NT_ ((uint32_t)NT)
-  if (seg == 2u || seg == 4u) PL_PHASE(pl_sh_restore);
+#ifdef PL_STAMP
+  c.st_on = prof && b == 0 && tid == 0; c.st_prev = 0;
+  if (tid < 24) sh->st_acc[tid] = 0;
+  __syncthreads();
+#endif
+  if (PL_SEG_ == 2u || PL_SEG_ == 4u) PL_PHASE(pl_sh_restore);
 #include "planner_seq.h"
-  if (seg == 1u || seg == 4u) PL_PHASE(pl_mh_ext_clear);
-  if (seg == 1u || seg == 3u || seg == 4u) PL_PHASE(pl_sh_save);
+#ifdef PL_STAMP
+  if (c.st_on) { for (int i_ = 0; i_ < 24; i_++) prof[32 + i_] = sh->st_acc[i_]; }
+#endif
+  if (PL_SEG_ == 1u || PL_SEG_ == 4u) PL_PHASE(pl_mh_ext_clear);
+  if (PL_SEG_ == 1u || PL_SEG_ == 3u || PL_SEG_ == 4u) PL_PHASE(pl_sh_save);
 #undef PL_SEG
+#undef PL_SEG_
 #undef PL_STEER_SYNC
 #undef PL_NT_
 #undef PL_PHASE
@@ -1168,10 +1185,12 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
   const uint32_t nparts_run = !seg ? 1u : wentry ? 3u : 2u;
   for (uint32_t pi = 0; pi < nparts_run; pi++) {
     const uint32_t part = seg ? parts_seg[pi] : 0u;
+    const bool hbm_state = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L) > dyn_bytes; /* (pl_ctx_setup's rule) */
+    if (part && (small_wg || !hbm_state)) return fail(ctx, -2, "planner: a segmented run needs the instance for big blocks");
     if (small_wg)
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
                          nblk, Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
-    else if (2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L) > dyn_bytes) /* (pl_ctx_setup's rule: the state stays in HBM) */
+    else if (hbm_state) /* (the state stays in HBM) */
       hipLaunchKernelGGL((nrq_plan_kernel<(int)PL_NT, 1>), dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
                          Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
     else
@@ -2245,8 +2264,8 @@ static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32
   }
   unsigned long long *pprof = nullptr;
   if (ctx->tune.prof) {
-    HIPCHK(ctx, hipMalloc((void **)&pprof, 32 * 8));
-    HIPCHK(ctx, hipMemsetAsync(pprof, 0, 32 * 8, ps));
+    HIPCHK(ctx, hipMalloc((void **)&pprof, 64 * 8));
+    HIPCHK(ctx, hipMemsetAsync(pprof, 0, 64 * 8, ps));
   }
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   if (ctx->ktime_on) {
@@ -2267,7 +2286,7 @@ static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32
     return rc;
   if (pe1) HIPCHK(ctx, hipEventRecord(pe1, ps));
   if (pprof) {
-    unsigned long long hp[32];
+    unsigned long long hp[64];
     HIPCHK(ctx, hipMemcpyAsync(hp, pprof, sizeof(hp), hipMemcpyDeviceToHost, ps));
     HIPCHK(ctx, hipStreamSynchronize(ps));
     static const char *nm[16] = {"init", "claim", "Wrun", "drop", "Wmove", "ifind", "iapply", "lev", "W", "low", "ops", "mh",
@@ -2277,6 +2296,11 @@ static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32
     fprintf(stderr, "[NRQ_PROF] planner nblk=%u total=%llu clk:", nblk, tot);
     for (int k = 0; k < 16; k++) fprintf(stderr, " %s=%llu(%llu)", nm[k], hp[k], hp[16 + k]);
     fprintf(stderr, "\n");
+#ifdef PL_STAMP
+    fprintf(stderr, "[NRQ_PROF] round stamps (clocks up to point i, summed over the rounds):");
+    for (int k = 0; k < 24; k++) fprintf(stderr, " %d:%llu", k, hp[32 + k]);
+    fprintf(stderr, "\n");
+#endif
     (void)hipFree(pprof);
   }
   HIPCHK(ctx, hipMemcpy2DAsync(hs + off_hdrs, sizeof(nrq_plan_hdr), ctx->plan_arena[ab].p, arena_cap, sizeof(nrq_plan_hdr), nblk,

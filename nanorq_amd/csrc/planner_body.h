@@ -162,6 +162,28 @@ template <class LOAD, class STORE> SB_HD void pl_for_batched(uint32_t tid, uint3
 #define PL_ASSUME_LDS(p) ((void)0)
 #endif
 
+#if defined(PL_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+#define PL_ST(c, i) do { if ((c).st_on) { const unsigned long long t_ = (unsigned long long)clock64(); \
+    atomicAdd(&(c).sh->st_acc[i], t_ - (c).st_prev); (c).st_prev = t_; } } while (0)
+#else
+#define PL_ST(c, i) ((void)0)
+#endif
+#define PL_LIKELY(x) __builtin_expect(!!(x), 1)
+#define PL_UNLIKELY(x) __builtin_expect(!!(x), 0)
+/* Which form of the peeling phases an instance Z of the phase functions carries (PL_PEEL_DISPATCH3).  On the device the kernel
+ * instance says where the state is -- launch_plan_kernel starts Z = 0 for blocks whose state fits the LDS by pl_ctx_setup's
+ * rule, Z = 1 (compact state in LDS, arrays in HBM) for the others -- so each instance carries ONE form, not two or three: the
+ * peeling loop's code is fetched round after round, and with the forms that never run compiled out the headline planner went
+ * 3.19 -> 2.89 ms per 256 blocks.  The emulator (Z = 1) decides at run time, as does a PL_NO_COMPACT build. */
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(PL_NO_COMPACT) && PL_NO_COMPACT)
+#define PL_PEEL_LDS(Z) ((Z) == 0)
+#define PL_PEEL_PK(Z) ((Z) != 0)
+#define PL_PEEL_FORM_OK(Z) ((Z) == 0 ? pl_peel_in_lds(c) : (!pl_peel_in_lds(c) && c.pk_cnt != nullptr))
+#else
+#define PL_PEEL_LDS(Z) pl_peel_in_lds(c)
+#define PL_PEEL_PK(Z) ((Z) != 0 && c.pk_cnt)
+#define PL_PEEL_FORM_OK(Z) true
+#endif
 /* ---- workgroup-shared scalars and small arrays (LDS) ---- */
 /* status: 0 ok, 1 = not decodable (too few symbols / rank deficient), 2 = a planner capacity was
  * exceeded (queues, inactive-column cap, arena, LDS): the caller re-plans that block on the host */
@@ -169,6 +191,9 @@ template <class LOAD, class STORE> SB_HD void pl_for_batched(uint32_t tid, uint3
 #define PL_FAIL_CAPACITY 2u
 
 typedef struct pl_shared {
+#ifdef PL_STAMP
+  unsigned long long st_acc[24];
+#endif
   uint32_t status, fail_site; /* fail_site: source line that raised PL_FAIL_CAPACITY (diagnostics) */
   uint32_t defer_wt;          /* segmented run: W is transposed by nrq_wt_kernel, not by pl_final_c */
   uint32_t M, overhead, npatch, wpr, lpr, rowlen;
@@ -299,6 +324,10 @@ struct PlanCtx {
    * left V" (a bit each): 79 KB at K'=56403.  The HBM arrays are kept up to date by stores and atomics nobody waits for
    * (later phases read them); a round then waits for three trips to memory instead of six (pl_round_claim_k). */
   uint32_t *pk_cnt, *pk_un, *pk_pa, *pk_vb;
+#ifdef PL_STAMP /* diagnostic build: thread 0 of block 0 accumulates shader clocks between points of a peeling round (pl_shared::st_acc) */
+  unsigned long long st_prev;
+  bool st_on;
+#endif
   /* the entry pass on many workgroups (nrq_wentry_kernel, big blocks; job.mode bit 9): the column levels stay in HBM whatever the
    * LDS would hold, and while the helper's workgroups count, the class counters and the record counter are the workspace's */
   bool collev_hbm;
@@ -466,6 +495,7 @@ SB_HD uint8_t pl_gfmul(const pl_shared *sh, uint8_t a, uint8_t b) {
 }
 
 /* =============================== phase 0: inputs, patch rows, state ========================== */
+SB_HD bool pl_peel_in_lds(const PlanCtx &c);
 template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const rq_params &p = c.p;
@@ -476,8 +506,10 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     uint32_t oh = st ? 0 : nr - nl;
     if (!st && (p.L + oh + PL_EXTRA_ROWS > c.Mcap || nr + PL_EXTRA_ROWS > c.npcap || p.L + oh + PL_EXTRA_ROWS > 65534u))
       st = PL_FAIL_CAPACITY;
+    /* (the kernel instances carry one form of the peeling phases each, PL_PEEL_DISPATCH3: a block whose state is not where its
+     * instance expects it goes back to the host planner) */
+    if (!st && !PL_PEEL_FORM_OK(Z)) { st = PL_FAIL_CAPACITY; sh->fail_site = __LINE__; } else sh->fail_site = 0;
     sh->status = st;
-    sh->fail_site = 0;
     sh->defer_wt = c.job.mode >> 8; /* (bit 8 of the job's mode: set by the host for segmented runs) */
     sh->overhead = oh;
     sh->M = p.L + oh;
@@ -647,7 +679,7 @@ template <bool LDS> SB_HD PlPeel pl_peel_state(const PlanCtx &c) {
 /* three ways: the state in LDS | the compact state in LDS with the HBM arrays kept up to date (fn##k) | the HBM arrays alone.
  * Z: template argument of the phase functions -- 0 compiles the compact form out (the kernel instance for blocks whose state
  * fits the LDS: with the extra code in it that instance ran 11 % slower, 3.19 -> 3.55 ms per 256 blocks of K=8192) */
-#define PL_PEEL_DISPATCH3(fn, ...) do { if (pl_peel_in_lds(c)) fn##t<true>(__VA_ARGS__); else if (Z != 0 && c.pk_cnt) fn##k(__VA_ARGS__); \
+#define PL_PEEL_DISPATCH3(fn, ...) do { if (PL_PEEL_LDS(Z)) fn##t<true>(__VA_ARGS__); else if (PL_PEEL_PK(Z)) fn##k(__VA_ARGS__); \
                                         else fn##t<false>(__VA_ARGS__); } while (0)
 struct PlPk { uint32_t *cnt, *un, *pa, *vb; };
 SB_HD PlPk pl_pk(const PlanCtx &c) {
@@ -665,18 +697,35 @@ template <bool LDS> SB_HD void pl_drop_column(PlanCtx &c, const PlPeel &s, uint3
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const uint32_t dec = (1u << 24) | col;
   uint16_t *nextq = c.queue(np);
+#ifdef PL_STAMP
+  if (col + lvl1 != 0x7FFFFFF1u) PL_ST(c, 17);
+  const uint32_t a = c.b_cptr[col];
+  if (a != 0x7FFFFFF1u) PL_ST(c, 18);
+  const uint32_t nb = c.b_cptr[col + 1 + (a == 0x7FFFFFF1u ? 1u : 0u)] - a;
+#else
   const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a;
+#endif
+#ifdef PL_STAMP
+  if (a + nb != 0x7FFFFFF1u) PL_ST(c, 16);
+  const uint32_t col2 = col + (a == 0xFFFFFFF1u ? 1u : 0u);
+  const uint32_t pa = c.pc_ptr[col2], npc = c.pc_ptr[col2 + 1] - pa;
+#else
   const uint32_t pa = c.pc_ptr[col], npc = c.pc_ptr[col + 1] - pa;
+#endif
+  if (nb + npc > lane0) PL_ST(c, 10);
   for (uint32_t e = lane0; e < nb + npc; e += lanes) {
     const bool base = e < nb;
     const uint32_t r = base ? c.b_ridx[a + e] : c.pc_rows[pa + (e - nb)];
+    if (e == lane0 && r != 0xFFFFFFFFu) PL_ST(c, 11);
     const uint32_t info = s.rowinfo[r]; /* flags change in other phases only: stable here */
     if (base && (info & PL_PATCHED)) continue; /* base entry of a row this block replaced */
+    if (e == lane0 && info != 0x12345u) PL_ST(c, 12);
     if (lvl1 && (info & PL_UNASSIGNED)) PL_ATOM_MAX(&s.rowinfo[r], (info & ~PL_LEVEL_MASK) | lvl1);
     const uint32_t old = PL_ATOM_SUB(&s.rowstate[r], dec);
+    if (e == lane0 && old != 0x12345u) PL_ST(c, 13);
     if ((old >> 24) == 2u && (info & PL_UNASSIGNED)) {
       const uint32_t j = PL_ATOM_ADD(&sh->nq[np], 1u);
-      if (j < c.qcap) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+      if (PL_LIKELY(j < c.qcap)) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     } else if (!LDS && (old >> 24) == 3u && (info & PL_UNASSIGNED)) { /* two V columns left: a candidate of the next inactivation */
       const uint32_t j = PL_ATOM_ADD(&sh->ncand[0], 1u);
       if (j < c.Mcap) c.cand[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
@@ -704,7 +753,7 @@ SB_HD void pl_drop_column_k(PlanCtx &c, const PlPk &k, uint32_t col, uint32_t lv
     const uint32_t old = (PL_ATOM_SUB(&k.cnt[r >> 2], 1u << sh8) >> sh8) & 0xFFu;
     if (old == 2u && open) {
       const uint32_t j = PL_ATOM_ADD(&sh->nq[np], 1u);
-      if (j < c.qcap) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+      if (PL_LIKELY(j < c.qcap)) nextq[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     } else if (old == 3u && open) { /* two V columns left: a candidate of the next inactivation */
       const uint32_t j = PL_ATOM_ADD(&sh->ncand[0], 1u);
       if (j < c.Mcap) c.cand[j] = (uint16_t)r; else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
@@ -722,23 +771,28 @@ template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_
   const uint32_t pq = rd & 1u;
   const uint16_t *fq = c.queue(pq);
   const uint32_t nf = sh->nq[pq] < c.qcap ? sh->nq[pq] : c.qcap;
+  if (nf) PL_ST(c, 3);
   for (uint32_t t = tid; t < nf; t += nt) {
     const uint32_t r = fq[t];
     const uint32_t st = s.rowstate[r], info = s.rowinfo[r];
     if ((st >> 24) != 1u || !(info & PL_UNASSIGNED)) continue;
+    PL_ST(c, 4);
     const uint32_t col = st & 0xFFFFFFu;
     if (PL_ATOM_CAS(&s.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue;
+    PL_ST(c, 5);
     const uint32_t lv = info & PL_LEVEL_MASK;
     const uint32_t k = PL_ATOM_ADD(&sh->npiv, 1u);
     const uint32_t i = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
+    PL_ST(c, 6);
     s.rowinfo[r] = (info & PL_PATCHED) | lv; /* assigned: bit 31 cleared */
     s.colinfo[col] = (PL_ST_PIVOT << 30) | k;
     PL_ATOM_SUB(&sh->nV, 1u); /* (the number of levels is taken from the pivots once peeling is over: pl_lev_0) */
-    if (i < c.qcap) { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    if (PL_LIKELY(i < c.qcap)) { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
     c.pivcol[k] = (uint16_t)col;
   }
   if (tid == 0) { sh->nq[pq ^ 1u] = 0; sh->best = PL_NONE; }
+  PL_ST(c, 7);
 }
 /* compact state: whether a frontier row still has exactly one V column and no pivot is in LDS; WHICH column that is, is the
  * sum left in the HBM row state (all of last round's subtractions have arrived: the barrier waited for them) -- one trip,
@@ -763,7 +817,7 @@ SB_HD void pl_round_claim_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) 
     PL_GSTORE(&c.rowinfo[r], (info & PL_PATCHED) | lv);
     PL_GSTORE(&c.colinfo[col], (PL_ST_PIVOT << 30) | kk);
     PL_ATOM_SUB(&sh->nV, 1u);
-    if (i < c.qcap) { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    if (PL_LIKELY(i < c.qcap)) { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     c.pivslot[kk] = (uint16_t)r; /* (HBM; read after peeling) */
     c.pivcol[kk] = (uint16_t)col;
   }
@@ -772,6 +826,9 @@ SB_HD void pl_round_claim_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) 
 template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   PL_PEEL_DISPATCH3(pl_round_claim_, c, rd, tid, nt);
 }
+#ifndef PL_DROP_LG_MAX
+#define PL_DROP_LG_MAX 4u
+#endif
 /* B: the claimed columns leave V.  A group of 8..64 lanes per column -- as many as the round's claim count leaves
  * (most rounds claim a dozen columns; each trip over a column's row list is a dependent HBM/L2 round trip) */
 template <bool LDS> SB_HD void pl_round_drop_t(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
@@ -780,12 +837,25 @@ template <bool LDS> SB_HD void pl_round_drop_t(PlanCtx &c, uint32_t rd, uint32_t
   const uint32_t pq = rd & 1u;
   const uint32_t nc = sh->nclaim[pq] < c.qcap ? sh->nclaim[pq] : c.qcap;
   uint32_t lg = 3;
-  while (lg < 6u && (nc << (lg + 1u)) <= nt) lg++;
+  while (lg < PL_DROP_LG_MAX && (nc << (lg + 1u)) <= nt) lg++;
   const uint32_t grp = tid >> lg, lane = tid & ((1u << lg) - 1u), ngrp = nt >> lg;
+  if (nc) PL_ST(c, 9);
+#ifdef PL_STAMP
+  if (nc && grp + lane + ngrp != 0x7FFFFFF1u) PL_ST(c, 19);
+#endif
   for (uint32_t i = grp; i < nc; i += ngrp) {
+#ifdef PL_STAMP
+    const uint32_t cc_ = c.claim_c()[i];
+    if (cc_ != 0x7FFFFFF1u) PL_ST(c, 20);
+    const uint32_t cl_ = c.claim_l()[i];
+    if (cl_ != 0x7FFFFFF1u) PL_ST(c, 21);
+    pl_drop_column<LDS>(c, s, cc_, cl_, pq ^ 1u, lane, 1u << lg);
+#else
     pl_drop_column<LDS>(c, s, c.claim_c()[i], c.claim_l()[i], pq ^ 1u, lane, 1u << lg);
+#endif
   }
   if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
+  PL_ST(c, 14);
 }
 SB_HD void pl_round_drop_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
@@ -793,7 +863,7 @@ SB_HD void pl_round_drop_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   const uint32_t pq = rd & 1u;
   const uint32_t nc = sh->nclaim[pq] < c.qcap ? sh->nclaim[pq] : c.qcap;
   uint32_t lg = 3;
-  while (lg < 6u && (nc << (lg + 1u)) <= nt) lg++;
+  while (lg < PL_DROP_LG_MAX && (nc << (lg + 1u)) <= nt) lg++;
   const uint32_t grp = tid >> lg, lane = tid & ((1u << lg) - 1u), ngrp = nt >> lg;
   for (uint32_t i = grp; i < nc; i += ngrp) pl_drop_column_k(c, k, c.claim_c()[i], c.claim_l()[i], pq ^ 1u, lane, 1u << lg);
   if (tid == 0) sh->nclaim[pq ^ 1u] = 0;

@@ -38,12 +38,17 @@
     uint32_t rd_ = 0;
     for (;;) {
       /* (one LDS round trip for the three words, not one per test: a round is a chain of such trips) */
+      PL_ST(c, 0);
       const uint32_t st_ = sh_->status, nv_ = sh_->nV, nq_ = sh_->nq[rd_ & 1u];
+      if (st_ + nv_ + nq_ != 0x12345u) PL_ST(c, 1);
       PL_STEER_SYNC; /* (pl_round_claim lowers nV and may raise status) */
+      PL_ST(c, 2);
       if (st_ != 0 || nv_ == 0 || rd_ >= guard_max) break;
-      if (nq_ > 0) {
+      if (PL_LIKELY(nq_ > 0)) {
         PL_PHASE1_CLAIM(pl_round_claim, rd_);
+        PL_ST(c, 8);
         PL_PHASE1(pl_round_drop, rd_);
+        PL_ST(c, 15);
       } else {
         /* one inactivation event: up to NRQ_MULTI_INACT open rows, sparsest first */
         for (uint32_t rep_ = 0; rep_ < NRQ_MULTI_INACT; rep_++) {
