@@ -153,7 +153,12 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
 #ifndef NRQ_RING_4W
 #define NRQ_RING_4W NRQ_RING
 #endif
-  constexpr uint32_t RU = NT >= 512 ? NRQ_BIG_RING : WV >= 5 ? NRQ_RING_5W : NRQ_RING_4W;
+#ifndef NRQ_RING_TINY
+#define NRQ_RING_TINY 24u /* the single-wave variant: a dozen workgroups per CU hide each other's op-word latency, and a short ring is less code for
+                           * them to share the instruction cache with (K=100 T=1024 / K=256, ring 60 / 36 / 24 / 12 rows: 460 / 468 / 471 / 473 and
+                           * 815 / 833 / 835 / 836 Gbit/s; the 256-thread variant loses with a shorter ring: K=1000 1156 / 1093 / 1087 / 1057) */
+#endif
+  constexpr uint32_t RU = NT >= 512 ? NRQ_BIG_RING : NT == 64 ? NRQ_RING_TINY : WV >= 5 ? NRQ_RING_5W : NRQ_RING_4W;
   /* NT == 64: ONE wave solves the strip on its own (no mover waves: it gathers and scatters its portions itself after
    * the forward passes; barriers are free).  For images of a few KB -- K up to ~400 -- where a strip is a chain of
    * short phases with little parallel work: 19-20 such workgroups share a CU instead of five 256-thread ones, i.e.
