@@ -770,7 +770,7 @@ template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_
   const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t pq = rd & 1u;
   const uint16_t *fq = c.queue(pq);
-  const uint32_t nf = sh->nq[pq] < c.qcap ? sh->nq[pq] : c.qcap;
+  const uint32_t nf = sh->nq[pq] < c.qcap ? sh->nq[pq] : c.qcap, npiv0 = sh->npiv;
   if (nf) PL_ST(c, 3);
   for (uint32_t t = tid; t < nf; t += nt) {
     const uint32_t r = fq[t];
@@ -781,12 +781,14 @@ template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_
     if (PL_ATOM_CAS(&s.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue;
     PL_ST(c, 5);
     const uint32_t lv = info & PL_LEVEL_MASK;
-    const uint32_t k = PL_ATOM_ADD(&sh->npiv, 1u);
+    /* ONE counter per claim: the place in the round's claim list; the pivot number is that place behind the pivots of the
+     * rounds before, and the drop phase adds the round's claims to the pivot count and takes them off the count of open
+     * columns (three wave-aggregated atomics per claiming wave were ~35 instructions and a trip of its critical path) */
     const uint32_t i = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
+    const uint32_t k = npiv0 + i;
     PL_ST(c, 6);
     s.rowinfo[r] = (info & PL_PATCHED) | lv; /* assigned: bit 31 cleared */
     s.colinfo[col] = (PL_ST_PIVOT << 30) | k;
-    PL_ATOM_SUB(&sh->nV, 1u); /* (the number of levels is taken from the pivots once peeling is over: pl_lev_0) */
     if (PL_LIKELY(i < c.qcap)) { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
     c.pivcol[k] = (uint16_t)col;
@@ -802,7 +804,7 @@ SB_HD void pl_round_claim_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) 
   const PlPk k = pl_pk(c);
   const uint32_t pq = rd & 1u;
   const uint16_t *fq = c.queue(pq);
-  const uint32_t nf = sh->nq[pq] < c.qcap ? sh->nq[pq] : c.qcap;
+  const uint32_t nf = sh->nq[pq] < c.qcap ? sh->nq[pq] : c.qcap, npiv0 = sh->npiv;
   for (uint32_t t = tid; t < nf; t += nt) {
     const uint32_t r = fq[t];
     if (pk_count(k, r) != 1u || !pk_bit(k.un, r)) continue;
@@ -811,12 +813,11 @@ SB_HD void pl_round_claim_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) 
     const uint32_t col = st & 0xFFFFFFu, cbit = 1u << (col & 31u);
     if (PL_ATOM_OR(&k.vb[col >> 5], cbit) & cbit) continue; /* another row of this round took the column */
     const uint32_t lv = info & PL_LEVEL_MASK;
-    const uint32_t kk = PL_ATOM_ADD(&sh->npiv, 1u);
     const uint32_t i = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
+    const uint32_t kk = npiv0 + i; /* (pl_round_claim_t) */
     PL_ATOM_XOR(&k.un[r >> 5], 1u << (r & 31u)); /* assigned (the bit was set: only this thread clears it) */
     PL_GSTORE(&c.rowinfo[r], (info & PL_PATCHED) | lv);
     PL_GSTORE(&c.colinfo[col], (PL_ST_PIVOT << 30) | kk);
-    PL_ATOM_SUB(&sh->nV, 1u);
     if (PL_LIKELY(i < c.qcap)) { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     c.pivslot[kk] = (uint16_t)r; /* (HBM; read after peeling) */
     c.pivcol[kk] = (uint16_t)col;
@@ -854,7 +855,7 @@ template <bool LDS> SB_HD void pl_round_drop_t(PlanCtx &c, uint32_t rd, uint32_t
     pl_drop_column<LDS>(c, s, c.claim_c()[i], c.claim_l()[i], pq ^ 1u, lane, 1u << lg);
 #endif
   }
-  if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
+  if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->npiv += nc; sh->nV -= nc; } /* (the round's claims: pl_round_claim_t) */
   PL_ST(c, 14);
 }
 SB_HD void pl_round_drop_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
@@ -866,7 +867,7 @@ SB_HD void pl_round_drop_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   while (lg < PL_DROP_LG_MAX && (nc << (lg + 1u)) <= nt) lg++;
   const uint32_t grp = tid >> lg, lane = tid & ((1u << lg) - 1u), ngrp = nt >> lg;
   for (uint32_t i = grp; i < nc; i += ngrp) pl_drop_column_k(c, k, c.claim_c()[i], c.claim_l()[i], pq ^ 1u, lane, 1u << lg);
-  if (tid == 0) sh->nclaim[pq ^ 1u] = 0;
+  if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->npiv += nc; sh->nV -= nc; }
 }
 template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   PL_PEEL_DISPATCH3(pl_round_drop_, c, rd, tid, nt);
