@@ -959,6 +959,8 @@ struct Tuning {
   bool plan_split_force = false; /* "plan_split_force": every block planned in two parts + helper kernels (tests) */
   bool no_plan_split = false;  /* NRQ_NO_PLAN_SPLIT: big blocks planned by one kernel (no helper kernels for the HDPC fold / W transposition) */
   bool no_plan_stream = false; /* NRQ_NO_PLAN_STREAM: planner kernel on the caller's stream (no overlap with the solve before it) */
+  bool plan_wrong_instance = false; /* "plan_wrong_instance" (tests): blocks whose peeling state fits the LDS are given to the planner instance for
+                                     * the others -- pl_init_a must notice (PL_PEEL_FORM_OK) and the blocks go to the host planner */
   uint32_t plan_ucap = 0;      /* "plan_ucap": inactive-column capacity of the device planner (0 = P + 768, at most 1280); tests lower it
                                 * to send blocks through the capacity fallback (host re-plan) */
   void read() {
@@ -1195,7 +1197,7 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     if (small_wg)
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
                          nblk, Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
-    else if (hbm_state) /* (the state stays in HBM) */
+    else if (hbm_state || ctx->tune.plan_wrong_instance) /* (the state stays in HBM) */
       hipLaunchKernelGGL((nrq_plan_kernel<(int)PL_NT, 1>), dim3(nblk), dim3(PL_NT), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs, nblk,
                          Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
     else
@@ -1859,6 +1861,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "map_spread") t.map_spread = value != 0;
   else if (n == "encplan_dev_min_l") t.encplan_dev_min_l = (uint32_t)value;
   else if (n == "plan_ucap") t.plan_ucap = (uint32_t)value;
+  else if (n == "plan_wrong_instance") t.plan_wrong_instance = value != 0;
   else return fail(ctx, -1, "unknown option %s", name);
   return 0;
 }

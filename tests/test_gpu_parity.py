@@ -533,6 +533,39 @@ def test_capacity_fallback_replans_on_the_host(G, orc, K, T, nblk, loss):
     assert mixed, "no capacity setting split the batch between the device and the host planner"
 
 
+def test_planner_instance_guard(G, orc):
+    """Each planner kernel instance carries ONE form of the peeling phases (state in LDS | compact state beside arrays in HBM;
+    planner_body.h PL_PEEL_DISPATCH3) and launch_plan_kernel picks the instance by pl_ctx_setup's rule.  "plan_wrong_instance"
+    gives LDS-sized blocks to the other instance: pl_init_a must report them (PL_FAIL_CAPACITY) instead of peeling with the
+    wrong form, and they come back from the host planner decoded like any other block."""
+    K, T, nblk = 1024, 32, 8
+    c = G.ctx()
+    src = np.stack([payload(K * T, seed=70 + b).reshape(K, T) for b in range(nblk)])
+    esis = np.arange(K, K + 120, dtype=np.uint32)
+    rep, _ = G.gpu_encode(src, K, T, esis)
+    lost = [loss_pattern(K, 0.08, seed=11, block=b) for b in range(nblk)]
+    work = src.copy()
+    for b in range(nblk):
+        work[b][lost[b]] = 0x5A
+    args = (work, K, T, lost, [esis[:len(l) + 2] for l in lost], [rep[b][:len(lost[b]) + 2] for b in range(nblk)])
+    st0, out0, _ = G.gpu_decode(*args)
+    assert c.stats()["host_planned"] == 0 and st0.all() and np.array_equal(out0, src)
+    ok, ref, _ = orc.decode_block(np.concatenate([np.setdiff1d(np.arange(K, dtype=np.uint32), lost[0]), esis[:len(lost[0]) + 2]]),
+                                  np.concatenate([src[0][np.setdiff1d(np.arange(K), lost[0])], rep[0][:len(lost[0]) + 2]]), K, T)
+    assert ok and np.array_equal(ref, out0[0])
+    try:
+        c.set_option("plan_big_wg", 1)          # (1024-thread planner workgroups: the instance pair the guard tells apart)
+        c.set_option("plan_wrong_instance", 1)
+        st, out, _ = G.gpu_decode(*args)
+        assert c.stats()["host_planned"] == nblk, "the guard did not send the blocks to the host planner"
+        assert st.all() and np.array_equal(out, src)
+    finally:
+        c.set_option("plan_wrong_instance", 0)
+        c.set_option("plan_big_wg", 0)
+    st, out, _ = G.gpu_decode(*args)
+    assert c.stats()["host_planned"] == 0 and np.array_equal(out, src)
+
+
 def test_decode_plan_issued_ahead(G, orc):
     """nrq_decode_plan_ahead: the planner run of a decode call issued before the call (the symbolic stage needs the reception
     pattern only) -- the decode with the same arguments finds it (stats.plan_ahead), a decode with OTHER arguments discards it
