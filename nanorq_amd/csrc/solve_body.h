@@ -1349,7 +1349,7 @@ SB_HD void backsub_one(const StripCtx<WB, G> &c, const uint8_t *t4, uint32_t slo
       continue;
     }
     if constexpr (WB == 8 && G == 1) {
-      /* the same for 8-byte strips (blocks whose 16-byte image does not fit the LDS: K from ~9800 on): table entries of 8
+      /* the same for 8-byte strips (blocks whose 16-byte image does not fit the LDS: K from ~8500 on): table entries of 8
        * bytes, so a nibble is brought to "8 * nibble" in place and a word's tables are 1 KB */
       uint32_t odd = (bits >> 1) & 0x78787878u, even = (bits << 3) & 0x78787878u;
       asm volatile("" : "+v"(odd), "+v"(even));
