@@ -959,6 +959,7 @@ struct Tuning {
   bool plan_split_force = false; /* "plan_split_force": every block planned in two parts + helper kernels (tests) */
   bool no_plan_split = false;  /* NRQ_NO_PLAN_SPLIT: big blocks planned by one kernel (no helper kernels for the HDPC fold / W transposition) */
   bool no_plan_stream = false; /* NRQ_NO_PLAN_STREAM: planner kernel on the caller's stream (no overlap with the solve before it) */
+  bool plan_no_wg128 = false;  /* NRQ_PLAN_NO_WG128: the smallest blocks' planner workgroups stay at 256 threads */
   bool plan_wrong_instance = false; /* "plan_wrong_instance" (tests): blocks whose peeling state fits the LDS are given to the planner instance for
                                      * the others -- pl_init_a must notice (PL_PEEL_FORM_OK) and the blocks go to the host planner */
   uint32_t plan_ucap = 0;      /* "plan_ucap": inactive-column capacity of the device planner (0 = P + 768, at most 1280); tests lower it
@@ -976,7 +977,7 @@ struct Tuning {
     no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 6);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
-    plan_small_state = !flag("NRQ_PLAN_BIG_STATE");
+    plan_small_state = !flag("NRQ_PLAN_BIG_STATE"); plan_no_wg128 = flag("NRQ_PLAN_NO_WG128");
   }
 };
 
@@ -1114,6 +1115,8 @@ static int plan_attr_once(nrq_ctx *ctx) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT_MIN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_plan_kernel<(int)PL_NT_TINY>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRQ_LDS_MAX));
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_mh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)NRQ_LDS_MAX));
   HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_wpass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1162,6 +1165,7 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
    * dense-stage reserve, or a 16-byte strip image of the W rows), so that several workgroups share a CU */
   uint32_t dyn_bytes = NRQ_LDS_MAX - sh_bytes;
   bool small_wg = false; /* 256-thread workgroups: a small block has no use for 1024 threads, a CU has for 4 blocks */
+  bool tiny_wg = false;  /* 128-thread workgroups (with small_wg) */
   {
     const uint32_t peel = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L);
     const uint32_t wimg = (Mcap + 320u + NRQ_SCRATCH) * 16u;
@@ -1172,6 +1176,12 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
       dyn_bytes = fit;
       small_wg = !ctx->tune.plan_big_wg;
       if (small_wg && ctx->tune.plan_small_state) { qcap = q_s; lowcap = low_s; sh_bytes = sh_s; }
+      /* The smallest blocks: 128 threads.  A planner phase is one wave's chain of instructions and trips,
+       * the other waves of the workgroup mostly wait; the registers of the kernel (~100) let a CU hold 20 waves -- five
+       * 256-thread workgroups, or as many 128-thread ones as the LDS takes (six or more from here on): more blocks in flight
+       * for the same waves. */
+      const uint32_t sh_t = pl_shared_bytes(q_s, low_s, PL_NT_TINY);
+      if (small_wg && ctx->tune.plan_small_state && !ctx->tune.plan_no_wg128 && fit + sh_t <= NRQ_LDS_MAX / 6u) { tiny_wg = true; sh_bytes = sh_t; }
     }
   }
   const bool seg = plan_is_segmented(ctx, p, Mcap);
@@ -1181,7 +1191,7 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     const uint32_t need = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u);
     const uint32_t only_dense = (pl_dense_reserve(p.L) + need - 16u) & ~15u; /* 16 bytes short of holding the peeling state */
     if (only_dense < dyn_bytes) dyn_bytes = only_dense;
-    small_wg = false;
+    small_wg = false; tiny_wg = false;
     qcap = PL_QCAP; lowcap = PL_LOWCAP; sh_bytes = pl_shared_bytes(qcap, lowcap, PL_NT);
   }
   const uint32_t mh_dyn = 72u * 1024u; /* nrq_mh_kernel: MhT (16 B x u <= 20 KB) + the tiles (4 KB + 256 x wpr words <= 40 KB) */
@@ -1193,8 +1203,11 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
   for (uint32_t pi = 0; pi < nparts_run; pi++) {
     const uint32_t part = seg ? parts_seg[pi] : 0u;
     const bool hbm_state = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L) > dyn_bytes; /* (pl_ctx_setup's rule) */
-    if (part && (small_wg || !hbm_state)) return fail(ctx, -2, "planner: a segmented run needs the instance for big blocks");
-    if (small_wg)
+    if (part && (tiny_wg || small_wg || !hbm_state)) return fail(ctx, -2, "planner: a segmented run needs the instance for big blocks");
+    if (tiny_wg)
+      hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_TINY>, dim3(nblk), dim3(PL_NT_TINY), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
+                         nblk, Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
+    else if (small_wg)
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_MIN>, dim3(nblk), dim3(PL_NT_MIN), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,
                          nblk, Mcap, npcap, ucap, dyn_bytes, pprof, part, qcap, lowcap);
     else if (hbm_state || ctx->tune.plan_wrong_instance) /* (the state stays in HBM) */
@@ -1862,6 +1875,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "encplan_dev_min_l") t.encplan_dev_min_l = (uint32_t)value;
   else if (n == "plan_ucap") t.plan_ucap = (uint32_t)value;
   else if (n == "plan_wrong_instance") t.plan_wrong_instance = value != 0;
+  else if (n == "plan_no_wg128") t.plan_no_wg128 = value != 0;
   else return fail(ctx, -1, "unknown option %s", name);
   return 0;
 }

@@ -34,6 +34,7 @@
 #define PL_NT 1024u     /* threads of a planner workgroup: big blocks */
 #endif
 #define PL_NT_MIN 256u  /* small blocks (several workgroups per CU) */
+#define PL_NT_TINY 128u /* the smallest blocks (six or more workgroups per CU) */
 #define PL_QCAP 2048u          /* frontier / claim queue capacity */
 #define PL_UNASSIGNED 0x80000000u /* rowinfo bit 31: row has no pivot column (yet) */
 #define PL_PATCHED 0x40000000u    /* rowinfo bit 30: this block replaced the base row (its base CSC entries are void) */
@@ -1444,13 +1445,13 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
   const uint32_t *opq = pl_aux_opq(c, group & 1u);
   auto op_at = [&](uint32_t e) { return staged ? opq[e] : gops[NRQ_OP_INDEX(base + e / NRQ_ROW, e % NRQ_ROW)]; };
   /* issue the prefetch of the next group first: its loads overlap with this group's work */
-  uint32_t pf[PL_OPQ_WORDS / PL_NT_MIN], pf_n = 0; /* (PL_OPQ_WORDS / nt of them are used) */
+  uint32_t pf[PL_OPQ_WORDS / PL_NT_TINY], pf_n = 0; /* (PL_OPQ_WORDS / nt of them are used) */
   if (lds && group + 1u <= sh->nlev) {
     const uint32_t b2 = pl_aux_lvbase(c)[group + 1u], n2 = (pl_aux_lvbase(c)[group + 2u] - b2) * NRQ_ROW;
     if (n2 <= PL_OPQ_WORDS) {
       pf_n = n2;
 #pragma unroll
-      for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT_MIN; q++)
+      for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT_TINY; q++)
         if (q < PL_OPQ_WORDS / nt) {
           const uint32_t e = tid + q * nt;
           pf[q] = e < n2 ? gops[NRQ_OP_INDEX(b2 + e / NRQ_ROW, e % NRQ_ROW)] : 0u /* a padding op */;
@@ -1506,7 +1507,7 @@ template <int Z> SB_HD void pl_w_group(PlanCtx &c, uint32_t group, uint32_t tid,
   if (pf_n) {
     uint32_t *dstq = pl_aux_opq(c, (group + 1u) & 1u);
 #pragma unroll
-    for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT_MIN; q++)
+    for (uint32_t q = 0; q < PL_OPQ_WORDS / PL_NT_TINY; q++)
       if (q < PL_OPQ_WORDS / nt)
       if ((tid + q * nt) < pf_n) dstq[tid + q * nt] = pf[q];
   }
