@@ -478,8 +478,11 @@ enum {
  * planner_seq.h): reception pattern -> device plan + the block's solve job. */
 /* PK = 1: the instance for blocks whose peeling state does not fit the LDS -- it carries the compact form of that state
  * (planner_body.h "compact peeling state"); the others are compiled without it */
+/* (the instances for small blocks are built for five waves per SIMD, 96 registers: at the ~100 the compiler takes by itself a
+ * SIMD holds four, and what bounds their planner is the number of blocks in flight per CU) */
 template <int NT, int PK = 0>
-__global__ __launch_bounds__(NT) void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 256 ? 5 : 1)))
+void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
                                                          const nrq_planjob *__restrict__ pjobs,
                                                          nrq_job *__restrict__ jobs_out, uint32_t nblk, uint32_t Mcap,
                                                          uint32_t npcap, uint32_t ucap, uint32_t lds_dyn_bytes,
@@ -1170,7 +1173,8 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     const uint32_t peel = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L);
     const uint32_t wimg = (Mcap + 320u + NRQ_SCRATCH) * 16u;
     const uint32_t fit = pl_r16((peel > wimg ? peel : wimg) + 2048u);
-    const uint32_t q_s = p.L <= 1500u ? 512u : 1024u, low_s = p.L <= 1500u ? 384u : 768u;
+    /* (queues / claim lists / Gauss-Jordan flags: a frontier, a round's claims and the leftover rows are at most the block's rows) */
+    const uint32_t q_s = Mcap <= 248u ? 256u : p.L <= 1500u ? 512u : 1024u, low_s = Mcap <= 248u ? 256u : p.L <= 1500u ? 384u : 768u;
     const uint32_t sh_s = ctx->tune.plan_small_state ? pl_shared_bytes(q_s, low_s, PL_NT_MIN) : sh_bytes;
     if (fit + sh_s <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) {
       dyn_bytes = fit;

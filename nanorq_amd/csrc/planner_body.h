@@ -52,7 +52,10 @@
 #define PL_LOWCAP 1344u /* leftover rows the dense stage can take (>= inactive-column cap 1280 + 32) */
 /* LDS kept for the dense stage when the peeling state is in LDS too: 36 KB for big blocks, less for small ones (whose
  * planner workgroups then share a CU) */
-SB_HD uint32_t pl_dense_reserve(uint32_t L) { const uint32_t r = 8u * 1024u + L * 6u; return r < 36u * 1024u ? (r + 15u) & ~15u : 36u * 1024u; }
+/* (what the dense stage takes is 16 bytes per inactive column plus the larger of Mb and the HDPC fold's tiles -- 4 KB + 1 KB per
+ * 32 inactive columns: pl_low_b checks --; the smallest blocks, a few dozen inactive columns, get by with 6 KB + 6 L, and one
+ * more of their workgroups fits a CU) */
+SB_HD uint32_t pl_dense_reserve(uint32_t L) { const uint32_t r = (L < 400u ? 6u : 8u) * 1024u + L * 6u; return r < 36u * 1024u ? (r + 15u) & ~15u : 36u * 1024u; }
 
 /* what the host hands the planner for one block */
 typedef struct nrq_planjob {
