@@ -55,7 +55,7 @@
 /* (what the dense stage takes is 16 bytes per inactive column plus the larger of Mb and the HDPC fold's tiles -- 4 KB + 1 KB per
  * 32 inactive columns: pl_low_b checks --; the smallest blocks, a few dozen inactive columns, get by with 6 KB + 6 L, and one
  * more of their workgroups fits a CU) */
-SB_HD uint32_t pl_dense_reserve(uint32_t L) { const uint32_t r = (L < 400u ? 6u : 8u) * 1024u + L * 6u; return r < 36u * 1024u ? (r + 15u) & ~15u : 36u * 1024u; }
+SB_HD uint32_t pl_dense_reserve(uint32_t L) { const uint32_t r = (L < 1200u ? 6u : 8u) * 1024u + L * 6u; return r < 36u * 1024u ? (r + 15u) & ~15u : 36u * 1024u; }
 
 /* what the host hands the planner for one block */
 typedef struct nrq_planjob {
