@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- RaptorQ encode+decode throughput of the MI355X path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: under torch.distributed.run (RANK / WORLD_SIZE set) this process is one rank; run on its own it starts the N ranks
+itself (nanorq_amd.shard.spawn_ranks) and refuses (exit code 2) when fewer than N GPUs are visible.
 
 Workload (config.workload "cfg3"): BASELINE.json configs[2] -- K=8192 source symbols of T=1280 bytes per
 source block, 10 % independent random loss per block, decode with exactly K received symbols
@@ -86,6 +89,9 @@ def parse():
     ap.add_argument("--overhead", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0, help="host planner threads per rank (0 = cores / ranks)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="blocks timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--alg-sample", type=int, default=2,
+                    help="with --cpu-sample 0: blocks whose reference-equivalent op counts (SURVEY 8d) the oracle forms on a "
+                         "32-byte column slice, so that roofline.frac is there without the full-width CPU leg (0 = skip)")
     ap.add_argument("--no-replan", action="store_true", help="keep the encode plan cached across steps")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams per GPU: the step's blocks are split into this many groups, each on its own stream")
@@ -231,8 +237,8 @@ def pmc_collect(args):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     import sqlite3
-    inner = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--pmc", "off", "--no-e2e",
-             "--K", str(args.K), "--T", str(args.T), "--blocks", str(args.blocks), "--loss", str(args.loss), "--overhead", str(args.overhead)]
+    inner = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--alg-sample", "0", "--pmc", "off",
+             "--no-e2e", "--K", str(args.K), "--T", str(args.T), "--blocks", str(args.blocks), "--loss", str(args.loss), "--overhead", str(args.overhead)]
     if args.no_replan:
         inner.append("--no-replan")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -336,16 +342,74 @@ def e2e_leg(args):
                     "`value` of the bench line."}
 
 
+def config_name(K, T, loss, overhead):
+    """BASELINE.json's name for the configuration actually run (SURVEY.md section 8(d) restates them), else "custom"."""
+    table = {(100, 1024): "cfg1", (1024, 1280): "cfg2", (8192, 1280): "cfg3", (27000, 65504): "cfg4", (56403, 1280): "cfg5"}
+    name = table.get((K, T))
+    if name is None:
+        return "custom"
+    want_loss = {"cfg1": (0.0, 0.06), "cfg2": (0.05, 0.06), "cfg3": (0.10,), "cfg4": (0.10,), "cfg5": (0.20,)}[name]
+    if not any(abs(loss - w) < 1e-9 for w in want_loss):
+        return name + "-shape"      # the configuration's block shape at another loss rate
+    return name
+
+
+def algorithmic_sample(args, lost_np, nrep_enc, nblocks):
+    """n1 / nB / n0 of the reference-equivalent plan do not depend on T: the oracle run on a 32-byte column slice of synthetic
+    symbols gives the algorithmic bytes of SURVEY 8(d) per block when the full-width CPU leg is skipped (--cpu-sample 0) or
+    too big to run (cfg4: 1.77 GB per block)."""
+    import oracle
+    K, T, Ts = args.K, args.T, 32
+    prm = oracle.params(K)
+    esis = np.arange(K, K + nrep_enc, dtype=np.uint32)
+    rng = np.random.default_rng(99)
+    be = bd = 0.0
+    n = min(nblocks, len(lost_np))
+    for b in range(n):
+        src = rng.integers(0, 256, (K, Ts), dtype=np.uint8)
+        rep, _, st_e = oracle.encode_block(src, K, Ts, esis)
+        lost = lost_np[b]
+        keep = np.setdiff1d(np.arange(K, dtype=np.uint32), lost)
+        nr, ok = len(lost) + args.overhead, False
+        while not ok:
+            ok, out, st_d = oracle.decode_block(np.concatenate([keep, esis[:nr]]), np.concatenate([src[keep], rep[:nr]]), K, Ts)
+            nr += 1
+        assert np.array_equal(out, src)
+        be += algorithmic_bytes(st_e, K, T, prm["L"], K, st_e["gen_rows"])
+        bd += algorithmic_bytes(st_d, K, T, prm["L"], K + st_d["overhead"], st_d["gen_rows"])
+    return be / n, bd / n
+
+
 def main():
     args = parse()
+    from nanorq_amd import shard
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if not shard.launched():
+        if args.gpus > 1:
+            # `python bench.py --gpus N` on its own: this process becomes the launcher of N ranks (one process per GPU, RCCL for
+            # the barrier and the timing reduction only -- DESIGN.md section 8) and rank 0 prints the one line
+            if args.force_device < 0:
+                import torch
+                have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+                if have < args.gpus:
+                    sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible: refusing to print a line for fewer "
+                                     "GPUs than asked\n" % (args.gpus, have))
+                    raise SystemExit(2)
+            raise SystemExit(shard.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     import torch
     import nanorq_amd
     from util import loss_pattern
 
-    from nanorq_amd import shard
     rank, world, local = shard.env_rank()
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.force_device < 0 and local >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d has no GPU (%d visible)\n" % (rank, torch.cuda.device_count()))
+        raise SystemExit(2)
     e2e = e2e_leg(args) if (rank == 0 and world == 1 and not args.no_e2e and args.streams <= 1) else None
     if args.force_device >= 0:
         local = args.force_device
@@ -578,7 +642,7 @@ def main():
         check["oracle"] = True
     if args.digest_out:
         import hashlib
-        with open(args.digest_out, "w") as f:
+        with open(args.digest_out + (".rank%d" % rank if world > 1 else ""), "w") as f:
             json.dump({str(gb): hashlib.sha256(rep[b, :int(nr_first[b])].cpu().numpy().tobytes()).hexdigest()
                        for b, gb in enumerate(my_blocks)}, f)
 
@@ -610,6 +674,8 @@ def main():
         if args.cpu_sample > 0:
             src_np = src[:args.cpu_sample].cpu().numpy()
             cpu, balg_enc, balg_dec = cpu_baseline(args, src_np, lost, nrep)
+        elif args.alg_sample > 0:
+            balg_enc, balg_dec = algorithmic_sample(args, lost, nrep, args.alg_sample)
         # solve-kernel launches in the timed region: [encode, decode(, retries...)] per step
         roof = None
         if ktimes:
@@ -690,8 +756,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "cfg3: K=%d T=%d, %d blocks/GPU/step, %.0f%% loss, overhead %d, encode(+%d repair)"
-                                   "+decode" % (K, T, NB, args.loss * 100, args.overhead, nrep),
+            "config": {"workload": "%s: K=%d T=%d, %d blocks/GPU/step, %.0f%% loss, overhead %d, encode(+%d repair)"
+                                   "+decode" % (config_name(K, T, args.loss, args.overhead), K, T, NB, args.loss * 100, args.overhead,
+                                                nrep),
                        "K": K, "T": T, "blocks_per_gpu": NB, "loss": args.loss, "overhead": args.overhead,
                        "repair_per_block": nrep, "sharding": "blocks over GPUs, no collective",
                        "streams_per_gpu": nstreams,

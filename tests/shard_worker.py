@@ -27,9 +27,9 @@ def main():
     t0 = time.perf_counter()
     digests = {}
     for b in mine:
-        seed, blk = shard.block_seed(1, b)
-        src = payload(K * T, seed=seed, block=blk).reshape(K, T)
-        lost = loss_pattern(K, 0.1, seed=7, block=blk)
+        # payload and loss are functions of the GLOBAL block id: a block's content does not depend on how many ranks share the job
+        src = payload(K * T, seed=1, block=b).reshape(K, T)
+        lost = loss_pattern(K, 0.1, seed=7, block=b)
         esis = np.arange(K, K + len(lost) + 3, dtype=np.uint32)
         rep, _, _ = oracle.encode_block(src, K, T, esis)
         keep = np.setdiff1d(np.arange(K, dtype=np.uint32), lost)

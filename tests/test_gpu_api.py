@@ -174,9 +174,10 @@ def test_short_last_block_is_coded_with_block_zeros_table_row(orc):
 
 
 def test_two_ranks_through_the_real_library(tmp_path):
-    """The N>1 path of bench.py through libnanorq_hip.so: two ranks (gloo, both on GPU 0) shard 16 source blocks --
-    block b on rank b mod 2, no data-path collective -- and must produce, block for block, the repair symbols a
-    single rank produces for the same 16 blocks (per-block SHA-256); each rank's decode is verified inside bench.py."""
+    """The N>1 path of bench.py through libnanorq_hip.so, started the way the driver starts it: `python bench.py --gpus 2`
+    with a clean environment launches its two ranks itself (gloo, both on GPU 0), which shard 16 source blocks -- block b on
+    rank b mod 2, no data-path collective -- and must produce, block for block, the repair symbols a single rank produces
+    for the same 16 blocks (per-block SHA-256); each rank's decode is verified inside bench.py."""
     import json
     import os
     import subprocess
@@ -184,23 +185,28 @@ def test_two_ranks_through_the_real_library(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--K", "1024", "--T", "256", "--steps", "1", "--warmup", "1", "--cpu-sample", "0",
             "--pmc", "off", "--no-e2e", "--force-device", "0", "--dist-backend", "gloo"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
-    procs = []
-    for r in range(2):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2")
-        procs.append(subprocess.Popen(base + ["--gpus", "2", "--blocks", "8", "--digest-out", str(tmp_path / ("r%d.json" % r))], env=e,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
-    line = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][-1])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(base + ["--gpus", "2", "--blocks", "8", "--digest-out", str(tmp_path / "two.json")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE line"
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["check"]["oracle"]
-    e = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    r = subprocess.run(base + ["--gpus", "1", "--blocks", "16", "--digest-out", str(tmp_path / "solo.json")], env=e, stdout=subprocess.PIPE,
+    assert line["config"]["workload"].startswith("custom")
+    r = subprocess.run(base + ["--gpus", "1", "--blocks", "16", "--digest-out", str(tmp_path / "solo.json")], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()
-    two = dict(json.load(open(tmp_path / "r0.json")), **json.load(open(tmp_path / "r1.json")))
+    two = dict(json.load(open(str(tmp_path / "two.json") + ".rank0")), **json.load(open(str(tmp_path / "two.json") + ".rank1")))
     solo = json.load(open(tmp_path / "solo.json"))
     assert sorted(two, key=int) == [str(b) for b in range(16)] and two == solo
+    # under an external launcher (torch.distributed.run exports these) the process is one rank and starts nothing
+    e = dict(env, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
+    procs = [subprocess.Popen(base + ["--gpus", "2", "--blocks", "8"], env=dict(e, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE="2"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for k in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][-1])["n_gpus"] == 2
 
 
 # ------------------------------------------------------------------ streaming path (page-locked memory) ----

@@ -48,3 +48,39 @@ def test_two_rank_gloo_job(tmp_path):
     solo = json.load(open(solo_dir / "rank0.json"))
     merged = dict(recs[0]["digests"], **recs[1]["digests"])
     assert merged == solo["digests"]
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "LOCAL_WORLD_SIZE")}
+
+
+@pytest.mark.timeout(300)
+def test_spawn_ranks_starts_the_job_by_itself(tmp_path):
+    """bench.py --gpus N run on its own goes through shard.spawn_ranks: N processes with the launcher's environment, a
+    rendezvous on 127.0.0.1, the largest exit code back."""
+    total, K, T = 5, 48, 16
+    rc = shard.spawn_ranks(2, [sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), str(total), str(K), str(T), str(tmp_path)],
+                           env=dict(_clean_env(), OMP_NUM_THREADS="1"), timeout=280)
+    assert rc == 0
+    recs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert [r["world"] for r in recs] == [2, 2]
+    assert sorted(recs[0]["blocks"] + recs[1]["blocks"]) == list(range(total))
+    # a failing rank ends the job with its code
+    rc = shard.spawn_ranks(2, [sys.executable, "-c", "import os, sys, time; time.sleep(0 if os.environ['RANK'] == '1' else 30); sys.exit(3)"],
+                           env=_clean_env(), timeout=60)
+    assert rc == 3
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` must not print an n_gpus=1 line: without two devices it exits non-zero (no GPU here)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_clean_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 2 and b"refusing" in r.stderr and not r.stdout.strip()
+    # and a launcher that started another number of ranks than --gpus says is refused as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(_clean_env(), RANK="0", LOCAL_RANK="0",
+                       WORLD_SIZE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 2 and b"launcher started 1" in r.stderr
