@@ -522,8 +522,9 @@ def main():
             return r.sum(dtype=torch.int64)
         return torch.stack([dg(t, ix) for t, ix in ((rep_rows_all, ph_rep[ph]), (int_rows_all, ph_int[ph]), (wrows, ph_wrk[ph]))])
 
-    def step():
+    def step(ahead=None):
         nonlocal retries, step_no, ahead_out
+        ahead = plan_ahead if ahead is None else ahead
         enc_stats = dec_stats = None
         ph = step_no % NPHASE
         step_no += 1
@@ -553,11 +554,13 @@ def main():
             if not st.all():
                 raise RuntimeError("decode failed for %d blocks" % int((st == 0).sum()))
             retries += int((used - nr_first[lo:hi]).sum())
-            if plan_ahead:
+            if ahead:
                 # the decode plans of the NEXT steps (same reception pattern every step in this bench; a planner run per step
                 # all the same): enqueued now, they run beside this step's decode solve and the next steps' solves
                 if c_.stats().get("plan_ahead"):
                     ahead_out -= 1
+                else:
+                    ahead_out = 0   # (a decode that found no run issued for it has discarded the waiting ones)
                 while ahead_out < ahead_depth:
                     c_.decode_plan_ahead(K, T, n_, work[lo].data_ptr(), K * T, lost_arr[lo:hi], nlost[lo:hi], resi[lo:hi],
                                          nr_first[lo:hi], nr_avail[lo:hi], rep[lo].data_ptr(), nrep * T)
@@ -598,6 +601,21 @@ def main():
     ktimes = [d for _, d in intervals]
     rdev = dev if args.dist_backend == "nccl" else None
     elapsed = shard.reduce_max(elapsed, world, device=rdev)   # the slowest rank defines the step time
+    # the same step with the decode plan built INSIDE the decode call (a receiver that learns the reception pattern when it
+    # decodes): reported beside the headline, never `value`.  The runs still waiting are consumed first (untimed).
+    ms_plan_in_call = None
+    if plan_ahead and world == 1 and args.steps >= 2:
+        for c_ in ctxs:
+            c_.ktime_enable(False)
+        for _ in range(ahead_depth + 1):
+            step(ahead=False)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        nplain = min(args.steps, 5)
+        for _ in range(nplain):
+            step(ahead=False)
+        torch.cuda.synchronize(dev)
+        ms_plan_in_call = (time.perf_counter() - t1) / nplain * 1e3   # (these steps' digests are checked with the others)
     retries_total = int(shard.reduce_sum(retries, world, device=rdev))
 
     # ---- correctness of what was timed ----
@@ -770,6 +788,8 @@ def main():
                                        "beside the solves of the steps before it" % ahead_depth if plan_ahead else
                                        "inside the decode call"),
                        "decode_found_plan_ahead": bool(dec_stats.get("plan_ahead", 0)),
+                       "ms_per_step_plan_inside_decode_call": ms_plan_in_call,
+                       "value_plan_inside_decode_call": (8.0 * payload_step / (ms_plan_in_call * 1e-3) / 1e9) if ms_plan_in_call else None,
                        "decode_retries": retries_total, "spare_symbols_taken": retries_total,
                        "in_step": "damage of the receiver's copy (every lost row overwritten over its full width: %.0f MB of writes), "
                                   "poisoning of %d repair + %d intermediate rows of EVERY block and a digest of them and of %d decoded "

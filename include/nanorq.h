@@ -14,6 +14,19 @@
  *   - `nanorq` is opaque; one object is not thread-safe, distinct objects are independent;
  *   - `data` buffers are caller-owned and exactly nanorq_symbol_size() bytes;
  *   - the OTI words are nanorq's own packing (T-1, Z-1, N-1 stored), not RFC 6330 section 3.3.
+ *
+ * What a GPU behind the API adds, and its switches (environment, read once):
+ *   - the constructors pay the first-use costs -- GPU context, code object, the per-K' constants and (encoders) the encode plan:
+ *     tens of milliseconds (the host planner takes 25 ms at K=27000, the device-built plan of K'=56403 is waited for ~15 ms);
+ *     NANORQ_HIP_LAZY=1 leaves them to the first call that needs the GPU, for callers that construct an object only to read
+ *     its OTI;
+ *   - an ioctx_from_mem region of >= 1 MiB handed to nanorq_generate_symbols is page-locked in place on first use and stays
+ *     so until its destroy() (the block is then read by DMA, with no host copy); NANORQ_HIP_AUTOPIN=0 switches that off;
+ *   - nanorq_repair_block decodes, in the same device batch, the other decodable blocks of the object and hands their rows
+ *     out when their own call comes (same verdicts, same bytes); NANORQ_HIP_REPAIR_AHEAD=0 decodes one block per call;
+ *   - NANORQ_HIP_DEVICES=0,1,... / NANORQ_HIP_DEVICE=n choose the GPUs (nanorq_batch.h);
+ *   - the library runs six streams beside the caller's: a host process should export GPU_MAX_HW_QUEUES=8 before its first
+ *     HIP call (the library sets it when it is loaded and the variable is unset; NANORQ_HIP_NO_ENV=1 keeps its hands off).
  */
 #ifndef NANORQ_H
 #define NANORQ_H

@@ -80,6 +80,10 @@ size_t nanorq_decoder_flush(nanorq *rq, struct ioctx *io);
 size_t nanorq_devices(void); /* contexts in use (0: no GPU could be opened -- every call that needs one fails) */
 /* give back the page-locked host rows and device pool blocks cached from freed objects */
 void nanorq_trim(void);
+/* nrq_ctx_set_option (include/nanorq_hip.h) on the context of device number `dev` of the process (0 .. nanorq_devices() - 1):
+ * tuning switches and the fault injection the tests use ("fail_after").  Returns what nrq_ctx_set_option returns, -1 without
+ * such a device. */
+int nanorq_hip_option(size_t dev, const char *name, long long value);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,12 @@ struct blockst {
   bool dirty;         /* received source symbols have not reached the output context yet */
   uint32_t up_seq;    /* deferred ingestion: 1 + index (in the object's list for the block's device) of the last upload piece that
                        * carries symbols of this block; 0 = none in flight */
+  /* decoded ahead of its nanorq_repair_block call, in the device batch of an earlier block's call (repair_ahead below):
+   * 1 = recovered -- the rows are in `src`, the output context and the bitmap have not seen them yet --, 2 = rank deficient
+   * with the symbols held then (a new symbol clears it) */
+  int pre_state;
+  uint32_t *pre_lost; /* the ESIs that were missing when the block was decoded ahead */
+  uint32_t pre_n;
   /* encoder side: window of generated symbols */
   uint8_t *win;
   uint32_t win_isi0, win_n;
@@ -163,6 +169,13 @@ static nrq_ctx *dctx(int di) { return di < ndev() ? g_dev[di].c : NULL; }
 static void gpu_lock(int di) { pthread_mutex_lock(&g_dev[di].lock); }
 static void gpu_unlock(int di) { pthread_mutex_unlock(&g_dev[di].lock); }
 size_t nanorq_devices(void) { return (size_t)ndev(); }
+int nanorq_hip_option(size_t dev, const char *name, long long value) {
+  if (dev >= (size_t)ndev()) return -1;
+  gpu_lock((int)dev);
+  const int rc = nrq_ctx_set_option(g_dev[dev].c, name, value);
+  gpu_unlock((int)dev);
+  return rc;
+}
 void nanorq_trim(void); /* (below) */
 
 /* -------------------------------------------------------------------------- small helpers ---- */
@@ -482,7 +495,7 @@ void nanorq_encoder_cleanup(nanorq *rq, uint8_t sbn) { /* nanorq.c:437-451 */
   nrq_event_free(b->ev_up); nrq_event_free(b->ev_read[0]); nrq_event_free(b->ev_read[1]);
   host_free(b->src, b->src_pinned);
   host_free(b->rep_data, b->rep_pinned);
-  free(b->mask); free(b->rep_esi); free(b->win); free(b);
+  free(b->mask); free(b->rep_esi); free(b->win); free(b->pre_lost); free(b);
   rq->blocks[sbn] = NULL;
 }
 
@@ -497,6 +510,7 @@ void nanorq_encoder_reset(nanorq *rq, uint8_t sbn) { /* nanorq.c:453-469 */
   b->nrep = 0;
   b->win_n = 0;
   b->have = 0;
+  b->pre_state = 0;
   if (b->dev && b->up_seq) settle_uploads(rq, b->di);
   if (b->dev) drop_device(b); /* a device-resident decoder block: its rows go back to the pool (the next packet batch allocates anew) */
   b->dev = b->dirty = false;
@@ -686,9 +700,11 @@ size_t nanorq_encode(nanorq *rq, void *data, uint32_t esi, uint8_t sbn, struct i
   if (!b) return 0;
   const size_t T = rq->T;
   if (esi < b->K) {
-    /* before the solve: the source symbol itself; after it the reference regenerates the same bytes from
-     * the intermediate symbols (RFC 6330 is systematic) -- either way the loaded source row (a block that was
-     * solved straight out of a page-locked context is read here on first use) */
+    /* before the solve: the source symbol itself (nanorq.c:414-421).  After it the reference regenerates the symbol from the
+     * intermediate symbols, whatever has become of the io since (nanorq.c:410-413): a block that was solved straight out of
+     * the caller's memory (no host copy) does the same -- LT(C, esi) on the device; with a host copy the loaded row is those
+     * bytes (RFC 6330 is systematic). */
+    if (b->inverted && !b->loaded) return fetch_symbol(rq, b, esi, data) ? T : 0;
     if (!b->loaded) b->loaded = load_block(rq, sbn, b, io);
     if (!b->loaded) return 0;
     memcpy(data, b->src + (size_t)esi * T, T);
@@ -740,6 +756,7 @@ int nanorq_decoder_add_symbol(nanorq *rq, void *data, uint32_t tag, struct ioctx
   if (mask_get(b, esi)) return NANORQ_SYM_DUP;
   const size_t T = rq->T;
   if (b->dev && b->up_seq) settle_uploads(rq, b->di); /* (a deferred batch is still being sorted into this block's rows) */
+  if (b->pre_state == 2) b->pre_state = 0; /* (the verdict formed ahead was for the symbols held then; a recovered block stays recovered) */
   if (esi < b->K) {
     if (b->dev) {
       if (!dev_put_row(rq, b, (uint8_t *)b->d_src + (size_t)esi * T, data)) return NANORQ_SYM_ERR;
@@ -826,10 +843,83 @@ static bool flush_dev_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct i
   return true;
 }
 
+/* The unchanged caller's decode loop (reference benchmark.c:143-151, decode.c: `for sbn: nanorq_repair_block`) asks for the
+ * blocks of an object one call at a time; behind a GPU every call is a planner run the host waits for, a solve launch and a
+ * PCIe round trip for ONE block.  So the first call decodes, in the same device batch, every other host-resident block of
+ * the same size on the same device that is decodable right now -- one planner run and one solve launch for all of them --
+ * and leaves their recovered rows in the blocks' host rows with the verdict (blockst::pre_state); the calls that follow
+ * commit them (rows to the output context, bitmap) without touching the GPU.  What a call returns and writes is what the
+ * reference's call does: the verdict is the block's own, a rank-deficient block stays retryable (a new symbol clears the
+ * cached verdict), a recovered block stays recovered whatever arrives later (the solution is unique).
+ * NANORQ_HIP_REPAIR_AHEAD=0 switches it off (one block per call). */
+static bool repair_ahead_on(void) {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("NANORQ_HIP_REPAIR_AHEAD");
+    on = (e && *e == '0') ? 0 : 1;
+  }
+  return on != 0;
+}
+static bool block_decodable(const struct blockst *b) {
+  if (!b || b->K == 0) return false;
+  const size_t gaps = mask_gaps(b, b->K);
+  return gaps > 0 && b->nrep >= gaps && b->nrep - gaps <= b->spare;
+}
+/* recovered rows of a host-resident block: to the output context and into the bitmap (write_repair_rows, nanorq.c:579-589) */
+static void commit_rows(nanorq *rq, uint8_t sbn, struct blockst *b, const uint32_t *lost, size_t n, struct ioctx *io) {
+  for (size_t k = 0; k < n; k++) {
+    if (io) transfer_symbol(rq, sbn, lost[k], b->K, b->src + (size_t)lost[k] * rq->T, io, 1);
+    mask_set(b, lost[k]);
+  }
+}
+/* decode the host-resident blocks `sbns` (equal K, one device) in one device batch; status[k] = 1 recovered (rows in the
+ * block's host rows), 0 rank deficient; lost lists at lost + k * lost_cap.  false: a device error (nothing is valid). */
+static bool decode_host_blocks(nanorq *rq, int di, const unsigned *sbns, unsigned n, uint32_t *lost, uint32_t *nlost, size_t lost_cap,
+                               int *status) {
+  nrq_ctx *c = dctx(di);
+  const size_t T = rq->T;
+  size_t rep_cap = 0;
+  for (unsigned k = 0; k < n; k++)
+    if (rq->blocks[sbns[k]]->nrep > rep_cap) rep_cap = rq->blocks[sbns[k]]->nrep;
+  uint32_t *resi = calloc((size_t)n * rep_cap, sizeof(uint32_t)), *nuse = calloc(n, sizeof(uint32_t)), *navail = calloc(n, sizeof(uint32_t));
+  uint64_t *sv = calloc(n, sizeof(uint64_t)), *rv = calloc(n, sizeof(uint64_t));
+  void **tmp = calloc(n, sizeof(void *));
+  bool ok = resi && nuse && navail && sv && rv && tmp;
+  const struct blockst *b0 = rq->blocks[sbns[0]];
+  const size_t bytes = (size_t)b0->K * T;
+  gpu_lock(di);
+  for (unsigned k = 0; k < n && ok; k++) {
+    struct blockst *b = rq->blocks[sbns[k]];
+    nlost[k] = list_lost(b, lost + (size_t)k * lost_cap);
+    nuse[k] = rep_upfront(nlost[k], b->nrep);
+    navail[k] = (uint32_t)b->nrep;
+    memcpy(resi + (size_t)k * rep_cap, b->rep_esi, b->nrep * sizeof(uint32_t));
+    ok = ensure_src(rq, b) && (b->d_src || nrq_dev_alloc(c, bytes, &b->d_src) == 0) && nrq_dev_alloc(c, b->nrep * T, &tmp[k]) == 0 &&
+         nrq_dev_upload_async(c, b->d_src, b->src, bytes) == 0 && nrq_dev_upload_async(c, tmp[k], b->rep_data, b->nrep * T) == 0;
+    sv[k] = (uint64_t)(uintptr_t)b->d_src;
+    rv[k] = (uint64_t)(uintptr_t)tmp[k];
+  }
+  ok = ok && nrq_decode_blocks_v(c, b0->K, b0->Kp, (uint32_t)T, n, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv,
+                                 status, NULL) == 0;
+  for (unsigned k = 0; k < n && ok; k++)
+    if (status[k]) ok = nrq_dev_download_async(c, rq->blocks[sbns[k]]->src, rq->blocks[sbns[k]]->d_src, bytes) == 0;
+  ok = nrq_ctx_sync(c) == 0 && ok; /* (also on failure: the temporaries below may be in use) */
+  for (unsigned k = 0; k < n && tmp; k++)
+    if (tmp[k]) nrq_dev_free(c, tmp[k]);
+  gpu_unlock(di);
+  free(resi); free(nuse); free(navail); free(sv); free(rv); free(tmp);
+  return ok;
+}
+
 bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.c:591-631 */
   struct blockst *b = get_block(rq, sbn);
   if (!b) return false;
   if (b->up_seq) settle_uploads(rq, b->di); /* (symbols of a deferred batch still on their way) */
+  if (b->pre_state == 1) { /* decoded in the batch of an earlier call: commit */
+    commit_rows(rq, sbn, b, b->pre_lost, b->pre_n, io);
+    b->pre_state = 0;
+    return mask_gaps(b, b->K) == 0;
+  }
   const size_t gaps = mask_gaps(b, b->K);
   nrq_ctx *c = dctx(b->di);
   if (gaps == 0) {
@@ -844,47 +934,70 @@ bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.
   const size_t overhead = b->nrep - gaps;
   if (overhead > b->spare) return false; /* D.rows < L + overhead in the reference */
   if (!c) return false;
-  const size_t T = rq->T, bytes = (size_t)b->K * T;
-  uint32_t *lost = malloc(gaps * sizeof(uint32_t));
-  if (!lost) return false;
-  list_lost(b, lost);
-  bool ok = false;
-  void *d_rep = NULL;
-  uint32_t nlost = (uint32_t)gaps, nuse = rep_upfront(gaps, b->nrep), navail = (uint32_t)b->nrep, used = 0;
-  int status = 0;
-  gpu_lock(b->di);
+  if (b->pre_state == 2) { b->pre_state = 0; return false; } /* found rank deficient ahead, and nothing has arrived since */
+  const size_t T = rq->T;
   if (b->dev) {
+    uint32_t *lost = malloc(gaps * sizeof(uint32_t));
+    if (!lost) return false;
+    list_lost(b, lost);
+    bool ok = false;
+    uint32_t nlost = (uint32_t)gaps, nuse = rep_upfront(gaps, b->nrep), navail = (uint32_t)b->nrep, used = 0;
+    int status = 0;
+    gpu_lock(b->di);
     const uint64_t sv = (uint64_t)(uintptr_t)b->d_src, rv = (uint64_t)(uintptr_t)b->d_rep;
-    if (nrq_decode_blocks_v(c, b->K, b->Kp, (uint32_t)T, 1, &sv, lost, &nlost, nlost, b->rep_esi, &nuse, &navail, navail, &rv, &status, &used) != 0) goto out;
-    if (!status) goto out;
-    for (size_t k = 0; k < gaps; k++) mask_set(b, lost[k]);
-    if (nrq_ctx_sync(c) != 0) goto out; /* the recovered rows are in d_src */
-    if (io) {
-      if (!flush_dev_block(rq, sbn, b, io, true) || nrq_stream_sync(c, 2) != 0) goto out;
-      b->dirty = false;
+    if (nrq_decode_blocks_v(c, b->K, b->Kp, (uint32_t)T, 1, &sv, lost, &nlost, nlost, b->rep_esi, &nuse, &navail, navail, &rv, &status, &used) == 0 &&
+        status) {
+      for (size_t k = 0; k < gaps; k++) mask_set(b, lost[k]);
+      if (nrq_ctx_sync(c) == 0) { /* the recovered rows are in d_src */
+        ok = true;
+        if (io) {
+          ok = flush_dev_block(rq, sbn, b, io, true) && nrq_stream_sync(c, 2) == 0;
+          if (ok) b->dirty = false;
+        }
+      }
     }
-    ok = true;
-    goto out;
+    gpu_unlock(b->di);
+    free(lost);
+    return ok;
   }
-  if (!ensure_src(rq, b)) goto out;
-  if (!b->d_src && nrq_dev_alloc(c, bytes, &b->d_src) != 0) goto out;
-  if (nrq_dev_alloc(c, b->nrep * T, &d_rep) != 0) goto out;
-  if (nrq_dev_upload_async(c, b->d_src, b->src, bytes) != 0) goto out;
-  if (nrq_dev_upload_async(c, d_rep, b->rep_data, b->nrep * T) != 0) goto out;
-  if (nrq_decode_blocks_lazy(c, b->K, b->Kp, (uint32_t)T, 1, b->d_src, bytes, lost, &nlost, nlost, b->rep_esi, &nuse, &navail, navail, d_rep,
-                             b->nrep * T, NULL, 0, &status, &used) != 0)
-    goto out;
-  if (!status) { nrq_ctx_sync(c); goto out; } /* rank deficient: retry after more symbols (nanorq.c:620-623) */
-  if (nrq_dev_download(c, b->src, b->d_src, bytes) != 0) goto out;
-  for (size_t k = 0; k < gaps; k++) { /* write_repair_rows, nanorq.c:579-589 */
-    if (io) transfer_symbol(rq, sbn, lost[k], b->K, b->src + (size_t)lost[k] * T, io, 1);
-    mask_set(b, lost[k]);
+  /* host-resident: this block and, in the same device batch, the other blocks of its size that can be decoded now */
+  unsigned sbns[NRQ_Z_MAX], n = 0;
+  size_t lost_cap = gaps;
+  sbns[n++] = sbn;
+  if (repair_ahead_on()) {
+    const size_t Z = nanorq_blocks(rq);
+    size_t batch_bytes = (size_t)b->K * T;
+    for (unsigned s2 = 0; s2 < Z; s2++) {
+      const struct blockst *o = rq->blocks[s2];
+      if (s2 == sbn || !o || o->dev || o->di != b->di || o->K != b->K || o->Kp != b->Kp || o->pre_state || o->up_seq || !block_decodable(o)) continue;
+      if (batch_bytes + (size_t)o->K * T > ((size_t)2 << 30)) break; /* (bounded device footprint per call) */
+      batch_bytes += (size_t)o->K * T;
+      const size_t g2 = mask_gaps(o, o->K);
+      if (g2 > lost_cap) lost_cap = g2;
+      sbns[n++] = s2;
+    }
   }
-  ok = mask_gaps(b, b->K) == 0;
-out:
-  if (d_rep) { nrq_ctx_sync(c); nrq_dev_free(c, d_rep); }
-  gpu_unlock(b->di);
-  free(lost);
+  uint32_t *lost = malloc((size_t)n * lost_cap * sizeof(uint32_t)), *nlost = calloc(n, sizeof(uint32_t));
+  int *status = calloc(n, sizeof(int));
+  bool ok = lost && nlost && status && decode_host_blocks(rq, b->di, sbns, n, lost, nlost, lost_cap, status);
+  if (ok) {
+    for (unsigned k = 1; k < n; k++) { /* the others: rows and verdict wait for their own call */
+      struct blockst *o = rq->blocks[sbns[k]];
+      if (!status[k]) { o->pre_state = 2; continue; }
+      uint32_t *pl = realloc(o->pre_lost, (size_t)(nlost[k] ? nlost[k] : 1) * sizeof(uint32_t));
+      if (!pl) continue; /* (no memory for the list: the block is decoded again by its own call) */
+      memcpy(pl, lost + (size_t)k * lost_cap, (size_t)nlost[k] * sizeof(uint32_t));
+      o->pre_lost = pl;
+      o->pre_n = nlost[k];
+      o->pre_state = 1;
+    }
+    ok = status[0] != 0; /* rank deficient: retry after more symbols (nanorq.c:620-623) */
+    if (ok) {
+      commit_rows(rq, sbn, b, lost, nlost[0], io);
+      ok = mask_gaps(b, b->K) == 0;
+    }
+  }
+  free(lost); free(nlost); free(status);
   return ok;
 }
 
@@ -1147,6 +1260,9 @@ static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, size_t k
   void *p = NULL;
   gpu_lock(b->di);
   bool ok = nrq_dev_alloc(c, nc * rq->T, &p) == 0;
+  /* a deferred batch may still be sorting symbols into the rows that are copied (on the sorting stream, which nothing else
+   * orders against the upload stream): the copy waits for the block's last piece */
+  if (ok && b->d_rep && keep && b->up_seq && b->up_seq <= rq->up[b->di].nev) ok = nrq_stream_wait(c, 1, rq->up[b->di].ev[b->up_seq - 1u]) == 0;
   if (ok && b->d_rep && keep) ok = nrq_copy_on(c, 1, p, b->d_rep, keep * rq->T) == 0;
   if (!ok && p) nrq_dev_free(c, p);
   gpu_unlock(b->di);
@@ -1551,12 +1667,20 @@ static void *repair_all_worker(void *arg) {
         }
         sv[k] = (uint64_t)(uintptr_t)b->d_src;
       }
-      if (any_up && ok) ok = nrq_event_new(c, &ev_up[ci]) == 0 && nrq_event_record(c, ev_up[ci], 1) == 0; /* (behind every earlier piece too) */
-      else if (ok) { /* device-resident blocks fed by a deferred batch: the chunk waits for the last piece any of them is in */
-        uint32_t seq = 0;
-        for (unsigned k = c0; k < c0 + m; k++)
-          if (rq->blocks[todo[k]]->up_seq > seq) seq = rq->blocks[todo[k]]->up_seq;
-        if (seq && seq <= rq->up[di].nev) { ev_up[ci] = rq->up[di].ev[seq - 1u]; ev_up_borrowed[ci] = true; }
+      /* device-resident blocks fed by a deferred batch: the chunk waits for the last piece any of them is in */
+      uint32_t seq = 0;
+      for (unsigned k = c0; k < c0 + m; k++)
+        if (rq->blocks[todo[k]]->up_seq > seq) seq = rq->blocks[todo[k]]->up_seq;
+      if (seq > rq->up[di].nev) seq = 0;
+      if (any_up && ok) {
+        /* host-resident blocks in the chunk too: ONE event for both -- recorded on the upload stream behind this chunk's
+         * copies, after that stream has been made to wait for the deferred piece (whose sort runs on another stream: the
+         * upload stream's own order does not cover it) */
+        if (seq) ok = nrq_stream_wait(c, 1, rq->up[di].ev[seq - 1u]) == 0;
+        ok = ok && nrq_event_new(c, &ev_up[ci]) == 0 && nrq_event_record(c, ev_up[ci], 1) == 0;
+      } else if (ok && seq) {
+        ev_up[ci] = rq->up[di].ev[seq - 1u];
+        ev_up_borrowed[ci] = true;
       }
     }
     ok = ok && nrq_decode_blocks_vc(c, K, Kp, (uint32_t)T, n, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv, status,
@@ -1618,6 +1742,12 @@ static void *repair_all_worker(void *arg) {
 }
 size_t nanorq_repair_all(nanorq *rq, struct ioctx *io) {
   const size_t Z = nanorq_blocks(rq);
+  for (unsigned sbn = 0; sbn < Z; sbn++) { /* blocks an earlier nanorq_repair_block call decoded ahead (repair_ahead): commit / forget */
+    struct blockst *b = rq->blocks[sbn];
+    if (!b || !b->pre_state) continue;
+    if (b->pre_state == 1) commit_rows(rq, (uint8_t)sbn, b, b->pre_lost, b->pre_n, io);
+    b->pre_state = 0;
+  }
   if (ndev()) {
     struct all_job j;
     memset(&j, 0, sizeof(j));

@@ -989,6 +989,8 @@ struct PlanRun;
 static void plan_ahead_drop(struct nrq_ctx *ctx);
 struct nrq_ctx {
   int device = 0;
+  long long fail_after = 0;      /* fault injection: checked runtime calls until the injected failure (0 = off) */
+  long long faults_injected = 0;
   Tuning tune;
   int ncu = 256; /* compute units of the device */
   hipStream_t stream = nullptr;
@@ -1063,6 +1065,13 @@ struct nrq_ctx {
 
 namespace {
 
+static inline bool nrq_inject(nrq_ctx *ctx) {
+  if (!ctx || ctx->fail_after <= 0) return false;
+  if (--ctx->fail_after > 0) return false;
+  ctx->faults_injected++;
+  return true;
+}
+
 int fail(nrq_ctx *ctx, int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
@@ -1073,9 +1082,14 @@ int fail(nrq_ctx *ctx, int code, const char *fmt, ...) {
   return code;
 }
 
+/* Fault injection (nrq_ctx_set_option "fail_after" n): the n-th checked runtime call of the context from now on -- an
+ * allocation, a copy, an event or stream operation, the error check behind a launch -- is not made and reports an error
+ * instead, once.  The tests drive the error paths of the object layer with it (rollback of a packet batch, a failed chunk of
+ * nanorq_repair_all, ...); nothing else sets it. */
+static inline bool nrq_inject(nrq_ctx *ctx);
 #define HIPCHK(ctx, call)                                                                                   \
   do {                                                                                                      \
-    hipError_t e_ = (call);                                                                                 \
+    hipError_t e_ = nrq_inject(ctx) ? hipErrorUnknown : (call);                                             \
     if (e_ != hipSuccess) return fail(ctx, -10, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
                                       __FILE__, __LINE__);                                                  \
   } while (0)
@@ -1704,11 +1718,20 @@ int nrq_params(uint32_t K, uint32_t out[10]) {
   return 0;
 }
 
-int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
-  /* (the runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues, 4 by default; a context runs up to six
-   * streams beside the caller's, and two streams on one queue execute one after the other.  Only effective when this is the
-   * process's first HIP call; a host that initialises the runtime itself sets the variable itself, as bench.py does.) */
+/* The runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues, 4 by default; a context runs up to six
+ * streams beside the caller's, and two streams on one queue execute one after the other (seen as the encode-plan build
+ * serialised into the solve stream).  The variable must be there before the runtime initialises, so it is set -- if unset --
+ * when the library is LOADED, not from nrq_ctx_create: a load-time constructor runs before the library's first HIP call and,
+ * in the usual case of a library linked at program start, before the process has other threads that could be reading the
+ * environment.  A host that initialises HIP before loading this library sets the variable itself (bench.py does);
+ * NANORQ_HIP_NO_ENV=1 makes the library leave the environment alone. */
+__attribute__((constructor)) static void nrq_env_at_load(void) {
+  const char *e = getenv("NANORQ_HIP_NO_ENV");
+  if (e && *e == '1') return;
   setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
+int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
   if (!out) return -1;
   *out = nullptr;
   int ndev = 0;
@@ -1880,6 +1903,8 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "plan_ucap") t.plan_ucap = (uint32_t)value;
   else if (n == "plan_wrong_instance") t.plan_wrong_instance = value != 0;
   else if (n == "plan_no_wg128") t.plan_no_wg128 = value != 0;
+  else if (n == "fail_after") ctx->fail_after = value > 0 ? value : 0;
+  else if (n == "faults_injected") return (int)ctx->faults_injected; /* (read: injected failures so far) */
   else return fail(ctx, -1, "unknown option %s", name);
   return 0;
 }
@@ -2595,6 +2620,7 @@ int nrq_dev_alloc(nrq_ctx *ctx, size_t bytes, void **out) {
     ctx->pool_free.erase(it);
     return 0;
   }
+  if (nrq_inject(ctx)) { *out = nullptr; return fail(ctx, -10, "hipMalloc(%zu) failed: injected fault", want); }
   hipError_t e = hipMalloc(out, want);
   if (e != hipSuccess && !ctx->pool_free.empty()) { /* give the cached blocks back and try once more */
     (void)hipGetLastError();
