@@ -1,5 +1,5 @@
 # Runs ON THE GPU BOX: kernel timeline (three queues) of the last steps of a big-block config, plan-ahead off / depth 1 / 2
-#   bash tools/tl_big.sh K T blocks loss
+#   bash tools/timeline.sh K T blocks loss
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/tlb
