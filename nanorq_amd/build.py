@@ -45,9 +45,11 @@ def _deps():
     return out
 
 
-def build_lib(force=False, verbose=False, out=None, extra=()):
+def build_lib(force=False, verbose=False, out=None, extra=(), host_extra=(), reuse_hip_obj=False):
     """Build libnanorq_hip.so.  `out`/`extra` build a tuning variant (other file, extra compiler flags) that
-    NANORQ_HIP_LIB=<path> makes the binding load instead -- for A/B runs on the GPU box."""
+    NANORQ_HIP_LIB=<path> makes the binding load instead -- for A/B runs on the GPU box.  `host_extra`: flags for the C / C++
+    host sources only (gcc / g++: the sanitizer builds of tools/sanitize.sh); `reuse_hip_obj`: take the kernels' object of the
+    regular build instead of compiling nrq_device.hip again."""
     if out is None and not force and not _newer(LIB, _deps()):
         return LIB
     hipcc = _hipcc()
@@ -64,6 +66,9 @@ def build_lib(force=False, verbose=False, out=None, extra=()):
 
     for s in HIP_SOURCES:
         o = os.path.join(objdir, s + ".o")
+        if reuse_hip_obj and os.path.exists(os.path.join(HERE, "build", s + ".o")):
+            objs.append(os.path.join(HERE, "build", s + ".o"))
+            continue
         if stale(o, os.path.join(CSRC, s)):
             subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", *common, "-c", os.path.join(CSRC, s), "-o", o],
                            check=True)
@@ -71,7 +76,7 @@ def build_lib(force=False, verbose=False, out=None, extra=()):
     for s in CXX_SOURCES:
         o = os.path.join(objdir, s + ".o")
         if stale(o, os.path.join(CSRC, s)):
-            subprocess.run(["g++", "-std=c++17", "-Wall", *common, "-c", os.path.join(CSRC, s), "-o", o], check=True)
+            subprocess.run(["g++", "-std=c++17", "-Wall", *common, *host_extra, "-c", os.path.join(CSRC, s), "-o", o], check=True)
         objs.append(o)
     for s in C_SOURCES:
         src = os.path.join(CSRC, s)
@@ -79,7 +84,7 @@ def build_lib(force=False, verbose=False, out=None, extra=()):
             continue
         o = os.path.join(objdir, s + ".o")
         if stale(o, src):
-            subprocess.run(["gcc", "-std=gnu11", "-Wall", "-D_FILE_OFFSET_BITS=64", *common, "-c", src, "-o", o], check=True)
+            subprocess.run(["gcc", "-std=gnu11", "-Wall", "-D_FILE_OFFSET_BITS=64", *common, *host_extra, "-c", src, "-o", o], check=True)
         objs.append(o)
     target = out or LIB
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target, *objs, "-lpthread"], check=True)

@@ -718,8 +718,11 @@ size_t nanorq_encode(nanorq *rq, void *data, uint32_t esi, uint8_t sbn, struct i
 
 /* ------------------------------------------------------------------------- decoding ---- */
 static bool rep_reserve_host(nanorq *rq, struct blockst *b) { /* room for one more repair symbol (esi list + host bytes) */
-  if (b->nrep < b->rep_cap) return true;
-  const size_t nc = b->rep_cap ? b->rep_cap * 2 : 64, T = rq->T;
+  /* (a block that became device-resident in a batch that was then taken back is host-resident again with an ESI list but no
+   * host bytes behind it: found by the fault-injection sweep under UBSan) */
+  const bool no_bytes = !b->dev && !b->rep_data;
+  if (b->nrep < b->rep_cap && !no_bytes) return true;
+  const size_t nc = b->nrep < b->rep_cap ? b->rep_cap : (b->rep_cap ? b->rep_cap * 2 : 64), T = rq->T;
   uint32_t *e = realloc(b->rep_esi, nc * sizeof(uint32_t));
   if (!e) return false;
   b->rep_esi = e;
@@ -903,7 +906,7 @@ static bool decode_host_blocks(nanorq *rq, int di, const unsigned *sbns, unsigne
                                  status, NULL) == 0;
   for (unsigned k = 0; k < n && ok; k++)
     if (status[k]) ok = nrq_dev_download_async(c, rq->blocks[sbns[k]]->src, rq->blocks[sbns[k]]->d_src, bytes) == 0;
-  ok = nrq_ctx_sync(c) == 0 && ok; /* (also on failure: the temporaries below may be in use) */
+  ok = (nrq_ctx_sync(c) == 0 || nrq_ctx_sync(c) == 0) && ok; /* (also on failure, and twice: the temporaries below may be in use) */
   for (unsigned k = 0; k < n && tmp; k++)
     if (tmp[k]) nrq_dev_free(c, tmp[k]);
   gpu_unlock(di);
@@ -947,13 +950,14 @@ bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.
     const uint64_t sv = (uint64_t)(uintptr_t)b->d_src, rv = (uint64_t)(uintptr_t)b->d_rep;
     if (nrq_decode_blocks_v(c, b->K, b->Kp, (uint32_t)T, 1, &sv, lost, &nlost, nlost, b->rep_esi, &nuse, &navail, navail, &rv, &status, &used) == 0 &&
         status) {
-      for (size_t k = 0; k < gaps; k++) mask_set(b, lost[k]);
       if (nrq_ctx_sync(c) == 0) { /* the recovered rows are in d_src */
         ok = true;
         if (io) {
           ok = flush_dev_block(rq, sbn, b, io, true) && nrq_stream_sync(c, 2) == 0;
           if (ok) b->dirty = false;
         }
+        if (ok) /* (only now: a block counts as complete when its rows are where the caller will look for them) */
+          for (size_t k = 0; k < gaps; k++) mask_set(b, lost[k]);
       }
     }
     gpu_unlock(b->di);
@@ -1605,6 +1609,12 @@ static void *repair_all_worker(void *arg) {
   nrq_ctx *c = g_dev[di].c;
   const size_t Z = nanorq_blocks(rq), T = rq->T;
   gpu_lock(di);
+  /* Nothing is believed before it is known to have happened: a block's bitmap (and the "output has not seen these rows" flag of
+   * a device-resident block) changes only after the copies that carry its rows have been WAITED for successfully.  (The fault
+   * sweep of tools/sanitize_exercise.c: with a copy or a wait failing, a block used to count as complete while its rows had
+   * not reached the output context.) */
+  unsigned char wrote[NRQ_Z_MAX]; /* device-resident blocks whose rows were enqueued for the output: 1 = all rows, 2 = the received ones */
+  memset(wrote, 0, sizeof(wrote));
   for (uint32_t cls = 0; cls < 2; cls++) {
     unsigned todo[NRQ_Z_MAX], n = 0;
     uint32_t K = 0, Kp = 0;
@@ -1616,8 +1626,9 @@ static void *repair_all_worker(void *arg) {
       const size_t gaps = mask_gaps(b, b->K);
       if (gaps == 0) { /* complete; a device-resident block may still owe the output its received symbols */
         if (b->dev && b->dirty && io) {
-          if (b->up_seq && b->up_seq <= rq->up[di].nev) nrq_stream_wait(c, 2, rq->up[di].ev[b->up_seq - 1u]); /* (still on their way up) */
-          if (flush_dev_block(rq, (uint8_t)sbn, b, io, true)) b->dirty = false; /* (the sync is at the end) */
+          bool fl = true;
+          if (b->up_seq && b->up_seq <= rq->up[di].nev) fl = nrq_stream_wait(c, 2, rq->up[di].ev[b->up_seq - 1u]) == 0; /* (still on their way up) */
+          if (fl && flush_dev_block(rq, (uint8_t)sbn, b, io, true)) wrote[sbn] = 1; /* (committed behind the sync at the end) */
         }
         continue;
       }
@@ -1639,12 +1650,13 @@ static void *repair_all_worker(void *arg) {
     uint32_t *lost = calloc((size_t)n * lost_cap, sizeof(uint32_t)), *nlost = calloc(n, sizeof(uint32_t));
     uint32_t *resi = calloc((size_t)n * rep_cap, sizeof(uint32_t)), *nuse = calloc(n, sizeof(uint32_t)), *navail = calloc(n, sizeof(uint32_t));
     int *status = calloc(n, sizeof(int));
+    bool *dev_done = calloc(n, sizeof(bool)); /* device-resident blocks whose recovered rows are (enqueued to be) where they belong */
     uint64_t *sv = calloc(n, sizeof(uint64_t)), *rv = calloc(n, sizeof(uint64_t));
     void **ev_done = calloc(nch, sizeof(void *)), **ev_up = calloc(nch, sizeof(void *)), **ev_dl = calloc(nch, sizeof(void *));
     bool *ev_up_borrowed = calloc(nch, sizeof(bool)); /* (an event of the deferred ingestion: released by settle_uploads) */
     void *tmp_rep[NRQ_Z_MAX]; /* device copies of host-resident blocks' repair symbols (freed at the end) */
     unsigned ntmp = 0;
-    bool ok = lost && nlost && resi && nuse && navail && status && sv && rv && ev_done && ev_up && ev_dl && ev_up_borrowed;
+    bool ok = lost && nlost && resi && nuse && navail && status && dev_done && sv && rv && ev_done && ev_up && ev_dl && ev_up_borrowed;
     for (unsigned ci = 0; ci < nch && ok; ci++) ok = nrq_event_new(c, &ev_done[ci]) == 0 && nrq_event_new(c, &ev_dl[ci]) == 0;
     for (unsigned c0 = 0, ci = 0; c0 < n && ok; c0 += C, ci++) { /* lists, and what has to go up, chunk by chunk */
       const unsigned m = n - c0 < C ? n - c0 : C;
@@ -1693,13 +1705,13 @@ static void *repair_all_worker(void *arg) {
         struct blockst *b = rq->blocks[todo[k]];
         const uint8_t sbn = (uint8_t)todo[k];
         if (!status[k]) { /* rank deficient: retry after more symbols (nanorq.c:620-623); what was received is written */
-          if (b->dev && b->dirty && io && flush_dev_block(rq, sbn, b, io, false)) b->dirty = false;
+          if (b->dev && b->dirty && io && flush_dev_block(rq, sbn, b, io, false)) wrote[sbn] = 2;
           continue;
         }
         if (b->dev) {
           if (io) ok = flush_dev_block(rq, sbn, b, io, true);
-          for (uint32_t q = 0; q < nlost[k]; q++) mask_set(b, lost[(size_t)k * lost_cap + q]);
-          if (io && ok) b->dirty = false;
+          if (ok) wrote[sbn] = 1; /* (bitmap and flag: behind the sync at the end) */
+          dev_done[k] = ok;
         } else {
           ok = nrq_copy_on(c, 2, b->src, b->d_src, sbytes) == 0;
           any_host = true;
@@ -1723,9 +1735,17 @@ static void *repair_all_worker(void *arg) {
       }
       pthread_mutex_unlock(&rq->io_lock);
     }
-    nrq_ctx_sync(c);
-    nrq_stream_sync(c, 1);
-    nrq_stream_sync(c, 2);
+    /* (each wait is tried twice: the temporaries below must not be freed under work in flight whatever the first attempt said) */
+    const bool s0 = nrq_ctx_sync(c) == 0 || nrq_ctx_sync(c) == 0, s1 = nrq_stream_sync(c, 1) == 0 || nrq_stream_sync(c, 1) == 0;
+    const bool s2 = nrq_stream_sync(c, 2) == 0;
+    if (ok && s0 && s1 && s2 && dev_done)
+      for (unsigned k = 0; k < n; k++) { /* device-resident blocks: recovered, and (with an output context) written */
+        if (!dev_done[k]) continue;
+        struct blockst *b = rq->blocks[todo[k]];
+        for (uint32_t q = 0; q < nlost[k]; q++) mask_set(b, lost[(size_t)k * lost_cap + q]);
+      }
+    else
+      for (unsigned k = 0; k < n; k++) wrote[todo[k]] = 0;
     for (unsigned i = 0; i < ntmp; i++) nrq_dev_free(c, tmp_rep[i]);
     for (unsigned ci = 0; ci < nch; ci++) {
       if (ev_done) nrq_event_free(ev_done[ci]);
@@ -1733,9 +1753,11 @@ static void *repair_all_worker(void *arg) {
       if (ev_dl) nrq_event_free(ev_dl[ci]);
     }
     free(ev_done); free(ev_up); free(ev_dl); free(ev_up_borrowed);
-    free(lost); free(nlost); free(resi); free(nuse); free(navail); free(status); free(sv); free(rv);
+    free(lost); free(nlost); free(resi); free(nuse); free(navail); free(status); free(dev_done); free(sv); free(rv);
   }
-  nrq_stream_sync(c, 2);
+  if ((nrq_stream_sync(c, 2) == 0 || nrq_stream_sync(c, 2) == 0) && io)
+    for (unsigned sbn = 0; sbn < Z; sbn++) /* what was written is down: the output context has seen these blocks' rows */
+      if (wrote[sbn] && rq->blocks[sbn]) rq->blocks[sbn]->dirty = false;
   settle_uploads(rq, di); /* (whatever a deferred batch still had in flight: the blocks that waited for it are done) */
   gpu_unlock(di);
   return NULL;

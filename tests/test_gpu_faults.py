@@ -82,8 +82,12 @@ def test_a_failed_packet_batch_is_taken_back_and_can_be_sent_again():
         if added != len(pk):
             rolled_back += added == 0
             again = [x for x, r in zip(pk, res) if r == SYM_ERR]
-            a2, r2, addr2 = _feed_pinned(L, dq, again, T, oio)
-            assert a2 == len(again) and (r2 == SYM_ADDED).all(), (n, a2)
+            if n % 2:   # ... through the batch call, or one symbol per call (a block taken back is host-resident again)
+                a2, r2, addr2 = _feed_pinned(L, dq, again, T, oio)
+                assert a2 == len(again) and (r2 == SYM_ADDED).all(), (n, a2)
+            else:
+                for t, p in again:
+                    assert L.nanorq_decoder_add_symbol(dq, (C.c_uint8 * T).from_buffer_copy(p), t, oio) == SYM_ADDED, n
         assert L.nanorq_repair_all(dq, oio) == L.nanorq_blocks(dq)
         assert np.array_equal(out, data), n
         L.nanorq_free(dq)
@@ -119,9 +123,10 @@ def test_a_failed_repair_all_leaves_the_blocks_retryable(resident):
         _opt("fail_after", 0)
         hit += _faults() > before
         assert done <= L.nanorq_blocks(dq)
-        # whatever is marked complete is right, byte for byte
+        # whatever counts as complete is where the caller looks for it, byte for byte -- also when the failure hit a copy on
+        # the way back or the wait for it (a block used to count as complete with its rows still on the device)
         for b in range(L.nanorq_blocks(dq)):
-            if L.nanorq_num_missing(dq, b) == 0 and resident == "host":
+            if L.nanorq_num_missing(dq, b) == 0:
                 assert np.array_equal(out[b * K * T:(b + 1) * K * T], data[b * K * T:(b + 1) * K * T]), (n, b)
         assert L.nanorq_repair_all(dq, oio) == L.nanorq_blocks(dq), n
         assert np.array_equal(out, data), n

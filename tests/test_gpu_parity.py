@@ -197,6 +197,43 @@ def test_headline_block_vs_oracle_checksum(G, orc):
     assert st[0] == 1 and np.array_equal(out[0], src)
 
 
+def test_headline_reception_overhead0_full_width_vs_oracle(G, orc):
+    """The reception shape bench.py's headline is quoted on -- K=8192, T=1280, 10 % loss, EXACTLY K symbols received (the
+    GF(256)/HDPC path, reference precode.c:365-371) -- at full symbol width, two blocks: repair symbols, intermediate symbols
+    (encode and decode side) and the recovered blocks against the oracle byte for byte; a block whose K-symbol system is rank
+    deficient must be reported so by both, and decodes with one more symbol."""
+    K, T, nblk = 8192, 1280, 2
+    src = np.stack([payload(K * T, seed=91, block=b).reshape(K, T) for b in range(nblk)])
+    lost = [loss_pattern(K, 0.10, seed=92, block=b) for b in range(nblk)]
+    esis = np.arange(K, K + max(len(l) for l in lost) + 2, dtype=np.uint32)
+    rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+    for b in range(nblk):
+        r_rep, r_int, _ = orc.encode_block(src[b], K, T, esis, want_inter=True)
+        assert np.array_equal(rep[b], r_rep) and np.array_equal(inter[b], r_int), "encode of block %d differs from the oracle" % b
+    work = src.copy()
+    for b in range(nblk):
+        work[b][lost[b]] = 0xEE
+    nuse = [len(l) for l in lost]
+    for attempt in range(3):
+        resi = [esis[:n] for n in nuse]
+        st, out, dint = G.gpu_decode(work, K, T, lost, resi, [rep[b][:nuse[b]] for b in range(nblk)], want_inter=True)
+        done = True
+        for b in range(nblk):
+            recv = np.concatenate([np.setdiff1d(np.arange(K, dtype=np.uint32), lost[b]), resi[b]])
+            ok, o_out, _ = orc.decode_block(recv, np.concatenate([src[b][recv[recv < K]], rep[b][:nuse[b]]]), K, T)
+            assert bool(st[b]) == bool(ok), "verdict of block %d differs from the oracle's" % b
+            if ok:
+                assert np.array_equal(out[b], src[b]) and np.array_equal(o_out, src[b])
+                assert np.array_equal(dint[b], inter[b]), "intermediate symbols of the decode differ (block %d)" % b
+            else:
+                assert np.array_equal(out[b], work[b])
+                nuse[b] += 1
+                done = False
+        if done:
+            break
+    assert done
+
+
 def test_roundtrip_max_k(G):
     """BASELINE configs[4] shape: K'=56403 (RFC 6330 maximum), T=1280, 20 % loss, +16 (2-byte strips)."""
     st, out, src = _roundtrip(G, 56403, 1280, 1, 0.20, 16, seed=41)

@@ -14,7 +14,7 @@ cd /tmp
 timeout 900 python $REPO/bench.py > "$OUT/${TAG}_bench_1gpu.json" 2> "$OUT/bench_1gpu.err"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 python $REPO/tools/rocprof_summary.py stats $(find "$OUT/trace" -name '*.db' | head -1) > "$OUT/${TAG}_kernel_stats.txt"
-echo "# (averages over ALL launches of the run: 1 warm-up step + 3 timed steps, i.e. they include the cold first launch -- the max column; the steady-state durations are in ${TAG}_kernel_timeline.txt and in roofline.avg_launch_ms of ${TAG}_bench_1gpu.json)" >> "$OUT/${TAG}_kernel_stats.txt"
+echo "# (avg_us is over ALL launches of the run: 1 warm-up step + 3 timed steps, i.e. it includes the cold first launch -- the max column; steady_avg_us leaves the warm-up step's launches out and is the figure that roofline.avg_launch_ms of ${TAG}_bench_1gpu.json must agree with)" >> "$OUT/${TAG}_kernel_stats.txt"
 python $REPO/tools/rocprof_summary.py timeline $(find "$OUT/trace" -name "*.db" | head -1) -1 > "$OUT/${TAG}_kernel_timeline.txt"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES" \

@@ -18,18 +18,23 @@ def short(name):
     return name.replace("void ", "")[:70]
 
 
-def stats(path):
+def stats(path, warm=2):
+    """per (kernel, grid): all launches, and the STEADY launches -- without the first `warm` of the pair (the warm-up step of
+    the profiled command: bench.py --warmup 1 launches the solve kernel twice, encode and decode, before its timed region; the
+    cold first launch is the max column) -- whose average is what bench.py's roofline.avg_launch_ms measures with HIP events"""
     db = sqlite3.connect(path)
-    rows = db.execute("select name, grid_x, duration from kernels").fetchall()
+    rows = db.execute("select name, grid_x, duration, start from kernels order by start").fetchall()
     agg = defaultdict(list)
-    for name, grid, dur in rows:
+    for name, grid, dur, _ in rows:
         agg[(short(name), grid)].append(dur / 1000.0)
     total = sum(sum(v) for v in agg.values())
-    print("# rocprofv3 --kernel-trace --stats: per (kernel, grid) launch statistics, microseconds")
-    print("%-64s %10s %6s %12s %10s %10s %10s %6s" % ("kernel", "grid_x", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
+    print("# rocprofv3 --kernel-trace --stats: per (kernel, grid) launch statistics, microseconds; steady_* = without the first %d launches" % warm)
+    print("%-64s %10s %6s %12s %10s %10s %10s %6s %8s %12s" % ("kernel", "grid_x", "calls", "total_us", "avg_us", "min_us", "max_us", "pct",
+                                                             "steady_n", "steady_avg_us"))
     for (name, grid), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:14]:
-        print("%-64s %10d %6d %12.1f %10.1f %10.1f %10.1f %6.2f" % (name, grid, len(v), sum(v), sum(v) / len(v), min(v), max(v),
-                                                                  100.0 * sum(v) / total))
+        st = v[warm:] if len(v) > warm + 1 else v
+        print("%-64s %10d %6d %12.1f %10.1f %10.1f %10.1f %6.2f %8d %12.1f" % (name, grid, len(v), sum(v), sum(v) / len(v), min(v), max(v),
+                                                                            100.0 * sum(v) / total, len(st), sum(st) / len(st)))
 
 
 def pmc(paths):
