@@ -28,7 +28,11 @@ size_t nanorq_encode_range(nanorq *rq, void *data, uint32_t esi0, uint32_t n, ui
 
 /* Encoder: the n consecutive REPAIR symbols esi0 .. esi0+n-1 (esi0 >= the symbols of every block) of ALL blocks: `data`
  * receives, block after block, n * nanorq_symbol_size(rq) bytes each (solving what is not solved yet).  One download per
- * device instead of a launch, a wait and a download per block.  Returns the bytes written (0 on failure). */
+ * device instead of a launch, a wait and a download per block.  Called on an object none of whose blocks is solved yet, with
+ * `data` in page-locked memory, it is the whole sender as one pipeline: a chunk of blocks travels up, is solved, its repair
+ * symbols are generated and travel down while the next chunk travels up -- both directions of the link at once (128 blocks of
+ * K=8192, T=1280: 26.8 ms against 30.9 ms for nanorq_generate_symbols_all followed by this call).  Returns the bytes written
+ * (0 on failure). */
 size_t nanorq_encode_range_all(nanorq *rq, void *data, uint32_t esi0, uint32_t n, struct ioctx *io);
 
 /* Decoder: nanorq_decoder_add_symbol (reference lib/nanorq.c:478-509) for n symbols: symbol k is the T bytes at

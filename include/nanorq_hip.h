@@ -165,6 +165,11 @@ int nrq_decode_blocks_vc(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint
 int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,
                     uint32_t n, const uint32_t *h_isi, void *d_out, size_t out_stride);
 
+/* the same with the list of internal symbol ids already in device memory (enqueue only: nothing is staged, nothing waited for;
+ * a pipeline that generates the same symbols for block after block uploads the list once) */
+int nrq_gen_symbols_dev(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,
+                        uint32_t n, const uint32_t *d_isi, void *d_out, size_t out_stride);
+
 /* Raw device memory helpers for hosts without a HIP binding of their own (the drop-in C library and
  * the ctypes tests use them; PyTorch callers pass tensor data pointers instead). */
 int nrq_dev_alloc(nrq_ctx *ctx, size_t bytes, void **out);

@@ -1070,6 +1070,10 @@ static void *gen_all_worker(void *arg) {
   const size_t Z = nanorq_blocks(rq), T = rq->T;
   const bool dma = j->dma;
   uint8_t *base = j->base;
+  /* j->out != NULL (nanorq_encode_range_all on blocks that are not solved yet): the sender's two legs as ONE pipeline -- behind
+   * the solve of a chunk its repair symbols esi0 .. esi0+n-1 are generated and travel down (download stream) while the next
+   * chunk travels up and is solved; the two directions of the link work at the same time. */
+  const size_t per = (size_t)j->n * T;
   gpu_lock(di);
   for (uint32_t cls = 0; cls < 2; cls++) {
     /* the blocks of this size on this device that still need the solve */
@@ -1089,9 +1093,20 @@ static void *gen_all_worker(void *arg) {
     if (C < 1) C = 1;
     if (C > n) C = n;
     void *dsrc[2] = {NULL, NULL}, *up_done[2] = {NULL, NULL}, *solved[2] = {NULL, NULL};
+    void *dout[2] = {NULL, NULL}, *gen_done[2] = {NULL, NULL}, *dl_done[2] = {NULL, NULL}, *d_isi = NULL;
+    uint32_t *isis = NULL;
     bool ok = true;
     for (int i = 0; i < 2 && ok; i++)
       ok = nrq_dev_alloc(c, sbytes * C, &dsrc[i]) == 0 && nrq_event_new(c, &up_done[i]) == 0 && nrq_event_new(c, &solved[i]) == 0;
+    if (j->out && ok) {
+      /* the list of internal symbol ids is the same for every block of the class: uploaded once */
+      isis = malloc((size_t)j->n * sizeof(uint32_t));
+      ok = isis != NULL && nrq_dev_alloc(c, (size_t)j->n * sizeof(uint32_t), &d_isi) == 0;
+      for (uint32_t q = 0; q < j->n && ok; q++) isis[q] = j->esi0 + q + (Kp - K);
+      ok = ok && nrq_dev_upload(c, d_isi, isis, (size_t)j->n * sizeof(uint32_t)) == 0;
+      for (int i = 0; i < 2 && ok; i++)
+        ok = nrq_dev_alloc(c, per * C, &dout[i]) == 0 && nrq_event_new(c, &gen_done[i]) == 0 && nrq_event_new(c, &dl_done[i]) == 0;
+    }
     unsigned done_blocks = 0;
     for (unsigned c0 = 0, step = 0; c0 < n && ok; c0 += C, step++) {
       const int i = (int)(step & 1u);
@@ -1127,30 +1142,51 @@ static void *gen_all_worker(void *arg) {
       }
       ok = ok && nrq_event_record(c, up_done[i], 1) == 0 && nrq_stream_wait(c, 0, up_done[i]) == 0 &&
            nrq_encode_blocks_v(c, K, Kp, (uint32_t)T, m, dsrc[i], sbytes, iv) == 0 && nrq_event_record(c, solved[i], 0) == 0;
+      if (j->out && ok) {
+        if (step >= 2) ok = nrq_stream_wait(c, 0, dl_done[i]) == 0; /* (the download out of this buffer two steps ago) */
+        for (unsigned k = 0; k < m && ok; k++)
+          ok = nrq_gen_symbols_dev(c, K, Kp, (uint32_t)T, 1, rq->blocks[todo[c0 + k]]->d_inter, ibytes, j->n, d_isi, (uint8_t *)dout[i] + per * k, per) == 0;
+        ok = ok && nrq_event_record(c, gen_done[i], 0) == 0 && nrq_stream_wait(c, 2, gen_done[i]) == 0;
+        for (unsigned k = 0; k < m && ok;) { /* consecutive blocks of this device: one copy for the run */
+          unsigned run = 1;
+          while (k + run < m && todo[c0 + k + run] == todo[c0 + k] + run) run++;
+          ok = nrq_copy_on(c, 2, j->out + per * todo[c0 + k], (uint8_t *)dout[i] + per * k, per * run) == 0;
+          k += run;
+        }
+        ok = ok && nrq_event_record(c, dl_done[i], 2) == 0;
+      }
       if (ok) done_blocks = c0 + m;
     }
     ok = nrq_ctx_sync(c) == 0 && ok;
     nrq_stream_sync(c, 1);
+    if (j->out) ok = nrq_stream_sync(c, 2) == 0 && ok;
     for (unsigned k = 0; k < done_blocks && ok; k++) {
       struct blockst *b = rq->blocks[todo[k]];
       b->win_n = 0;
       b->inverted = true;
     }
+    if (!ok) j->ok = false;
     for (int i = 0; i < 2; i++) {
       if (dsrc[i]) nrq_dev_free(c, dsrc[i]);
+      if (dout[i]) nrq_dev_free(c, dout[i]);
       nrq_event_free(up_done[i]);
       nrq_event_free(solved[i]);
+      nrq_event_free(gen_done[i]);
+      nrq_event_free(dl_done[i]);
     }
+    if (d_isi) nrq_dev_free(c, d_isi);
+    free(isis);
   }
   gpu_unlock(di);
   return NULL;
 }
-size_t nanorq_generate_symbols_all(nanorq *rq, struct ioctx *io) {
+/* all blocks that are not solved yet; with `out`: their repair symbols esi0 .. esi0+n-1 too, block sbn's at out + sbn * n * T */
+static size_t generate_all(nanorq *rq, struct ioctx *io, uint8_t *out, uint32_t esi0, uint32_t nsym) {
   const size_t Z = nanorq_blocks(rq);
   if (!ndev() || !io) return 0;
   struct all_job j;
   memset(&j, 0, sizeof(j));
-  j.rq = rq; j.io = io;
+  j.rq = rq; j.io = io; j.out = out; j.esi0 = esi0; j.n = nsym;
   j.dma = ioctx_dma_region(io, &j.base, &j.rlen) && rq->N == 1 && j.rlen >= rq->F;
   /* the blocks' state (and, without a page-locked context, their source rows: the context has ONE cursor) before the
    * device threads start */
@@ -1163,8 +1199,9 @@ size_t nanorq_generate_symbols_all(nanorq *rq, struct ioctx *io) {
   size_t done = 0;
   for (unsigned sbn = 0; sbn < Z; sbn++)
     if (rq->blocks[sbn] && rq->blocks[sbn]->inverted) done++;
-  return done;
+  return (out && !j.ok) ? 0 : done;
 }
+size_t nanorq_generate_symbols_all(nanorq *rq, struct ioctx *io) { return generate_all(rq, io, NULL, 0, 0); }
 
 /* Encoder: the repair symbols esi0 .. esi0+n-1 (esi0 >= K of every block) of ALL blocks in one go: `data` receives, block
  * after block, n * T bytes each.  One generation launch per block, queued without waiting, and one download per device
@@ -1213,6 +1250,12 @@ size_t nanorq_encode_range_all(nanorq *rq, void *data, uint32_t esi0, uint32_t n
   for (unsigned sbn = 0; sbn < Z; sbn++) {
     struct blockst *b = get_block(rq, (uint8_t)sbn);
     if (!b || esi0 < b->K) return 0; /* repair symbols only */
+  }
+  {
+    /* no block solved yet and a page-locked target (the sender's usual case): solve and generate as one pipeline */
+    bool fresh = nrq_host_is_pinned(data) == 1;
+    for (unsigned sbn = 0; sbn < Z && fresh; sbn++) fresh = !rq->blocks[sbn]->inverted && rq->blocks[sbn]->K > 0;
+    if (fresh) return generate_all(rq, io, data, esi0, n) == Z ? Z * (size_t)n * T : 0;
   }
   if (nanorq_generate_symbols_all(rq, io) != Z) return 0;
   struct all_job j;

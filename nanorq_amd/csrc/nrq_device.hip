@@ -2608,6 +2608,21 @@ int nrq_gen_symbols(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t 
   return 0;
 }
 
+int nrq_gen_symbols_dev(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, uint32_t nblk, const void *d_inter, size_t inter_stride,
+                        uint32_t n, const uint32_t *d_isi, void *d_out, size_t out_stride) {
+  if (!ctx) return -1;
+  if (!d_inter || !d_out || !d_isi || T == 0 || nblk == 0) return fail(ctx, -1, "bad arguments");
+  if (n == 0) return 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  rq_params p;
+  int rc = block_params(ctx, K, Kp, &p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nrq_gen_kernel, dim3(n, nblk), dim3(NRQ_GEN_WG), 0, ctx->stream, p, T, (const uint8_t *)d_inter,
+                     inter_stride, d_isi, (uint8_t *)d_out, out_stride);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
 int nrq_dev_alloc(nrq_ctx *ctx, size_t bytes, void **out) {
   if (!ctx || !out) return -1;
   HIPCHK(ctx, hipSetDevice(ctx->device));
