@@ -448,6 +448,7 @@ enum {
   pl_tag_pl_gjp_init = 12,
   pl_tag_pl_gjp_bid = 12,
   pl_tag_pl_gjp_step = 12,
+  pl_tag_pl_gjp_wave = 12,
   pl_tag_pl_gjp_comb = 12,
   pl_tag_pl_gjp_stage = 12,
   pl_tag_pl_gjp_apply = 12,

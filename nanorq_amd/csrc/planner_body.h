@@ -1964,6 +1964,12 @@ template <int Z> SB_HD void pl_gj_b(PlanCtx &c, uint32_t xarg, uint32_t tid, uin
 #ifndef PL_GJ_BLOCK_MIN
 #define PL_GJ_BLOCK_MIN 4u /* words of the matrix per thread from which the panel form is used */
 #endif
+/* where the 32 panel-start pivot rows wait for pl_gjp_apply: the per-thread scratch words of the workgroup (LDS; idle between
+ * the init scans and the final phases) when they fit, else a dead HBM array (rec_word: the op stream has been emitted) */
+SB_HD uint32_t *pl_gj_rows_aside(const PlanCtx &c, uint32_t nt) {
+  if (32u * c.sh->rowlen <= nt) return c.part();
+  return c.rec_word;
+}
 SB_HD uint32_t *pl_gj_mask(const PlanCtx &c) { uint32_t *q = reinterpret_cast<uint32_t *>(c.qmem); PL_ASSUME_LDS(q); return q; } /* [2 * qcap] words */
 /* (worth it when a pass over the matrix is more than a few words per thread: measured at K=8192 -- 216 rows of 15 words on
  * 1024 threads -- the column-at-a-time loop with its single barrier per column is faster: 0.8 M against 1.2 M clocks) */
@@ -2016,6 +2022,115 @@ template <int Z> SB_HD void pl_gjp_step(PlanCtx &c, uint32_t x, uint32_t tid, ui
     sh->gj_pr[b] = (uint16_t)pr;
   }
 }
+/* Steps (1) of all 32 columns of a panel by ONE wave, in one phase.  pl_gjp_bid / pl_gjp_step are two phases per column --
+ * a shared atomic-min, two barriers, ~3 k clocks each, for a pass over ONE word per row: 64 phases per panel.  One wave holds
+ * the panel word of every row in registers (row j with lane j % 64, PL_GJW_ROWS rows per lane), finds a column's pivot by a
+ * minimum over the wave, takes the pivot row's word from its lane, and XORs: ~100 instructions per column, no barrier, no
+ * shared word.  Same pivot rule (the unused row with the lowest index), same masks, same books -- the plan is the same.
+ * The emulator runs the plain loop. */
+#ifndef PL_GJ_WAVE
+#define PL_GJ_WAVE 1
+#endif
+#ifndef PL_GJW_ROWS
+#define PL_GJW_ROWS 12u
+#endif
+#ifndef PL_GJW_MIN_ROWS
+#define PL_GJW_MIN_ROWS 64u /* leftover rows from which the panel form with the wave phase is used (small blocks keep the column loop) */
+#endif
+SB_HD bool pl_gjw_ok(const PlanCtx &c) {
+  return c.sh->nlow >= PL_GJW_MIN_ROWS && c.sh->nlow <= 64u * PL_GJW_ROWS && c.sh->nlow + PL_EXTRA_ROWS <= 2u * c.qcap && 32u * c.sh->rowlen <= c.reccap;
+}
+template <uint32_t R> SB_HD void pl_gjp_wave_r(PlanCtx &c, uint32_t w, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  uint32_t *Mb = pl_mb(c);
+  uint32_t *m = pl_gj_mask(c);
+  const uint32_t rowlen = sh->rowlen, nlow = sh->nlow, u = c.p.L - sh->npiv;
+  const uint32_t nb = u - 32u * w < 32u ? u - 32u * w : 32u; /* columns of this panel */
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)nt;
+  if (tid >= 64u) return;
+  uint32_t v[R], mk[R], used = 0u;
+  /* mk[k]: which PANEL-START pivot rows have been XORed into the lane's k-th row so far -- kept in those terms from the start
+   * (a row that absorbs pivot b absorbs what that pivot row had absorbed: its mask, and itself), so that no combination step
+   * (pl_gjp_comb) is needed afterwards: gj_A is the identity */
+  if (tid < 32u) { sh->gj_pr[tid] = PL_NONE16; sh->gj_A[tid] = 1u << tid; }
+#pragma unroll
+  for (uint32_t k = 0; k < R; k++) {
+    const uint32_t j = tid + 64u * k;
+    v[k] = j < nlow ? Mb[(size_t)j * rowlen + w] : 0u;
+    mk[k] = 0u;
+    if (j < nlow && c.gj_used()[j]) used |= 1u << k;
+  }
+  uint32_t r2 = sh->r2, nfree = sh->nfree;
+  for (uint32_t b = 0; b < nb; b++) {
+    uint32_t best = PL_NONE;
+#pragma unroll
+    for (uint32_t k = R; k-- > 0u;) /* (descending: the lowest k that qualifies stays) */
+      if (((v[k] >> b) & 1u) && !((used >> k) & 1u)) best = tid + 64u * k;
+    const uint32_t pr = PL_WAVE_MIN(best);
+    if (pr == PL_NONE) { /* no unused row has the column: free */
+      if (tid == 0u && nfree < NRQ_MAX_FREE) sh->freex[nfree] = 32u * w + b;
+      nfree++;
+      continue;
+    }
+    const uint32_t owner = pr & 63u, kk = pr >> 6;
+    uint32_t mine = 0u, mmine = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < R; k++) { mine = k == kk ? v[k] : mine; mmine = k == kk ? mk[k] : mmine; }
+    const uint32_t pw = (uint32_t)__shfl((int)mine, (int)owner);
+    const uint32_t pa = (uint32_t)__shfl((int)mmine, (int)owner) ^ (1u << b); /* the pivot row in terms of panel-start rows */
+#pragma unroll
+    for (uint32_t k = 0; k < R; k++) {
+      const bool hit = ((v[k] >> b) & 1u) && !(tid == owner && k == kk);
+      v[k] ^= hit ? pw : 0u;
+      mk[k] ^= hit ? pa : 0u;
+    }
+    if (tid == owner) used |= 1u << kk;
+    if (tid == 0u) { c.red_row[r2] = pr; c.red_x[r2] = 32u * w + b; sh->gj_pr[b] = (uint16_t)pr; }
+    r2++;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < R; k++) {
+    const uint32_t j = tid + 64u * k;
+    if (j < nlow) { Mb[(size_t)j * rowlen + w] = v[k]; m[j] = mk[k]; c.gj_used()[j] = (uint8_t)((used >> k) & 1u); }
+  }
+  if (tid == 0u) { sh->r2 = r2; sh->nfree = nfree; }
+#else
+  if (tid != 0u) return;
+  (void)nt;
+  for (uint32_t b = 0; b < 32u; b++) { sh->gj_pr[b] = PL_NONE16; sh->gj_A[b] = 1u << b; }
+  for (uint32_t j = 0; j < nlow; j++) m[j] = 0u;
+  for (uint32_t b = 0; b < nb; b++) {
+    const uint32_t x = 32u * w + b;
+    uint32_t pr = PL_NONE;
+    for (uint32_t j = 0; j < nlow; j++)
+      if (((Mb[(size_t)j * rowlen + w] >> b) & 1u) && !c.gj_used()[j]) { pr = j; break; }
+    if (pr == PL_NONE) {
+      if (sh->nfree < NRQ_MAX_FREE) sh->freex[sh->nfree] = x;
+      sh->nfree++;
+      continue;
+    }
+    const uint32_t pw = Mb[(size_t)pr * rowlen + w], pa = m[pr] ^ (1u << b);
+    for (uint32_t j = 0; j < nlow; j++) {
+      if (j == pr) continue;
+      const uint32_t val = Mb[(size_t)j * rowlen + w];
+      if ((val >> b) & 1u) { Mb[(size_t)j * rowlen + w] = val ^ pw; m[j] ^= pa; }
+    }
+    c.gj_used()[pr] = 1;
+    c.red_row[sh->r2] = pr;
+    c.red_x[sh->r2] = x;
+    sh->r2++;
+    sh->gj_pr[b] = (uint16_t)pr;
+  }
+#endif
+}
+template <int Z> SB_HD void pl_gjp_wave(PlanCtx &c, uint32_t w, uint32_t tid, uint32_t nt) {
+  /* (rows per lane as a compile-time bound: the column loop is ~12 instructions per row a lane may hold) */
+  const uint32_t nlow = c.sh->nlow;
+  if (nlow <= 64u * 4u) pl_gjp_wave_r<4u>(c, w, tid, nt);
+  else if (nlow <= 64u * 8u) pl_gjp_wave_r<8u>(c, w, tid, nt);
+  else pl_gjp_wave_r<PL_GJW_ROWS>(c, w, tid, nt);
+}
 /* pivot row b when it was used = the panel-start pivot rows named by gj_A[b]: itself and what it had absorbed before */
 template <int Z> SB_HD void pl_gjp_comb(PlanCtx &c, uint32_t w, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
@@ -2034,7 +2149,7 @@ template <int Z> SB_HD void pl_gjp_stage(PlanCtx &c, uint32_t w, uint32_t tid, u
   const uint32_t *Mb = pl_mb(c);
   uint32_t *m = pl_gj_mask(c);
   const uint32_t rowlen = sh->rowlen;
-  uint32_t *P = c.rec_word; /* (dead since the op stream was emitted; 32 * rowlen <= 32 * 64 words) */
+  uint32_t *P = pl_gj_rows_aside(c, nt);
   for (uint32_t e = tid; e < 32u * rowlen; e += nt) {
     const uint32_t b = e / rowlen, wd = e - b * rowlen, pr = sh->gj_pr[b];
     P[e] = pr == PL_NONE16 ? 0u : Mb[(size_t)pr * rowlen + wd];
@@ -2049,7 +2164,7 @@ template <int Z> SB_HD void pl_gjp_apply(PlanCtx &c, uint32_t w, uint32_t tid, u
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   uint32_t *Mb = pl_mb(c);
   const uint32_t *m = pl_gj_mask(c);
-  const uint32_t *P = c.rec_word;
+  const uint32_t *P = pl_gj_rows_aside(c, nt);
   const uint32_t rowlen = sh->rowlen, total = sh->nlow * rowlen;
   const uint32_t inv = 0xFFFFFFFFu / rowlen + 1u; /* e / rowlen == mulhi(e, inv) for e < 2^16 * rowlen */
   for (uint32_t e = tid; e < total; e += nt) {

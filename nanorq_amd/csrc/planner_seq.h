@@ -136,14 +136,18 @@
     PL_PHASE(pl_low_c); /* (after the fold: Mb takes the place of the fold's tiles) */
     {
       const uint32_t u_ = c.p.L - sh_->npiv;
-      if (pl_gj_blocked(c, PL_NT_)) { /* a panel of 32 columns at a time: one pass over the matrix per panel, not per column */
+      const bool wave_ = PL_GJ_WAVE && pl_gjw_ok(c); /* the 32 columns of a panel by one wave in one phase */
+      if (wave_ || pl_gj_blocked(c, PL_NT_)) { /* a panel of 32 columns at a time: one pass over the matrix per panel, not per column */
         for (uint32_t w_ = 0; w_ * 32u < u_; w_++) {
+          if (wave_) PL_PHASE1(pl_gjp_wave, w_); /* (sets up its own books, leaves the rows' masks in their final form) */
+          else {
           PL_PHASE1(pl_gjp_init, w_);
           for (uint32_t x_ = w_ * 32u; x_ < u_ && x_ < w_ * 32u + 32u; x_++) {
             PL_PHASE1(pl_gjp_bid, x_);
             PL_PHASE1(pl_gjp_step, x_);
           }
           PL_PHASE1(pl_gjp_comb, w_);
+          }
           PL_PHASE1(pl_gjp_stage, w_);
           PL_PHASE1(pl_gjp_apply, w_);
         }

@@ -12,6 +12,9 @@
 static uint32_t g_gj_block_min = 4; /* words of the GF(2) matrix per thread from which the Gauss-Jordan runs in panels (kernel: 4) */
 #define PL_GJ_BLOCK_MIN g_gj_block_min
 extern "C" void emu_plan_set_gj_block_min(uint32_t v) { g_gj_block_min = v; }
+static uint32_t g_gj_wave = 1; /* the 32 columns of a panel in one phase (pl_gjp_wave; kernel: on) */
+#define PL_GJ_WAVE g_gj_wave
+extern "C" void emu_plan_set_gj_wave(uint32_t v) { g_gj_wave = v; }
 #include "../../nanorq_amd/csrc/planner_body.h"
 
 extern "C" uint32_t emu_plan_arena_bound(uint32_t K, const uint8_t *kc, uint32_t overhead_cap, uint32_t nlost_cap) {

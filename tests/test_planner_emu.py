@@ -339,14 +339,19 @@ def test_blocked_gauss_jordan_gives_the_same_plan(K, p, oh):
         lost = loss_pattern(K, p, seed + 40)
         rep_esis = np.arange(K, K + len(lost) + oh + 3, dtype=np.uint32)
         pemu().emu_plan_set_gj_block_min(1 << 30)
+        pemu().emu_plan_set_gj_wave(0)
         try:
-            ref, ref_hdr = emu_device_plan(K, kc, lost, rep_esis, use=len(lost) + oh)
+            ref, ref_hdr = emu_device_plan(K, kc, lost, rep_esis, use=len(lost) + oh)          # a column at a time
             pemu().emu_plan_set_gj_block_min(0)
-            blk, blk_hdr = emu_device_plan(K, kc, lost, rep_esis, use=len(lost) + oh)
+            blk, blk_hdr = emu_device_plan(K, kc, lost, rep_esis, use=len(lost) + oh)          # panels, two phases per column
+            pemu().emu_plan_set_gj_wave(1)
+            wav, wav_hdr = emu_device_plan(K, kc, lost, rep_esis, use=len(lost) + oh)          # panels, a panel's columns in one phase
         finally:
             pemu().emu_plan_set_gj_block_min(4)
-        assert ref_hdr["status"] == blk_hdr["status"]
+            pemu().emu_plan_set_gj_wave(1)
+        assert ref_hdr["status"] == blk_hdr["status"] == wav_hdr["status"]
         assert ref == blk
+        assert ref == wav
 
 
 def _atomic_cycles_per_row(plan):
