@@ -1165,9 +1165,8 @@ int get_kconst(nrq_ctx *ctx, uint32_t K, KConst **out) {
  * bit 8 of nrq_planjob::mode (pl_final_c then leaves the W transposition to nrq_wt_kernel). */
 bool plan_is_segmented(const nrq_ctx *ctx, const rq_params &p, uint32_t Mcap) {
   const uint32_t sh_bytes = pl_shared_bytes(PL_QCAP, PL_LOWCAP, PL_NT), dyn = NRQ_LDS_MAX - sh_bytes;
-  const uint32_t need = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u);
   if (ctx->tune.plan_split_force) return true; /* (tests: the segmented path at sizes the oracle checks quickly) */
-  return need + pl_dense_reserve(p.L) > dyn && !ctx->tune.no_plan_split;
+  return pl_state_in_lds(p.L, Mcap, dyn) == 0u && !ctx->tune.no_plan_split;
 }
 
 int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const uint8_t *d_kc, const nrq_planjob *d_pj,
@@ -1208,8 +1207,9 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     /* a segmented run keeps nothing in LDS between its parts: its peeling state must live in the workspace, which
      * pl_ctx_setup chooses when the dynamic region is too small for it -- so make it too small (dense stage only) */
     const uint32_t need = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u);
-    const uint32_t only_dense = (pl_dense_reserve(p.L) + need - 16u) & ~15u; /* 16 bytes short of holding the peeling state */
+    uint32_t only_dense = (pl_dense_reserve(p.L) + need - 16u) & ~15u; /* 16 bytes short of holding the peeling state */
     if (only_dense < dyn_bytes) dyn_bytes = only_dense;
+    if (pl_state_in_lds(p.L, Mcap, dyn_bytes) != 0u) dyn_bytes = (need - 16u) & ~15u; /* (... also for the form that shares the rowstate image) */
     small_wg = false; tiny_wg = false;
     qcap = PL_QCAP; lowcap = PL_LOWCAP; sh_bytes = pl_shared_bytes(qcap, lowcap, PL_NT);
   }
@@ -1221,7 +1221,7 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
   const uint32_t nparts_run = !seg ? 1u : wentry ? 3u : 2u;
   for (uint32_t pi = 0; pi < nparts_run; pi++) {
     const uint32_t part = seg ? parts_seg[pi] : 0u;
-    const bool hbm_state = 2u * pl_r16(Mcap * 4u) + pl_r16(p.L * 4u) + pl_dense_reserve(p.L) > dyn_bytes; /* (pl_ctx_setup's rule) */
+    const bool hbm_state = pl_state_in_lds(p.L, Mcap, dyn_bytes) == 0u; /* (pl_ctx_setup's rule) */
     if (part && (tiny_wg || small_wg || !hbm_state)) return fail(ctx, -2, "planner: a segmented run needs the instance for big blocks");
     if (tiny_wg)
       hipLaunchKernelGGL(nrq_plan_kernel<(int)PL_NT_TINY>, dim3(nblk), dim3(PL_NT_TINY), dyn_bytes + sh_bytes, ps, p, d_kc, d_pj, d_jobs,

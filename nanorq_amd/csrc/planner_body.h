@@ -57,6 +57,21 @@
  * more of their workgroups fits a CU) */
 SB_HD uint32_t pl_dense_reserve(uint32_t L) { const uint32_t r = (L < 1200u ? 6u : 8u) * 1024u + L * 6u; return r < 36u * 1024u ? (r + 15u) & ~15u : 36u * 1024u; }
 
+/* Where a block's peeling state (rowstate, rowinfo, colinfo: 12 bytes per row) lives, given the dynamic LDS region of its
+ * workgroup: 1 = in LDS next to the dense-stage reserve; 2 = in LDS with the dense stage taking over the rowstate image, which
+ * is dead once peeling is over (blocks of ~8500 to ~11000 symbols: 12 bytes x 10300 rows + 36 KB do not fit, 12 x 10300 do, and
+ * the image of 41 KB holds the reserve -- the level tables and class counters that live there between peeling and the W pass
+ * are done with before the dense stage starts); 0 = in the workspace (HBM), with the compact copy in LDS.  One rule for
+ * pl_ctx_setup, the launch (kernel instance, segmented run) and the tests. */
+SB_HD uint32_t pl_state_in_lds(uint32_t L, uint32_t Mcap, uint32_t dyn_bytes) {
+  const uint32_t img = (Mcap * 4u + 15u) & ~15u, need = 2u * img + ((L * 4u + 15u) & ~15u);
+  if (need + pl_dense_reserve(L) <= dyn_bytes) return 1u;
+#ifndef PL_NO_DENSE_OVERLAY
+  if (need <= dyn_bytes && pl_dense_reserve(L) <= img) return 2u;
+#endif
+  return 0u;
+}
+
 /* what the host hands the planner for one block */
 typedef struct nrq_planjob {
   uint64_t lost;     /* u32[nlost]: missing source ESIs, ascending */
@@ -405,13 +420,19 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.aux_bytes = lds_dyn_bytes;
   {
     uint32_t need = pl_r16(Mcap * 4u) * 2u + pl_r16(c.p.L * 4u);
-    if (lds_dyn && need + pl_dense_reserve(c.p.L) <= lds_dyn_bytes) {
+    const uint32_t where = lds_dyn ? pl_state_in_lds(c.p.L, Mcap, lds_dyn_bytes) : 0u;
+    if (where) {
       c.rowstate = reinterpret_cast<uint32_t *>(lds_dyn);
       c.rowinfo = reinterpret_cast<uint32_t *>(lds_dyn + pl_r16(Mcap * 4u));
       c.colinfo = reinterpret_cast<uint32_t *>(lds_dyn + 2u * pl_r16(Mcap * 4u));
-      c.dense_lds = lds_dyn + need;
-      c.dense_bytes = lds_dyn_bytes - need;
       c.aux_bytes = pl_r16(Mcap * 4u); /* the rowstate image, dead once peeling is over */
+      if (where == 1u) {
+        c.dense_lds = lds_dyn + need;
+        c.dense_bytes = lds_dyn_bytes - need;
+      } else { /* the dense stage takes over the rowstate image (= the aux region: pl_cls_place / pl_collev_in_lds see one region) */
+        c.dense_lds = lds_dyn;
+        c.dense_bytes = c.aux_bytes;
+      }
     }
     c.collev_hbm = (job.mode & 0x200u) != 0u;
     c.cls_glob = nullptr;

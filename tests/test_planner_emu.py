@@ -328,6 +328,33 @@ def test_device_planner_builds_encode_plans(orc, K, T, wb, lds):
     assert emu_device_plan(K, kc, [], [])[1]["status"] == 1
 
 
+def test_dense_stage_over_the_dead_rowstate_image_gives_the_same_plan(orc):
+    """Blocks of ~8500 to ~11000 symbols: the peeling state fits the LDS only if the dense stage takes over the rowstate
+    image once peeling is done (planner_body.h pl_state_in_lds == 2).  Same plan as with an LDS region that holds state and
+    dense-stage reserve side by side (the state in the workspace peels with another search order: its plan may differ), and
+    the plan solves the block."""
+    import ctypes as C
+    K, T = 9400, 16
+    prm = orc.params(K)
+    kc = nanorq_amd.host_kconst(K)
+    src = payload(K * T, seed=33).reshape(K, T)
+    lost = loss_pattern(K, 0.1, 7)
+    esis = received_set(K, lost, 0)
+    rep_esis = esis[esis >= K]
+    rep, _, _ = orc.encode_block(src, K, T, rep_esis)
+    ok, _, _ = orc.decode_block(esis, np.concatenate([src[esis[esis < K]], rep]), K, T)
+    plan_side, hdr_side = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=160 * 1024)
+    plan_ovl, hdr_ovl = emu_device_plan(K, kc, lost, rep_esis, lds_bytes=134 * 1024)
+    assert (hdr_ovl["status"] == 0) == ok and hdr_side["status"] == hdr_ovl["status"]
+    assert plan_ovl == plan_side
+    if ok:
+        _, rowsrc = decode_setup(orc, K, lost, rep_esis)
+        work = src.copy()
+        work[lost] = 0x77
+        r, _ = emu_solve(plan_ovl, kc, rowsrc, work, rep, T, prm["L"], lt_lists(orc, K, lost, plan_ovl), lost, work, 8)
+        assert r == 1 and np.array_equal(work, src)
+
+
 @pytest.mark.parametrize("K,p,oh", [(300, 0.3, 0), (1024, 0.12, 0), (1024, 0.12, 2), (4000, 0.2, 0)])
 def test_blocked_gauss_jordan_gives_the_same_plan(K, p, oh):
     """Big matrices run the GF(2) Gauss-Jordan a panel of 32 columns at a time (planner_body.h pl_gjp_*): same pivot rule, so
