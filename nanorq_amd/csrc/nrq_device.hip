@@ -449,6 +449,10 @@ enum {
   pl_tag_pl_gjp_bid = 12,
   pl_tag_pl_gjp_step = 12,
   pl_tag_pl_gjp_wave = 12,
+  pl_tag_pl_mhrev_load = 11,
+  pl_tag_pl_mhrev_load_b = 11,
+  pl_tag_pl_mhrev_store = 11,
+  pl_tag_pl_mhrev_scatter = 11,
   pl_tag_pl_gjp_comb = 12,
   pl_tag_pl_gjp_stage = 12,
   pl_tag_pl_gjp_apply = 12,
@@ -531,6 +535,14 @@ void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
       else fwd_rows<4>(ops_, pl_wfast_rows(c), tid); \
     } \
     __syncthreads(); PL_ACC(2); } while (0)
+#define PL_MHREV_RUN(wb) do { \
+    if (tid < NRQ_ROW) { \
+      const NRQ_GAS uint32_t *ops_ = gptr<uint32_t>(c.arena + c.sh->off_ops); \
+      if ((wb) == 16u) rev_rows<16>(ops_, pl_wfast_rows(c), tid); \
+      else if ((wb) == 8u) rev_rows<8>(ops_, pl_wfast_rows(c), tid); \
+      else rev_rows<4>(ops_, pl_wfast_rows(c), tid); \
+    } \
+    __syncthreads(); PL_ACC(11); } while (0)
 #define PL_SEG PL_SEG_ /* (blocks whose peeling state fits the LDS run in one part: launch_plan_kernel) */
 #define PL_STEER_SYNC __syncthreads()
 #define PL_NT_ ((uint32_t)NT)
@@ -554,6 +566,7 @@ void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
 #undef PL_PHASE1
 #undef PL_PHASE1_CLAIM
 #undef PL_WFAST_RUN
+#undef PL_MHREV_RUN
 #undef PL_ACC
 }
 

@@ -227,7 +227,7 @@ typedef struct pl_shared {
   uint32_t lv_in_lds, opq_group[2];
   uint32_t tmp_mhoff; /* byte offset of Mb inside the dense LDS region, behind MhT (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
-  uint32_t off_augt, aug_stride, pad_to_16[1];
+  uint32_t off_augt, aug_stride, mhrev; /* mhrev: the HDPC fold's z rows are in the workspace (pl_mhrev_store) */
   uint32_t bin_ct[NRQ_LANE_CLASSES]; /* ops of the GF(2) combination group per lane class of the target */
   uint32_t gj_A[32];   /* blocked Gauss-Jordan: pivot row b at its pivot step = XOR of the panel-start rows gj_pr[k], k in gj_A[b] */
   uint16_t gj_pr[32];  /* pivot row of bit b of the current panel (PL_NONE16: the column is free) */
@@ -544,7 +544,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->ncand[0] = sh->ncand[1] = 0;
     sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = sh->cand[2] = PL_NONE;
     sh->nrows = 0; sh->nrec = 0; sh->uslot_fill = 0;
-    sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE;
+    sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE; sh->mhrev = 0;
   }
   /* GF(256) tables into LDS (RFC 6330 section 5.7): generated by one thread, 255 steps */
   if (tid == 1 % nt) {
@@ -1587,6 +1587,92 @@ template <int Z> SB_HD void pl_wfast_store(PlanCtx &c, uint32_t strip, uint32_t 
 }
 /* the rows of the stream that exist at this point: the pivot levels and the leftover rows */
 SB_HD uint32_t pl_wfast_rows(const PlanCtx &c) { return c.sh->spare_base; }
+
+/* ---- HDPC fold through the transposed op stream ----
+ * MhT[x] = G_U[x] ^ SUM_k W[k][x] * g_k  (g_k = the HDPC column of pivot k, 16 bytes).  With W = X^-1 * A_U that sum is
+ * (g^T X^-1) A_U[:, x]: ONE pass of the op stream, transposed and in reverse, over a 16-byte value per slot (z <- g^T X^-1: rev_rows
+ * of solve_body.h on the same LDS image the W pass uses), then MhT[x] ^= z_r for the rows r that have column x -- the column lists,
+ * ~21 k entries at K=8192, most of them in the permanently inactive columns.  The fold over tiles of pivots (pl_mh_load /
+ * pl_mh_acc: npiv x u masked 16-byte XORs, 0.59 M of the planner's 6.1 M clocks at K=8192) stays for the paths without an LDS
+ * image (level-by-level W pass) and for the segmented runs of big blocks (nrq_mh_kernel).  The image holds wb bytes per slot, so
+ * the 16 bytes go through in 16 / wb passes ("parts").  z is kept in the workspace (rec_word: dead since the op stream was
+ * emitted), 16 bytes per slot, because the dense stage's LDS lies where the image was. */
+#ifndef PL_MH_REV
+#define PL_MH_REV 1
+#endif
+SB_HD uint8_t *pl_mhm(const PlanCtx &c); /* (below: MhT, 16 bytes per inactive column, at the start of the dense stage's LDS) */
+SB_HD bool pl_mhrev_ok(const PlanCtx &c) { return PL_MH_REV && pl_wfast_wb(c) != 0u && c.sh->M * 4u <= c.reccap; }
+template <int Z> SB_HD void pl_mhrev_load(PlanCtx &c, uint32_t part, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (sh->status) return;
+  const uint32_t wpl = pl_wfast_wb(c) / 4u, n = (sh->M + NRQ_SCRATCH) * wpl;
+  uint32_t *img = reinterpret_cast<uint32_t *>(c.lds_dyn);
+  for (uint32_t e = tid; e < n; e += nt) img[e] = 0u;
+}
+/* (after a barrier: the pivot rows' slots take their HDPC columns -- words [part * wpl, +wpl) of the 16 bytes) */
+template <int Z> SB_HD void pl_mhrev_load_b(PlanCtx &c, uint32_t part, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (sh->status) return;
+  const uint32_t wpl = pl_wfast_wb(c) / 4u;
+  uint32_t *img = reinterpret_cast<uint32_t *>(c.lds_dyn);
+  struct SC { uint32_t slot, col; };
+  pl_for_batched(tid, nt, sh->npiv, [&](uint32_t k) { return SC{c.pivslot[k], c.pivcol[k]}; },
+                 [&](uint32_t, SC v) {
+                   const uint32_t *g = reinterpret_cast<const uint32_t *>(c.GT + (size_t)v.col * 16u) + part * wpl;
+                   for (uint32_t j = 0; j < wpl; j++) img[(size_t)(v.slot + NRQ_SCRATCH) * wpl + j] = g[j];
+                 });
+}
+template <int Z> SB_HD void pl_mhrev_store(PlanCtx &c, uint32_t part, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (sh->status) return;
+  const uint32_t wpl = pl_wfast_wb(c) / 4u, n = sh->M * wpl;
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(c.lds_dyn) + NRQ_SCRATCH * wpl;
+  uint32_t *z = c.rec_word; /* [M][4] words */
+  for (uint32_t e = tid; e < n; e += nt) {
+    const uint32_t slot = e / wpl, j = e - slot * wpl;
+    z[(size_t)slot * 4u + part * wpl + j] = img[e];
+  }
+  if (tid == 0) sh->mhrev = 1u;
+}
+/* MhT[x] ^= z_r over the rows r of inactive column x (MhT = G_U from pl_mh_init); 32 lanes per column */
+template <int Z> SB_HD void pl_mhrev_scatter(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (sh->status) return;
+  const uint32_t u = c.p.L - sh->npiv, lane = tid & 31u, grp = tid >> 5, ngrp = nt >> 5;
+  const uint4 *z = reinterpret_cast<const uint4 *>(c.rec_word);
+  uint32_t *MhT = reinterpret_cast<uint32_t *>(pl_mhm(c));
+  for (uint32_t x = grp; x < u; x += ngrp) {
+    const uint32_t col = c.ucol[x];
+    const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a, pa = c.pc_ptr[col], npc = c.pc_ptr[col + 1] - pa;
+    uint4 acc; acc.x = acc.y = acc.z = acc.w = 0u;
+    for (uint32_t e0 = lane; e0 < nb + npc; e0 += 4u * 32u) { /* four entries of the lane in flight: row, flags, z */
+      uint32_t r[4];
+      bool use[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t e = e0 + q * 32u;
+        use[q] = e < nb + npc;
+        r[q] = !use[q] ? 0u : e < nb ? (uint32_t)c.b_ridx[a + e] : (uint32_t)c.pc_rows[pa + (e - nb)];
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t e = e0 + q * 32u;
+        if (use[q] && e < nb && (c.rowinfo[r[q]] & PL_PATCHED)) use[q] = false; /* base entry of a row this block replaced */
+      }
+      uint4 v[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) v[q] = z[use[q] ? r[q] : 0u];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++)
+        if (use[q]) { acc.x ^= v[q].x; acc.y ^= v[q].y; acc.z ^= v[q].z; acc.w ^= v[q].w; }
+    }
+    uint32_t *dst = MhT + (size_t)x * 4u;
+    if (acc.x) PL_ATOM_XOR(&dst[0], acc.x);
+    if (acc.y) PL_ATOM_XOR(&dst[1], acc.y);
+    if (acc.z) PL_ATOM_XOR(&dst[2], acc.z);
+    if (acc.w) PL_ATOM_XOR(&dst[3], acc.w);
+  }
+}
 
 /* =============================== phase 3: leftover rows ====================================== */
 template <int Z> SB_HD void pl_low_a(PlanCtx &c, uint32_t tid, uint32_t nt) { /* list them */

@@ -116,6 +116,13 @@
           PL_WFAST_RUN(wb_);
           PL_PHASE1(pl_wfast_store, s_);
         }
+        if (pl_mhrev_ok(c)) /* the HDPC fold's z = g^T X^-1 while the image is here: the stream once more, transposed and in reverse */
+          for (uint32_t s_ = 0; s_ * wb_ < 16u; s_++) {
+            PL_PHASE1(pl_mhrev_load, s_);
+            PL_PHASE1(pl_mhrev_load_b, s_);
+            PL_MHREV_RUN(wb_);
+            PL_PHASE1(pl_mhrev_store, s_);
+          }
         PL_PHASE(pl_wfast_restore);
       } else {
         PL_PHASE(pl_w_stage);
@@ -126,6 +133,10 @@
     if (PL_SEG != 1 && PL_SEG != 3 && PL_SEG != 4) {
     if (PL_SEG == 0) {
       PL_PHASE(pl_mh_init);
+      const bool rev_ = sh_->mhrev != 0u;
+      PL_STEER_SYNC;
+      if (rev_) PL_PHASE(pl_mhrev_scatter); /* (z is in the workspace: one pass over the inactive columns' row lists) */
+      else
       for (uint32_t tl_ = 0; tl_ * PL_MH_TILE < sh_->npiv; tl_++) {
         PL_PHASE1(pl_mh_load, tl_);
         PL_PHASE1(pl_mh_acc, tl_);

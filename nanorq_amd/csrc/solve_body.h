@@ -771,6 +771,53 @@ template <int WB, int OFF, uint32_t U = NRQ_RING> __device__ __forceinline__ voi
   static_assert(WB == 16 || WB == 8, "half-width pipeline: 16- and 8-byte strips only");
   fwd_rows_impl<WB, OFF, typename HalfVal<WB>::type, U>(ops, nrows, lane);
 }
+/* The op stream TRANSPOSED and in reverse: row by row from the last to the first, every op dst ^= src becomes
+ * slot(src) ^= slot(dst).  With z = one 16-byte value per slot this computes z <- z * X^-1 for the row vector z (the forward
+ * passes compute X^-1 * D for the columns of D): the planner folds the pivot columns out of the HDPC rows with it (planner_body.h
+ * pl_mhrev_*).  The stream's hazard rule carries over: a row's ops read the targets of the forward ops and write their sources,
+ * never a slot the row itself reads, and whatever wrote a slot it reads lies NRQ_PIPE or more rows later in the stream (the
+ * forward rule applied to the later op).  Same depth-2 pipeline, one wave, no barriers; op words 16 rows (four quads) at a time,
+ * the next 16 requested while these run.  The stream's padding rows behind nrows are all NOPs, so the first chunk may start in them. */
+template <int WB> __device__ __forceinline__ void rev_rows(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
+  typedef typename RowVal<WB>::type V;
+  constexpr uint32_t P = NRQ_PIPE, CH = 16u;
+  static_assert(WB == 16 || WB == 8 || WB == 4, "transposed pass: 16-, 8- and 4-byte slots");
+  static_assert(CH % P == 0u && P <= 4u, "chunk: whole turns of the pending ring");
+  if (nrows == 0u) return;
+  const NRQ_GAS OpQuad *q4 = reinterpret_cast<const NRQ_GAS OpQuad *>(ops) + lane; /* quad g of this lane: q4[g * NRQ_ROW] */
+  const uint32_t top = (nrows + CH - 1u) / CH * CH; /* rows [nrows, top) are padding */
+  uint32_t o[CH], on[CH];
+  auto fetch = [&](uint32_t base, uint32_t (&dst)[CH]) {
+#pragma unroll
+    for (uint32_t g = 0; g < CH / 4u; g++) {
+      const OpQuad w = q4[(size_t)(base / 4u + g) * NRQ_ROW];
+      dst[4u * g] = w.x; dst[4u * g + 1u] = w.y; dst[4u * g + 2u] = w.z; dst[4u * g + 3u] = w.w;
+    }
+  };
+  V pv[P];
+  uint32_t pa[P]; /* pending: values read (slot(dst)) and the LDS address they go to (slot(src)), oldest at index row % P */
+#pragma unroll
+  for (uint32_t k = 0; k < P; k++) { V z = {}; pv[k] = z; pa[k] = row_addr_hi<WB>(NRQ_NOP_AT(lane)); }
+  fetch(top - CH, o);
+  for (uint32_t base = top - CH;; base -= CH) {
+    if (base >= CH) fetch(base - CH, on);
+#pragma unroll
+    for (uint32_t kk = 0; kk < CH; kk++) {
+      const uint32_t k = CH - 1u - kk; /* row base + k, descending */
+      const uint32_t a_rd = row_addr_lo<WB>(o[k]), a_wr = row_addr_hi<WB>(o[k]);
+      NRQ_SCHED_FENCE();
+      row_apply_at<WB, V>(pa[k % P], pv[k % P]); /* the row read P steps ago */
+      pv[k % P] = *NRQ_LDSP(V, a_rd);
+      pa[k % P] = a_wr;
+      NRQ_SCHED_FENCE();
+    }
+    if (base < CH) break;
+#pragma unroll
+    for (uint32_t k = 0; k < CH; k++) o[k] = on[k];
+  }
+#pragma unroll
+  for (uint32_t kk = 0; kk < P; kk++) { const uint32_t k = P - 1u - kk; row_apply_at<WB, V>(pa[k % P], pv[k % P]); } /* (oldest first: rows P-1 ... 0) */
+}
 /* The forward passes on a WIDE strip (G lanes per op, 16 bytes each; lane = op * G + sub): a row of 64 op slots is G
  * wave instructions of 64 / G ops.  Ops of one row never read what the row writes (plan.h), so a row is: fetch the G
  * source pieces, then the G XORs; instructions whose 64 / G ops are all padding are skipped (the planners fill a row from
@@ -838,6 +885,7 @@ template <int WB> SB_HD SV<WB> row_zero() { return sv_zero<WB>(); }
  * their own row loops over ph_row_read / ph_row_apply) */
 template <int WB, uint32_t U = NRQ_RING> SB_HD void fwd_rows(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
 template <int WB, int OFF, uint32_t U = NRQ_RING> SB_HD void fwd_rows_half(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
+template <int WB> SB_HD void rev_rows(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
 #endif
 
 /* phase 3: HDPC right-hand sides R_h = SUM_c HDPC[h][c] * Y(c) over the peeled columns, through

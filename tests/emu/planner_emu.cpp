@@ -44,6 +44,28 @@ static void emu_wfast_run(PlanCtx &c, uint32_t wb) {
   }
 }
 
+/* PL_MHREV_RUN on the CPU: the op stream transposed, rows from the last to the first in the order the kernel's wave issues them
+ * (step for row q: apply row q + NRQ_PIPE -- slot(src) ^= what was read from slot(dst) --, then read row q's dst slots) */
+static void emu_mhrev_run(PlanCtx &c, uint32_t wb) {
+  const uint32_t wpl = wb / 4u, nrows = pl_wfast_rows(c), P = NRQ_PIPE;
+  uint32_t *img = reinterpret_cast<uint32_t *>(c.lds_dyn);
+  const uint32_t *ops = reinterpret_cast<const uint32_t *>(c.arena + c.sh->off_ops);
+  std::vector<uint32_t> v((size_t)(P + 1) * NRQ_ROW * wpl);
+  for (int64_t q = (int64_t)nrows - 1; q >= -(int64_t)P; q--) {
+    if (q + P < (int64_t)nrows) {
+      const uint32_t r = (uint32_t)(q + P);
+      const uint32_t *vr = &v[(size_t)(r % (P + 1)) * NRQ_ROW * wpl];
+      for (uint32_t l = 0; l < NRQ_ROW; l++)
+        for (uint32_t k = 0; k < wpl; k++) img[(size_t)(ops[NRQ_OP_INDEX(r, l)] >> 16) * wpl + k] ^= vr[l * wpl + k];
+    }
+    if (q >= 0) {
+      uint32_t *vr = &v[(size_t)((uint32_t)q % (P + 1)) * NRQ_ROW * wpl];
+      for (uint32_t l = 0; l < NRQ_ROW; l++)
+        for (uint32_t k = 0; k < wpl; k++) vr[l * wpl + k] = img[(size_t)(ops[NRQ_OP_INDEX((uint32_t)q, l)] & 0xFFFFu) * wpl + k];
+    }
+  }
+}
+
 /* returns 0 and fills arena (status in its header); job_out receives the solve job (host pointers) */
 /* nrq_wpass_kernel on the CPU: every 2-byte strip of the W rows through the op stream, rows applied in stream order
  * (what fwd_rows<2> computes: a row never reads what it or its predecessor writes) */
@@ -101,6 +123,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
 #define PL_PHASE1(fn, a) do { for (uint32_t t_ = 0; t_ < PL_NT; t_++) fn<1>(c, (a), t_, PL_NT); } while (0)
 #define PL_PHASE1_CLAIM(fn, a) PL_PHASE1(fn, a)
 #define PL_WFAST_RUN(wb) emu_wfast_run(c, (wb))
+#define PL_MHREV_RUN(wb) emu_mhrev_run(c, (wb))
 #define PL_SEG g_seg
 #define PL_STEER_SYNC do { } while (0)
 #define PL_NT_ PL_NT
@@ -146,5 +169,6 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
 #undef PL_PHASE1
 #undef PL_PHASE1_CLAIM
 #undef PL_WFAST_RUN
+#undef PL_MHREV_RUN
   return 0;
 }
