@@ -409,6 +409,7 @@ enum {
 #endif
   pl_tag_pl_round_claim = 1,
   pl_tag_pl_round_drop = 3,
+  pl_tag_pl_round_chain_end = 3,
   pl_tag_pl_inact_find = 5,
   pl_tag_pl_inact_find_b = 5,
   pl_tag_pl_inact_find_c = 5,
@@ -416,6 +417,7 @@ enum {
   pl_tag_pl_inact_apply_b = 6,
   pl_tag_pl_inact_next = 6,
   pl_tag_pl_lev_0 = 7,
+  pl_tag_pl_pivot_sort = 7,
   pl_tag_pl_lev_a = 7,
   pl_tag_pl_lev_b = 7,
   pl_tag_pl_w_init = 8,
@@ -546,6 +548,7 @@ void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
 #define PL_SEG PL_SEG_ /* (blocks whose peeling state fits the LDS run in one part: launch_plan_kernel) */
 #define PL_STEER_SYNC __syncthreads()
 #define PL_NT_ ((uint32_t)NT)
+#define PL_Z ((uint32_t)PK)
 #ifdef PL_STAMP
   c.st_on = prof && b == 0 && tid == 0; c.st_prev = 0;
   if (tid < 24) sh->st_acc[tid] = 0;
@@ -567,6 +570,7 @@ void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
 #undef PL_PHASE1_CLAIM
 #undef PL_WFAST_RUN
 #undef PL_MHREV_RUN
+#undef PL_Z
 #undef PL_ACC
 }
 

@@ -44,6 +44,7 @@
 #define PL_ST_INACT 2u
 #define PL_ST_CLAIM 3u
 #define PL_NONE 0xFFFFFFFFu
+#define PL_RING_EMPTY 0xFFFFFFFFu
 #define PL_MAXH 16u
 #define PL_PATCH_STRIDE RQ_MAX_LT_COLS
 #define PL_MH_TILE 256u
@@ -227,6 +228,7 @@ typedef struct pl_shared {
   uint32_t lv_in_lds, opq_group[2];
   uint32_t tmp_mhoff; /* byte offset of Mb inside the dense LDS region, behind MhT (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
+  uint32_t ndone;             /* chained peeling (pl_round_chain): claims of the current list that have been dropped */
   uint32_t off_augt, aug_stride, mhrev; /* mhrev: the HDPC fold's z rows are in the workspace (pl_mhrev_store) */
   uint32_t bin_ct[NRQ_LANE_CLASSES]; /* ops of the GF(2) combination group per lane class of the target */
   uint32_t gj_A[32];   /* blocked Gauss-Jordan: pivot row b at its pivot step = XOR of the panel-start rows gj_pr[k], k in gj_A[b] */
@@ -324,9 +326,14 @@ struct PlanCtx {
   SB_MEM uint16_t *queue(uint32_t pq) const { uint16_t *q = qmem + (size_t)pq * qcap; PL_ASSUME_LDS(q); return q; }
   SB_MEM uint16_t *claim_l() const { uint16_t *q = qmem + 2u * (size_t)qcap; PL_ASSUME_LDS(q); return q; }
   SB_MEM uint16_t *claim_c() const { uint16_t *q = qmem + 3u * (size_t)qcap; PL_ASSUME_LDS(q); return q; }
+  /* the chained peel's list: the same bytes as qcap words, column | level + 1 << 16 (pl_round_chain_dev) */
+  SB_MEM uint32_t *ring() const { uint32_t *q = reinterpret_cast<uint32_t *>(qmem + 2u * (size_t)qcap); PL_ASSUME_LDS(q); return q; }
   SB_MEM uint32_t *part() const { uint32_t *q = partial; PL_ASSUME_LDS(q); return q; }
   SB_MEM uint8_t *gj_flag() const { uint8_t *q = gjmem; PL_ASSUME_LDS(q); return q; }
   SB_MEM uint8_t *gj_used() const { uint8_t *q = gjmem + lowcap; PL_ASSUME_LDS(q); return q; }
+  /* during peeling the same bytes hold one bit per column: "has entries in the patch CSC" (pl_init_a clears, pl_init_b sets,
+   * the chained drop phase reads -- a column without the bit needs no trip to pc_ptr); nullptr when L has more bits than that */
+  SB_MEM uint32_t *pcbits() const { if (p.L > 16u * lowcap) return nullptr; uint32_t *q = reinterpret_cast<uint32_t *>(gjmem); PL_ASSUME_LDS(q); return q; }
   uint8_t *lds_dyn; /* dynamic LDS region: peeling state (if it fits) and the dense stage (Mb, Mh) */
   uint32_t lds_dyn_bytes;
   uint8_t *dense_lds;
@@ -544,7 +551,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->ncand[0] = sh->ncand[1] = 0;
     sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = sh->cand[2] = PL_NONE;
     sh->nrows = 0; sh->nrec = 0; sh->uslot_fill = 0;
-    sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE; sh->mhrev = 0;
+    sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE; sh->mhrev = 0; sh->ndone = 0;
   }
   /* GF(256) tables into LDS (RFC 6330 section 5.7): generated by one thread, 255 steps */
   if (tid == 1 % nt) {
@@ -566,7 +573,9 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     c.pc_fill[col] = 0;
   }
   for (uint32_t x = tid; x < p.P; x += nt) c.ucol[x] = (uint16_t)(p.W + x);
-  for (uint32_t j = tid; j < c.lowcap; j += nt) c.gj_used()[j] = 0;
+  if (uint32_t *pcb = c.pcbits())
+    for (uint32_t j = tid; j < c.lowcap / 2u; j += nt) pcb[j] = 0u; /* (gj_flag / gj_used: theirs again from pl_lev_a on) */
+  for (uint32_t j = tid; j < c.qcap; j += nt) c.ring()[j] = PL_RING_EMPTY; /* (claim_l and claim_c as one list of words: pl_round_chain polls it) */
   if (Z != 0 && c.pk_cnt) {
     uint32_t *cnt = c.pk_cnt, *un = c.pk_un, *pa = c.pk_pa, *vb = c.pk_vb;
     PL_ASSUME_LDS(cnt); PL_ASSUME_LDS(un); PL_ASSUME_LDS(pa); PL_ASSUME_LDS(vb);
@@ -592,6 +601,7 @@ template <int Z> SB_HD void pl_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   if (sh->status) return;
   const rq_params &p = c.p;
   const uint32_t nl = c.job.nlost, pad = p.Kp - p.K;
+  uint32_t *pcb = c.pcbits();
   for (uint32_t i = tid; i < sh->npatch; i += nt) {
     uint32_t esi = c.rep_esi[i], row;
     bool bad = esi < p.K || esi >= (1u << 24);
@@ -611,6 +621,7 @@ template <int Z> SB_HD void pl_init_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
       dst[k] = (uint16_t)cols[k];
       if (cols[k] < p.W) { cnt++; sum += cols[k]; }
       PL_ATOM_ADD(&c.pc_fill[cols[k]], 1u);
+      if (pcb) PL_ATOM_OR(&pcb[cols[k] >> 5], 1u << (cols[k] & 31u));
     }
     c.patch_len[i] = (uint8_t)n;
     c.patch_of[row] = (uint16_t)i;
@@ -790,7 +801,7 @@ SB_HD void pl_drop_column_k(PlanCtx &c, const PlPk &k, uint32_t col, uint32_t lv
 /* Round `rd`: frontier = queue[rd&1], next frontier = queue[(rd+1)&1].
  * A: every frontier row that still has exactly one V column tries to claim it (compare-and-swap on the
  *    column); the winner becomes a pivot at the level its earlier column drops accumulated. */
-template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+template <bool LDS, bool RING = false> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   const uint32_t pq = rd & 1u;
@@ -814,7 +825,10 @@ template <bool LDS> SB_HD void pl_round_claim_t(PlanCtx &c, uint32_t rd, uint32_
     PL_ST(c, 6);
     s.rowinfo[r] = (info & PL_PATCHED) | lv; /* assigned: bit 31 cleared */
     s.colinfo[col] = (PL_ST_PIVOT << 30) | k;
-    if (PL_LIKELY(i < c.qcap)) { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    if (PL_LIKELY(i < c.qcap)) {
+      if (RING) c.ring()[i] = ((lv + 1u) << 16) | col;
+      else { c.claim_l()[i] = (uint16_t)(lv + 1u); c.claim_c()[i] = (uint16_t)col; }
+    } else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
     c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
     c.pivcol[k] = (uint16_t)col;
   }
@@ -849,7 +863,9 @@ SB_HD void pl_round_claim_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) 
   }
   if (tid == 0) { sh->nq[pq ^ 1u] = 0; sh->best = PL_NONE; }
 }
+SB_HD bool pl_chained(uint32_t Z);
 template <int Z> SB_HD void pl_round_claim(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  if (pl_chained((uint32_t)Z)) { pl_round_claim_t<true, true>(c, rd, tid, nt); return; } /* (the chained drop phase takes the claims as words) */
   PL_PEEL_DISPATCH3(pl_round_claim_, c, rd, tid, nt);
 }
 #ifndef PL_DROP_LG_MAX
@@ -894,8 +910,109 @@ SB_HD void pl_round_drop_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   for (uint32_t i = grp; i < nc; i += ngrp) pl_drop_column_k(c, k, c.claim_c()[i], c.claim_l()[i], pq ^ 1u, lane, 1u << lg);
   if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->npiv += nc; sh->nV -= nc; }
 }
+/* B, chained (peeling state in LDS, device): the claimed columns leave V, and a row that is left with ONE V column by that is
+ * claimed on the spot -- by the lane whose subtraction brought it there -- and joins the list this phase is working through,
+ * instead of waiting in the next frontier for the next round's claim phase.  The rounds between two inactivation events (a claim
+ * phase and a drop phase each, two barriers and ~4.1 k clocks per dependency level: 643 rounds at K=8192) become ONE phase whose
+ * chain is a claim's row list (two trips to L2), the subtraction, the compare-and-swap and the list entry: ~1.7 k clocks per
+ * level.  A row's level is the maximum over its dropped columns as before (each drop folds its level into the row before it
+ * subtracts, so the lane that brings the count to one sees them all), pivots are numbered by their place in the list, and who
+ * wins a column two rows are left with is decided by the compare-and-swap as before: same levels, an equally valid plan.
+ * List protocol: nclaim[pq] counts entries handed out; an entry is there when its column is not 0xFFFF (level first, column
+ * last, by the one lane); group g of 16 lanes takes entries g, g + groups, ...; ndone counts entries dropped; the phase is over
+ * when every entry handed out has been dropped (nobody is working, so nothing can be added).  The list is a ring of qcap
+ * entries.  The emulator (threads one after the other) keeps the round form. */
+#ifndef PL_CHAIN
+#define PL_CHAIN 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+/* (volatile accesses to LDS as DS instructions: through a generic pointer they become FLAT ones, whose waits count the
+ * outstanding HBM stores as well -- a trip to memory on the chain for every claim) */
+#define PL_VOL32(p) (*(volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t)(p))
+#define PL_VOL16(p) (*(volatile __attribute__((address_space(3))) uint16_t *)(uintptr_t)(p))
+__device__ __forceinline__ void pl_drop_column_chain(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lvl1, uint32_t pq, uint32_t npiv0, uint32_t lane0,
+                                                     uint32_t lanes) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint32_t dec = (1u << 24) | col;
+  const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a;
+  uint32_t pa = 0, npc = 0;
+  const uint32_t *pcb = c.pcbits();
+  if (!pcb || ((pcb[col >> 5] >> (col & 31u)) & 1u)) { pa = c.pc_ptr[col]; npc = c.pc_ptr[col + 1] - pa; } /* (per block: far away) */
+  for (uint32_t e = lane0; e < nb + npc; e += lanes) {
+    const bool base = e < nb;
+    const uint32_t r = base ? c.b_ridx[a + e] : c.pc_rows[pa + (e - nb)];
+    const uint32_t info = PL_VOL32(&s.rowinfo[r]);
+    if (base && (info & PL_PATCHED)) continue; /* base entry of a row this block replaced */
+    if (!(info & PL_UNASSIGNED)) { (void)PL_ATOM_SUB(&s.rowstate[r], dec); continue; } /* (the column's own pivot row, or a row that has its pivot) */
+    if (lvl1) PL_ATOM_MAX(&s.rowinfo[r], (info & ~PL_LEVEL_MASK) | lvl1);
+    /* the subtraction and, behind it in the LDS queue, the row's level as every earlier drop left it: one trip for both */
+    const uint32_t old = PL_ATOM_SUB(&s.rowstate[r], dec);
+    const uint32_t now = PL_VOL32(&s.rowinfo[r]);
+    if ((old >> 24) != 2u) continue;
+    /* one V column left, and every other column's level is in the row by now: claim it */
+    const uint32_t col2 = (old - dec) & 0xFFFFFFu;
+    if (PL_ATOM_CAS(&s.colinfo[col2], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue; /* another row got the column first */
+    const uint32_t lv = now & PL_LEVEL_MASK;
+    const uint32_t i2 = PL_ATOM_ADD(&sh->nclaim[pq], 1u), k = npiv0 + i2;
+    /* "assigned" before the list entry: whoever takes the entry meets this row in the column's list and must find it done (the
+     * LDS takes a wave's instructions in order: no wait, but the compiler must keep the two where they are).  The entry before
+     * everything else -- the chain waits for it; a slot that is not empty: the ring has come round on an entry nobody has dropped
+     * yet (qcap entries in flight) */
+    PL_VOL32(&s.rowinfo[r]) = (now & PL_PATCHED) | lv;
+    __asm__ volatile("" ::: "memory");
+    if (PL_ATOM_CAS(&c.ring()[i2 & (c.qcap - 1u)], PL_RING_EMPTY, ((lv + 1u) << 16) | col2) != PL_RING_EMPTY) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+    s.colinfo[col2] = (PL_ST_PIVOT << 30) | k;
+    c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
+    c.pivcol[k] = (uint16_t)col2;
+  }
+}
+__device__ __forceinline__ void pl_round_chain_dev(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const PlPeel s = pl_peel_state<true>(c);
+  const uint32_t pq = rd & 1u, npiv0 = sh->npiv;
+  constexpr uint32_t LG = 4u;
+  /* (consecutive entries to different waves: a wave's four groups move in lockstep, and an entry that arrives just after its
+   * neighbour would wait out the wave's whole trip) */
+  const uint32_t nwave = nt >> 6, grp = (tid >> 6) + nwave * ((tid >> LG) & 3u), lane = tid & ((1u << LG) - 1u), ngrp = nt >> LG;
+  const uint32_t qm = c.qcap - 1u; /* (a power of two: 256 .. 2048, nrq_plan_launch) */
+  uint32_t i = grp, idle = 0;
+  for (uint32_t guard = 0; guard < (1u << 24); guard++) {
+    const uint32_t v = PL_VOL32(&c.ring()[i & qm]); /* (the group's next entry: there as soon as its claimant has written it) */
+    if (v != PL_RING_EMPTY) {
+      pl_drop_column_chain(c, s, v & 0xFFFFu, v >> 16, pq, npiv0, lane, 1u << LG);
+      if (lane == 0u) { PL_VOL32(&c.ring()[i & qm]) = PL_RING_EMPTY; (void)PL_ATOM_ADD(&sh->ndone, 1u); }
+      i += ngrp; idle = 0;
+      continue;
+    }
+    if ((++idle & 3u) != 0u) continue;
+    /* nothing for this group for a while: over when everything handed out has been dropped (then nobody can add anything) */
+    const uint32_t d = PL_VOL32(&sh->ndone), n = PL_VOL32(&sh->nclaim[pq]);
+    if ((d == n && i >= n) || PL_VOL32(&sh->status)) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+#endif
 template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (PL_CHAIN && Z == 0) { pl_round_chain_dev(c, rd, tid, nt); return; } /* (the instance for peeling state in LDS; the books: pl_round_chain_end) */
+#endif
   PL_PEEL_DISPATCH3(pl_round_drop_, c, rd, tid, nt);
+}
+/* behind the barrier that ends a chained drop phase: the round's claims (the claim phase's and the chained ones) into the counts */
+template <int Z> SB_HD void pl_round_chain_end(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (tid != 0) return;
+  const uint32_t pq = rd & 1u, nc = sh->nclaim[pq];
+  sh->nclaim[pq ^ 1u] = 0; sh->npiv += nc; sh->nV -= nc; sh->ndone = 0;
+  (void)nt;
+}
+SB_HD bool pl_chained(uint32_t Z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return PL_CHAIN && Z == 0u;
+#else
+  (void)Z;
+  return false;
+#endif
 }
 /* No claimant in the frontier: find an open row with the fewest V columns.  Almost always that is a row with two; those
  * are kept on a stack as they come up (pl_drop_column pushes a row when its count drops to two; rows that start with
@@ -1111,7 +1228,12 @@ template <bool LDS> SB_HD void pl_inact_apply_b_t(PlanCtx &c, uint32_t rdrep, ui
     return;
   }
   const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
-  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column<LDS>(c, s, c.claim_c()[i], 0u, pq ^ 1u, lane, 32u);
+  for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) {
+    pl_drop_column<LDS>(c, s, c.claim_c()[i], 0u, pq ^ 1u, lane, 32u);
+#if defined(__HIP_DEVICE_COMPILE__) /* (the 32 lanes of a group run in lockstep there; the emulator's threads run one after the other and never chain) */
+    if (lane == 0u) c.claim_c()[i] = 0xFFFFu; /* (a list entry that is not "no entry" is one pl_round_chain may take) */
+#endif
+  }
   if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; }
 }
 SB_HD void pl_inact_apply_b_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
@@ -1221,6 +1343,55 @@ template <int Z> SB_HD void pl_lev_0(PlanCtx &c, uint32_t tid, uint32_t nt) {
   m = PL_WAVE_MAX(m);
   if (m && PL_WAVE_LEADER(tid)) PL_ATOM_MAX(&sh->nlev, m);
 }
+/* Behind a chained peel the pivots are numbered in the order the chain reached them, not level by level as the rounds number
+ * them; everything after walks the pivots in that order, and with the levels mixed the op records of one wave scatter over the
+ * whole stream (pl_w_init / pl_ops_emit: +0.35 M clocks at K=8192).  One counting sort by level puts the order back: the
+ * thread keeps its pivots in registers across the barriers, so the lists are permuted in place.  Device only, as the chain is. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void pl_pivot_sort_dev(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  constexpr uint32_t PER = 16u;
+  const uint32_t npiv = sh->npiv, nlev = sh->nlev; /* (levels 0 .. nlev-1) */
+  if (sh->status || nlev > c.qcap || npiv > PER * nt) return; /* (only the order is at stake) */
+  uint32_t *hist = reinterpret_cast<uint32_t *>(c.queue(0u)), *base = hist + c.qcap; /* (the queues and claim lists: 2 x qcap words) */
+  PL_ASSUME_LDS(hist); PL_ASSUME_LDS(base);
+  const uint32_t *rowinfo = c.rowinfo; PL_ASSUME_LDS(rowinfo);
+  uint32_t *colinfo = c.colinfo; PL_ASSUME_LDS(colinfo);
+  for (uint32_t l = tid; l < nlev; l += nt) hist[l] = 0u;
+  __syncthreads();
+  uint32_t slot[PER], col[PER], lv[PER], rk[PER];
+#pragma unroll
+  for (uint32_t j = 0; j < PER; j++) {
+    const uint32_t k = tid + j * nt;
+    slot[j] = k < npiv ? c.pivslot[k] : 0u; col[j] = k < npiv ? c.pivcol[k] : 0u;
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < PER; j++) lv[j] = rowinfo[slot[j]] & PL_LEVEL_MASK;
+#pragma unroll
+  for (uint32_t j = 0; j < PER; j++) rk[j] = tid + j * nt < npiv ? PL_ATOM_ADD(&hist[lv[j]], 1u) : 0u;
+  __syncthreads();
+  for (uint32_t l = tid; l < nlev; l += nt) {
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < l; i++) run += hist[i];
+    base[l] = run;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < PER; j++) {
+    if (tid + j * nt >= npiv) continue;
+    const uint32_t k2 = base[lv[j]] + rk[j];
+    c.pivslot[k2] = (uint16_t)slot[j]; c.pivcol[k2] = (uint16_t)col[j];
+    colinfo[col[j]] = (PL_ST_PIVOT << 30) | k2;
+  }
+}
+#endif
+template <int Z> SB_HD void pl_pivot_sort(PlanCtx &c, uint32_t tid, uint32_t nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (PL_CHAIN && Z == 0) pl_pivot_sort_dev(c, tid, nt);
+#else
+  (void)c; (void)tid; (void)nt;
+#endif
+}
 template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (tid == 0) {
@@ -1229,6 +1400,7 @@ template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     if (c.p.P + sh->ninact != u) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* cannot happen: every column is pivot or inactive */
   }
   for (uint32_t l = tid; l < sh->nlev + 2u; l += nt) { c.lev_ops[l] = 0; c.lev_fill[l] = 0; }
+  for (uint32_t j = tid; j < c.lowcap; j += nt) c.gj_used()[j] = 0; /* (the bytes were the patch-column bits during peeling) */
 }
 template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);

@@ -17,6 +17,7 @@
  *                         peeling decisions are taken in LDS), so the barrier behind it need not wait for those stores
  *     PL_STEER_SYNC       a workgroup barrier (nothing in the emulator)
  *     PL_NT_              threads of the workgroup
+ *     PL_Z                the instance of the phase functions the includer runs (kernel: its PK template argument; emulator: 1)
  * and provides `PlanCtx c`.  Every value that steers control flow is read from workgroup-shared state right after a
  * barrier -- and where the phase that follows may CHANGE that value (peeling counts, `best`, `status`), every thread
  * reads it into a local first and PL_STEER_SYNC separates the reads from that phase: without it a wave that is late
@@ -48,6 +49,7 @@
         PL_PHASE1_CLAIM(pl_round_claim, rd_);
         PL_ST(c, 8);
         PL_PHASE1(pl_round_drop, rd_);
+        if (pl_chained(PL_Z)) PL_PHASE1(pl_round_chain_end, rd_); /* (the chained form leaves the books to one thread behind its barrier) */
         PL_ST(c, 15);
       } else {
         /* one inactivation event: up to NRQ_MULTI_INACT open rows, sparsest first */
@@ -77,6 +79,7 @@
     }
   }
   PL_PHASE(pl_lev_0);
+  if (pl_chained(PL_Z)) PL_PHASE(pl_pivot_sort); /* (the chain numbers the pivots as it reaches them: back to level order) */
   PL_PHASE(pl_lev_a);
   const bool peeled_ = sh_->status == 0 && sh_->nV == 0;
   PL_STEER_SYNC; /* (later phases raise status when a capacity is exceeded) */

@@ -127,6 +127,7 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
 #define PL_SEG g_seg
 #define PL_STEER_SYNC do { } while (0)
 #define PL_NT_ PL_NT
+#define PL_Z 1u
   const uint32_t segs_[3] = {(g_split && g_went) ? 3u : 1u, (g_split && g_went) ? 4u : 2u, 2u};
   for (uint32_t pass_ = 0; pass_ < (!g_split ? 1u : g_went ? 3u : 2u); pass_++) {
     const uint32_t g_seg = g_split ? segs_[pass_] : 0u;
