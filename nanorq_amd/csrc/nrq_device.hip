@@ -416,6 +416,9 @@ enum {
   pl_tag_pl_inact_apply_a = 6,
   pl_tag_pl_inact_apply_b = 6,
   pl_tag_pl_inact_next = 6,
+  pl_tag_pl_event_scan = 5,
+  pl_tag_pl_event_pick = 6,
+  pl_tag_pl_event_drop = 6,
   pl_tag_pl_lev_0 = 7,
   pl_tag_pl_pivot_sort = 7,
   pl_tag_pl_lev_a = 7,
@@ -550,14 +553,14 @@ void nrq_plan_kernel(rq_params p, const uint8_t *__restrict__ kc,
 #define PL_NT_ ((uint32_t)NT)
 #define PL_Z ((uint32_t)PK)
 #ifdef PL_STAMP
-  c.st_on = prof && b == 0 && tid == 0; c.st_prev = 0;
-  if (tid < 24) sh->st_acc[tid] = 0;
+  c.st_on = prof && b == 0 && tid == 0; c.st_prev = 0; c.st_blk = prof && b == 0;
+  if (tid < 32) sh->st_acc[tid] = 0;
   __syncthreads();
 #endif
   if (PL_SEG_ == 2u || PL_SEG_ == 4u) PL_PHASE(pl_sh_restore);
 #include "planner_seq.h"
 #ifdef PL_STAMP
-  if (c.st_on) { for (int i_ = 0; i_ < 24; i_++) prof[32 + i_] = sh->st_acc[i_]; }
+  if (c.st_on) { for (int i_ = 0; i_ < 32; i_++) prof[32 + i_] = sh->st_acc[i_]; }
 #endif
   if (PL_SEG_ == 1u || PL_SEG_ == 4u) PL_PHASE(pl_mh_ext_clear);
   if (PL_SEG_ == 1u || PL_SEG_ == 3u || PL_SEG_ == 4u) PL_PHASE(pl_sh_save);
@@ -971,8 +974,10 @@ struct Tuning {
   bool no_wentry = false;    /* NRQ_NO_WENTRY: big blocks' entry pass by the planner workgroup itself, not by nrq_wentry_kernel */
   bool no_tiny = false;      /* NRQ_NO_TINY: no single-wave workgroups for tiny strip images */
   uint32_t tiny_div = 12;    /* NRQ_TINY_DIV: LDS images per CU from which the single-wave variant is used (launches with ONE plan: encode) */
-  uint32_t tiny_div_dec = 6; /* NRQ_TINY_DIV_DEC: the same for launches with a plan per block (decode): every strip walks a plan of its own
-                              * through L2 / HBM, and more independent strips in flight hide more of those trips */
+  uint32_t tiny_div_dec = 7; /* NRQ_TINY_DIV_DEC: the same for launches with a plan per block (decode): every strip walks a plan of its own
+                              * through L2 / HBM, and more independent strips in flight hide more of those trips.  (Seven: at six
+                              * images per CU -- K=1000 once its plans have a few inactive columns fewer -- the single waves lose to
+                              * the 256-thread workgroups, decode 11.1 against 7.4 ms per 2048 blocks; at seven, K=700, they win 5.2 : 6.2.) */
   bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
   bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
   int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
@@ -995,7 +1000,7 @@ struct Tuning {
     encplan_dev_min_l = (uint32_t)num("NRQ_ENCPLAN_DEV_MIN_L", 12000);
     wide_g = (uint32_t)num("NRQ_WIDE_G", 0);
     if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
-    no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 6);
+    no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 7);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
     plan_small_state = !flag("NRQ_PLAN_BIG_STATE"); plan_no_wg128 = flag("NRQ_PLAN_NO_WG128");
@@ -2368,7 +2373,8 @@ static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32
 #ifdef PL_STAMP
     fprintf(stderr, "[NRQ_PROF] round stamps (clocks up to point i, summed over the rounds):");
     for (int k = 0; k < 24; k++) fprintf(stderr, " %d:%llu", k, hp[32 + k]);
-    fprintf(stderr, "\n");
+    fprintf(stderr, "\n[NRQ_PROF] chained peel: entries %llu, group clocks busy %llu (waiting for the rows %llu), claims %llu, phases %llu clocks %llu; flags trip %llu, subtraction trip %llu, claims %llu\n",
+            hp[56], hp[57], hp[58], hp[59], hp[61], hp[60], hp[62], hp[63], hp[54]);
 #endif
     (void)hipFree(pprof);
   }

@@ -169,6 +169,7 @@ typedef struct nrq_plan_hdr {
  * "base" constraint structure -- the S LDPC rows and the LT rows of ISI 0..K'-1 (reference
  * precode_matrix_gen, precode.c:90-97) in CSR and CSC form -- which a decode only patches in the rows
  * whose source symbol was replaced by a repair symbol (reference patch_precode_matrix, nanorq.c:527-547). */
+#define NRQ_CHEAD 16u /* entries of a column head (off_chead) */
 typedef struct nrq_kconst_hdr {
   uint32_t Kp, S, H, n; /* n = Kp + S */
   uint32_t off_g;       /* u8[H*n] row-major: the HDPC block (reference precode.c:60-83) */
@@ -182,7 +183,8 @@ typedef struct nrq_kconst_hdr {
   uint32_t off_state;   /* u32[L]: per base row, (count << 24 | sum) of its column ids below W */
   uint32_t off_gt;      /* u8[n*16]: the HDPC block transposed, 16 bytes per column (rows >= H are 0) */
   uint32_t off_erow;    /* u16[nnz]: the row of every base CSR entry (lets a pass run over entries, not rows) */
-  uint32_t reserved[1];
+  uint32_t off_chead;   /* u16[L*16]: the first 16 row indices of every base CSC column, 0xFFFF behind the last (one trip to a
+                         * column's rows instead of pointer-then-list: the chained peel, planner_body.h) */
 } nrq_kconst_hdr;
 
 #endif

@@ -45,6 +45,7 @@
 #define PL_ST_CLAIM 3u
 #define PL_NONE 0xFFFFFFFFu
 #define PL_RING_EMPTY 0xFFFFFFFFu
+#define PL_PCHEAD 4u
 #define PL_MAXH 16u
 #define PL_PATCH_STRIDE RQ_MAX_LT_COLS
 #define PL_MH_TILE 256u
@@ -212,7 +213,7 @@ template <class LOAD, class STORE> SB_HD void pl_for_batched(uint32_t tid, uint3
 
 typedef struct pl_shared {
 #ifdef PL_STAMP
-  unsigned long long st_acc[24];
+  unsigned long long st_acc[32]; /* (24..31: the chained peel's counters, PL_STAMP) */
 #endif
   uint32_t status, fail_site; /* fail_site: source line that raised PL_FAIL_CAPACITY (diagnostics) */
   uint32_t defer_wt;          /* segmented run: W is transposed by nrq_wt_kernel, not by pl_final_c */
@@ -229,6 +230,8 @@ typedef struct pl_shared {
   uint32_t tmp_mhoff; /* byte offset of Mb inside the dense LDS region, behind MhT (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
   uint32_t ndone;             /* chained peeling (pl_round_chain): claims of the current list that have been dropped */
+  uint32_t ev_n, ev_min, ev_none; /* inactivation event, peeling state in LDS (pl_event_*): open rows with two V columns listed, the
+                                   * sparsest of the others, "no open row is left" */
   uint32_t off_augt, aug_stride, mhrev; /* mhrev: the HDPC fold's z rows are in the workspace (pl_mhrev_store) */
   uint32_t bin_ct[NRQ_LANE_CLASSES]; /* ops of the GF(2) combination group per lane class of the target */
   uint32_t gj_A[32];   /* blocked Gauss-Jordan: pivot row b at its pivot step = XOR of the panel-start rows gj_pr[k], k in gj_A[b] */
@@ -252,7 +255,7 @@ SB_HD bool pl_bin_in_stream(uint32_t L) { return L < NRQ_AUG_MATRIX_MIN_L; } /* 
 
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
-  uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, ucol, wrows,
+  uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, pc_head, ucol, wrows,
       lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, sh_save, mh_ext, cls_g, wentry, total;
 } pl_work_layout;
 
@@ -270,6 +273,7 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.pc_ptr = o;     o = pl_r16(o + (L + 1u) * 4u);
   w.pc_fill = o;    o = pl_r16(o + (L + 1u) * 4u);
   w.pc_rows = o;    o = pl_r16(o + npcap * PL_PATCH_STRIDE * 2u);
+  w.pc_head = o;    o = pl_r16(o + L * PL_PCHEAD * 2u); /* the first PL_PCHEAD patch rows of every column (pl_pcsc_fill; the chained peel reads them with pc_fill, the column's count) */
   w.ucol = o;       o = pl_r16(o + ucap * 2u);
   w.wrows = o;      o = pl_r16(o + Mcap * wprcap * 4u); /* W rows by SLOT (pivot rows and leftover rows) */
   w.lev_ops = o;    o = pl_r16(o + (L + 2u) * 4u);
@@ -314,7 +318,7 @@ struct PlanCtx {
   const uint8_t *kc;
   const nrq_kconst_hdr *kh;
   const uint32_t *b_rptr, *b_cptr, *b_state;
-  const uint16_t *b_cidx, *b_ridx, *b_erow;
+  const uint16_t *b_cidx, *b_ridx, *b_erow, *b_chead;
   const uint8_t *G, *GT;
   nrq_planjob job;
   const uint32_t *lost, *rep_esi;
@@ -353,6 +357,7 @@ struct PlanCtx {
 #ifdef PL_STAMP /* diagnostic build: thread 0 of block 0 accumulates shader clocks between points of a peeling round (pl_shared::st_acc) */
   unsigned long long st_prev;
   bool st_on;
+  bool st_blk; /* every thread of block 0 */
 #endif
   /* the entry pass on many workgroups (nrq_wentry_kernel, big blocks; job.mode bit 9): the column levels stay in HBM whatever the
    * LDS would hold, and while the helper's workgroups count, the class counters and the record counter are the workspace's */
@@ -360,7 +365,7 @@ struct PlanCtx {
   uint32_t *cls_glob;  /* non-null: pl_cls() is this array in HBM */
   uint32_t *nrec_ptr;  /* the record counter: &sh->nrec, or the workspace's */
   uint32_t *wentry;    /* workspace: [0] records, [1] status, [2] fail site */
-  uint16_t *patch_of, *patch_cols, *pc_rows, *ucol;
+  uint16_t *patch_of, *patch_cols, *pc_rows, *pc_head, *ucol;
   uint8_t *patch_len;
   uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *lev_fin, *red_row,
       *red_x, *rec_word, *rec_idx;
@@ -401,6 +406,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.b_cidx = reinterpret_cast<const uint16_t *>(kc + c.kh->off_cidx);
   c.b_cptr = reinterpret_cast<const uint32_t *>(kc + c.kh->off_cptr);
   c.b_ridx = reinterpret_cast<const uint16_t *>(kc + c.kh->off_ridx);
+  c.b_chead = reinterpret_cast<const uint16_t *>(kc + c.kh->off_chead);
   c.b_erow = reinterpret_cast<const uint16_t *>(kc + c.kh->off_erow);
   c.b_state = reinterpret_cast<const uint32_t *>(kc + c.kh->off_state);
   c.G = kc + c.kh->off_g;
@@ -464,6 +470,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.pc_ptr = reinterpret_cast<uint32_t *>(w + c.wl.pc_ptr);
   c.pc_fill = reinterpret_cast<uint32_t *>(w + c.wl.pc_fill);
   c.pc_rows = reinterpret_cast<uint16_t *>(w + c.wl.pc_rows);
+  c.pc_head = reinterpret_cast<uint16_t *>(w + c.wl.pc_head);
   c.ucol = reinterpret_cast<uint16_t *>(w + c.wl.ucol);
   c.wrows = reinterpret_cast<uint32_t *>(w + c.wl.wrows);
   c.lev_ops = reinterpret_cast<uint32_t *>(w + c.wl.lev_ops);
@@ -551,7 +558,7 @@ template <int Z> SB_HD void pl_init_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
     sh->ncand[0] = sh->ncand[1] = 0;
     sh->nlow = 0; sh->r2 = 0; sh->nfree = 0; sh->cand[0] = sh->cand[1] = sh->cand[2] = PL_NONE;
     sh->nrows = 0; sh->nrec = 0; sh->uslot_fill = 0;
-    sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE; sh->mhrev = 0; sh->ndone = 0;
+    sh->dense_ok = 0; sh->nextra = 0; sh->spare_base = 0; sh->spare_fill = 0; sh->xcol = PL_NONE; sh->mhrev = 0; sh->ndone = 0; sh->ev_n = 0; sh->ev_min = PL_NONE; sh->ev_none = 0;
   }
   /* GF(256) tables into LDS (RFC 6330 section 5.7): generated by one thread, 255 steps */
   if (tid == 1 % nt) {
@@ -683,7 +690,10 @@ template <int Z> SB_HD void pl_pcsc_fill(PlanCtx &c, uint32_t tid, uint32_t nt) 
       for (uint32_t j = 0; j < PL_BATCH; j++) pos[j] = k0 + j < n ? PL_ATOM_ADD(&c.pc_fill[col[j]], 1u) : 0u;
 #pragma unroll
       for (uint32_t j = 0; j < PL_BATCH; j++)
-        if (k0 + j < n) c.pc_rows[base[j] + pos[j]] = (uint16_t)row;
+        if (k0 + j < n) {
+          c.pc_rows[base[j] + pos[j]] = (uint16_t)row;
+          if (pos[j] < PL_PCHEAD) c.pc_head[col[j] * PL_PCHEAD + pos[j]] = (uint16_t)row;
+        }
     }
   }
   const bool stack2 = !pl_peel_in_lds(c);
@@ -930,40 +940,90 @@ SB_HD void pl_round_drop_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
  * outstanding HBM stores as well -- a trip to memory on the chain for every claim) */
 #define PL_VOL32(p) (*(volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t)(p))
 #define PL_VOL16(p) (*(volatile __attribute__((address_space(3))) uint16_t *)(uintptr_t)(p))
-__device__ __forceinline__ void pl_drop_column_chain(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lvl1, uint32_t pq, uint32_t npiv0, uint32_t lane0,
-                                                     uint32_t lanes) {
+/* a row left with one V column by this lane's subtraction (old: what the subtraction found, now: the row's flags and level behind
+ * it): claim that column, number the pivot, hand the column to the list */
+__device__ __forceinline__ void pl_chain_claim(PlanCtx &c, const PlPeel &s, uint32_t r, uint32_t old, uint32_t now, uint32_t dec, uint32_t pq, uint32_t npiv0) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint32_t col2 = (old - dec) & 0xFFFFFFu;
+  if (PL_ATOM_CAS(&s.colinfo[col2], 0u, (PL_ST_CLAIM << 30) | r) != 0u) return; /* another row got the column first */
+  const uint32_t lv = now & PL_LEVEL_MASK;
+  const uint32_t i2 = PL_ATOM_ADD(&sh->nclaim[pq], 1u), k = npiv0 + i2;
+  /* "assigned" before the list entry: whoever takes the entry meets this row in the column's list and must find it done (the
+   * LDS takes a wave's instructions in order: no wait, but the compiler must keep the two where they are).  The entry before
+   * everything else -- the chain waits for it; a slot that is not empty: the ring has come round on an entry nobody has dropped
+   * yet (qcap entries in flight) */
+  PL_VOL32(&s.rowinfo[r]) = (now & PL_PATCHED) | lv;
+  __asm__ volatile("" ::: "memory");
+  const uint32_t was = PL_ATOM_CAS(&c.ring()[i2 & (c.qcap - 1u)], PL_RING_EMPTY, ((lv + 1u) << 16) | col2);
+  s.colinfo[col2] = (PL_ST_PIVOT << 30) | k;
+  c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
+  c.pivcol[k] = (uint16_t)col2;
+  if (was != PL_RING_EMPTY) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+#ifdef PL_STAMP
+  if (c.st_blk) atomicAdd(&sh->st_acc[27], 1ull);
+#endif
+}
+/* one row of a column that leaves V (the chained form of pl_drop_column's loop body).  Four LDS instructions, two of them waited
+ * for (the flags; the subtraction with the level behind it) -- and a claim's three atomics, each waited for: measured on the
+ * stamped build (-DPL_STAMP) a read costs ~130 clocks, an atomic with a result ~300, and these trips, not the one to memory
+ * (~350 for the rows), are the chain: ~2.2 k clocks from taking an entry to having dropped it at K=8192.  (Base and patch row of a
+ * lane side by side, one pass for both, was no faster: the second row's instructions are issued for every column then.) */
+__device__ __forceinline__ void pl_chain_row(PlanCtx &c, const PlPeel &s, uint32_t r, bool base, uint32_t dec, uint32_t lvl1, uint32_t pq, uint32_t npiv0) {
+#ifdef PL_STAMP
+  const bool st_ = c.st_blk && (threadIdx.x & 15u) == 0u;
+  const unsigned long long ta_ = clock64();
+#endif
+  const uint32_t info = PL_VOL32(&s.rowinfo[r]);
+#ifdef PL_STAMP
+  __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long tb_ = clock64();
+  if (st_) atomicAdd(&c.sh->st_acc[30], tb_ - ta_);
+#endif
+  if (base && (info & PL_PATCHED)) return; /* base entry of a row this block replaced */
+  if (!(info & PL_UNASSIGNED)) { (void)PL_ATOM_SUB(&s.rowstate[r], dec); return; } /* (the column's own pivot row, or a row that has its pivot) */
+  if (lvl1) PL_ATOM_MAX(&s.rowinfo[r], (info & ~PL_LEVEL_MASK) | lvl1);
+  /* the subtraction and, behind it in the LDS queue, the row's level as every earlier drop left it: one trip for both */
+  const uint32_t old = PL_ATOM_SUB(&s.rowstate[r], dec);
+  const uint32_t now = PL_VOL32(&s.rowinfo[r]);
+#ifdef PL_STAMP
+  __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long tc_ = clock64();
+  if (st_) atomicAdd(&c.sh->st_acc[31], tc_ - tb_);
+#endif
+  /* one V column left, and every other column's level is in the row by now: claim it */
+  if ((old >> 24) == 2u) pl_chain_claim(c, s, r, old, now, dec, pq, npiv0);
+#ifdef PL_STAMP
+  if (st_) atomicAdd(&c.sh->st_acc[22], (unsigned long long)clock64() - tc_);
+#endif
+}
+/* column `col` leaves V, by a group of 16 lanes: the rows come from the column's head in the constants (NRQ_CHEAD = 16 entries:
+ * the lane's own, ONE trip -- pointer-then-list is two, on a chain that is little else) and, for a column the block's patch rows
+ * touch (a bit in LDS says so), from the block's patch heads with the column's count beside them, in flight with the first.
+ * Columns with more than 16 base rows or PL_PCHEAD patch rows (a few per block) go on through the pointers. */
+__device__ __forceinline__ void pl_drop_column_chain(PlanCtx &c, const PlPeel &s, uint32_t col, uint32_t lvl1, uint32_t pq, uint32_t npiv0, uint32_t lane0) {
   const uint32_t dec = (1u << 24) | col;
-  const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a;
-  uint32_t pa = 0, npc = 0;
+  const uint16_t *hd = c.b_chead + (size_t)col * NRQ_CHEAD;
+  const uint32_t r0 = hd[lane0], last = hd[NRQ_CHEAD - 1u];
+  uint32_t pcnt = 0, r1 = 0xFFFFu;
   const uint32_t *pcb = c.pcbits();
-  if (!pcb || ((pcb[col >> 5] >> (col & 31u)) & 1u)) { pa = c.pc_ptr[col]; npc = c.pc_ptr[col + 1] - pa; } /* (per block: far away) */
-  for (uint32_t e = lane0; e < nb + npc; e += lanes) {
-    const bool base = e < nb;
-    const uint32_t r = base ? c.b_ridx[a + e] : c.pc_rows[pa + (e - nb)];
-    const uint32_t info = PL_VOL32(&s.rowinfo[r]);
-    if (base && (info & PL_PATCHED)) continue; /* base entry of a row this block replaced */
-    if (!(info & PL_UNASSIGNED)) { (void)PL_ATOM_SUB(&s.rowstate[r], dec); continue; } /* (the column's own pivot row, or a row that has its pivot) */
-    if (lvl1) PL_ATOM_MAX(&s.rowinfo[r], (info & ~PL_LEVEL_MASK) | lvl1);
-    /* the subtraction and, behind it in the LDS queue, the row's level as every earlier drop left it: one trip for both */
-    const uint32_t old = PL_ATOM_SUB(&s.rowstate[r], dec);
-    const uint32_t now = PL_VOL32(&s.rowinfo[r]);
-    if ((old >> 24) != 2u) continue;
-    /* one V column left, and every other column's level is in the row by now: claim it */
-    const uint32_t col2 = (old - dec) & 0xFFFFFFu;
-    if (PL_ATOM_CAS(&s.colinfo[col2], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue; /* another row got the column first */
-    const uint32_t lv = now & PL_LEVEL_MASK;
-    const uint32_t i2 = PL_ATOM_ADD(&sh->nclaim[pq], 1u), k = npiv0 + i2;
-    /* "assigned" before the list entry: whoever takes the entry meets this row in the column's list and must find it done (the
-     * LDS takes a wave's instructions in order: no wait, but the compiler must keep the two where they are).  The entry before
-     * everything else -- the chain waits for it; a slot that is not empty: the ring has come round on an entry nobody has dropped
-     * yet (qcap entries in flight) */
-    PL_VOL32(&s.rowinfo[r]) = (now & PL_PATCHED) | lv;
-    __asm__ volatile("" ::: "memory");
-    if (PL_ATOM_CAS(&c.ring()[i2 & (c.qcap - 1u)], PL_RING_EMPTY, ((lv + 1u) << 16) | col2) != PL_RING_EMPTY) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
-    s.colinfo[col2] = (PL_ST_PIVOT << 30) | k;
-    c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
-    c.pivcol[k] = (uint16_t)col2;
+  if (!pcb || ((pcb[col >> 5] >> (col & 31u)) & 1u)) { /* (per block: far away) */
+    pcnt = c.pc_fill[col];
+    if (lane0 < PL_PCHEAD) r1 = c.pc_head[col * PL_PCHEAD + lane0];
+  }
+#ifdef PL_STAMP
+  const unsigned long long t0_ = clock64();
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (c.st_blk && lane0 == 0u) atomicAdd(&c.sh->st_acc[26], (unsigned long long)clock64() - t0_);
+#endif
+  if (r0 != 0xFFFFu) pl_chain_row(c, s, r0, true, dec, lvl1, pq, npiv0);
+  if (lane0 < PL_PCHEAD && lane0 < pcnt) pl_chain_row(c, s, r1, false, dec, lvl1, pq, npiv0);
+  if (last != 0xFFFFu) { /* (the head is full: there may be more) */
+    const uint32_t a = c.b_cptr[col], nb = c.b_cptr[col + 1] - a;
+    for (uint32_t e = NRQ_CHEAD + lane0; e < nb; e += 16u) pl_chain_row(c, s, c.b_ridx[a + e], true, dec, lvl1, pq, npiv0);
+  }
+  if (pcnt > PL_PCHEAD) {
+    const uint32_t pa = c.pc_ptr[col];
+    for (uint32_t e = PL_PCHEAD + lane0; e < pcnt; e += 16u) pl_chain_row(c, s, c.pc_rows[pa + e], false, dec, lvl1, pq, npiv0);
   }
 }
 __device__ __forceinline__ void pl_round_chain_dev(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
@@ -976,10 +1036,19 @@ __device__ __forceinline__ void pl_round_chain_dev(PlanCtx &c, uint32_t rd, uint
   const uint32_t nwave = nt >> 6, grp = (tid >> 6) + nwave * ((tid >> LG) & 3u), lane = tid & ((1u << LG) - 1u), ngrp = nt >> LG;
   const uint32_t qm = c.qcap - 1u; /* (a power of two: 256 .. 2048, nrq_plan_launch) */
   uint32_t i = grp, idle = 0;
+#ifdef PL_STAMP
+  const unsigned long long tp_ = clock64();
+#endif
   for (uint32_t guard = 0; guard < (1u << 24); guard++) {
     const uint32_t v = PL_VOL32(&c.ring()[i & qm]); /* (the group's next entry: there as soon as its claimant has written it) */
     if (v != PL_RING_EMPTY) {
-      pl_drop_column_chain(c, s, v & 0xFFFFu, v >> 16, pq, npiv0, lane, 1u << LG);
+#ifdef PL_STAMP
+      const unsigned long long t0_ = clock64();
+#endif
+      pl_drop_column_chain(c, s, v & 0xFFFFu, v >> 16, pq, npiv0, lane);
+#ifdef PL_STAMP
+      if (c.st_blk && lane == 0u) { atomicAdd(&sh->st_acc[24], 1ull); atomicAdd(&sh->st_acc[25], (unsigned long long)clock64() - t0_); }
+#endif
       if (lane == 0u) { PL_VOL32(&c.ring()[i & qm]) = PL_RING_EMPTY; (void)PL_ATOM_ADD(&sh->ndone, 1u); }
       i += ngrp; idle = 0;
       continue;
@@ -990,6 +1059,9 @@ __device__ __forceinline__ void pl_round_chain_dev(PlanCtx &c, uint32_t rd, uint
     if ((d == n && i >= n) || PL_VOL32(&sh->status)) break;
     __builtin_amdgcn_s_sleep(1);
   }
+#ifdef PL_STAMP
+  if (c.st_blk && tid == 0u) { atomicAdd(&sh->st_acc[28], (unsigned long long)clock64() - tp_); atomicAdd(&sh->st_acc[29], 1ull); }
+#endif
 }
 #endif
 template <int Z> SB_HD void pl_round_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
@@ -1068,15 +1140,17 @@ template <bool LDS> SB_HD void pl_inact_find_b_t(PlanCtx &c, uint32_t rdrep, uin
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const PlPeel s = pl_peel_state<LDS>(c);
   uint32_t best = PL_NONE;
-  for (uint32_t r = tid; r < sh->M; r += nt) {
-    if (!(s.rowinfo[r] & PL_UNASSIGNED)) continue;
-    const uint32_t cnt = s.rowstate[r] >> 24;
-    if (cnt >= 2u) {
+  /* (a batch of rows' words asked for together: row by row, flags then count, each was a trip of its own -- 3.8 k clocks a search
+   * for nine rows per thread at K=8192, 78 searches) */
+  struct IS { uint32_t info, st; };
+  pl_for_batched(tid, nt, sh->M, [&](uint32_t r) { return IS{s.rowinfo[r], s.rowstate[r]}; }, [&](uint32_t r, IS v) {
+    const uint32_t cnt = v.st >> 24;
+    if ((v.info & PL_UNASSIGNED) && cnt >= 2u) {
       const uint32_t key = (cnt << 16) | r; /* (ties by level-so-far give 424 -> 312 levels at the same u, but the kernel is
                                               * 2.5 % slower for it: measured, not adopted) */
       if (key < best) best = key;
     }
-  }
+  });
   best = PL_WAVE_MIN(best);
   if (best != PL_NONE && PL_WAVE_LEADER(tid)) PL_ATOM_MIN(&sh->best, best);
   (void)rdrep;
@@ -1256,6 +1330,105 @@ template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rdrep, uint32_
 /* between two rows of one event: forget the previous choice */
 template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   if (tid == 0) { c.sh->best = PL_NONE; c.sh->nclaim[rdrep & 1u] = 0; }
+}
+
+/* ---- one inactivation event in three phases (peeling state in LDS) ----
+ * Row after row -- search, choose, drop, a handful of barriers each, up to NRQ_MULTI_INACT rows an event -- an event was ~60 k
+ * clocks of mostly barriers (78 rows in 14 events at K=8192: 0.86 M clocks).  Here the search lists up to PL_EVENT_ROWS open
+ * rows with two V columns in one pass (which of the thousands there are does not matter: whichever waves come first), one
+ * thread per listed row walks its row and inactivates all but one of its V columns (a compare-and-swap on the column: two rows
+ * may hold the same one), and one drop phase takes all those columns out of V.  Rows of one event almost never share a column
+ * (two of ~5000); when they do, a column more than necessary may go inactive, which costs nothing but that column. */
+#define PL_EVENT_ROWS NRQ_MULTI_INACT
+/* (small blocks: fewer rows an event -- with six at once a block of a few hundred symbols ends up with more inactive columns than
+ * row after row, K=256: the decode launch lost a workgroup per CU to the larger dense stage) */
+SB_HD uint32_t pl_event_rows(const PlanCtx &c) { const uint32_t n = c.p.W / 128u; return n < 2u ? 2u : n < PL_EVENT_ROWS ? n : PL_EVENT_ROWS; }
+template <int Z> SB_HD void pl_event_scan(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (!PL_PEEL_LDS(Z)) return;
+  const PlPeel s = pl_peel_state<true>(c);
+  const uint32_t pq = rd & 1u;
+  uint16_t *evrow = c.queue(pq); /* (the frontier is empty: that is why there is an event) */
+  uint32_t best = PL_NONE;
+  struct IS { uint32_t info, st; };
+  pl_for_batched(tid, nt, sh->M, [&](uint32_t r) { return IS{s.rowinfo[r], s.rowstate[r]}; }, [&](uint32_t r, IS v) {
+    const uint32_t cnt = v.st >> 24;
+    const bool open = (v.info & PL_UNASSIGNED) && cnt >= 2u, two = open && cnt == 2u;
+    const uint32_t at = PL_WAVE_TAKE(&sh->ev_n, two);
+    if (two && at < PL_EVENT_ROWS) evrow[at] = (uint16_t)r; /* (pl_event_pick takes pl_event_rows() of them) */
+    if (open && !two) { const uint32_t key = (cnt << 16) | r; if (key < best) best = key; }
+  });
+  best = PL_WAVE_MIN(best);
+  if (best != PL_NONE && PL_WAVE_LEADER(tid)) PL_ATOM_MIN(&sh->ev_min, best);
+  if (tid == 0) { sh->nq[pq ^ 1u] = 0; sh->nclaim[pq] = 0; }
+}
+/* all but one V column of row r leave V for the inactive set: the one with the fewest entries stays (heuristic) */
+template <bool LDS> SB_HD void pl_event_row(PlanCtx &c, const PlPeel &s, uint32_t r, uint32_t pq) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint16_t *cols;
+  const uint32_t n = pl_row(c, r, &cols);
+  uint32_t keep = PL_NONE, keepdeg = PL_NONE;
+  constexpr uint32_t CB = 8; /* (eight entries at a time with all their loads in flight together -- entry, column state, four list bounds) */
+  for (uint32_t k0 = 0; k0 < n; k0 += CB) {
+    uint32_t col[CB], inf[CB], dg[CB];
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) {
+      inf[q] = s.colinfo[col[q]];
+      dg[q] = (c.b_cptr[col[q] + 1] - c.b_cptr[col[q]]) + (c.pc_ptr[col[q] + 1] - c.pc_ptr[col[q]]);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++)
+      if (k0 + q < n && inf[q] == 0u && dg[q] < keepdeg) { keepdeg = dg[q]; keep = col[q]; }
+  }
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t col = cols[k];
+    if (col == keep || s.colinfo[col] != 0u) continue;
+    if (PL_ATOM_CAS(&s.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue; /* (another row of the event took it) */
+    const uint32_t x = c.p.P + PL_ATOM_ADD(&sh->ninact, 1u), m = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
+    if (x >= c.ucap || m >= c.qcap) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); continue; }
+    s.colinfo[col] = (PL_ST_INACT << 30) | x;
+    c.ucol[x] = (uint16_t)col;
+    c.claim_c()[m] = (uint16_t)col; /* "columns to drop" */
+    (void)PL_ATOM_SUB(&sh->nV, 1u);
+  }
+}
+template <int Z> SB_HD void pl_event_pick(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (!PL_PEEL_LDS(Z)) return;
+  const PlPeel s = pl_peel_state<true>(c);
+  const uint32_t pq = rd & 1u;
+  const uint32_t n2 = sh->ev_n < pl_event_rows(c) ? sh->ev_n : pl_event_rows(c), lone = sh->ev_min;
+  if (n2 == 0u && lone == PL_NONE) { /* no open row is left: what remains of V goes inactive, and peeling is over */
+    for (uint32_t col = tid; col < c.p.W; col += nt) {
+      if (s.colinfo[col] == 0u) {
+        const uint32_t x = c.p.P + PL_ATOM_ADD(&sh->ninact, 1u);
+        if (x < c.ucap) { s.colinfo[col] = (PL_ST_INACT << 30) | x; c.ucol[x] = (uint16_t)col; }
+        else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+      }
+    }
+    if (tid == 0) sh->ev_none = 1u;
+    return;
+  }
+  if (n2) { if (tid < n2) pl_event_row<true>(c, s, c.queue(pq)[tid], pq); }
+  else if (tid == 0) pl_event_row<true>(c, s, lone & 0xFFFFu, pq); /* (no row with two: the sparsest one) */
+}
+template <int Z> SB_HD void pl_event_drop(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (!PL_PEEL_LDS(Z)) return;
+  const PlPeel s = pl_peel_state<true>(c);
+  const uint32_t pq = rd & 1u;
+  if (sh->status) return; /* (a capacity gave out while the columns were listed: the list has holes, and the block goes to the host planner) */
+  if (sh->ev_none) { if (tid == 0) sh->nV = 0; return; }
+  const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5, nc = sh->nclaim[pq] < c.qcap ? sh->nclaim[pq] : c.qcap;
+  for (uint32_t i = grp; i < nc; i += ngrp) {
+    pl_drop_column<true>(c, s, c.claim_c()[i], 0u, pq ^ 1u, lane, 32u);
+#if defined(__HIP_DEVICE_COMPILE__) /* (the 32 lanes of a group run in lockstep there; the emulator's threads run one after the other and never chain) */
+    if (lane == 0u) c.claim_c()[i] = 0xFFFFu; /* (a list entry that is not "no entry" is one pl_round_chain may take) */
+#endif
+  }
+  if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->ev_n = 0; sh->ev_min = PL_NONE; }
 }
 
 /* =============================== phase 2: levels, W ========================================== */

@@ -127,6 +127,7 @@ extern "C" int nrq_host_kconst_build(uint32_t K, uint8_t **out, uint32_t *out_by
   h.off_state = off; off = align16(off + L * 4);
   h.off_gt = off; off = align16(off + n * 16);
   h.off_erow = off; off = align16(off + nnz * 2);
+  h.off_chead = off; off = align16(off + L * NRQ_CHEAD * 2);
   h.total_bytes = off;
   uint8_t *buf = (uint8_t *)calloc(off, 1);
   if (!buf) return -2;
@@ -150,6 +151,9 @@ extern "C" int nrq_host_kconst_build(uint32_t K, uint8_t **out, uint32_t *out_by
   memcpy(buf + h.off_cptr, cptr.data(), (size_t)(L + 1) * 4);
   memcpy(buf + h.off_ridx, ridx.data(), (size_t)nnz * 2);
   memcpy(buf + h.off_state, state.data(), (size_t)L * 4);
+  for (uint32_t c = 0; c < L; c++)
+    for (uint32_t q = 0; q < NRQ_CHEAD; q++)
+      reinterpret_cast<uint16_t *>(buf + h.off_chead)[(size_t)c * NRQ_CHEAD + q] = cptr[c] + q < cptr[c + 1] ? ridx[cptr[c] + q] : (uint16_t)0xFFFFu;
   for (uint32_t r = 0; r < L; r++)
     for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++) reinterpret_cast<uint16_t *>(buf + h.off_erow)[e] = (uint16_t)r;
   for (uint32_t c = 0; c < n; c++)

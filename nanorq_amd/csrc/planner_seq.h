@@ -51,6 +51,11 @@
         PL_PHASE1(pl_round_drop, rd_);
         if (pl_chained(PL_Z)) PL_PHASE1(pl_round_chain_end, rd_); /* (the chained form leaves the books to one thread behind its barrier) */
         PL_ST(c, 15);
+      } else if (pl_peel_in_lds(c)) {
+        /* one inactivation event, peeling state in LDS: up to NRQ_MULTI_INACT open rows with two V columns, all at once */
+        PL_PHASE1(pl_event_scan, rd_);
+        PL_PHASE1(pl_event_pick, rd_);
+        PL_PHASE1(pl_event_drop, rd_);
       } else {
         /* one inactivation event: up to NRQ_MULTI_INACT open rows, sparsest first */
         for (uint32_t rep_ = 0; rep_ < NRQ_MULTI_INACT; rep_++) {
