@@ -33,6 +33,11 @@
 static_assert(RQ_LT_COLS_MAX_REAL <= NRQ_LT_LIST_MAX, "solve_body.h sizes the slack behind out_slots[] for the longest LT list");
 
 #define NRQ_LDS_MAX 163840u /* 160 KiB per workgroup on gfx950 */
+/* ... handed out in pieces of 320 dwords (LLVM getLdsDwGranularity for the 160 KiB parts): what a workgroup asks for is rounded
+ * up to that, and how many workgroups share a CU follows from the rounded size.  (The HIP occupancy query divides the bytes:
+ * it said nine 18 016-byte workgroups fit, eight were resident, and the ninth of every CU ran as a second round -- K=500.) */
+#define NRQ_LDS_GRANULE 1280u
+static inline uint32_t lds_alloc(uint32_t bytes) { return (bytes + NRQ_LDS_GRANULE - 1u) / NRQ_LDS_GRANULE * NRQ_LDS_GRANULE; }
 #ifndef NRQ_WG
 #define NRQ_WG 768 /* threads of the solve workgroup: 3 waves per SIMD.  One workgroup owns the CU (LDS), and its phases are
                     * bound by instruction issue and LDS latency: measured 256 -> 512 -> 768 -> 1024 threads = 673 / 796 / 835 /
@@ -973,7 +978,10 @@ struct Tuning {
   uint32_t wide_g = 0;       /* NRQ_WIDE_G: wide strips of G = 2, 4, 8 lanes per element where two such images fit a CU */
   bool no_wentry = false;    /* NRQ_NO_WENTRY: big blocks' entry pass by the planner workgroup itself, not by nrq_wentry_kernel */
   bool no_tiny = false;      /* NRQ_NO_TINY: no single-wave workgroups for tiny strip images */
-  uint32_t tiny_div = 12;    /* NRQ_TINY_DIV: LDS images per CU from which the single-wave variant is used (launches with ONE plan: encode) */
+  uint32_t tiny_div = 7;     /* NRQ_TINY_DIV: LDS images per CU from which the single-wave variant is used (launches with ONE plan: encode).
+                              * (Twelve until the workgroups per CU were counted by allocated LDS, lds_alloc(): between eight and
+                              * eleven images the ninth.. workgroup of a CU had run as a second round and the variant looked slow;
+                              * with the count right it wins from seven on -- K=450 +22 %, K=500 +14 %, K=600 +12 %, K=700 +2 %.) */
   uint32_t tiny_div_dec = 7; /* NRQ_TINY_DIV_DEC: the same for launches with a plan per block (decode): every strip walks a plan of its own
                               * through L2 / HBM, and more independent strips in flight hide more of those trips.  (Seven: at six
                               * images per CU -- K=1000 once its plans have a few inactive columns fewer -- the single waves lose to
@@ -1000,7 +1008,7 @@ struct Tuning {
     encplan_dev_min_l = (uint32_t)num("NRQ_ENCPLAN_DEV_MIN_L", 12000);
     wide_g = (uint32_t)num("NRQ_WIDE_G", 0);
     if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
-    no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 12); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 7);
+    no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 7); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 7);
     no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
     plan_small_state = !flag("NRQ_PLAN_BIG_STATE"); plan_no_wg128 = flag("NRQ_PLAN_NO_WG128");
@@ -1212,7 +1220,7 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     /* (queues / claim lists / Gauss-Jordan flags: a frontier, a round's claims and the leftover rows are at most the block's rows) */
     const uint32_t q_s = Mcap <= 248u ? 256u : p.L <= 1500u ? 512u : 1024u, low_s = Mcap <= 248u ? 256u : p.L <= 1500u ? 384u : 768u;
     const uint32_t sh_s = ctx->tune.plan_small_state ? pl_shared_bytes(q_s, low_s, PL_NT_MIN) : sh_bytes;
-    if (fit + sh_s <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) {
+    if (lds_alloc(fit + sh_s) <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) {
       dyn_bytes = fit;
       small_wg = !ctx->tune.plan_big_wg;
       if (small_wg && ctx->tune.plan_small_state) { qcap = q_s; lowcap = low_s; sh_bytes = sh_s; }
@@ -1221,7 +1229,7 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
        * 256-thread workgroups, or as many 128-thread ones as the LDS takes (six or more from here on): more blocks in flight
        * for the same waves. */
       const uint32_t sh_t = pl_shared_bytes(q_s, low_s, PL_NT_TINY);
-      if (small_wg && ctx->tune.plan_small_state && !ctx->tune.plan_no_wg128 && fit + sh_t <= NRQ_LDS_MAX / 6u) { tiny_wg = true; sh_bytes = sh_t; }
+      if (small_wg && ctx->tune.plan_small_state && !ctx->tune.plan_no_wg128 && lds_alloc(fit + sh_t) * 6u <= NRQ_LDS_MAX) { tiny_wg = true; sh_bytes = sh_t; }
     }
   }
   const bool seg = plan_is_segmented(ctx, p, Mcap);
@@ -1475,7 +1483,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     uint32_t need = 0;
     for (const nrq_plan_hdr *h : hdrs)
       if (!h->status) { const uint32_t t = nrq_lds_plan(h, 16u * ctx->tune.wide_g).total; if (t > need) need = t; }
-    if (need * 2u <= NRQ_LDS_MAX) { G = ctx->tune.wide_g; lds_bytes = need; }
+    if (lds_alloc(need) * 2u <= NRQ_LDS_MAX) { G = ctx->tune.wide_g; lds_bytes = need; }
   }
   const uint32_t WBE = WB * G;
   /* narrow strips: the solve kernel stops after the dense stage, nrq_backsub_kernel / nrq_collect_kernel finish on
@@ -1487,12 +1495,12 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   const bool by_block = nrq_map_by_block(nblk) && !ctx->tune.map_spread;
   /* workgroup shape: the full-size workgroup when a strip image needs more than half of the CU's LDS, 256-thread ones
    * when two or more fit */
-  const bool small = lds_bytes * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg;
+  const bool small = lds_alloc(lds_bytes) * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg;
   /* single-wave workgroups when 12 or more images fit a CU (see the kernel; K=256: +26 % over five 256-thread workgroups) */
   const uint32_t tdiv = hdrs.size() > 1u ? ctx->tune.tiny_div_dec : ctx->tune.tiny_div;
-  const bool tiny = G == 1 && small && (uint64_t)lds_bytes * tdiv <= NRQ_LDS_MAX && !ctx->tune.no_tiny;
+  const bool tiny = G == 1 && small && (uint64_t)lds_alloc(lds_bytes) * tdiv <= NRQ_LDS_MAX && !ctx->tune.no_tiny;
   const uint32_t nt = tiny ? 64u : small ? 256u : (uint32_t)NRQ_WG;
-  uint32_t occ = NRQ_LDS_MAX / (lds_bytes ? lds_bytes : 1u);
+  uint32_t occ = NRQ_LDS_MAX / lds_alloc(lds_bytes ? lds_bytes : 1u);
   if (occ > 2048u / nt) occ = 2048u / nt;
   /* registers: the 256-thread variant (one wave per SIMD) is compiled for NRQ_SMALL_WAVES waves per SIMD.  More
    * workgroups than are resident at once would run as a second, thinner round of a statically partitioned job. */
@@ -1501,6 +1509,7 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
                                               * measured: with 20 x 256 workgroups not all are resident and the rest runs as a second
                                               * round (10.4 ms against 8.7 ms with 18 x 256 at K=100, T=1024, 8192 blocks) */
   else if (small && occ > (five ? 5u : (uint32_t)NRQ_SMALL_WV)) occ = five ? 5u : (uint32_t)NRQ_SMALL_WV;
+  if (tiny && ctx->tune.diag) fprintf(stderr, "[NRQ_DIAG] single-wave workgroups: %u bytes of LDS each, %u per CU\n", lds_bytes, occ);
   if (occ < 1u) occ = 1u;
   /* persistent workgroups fill the device; a multiple of 8 keeps a workgroup's slots on its XCD */
   uint64_t grid = (uint64_t)(ctx->ncu / 8) * 8 * occ;
