@@ -167,8 +167,12 @@ extern "C" int nrq_host_kconst_build(uint32_t K, uint8_t **out, uint32_t *out_by
 extern "C" void nrq_host_free(void *p) { free(p); }
 
 /* ------------------------------------------------------------------------------------------ */
-extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *isis, const uint8_t *kconst,
-                                   uint8_t **out, uint32_t *out_bytes) {
+/* comp_rows: 0 = an inactivation event takes the first open rows with two columns in V it finds, one after the other (what the
+ * device planner does); n > 0 = RFC 6330 section 5.4.2.2's choice -- a row from the LARGEST component of the graph whose edges
+ * are those rows -- and, in the same event, one row from each of the next n - 1 components (rows of one component must not
+ * share an event: the first inactivation lets the whole component peel, a second one in it is a column wasted). */
+static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis, const uint8_t *kconst, uint8_t **out, uint32_t *out_bytes,
+                                uint32_t comp_rows) {
   rq_params p;
   if (!rq_params_init(K, &p)) return -1;
   if (nrows < p.Kp) return -1;
@@ -286,7 +290,9 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
      * inactivate all but one column of each */
     next.clear();
     bool none_left = false;
-    for (uint32_t rep = 0; rep < NRQ_MULTI_INACT; rep++) {
+    std::vector<uint32_t> ev_rows;
+    const uint32_t reps_ = comp_rows ? comp_rows : NRQ_MULTI_INACT;
+    for (uint32_t rep = 0; rep < reps_; rep++) {
       uint32_t best = M, bestc = 0xFFFFFFFFu;
       for (uint32_t r = 0; r < M; r++)
         if (!assigned[r] && cnt[r] >= 2 && cnt[r] < bestc) {
@@ -294,6 +300,32 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
           if (bestc == 2) break;
         }
       if (best == M) { none_left = (rep == 0); break; }
+      if (comp_rows && bestc == 2) {
+        if (rep == 0) { /* the components of the two-column rows as the event finds them: union-find over the columns */
+          ev_rows.clear();
+          std::vector<uint32_t> par(W), sz(W, 1), e1, er;
+          for (uint32_t c = 0; c < W; c++) par[c] = c;
+          auto find = [&](uint32_t x) { while (par[x] != x) { par[x] = par[par[x]]; x = par[x]; } return x; };
+          for (uint32_t r = 0; r < M; r++) {
+            if (assigned[r] || cnt[r] != 2) continue;
+            uint32_t a = 0xFFFFFFFFu, b = 0xFFFFFFFFu;
+            for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++)
+              if (cstate[cidx[e]] == IN_V) { if (a == 0xFFFFFFFFu) a = cidx[e]; else b = cidx[e]; }
+            if (b == 0xFFFFFFFFu) continue;
+            e1.push_back(a); er.push_back(r);
+            uint32_t ra = find(a), rb = find(b);
+            if (ra != rb) { if (sz[ra] < sz[rb]) std::swap(ra, rb); par[rb] = ra; sz[ra] += sz[rb]; }
+          }
+          std::vector<std::pair<uint32_t, uint32_t>> comps; /* (columns, a row) per component */
+          std::vector<uint8_t> seen(W, 0);
+          for (size_t i = 0; i < er.size(); i++) { const uint32_t rt = find(e1[i]); if (!seen[rt]) { seen[rt] = 1; comps.push_back({sz[rt], er[i]}); } }
+          std::stable_sort(comps.begin(), comps.end(), [](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) { return x.first > y.first; });
+          for (auto &c_ : comps) ev_rows.push_back(c_.second);
+        }
+        if (rep >= ev_rows.size()) break;
+        best = ev_rows[rep];
+        if (assigned[best] || cnt[best] != 2) continue;
+      }
       uint32_t keep = 0xFFFFFFFFu, keepdeg = 0xFFFFFFFFu;
       for (uint32_t e = rptr[best]; e < rptr[best + 1]; e++) {
         uint32_t c = cidx[e];
@@ -643,4 +675,23 @@ extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *i
   *out = res;
   *out_bytes = hd.total_bytes;
   return 0;
+}
+
+/* The plan of an ENCODER (no symbol missing: rows are ISI 0 .. K'-1) is walked by every strip of every block of its object, and
+ * it is built on the host beside the GPU's work: it can afford RFC 6330's component rule.  One row an event ends at the fewest
+ * inactive columns (K'=8192: 184 against 209 first-found, 197 with six rows an event) but at more levels and stream rows, six
+ * rows an event at the shortest stream; measured on the encode solve per 256 blocks (first-found / 6 / 3 / 1 rows an event):
+ * K=500 10.99 / 9.77 / 10.15 / 10.30 ms, K=1000 8.53 / 8.52 / 8.36 / 8.50, K=2000 7.18 / 7.16 / 7.15 / 6.98, K=5000 4.55 / 4.25 /
+ * 4.37 / 4.37, K=8192 6.48 / 6.42 / 6.42 / 6.25, K=10000 12.31 / 12.09 / 11.80 / 11.61 -- so: one row from K' = 1500 on, six
+ * below.  (Building all four and keeping the cheapest by a fitted cost was tried: four builds a step no longer hide behind the
+ * GPU.)  The build takes ~1.5 x the first-found one.  A decoder's plan is used once: it keeps the first-found rule, which is
+ * also what the device planner implements.  NRQ_HOST_WAY=n forces n rows an event (0: first-found) for measurements. */
+extern "C" int nrq_host_plan_build(uint32_t K, uint32_t nrows, const uint32_t *isis, const uint8_t *kconst, uint8_t **out, uint32_t *out_bytes) {
+  rq_params p;
+  if (!rq_params_init(K, &p)) return -1;
+  bool encoder = nrows == p.Kp;
+  for (uint32_t k = 0; encoder && k < nrows; k++) encoder = isis[k] == k;
+  uint32_t way = !encoder ? 0u : p.Kp >= 1500u ? 1u : 6u;
+  if (const char *e = getenv("NRQ_HOST_WAY")) { if (encoder) way = (uint32_t)atoi(e); }
+  return host_plan_build_with(K, nrows, isis, kconst, out, out_bytes, way);
 }

@@ -464,8 +464,9 @@ def test_five_workgroups_per_cu_variant(G, orc):
     = 0 selects it where five strip images fit): same bytes as the oracle."""
     c = G.ctx()
     c.set_option("small_waves4", 0)
+    c.set_option("no_tiny", 1)   # (from seven strip images per CU on the single-wave workgroups would take over)
     try:
-        for K, T, nblk, p in [(1000, 1280, 6, 0.06), (800, 333, 5, 0.1)]:   # (from seven strip images per CU on -- K=700 -- the single-wave workgroups take over)
+        for K, T, nblk, p in [(1000, 1280, 6, 0.06), (700, 333, 5, 0.1)]:
             src = np.stack([payload(K * T, seed=K + 3, block=b).reshape(K, T) for b in range(nblk)])
             esis = np.array([K, K + 1, K + 9, K + 500], np.uint32)
             rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
@@ -478,6 +479,7 @@ def test_five_workgroups_per_cu_variant(G, orc):
                 assert not st[b] or np.array_equal(out[b], src2[b]), (K, T, b)
     finally:
         c.set_option("small_waves4", 1)
+        c.set_option("no_tiny", 0)
 
 
 def test_segmented_planner_at_small_sizes(G, orc):
