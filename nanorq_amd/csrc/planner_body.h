@@ -1086,6 +1086,72 @@ SB_HD bool pl_chained(uint32_t Z) {
   return false;
 #endif
 }
+#define PL_EVENT_ROWS NRQ_MULTI_INACT
+/* (small blocks: fewer rows an event -- with six at once a block of a few hundred symbols ends up with more inactive columns than
+ * row after row, K=256: the decode launch lost a workgroup per CU to the larger dense stage) */
+SB_HD uint32_t pl_event_rows(const PlanCtx &c) { const uint32_t n = c.p.W / 128u; return n < 2u ? 2u : n < PL_EVENT_ROWS ? n : PL_EVENT_ROWS; }
+/* all but one V column of row r leave V for the inactive set: the one with the fewest entries stays (heuristic) */
+template <bool LDS> SB_HD void pl_event_row(PlanCtx &c, const PlPeel &s, uint32_t r, uint32_t pq) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint16_t *cols;
+  const uint32_t n = pl_row(c, r, &cols);
+  uint32_t keep = PL_NONE, keepdeg = PL_NONE;
+  constexpr uint32_t CB = 8; /* (eight entries at a time with all their loads in flight together -- entry, column state, four list bounds) */
+  for (uint32_t k0 = 0; k0 < n; k0 += CB) {
+    uint32_t col[CB], inf[CB], dg[CB];
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) {
+      inf[q] = s.colinfo[col[q]];
+      dg[q] = (c.b_cptr[col[q] + 1] - c.b_cptr[col[q]]) + (c.pc_ptr[col[q] + 1] - c.pc_ptr[col[q]]);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++)
+      if (k0 + q < n && inf[q] == 0u && dg[q] < keepdeg) { keepdeg = dg[q]; keep = col[q]; }
+  }
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t col = cols[k];
+    if (col == keep || s.colinfo[col] != 0u) continue;
+    if (PL_ATOM_CAS(&s.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue; /* (another row of the event took it) */
+    const uint32_t x = c.p.P + PL_ATOM_ADD(&sh->ninact, 1u), m = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
+    if (x >= c.ucap || m >= c.qcap) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); continue; }
+    s.colinfo[col] = (PL_ST_INACT << 30) | x;
+    c.ucol[x] = (uint16_t)col;
+    c.claim_c()[m] = (uint16_t)col; /* "columns to drop" */
+    (void)PL_ATOM_SUB(&sh->nV, 1u);
+  }
+}
+/* the same on the compact state: "in V" is a bit in LDS (its atomic OR is the claim), the column's state word in HBM is stored */
+SB_HD void pl_event_row_k(PlanCtx &c, const PlPk &k, uint32_t r, uint32_t pq) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  const uint16_t *cols;
+  const uint32_t n = pl_row(c, r, &cols);
+  uint32_t keep = PL_NONE, keepdeg = PL_NONE;
+  constexpr uint32_t CB = 8;
+  for (uint32_t k0 = 0; k0 < n; k0 += CB) {
+    uint32_t col[CB], dg[CB];
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++)
+      dg[q] = (c.b_cptr[col[q] + 1] - c.b_cptr[col[q]]) + (c.pc_ptr[col[q] + 1] - c.pc_ptr[col[q]]);
+#pragma unroll
+    for (uint32_t q = 0; q < CB; q++)
+      if (k0 + q < n && !pk_bit(k.vb, col[q]) && dg[q] < keepdeg) { keepdeg = dg[q]; keep = col[q]; }
+  }
+  for (uint32_t e = 0; e < n; e++) {
+    const uint32_t col = cols[e], bit = 1u << (col & 31u);
+    if (col == keep || pk_bit(k.vb, col)) continue;
+    if (PL_ATOM_OR(&k.vb[col >> 5], bit) & bit) continue; /* (another row of the event took it; also: a column listed twice) */
+    const uint32_t x = c.p.P + PL_ATOM_ADD(&sh->ninact, 1u), m = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
+    if (x >= c.ucap || m >= c.qcap) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); continue; }
+    c.colinfo[col] = (PL_ST_INACT << 30) | x;
+    c.ucol[x] = (uint16_t)col;
+    c.claim_c()[m] = (uint16_t)col; /* "columns to drop" */
+    (void)PL_ATOM_SUB(&sh->nV, 1u);
+  }
+}
 /* No claimant in the frontier: find an open row with the fewest V columns.  Almost always that is a row with two; those
  * are kept on a stack as they come up (pl_drop_column pushes a row when its count drops to two; rows that start with
  * two are pushed by pl_pcsc_fill), and the search looks at the top nt entries only -- the rows that reached two most
@@ -1099,9 +1165,15 @@ template <bool LDS> SB_HD void pl_inact_find_t(PlanCtx &c, uint32_t rdrep, uint3
   const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24; /* rep-th row of this inactivation event */
   const uint32_t n = sh->ncand[0], lo = n > nt ? n - nt : 0u, i = lo + tid;
   uint32_t best = PL_NONE, hi = 0;
+  bool valid = false;
+  uint32_t vr = 0;
   if (i < n) {
     const uint32_t r = c.cand[i];
-    if ((s.rowinfo[r] & PL_UNASSIGNED) && (s.rowstate[r] >> 24) == 2u) { best = (2u << 16) | r; hi = i + 1u; }
+    if ((s.rowinfo[r] & PL_UNASSIGNED) && (s.rowstate[r] >> 24) == 2u) { best = (2u << 16) | r; hi = i + 1u; valid = true; vr = r; }
+  }
+  { /* (the event's rows: the first few valid entries, pl_event_rows() of them are used -- pl_inact_apply_a) */
+    const uint32_t at = PL_WAVE_TAKE(&sh->ev_n, valid);
+    if (valid && at < PL_EVENT_ROWS) c.queue(rd & 1u)[at] = (uint16_t)vr;
   }
   best = PL_WAVE_MIN(best);
   hi = PL_WAVE_MAX(hi);
@@ -1114,9 +1186,15 @@ SB_HD void pl_inact_find_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt
   const uint32_t rd = rdrep & 0xFFFFFFu, rep = rdrep >> 24;
   const uint32_t n = sh->ncand[0], lo = n > nt ? n - nt : 0u, i = lo + tid;
   uint32_t best = PL_NONE, hi = 0;
+  bool valid = false;
+  uint32_t vr = 0;
   if (i < n) {
     const uint32_t r = c.cand[i];
-    if (pk_bit(k.un, r) && pk_count(k, r) == 2u) { best = (2u << 16) | r; hi = i + 1u; }
+    if (pk_bit(k.un, r) && pk_count(k, r) == 2u) { best = (2u << 16) | r; hi = i + 1u; valid = true; vr = r; }
+  }
+  { /* (the event's rows: pl_inact_find_t) */
+    const uint32_t at = PL_WAVE_TAKE(&sh->ev_n, valid);
+    if (valid && at < PL_EVENT_ROWS) c.queue(rd & 1u)[at] = (uint16_t)vr;
   }
   best = PL_WAVE_MIN(best);
   hi = PL_WAVE_MAX(hi);
@@ -1191,48 +1269,12 @@ template <bool LDS> SB_HD void pl_inact_apply_a_t(PlanCtx &c, uint32_t rdrep, ui
     }
     return;
   }
-  if (tid != 0) return;
-  /* list the row's V columns; keep the one with the fewest entries (heuristic), inactivate the others */
-  const uint32_t r = sh->best & 0xFFFFu;
-  const uint16_t *cols;
-  const uint32_t n = pl_row(c, r, &cols);
-  uint32_t keep = PL_NONE, keepdeg = PL_NONE, m = 0;
-  /* (one thread walks the row; eight entries at a time with all their loads in flight together -- entry, column
-   * state, four list bounds: a trip each if taken one by one) */
-  constexpr uint32_t CB = 8;
-  for (uint32_t k0 = 0; k0 < n; k0 += CB) {
-    uint32_t col[CB], inf[CB], dg[CB];
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) {
-      inf[q] = s.colinfo[col[q]];
-      dg[q] = (c.b_cptr[col[q] + 1] - c.b_cptr[col[q]]) + (c.pc_ptr[col[q] + 1] - c.pc_ptr[col[q]]);
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++)
-      if (k0 + q < n && inf[q] == 0u && dg[q] < keepdeg) { keepdeg = dg[q]; keep = col[q]; }
-  }
-  bool full = false;
-  for (uint32_t k0 = 0; k0 < n && !full; k0 += CB) {
-    uint32_t col[CB], inf[CB];
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) inf[q] = s.colinfo[col[q]];
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) {
-      if (k0 + q >= n || inf[q] != 0u || col[q] == keep || full) continue;
-      const uint32_t x = p.P + sh->ninact;
-      if (x >= c.ucap || m >= c.qcap) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); full = true; continue; }
-      sh->ninact++;
-      s.colinfo[col[q]] = (PL_ST_INACT << 30) | x;
-      c.ucol[x] = (uint16_t)col[q];
-      c.claim_c()[m++] = (uint16_t)col[q];
-    }
-  }
-  sh->nclaim[rd & 1u] = m; /* "columns to drop" */
-  sh->nV -= m;
+  /* the event's rows (pl_inact_find listed them; none listed: the sparsest open row), a thread each: all but one V column of a
+   * row go inactive -- pl_event_row; the columns end up in the claim list for pl_inact_apply_b */
+  const uint32_t n2 = sh->ev_n < pl_event_rows(c) ? sh->ev_n : pl_event_rows(c);
+  if (n2) { if (tid < n2) pl_event_row<LDS>(c, s, c.queue(rd & 1u)[tid], rd & 1u); }
+  else if (tid == 0) pl_event_row<LDS>(c, s, sh->best & 0xFFFFu, rd & 1u);
+  (void)p;
 }
 SB_HD void pl_inact_apply_a_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
@@ -1250,43 +1292,10 @@ SB_HD void pl_inact_apply_a_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t
     }
     return;
   }
-  if (tid != 0) return;
-  /* list the row's V columns; keep the one with the fewest entries (heuristic), inactivate the others */
-  const uint32_t r = sh->best & 0xFFFFu;
-  const uint16_t *cols;
-  const uint32_t n = pl_row(c, r, &cols);
-  uint32_t keep = PL_NONE, keepdeg = PL_NONE, m = 0;
-  constexpr uint32_t CB = 8;
-  for (uint32_t k0 = 0; k0 < n; k0 += CB) {
-    uint32_t col[CB], dg[CB];
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++)
-      dg[q] = (c.b_cptr[col[q] + 1] - c.b_cptr[col[q]]) + (c.pc_ptr[col[q] + 1] - c.pc_ptr[col[q]]);
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++)
-      if (k0 + q < n && !pk_bit(k.vb, col[q]) && dg[q] < keepdeg) { keepdeg = dg[q]; keep = col[q]; }
-  }
-  bool full = false;
-  for (uint32_t k0 = 0; k0 < n && !full; k0 += CB) {
-    uint32_t col[CB];
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) {
-      if (k0 + q >= n || pk_bit(k.vb, col[q]) || col[q] == keep || full) continue;
-      const uint32_t x = p.P + sh->ninact;
-      if (x >= c.ucap || m >= c.qcap) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); full = true; continue; }
-      sh->ninact++;
-      k.vb[col[q] >> 5] |= 1u << (col[q] & 31u); /* (one thread; also keeps a column listed twice from being taken twice) */
-      c.colinfo[col[q]] = (PL_ST_INACT << 30) | x;
-      c.ucol[x] = (uint16_t)col[q];
-      c.claim_c()[m++] = (uint16_t)col[q];
-    }
-  }
-  sh->nclaim[rd & 1u] = m; /* "columns to drop" */
-  sh->nV -= m;
+  const uint32_t n2 = sh->ev_n < pl_event_rows(c) ? sh->ev_n : pl_event_rows(c); /* (pl_inact_apply_a_t) */
+  if (n2) { if (tid < n2) pl_event_row_k(c, k, c.queue(rd & 1u)[tid], rd & 1u); }
+  else if (tid == 0) pl_event_row_k(c, k, sh->best & 0xFFFFu, rd & 1u);
+  (void)p;
 }
 template <int Z> SB_HD void pl_inact_apply_a(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   PL_PEEL_DISPATCH3(pl_inact_apply_a_, c, rdrep, tid, nt);
@@ -1301,6 +1310,7 @@ template <bool LDS> SB_HD void pl_inact_apply_b_t(PlanCtx &c, uint32_t rdrep, ui
     if (tid == 0) sh->tmp1 = 1u; /* event over */
     return;
   }
+  if (sh->status) return; /* (a capacity gave out while the columns were listed: the list has holes) */
   const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
   for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) {
     pl_drop_column<LDS>(c, s, c.claim_c()[i], 0u, pq ^ 1u, lane, 32u);
@@ -1308,7 +1318,7 @@ template <bool LDS> SB_HD void pl_inact_apply_b_t(PlanCtx &c, uint32_t rdrep, ui
     if (lane == 0u) c.claim_c()[i] = 0xFFFFu; /* (a list entry that is not "no entry" is one pl_round_chain may take) */
 #endif
   }
-  if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; }
+  if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; sh->ev_n = 0; }
 }
 SB_HD void pl_inact_apply_b_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
@@ -1320,9 +1330,10 @@ SB_HD void pl_inact_apply_b_k(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t
     if (tid == 0) sh->tmp1 = 1u; /* event over */
     return;
   }
+  if (sh->status) return;
   const uint32_t grp = tid >> 5, lane = tid & 31u, ngrp = nt >> 5;
   for (uint32_t i = grp; i < sh->nclaim[pq]; i += ngrp) pl_drop_column_k(c, k, c.claim_c()[i], 0u, pq ^ 1u, lane, 32u);
-  if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; }
+  if (tid == 0) { sh->nclaim[pq ^ 1u] = 0; sh->tmp1 = 0u; sh->ev_n = 0; }
 }
 template <int Z> SB_HD void pl_inact_apply_b(PlanCtx &c, uint32_t rdrep, uint32_t tid, uint32_t nt) {
   PL_PEEL_DISPATCH3(pl_inact_apply_b_, c, rdrep, tid, nt);
@@ -1339,10 +1350,6 @@ template <int Z> SB_HD void pl_inact_next(PlanCtx &c, uint32_t rdrep, uint32_t t
  * thread per listed row walks its row and inactivates all but one of its V columns (a compare-and-swap on the column: two rows
  * may hold the same one), and one drop phase takes all those columns out of V.  Rows of one event almost never share a column
  * (two of ~5000); when they do, a column more than necessary may go inactive, which costs nothing but that column. */
-#define PL_EVENT_ROWS NRQ_MULTI_INACT
-/* (small blocks: fewer rows an event -- with six at once a block of a few hundred symbols ends up with more inactive columns than
- * row after row, K=256: the decode launch lost a workgroup per CU to the larger dense stage) */
-SB_HD uint32_t pl_event_rows(const PlanCtx &c) { const uint32_t n = c.p.W / 128u; return n < 2u ? 2u : n < PL_EVENT_ROWS ? n : PL_EVENT_ROWS; }
 template <int Z> SB_HD void pl_event_scan(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (!PL_PEEL_LDS(Z)) return;
@@ -1361,38 +1368,6 @@ template <int Z> SB_HD void pl_event_scan(PlanCtx &c, uint32_t rd, uint32_t tid,
   best = PL_WAVE_MIN(best);
   if (best != PL_NONE && PL_WAVE_LEADER(tid)) PL_ATOM_MIN(&sh->ev_min, best);
   if (tid == 0) { sh->nq[pq ^ 1u] = 0; sh->nclaim[pq] = 0; }
-}
-/* all but one V column of row r leave V for the inactive set: the one with the fewest entries stays (heuristic) */
-template <bool LDS> SB_HD void pl_event_row(PlanCtx &c, const PlPeel &s, uint32_t r, uint32_t pq) {
-  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
-  const uint16_t *cols;
-  const uint32_t n = pl_row(c, r, &cols);
-  uint32_t keep = PL_NONE, keepdeg = PL_NONE;
-  constexpr uint32_t CB = 8; /* (eight entries at a time with all their loads in flight together -- entry, column state, four list bounds) */
-  for (uint32_t k0 = 0; k0 < n; k0 += CB) {
-    uint32_t col[CB], inf[CB], dg[CB];
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) col[q] = k0 + q < n ? cols[k0 + q] : 0u;
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++) {
-      inf[q] = s.colinfo[col[q]];
-      dg[q] = (c.b_cptr[col[q] + 1] - c.b_cptr[col[q]]) + (c.pc_ptr[col[q] + 1] - c.pc_ptr[col[q]]);
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < CB; q++)
-      if (k0 + q < n && inf[q] == 0u && dg[q] < keepdeg) { keepdeg = dg[q]; keep = col[q]; }
-  }
-  for (uint32_t k = 0; k < n; k++) {
-    const uint32_t col = cols[k];
-    if (col == keep || s.colinfo[col] != 0u) continue;
-    if (PL_ATOM_CAS(&s.colinfo[col], 0u, (PL_ST_CLAIM << 30) | r) != 0u) continue; /* (another row of the event took it) */
-    const uint32_t x = c.p.P + PL_ATOM_ADD(&sh->ninact, 1u), m = PL_ATOM_ADD(&sh->nclaim[pq], 1u);
-    if (x >= c.ucap || m >= c.qcap) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); continue; }
-    s.colinfo[col] = (PL_ST_INACT << 30) | x;
-    c.ucol[x] = (uint16_t)col;
-    c.claim_c()[m] = (uint16_t)col; /* "columns to drop" */
-    (void)PL_ATOM_SUB(&sh->nV, 1u);
-  }
 }
 template <int Z> SB_HD void pl_event_pick(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);

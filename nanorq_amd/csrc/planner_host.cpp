@@ -248,11 +248,16 @@ static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis
   for (uint32_t r = 0; r < M; r++)
     if (cnt[r] == 1) frontier.push_back(r);
 
+  std::vector<uint32_t> edge_a, edge_b; /* component rule: the two V columns of a row that has two left */
+  std::vector<uint32_t> par, sz, two_rows, touched, comp_of; /* ... union-find over the columns, the rows with two columns, what an event touched */
+  std::vector<uint8_t> seen;
+  bool track_two = false;
   auto drop_column = [&](uint32_t c) { /* c leaves V */
     for (uint32_t e = cptr[c]; e < cptr[c + 1]; e++) {
       uint32_t r = ridx[e];
       cnt[r]--; xs[r] ^= c;
       if (cnt[r] == 1 && !assigned[r]) next.push_back(r);
+      else if (cnt[r] == 2 && track_two && !assigned[r]) two_rows.push_back(r);
     }
   };
 
@@ -303,24 +308,43 @@ static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis
       if (comp_rows && bestc == 2) {
         if (rep == 0) { /* the components of the two-column rows as the event finds them: union-find over the columns */
           ev_rows.clear();
-          std::vector<uint32_t> par(W), sz(W, 1), e1, er;
-          for (uint32_t c = 0; c < W; c++) par[c] = c;
+          if (par.empty()) { /* first event: the rows that have two columns now; the others join as they get there (drop_column) */
+            par.resize(W); sz.assign(W, 1); seen.assign(W, 0); comp_of.assign(W, 0); edge_a.assign(M, 0xFFFFFFFFu); edge_b.assign(M, 0xFFFFFFFFu);
+            for (uint32_t c = 0; c < W; c++) par[c] = c;
+            for (uint32_t r = 0; r < M; r++) if (cnt[r] == 2) two_rows.push_back(r);
+            track_two = true;
+          }
           auto find = [&](uint32_t x) { while (par[x] != x) { par[x] = par[par[x]]; x = par[x]; } return x; };
-          for (uint32_t r = 0; r < M; r++) {
-            if (assigned[r] || cnt[r] != 2) continue;
-            uint32_t a = 0xFFFFFFFFu, b = 0xFFFFFFFFu;
-            for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++)
-              if (cstate[cidx[e]] == IN_V) { if (a == 0xFFFFFFFFu) a = cidx[e]; else b = cidx[e]; }
+          size_t keepn = 0;
+          touched.clear();
+          for (size_t i = 0; i < two_rows.size(); i++) {
+            const uint32_t r = two_rows[i];
+            if (assigned[r] || cnt[r] != 2) continue; /* (left the list for good: a row only loses columns) */
+            two_rows[keepn++] = r;
+            /* (a row keeps its last two V columns for as long as it has two: found once, by a walk of the row) */
+            if (edge_a[r] == 0xFFFFFFFFu) {
+              for (uint32_t e = rptr[r]; e < rptr[r + 1]; e++)
+                if (cstate[cidx[e]] == IN_V) { if (edge_a[r] == 0xFFFFFFFFu) edge_a[r] = cidx[e]; else edge_b[r] = cidx[e]; }
+            }
+            const uint32_t a = edge_a[r], b = edge_b[r];
             if (b == 0xFFFFFFFFu) continue;
-            e1.push_back(a); er.push_back(r);
+            touched.push_back(a); touched.push_back(b);
             uint32_t ra = find(a), rb = find(b);
             if (ra != rb) { if (sz[ra] < sz[rb]) std::swap(ra, rb); par[rb] = ra; sz[ra] += sz[rb]; }
           }
+          two_rows.resize(keepn);
           std::vector<std::pair<uint32_t, uint32_t>> comps; /* (columns, a row) per component */
-          std::vector<uint8_t> seen(W, 0);
-          for (size_t i = 0; i < er.size(); i++) { const uint32_t rt = find(e1[i]); if (!seen[rt]) { seen[rt] = 1; comps.push_back({sz[rt], er[i]}); } }
-          std::stable_sort(comps.begin(), comps.end(), [](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) { return x.first > y.first; });
-          for (auto &c_ : comps) ev_rows.push_back(c_.second);
+          for (uint32_t r : two_rows) { /* (a component's row: the one with the lowest number, whatever order the list is in) */
+            if (edge_b[r] == 0xFFFFFFFFu) continue;
+            const uint32_t rt = find(edge_a[r]);
+            if (!seen[rt]) { seen[rt] = 1; comp_of[rt] = (uint32_t)comps.size(); comps.push_back({sz[rt], r}); }
+            else if (r < comps[comp_of[rt]].second) comps[comp_of[rt]].second = r;
+          }
+          const size_t top = std::min<size_t>(reps_, comps.size());
+          std::partial_sort(comps.begin(), comps.begin() + top, comps.end(),
+                            [](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+          for (size_t i = 0; i < top; i++) ev_rows.push_back(comps[i].second);
+          for (uint32_t c : touched) { par[c] = c; sz[c] = 1; seen[c] = 0; } /* (for the next event) */
         }
         if (rep >= ev_rows.size()) break;
         best = ev_rows[rep];

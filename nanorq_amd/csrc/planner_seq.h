@@ -57,8 +57,9 @@
         PL_PHASE1(pl_event_pick, rd_);
         PL_PHASE1(pl_event_drop, rd_);
       } else {
-        /* one inactivation event: up to NRQ_MULTI_INACT open rows, sparsest first */
-        for (uint32_t rep_ = 0; rep_ < NRQ_MULTI_INACT; rep_++) {
+        /* one inactivation event: up to NRQ_MULTI_INACT open rows with two V columns from the top of the stack, all at once
+         * (pl_inact_find lists them, pl_inact_apply_a gives a thread to each); the sparsest open row if there is none */
+        for (uint32_t rep_ = 0; rep_ < 1u; rep_++) {
           const uint32_t a_ = rd_ | (rep_ << 24);
           if (rep_) PL_PHASE1(pl_inact_next, a_);
           /* peeling state in LDS: all open rows are scanned (cheap there, and ties go to the lowest row); in HBM: the

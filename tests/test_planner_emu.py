@@ -41,6 +41,27 @@ def test_encode_emulated_matches_oracle(orc, K, T, wb):
     _encode_case(orc, K, T, wb)
 
 
+@pytest.mark.parametrize("K", [300, 2000])
+def test_encoder_plan_by_components(orc, K, monkeypatch):
+    """The encoder's plan takes the rows of an inactivation event from the largest components of the two-column rows' graph (RFC
+    6330 section 5.4.2.2; planner_host.cpp nrq_host_plan_build: one row an event from K'=1500 on, six below).  Whatever the
+    rule -- NRQ_HOST_WAY forces first-found (0) or n rows an event -- the encode is the oracle's, byte for byte (the reference
+    takes any row with two columns left, precode.c:115-126: the choice is the plan's business, not the result's); and the
+    rule must not end at more inactive columns than first-found does."""
+    p = orc.params(K)
+    kc = nanorq_amd.host_kconst(K)
+    u = {}
+    for way in ("0", "6", "1", None):
+        if way is None:
+            monkeypatch.delenv("NRQ_HOST_WAY", raising=False)
+        else:
+            monkeypatch.setenv("NRQ_HOST_WAY", way)
+        u[way] = nanorq_amd.plan_header(nanorq_amd.host_plan(K, np.arange(p["Kp"], dtype=np.uint32), kc))["u"]
+        _encode_case(orc, K, 16, 16, nrep=3)
+    assert u[None] == u["1" if p["Kp"] >= 1500 else "6"]
+    assert u[None] <= u["0"], u
+
+
 @pytest.mark.parametrize("K,T,wb,p,oh", [(10, 16, 16, 0.3, 0), (100, 32, 16, 0.06, 0), (100, 32, 8, 0.06, 2),
                                          (100, 8, 2, 0.5, 30), (1024, 16, 16, 0.05, 0), (1024, 16, 4, 0.06, 52),
                                          (8192, 16, 16, 0.1, 0), (8192, 16, 16, 0.1, 2)])
