@@ -652,10 +652,26 @@ template <int Z> SB_HD void pl_scan_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   c.part()[tid] = s;
 }
 template <int Z> SB_HD void pl_scan_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  /* one wave: a lane sums nt / 64 partial sums, the lanes' sums are scanned across the wave, the lane writes its run back.  (One
+   * thread walking all nt words was a chain of nt LDS round trips: ~130 k clocks at 1024 threads, 3 % of the planner at K=8192.) */
+  if (tid >= 64u) return;
+  uint32_t *part = c.part();
+  const uint32_t per = (nt + 63u) / 64u, a = tid * per, b = a + per < nt ? a + per : nt;
+  uint32_t sum = 0;
+  for (uint32_t t = a; t < b; t++) sum += part[t];
+  uint32_t incl = sum;
+#pragma unroll
+  for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (tid >= d) incl += o; }
+  uint32_t run = incl - sum;
+  for (uint32_t t = a; t < b; t++) { const uint32_t v = part[t]; part[t] = run; run += v; }
+  if (tid == 63u) c.pc_ptr[c.p.L] = incl;
+#else
   if (tid != 0) return;
   uint32_t run = 0;
   for (uint32_t t = 0; t < nt; t++) { uint32_t v = c.part()[t]; c.part()[t] = run; run += v; }
   c.pc_ptr[c.p.L] = run;
+#endif
 }
 template <int Z> SB_HD void pl_scan_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
   const uint32_t L = c.p.L, per = (L + nt - 1) / nt;
@@ -1075,6 +1091,7 @@ template <int Z> SB_HD void pl_round_chain_end(PlanCtx &c, uint32_t rd, uint32_t
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (tid != 0) return;
   const uint32_t pq = rd & 1u, nc = sh->nclaim[pq];
+  if (sh->ndone != nc && !sh->status) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* (the phase gave up on an entry that never came: cannot happen; the host planner takes the block) */
   sh->nclaim[pq ^ 1u] = 0; sh->npiv += nc; sh->nV -= nc; sh->ndone = 0;
   (void)nt;
 }
