@@ -34,7 +34,9 @@
 #define PL_NT 1024u     /* threads of a planner workgroup: big blocks */
 #endif
 #define PL_NT_MIN 256u  /* small blocks (several workgroups per CU) */
+#ifndef PL_NT_TINY
 #define PL_NT_TINY 128u /* the smallest blocks (six or more workgroups per CU) */
+#endif
 #define PL_QCAP 2048u          /* frontier / claim queue capacity */
 #define PL_UNASSIGNED 0x80000000u /* rowinfo bit 31: row has no pivot column (yet) */
 #define PL_PATCHED 0x40000000u    /* rowinfo bit 30: this block replaced the base row (its base CSC entries are void) */
