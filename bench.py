@@ -275,7 +275,7 @@ def pmc_collect(args):
 
 def pmc_committed(args):
     """the counters of the committed profile (tools/collect_profiles.sh), if it is of this workload"""
-    for name in ("r4_pmc.json", "r3_pmc.json", "r2_pmc.json", "r1_pmc_hbm.json"):
+    for name in ("r5_pmc.json", "r4_pmc.json", "r3_pmc.json", "r2_pmc.json", "r1_pmc_hbm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
