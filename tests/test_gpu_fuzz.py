@@ -51,3 +51,39 @@ def test_random_shapes(G, orc, seed):
         syms = np.concatenate([src[b0][rx[rx < K]], rep[b0][:use[b0]]]) if use[b0] else src[b0][rx[rx < K]]
         ok, _, _ = orc.decode_block(rx, syms, K, T)
         assert bool(st[b0]) == ok, (K, T, nblk, p, oh, b0, "verdict")
+
+
+@pytest.mark.parametrize("K,T,nblk,p,iters", [(700, 32, 2048, 0.1, 6), (2000, 32, 1024, 0.2, 4), (8192, 16, 256, 0.1, 3), (9400, 16, 64, 0.1, 2)])
+def test_many_reception_patterns_through_the_device_planner(K, T, nblk, p, iters):
+    """Thousands of different reception patterns per launch through the device planner -- the chained peel, the batched
+    inactivation events and the forms of the peeling state by block size (planner_body.h) race by design (who claims a column
+    first, in which order the list fills), so their check is volume: every block of every launch must decode to its source.  (One
+    in ~20 000 plans of K=700 / 2000 was wrong while a list entry could be seen before its row was marked assigned; the full
+    sweep over all sizes is tools/stress_sweep.sh.)  The reference has no counterpart: its elimination is sequential
+    (precode.c:115-203)."""
+    import torch
+    import nanorq_amd
+    dev = torch.device("cuda", 0)
+    ctx = nanorq_amd.Context(0, torch.cuda.current_stream(dev).cuda_stream)
+    src = torch.randint(0, 256, (nblk, K, T), dtype=torch.uint8, device=dev, generator=torch.Generator(device=dev).manual_seed(K))
+    for it in range(iters):
+        lost = [loss_pattern(K, p, seed=7000 + it, block=b) for b in range(nblk)]
+        ml = max(len(x) for x in lost)
+        nrep = ml + 3
+        esis = np.arange(K, K + nrep, dtype=np.uint32)
+        rep = torch.empty((nblk, nrep, T), dtype=torch.uint8, device=dev)
+        ctx.encode_blocks(K, T, nblk, src.data_ptr(), K * T, rep.data_ptr(), nrep * T, esis, 0, 0)
+        work = src.clone()
+        la = np.zeros((nblk, ml + 1), np.uint32)
+        for b in range(nblk):
+            la[b, :len(lost[b])] = lost[b]
+            work[b, torch.from_numpy(lost[b].astype(np.int64)).to(dev)] = 0xEE
+        nl = np.array([len(x) for x in lost], np.uint32)
+        st, used = ctx.decode_blocks_lazy(K, T, nblk, work.data_ptr(), K * T, la, nl, np.tile(esis, (nblk, 1)), nl, nl + 3, rep.data_ptr(), nrep * T)
+        torch.cuda.synchronize()
+        st = np.asarray(st)
+        assert st.all(), (K, it, int((st == 0).sum()))
+        wrong = (~(work == src).flatten(1).all(1)).cpu().numpy()
+        assert not wrong.any(), (K, it, np.nonzero(wrong)[0][:8])
+        assert ctx.stats().get("host_planned", 0) == 0
+    ctx.close()
