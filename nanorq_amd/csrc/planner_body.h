@@ -47,6 +47,8 @@
 #define PL_ST_CLAIM 3u
 #define PL_NONE 0xFFFFFFFFu
 #define PL_RING_EMPTY 0xFFFFFFFFu
+#define PL_EMIT_TILES_MAX 24u   /* tiles of the op stream's permutation pass through LDS (pl_ops_emit_tiled) ... */
+#define PL_EMIT_TILE_WORDS 12288u /* ... and op words a tile holds at most (48 KB) */
 #define PL_PCHEAD 4u
 #define PL_MAXH 16u
 #define PL_PATCH_STRIDE RQ_MAX_LT_COLS
@@ -232,6 +234,7 @@ typedef struct pl_shared {
   uint32_t tmp_mhoff; /* byte offset of Mb inside the dense LDS region, behind MhT (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
   uint32_t ndone;             /* chained peeling (pl_round_chain): claims of the current list that have been dropped */
+  uint32_t bkt_n[PL_EMIT_TILES_MAX]; /* pl_ops_emit_tiled: ops sorted out to every tile of the stream so far */
   uint32_t ev_n, ev_min, ev_none; /* inactivation event, peeling state in LDS (pl_event_*): open rows with two V columns listed, the
                                    * sparsest of the others, "no open row is left" */
   uint32_t off_augt, aug_stride, mhrev; /* mhrev: the HDPC fold's z rows are in the workspace (pl_mhrev_store) */
@@ -258,7 +261,7 @@ SB_HD bool pl_bin_in_stream(uint32_t L) { return L < NRQ_AUG_MATRIX_MIN_L; } /* 
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
   uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, pc_head, ucol, wrows,
-      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, sh_save, mh_ext, cls_g, wentry, total;
+      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, sh_save, mh_ext, cls_g, wentry, emit_bkt, total;
 } pl_work_layout;
 
 /* nnzcap: entries of the base structure plus the patch rows (bounds the number of row ops) */
@@ -295,6 +298,7 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.mh_ext = o;     o = pl_r16(o + ucap * PL_MAXH);               /* MhT as nrq_mh_kernel leaves it (16 bytes per inactive column) */
   w.cls_g = o;      o = pl_r16(o + (L + 2u) * 32u);               /* the class counters (PL_CLS_BYTES per level group) while nrq_wentry_kernel's workgroups count into them */
   w.wentry = o;     o = pl_r16(o + 16u);                           /* ... and their record counter / failure report */
+  w.emit_bkt = o;   o = pl_r16(o + 3u * nnzcap * 8u);             /* (place inside the tile, op word), a list per tile of the stream: pl_ops_emit_tiled */
   w.total = o;
   return w;
 }
@@ -368,6 +372,7 @@ struct PlanCtx {
   uint32_t *nrec_ptr;  /* the record counter: &sh->nrec, or the workspace's */
   uint32_t *wentry;    /* workspace: [0] records, [1] status, [2] fail site */
   uint16_t *patch_of, *patch_cols, *pc_rows, *pc_head, *ucol;
+  uint32_t *emit_bkt;
   uint8_t *patch_len;
   uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *lev_fin, *red_row,
       *red_x, *rec_word, *rec_idx;
@@ -487,6 +492,7 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.rec_idx = reinterpret_cast<uint32_t *>(w + c.wl.rec_idx);
   c.rec_g = reinterpret_cast<uint16_t *>(w + c.wl.rec_g);
   c.cand = reinterpret_cast<uint16_t *>(w + c.wl.cand);
+  c.emit_bkt = reinterpret_cast<uint32_t *>(w + c.wl.emit_bkt);
   /* arena: header, then the arrays whose size is bounded by (L, ucap) */
   c.arena = PL_HBM(uint8_t, job.arena);
   c.hdr = reinterpret_cast<nrq_plan_hdr *>(c.arena);
@@ -2175,10 +2181,83 @@ SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t lev, uint3
     *pl_op_at(ops, c.lev_base[lev], pl_spread(run++, c.lev_ops[lev])) = NRQ_OP(r, c.pivslot[info & 0x3FFFFFFFu]);
   }
 }
+/* The permutation pass through LDS.  As stores, the ~46 k op words of a block of K=8192 are 4-byte writes scattered over a
+ * quarter megabyte -- every one a partial line the memory has to read, merge and write -- and with all 256 planner workgroups in
+ * this phase together (the chained peel keeps them in step) the pass took 0.72 M clocks against 0.13 M for the same pass
+ * without its stores.  Here every record's place is computed once, as before, but the op goes to the list of the TILE of the
+ * stream its place lies in (a tile: the quads that fit the aux region -- the rowstate image, dead since peeling, the column
+ * levels in it since the entry pass; the lists: appended to at a counter in LDS, so their tails are lines being filled, not
+ * lines being patched; a tile cannot receive more ops than it has places, so a list of that many entries never overflows); then
+ * tile after tile is built in LDS -- padding everywhere, the list's ops at their places -- and written out as whole lines.
+ * Device only (barriers inside the phase); the emulator and blocks whose class counters or tile would not be in LDS keep the
+ * scattered form: same places, same stream. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool pl_ops_emit_tiled(PlanCtx &c, const uint32_t *cls, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (c.cls_glob || !c.aux_lds || c.dense_lds == c.aux_lds || pl_cls_place(c) != c.dense_lds) return false; /* (the aux region is not free) */
+  uint32_t tq = c.aux_bytes / 1024u; /* quads per tile: 4 rows x 64 lanes x 4 bytes each */
+  if (tq > PL_EMIT_TILE_WORDS / 256u) tq = PL_EMIT_TILE_WORDS / 256u;
+  const uint32_t nlev = sh->nlev, rows_emit = c.lev_base[nlev + 1u], nquad = (rows_emit + 3u) / 4u;
+  if (tq < 16u || nquad == 0u || (nquad + tq - 1u) / tq > PL_EMIT_TILES_MAX) return false; /* (small blocks -- a tile of a few rows, a dozen
+                                                                                               * tiles of three barriers each: K=2000 1.90 -> 1.95 ms per 1024 blocks -- keep the scattered form) */
+  const uint32_t ntile = (nquad + tq - 1u) / tq, tile_words = tq * 4u * NRQ_ROW;
+  if ((uint64_t)ntile * tile_words > 3ull * c.reccap) return false; /* (the lists' room in the workspace: pl_work_plan) */
+  uint32_t *tile = reinterpret_cast<uint32_t *>(c.aux_lds); PL_ASSUME_LDS(tile);
+  uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
+  uint2 *bkt = reinterpret_cast<uint2 *>(c.emit_bkt);
+  const uint32_t nrec = sh->nrec;
+  if (tid < PL_EMIT_TILES_MAX) sh->bkt_n[tid] = 0u;
+  __syncthreads();
+  for (uint32_t i0 = tid; i0 < nrec; i0 += PL_WU * nt) { /* PL_WU records in flight per thread */
+    uint32_t m[PL_WU], g[PL_WU], w[PL_WU], base[PL_WU], next[PL_WU];
+#pragma unroll
+    for (uint32_t j = 0; j < PL_WU; j++) {
+      const uint32_t i = i0 + j * nt < nrec ? i0 + j * nt : i0;
+      m[j] = c.rec_idx[i]; g[j] = c.rec_g[i]; w[j] = c.rec_word[i];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < PL_WU; j++) { base[j] = c.lev_base[g[j]]; next[j] = c.lev_base[g[j] + 1u]; }
+#pragma unroll
+    for (uint32_t j = 0; j < PL_WU; j++) {
+      if (i0 + j * nt >= nrec) continue;
+      uint32_t cf[NRQ_LANE_CLASSES], ct[NRQ_LANE_CLASSES], nf;
+      pl_cls_counts(cls, g[j], cf, ct, &nf);
+      const uint32_t d = nrq_op_class(w[j]);
+      const uint32_t rank = (m[j] >> 31) ? cf[d] + (m[j] & 0x7FFFFFFFu) : m[j]; /* early ops rank behind the finishing ones */
+      const uint32_t pos = nrq_lane_place(next[j] - base[j], ct, d, rank);
+      const uint32_t at = (uint32_t)NRQ_OP_INDEX(base[j] + pos / NRQ_ROW, pos % NRQ_ROW), t = at / tile_words; /* word index in the stream, its tile */
+      if (t >= ntile) { (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); continue; } /* (cannot happen: a place behind the groups' rows) */
+      const uint32_t k = PL_ATOM_ADD(&sh->bkt_n[t], 1u);
+      if (k < tile_words) bkt[(size_t)t * tile_words + k] = make_uint2(at - t * tile_words, w[j]);
+      else (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY); /* (cannot happen: more ops than places) */
+    }
+  }
+  __syncthreads(); /* (the lists: global stores of this workgroup read back by it -- the barrier's release / acquire covers them) */
+  for (uint32_t t = 0; t < ntile; t++) {
+    const uint32_t q0 = t * tq, q1 = q0 + tq < nquad ? q0 + tq : nquad, nw = (q1 - q0) * 4u * NRQ_ROW;
+    for (uint32_t k = tid; k < nw; k += nt) tile[k] = NRQ_NOP_AT(NRQ_OP_LANE_OF_INDEX(k));
+    __syncthreads();
+    const uint32_t n = sh->bkt_n[t] < tile_words ? sh->bkt_n[t] : tile_words;
+    const uint2 *lst = bkt + (size_t)t * tile_words;
+    pl_for_batched(tid, nt, n, [&](uint32_t k) { return lst[k]; }, [&](uint32_t, uint2 e) { if (e.x < nw) tile[e.x] = e.y; });
+    __syncthreads();
+    { /* the tile as whole lines */
+      const uint4 *src = reinterpret_cast<const uint4 *>(tile);
+      uint4 *dst = reinterpret_cast<uint4 *>(ops + (size_t)q0 * 4u * NRQ_ROW);
+      for (uint32_t k = tid; k < nw / 4u; k += nt) dst[k] = src[k];
+    }
+    __syncthreads();
+  }
+  return true;
+}
+#endif
 template <int Z> SB_HD void pl_ops_emit(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   if (const uint32_t *cls = pl_cls(c)) { /* the ops were recorded with group, class and rank: their lanes follow (plan.h "lane placement") */
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (pl_ops_emit_tiled(c, cls, tid, nt)) return;
+#endif
     uint32_t *ops = reinterpret_cast<uint32_t *>(c.arena + sh->off_ops);
     const uint32_t nrec = sh->nrec;
     for (uint32_t i0 = tid; i0 < nrec; i0 += PL_WU * nt) { /* PL_WU records in flight per thread */
