@@ -2194,8 +2194,15 @@ SB_HD void pl_emit_row(PlanCtx &c, uint32_t r, uint32_t own, uint32_t lev, uint3
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ bool pl_ops_emit_tiled(PlanCtx &c, const uint32_t *cls, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
-  if (c.cls_glob || !c.aux_lds || c.dense_lds == c.aux_lds || pl_cls_place(c) != c.dense_lds) return false; /* (the aux region is not free) */
-  uint32_t tq = c.aux_bytes / 1024u; /* quads per tile: 4 rows x 64 lanes x 4 bytes each */
+  if (c.cls_glob || !c.aux_lds) return false;
+  /* the tile: the aux region -- all of it when the class counters have a place of their own (the dense stage's region), what
+   * lies in front of them when they sit at its end (blocks whose dense stage takes over the rowstate image: pl_cls_place) */
+  const uint8_t *clsp = pl_cls_place(c);
+  uint32_t tile_bytes;
+  if (c.dense_lds != c.aux_lds && clsp == c.dense_lds) tile_bytes = c.aux_bytes;
+  else if (clsp > c.aux_lds && clsp <= c.aux_lds + c.aux_bytes) tile_bytes = (uint32_t)(clsp - c.aux_lds);
+  else return false;
+  uint32_t tq = tile_bytes / 1024u; /* quads per tile: 4 rows x 64 lanes x 4 bytes each */
   if (tq > PL_EMIT_TILE_WORDS / 256u) tq = PL_EMIT_TILE_WORDS / 256u;
   const uint32_t nlev = sh->nlev, rows_emit = c.lev_base[nlev + 1u], nquad = (rows_emit + 3u) / 4u;
   if (tq < 16u || nquad == 0u || (nquad + tq - 1u) / tq > PL_EMIT_TILES_MAX) return false; /* (small blocks -- a tile of a few rows, a dozen
