@@ -373,6 +373,7 @@ struct PlanCtx {
   uint32_t *wentry;    /* workspace: [0] records, [1] status, [2] fail site */
   uint16_t *patch_of, *patch_cols, *pc_rows, *pc_head, *ucol;
   uint32_t *emit_bkt;
+  bool pcfill_lds; /* pc_fill (patch entries per column) lives in the dense stage's LDS region, idle until peeling is over */
   uint8_t *patch_len;
   uint32_t *pc_ptr, *pc_fill, *wrows, *lev_ops, *lev_base, *lev_fill, *pivdeg, *lowdeg, *lev_fin, *red_row,
       *red_x, *rec_word, *rec_idx;
@@ -476,6 +477,11 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
   c.patch_len = w + c.wl.patch_len;
   c.pc_ptr = reinterpret_cast<uint32_t *>(w + c.wl.pc_ptr);
   c.pc_fill = reinterpret_cast<uint32_t *>(w + c.wl.pc_fill);
+  /* (the counts of patch entries per column -- counted and handed out by atomics while the patch CSC is built, read by the chained
+   * peel for every column with patch rows: in the dense stage's region when that is idle until peeling is over, i.e. when the
+   * peeling state has its own place in LDS) */
+  c.pcfill_lds = lds_dyn && c.dense_lds != c.aux_lds && c.dense_lds != lds_dyn && (c.p.L + 1u) * 4u <= c.dense_bytes;
+  if (c.pcfill_lds) c.pc_fill = reinterpret_cast<uint32_t *>(c.dense_lds);
   c.pc_rows = reinterpret_cast<uint16_t *>(w + c.wl.pc_rows);
   c.pc_head = reinterpret_cast<uint16_t *>(w + c.wl.pc_head);
   c.ucol = reinterpret_cast<uint16_t *>(w + c.wl.ucol);
@@ -1031,7 +1037,7 @@ __device__ __forceinline__ void pl_drop_column_chain(PlanCtx &c, const PlPeel &s
   uint32_t pcnt = 0, r1 = 0xFFFFu;
   const uint32_t *pcb = c.pcbits();
   if (!pcb || ((pcb[col >> 5] >> (col & 31u)) & 1u)) { /* (per block: far away) */
-    pcnt = c.pc_fill[col];
+    pcnt = c.pcfill_lds ? (uint32_t)PL_VOL32(&c.pc_fill[col]) : c.pc_fill[col]; /* (a DS read when the counts are in LDS: pl_ctx_setup) */
     if (lane0 < PL_PCHEAD) r1 = c.pc_head[col * PL_PCHEAD + lane0];
   }
 #ifdef PL_STAMP
@@ -3005,6 +3011,26 @@ template <int Z> SB_HD void pl_final_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (sh->status) return;
   struct CS { uint32_t col, slot; };
+#if defined(__HIP_DEVICE_COMPILE__)
+  /* the two maps by column through LDS when they fit the dense stage's region (done with by now): 2 x npiv two-byte stores
+   * scattered over the maps are partial lines for the memory to patch, like the op words of pl_ops_emit_tiled; built in LDS the
+   * maps go out as whole lines */
+  const uint32_t n_hd8 = (c.p.Kp + c.p.S + 7u) & ~7u, Lp = (c.p.L + 7u) & ~7u;
+  if (c.dense_lds && (Lp + n_hd8) * 2u <= c.dense_bytes) { /* (uniform: every thread takes the same way) */
+    uint16_t *cs = reinterpret_cast<uint16_t *>(c.dense_lds), *po = cs + Lp;
+    PL_ASSUME_LDS(cs); PL_ASSUME_LDS(po);
+    const uint32_t u = c.p.L - sh->npiv;
+    for (uint32_t col = tid; col < n_hd8; col += nt) po[col] = NRQ_NOSLOT;
+    for (uint32_t col = tid; col < Lp; col += nt) cs[col] = 0;
+    __syncthreads();
+    for (uint32_t x = tid; x < u; x += nt) cs[c.ucol[x]] = c.uslot[x]; /* (pl_final_a's homes of the inactive columns) */
+    pl_for_batched(tid, nt, sh->npiv, [&](uint32_t k) { return CS{c.pivcol[k], c.pivslot[k]}; },
+                   [&](uint32_t, CS v) { cs[v.col] = (uint16_t)v.slot; if (v.col < n_hd8) po[v.col] = (uint16_t)v.slot; });
+    __syncthreads();
+    for (uint32_t col = tid; col < c.p.L; col += nt) c.colslot[col] = cs[col];
+    for (uint32_t col = tid; col < n_hd8; col += nt) c.pivof[col] = po[col];
+  } else
+#endif
   pl_for_batched(tid, nt, sh->npiv, [&](uint32_t k) { return CS{c.pivcol[k], c.pivslot[k]}; },
                  [&](uint32_t, CS v) { c.colslot[v.col] = (uint16_t)v.slot; c.pivof[v.col] = (uint16_t)v.slot; });
   if (tid == 0) {
