@@ -511,17 +511,27 @@ static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis
     for (uint32_t h = 0; h < H; h++)
       Mh[(size_t)h * u + x] = (c < n_hd) ? G[(size_t)h * n_hd + c] : (uint8_t)(c - n_hd == h);
   }
-  for (uint32_t k = 0; k < npiv; k++) {
-    const uint32_t *wk = &Wm[(size_t)k * wpr];
-    uint32_t c = pivcol[k];
-    for (uint32_t w = 0; w < wpr; w++) {
-      uint32_t bits = wk[w];
-      while (bits) {
-        uint32_t x = w * 32 + (uint32_t)__builtin_ctz(bits);
-        bits &= bits - 1;
-        for (uint32_t h = 0; h < H; h++) Mh[(size_t)h * u + x] ^= G[(size_t)h * n_hd + c];
+  { /* G_left * W with the HDPC block by COLUMN (kconst off_gt: 16 bytes per column, rows >= H zero): one 16-byte XOR per set
+     * bit of W into MhT[x], transposed into Mh at the end (H single bytes at stride u per set bit were 3.5 of the 11.7 ms of a
+     * K'=8192 build) */
+    const uint8_t *GT = kconst + kh->off_gt;
+    std::vector<uint64_t> MhT((size_t)u * 2u, 0);
+    for (uint32_t k = 0; k < npiv; k++) {
+      const uint32_t *wk = &Wm[(size_t)k * wpr];
+      uint64_t g0, g1;
+      memcpy(&g0, GT + (size_t)pivcol[k] * 16u, 8); memcpy(&g1, GT + (size_t)pivcol[k] * 16u + 8u, 8);
+      for (uint32_t w = 0; w < wpr; w++) {
+        uint32_t bits = wk[w];
+        while (bits) {
+          const uint32_t x = w * 32 + (uint32_t)__builtin_ctz(bits);
+          bits &= bits - 1;
+          MhT[(size_t)x * 2u] ^= g0; MhT[(size_t)x * 2u + 1u] ^= g1;
+        }
       }
     }
+    const uint8_t *mt = reinterpret_cast<const uint8_t *>(MhT.data());
+    for (uint32_t x = 0; x < u; x++)
+      for (uint32_t h = 0; h < H; h++) Mh[(size_t)h * u + x] ^= mt[(size_t)x * 16u + h];
   }
 
   /* ---- GF(2) Gauss-Jordan on the leftover binary rows ---- */
