@@ -2314,7 +2314,7 @@ static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32
   r.f = f;
   HIPCHK(ctx, hipEventSynchronize(ctx->pstaged[f]));
   if ((rc = ensure_pin(ctx, ctx->pstaging[f], total))) return rc;
-  if ((rc = ensure_dev(ctx, ctx->pscratch[f], in_bytes))) return rc;
+  if ((rc = ensure_dev(ctx, ctx->pscratch[f], total))) return rc; /* (inputs, and the headers side by side behind them) */
   uint8_t *hs = ctx->pstaging[f].p, *ds = ctx->pscratch[f].p;
   if (ctx->arena_busy[ab] && ps != ctx->stream) HIPCHK(ctx, hipStreamWaitEvent(ps, ctx->arena_free[ab], 0));
   memcpy(hs + off_lost, h_lost, (size_t)nblk * lost_cap * 4);
@@ -2328,6 +2328,7 @@ static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32
     j.rep_esi = (uint64_t)(uintptr_t)(ds + off_resi + (size_t)b * rep_cap * 4);
     j.work = (uint64_t)(uintptr_t)(work.p + (size_t)b * wl.total);
     j.arena = (uint64_t)(uintptr_t)(ctx->plan_arena[ab].p + (size_t)b * arena_cap);
+    j.hdr_out = (uint64_t)(uintptr_t)(ds + off_hdrs + (size_t)b * sizeof(nrq_plan_hdr));
     j.src = (ctx->vec_src ? ctx->vec_src[b] : (uint64_t)(uintptr_t)((uint8_t *)d_src + (size_t)b * src_stride));
     j.rep = (ctx->vec_rep ? ctx->vec_rep[b] : (uint64_t)(uintptr_t)((const uint8_t *)d_rep + (size_t)b * rep_stride));
     j.inter = d_inter ? (uint64_t)(uintptr_t)((uint8_t *)d_inter + (size_t)b * inter_stride) : 0;
@@ -2387,8 +2388,7 @@ static int plan_launch(nrq_ctx *ctx, PlanRun &r, uint32_t K, uint32_t Kp, uint32
 #endif
     (void)hipFree(pprof);
   }
-  HIPCHK(ctx, hipMemcpy2DAsync(hs + off_hdrs, sizeof(nrq_plan_hdr), ctx->plan_arena[ab].p, arena_cap, sizeof(nrq_plan_hdr), nblk,
-                               hipMemcpyDeviceToHost, ps));
+  HIPCHK(ctx, hipMemcpyAsync(hs + off_hdrs, ds + off_hdrs, (size_t)nblk * sizeof(nrq_plan_hdr), hipMemcpyDeviceToHost, ps)); /* (pl_final_d's second copies) */
   HIPCHK(ctx, hipEventRecord(ctx->pstaged[f], ps));
   HIPCHK(ctx, hipEventRecord(ctx->planned[ab], ps));
   return 0;

@@ -90,6 +90,8 @@ typedef struct nrq_planjob {
   uint32_t nrep_avail;  /* >= nrep: further symbols the planner may take, one at a time, if the system is rank deficient */
   uint32_t mode;        /* 0 = decode; 1 = encode plan: no symbol is missing, the system is the encoder's (nlost = nrep = 0) */
   uint32_t pad_;
+  uint64_t hdr_out;     /* 0, or where a second copy of the plan header goes: the headers of a batch side by side, so that they come
+                         * back to the host as ONE copy (8192 headers out of 8192 arenas were a strided copy of ~150 us) */
 } nrq_planjob;
 
 /* ---- atomics: device intrinsics / plain memory in the emulator ---- */
@@ -3157,6 +3159,7 @@ template <int Z> SB_HD void pl_final_d(PlanCtx &c, uint32_t tid, uint32_t nt) {
     h.n_xor_ops = sh->tmp1 + run + sh->spare_fill; /* (tmp1: the level groups' ops, summed in pl_final_c) */
   }
   *c.hdr = h;
+  if (c.job.hdr_out) *PL_HBM(nrq_plan_hdr, c.job.hdr_out) = h; /* (the batch's headers side by side: one copy back to the host) */
   if (c.jobout) {
     nrq_job j;
     memset(&j, 0, sizeof(j));
