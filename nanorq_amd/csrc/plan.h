@@ -111,9 +111,14 @@ NRQ_PLAN_FN uint32_t nrq_lane_place(uint32_t span, const uint32_t *ct, uint32_t 
 /* When a peeling round has no row of weight 1, this many open rows (sparsest first) are resolved by
  * inactivation before peeling resumes: fewer, wider cascades -> fewer rounds in the planner and fewer dependency
  * levels in the plan, for a few more inactive columns (which the back-substitution pays for).  Measured on the
- * headline workload: 2 / 3 / 4 / 6 / 8 / 12 / 16 -> 1061 / 1074 / 1080 / 1084 / 1074 / 1070 / 1051 Gbit/s. */
+ * headline workload: 2 / 3 / 4 / 6 / 8 / 12 / 16 -> 1061 / 1074 / 1080 / 1084 / 1074 / 1070 / 1051 Gbit/s (round 2, rows taken one
+ * after the other).  With the rows of an event taken at once (round 5: pl_event_*, pl_inact_apply_a) 4 / 6 / 8 / 12 / 16 / 24 ->
+ * 1514 / 1521 / 1541 / 1540 / 1540 / 1293: more rows an event shorten the planner (1.80 / 1.70 / 1.64 / 1.61 / 1.62 ms) at the same
+ * decode solve until the inactive columns of SOME block of the launch no longer fit the 16-byte strip image and the whole launch
+ * falls to 8-byte strips (24: always; 12: one launch in 40 at 10 % loss, 13 in 40 at 30 %; 8: none / 4; 6: none / 2).  K=2000:
+ * 1352 / 1367 / 1354 for 6 / 8 / 12. */
 #ifndef NRQ_MULTI_INACT
-#define NRQ_MULTI_INACT 6u
+#define NRQ_MULTI_INACT 8u
 #endif
 
 /* From this many intermediate symbols on the GF(2) combinations of the dense stage are a bit matrix (off_augt), below it ops
