@@ -102,6 +102,9 @@ def parse():
     ap.add_argument("--plan-ahead", choices=("auto", "on", "off"), default="auto",
                     help="issue the decode planner run of the NEXT step while this step's decode is being solved (the symbolic stage "
                          "needs the reception pattern only): nrq_decode_plan_ahead.  auto = on")
+    ap.add_argument("--patterns", type=int, default=4, choices=(1, 2, 4, 8),
+                    help="different reception patterns the steps cycle through (step n loses pattern n mod this): no step's decode "
+                         "plan can be a leftover of the step before it; a plan issued ahead is the plan of THAT step's pattern")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffers-to-host-buffers leg")
     ap.add_argument("--one-object", choices=("auto", "on", "off"), default="auto",
                     help="ONE object over all N GPUs from rank 0's process (NANORQ_HIP_DEVICES=0..N-1, a host thread per device: "
@@ -448,30 +451,37 @@ def main():
         x = x ^ (x >> 33)
         src[b0:b0 + ch] = ((x >> 24) & 0xFF).to(torch.uint8).view(-1, K, T)
     del ar, x
-    lost = [loss_pattern(K, args.loss, seed=1000, block=gb) for gb in my_blocks]
-    max_lost = max(len(x) for x in lost)
+    # reception patterns: step n loses pattern n mod NPAT (seed 1000 + pattern: pattern 0 is the one earlier rounds used every step)
+    NPAT = args.patterns
+    lost_p = [[loss_pattern(K, args.loss, seed=1000 + q, block=gb) for gb in my_blocks] for q in range(NPAT)]
+    lost = lost_p[0]
+    max_lost = max(len(x) for lp in lost_p for x in lp)
     nrep = max_lost + args.overhead + 3  # repair symbols generated per block by the encoder (incl. spares)
     esis = np.arange(K, K + nrep, dtype=np.uint32)
     rep = torch.empty((NB, nrep, T), dtype=torch.uint8, device=dev)
     inter = torch.empty((NB, L, T), dtype=torch.uint8, device=dev)
     work = src.clone()  # what the receiver holds: source block with the lost rows destroyed
     # rows (block * K + esi) the channel destroyed: overwritten again at the start of EVERY step
-    lost_rows = torch.from_numpy(np.concatenate([b * K + lost[b].astype(np.int64) for b in range(NB)])).to(dev)
+    lost_rows_p = [torch.from_numpy(np.concatenate([b * K + lp[b].astype(np.int64) for b in range(NB)])).to(dev) for lp in lost_p]
     work_rows = work.view(NB * K, T)
     # the WHOLE lost row is destroyed (a decode that skips any column strip leaves 0xEE behind) -- written as 8-byte words:
     # torch's index_fill moves one element per thread, and byte elements made it 0.34 ms per step for 268 MB
     damage, damage_value = work_rows, 0xEE
     if T % 8 == 0:
         damage, damage_value = work.view(torch.int64).view(NB * K, T // 8), -0x1111111111111112   # = 0xEEEEEEEEEEEEEEEE
-    lost_arr = np.zeros((NB, max_lost + 1), np.uint32)
-    for b in range(NB):
-        lost_arr[b, :len(lost[b])] = lost[b]
-    nlost = np.array([len(x) for x in lost], np.uint32)
+    lost_arr_p, nlost_p, nr_first_p, nr_avail_p = [], [], [], []
+    spare = 3   # repair symbols a block may take beyond (lost + overhead) if its system is rank deficient
+    for lp in lost_p:
+        la = np.zeros((NB, max_lost + 1), np.uint32)
+        for b in range(NB):
+            la[b, :len(lp[b])] = lp[b]
+        nl = np.array([len(x) for x in lp], np.uint32)
+        lost_arr_p.append(la); nlost_p.append(nl)
+        nr_first_p.append((nl + args.overhead).astype(np.uint32))
+        nr_avail_p.append((nl + args.overhead + spare).astype(np.uint32))
+    nlost, nr_first = nlost_p[0], nr_first_p[0]
     resi = np.tile(esis, (NB, 1))
     retries = 0
-    spare = 3   # repair symbols a block may take beyond (lost + overhead) if its system is rank deficient
-    nr_first = (nlost + args.overhead).astype(np.uint32)
-    nr_avail = (nlost + args.overhead + spare).astype(np.uint32)
 
     # proof of work.  (1) oracle: `chk` blocks are compared with the oracle byte for byte after the timed region.  (2) every
     # step, EVERY block: a few full-width rows of its repair and intermediate symbols (which rows: a function of the step's
@@ -481,17 +491,18 @@ def main():
     # full (systematic property and repair symbols regenerated from the intermediate symbols, all on the device), and the
     # digests are compared with the ones formed from that verified state.
     chk = sorted(set([0, NB - 1][:max(0, args.check_blocks)]))[:args.check_blocks] if args.check_blocks > 0 else []
-    nchk_rep = int(min(nr_first[chk].min(), nrep)) if chk else 0   # repair symbols every reception of theirs uses
+    nchk_rep = int(min(min(nf[chk].min() for nf in nr_first_p), nrep)) if chk else 0   # repair symbols every reception of theirs uses
     digests = []
     NPHASE, REP_S, INT_S, WRK_S = 8, 2, 8, 8
     rng = np.random.default_rng(4242)
     ph_rep, ph_int, ph_wrk = [], [], []
     if args.check_blocks > 0:
-        for _ in range(NPHASE):
+        for ph_ in range(NPHASE):   # (phase ph_ belongs to the steps n with n mod NPHASE == ph_: their pattern is ph_ mod NPAT)
+            lq = lost_p[ph_ % NPAT]
             ph_rep.append(torch.from_numpy(np.concatenate([b * nrep + rng.integers(0, nrep, REP_S) for b in range(NB)])).to(dev))
             ph_int.append(torch.from_numpy(np.concatenate([b * L + rng.integers(0, L, INT_S) for b in range(NB)])).to(dev))
-            ph_wrk.append(torch.from_numpy(np.concatenate([b * K + lost[b][rng.integers(0, len(lost[b]), WRK_S)].astype(np.int64)
-                                                           for b in range(NB) if len(lost[b])])).to(dev))
+            ph_wrk.append(torch.from_numpy(np.concatenate([b * K + lq[b][rng.integers(0, len(lq[b]), WRK_S)].astype(np.int64)
+                                                           for b in range(NB) if len(lq[b])])).to(dev))
     # column weights (the far end of T counts); rows are read as 8-byte words: no widened copy of the sampled rows (with 8192
     # blocks of K=100 that copy was 1.2 GB per step)
     W8 = T // 8
@@ -525,14 +536,20 @@ def main():
             return r.sum(dtype=torch.int64)
         return torch.stack([dg(t, ix) for t, ix in ((rep_rows_all, ph_rep[ph]), (int_rows_all, ph_int[ph]), (wrows, ph_wrk[ph]))])
 
+    def pat_of(n):
+        return (n % NPHASE) % NPAT
+
     def step(ahead=None):
         nonlocal retries, step_no, ahead_out
         ahead = plan_ahead if ahead is None else ahead
         enc_stats = dec_stats = None
         ph = step_no % NPHASE
+        q = pat_of(step_no)   # this step's reception pattern
+        lost_arr, nlost, nr_first, nr_avail = lost_arr_p[q], nlost_p[q], nr_first_p[q], nr_avail_p[q]
+        this_step = step_no
         step_no += 1
         # the channel: the receiver's copy loses its rows again, over their full width (part of the step)
-        damage.index_fill_(0, lost_rows, damage_value)
+        damage.index_fill_(0, lost_rows_p[q], damage_value)
         if ph_rep:
             poison(ph)
         for (lo, hi), c_ in zip(groups, ctxs):
@@ -565,8 +582,11 @@ def main():
                 else:
                     ahead_out = 0   # (a decode that found no run issued for it has discarded the waiting ones)
                 while ahead_out < ahead_depth:
-                    c_.decode_plan_ahead(K, T, n_, work[lo].data_ptr(), K * T, lost_arr[lo:hi], nlost[lo:hi], resi[lo:hi],
-                                         nr_first[lo:hi], nr_avail[lo:hi], rep[lo].data_ptr(), nrep * T)
+                    # (the run for step this_step + 1 + ahead_out, with THAT step's reception pattern -- a receiver that has the
+                    # next objects' packets while this one is being solved; a run whose lists differ from its decode's is discarded)
+                    q2 = pat_of(this_step + 1 + ahead_out)
+                    c_.decode_plan_ahead(K, T, n_, work[lo].data_ptr(), K * T, lost_arr_p[q2][lo:hi], nlost_p[q2][lo:hi], resi[lo:hi],
+                                         nr_first_p[q2][lo:hi], nr_avail_p[q2][lo:hi], rep[lo].data_ptr(), nrep * T)
                     ahead_out += 1
         if ph_rep and nstreams == 1:
             digests.append((ph, digest_of(ph, work_rows)))
@@ -586,8 +606,7 @@ def main():
         step()
     barrier()
     retries = 0
-    digests.clear()
-    step_no = 0
+    digests.clear()   # (step_no runs on: the planner runs issued ahead in the warm-up are those of the first timed steps' patterns)
     for c_ in ctxs:
         c_.ktime_enable(True)
     t0 = time.perf_counter()
@@ -715,7 +734,7 @@ def main():
             blocks_per_launch = NB / float(nstreams)
             eff_ms = busy / len(ktimes)   # busy time attributable to one launch
             # physical bytes a launch cannot avoid / chooses to move (mean of the encode and the decode launch)
-            gaps = float(nlost.mean())
+            gaps = float(np.mean([nl.mean() for nl in nlost_p]))
             comp_enc = NB * T * (K + L + nrep)                       # source in; intermediate + repair symbols out
             comp_dec = NB * T * (K + gaps + gaps)                    # received symbols in; recovered symbols out
             stage_enc = NB * T * (L + (L + nrep))                    # slot image + results, once through the staging buffers
@@ -781,14 +800,16 @@ def main():
                                    "+decode" % (config_name(K, T, args.loss, args.overhead), K, T, NB, args.loss * 100, args.overhead,
                                                 nrep),
                        "K": K, "T": T, "blocks_per_gpu": NB, "loss": args.loss, "overhead": args.overhead,
+                       "reception_patterns": NPAT,
                        "repair_per_block": nrep, "sharding": "blocks over GPUs, no collective",
                        "streams_per_gpu": nstreams,
                        "encode_plan": "cached" if args.no_replan else "rebuilt every step",
                        "planner": ("device (nrq_plan_kernel, one workgroup per block)" if dec_stats["planner"] else
                                    "host, %d threads/rank" % threads),
                        "host_planned_blocks": dec_stats.get("host_planned", 0),
-                       "decode_plan": ("issued %d step(s) ahead (nrq_decode_plan_ahead): every step runs one planner pass per block, "
-                                       "beside the solves of the steps before it" % ahead_depth if plan_ahead else
+                       "decode_plan": ("issued %d step(s) ahead (nrq_decode_plan_ahead) from the reception pattern of the step it is for "
+                                       "(%d patterns in turn): every step runs one planner pass per block, beside the solves of the "
+                                       "steps before it" % (ahead_depth, NPAT) if plan_ahead else
                                        "inside the decode call"),
                        "decode_found_plan_ahead": bool(dec_stats.get("plan_ahead", 0)),
                        "ms_per_step_plan_inside_decode_call": ms_plan_in_call,

@@ -25,8 +25,9 @@
  *   - nanorq_repair_block decodes, in the same device batch, the other decodable blocks of the object and hands their rows
  *     out when their own call comes (same verdicts, same bytes); NANORQ_HIP_REPAIR_AHEAD=0 decodes one block per call;
  *   - NANORQ_HIP_DEVICES=0,1,... / NANORQ_HIP_DEVICE=n choose the GPUs (nanorq_batch.h);
- *   - the library runs six streams beside the caller's: a host process should export GPU_MAX_HW_QUEUES=8 before its first
- *     HIP call (the library sets it when it is loaded and the variable is unset; NANORQ_HIP_NO_ENV=1 keeps its hands off).
+ *   - the library runs six streams beside the caller's and the HIP runtime multiplexes a process's streams over 4 hardware
+ *     queues by default: a host process should export GPU_MAX_HW_QUEUES=8 before its first HIP call.  The library leaves the
+ *     process environment alone; NANORQ_HIP_SET_ENV=1 asks it to set the variable (if unset) when it is loaded.
  */
 #ifndef NANORQ_H
 #define NANORQ_H

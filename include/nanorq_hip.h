@@ -63,7 +63,8 @@ int nrq_ctx_set_planner(nrq_ctx *ctx, int device_planner);
  * planner has room for; a block that needs more is re-planned on the host).  Results never depend on them, only speed.
  * Fault injection for tests: "fail_after" n -- the n-th checked runtime call of the context from now on (allocation, copy,
  * event / stream operation, the error check behind a launch) is not made and fails instead, once (0 = off);
- * "faults_injected" returns the number of failures injected so far. */
+ * "faults_injected" returns the number of failures injected so far.  "fail_after" exists only on a context created with
+ * NANORQ_HIP_FAULT_INJECT=1 in the environment (else: unknown option, -1), and not at all in a -DNRQ_NO_FAULT_INJECT build. */
 int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value);
 /* threads used for host-side planning (0 = hardware concurrency) */
 int nrq_ctx_set_threads(nrq_ctx *ctx, int n);
@@ -194,6 +195,7 @@ void nrq_host_free_pinned(void *p);
 int nrq_host_register(void *p, size_t bytes);   /* page-lock caller memory in place */
 void nrq_host_unregister(void *p);
 int nrq_host_is_pinned(const void *p);          /* 1 if p lies in page-locked (allocated or registered) host memory */
+int nrq_host_range_is_pinned(const void *p, size_t bytes); /* 1 if all of [p, p + bytes) does (ends + a probe every 2 MiB) */
 /* Copies and ordering on the context's streams.  `stream`: 0 = the context's stream (kernels), 1 = its upload stream,
  * 2 = its download stream.  Everything is enqueue-only; events order the streams among each other. */
 int nrq_copy_on(nrq_ctx *ctx, int stream, void *dst, const void *src, size_t bytes); /* direction from the pointers */

@@ -909,6 +909,12 @@ static bool decode_host_blocks(nanorq *rq, int di, const unsigned *sbns, unsigne
   ok = (nrq_ctx_sync(c) == 0 || nrq_ctx_sync(c) == 0) && ok; /* (also on failure, and twice: the temporaries below may be in use) */
   for (unsigned k = 0; k < n && tmp; k++)
     if (tmp[k]) nrq_dev_free(c, tmp[k]);
+  /* the blocks decoded AHEAD (k >= 1) have their rows back on the host (or nothing valid): their device copies go back to the
+   * pool now instead of staying allocated until cleanup -- up to 2 GiB a call otherwise */
+  for (unsigned k = 1; k < n; k++) {
+    struct blockst *o = rq->blocks[sbns[k]];
+    if (o->d_src) { nrq_dev_free(c, o->d_src); o->d_src = NULL; }
+  }
   gpu_unlock(di);
   free(resi); free(nuse); free(navail); free(sv); free(rv); free(tmp);
   return ok;
@@ -970,12 +976,12 @@ bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.
   sbns[n++] = sbn;
   if (repair_ahead_on()) {
     const size_t Z = nanorq_blocks(rq);
-    size_t batch_bytes = (size_t)b->K * T;
+    size_t batch_bytes = ((size_t)b->K + b->nrep) * T; /* source rows AND the repair rows staged beside them */
     for (unsigned s2 = 0; s2 < Z; s2++) {
       const struct blockst *o = rq->blocks[s2];
       if (s2 == sbn || !o || o->dev || o->di != b->di || o->K != b->K || o->Kp != b->Kp || o->pre_state || o->up_seq || !block_decodable(o)) continue;
-      if (batch_bytes + (size_t)o->K * T > ((size_t)2 << 30)) break; /* (bounded device footprint per call) */
-      batch_bytes += (size_t)o->K * T;
+      if (batch_bytes + ((size_t)o->K + o->nrep) * T > ((size_t)2 << 30)) break; /* (bounded device footprint per call) */
+      batch_bytes += ((size_t)o->K + o->nrep) * T;
       const size_t g2 = mask_gaps(o, o->K);
       if (g2 > lost_cap) lost_cap = g2;
       sbns[n++] = s2;
@@ -984,6 +990,15 @@ bool nanorq_repair_block(nanorq *rq, struct ioctx *io, uint8_t sbn) { /* nanorq.
   uint32_t *lost = malloc((size_t)n * lost_cap * sizeof(uint32_t)), *nlost = calloc(n, sizeof(uint32_t));
   int *status = calloc(n, sizeof(int));
   bool ok = lost && nlost && status && decode_host_blocks(rq, b->di, sbns, n, lost, nlost, lost_cap, status);
+  if (!ok && n > 1 && lost && nlost && status) {
+    /* the BATCH failed (an allocation, an upload, the planner of some sibling): that says nothing about this block -- a
+     * one-block-per-call decoder would not have touched the others.  Once more with the requested block alone, so that
+     * `false` keeps meaning what it means in the reference: this block is rank deficient (nanorq.c:620-623) or the device failed it */
+    n = 1;
+    status[0] = 0;
+    nlost[0] = 0;
+    ok = decode_host_blocks(rq, b->di, sbns, 1, lost, nlost, lost_cap, status);
+  }
   if (ok) {
     for (unsigned k = 1; k < n; k++) { /* the others: rows and verdict wait for their own call */
       struct blockst *o = rq->blocks[sbns[k]];
@@ -1253,7 +1268,7 @@ size_t nanorq_encode_range_all(nanorq *rq, void *data, uint32_t esi0, uint32_t n
   }
   {
     /* no block solved yet and a page-locked target (the sender's usual case): solve and generate as one pipeline */
-    bool fresh = nrq_host_is_pinned(data) == 1;
+    bool fresh = nrq_host_range_is_pinned(data, Z * (size_t)n * T) == 1; /* (every byte the downloads will write, not just the first) */
     for (unsigned sbn = 0; sbn < Z && fresh; sbn++) fresh = !rq->blocks[sbn]->inverted && rq->blocks[sbn]->K > 0;
     if (fresh) return generate_all(rq, io, data, esi0, n) == Z ? Z * (size_t)n * T : 0;
   }
@@ -1506,7 +1521,7 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
   const size_t T = rq->T;
   uint8_t *obase;
   size_t olen;
-  const bool dma = ndev() && n >= 16 && rq->N == 1 && nrq_host_is_pinned(data) && (!io || (ioctx_dma_region(io, &obase, &olen) && olen >= rq->F));
+  const bool dma = ndev() && n >= 16 && rq->N == 1 && nrq_host_range_is_pinned(data, (size_t)n * T) && (!io || (ioctx_dma_region(io, &obase, &olen) && olen >= rq->F));
   /* Bookkeeping first, addresses afterwards: a repair symbol is recorded as (block, index in the block's repair rows) while
    * the loop runs; only when the batch's final repair count of every block is known are the blocks' device rows grown and
    * the indices turned into addresses (add_all_worker). */

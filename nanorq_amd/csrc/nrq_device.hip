@@ -427,6 +427,9 @@ enum {
   pl_tag_pl_lev_0 = 7,
   pl_tag_pl_pivot_sort = 7,
   pl_tag_pl_lev_a = 7,
+  pl_tag_pl_check_a = 7,
+  pl_tag_pl_check_b = 7,
+  pl_tag_pl_check_c = 7,
   pl_tag_pl_lev_b = 7,
   pl_tag_pl_w_init = 8,
   pl_tag_pl_w_init_b = 8,
@@ -600,6 +603,7 @@ __global__ __launch_bounds__(1024) void nrq_wentry_kernel(rq_params p, const uin
   if (sh->status != 0 || sh->nV != 0) return;
   c.cls_glob = reinterpret_cast<uint32_t *>(c.work + c.wl.cls_g);
   c.nrec_ptr = &c.wentry[0];
+  c.own_ptr = &c.wentry[3];
   pl_w_init_part<0>(c, part, nparts, tid, 1024u);
   __syncthreads();
   pl_wentry_report<0>(c, tid, 1024u);
@@ -1021,6 +1025,7 @@ static void plan_ahead_drop(struct nrq_ctx *ctx);
 struct nrq_ctx {
   int device = 0;
   long long fail_after = 0;      /* fault injection: checked runtime calls until the injected failure (0 = off) */
+  bool fault_inject_armed = false; /* NANORQ_HIP_FAULT_INJECT=1 was in the environment when the context was created */
   long long faults_injected = 0;
   Tuning tune;
   int ncu = 256; /* compute units of the device */
@@ -1096,12 +1101,16 @@ struct nrq_ctx {
 
 namespace {
 
+#ifdef NRQ_NO_FAULT_INJECT
+static inline bool nrq_inject(nrq_ctx *) { return false; } /* (a build without the hook: -DNRQ_NO_FAULT_INJECT) */
+#else
 static inline bool nrq_inject(nrq_ctx *ctx) {
-  if (!ctx || ctx->fail_after <= 0) return false;
+  if (!ctx || ctx->fail_after <= 0) return false; /* (fail_after can only be set on a context created with NANORQ_HIP_FAULT_INJECT=1) */
   if (--ctx->fail_after > 0) return false;
   ctx->faults_injected++;
   return true;
 }
+#endif
 
 int fail(nrq_ctx *ctx, int code, const char *fmt, ...) {
   char buf[512];
@@ -1116,7 +1125,10 @@ int fail(nrq_ctx *ctx, int code, const char *fmt, ...) {
 /* Fault injection (nrq_ctx_set_option "fail_after" n): the n-th checked runtime call of the context from now on -- an
  * allocation, a copy, an event or stream operation, the error check behind a launch -- is not made and reports an error
  * instead, once.  The tests drive the error paths of the object layer with it (rollback of a packet batch, a failed chunk of
- * nanorq_repair_all, ...); nothing else sets it. */
+ * nanorq_repair_all, ...); nothing else sets it.  It is a TEST facility: the option exists only on a context created while
+ * the environment holds NANORQ_HIP_FAULT_INJECT=1 (tests/conftest.py, tools/sanitize.sh set it) -- in any other process
+ * "fail_after" is an unknown option, so no caller of the public nanorq_hip_option can make a runtime call fail -- and
+ * -DNRQ_NO_FAULT_INJECT builds the library without the hook altogether. */
 static inline bool nrq_inject(nrq_ctx *ctx);
 #define HIPCHK(ctx, call)                                                                                   \
   do {                                                                                                      \
@@ -1752,15 +1764,15 @@ int nrq_params(uint32_t K, uint32_t out[10]) {
 
 /* The runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues, 4 by default; a context runs up to six
  * streams beside the caller's, and two streams on one queue execute one after the other (seen as the encode-plan build
- * serialised into the solve stream).  The variable must be there before the runtime initialises, so it is set -- if unset --
- * when the library is LOADED, not from nrq_ctx_create: a load-time constructor runs before the library's first HIP call and,
- * in the usual case of a library linked at program start, before the process has other threads that could be reading the
- * environment.  A host that initialises HIP before loading this library sets the variable itself (bench.py does);
- * NANORQ_HIP_NO_ENV=1 makes the library leave the environment alone. */
+ * serialised into the solve stream).  The variable must be there before the runtime initialises, and it belongs to the HOST
+ * process: the library does not touch the environment unless asked to -- NANORQ_HIP_SET_ENV=1 makes this load-time
+ * constructor set GPU_MAX_HW_QUEUES=8 if it is unset (a constructor runs before the library's first HIP call and, for a
+ * library linked at program start, before the process has other threads that could be reading the environment; a library
+ * dlopen'ed late gets neither guarantee, which is why it is opt-in).  bench.py, the tools and the tests export the variable
+ * themselves; include/nanorq.h and INTEGRATION.md tell a host process to. */
 __attribute__((constructor)) static void nrq_env_at_load(void) {
-  const char *e = getenv("NANORQ_HIP_NO_ENV");
-  if (e && *e == '1') return;
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  const char *e = getenv("NANORQ_HIP_SET_ENV");
+  if (e && *e == '1') setenv("GPU_MAX_HW_QUEUES", "8", 0);
 }
 
 int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
@@ -1779,6 +1791,10 @@ int nrq_ctx_create(int device, void *stream, nrq_ctx **out) {
   }
   ctx->tune.read();
   if (getenv("NRQ_HOST_PLANNER")) ctx->planner = 0;
+  {
+    const char *fi = getenv("NANORQ_HIP_FAULT_INJECT");
+    ctx->fault_inject_armed = fi && *fi == '1';
+  }
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->plan_stream_b, hipStreamNonBlocking) != hipSuccess ||
@@ -1935,7 +1951,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "plan_ucap") t.plan_ucap = (uint32_t)value;
   else if (n == "plan_wrong_instance") t.plan_wrong_instance = value != 0;
   else if (n == "plan_no_wg128") t.plan_no_wg128 = value != 0;
-  else if (n == "fail_after") ctx->fail_after = value > 0 ? value : 0;
+  else if (n == "fail_after" && ctx->fault_inject_armed) ctx->fail_after = value > 0 ? value : 0;
   else if (n == "faults_injected") return (int)ctx->faults_injected; /* (read: injected failures so far) */
   else return fail(ctx, -1, "unknown option %s", name);
   return 0;
@@ -2719,6 +2735,18 @@ int nrq_host_is_pinned(const void *p) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return a.type == hipMemoryTypeHost ? 1 : 0;
+}
+/* the whole range [p, p + bytes): its first and last byte and a probe every 2 MiB in between (registrations are page
+ * granular; a range that is page-locked at both ends and every 2 MiB is taken as page-locked throughout) */
+int nrq_host_range_is_pinned(const void *p, size_t bytes) {
+  if (!p) return 0;
+  if (!bytes) return nrq_host_is_pinned(p);
+  const uint8_t *q = static_cast<const uint8_t *>(p);
+  if (!nrq_host_is_pinned(q) || !nrq_host_is_pinned(q + bytes - 1)) return 0;
+  const size_t step = (size_t)2 << 20;
+  for (size_t o = step - (reinterpret_cast<uintptr_t>(q) & (step - 1)); o < bytes; o += step)
+    if (!nrq_host_is_pinned(q + o)) return 0;
+  return 1;
 }
 
 /* streams and events of the object layer's copy pipeline; stream selector: 0 = the context's stream, 1 = upload

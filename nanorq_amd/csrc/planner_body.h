@@ -236,6 +236,8 @@ typedef struct pl_shared {
   uint32_t tmp_mhoff; /* byte offset of Mb inside the dense LDS region, behind MhT (fixed once nlow is known) */
   uint32_t dense_ok, nextra, spare_base, spare_fill, xcol, xrow[48]; /* W pass: level tables staged in LDS; which group each op buffer holds */
   uint32_t ndone;             /* chained peeling (pl_round_chain): claims of the current list that have been dropped */
+  uint32_t own_hits;          /* plan check: entries (pivot row, its own pivot column) met by the entry pass (pl_w_entries) -- must be npiv */
+  uint32_t chk_piv, chk_inact;/* plan check (pl_check_b): columns found in state pivot / inactive */
   uint32_t bkt_n[PL_EMIT_TILES_MAX]; /* pl_ops_emit_tiled: ops sorted out to every tile of the stream so far */
   uint32_t ev_n, ev_min, ev_none; /* inactivation event, peeling state in LDS (pl_event_*): open rows with two V columns listed, the
                                    * sparsest of the others, "no open row is left" */
@@ -263,7 +265,7 @@ SB_HD bool pl_bin_in_stream(uint32_t L) { return L < NRQ_AUG_MATRIX_MIN_L; } /* 
 /* ---- per-block workspace in HBM (offsets from job.work) ---- */
 typedef struct pl_work_layout {
   uint32_t rowstate, rowinfo, colinfo, patch_of, patch_cols, patch_len, pc_ptr, pc_fill, pc_rows, pc_head, ucol, wrows,
-      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, sh_save, mh_ext, cls_g, wentry, emit_bkt, total;
+      lev_ops, lev_base, lev_fill, pivdeg, lowdeg, lev_fin, red_row, red_x, rec_word, rec_idx, rec_g, cand, sh_save, mh_ext, cls_g, wentry, emit_bkt, chk, total;
 } pl_work_layout;
 
 /* nnzcap: entries of the base structure plus the patch rows (bounds the number of row ops) */
@@ -301,6 +303,7 @@ SB_HD pl_work_layout pl_work_plan(uint32_t L, uint32_t Mcap, uint32_t npcap, uin
   w.cls_g = o;      o = pl_r16(o + (L + 2u) * 32u);               /* the class counters (PL_CLS_BYTES per level group) while nrq_wentry_kernel's workgroups count into them */
   w.wentry = o;     o = pl_r16(o + 16u);                           /* ... and their record counter / failure report */
   w.emit_bkt = o;   o = pl_r16(o + 3u * nnzcap * 8u);             /* (place inside the tile, op word), a list per tile of the stream: pl_ops_emit_tiled */
+  w.chk = o;        o = pl_r16(o + Mcap * 2u);                     /* pl_check_a / _b: the pivot that owns every slot */
   w.total = o;
   return w;
 }
@@ -372,7 +375,9 @@ struct PlanCtx {
   bool collev_hbm;
   uint32_t *cls_glob;  /* non-null: pl_cls() is this array in HBM */
   uint32_t *nrec_ptr;  /* the record counter: &sh->nrec, or the workspace's */
-  uint32_t *wentry;    /* workspace: [0] records, [1] status, [2] fail site */
+  uint32_t *wentry;    /* workspace: [0] records, [1] status, [2] fail site, [3] own-column entries met (plan check) */
+  uint32_t *own_ptr;   /* the plan check's counter of (pivot row, own pivot column) entries: &sh->own_hits, or the workspace's */
+  uint16_t *chk;       /* workspace: pivot that owns slot r (pl_check_a / _b) */
   uint16_t *patch_of, *patch_cols, *pc_rows, *pc_head, *ucol;
   uint32_t *emit_bkt;
   bool pcfill_lds; /* pc_fill (patch entries per column) lives in the dense stage's LDS region, idle until peeling is over */
@@ -460,7 +465,9 @@ SB_HD void pl_ctx_setup(PlanCtx &c, const rq_params &prm, const uint8_t *kc, con
     c.collev_hbm = (job.mode & 0x200u) != 0u;
     c.cls_glob = nullptr;
     c.nrec_ptr = &sh->nrec;
+    c.own_ptr = &sh->own_hits;
     c.wentry = reinterpret_cast<uint32_t *>(w + c.wl.wentry);
+    c.chk = reinterpret_cast<uint16_t *>(w + c.wl.chk);
     c.pk_cnt = c.pk_un = c.pk_pa = c.pk_vb = nullptr;
     const uint32_t pk_cnt_b = pl_r16(Mcap + 4u), pk_row_b = pl_r16((Mcap + 31u) / 32u * 4u), pk_col_b = pl_r16((c.p.L + 31u) / 32u * 4u);
 #ifndef PL_NO_COMPACT
@@ -967,6 +974,13 @@ SB_HD void pl_round_drop_k(PlanCtx &c, uint32_t rd, uint32_t tid, uint32_t nt) {
 #ifndef PL_CHAIN
 #define PL_CHAIN 1
 #endif
+/* How the chained peel publishes a claim (pl_chain_claim): 1 = release / acquire atomics at workgroup scope, as the memory
+ * model has it; 0 = plain volatile LDS accesses kept in place by a compiler barrier, resting on the LDS taking a wave's
+ * instructions in order (what rounds 4 and 5 shipped).  Either way the plan check behind the peel (pl_check_*) catches a
+ * claim that went wrong and sends the block to the host planner. */
+#ifndef PL_CHAIN_RELEASE
+#define PL_CHAIN_RELEASE 1
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 /* (volatile accesses to LDS as DS instructions: through a generic pointer they become FLAT ones, whose waits count the
  * outstanding HBM stores as well -- a trip to memory on the chain for every claim) */
@@ -984,9 +998,19 @@ __device__ __forceinline__ void pl_chain_claim(PlanCtx &c, const PlPeel &s, uint
    * LDS takes a wave's instructions in order: no wait, but the compiler must keep the two where they are).  The entry before
    * everything else -- the chain waits for it; a slot that is not empty: the ring has come round on an entry nobody has dropped
    * yet (qcap entries in flight) */
+#if PL_CHAIN_RELEASE
+  /* the memory model's way of saying it: the row's "assigned" is a relaxed atomic store, the list entry a RELEASE at workgroup
+   * scope (the reader's ring load is the acquire, pl_round_chain_dev) -- the compiler puts the wait for the LDS store in front
+   * of the compare-and-swap.  Measured against the in-order form below: profiles/r6_planner_release.txt. */
+  __hip_atomic_store((__attribute__((address_space(3))) uint32_t *)(uintptr_t)&s.rowinfo[r], (now & PL_PATCHED) | lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  uint32_t was = PL_RING_EMPTY;
+  (void)__hip_atomic_compare_exchange_strong((__attribute__((address_space(3))) uint32_t *)(uintptr_t)&c.ring()[i2 & (c.qcap - 1u)], &was,
+                                             ((lv + 1u) << 16) | col2, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
   PL_VOL32(&s.rowinfo[r]) = (now & PL_PATCHED) | lv;
   __asm__ volatile("" ::: "memory");
   const uint32_t was = PL_ATOM_CAS(&c.ring()[i2 & (c.qcap - 1u)], PL_RING_EMPTY, ((lv + 1u) << 16) | col2);
+#endif
   s.colinfo[col2] = (PL_ST_PIVOT << 30) | k;
   c.pivslot[k] = (uint16_t)r; /* (HBM; read after peeling) */
   c.pivcol[k] = (uint16_t)col2;
@@ -1072,7 +1096,11 @@ __device__ __forceinline__ void pl_round_chain_dev(PlanCtx &c, uint32_t rd, uint
   const unsigned long long tp_ = clock64();
 #endif
   for (uint32_t guard = 0; guard < (1u << 24); guard++) {
+#if PL_CHAIN_RELEASE
+    const uint32_t v = __hip_atomic_load((__attribute__((address_space(3))) uint32_t *)(uintptr_t)&c.ring()[i & qm], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     const uint32_t v = PL_VOL32(&c.ring()[i & qm]); /* (the group's next entry: there as soon as its claimant has written it) */
+#endif
     if (v != PL_RING_EMPTY) {
 #ifdef PL_STAMP
       const unsigned long long t0_ = clock64();
@@ -1583,6 +1611,53 @@ template <int Z> SB_HD void pl_lev_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
   for (uint32_t l = tid; l < sh->nlev + 2u; l += nt) { c.lev_ops[l] = 0; c.lev_fill[l] = 0; }
   for (uint32_t j = tid; j < c.lowcap; j += nt) c.gj_used()[j] = 0; /* (the bytes were the patch-column bits during peeling) */
 }
+/* Plan check behind the peel (the device-only peeling forms are race-based by design -- chained claims, batched
+ * inactivation events, the pivot sort -- and a wrong plan decodes to silently wrong bytes).  Two cheap passes establish, for
+ * every planner instance (device, big-block device, emulator), that the peel's books describe a permutation:
+ *   a) pivot k's column says "pivot k" (so pivot columns are distinct), its row is marked assigned, and k is written to chk[row];
+ *   b) chk[row of pivot k] still holds k (so pivot ROWS are distinct); every column is pivot or inactive, the pivot columns
+ *      number npiv, every inactive column x has ucol[index] == x (distinct W bits) and they number L - npiv.
+ * With the entry pass's two rules (pl_w_entries: a row op's source is final before the row's level; every pivot row holds
+ * its own column, counted) the plan then IS a forward substitution of the block's matrix; what is violated raises
+ * PL_FAIL_CAPACITY and the caller re-plans the block on the host (nrq_device.hip decode_device: capacity fallback).
+ * Cost at K=8192: two passes over 8.4 k pivots / columns by 1024 threads, ~10 k of the planner's 3.7 M clocks. */
+template <int Z> SB_HD void pl_check_a(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (tid == 0) { sh->own_hits = 0; sh->chk_piv = 0; sh->chk_inact = 0; } /* (a segmented run counts in wentry[3]: zeroed by pl_lev_b) */
+  if (sh->status) return;
+  struct PV { uint32_t slot, info, rinfo; };
+  bool bad = false;
+  pl_for_batched(tid, nt, sh->npiv,
+                 [&](uint32_t k) { const uint32_t sl = c.pivslot[k]; return PV{sl, c.colinfo[c.pivcol[k]], sl < sh->M ? c.rowinfo[sl] : PL_UNASSIGNED}; },
+                 [&](uint32_t k, PV v) {
+                   if (v.info != ((PL_ST_PIVOT << 30) | k) || (v.rinfo & PL_UNASSIGNED) || v.slot >= sh->M) { bad = true; return; }
+                   c.chk[v.slot] = (uint16_t)k;
+                 });
+  if (bad) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+}
+template <int Z> SB_HD void pl_check_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  if (sh->status) return;
+  bool bad = false;
+  pl_for_batched(tid, nt, sh->npiv, [&](uint32_t k) { return (uint32_t)c.chk[c.pivslot[k]]; },
+                 [&](uint32_t k, uint32_t owner) { if (owner != (k & 0xFFFFu)) bad = true; });
+  uint32_t np = 0, ni = 0;
+  const uint32_t u = c.p.L - sh->npiv;
+  for (uint32_t col = tid; col < c.p.L; col += nt) {
+    const uint32_t info = c.colinfo[col], st = info >> 30, idx = info & 0x3FFFFFFFu;
+    if (st == PL_ST_PIVOT) np++;
+    else if (st == PL_ST_INACT) { ni++; if (idx >= u || c.ucol[idx] != (uint16_t)col) bad = true; }
+    else bad = true; /* a column still in V (or claimed and never made a pivot) */
+  }
+  if (np) PL_ATOM_ADD(&sh->chk_piv, np);
+  if (ni) PL_ATOM_ADD(&sh->chk_inact, ni);
+  if (bad) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+}
+template <int Z> SB_HD void pl_check_c(PlanCtx &c, uint32_t tid, uint32_t nt) {
+  pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
+  (void)nt;
+  if (tid == 0 && !sh->status && (sh->chk_piv != sh->npiv || sh->chk_inact != c.p.L - sh->npiv)) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
+}
 template <int Z> SB_HD void pl_lev_b(PlanCtx &c, uint32_t tid, uint32_t nt) {
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   if (uint32_t *l = pl_cls(c)) { /* nlev is final now */
@@ -1640,11 +1715,17 @@ SB_HD void pl_w_entries(PlanCtx &c, uint32_t *cls, const uint16_t *collev, const
   for (uint32_t j = 0; j < PL_WU; j++) {
     const uint32_t idx = info[j] & 0x3FFFFFFFu;
     const bool inact = on[j] && (info[j] >> 30) == PL_ST_INACT;
-    const bool op = on[j] && !inact && src[j] != r[j]; /* (== : the row's own pivot column) */
+    const bool own = on[j] && !inact && src[j] == r[j]; /* the row's own pivot column */
+    const bool op = on[j] && !inact && !own;
     if (inact) PL_ATOM_XOR(&c.wrows[(size_t)r[j] * c.sh->wpr + (idx >> 5)], 1u << (idx & 31u));
+    (void)PL_WAVE_TAKE(c.own_ptr, own); /* (plan check: every pivot row must hold its pivot column -- counted, compared in pl_ops_layout_a) */
     const uint32_t i = PL_WAVE_TAKE(c.nrec_ptr, op); /* (by the whole wave: see there) */
     if (!op) continue;
     const uint32_t lev = (rinfo[j] & PL_UNASSIGNED) ? c.sh->nlev : (rinfo[j] & PL_LEVEL_MASK);
+    /* plan check, the rule the forward passes rest on: the source of a row op -- the pivot row of another column of the row --
+     * is final BEFORE the row's own level (peeling took this row when that column had left V).  A peel that claimed a row
+     * too early (the race-based device forms: chained claims, batched events) shows here; the block goes to the host planner. */
+    if (collev && (uint32_t)collev[col[j]] >= lev) { (c.sh->fail_site = __LINE__, c.sh->status = PL_FAIL_CAPACITY); continue; }
     const uint32_t g = pl_op_group(collev, lev, r[j], col[j]);
     const uint32_t early = g == lev ? 0u : 0x80000000u;
     const uint32_t word = NRQ_OP(r[j], src[j]);
@@ -2114,6 +2195,8 @@ template <int Z> SB_HD void pl_ops_layout_a(PlanCtx &c, uint32_t tid, uint32_t n
   pl_shared *sh = c.sh; PL_ASSUME_LDS(sh);
   const bool in_lds = sh->nlev + 1u <= 2u * c.qcap;
   uint16_t *rowq = c.queue(0u);
+  /* plan check (pl_check_a): the entry pass met the own pivot column of every pivot row exactly once */
+  if (tid == 0 && !sh->status && pl_col_level(c) && sh->own_hits != sh->npiv) (sh->fail_site = __LINE__, sh->status = PL_FAIL_CAPACITY);
   for (uint32_t l = tid; l <= sh->nlev; l += nt) {
     uint32_t n, nf;
     const uint32_t span = pl_group_span_of(c, l, &n, &nf);
@@ -2397,6 +2480,7 @@ template <int Z> SB_HD void pl_cls_fetch(PlanCtx &c, uint32_t tid, uint32_t nt) 
     for (uint32_t k = tid; k < pl_lev_words(c) * (PL_CLS_BYTES / 4u); k += nt) l[k] = g[k];
   if (tid == 0) {
     sh->nrec = c.wentry[0];
+    sh->own_hits = c.wentry[3];
     if (c.wentry[1] && !sh->status) { sh->status = c.wentry[1]; sh->fail_site = c.wentry[2]; }
   }
 }

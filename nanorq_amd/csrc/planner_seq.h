@@ -90,6 +90,12 @@
   const bool peeled_ = sh_->status == 0 && sh_->nV == 0;
   PL_STEER_SYNC; /* (later phases raise status when a capacity is exceeded) */
   if (peeled_) {
+#ifdef PL_SABOTAGE_HOOK
+    PL_SABOTAGE_HOOK; /* (the emulator's tests damage the peel's books here, to see the check find it) */
+#endif
+    PL_PHASE(pl_check_a); /* the peel's books describe a permutation, or the block goes to the host planner (planner_body.h) */
+    PL_PHASE(pl_check_b);
+    PL_PHASE(pl_check_c);
     PL_PHASE(pl_lev_b);
     PL_PHASE(pl_low_a);
     PL_PHASE(pl_low_b);

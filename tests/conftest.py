@@ -7,6 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The host process owns its environment (the library no longer sets anything on its own): eight hardware queues for the
+# library's streams, before anything initialises the HIP runtime; and the test-only fault injection of the contexts created
+# in this process and its children (nrq_ctx_set_option "fail_after": tests/test_gpu_faults.py).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("NANORQ_HIP_FAULT_INJECT", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

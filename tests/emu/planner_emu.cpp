@@ -17,6 +17,32 @@ static uint32_t g_gj_wave = 1; /* the 32 columns of a panel in one phase (pl_gjp
 extern "C" void emu_plan_set_gj_wave(uint32_t v) { g_gj_wave = v; }
 #include "../../nanorq_amd/csrc/planner_body.h"
 
+/* tests/test_planner_emu.py::test_plan_check_finds_damaged_books: damage done to the peel's books right before the plan check
+ * (planner_seq.h PL_SABOTAGE_HOOK) -- what a lost race of the device-only peeling forms would leave behind */
+static uint32_t g_sabotage = 0;
+extern "C" void emu_plan_set_sabotage(uint32_t kind) { g_sabotage = kind; }
+static void emu_sabotage(PlanCtx &c) {
+  pl_shared *sh = c.sh;
+  const uint32_t np = sh->npiv;
+  if (!g_sabotage || np < 8u) return;
+  switch (g_sabotage) {
+    case 1: c.pivslot[np / 2u] = c.pivslot[np / 2u + 1u]; break;                    /* two pivots share a row */
+    case 2: { const uint16_t t = c.pivcol[1]; c.pivcol[1] = c.pivcol[2]; c.pivcol[2] = t; } break; /* pivot columns swapped */
+    case 3: { /* a pivot row claimed too early: the deepest pivot pretends to be on level 0 */
+      uint32_t best = 0, bl = 0;
+      for (uint32_t k = 0; k < np; k++) { const uint32_t l = c.rowinfo[c.pivslot[k]] & PL_LEVEL_MASK; if (l >= bl) { bl = l; best = k; } }
+      c.rowinfo[c.pivslot[best]] &= ~PL_LEVEL_MASK;
+    } break;
+    case 4: c.colinfo[c.pivcol[np - 1u]] = 0u; break;                                 /* a column left in V */
+    case 5: { const uint32_t u = c.p.L - np; if (u >= 2u) c.colinfo[c.ucol[1]] = (PL_ST_INACT << 30) | 0u; } break; /* two inactive columns, one W bit */
+    case 6: { /* a pivot row that does not hold its pivot column: two pivots trade rows */
+      const uint16_t t = c.pivslot[np - 1u]; c.pivslot[np - 1u] = c.pivslot[np - 2u]; c.pivslot[np - 2u] = t;
+    } break;
+    default: break;
+  }
+}
+#define PL_SABOTAGE_HOOK emu_sabotage(c)
+
 extern "C" uint32_t emu_plan_arena_bound(uint32_t K, const uint8_t *kc, uint32_t overhead_cap, uint32_t nlost_cap) {
   const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(kc);
   (void)K;
@@ -137,11 +163,13 @@ extern "C" int emu_plan(uint32_t K, uint32_t Kp_hint, const uint8_t *kc, const u
       if (sh->status == 0 && sh->nV == 0) {
         c.cls_glob = reinterpret_cast<uint32_t *>(c.work + c.wl.cls_g);
         c.nrec_ptr = &c.wentry[0];
+        c.own_ptr = &c.wentry[3];
         for (uint32_t part = 0; part < 2u; part++)
           for (uint32_t t_ = 0; t_ < PL_NT; t_++) pl_w_init_part<1>(c, part, 2u, t_, PL_NT);
         PL_PHASE(pl_wentry_report);
         c.cls_glob = nullptr;
         c.nrec_ptr = &sh->nrec;
+        c.own_ptr = &sh->own_hits;
       }
       memset(sh, 0xEE, shb);
       PL_PHASE(pl_sh_restore);

@@ -354,3 +354,32 @@ def test_source_symbols_of_a_solved_block_do_not_depend_on_the_io_any_more():
     assert L.nanorq_encode(rq, buf, 7, 0, None) == T and bytes(buf) == keep[7 * T:8 * T].tobytes()
     L.nanorq_free(rq)
     io.contents.destroy(io)
+
+
+def test_fault_injection_is_a_test_facility_only():
+    """A process that did not ask for it (no NANORQ_HIP_FAULT_INJECT=1 when its context is created) cannot make the library's
+    runtime calls fail through the public nanorq_hip_option: "fail_after" is an unknown option there, and the library leaves
+    the process environment alone (no GPU_MAX_HW_QUEUES appears unless NANORQ_HIP_SET_ENV=1 asks for it)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import os, sys, ctypes as C\n"
+            "sys.path[:0] = [%r, %r]\n"
+            "import nanorq_amd\n"
+            "L = nanorq_amd.lib()\n"
+            "L.nanorq_hip_option.restype = C.c_int\n"
+            "L.nanorq_hip_option.argtypes = [C.c_size_t, C.c_char_p, C.c_longlong]\n"
+            "L.nanorq_devices.restype = C.c_size_t\n"
+            "assert L.nanorq_devices() >= 1\n"
+            "g = C.CDLL(None).getenv; g.restype = C.c_char_p; g.argtypes = [C.c_char_p]\n"   # (the C environment, not python's copy)
+            "v = g(b'GPU_MAX_HW_QUEUES')\n"
+            "print(L.nanorq_hip_option(0, b'fail_after', 3), v.decode() if v else None)\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    env = {k: v for k, v in os.environ.items() if k not in ("NANORQ_HIP_FAULT_INJECT", "GPU_MAX_HW_QUEUES", "NANORQ_HIP_SET_ENV")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert r.stdout.decode().split() == ["-1", "None"], r.stdout
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, NANORQ_HIP_FAULT_INJECT="1", NANORQ_HIP_SET_ENV="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert r.stdout.decode().split() == ["0", "8"], r.stdout

@@ -87,3 +87,26 @@ def test_many_reception_patterns_through_the_device_planner(K, T, nblk, p, iters
         assert not wrong.any(), (K, it, np.nonzero(wrong)[0][:8])
         assert ctx.stats().get("host_planned", 0) == 0
     ctx.close()
+
+
+STRESS_CASES = [  # K, T, blocks, loss, iterations -- the sizes every planner form covers (tools/stress_sweep.sh, same table)
+    (8192, 64, 256, 0.1, 60), (8192, 64, 256, 0.3, 30), (9400, 32, 256, 0.1, 30), (2000, 32, 1024, 0.2, 40), (5000, 32, 512, 0.06, 40),
+    (20000, 16, 64, 0.1, 15), (56403, 8, 8, 0.2, 10), (56403, 8, 8, 0.45, 6), (700, 32, 2048, 0.1, 30), (1000, 32, 2048, 0.5, 20),
+    (100, 32, 8192, 0.2, 20), (10, 32, 8192, 0.3, 20)]
+
+
+@pytest.mark.skipif(__import__("os").environ.get("NANORQ_STRESS") != "1", reason="long sweep: NANORQ_STRESS=1 enables it (~8 GPU-minutes)")
+@pytest.mark.parametrize("K,T,nblk,p,iters", STRESS_CASES)
+def test_stress_sweep(K, T, nblk, p, iters):
+    """tools/stress_decode.py as a gated test (NANORQ_STRESS=1): ~0.5 M block decodes with fresh reception patterns over every
+    form of the device planner -- none may fail, come out wrong, or need the host planner (a block the plan check of
+    planner_body.h pl_check_* sends there counts as a defect of the peel, not as a pass)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_decode.py"), str(K), str(T), str(nblk), str(p), str(iters)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-1500:]
+    assert "done: %d iterations x %d blocks, 0 bad" % (iters, nblk) in out and "host planner took" not in out, out[-1500:]

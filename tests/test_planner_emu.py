@@ -446,6 +446,32 @@ def test_small_planner_state_reports_overflow(orc):
     assert ok_hdr["status"] == 0 and hdr["status"] == 1
 
 
+@pytest.mark.parametrize("kind", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("split", [False, True])
+def test_plan_check_finds_damaged_books(orc, kind, split):
+    """The device-only peeling forms (chained claims, batched inactivation events, pivot sort) are race-based by design, and a
+    wrong plan would decode to silently wrong bytes: behind the peel every planner instance checks that its books describe a
+    permutation (planner_body.h pl_check_a / _b / _c, and the two rules of the entry pass).  Here the emulator damages the
+    books the way a lost race would -- two pivots on one row, pivot columns swapped, a row claimed before its sources were
+    final, a column left in V, two inactive columns on one W bit, pivots trading rows -- and every kind must come back as a
+    capacity failure (status 1 with reason PL_FAIL_CAPACITY = 2: the host planner then takes the block), the undamaged run as
+    a plan."""
+    from emu_support import pemu
+    K = 1024
+    kc = nanorq_amd.host_kconst(K)
+    lost = loss_pattern(K, 0.2, 7)
+    esis = received_set(K, lost, 0)
+    rep_esis = esis[esis >= K]
+    _, ok_hdr = emu_device_plan(K, kc, lost, rep_esis, split=split, wentry=split)
+    assert ok_hdr["status"] == 0
+    pemu().emu_plan_set_sabotage(kind)
+    try:
+        _, hdr = emu_device_plan(K, kc, lost, rep_esis, split=split, wentry=split)
+    finally:
+        pemu().emu_plan_set_sabotage(0)
+    assert hdr["status"] == 1 and hdr["reserved0"] == 2 and hdr["fail_site"] != 0, (kind, hdr["status"], hdr["reserved0"], hdr["fail_site"])
+
+
 def test_host_planner_fills_the_rows_of_the_stream():
     """plan.h "early ops by release": the host planner deals the early ops with wide windows out in the order of their release,
     so that a group takes what its rows have lanes for -- the stream's rows are nearly full (by hash alone a quarter of it was

@@ -7,6 +7,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/reference_benchmark.sh > gpurun_out/r4_reference_benchmark.txt'
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 B=$REPO/oracle/_refprog/benchmark_hip
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}   # (what include/nanorq.h asks a host process to export)
 [ -x "$B" ] || { echo "no $B (built in the build container only)"; exit 1; }
 $B 1280 1000 5.0 > /dev/null 2>&1   # first process on a fresh box: driver / code-object caches
 echo "# reference benchmark.c on libnanorq_hip.so, $(rocm-smi --showproductname 2>/dev/null | grep -m1 -o 'MI[0-9A-Za-z]*' || echo MI355X), T=1280, 6 % loss; Mbit/s"

@@ -40,6 +40,7 @@ cpu)
     NANORQ_HIP_LIB=$REPO/build_var/libnanorq_hip_asan.so python -m pytest tests/test_api_host.py tests/test_tables.py -x -q 2>&1 | tee $OUT/asan_cpu.log | tail -5
   ;;
 gpu)
+  export GPU_MAX_HW_QUEUES=8 NANORQ_HIP_FAULT_INJECT=1   # (the host process's to set: include/nanorq.h; "fail_after" is a test facility)
   export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:protect_shadow_gap=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
   ( $REPO/build_var/exercise_asan faults; echo "asan exercise rc=$?"
     head -c 3000000 /dev/urandom > /tmp/san_in.bin

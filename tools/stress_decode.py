@@ -39,6 +39,9 @@ for it in range(iters):
     torch.cuda.synchronize()
     st = np.asarray(st)
     wrong = (~(work == src).flatten(1).all(1)).cpu().numpy()
+    hp = ctx.stats().get("host_planned", 0)
+    if hp:  # (a capacity the device planner ran out of, or its plan check: planner_body.h pl_check_*)
+        print("iteration %d: host planner took %d blocks" % (it, hp), flush=True)
     for b in np.nonzero((st == 0) | wrong)[0]:
         bad += 1
         print("iteration %d block %d: status %d, data %s, lost %d, planner %s" % (it, b, st[b], "WRONG" if wrong[b] else "ok", nl[b], ctx.stats().get("host_planned")), flush=True)
