@@ -101,7 +101,8 @@ def parse():
     ap.add_argument("--plan-ahead-depth", type=int, default=2, help="planner runs kept in flight ahead of their decode (1 or 2)")
     ap.add_argument("--plan-ahead", choices=("auto", "on", "off"), default="auto",
                     help="issue the decode planner run of the NEXT step while this step's decode is being solved (the symbolic stage "
-                         "needs the reception pattern only): nrq_decode_plan_ahead.  auto = on")
+                         "needs the reception pattern only): nrq_decode_plan_ahead.  auto = for big blocks (L >= 12000) only; "
+                         "the headline builds the plan inside the decode call")
     ap.add_argument("--patterns", type=int, default=4, choices=(1, 2, 4, 8),
                     help="different reception patterns the steps cycle through (step n loses pattern n mod this): no step's decode "
                          "plan can be a leftover of the step before it; a plan issued ahead is the plan of THAT step's pattern")
@@ -517,7 +518,12 @@ def main():
     # blocks (the planner stays on the solve stream): what goes is the host's wait for the planner in the MIDDLE of the step and
     # its work behind it (2048 plan headers, the solve launch) with the GPU idle -- K=1000: 18.5 -> 18.1 ms on a quiet host,
     # 28.8 -> 18.1 ms on a busy one; the headline 15.87 -> 15.74.
-    plan_ahead = nstreams == 1 and args.plan_ahead in ("on", "auto")
+    # Round 6: auto = big blocks only (L >= 12000: one planner workgroup per block is 10-18 ms of latency on a few CUs, which a
+    # receiver of a stream of objects hides behind the solves of the objects before -- with the NEXT object's own reception
+    # pattern, see --patterns).  Elsewhere the plan is built inside the decode call, as a receiver does that learns the pattern
+    # when it decodes: that is the headline's `value` now (round 5 quoted the run-ahead figure; with a planner of 1.65 ms that
+    # owns every CU while it runs the two differ by < 1 % either way: 13.92 against 14.0-14.2 ms per step).
+    plan_ahead = nstreams == 1 and (args.plan_ahead == "on" or (args.plan_ahead == "auto" and replan_early))
     ahead_depth = max(1, min(2, args.plan_ahead_depth))
     ahead_out = 0   # planner runs issued ahead and not consumed yet
 
@@ -626,6 +632,22 @@ def main():
     # the same step with the decode plan built INSIDE the decode call (a receiver that learns the reception pattern when it
     # decodes): reported beside the headline, never `value`.  The runs still waiting are consumed first (untimed).
     ms_plan_in_call = None
+    ms_plan_ahead = None
+    if not plan_ahead and world == 1 and args.steps >= 2 and nstreams == 1 and args.plan_ahead == "auto":
+        # the other form beside the headline: planner runs issued two steps ahead (never `value`)
+        for c_ in ctxs:
+            c_.ktime_enable(False)
+        for _ in range(ahead_depth + 1):
+            step(ahead=True)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        nplain = min(args.steps, 5)
+        for _ in range(nplain):
+            step(ahead=True)
+        torch.cuda.synchronize(dev)
+        ms_plan_ahead = (time.perf_counter() - t1) / nplain * 1e3
+        step(ahead=False)   # (discards the runs still waiting)
+        torch.cuda.synchronize(dev)
     if plan_ahead and world == 1 and args.steps >= 2:
         for c_ in ctxs:
             c_.ktime_enable(False)
@@ -812,8 +834,10 @@ def main():
                                        "steps before it" % (ahead_depth, NPAT) if plan_ahead else
                                        "inside the decode call"),
                        "decode_found_plan_ahead": bool(dec_stats.get("plan_ahead", 0)),
+                       "ms_per_step_plans_issued_ahead": ms_plan_ahead,
                        "ms_per_step_plan_inside_decode_call": ms_plan_in_call,
                        "value_plan_inside_decode_call": (8.0 * payload_step / (ms_plan_in_call * 1e-3) / 1e9) if ms_plan_in_call else None,
+                       "value_plans_issued_ahead": (8.0 * payload_step / (ms_plan_ahead * 1e-3) / 1e9) if ms_plan_ahead else None,
                        "decode_retries": retries_total, "spare_symbols_taken": retries_total,
                        "in_step": "damage of the receiver's copy (every lost row overwritten over its full width: %.0f MB of writes), "
                                   "poisoning of %d repair + %d intermediate rows of EVERY block and a digest of them and of %d decoded "

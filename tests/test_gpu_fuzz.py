@@ -110,3 +110,25 @@ def test_stress_sweep(K, T, nblk, p, iters):
     out = r.stdout.decode()
     assert r.returncode == 0, out[-1500:]
     assert "done: %d iterations x %d blocks, 0 bad" % (iters, nblk) in out and "host planner took" not in out, out[-1500:]
+
+
+def test_failure_rates_match_rfc6330_design():
+    """10^5 random receptions of a K=100 block per overhead 0 / 1 / 2 (loss 10-50 %, random repair ESIs) through the device
+    planner: RFC 6330's design figures are ~1 % / ~0.01 % / ~1e-4 % failures -- a mis-restated generator or a planner that
+    loses rank lands far away from them.  Bounds are wide (Poisson: ~10 expected at overhead 1): 0.2-2 %, < 0.1 %, < 0.01 %.
+    No block reported decoded may differ from its source.  (tools/failure_rates.py; the table for K = 100 and 1000 is
+    profiles/r6_failure_rates.txt.)  Reference verdict: lib/nanorq.c:620-623, lib/precode.c:264-315."""
+    import os
+    import sys
+    import torch
+    import nanorq_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import failure_rates
+    dev = torch.device("cuda", 0)
+    ctx = nanorq_amd.Context(0, torch.cuda.current_stream(dev).cuda_stream)
+    r = failure_rates.rates(ctx, dev, 100, 8, 100000, [0.1, 0.3, 0.5])
+    ctx.close()
+    assert all(v["decoded_wrong"] == 0 for v in r.values()), r
+    assert 0.002 < r[0]["rate"] < 0.02, r
+    assert r[1]["rate"] < 0.001, r
+    assert r[2]["rate"] < 0.0001, r

@@ -71,3 +71,36 @@ def test_failure_sweep_vectors(G):
     assert [bool(x) for x in st] == [c["decodable"] for c in fs["cases"]]
     for b in range(n):
         assert np.array_equal(out[b], src if st[b] else work[b])
+
+
+def test_every_table2_row_on_the_hip_encoder(G):
+    """All 477 K' rows of RFC 6330 Table 2 through the HIP encoder (K = K', T = 8): every systematic constraint matrix must be
+    found nonsingular by the product's planners (host planner below L = 12000, nrq_plan_kernel above), the intermediate
+    symbols and the repair symbols ESI K'..K'+3 must be the committed ones (tests/golden/kprime_sweep.json, written by
+    tools/gen_kprime_sweep.py), and the source symbols must come back out of the intermediate symbols (systematic property,
+    RFC 6330 5.3.3.4.2; on the device: nrq_gen_symbols).  Reference: include/table2.h:6-211, lib/params.c:21-45,
+    lib/tuple.c:21-43, lib/precode.c:90-97."""
+    import nanorq_amd
+    doc = GS.load("kprime_sweep.json")
+    T, nrep = doc["T"], doc["repair_per_row"]
+    assert len(doc["rows"]) == 477
+    c = G.ctx()
+    for r in doc["rows"]:
+        Kp = r["Kp"]
+        L = nanorq_amd.params(Kp)["L"]
+        src = payload(Kp * T, seed=doc["payload_seed"], block=Kp).reshape(Kp, T)
+        d_src, d_rep, d_int, d_out = c.alloc(Kp * T), c.alloc(nrep * T), c.alloc(L * T), c.alloc(Kp * T)
+        try:
+            c.upload(d_src, src)
+            c.memset(d_rep, 0xCD, nrep * T); c.memset(d_int, 0xCD, L * T); c.memset(d_out, 0xCD, Kp * T)
+            c.encode_blocks(Kp, T, 1, d_src, Kp * T, d_rep, nrep * T, np.arange(Kp, Kp + nrep, dtype=np.uint32), d_int, L * T)
+            c.gen_symbols(Kp, T, 1, d_int, L * T, np.arange(Kp, dtype=np.uint32), d_out, Kp * T)
+            c.sync()
+            assert GS.sha(c.download(d_rep, nrep * T)) == r["sha256_repair"], Kp
+            assert GS.sha(c.download(d_int, L * T)) == r["sha256_intermediate"], Kp
+            assert np.array_equal(c.download(d_out, Kp * T).reshape(Kp, T), src), "K'=%d: LT(intermediate) is not the source block" % Kp
+        finally:
+            for d in (d_src, d_rep, d_int, d_out):
+                c.free(d)
+        if Kp % 7 == 0:
+            c.clear_plan_cache()
