@@ -403,7 +403,10 @@ def main():
                     sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible: refusing to print a line for fewer "
                                      "GPUs than asked\n" % (args.gpus, have))
                     raise SystemExit(2)
-            raise SystemExit(shard.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+            env_l = dict(os.environ)
+            if args.force_device >= 0:
+                env_l["NANORQ_FORCE_DEVICE"] = str(args.force_device)   # (CPU placement: every rank beside that one GPU)
+            raise SystemExit(shard.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env_l))
     import torch
     import nanorq_amd
     from util import loss_pattern
@@ -424,7 +427,9 @@ def main():
     # RCCL; only the barrier and the timing reduction use it
     shard.init(args.dist_backend, device_id=torch.device("cuda", local) if args.dist_backend == "nccl" else None)
     dev = torch.device("cuda", local)
-    threads = args.threads or max(1, (os.cpu_count() or 1) // max(1, world))
+    # host planner threads: the cores this rank was given (shard.spawn_ranks binds a rank to its GPU's NUMA node), else its share
+    ncpu_mine = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = args.threads or (max(1, ncpu_mine) if os.environ.get("NANORQ_RANK_CPUS") else max(1, ncpu_mine // max(1, world)))
     nstreams = max(1, min(args.streams, args.blocks))
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
     ctxs = [nanorq_amd.Context(local, st.cuda_stream) for st in streams]   # one context per stream, same GPU

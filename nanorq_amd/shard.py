@@ -78,7 +78,87 @@ def free_port():
     return port
 
 
-def spawn_ranks(n, argv, env=None, timeout=None):
+# ---- CPU placement of the ranks -----------------------------------------------------------------------------------------
+# One process per GPU means N host processes on one node; left alone they all float over every core, torch / OpenMP start a
+# thread per hardware thread in each of them, and a rank's page-locked staging memory may land on the other socket from its
+# GPU.  spawn_ranks therefore gives every rank the cores of its GPU's NUMA node (a disjoint slice of them when several GPUs
+# share a node: 4 per socket on an 8-GPU MI355X board) and an OMP_NUM_THREADS that fits the slice.
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_cpu_lists(sysfs="/sys"):
+    """Per GPU, in HIP device order: (numa node, cpus local to it), from the KFD topology (the nodes with SIMDs are the
+    GPUs, in the order the runtime numbers them) and the PCI device's local_cpulist.  [] when the tree is not there."""
+    import glob
+    out = []
+    nodes = sorted(glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*")), key=lambda d: int(os.path.basename(d)))
+    for d in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(d, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) == 0:
+                continue   # a CPU node
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            bdf = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7)
+            pdir = os.path.join(sysfs, "bus/pci/devices", bdf)
+            node = int(open(os.path.join(pdir, "numa_node")).read().strip())
+            cpus = parse_cpulist(open(os.path.join(pdir, "local_cpulist")).read())
+            out.append((node, cpus))
+        except (OSError, ValueError):
+            out.append((-1, []))
+    return out
+
+
+def visible_devices(env):
+    """HIP device index -> physical GPU index under ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES (None: identity)."""
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(k)
+        if v:
+            try:
+                return [int(x) for x in v.split(",") if x.strip() != ""]
+            except ValueError:
+                return None
+    return None
+
+
+def rank_cpus(n, allowed=None, gpus=None, device_of_rank=None):
+    """CPU set of each of n ranks: the allowed cpus of the rank's GPU's NUMA node, dealt out disjointly among the ranks that
+    share the node; without topology (or when a node has no allowed cpu) an even split of the allowed cpus.  Every rank gets
+    at least one cpu."""
+    allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    device_of_rank = device_of_rank or list(range(n))
+    sets = [None] * n
+    if gpus:
+        by_node = {}
+        for r in range(n):
+            d = device_of_rank[r]
+            if 0 <= d < len(gpus) and gpus[d][1]:
+                by_node.setdefault((gpus[d][0], tuple(gpus[d][1])), []).append(r)
+        for (_, cpus), ranks in by_node.items():
+            mine = [c for c in cpus if c in set(allowed)]
+            if len(mine) < len(ranks):
+                continue
+            per = len(mine) // len(ranks)
+            for i, r in enumerate(ranks):
+                sets[r] = mine[i * per:(i + 1) * per]
+    rest = [r for r in range(n) if not sets[r]]
+    if rest:
+        taken = set(c for s_ in sets if s_ for c in s_)
+        pool = [c for c in allowed if c not in taken] or allowed
+        per = max(1, len(pool) // len(rest))
+        for i, r in enumerate(rest):
+            sets[r] = pool[(i * per) % len(pool):(i * per) % len(pool) + per] or [pool[i % len(pool)]]
+    return sets
+
+
+def spawn_ranks(n, argv, env=None, timeout=None, bind=True, sysfs="/sys"):
     """Start `argv` n times on this node, one process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
     torch.distributed.run exports them, rendezvous on 127.0.0.1), and wait for all of them.  Rank 0 inherits stdout (it prints
     the one result line); the other ranks' stdout goes to stderr.  Returns the largest exit code; when a rank fails the others
@@ -87,10 +167,22 @@ def spawn_ranks(n, argv, env=None, timeout=None):
     base.setdefault("MASTER_ADDR", "127.0.0.1")
     base["MASTER_PORT"] = str(free_port())
     base["WORLD_SIZE"] = base["LOCAL_WORLD_SIZE"] = str(n)
+    cpus = [None] * n
+    if bind and base.get("NANORQ_NO_BIND") != "1" and hasattr(os, "sched_setaffinity"):
+        vis = visible_devices(base)
+        dev_of = [(vis[r] if vis and r < len(vis) else r) for r in range(n)]
+        if base.get("NANORQ_FORCE_DEVICE", "") != "":   # (plumbing runs: every rank on one GPU -- its node for all of them)
+            dev_of = [int(base["NANORQ_FORCE_DEVICE"])] * n
+        cpus = rank_cpus(n, gpus=gpu_cpu_lists(sysfs), device_of_rank=dev_of)
     procs = []
     for r in range(n):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(argv, env=e, stdout=None if r == 0 else sys.stderr, start_new_session=True))
+        pre = None
+        if cpus[r]:
+            e["NANORQ_RANK_CPUS"] = ",".join(str(c) for c in cpus[r])
+            e.setdefault("OMP_NUM_THREADS", str(max(1, min(len(cpus[r]), 16))))   # (torch / numpy / OpenMP pools sized for the slice)
+            pre = (lambda cs: (lambda: os.sched_setaffinity(0, cs)))(set(cpus[r]))
+        procs.append(subprocess.Popen(argv, env=e, stdout=None if r == 0 else sys.stderr, start_new_session=True, preexec_fn=pre))
     import signal
     import time
     rc, t0 = 0, time.time()

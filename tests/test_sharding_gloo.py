@@ -84,3 +84,79 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(_clean_env(), RANK="0", LOCAL_RANK="0",
                        WORLD_SIZE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
     assert r.returncode == 2 and b"launcher started 1" in r.stderr
+
+
+def _fake_sysfs(root, gpus):
+    """gpus: list of (numa node, cpulist text) in HIP order; node 0 of the topology is a CPU node (no SIMDs)."""
+    nodes = root / "class/kfd/kfd/topology/nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, (node, cpulist) in enumerate(gpus):
+        d = nodes / str(i + 1)
+        d.mkdir()
+        bus = 0x10 + i
+        d.joinpath("properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        p = root / "bus/pci/devices" / ("0000:%02x:00.0" % bus)
+        p.mkdir(parents=True)
+        p.joinpath("numa_node").write_text("%d\n" % node)
+        p.joinpath("local_cpulist").write_text(cpulist + "\n")
+
+
+def test_ranks_are_bound_to_their_gpus_numa_node(tmp_path):
+    """An 8-GPU MI355X board: four GPUs per socket.  Every rank gets cores of ITS GPU's NUMA node, ranks that share a node
+    get disjoint slices, nothing outside the allowed set is handed out; without a topology the allowed cores are split evenly."""
+    _fake_sysfs(tmp_path, [(0, "0-63,128-191")] * 4 + [(1, "64-127,192-255")] * 4)
+    gpus = shard.gpu_cpu_lists(str(tmp_path))
+    assert [g[0] for g in gpus] == [0, 0, 0, 0, 1, 1, 1, 1] and len(gpus[0][1]) == 128
+    sets = shard.rank_cpus(8, allowed=range(256), gpus=gpus)
+    assert all(len(s) == 32 for s in sets)
+    assert all(set(sets[r]) <= set(gpus[r][1]) for r in range(8))
+    assert len(set(c for s in sets for c in s)) == 256                       # disjoint
+    # a cgroup that allows only part of a node; a device list that maps ranks to other GPUs; a single-GPU plumbing run
+    sets = shard.rank_cpus(2, allowed=range(0, 16), gpus=gpus, device_of_rank=[0, 1])
+    assert sorted(sets[0] + sets[1]) == list(range(16)) and not set(sets[0]) & set(sets[1])
+    sets = shard.rank_cpus(2, allowed=range(256), gpus=gpus, device_of_rank=[5, 1])
+    assert set(sets[0]) <= set(gpus[5][1]) and set(sets[1]) <= set(gpus[1][1])
+    sets = shard.rank_cpus(4, allowed=range(256), gpus=gpus, device_of_rank=[0, 0, 0, 0])
+    assert all(set(s) <= set(gpus[0][1]) and len(s) == 32 for s in sets) and len(set(c for s in sets for c in s)) == 128
+    sets = shard.rank_cpus(3, allowed=[2, 3, 4, 5, 6, 7], gpus=[])
+    assert sets == [[2, 3], [4, 5], [6, 7]]
+    assert shard.rank_cpus(4, allowed=[0, 1], gpus=[]) and all(shard.rank_cpus(4, allowed=[0, 1], gpus=[]))  # more ranks than cores: everybody gets one
+    assert shard.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    assert shard.visible_devices({"HIP_VISIBLE_DEVICES": "4,5"}) == [4, 5] and shard.visible_devices({}) is None
+
+
+@pytest.mark.timeout(120)
+def test_spawned_ranks_see_their_binding(tmp_path):
+    """What spawn_ranks hands down: a disjoint CPU set per rank (applied before the child starts), NANORQ_RANK_CPUS naming it, and
+    an OMP_NUM_THREADS that fits it."""
+    if not hasattr(os, "sched_getaffinity") or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("one core")
+    code = ("import os, json; json.dump({'aff': sorted(os.sched_getaffinity(0)), 'env': os.environ['NANORQ_RANK_CPUS'], "
+            "'omp': os.environ['OMP_NUM_THREADS']}, open(os.path.join(%r, 'r' + os.environ['RANK']), 'w'))" % str(tmp_path))
+    env = {k: v for k, v in _clean_env().items() if k != "OMP_NUM_THREADS"}
+    assert shard.spawn_ranks(2, [sys.executable, "-c", code], env=env, timeout=60, sysfs=str(tmp_path / "nosys")) == 0
+    recs = [json.load(open(tmp_path / ("r%d" % r))) for r in range(2)]
+    assert not set(recs[0]["aff"]) & set(recs[1]["aff"])
+    for r in recs:
+        assert r["aff"] == sorted(int(x) for x in r["env"].split(",")) and 1 <= int(r["omp"]) <= len(r["aff"])
+    assert set(recs[0]["aff"]) | set(recs[1]["aff"]) <= set(os.sched_getaffinity(0))
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_job_gives_the_one_rank_digests(tmp_path):
+    """The split the driver's 8-GPU run uses (block b -> rank b mod 8, eight processes started by spawn_ranks, gloo here): every
+    block's repair symbols are the ones a one-rank run produces -- a block's content is a function of its GLOBAL id."""
+    total, K, T = 19, 40, 16
+    d8, d1 = tmp_path / "w8", tmp_path / "w1"
+    d8.mkdir(); d1.mkdir()
+    worker = [sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), str(total), str(K), str(T)]
+    assert shard.spawn_ranks(8, worker + [str(d8)], env=dict(_clean_env(), OMP_NUM_THREADS="1"), timeout=500) == 0
+    assert shard.spawn_ranks(1, worker + [str(d1)], env=dict(_clean_env(), OMP_NUM_THREADS="1"), timeout=200) == 0
+    recs = [json.load(open(d8 / ("rank%d.json" % r))) for r in range(8)]
+    assert [r["world"] for r in recs] == [8] * 8 and all(r["blocks_done"] == total for r in recs)
+    assert [r["blocks"] for r in recs] == [list(range(r, total, 8)) for r in range(8)]
+    merged = {}
+    for r in recs:
+        merged.update(r["digests"])
+    assert merged == json.load(open(d1 / "rank0.json"))["digests"] and len(merged) == total
