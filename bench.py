@@ -621,10 +621,12 @@ def main():
     for c_ in ctxs:
         c_.ktime_enable(True)
     t0 = time.perf_counter()
+    cpu0 = time.process_time()   # (all threads of this rank's process: host plan build, launch paths, torch)
     for _ in range(args.steps):
         enc_stats, dec_stats = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu_ms = (time.process_time() - cpu0) / args.steps * 1e3
     # solve-kernel launches of all streams on one time axis (HIP events recorded around each launch)
     intervals, ptimes = [], []
     for c_ in ctxs:
@@ -850,6 +852,10 @@ def main():
             "check": check,
             "roofline": roof, "e2e": e2e, "one_object": one_object, "cpu_baseline": cpu,
             "detail": {"solve_kernel_ms_sum_per_step": sum(ktimes) / args.steps,
+                       # CPU time this rank's process spent per step (every thread; the barrier's wait included when it spins):
+                       # what N ranks on N GPUs ask of the host is N x this, on N disjoint core sets (shard.spawn_ranks)
+                       "host_cpu_ms_per_step_rank0": host_cpu_ms,
+                       "rank_cpus": os.environ.get("NANORQ_RANK_CPUS", ""),
                        "planner_ms": (sum(ptimes) / len(ptimes)) if ptimes else None,
                        # the solve launches of a step are [encode, decode] per stream group, in that order
                        "encode_solve_ms": (sum(ktimes[0::2]) / max(1, len(ktimes[0::2]))) if nstreams == 1 else None,

@@ -43,6 +43,8 @@ typedef struct nrq_call_stats {
   uint32_t host_planned; /* decode blocks whose plan exceeded a device-planner capacity and was rebuilt on the host */
   uint32_t movers_aligned; /* 1: the solve kernel variant without byte-wise paths in its movers (all rows aligned, T a multiple of the strip) */
   uint32_t plan_ahead;  /* 1: the decode found its planner run already issued (nrq_decode_plan_ahead) */
+  uint32_t strip_bytes_b, blocks_b; /* the batch's SECOND block list: blocks whose LDS image does not fit at strip_bytes run in a launch
+                                     * of their own at this narrower width (0 / 0: one list) */
 } nrq_call_stats;
 
 /* One context per GPU (one process per GPU: no cross-device state).  `stream` is a hipStream_t the

@@ -18,7 +18,7 @@ class CallStats(C.Structure):
                 ("plan_bytes", C.c_uint64), ("xor_ops", C.c_uint64), ("npiv", C.c_uint32), ("u", C.c_uint32),
                 ("nlev", C.c_uint32), ("nfree", C.c_uint32), ("wg_threads", C.c_uint32), ("strips_per_slot", C.c_uint32),
                 ("wg_waves_per_simd", C.c_uint32), ("host_planned", C.c_uint32), ("movers_aligned", C.c_uint32),
-                ("plan_ahead", C.c_uint32)]
+                ("plan_ahead", C.c_uint32), ("strip_bytes_b", C.c_uint32), ("blocks_b", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

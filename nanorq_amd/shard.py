@@ -113,6 +113,11 @@ def gpu_cpu_lists(sysfs="/sys"):
             out.append((node, cpus))
         except (OSError, ValueError):
             out.append((-1, []))
+    # a container that is given some of a node's GPUs still sees every KFD node, but only its own GPUs' PCI directories: the
+    # devices the runtime numbers 0, 1, ... are then the nodes whose directories exist, in order (seen on the 1-GPU test boxes:
+    # eight nodes, the fourth one valid, and that one is HIP device 0)
+    if any(c for _, c in out) and not all(c for _, c in out):
+        out = [g for g in out if g[1]]
     return out
 
 

@@ -686,3 +686,40 @@ def test_decode_plan_issued_ahead(G, orc):
             c.free(d)
     finally:
         c.free(d_src); c.free(d_rep)
+
+
+def test_block_lists_per_launch(G, orc):
+    """A launch runs at one strip width, and the widest width a block can have is set by ITS plan (inactive columns grow the LDS
+    image).  A batch whose blocks do not all fit the widest width is solved as TWO lists (pick_and_launch): the blocks that fit,
+    in place at the wide width -- the kernel leaves the others out -- and the others side by side at the widest width they fit.
+    Here: K=8192 blocks with loss growing from 10 % to 60 % over the batch, so that some plans outgrow the 16-byte image.  Every
+    block must come back bit-exact (and equal to what ONE launch at the narrow width gives: "no_lists"), one block per list is
+    compared with the oracle, and the statistics must show both lists.  Reference: lib/precode.c:176-203 (u grows with the
+    loss), :15-32 (the replay every width computes)."""
+    c = G.ctx()
+    K, T, nblk = 8192, 32, 32
+    rng = np.random.default_rng(77)
+    src = rng.integers(0, 256, (nblk, K, T), dtype=np.uint8)
+    lost = [loss_pattern(K, 0.10 + 0.5 * b / nblk, seed=11, block=b) for b in range(nblk)]
+    nrep = max(len(x) for x in lost) + 2
+    esis = np.arange(K, K + nrep, dtype=np.uint32)
+    rep, _ = G.gpu_encode(src, K, T, esis)
+    work = src.copy()
+    for b in range(nblk):
+        work[b][lost[b]] = 0xEE
+    args = (work, K, T, lost, [esis[:len(l) + 2] for l in lost], [rep[b][:len(lost[b]) + 2] for b in range(nblk)])
+    st, out, _ = G.gpu_decode(*args)
+    s = c.stats()
+    assert st.all() and np.array_equal(out, src)
+    assert s["strip_bytes"] == 16 and s["strip_bytes_b"] == 8 and 0 < s["blocks_b"] < nblk, s
+    try:
+        c.set_option("no_lists", 1)
+        st1, out1, _ = G.gpu_decode(*args)
+        s1 = c.stats()
+    finally:
+        c.set_option("no_lists", 0)
+    assert s1["strip_bytes"] == 8 and s1["blocks_b"] == 0 and st1.all() and np.array_equal(out1, out)
+    for b in (0, nblk - 1):   # the oracle on the sparsest and the heaviest reception
+        keep = np.setdiff1d(np.arange(K, dtype=np.uint32), lost[b])
+        ok, ref, _ = orc.decode_block(np.concatenate([keep, esis[:len(lost[b]) + 2]]), np.concatenate([src[b][keep], rep[b][:len(lost[b]) + 2]]), K, T)
+        assert ok and np.array_equal(out[b], ref)

@@ -160,3 +160,14 @@ def test_eight_rank_job_gives_the_one_rank_digests(tmp_path):
     for r in recs:
         merged.update(r["digests"])
     assert merged == json.load(open(d1 / "rank0.json"))["digests"] and len(merged) == total
+
+
+def test_a_container_with_some_of_the_nodes_gpus(tmp_path):
+    """Eight KFD nodes, the PCI directory of one (what a 1-GPU slice of an 8-GPU node shows): that one is HIP device 0."""
+    _fake_sysfs(tmp_path, [(0, "0-63")] * 3 + [(1, "64-127")] + [(0, "0-63")] * 4)
+    import shutil
+    for i in (0, 1, 2, 4, 5, 6, 7):
+        shutil.rmtree(tmp_path / "bus/pci/devices" / ("0000:%02x:00.0" % (0x10 + i)))
+    gpus = shard.gpu_cpu_lists(str(tmp_path))
+    assert gpus == [(1, list(range(64, 128)))]
+    assert shard.rank_cpus(2, allowed=range(128), gpus=gpus, device_of_rank=[0, 0]) == [list(range(64, 96)), list(range(96, 128))]
