@@ -547,6 +547,9 @@ def main():
             return r.sum(dtype=torch.int64)
         return torch.stack([dg(t, ix) for t, ix in ((rep_rows_all, ph_rep[ph]), (int_rows_all, ph_int[ph]), (wrows, ph_wrk[ph]))])
 
+    # strip widths of the decode launches: a batch whose blocks do not all fit the widest strip runs as two block lists
+    lists = {"launches": 0, "second_list_launches": 0, "second_list_blocks": 0, "widths": {}}
+
     def pat_of(n):
         return (n % NPHASE) % NPAT
 
@@ -582,6 +585,11 @@ def main():
             st, used = c_.decode_blocks_lazy(K, T, n_, work[lo].data_ptr(), K * T, lost_arr[lo:hi], nlost[lo:hi], resi[lo:hi],
                                              nr_first[lo:hi], nr_avail[lo:hi], rep[lo].data_ptr(), nrep * T)
             dec_stats = dec_stats or c_.stats()
+            ds_ = c_.stats()
+            lists["launches"] += 1
+            lists["second_list_launches"] += 1 if ds_.get("blocks_b") else 0
+            lists["second_list_blocks"] += ds_.get("blocks_b", 0)
+            lists["widths"][str(ds_["strip_bytes"])] = lists["widths"].get(str(ds_["strip_bytes"]), 0) + 1
             if not st.all():
                 raise RuntimeError("decode failed for %d blocks" % int((st == 0).sum()))
             retries += int((used - nr_first[lo:hi]).sum())
@@ -617,6 +625,7 @@ def main():
         step()
     barrier()
     retries = 0
+    lists.update({"launches": 0, "second_list_launches": 0, "second_list_blocks": 0, "widths": {}})
     digests.clear()   # (step_no runs on: the planner runs issued ahead in the warm-up are those of the first timed steps' patterns)
     for c_ in ctxs:
         c_.ktime_enable(True)
@@ -830,6 +839,7 @@ def main():
                                                 nrep),
                        "K": K, "T": T, "blocks_per_gpu": NB, "loss": args.loss, "overhead": args.overhead,
                        "reception_patterns": NPAT,
+                       "decode_launch_widths": lists,   # {strip bytes of the (first) list: launches}; second lists = blocks whose image needs a narrower strip
                        "repair_per_block": nrep, "sharding": "blocks over GPUs, no collective",
                        "streams_per_gpu": nstreams,
                        "encode_plan": "cached" if args.no_replan else "rebuilt every step",

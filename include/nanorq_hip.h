@@ -61,7 +61,8 @@ int nrq_ctx_set_planner(nrq_ctx *ctx, int device_planner);
 /* Tuning / test knobs of the launch path (the NRQ_* environment variables read at nrq_ctx_create set the same
  * fields): "max_wb" widest column strip considered (16/8/4/2), "no_split", "no_balance", "no_plan_stream",
  * "reserve_cus", "solve_grid", "big_wg", "map_spread", "no_tiny", "tiny_div", "wide_g", "small_waves4", "no_plan_split",
- * "plan_split_force", "plan_small_state", "plan_big_wg", "encplan_dev_min_l", "plan_ucap" (inactive columns the device
+ * "plan_split_force", "plan_small_state", "plan_big_wg", "encplan_dev_min_l", "no_lists" (one solve launch per batch at the width every block fits, no second block list), "lds_max" (tests: LDS bytes a strip
+ * image may take when the block lists are formed), "plan_ucap" (inactive columns the device
  * planner has room for; a block that needs more is re-planned on the host).  Results never depend on them, only speed.
  * Fault injection for tests: "fail_after" n -- the n-th checked runtime call of the context from now on (allocation, copy,
  * event / stream operation, the error check behind a launch) is not made and fails instead, once (0 = off);

@@ -1010,6 +1010,7 @@ struct Tuning {
                               * the 256-thread workgroups, decode 11.1 against 7.4 ms per 2048 blocks; at seven, K=700, they win 5.2 : 6.2.) */
   bool no_split = false;     /* NRQ_NO_SPLIT: narrow strips also do their back-substitution in the solve kernel */
   bool no_balance = false;   /* NRQ_NO_BALANCE: keep whole-line work slots even when the rounds come out uneven */
+  uint32_t lds_max = NRQ_LDS_MAX; /* "lds_max" (tests): LDS bytes a strip image may take when the batch's block lists are formed (pick_and_launch) */
   bool no_lists = false;     /* NRQ_NO_LISTS: one solve launch per batch at the width EVERY block fits (round 5), no second list */
   int reserve_cus = -1;      /* NRQ_RESERVE_CUS: compute units a big-block solve launch leaves to the planner (-1 = automatic) */
   bool plan_small_state = true;  /* NRQ_PLAN_BIG_STATE clears it: small blocks' planner workgroups keep the full-size queues */
@@ -1759,7 +1760,7 @@ static uint32_t widest_fit(const nrq_ctx *ctx, const nrq_plan_hdr *h, uint32_t *
   for (int s = 0; s < 4; s++) {
     if (widths[s] > ctx->tune.max_wb) continue;
     const uint32_t t = nrq_lds_plan(h, widths[s]).total;
-    if (t <= NRQ_LDS_MAX) { *need = t; return widths[s]; }
+    if (t <= ctx->tune.lds_max) { *need = t; return widths[s]; }
   }
   *need = 0;
   return 0;
@@ -2032,6 +2033,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "tiny_div_dec") t.tiny_div_dec = (uint32_t)value;
   else if (n == "no_balance") t.no_balance = value != 0;
   else if (n == "no_lists") t.no_lists = value != 0;
+  else if (n == "lds_max") t.lds_max = value > 0 && value <= (long long)NRQ_LDS_MAX ? (uint32_t)value : NRQ_LDS_MAX;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
   else if (n == "no_plan_split") t.no_plan_split = value != 0;
   else if (n == "plan_split_force") t.plan_split_force = value != 0;
