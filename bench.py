@@ -155,6 +155,29 @@ def cpu_baseline(args, src_np, lost_np, nrep_enc):
         t_enc += t1 - t0
         balg_enc += algorithmic_bytes(st_e, K, T, prm["L"], K, st_e["gen_rows"])
         balg_dec += algorithmic_bytes(st_d, K, T, prm["L"], K + st_d["overhead"], st_d["gen_rows"])
+    # the same sample once more with the AVX-512 + GFNI row kernels where the host has them (oracle/rq_oracle.c row_axpy_gfni: an
+    # affine bit matrix per constant -- GFNI's own multiply is fixed to the AES polynomial); reported beside the AVX2 figure
+    gfni = None
+    if n > 0 and getattr(oracle, "has_gfni", lambda: False)():
+        g_enc = g_dec = 0.0
+        oracle.set_simd(2)
+        try:
+            for b in range(n):
+                t0 = time.perf_counter()
+                rep_g, _, _ = oracle.encode_block(src_np[b], K, T, esis)
+                g_enc += time.perf_counter() - t0
+                keep = np.setdiff1d(np.arange(K, dtype=np.uint32), lost_np[b])
+                nr, ok = len(lost_np[b]) + args.overhead, False
+                while not ok:
+                    t2 = time.perf_counter()
+                    ok, out_g, _ = oracle.decode_block(np.concatenate([keep, esis[:nr]]), np.concatenate([src_np[b][keep], rep_g[:nr]]), K, T)
+                    g_dec += time.perf_counter() - t2
+                    nr += 1
+                assert np.array_equal(out_g, src_np[b])
+        finally:
+            oracle.set_simd(1)
+        gfni = {"value": 8.0 * n * K * T / (g_enc + g_dec) / 1e9, "unit": "Gbit/s", "cores": 1, "isa": "AVX-512 + GFNI (vgf2p8affineqb, 64 bytes per instruction)",
+                "encode_gbps": 8.0 * n * K * T / g_enc / 1e9, "decode_gbps": 8.0 * n * K * T / g_dec / 1e9}
     # the GPU side amortises ONE encode plan over the step's blocks (the reference's "precalc" column, benchmark.c:95-96):
     # the same on the CPU -- the schedule of the first block is kept and replayed on the others (oracle.encode_block_cached)
     t_pre = None
@@ -204,6 +227,7 @@ def cpu_baseline(args, src_np, lost_np, nrep_enc):
                      "what": "encode with the schedule of the first block replayed on the others (plan amortised over the "
                              "blocks, as on the GPU side: reference 'precalc' column, benchmark.c:95-96, :210); decode as above"}
                     if t_pre else None),
+        "isa": "AVX2 (split-nibble vpshufb)" if oracle.has_avx2() else "scalar log/antilog", "gfni": gfni,
         "host_cpu": _cpu_model(), "host_threads": os.cpu_count(), "all_cores": allc,
     }, balg_enc / n, balg_dec / n
 
@@ -253,7 +277,11 @@ def pmc_collect(args):
     try:
         for i, grp in enumerate(PMC_PASSES):
             d = os.path.join(tmp, "p%d" % i)
-            rc = _run_group([exe, "--pmc", *grp, "-d", d, "--"] + inner, "/tmp", env, 240)
+            # (the SQ pass also records the kernel trace -- allowed beside --pmc, unlike the API / copy traces -- so that the
+            # counters and the duration they are divided by come from the SAME run: under the profiler kernels run one at a
+            # time, while in the timed region planner runs issued ahead execute beside the solve)
+            ktrace = ["--kernel-trace"] if "SQ_BUSY_CYCLES" in grp else []
+            rc = _run_group([exe, *ktrace, "--pmc", *grp, "-d", d, "--"] + inner, "/tmp", env, 240)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")] if os.path.isdir(d) else []
             if rc != 0 or not dbs:
                 return None, "rocprofv3 pass %s failed (rc %s)" % (grp, rc)
@@ -261,6 +289,16 @@ def pmc_collect(args):
             for path in dbs:
                 db = sqlite3.connect(path)
                 rows += db.execute("select kernel_name, grid_size, counter_name, value from counters_collection").fetchall()
+                if ktrace:
+                    try:
+                        kr = [r for r in db.execute("select name, grid_x, duration from kernels order by start").fetchall() if "nrq_solve_kernel" in r[0]]
+                        gx = max(r[1] for r in kr) if kr else 0
+                        du = [r[2] / 1e6 for r in kr if r[1] == gx]
+                        du = du[2:] if len(du) > 3 else du          # (the warm-up step's pair is cold)
+                        if du:
+                            out["_serialized_ms"] = sum(du) / len(du)
+                    except sqlite3.Error:
+                        pass
                 db.close()
             rows = [r for r in rows if "nrq_solve_kernel" in r[0]]
             if not rows:
@@ -793,9 +831,16 @@ def main():
                 # of this kernel is one -- so it is doubled; WRITE_SIZE is taken as reported
                 traffic_raw = counters["FETCH_SIZE"] + counters["WRITE_SIZE"]
                 traffic = 2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]
-            bind = binding_model(counters, avg_ms, torch.cuda.get_device_properties(dev).multi_processor_count)
+            # utilisations are counters over a duration: both from the profiled (serialized) run when it recorded one
+            ser_ms = (counters or {}).get("_serialized_ms")
+            bind_ms = ser_ms or avg_ms
+            bind = binding_model(counters, bind_ms, torch.cuda.get_device_properties(dev).multi_processor_count)
             if bind is not None and traffic:
-                bind["hbm_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                bind["hbm_frac"] = traffic / (bind_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if bind is not None:
+                bind["duration_ms_used"] = bind_ms
+                bind["duration_source"] = ("kernel trace of the counter pass (kernels one at a time)" if ser_ms else
+                                           "HIP events of the timed region (no trace in the counter pass)")
             if bind is not None:
                 cand = {k: bind[k] for k in ("lds_frac", "issue_frac", "hbm_frac") if bind.get(k) is not None}
                 bind["nearest"] = max(cand, key=cand.get) if cand else None
@@ -804,7 +849,13 @@ def main():
             bound = {"lds_frac": "lds", "issue_frac": "valu_issue", "hbm_frac": "hbm"}.get((bind or {}).get("nearest"), "lds")
             roof = {"bound": bound, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
                     "traffic_as_reported": traffic_raw,
-                    "frac_physical": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "frac_physical": (traffic / (bind_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    # the fractions that say what the kernel is bound by, first class: the LDS pipeline of an LDS-resident solver
+                    "lds": ({"busy_frac": bind.get("lds_frac"), "conflict_share": bind.get("lds_bank_conflict_share"),
+                             "useful_frac": (bind["lds_frac"] * (1.0 - bind["lds_bank_conflict_share"])
+                                             if bind.get("lds_frac") is not None and bind.get("lds_bank_conflict_share") is not None else None)}
+                            if bind else None),
+                    "avg_launch_ms_serialized": ser_ms, "avg_launch_ms_corunning": avg_ms,
                     "kernel": "nrq_solve_kernel<%d, %d, %d>" % (enc_stats["strip_bytes"], enc_stats["wg_threads"], enc_stats["wg_waves_per_simd"]),
                     "avg_launch_ms": avg_ms, "busy_ms_per_launch": eff_ms, "launches_timed": len(ktimes),
                     "blocks_per_launch": blocks_per_launch,
@@ -823,7 +874,9 @@ def main():
                              "work_rate": {"value": achieved, "unit": "GB/s of reference-equivalent row traffic (SURVEY 8d)",
                                            "over_hbm_peak": achieved / HBM_PEAK_GBS},
                              "algorithmic_bytes_per_block": {"encode": balg_enc, "decode": balg_dec},
-                             "note": "achieved/frac (= work_rate) = reference-equivalent row traffic (SURVEY 8d) over the launch "
+                             "note": "`bound` names the PHYSICAL resource nearest to saturation by the counters (lds = roofline.lds.busy_frac, "
+                                     "valu_issue = binding.issue_frac, hbm = frac_physical); peak / frac are SURVEY 8(d)'s convention: "
+                                     "achieved/frac (= work_rate) = reference-equivalent row traffic (SURVEY 8d) over the launch "
                                      "duration: a work rate, not an HBM utilisation (the strip solver keeps rows in LDS, so it "
                                      "exceeds 1); `bound` names the resource nearest to saturation, `frac_physical` the physical HBM "
                                      "traffic (FETCH_SIZE doubled as the guide prescribes) over duration x 8 TB/s; all utilisations "

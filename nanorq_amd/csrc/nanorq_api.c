@@ -27,6 +27,7 @@
  */
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -169,7 +170,12 @@ static nrq_ctx *dctx(int di) { return di < ndev() ? g_dev[di].c : NULL; }
 static void gpu_lock(int di) { pthread_mutex_lock(&g_dev[di].lock); }
 static void gpu_unlock(int di) { pthread_mutex_unlock(&g_dev[di].lock); }
 size_t nanorq_devices(void) { return (size_t)ndev(); }
+/* object-layer switches of nanorq_hip_option (not the context's): threads that book a packet batch, and from how many symbols on */
+static int g_book_threads = -1;        /* -1: NANORQ_HIP_BOOK_THREADS, else half the cores this process may use, at most 8 */
+static uint32_t g_book_min = 65536u;
 int nanorq_hip_option(size_t dev, const char *name, long long value) {
+  if (name && !strcmp(name, "book_threads")) { g_book_threads = value > 0 ? (int)(value > 8 ? 8 : value) : -1; return 0; }
+  if (name && !strcmp(name, "book_min")) { g_book_min = value > 0 ? (uint32_t)value : 65536u; return 0; }
   if (dev >= (size_t)ndev()) return -1;
   gpu_lock((int)dev);
   const int rc = nrq_ctx_set_option(g_dev[dev].c, name, value);
@@ -1515,6 +1521,81 @@ static void *add_all_worker(void *arg) {
   j->ok = ok;
   return NULL;
 }
+/* bookkeeping of a packet batch (add_symbols_impl), the blocks sbn mod P == t */
+#define NRQ_BOOK_THREADS 8u
+struct book_job {
+  nanorq *rq;
+  const uint8_t *p;
+  const uint32_t *tags;
+  uint32_t n;
+  int *results;
+  struct ioctx *io;
+  uint32_t *rix;
+  size_t *nrep0;
+  uint8_t *touched, *newdev;
+  bool early;
+  unsigned t, P;
+  size_t added;
+};
+static unsigned book_threads(void) {
+  static int n = -1;
+  if (g_book_threads > 0) return (unsigned)g_book_threads;
+  if (n < 0) {
+    const char *e = getenv("NANORQ_HIP_BOOK_THREADS");
+    long v = e && *e ? atol(e) : 0;
+    if (v <= 0) {
+      cpu_set_t set;
+      v = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) / 2 : 1; /* (the cores this process may use: a rank of N has its slice) */
+    }
+    n = v < 1 ? 1 : v > (long)NRQ_BOOK_THREADS ? (int)NRQ_BOOK_THREADS : (int)v;
+  }
+  return (unsigned)n;
+}
+static void *book_worker(void *arg) {
+  struct book_job *j = arg;
+  nanorq *rq = j->rq;
+  const size_t T = rq->T;
+  for (uint32_t k = 0; k < j->n; k++) {
+    const uint8_t sbn = (uint8_t)(j->tags[k] >> 24);
+    if (j->P > 1 && sbn % j->P != j->t) continue;
+    const uint32_t esi = j->tags[k] & 0x00ffffffu;
+    struct blockst *b = get_block(rq, sbn);
+    int r = NANORQ_SYM_ADDED;
+    j->rix[k] = RIX_NONE;
+    if (!b || esi > rq->max_esi) r = NANORQ_SYM_ERR;
+    else if (mask_gaps(b, b->K) == 0) r = NANORQ_SYM_IGN;
+    else if (mask_get(b, esi)) r = NANORQ_SYM_DUP;
+    else if (!b->dev && (b->have || b->nrep)) {
+      /* the block already holds symbols on the host (per-symbol calls came first): it stays host-resident */
+      r = j->P > 1 ? NANORQ_SYM_ERR /* (cannot happen: such an object is booked by one thread) */
+                   : nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(j->p + (size_t)k * T), j->tags[k], j->io);
+    } else {
+      if (!b->dev) { /* first symbol of the block: it becomes device-resident */
+        nrq_ctx *c = dctx(b->di);
+        gpu_lock(b->di);
+        if (!b->d_src && nrq_dev_alloc(c, (size_t)b->K * T, &b->d_src) != 0) r = NANORQ_SYM_ERR;
+        else if (nrq_memset_on(c, j->early ? 3 : 1, b->d_src, 0, (size_t)b->K * T) != 0) r = NANORQ_SYM_ERR; /* (in front of the sort into rows) */
+        else { b->dev = true; j->newdev[sbn] = 1; }
+        gpu_unlock(b->di);
+      }
+      if (r == NANORQ_SYM_ADDED && !j->touched[sbn]) { j->touched[sbn] = 1; j->nrep0[sbn] = b->nrep; }
+      if (r == NANORQ_SYM_ADDED && esi < b->K) {
+        j->rix[k] = RIX_SRC;
+      } else if (r == NANORQ_SYM_ADDED) {
+        if (!rep_reserve_host(rq, b)) r = NANORQ_SYM_ERR;
+        else {
+          j->rix[k] = (uint32_t)b->nrep;
+          b->rep_esi[b->nrep++] = esi;
+        }
+      }
+      if (r == NANORQ_SYM_ADDED) mask_set(b, esi);
+    }
+    if (j->results) j->results[k] = r;
+    if (r == NANORQ_SYM_ADDED) j->added++;
+  }
+  return NULL;
+}
+
 static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io, bool deferred) {
   size_t added = 0;
   const uint8_t *p = data;
@@ -1569,48 +1650,38 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
   uint8_t touched[NRQ_Z_MAX], newdev[NRQ_Z_MAX];
   memset(touched, 0, sizeof(touched));
   memset(newdev, 0, sizeof(newdev));
-  uint32_t nput = 0;
-  for (uint32_t k = 0; k < n; k++) {
-    const uint8_t sbn = (uint8_t)(tags[k] >> 24);
-    const uint32_t esi = tags[k] & 0x00ffffffu;
-    struct blockst *b = get_block(rq, sbn);
-    int r = NANORQ_SYM_ADDED;
-    rix[k] = RIX_NONE;
-    if (!b || esi > rq->max_esi) r = NANORQ_SYM_ERR;
-    else if (mask_gaps(b, b->K) == 0) r = NANORQ_SYM_IGN;
-    else if (mask_get(b, esi)) r = NANORQ_SYM_DUP;
-    else if (!b->dev && (b->have || b->nrep)) {
-      /* the block already holds symbols on the host (per-symbol calls came first): it stays host-resident */
-      r = nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(p + (size_t)k * T), tags[k], io);
-    } else {
-      if (!b->dev) { /* first symbol of the block: it becomes device-resident */
-        nrq_ctx *c = dctx(b->di);
-        gpu_lock(b->di);
-        if (!b->d_src && nrq_dev_alloc(c, (size_t)b->K * T, &b->d_src) != 0) r = NANORQ_SYM_ERR;
-        else if (nrq_memset_on(c, early_blob ? 3 : 1, b->d_src, 0, (size_t)b->K * T) != 0) r = NANORQ_SYM_ERR; /* (in front of the sort into rows) */
-        else { b->dev = true; newdev[sbn] = 1; }
-        gpu_unlock(b->di);
-      }
-      if (r == NANORQ_SYM_ADDED && !touched[sbn]) { touched[sbn] = 1; nrep0[sbn] = b->nrep; }
-      if (r == NANORQ_SYM_ADDED && esi < b->K) {
-        rix[k] = RIX_SRC;
-      } else if (r == NANORQ_SYM_ADDED) {
-        if (!rep_reserve_host(rq, b)) r = NANORQ_SYM_ERR;
-        else {
-          rix[k] = (uint32_t)b->nrep;
-          b->rep_esi[b->nrep++] = esi;
-        }
-      }
-      if (r == NANORQ_SYM_ADDED) { mask_set(b, esi); nput++; }
+  /* The bookkeeping of a symbol depends on the earlier symbols of ITS BLOCK only (bitmap, repair list, "block complete"): a big
+   * batch is booked by several threads, thread t the blocks sbn mod P == t, every thread walking all tags in order -- a million
+   * symbols took one thread ~7 ms, which a receiver's downloads had to wait out (they start behind the planner run, which needs the
+   * pattern).  Not when some block of the object is host-resident with symbols in it: those go through the per-symbol call and the
+   * output context, which has one cursor. */
+  struct book_job bj[NRQ_BOOK_THREADS];
+  unsigned P = 1;
+  if (n >= g_book_min) {
+    P = book_threads();
+    for (unsigned sbn = 0; sbn < NRQ_Z_MAX && P > 1; sbn++) {
+      const struct blockst *b = rq->blocks[sbn];
+      if (b && !b->dev && (b->have || b->nrep)) P = 1;
     }
-    if (results) results[k] = r;
-    if (r == NANORQ_SYM_ADDED) added++;
   }
+  pthread_t bth[NRQ_BOOK_THREADS];
+  bool bstarted[NRQ_BOOK_THREADS];
+  for (unsigned t = 0; t < P; t++) {
+    bj[t] = (struct book_job){.rq = rq, .p = p, .tags = tags, .n = n, .results = results, .io = io, .rix = rix, .nrep0 = nrep0, .touched = touched,
+                              .newdev = newdev, .early = early_blob != NULL, .t = t, .P = P, .added = 0};
+    bstarted[t] = false;
+  }
+  for (unsigned t = 1; t < P; t++) bstarted[t] = pthread_create(&bth[t], NULL, book_worker, &bj[t]) == 0;
+  book_worker(&bj[0]);
+  for (unsigned t = 1; t < P; t++) {
+    if (bstarted[t]) pthread_join(bth[t], NULL);
+    else book_worker(&bj[t]); /* (no thread to be had: one after the other) */
+  }
+  for (unsigned t = 0; t < P; t++) added += bj[t].added;
   struct all_job j;
   memset(&j, 0, sizeof(j));
   j.rq = rq; j.io = io; j.pk = p; j.tags = tags; j.rix = rix; j.n = n; j.nrep0 = nrep0; j.touched = touched; j.deferred = deferred;
   j.early_blob = early_blob; j.early_piece = early_piece; j.early_ev0 = early_ev0;
-  (void)nput;
   for_devices(add_all_worker, &j, ndev()); /* (also with nothing to put: the memsets of new blocks are waited for) */
   if (!j.ok) {
     /* The bytes did not reach the device rows: take the batch's bookkeeping back, so that the decoder does not believe in

@@ -45,6 +45,9 @@
       PL_STEER_SYNC; /* (pl_round_claim lowers nV and may raise status) */
       PL_ST(c, 2);
       if (st_ != 0 || nv_ == 0 || rd_ >= guard_max) break;
+#ifdef PL_TRACE_ROUND
+      PL_TRACE_ROUND(nq_, nv_); /* (the emulator's trace of the peel: frontier width and open columns, round by round) */
+#endif
       if (PL_LIKELY(nq_ > 0)) {
         PL_PHASE1_CLAIM(pl_round_claim, rd_);
         PL_ST(c, 8);

@@ -106,6 +106,11 @@ def has_avx2():
     return bool(lib().orc_has_avx2())
 
 
+def has_gfni():
+    """AVX-512 + GFNI on this host: set_simd(2) then runs the row kernels as vgf2p8affineqb (one instruction per 64 bytes)."""
+    return bool(lib().orc_has_gfni())
+
+
 def row_axpy(dst, src, beta):
     lib().orc_row_axpy(_u8(dst), _u8(src), dst.size, beta)
 

@@ -136,6 +136,9 @@ static uint8_t GF_LO[256][16], GF_HI[256][16]; /* split-nibble product tables fo
 static int gf_ready = 0;
 static int simd_mode = 1; /* 1: use AVX2 when the CPU has it */
 
+#if defined(__x86_64__)
+static void gf_aff_init(void);
+#endif
 static void gf_init(void) {
   if (gf_ready) return;
   uint32_t x = 1;
@@ -156,6 +159,9 @@ static void gf_init(void) {
       GF_HI[c][n] = (c && hi) ? GF_EXP[GF_LOG[c] + GF_LOG[hi]] : 0;
     }
   gf_ready = 1;
+#if defined(__x86_64__)
+  gf_aff_init();
+#endif
 }
 
 static inline uint8_t gf_mul(uint8_t a, uint8_t b) {
@@ -226,14 +232,66 @@ __attribute__((target("avx2"))) static void row_scal_avx2(uint8_t *dst, size_t n
   for (; k < n; k++) dst[k] = gf_mul(beta, dst[k]);
 }
 static int have_avx2(void) { return __builtin_cpu_supports("avx2"); }
+
+/* AVX-512 + GFNI: one vgf2p8affineqb per 64 bytes.  GFNI's own multiply (vgf2p8mulb) is fixed to the AES polynomial 0x11B;
+ * RFC 6330's field is 0x11D, so multiplication by a constant beta is done as the GF(2)-linear map it is: an 8x8 bit matrix
+ * per beta (column j = beta * x^j), applied to every byte by the affine instruction.  SURVEY.md section 7 step 2 asked for GFNI
+ * where the host has it (the GPU boxes' EPYC 9575F does); simd_mode 2 selects it. */
+static uint64_t GF_AFF[256]; /* matrix of y = beta * x in vgf2p8affineqb's layout */
+static int gf_aff_ready = 0;
+static void gf_aff_init(void) {
+  if (gf_aff_ready) return;
+  for (int c = 0; c < 256; c++) {
+    /* result bit i = parity(A.byte[7 - i] & x): byte 7-i holds, at bit j, bit i of c * x^j */
+    uint64_t m = 0;
+    for (int i = 0; i < 8; i++) {
+      uint8_t row = 0;
+      for (int j = 0; j < 8; j++)
+        if ((gf_mul((uint8_t)c, (uint8_t)(1u << j)) >> i) & 1u) row |= (uint8_t)(1u << j);
+      m |= (uint64_t)row << (8 * (7 - i));
+    }
+    GF_AFF[c] = m;
+  }
+  gf_aff_ready = 1;
+}
+__attribute__((target("avx512f,avx512bw,gfni"))) static void row_xor_avx512(uint8_t *dst, const uint8_t *src, size_t n) {
+  size_t k = 0;
+  for (; k + 64 <= n; k += 64)
+    _mm512_storeu_si512((void *)(dst + k), _mm512_xor_si512(_mm512_loadu_si512((const void *)(dst + k)), _mm512_loadu_si512((const void *)(src + k))));
+  for (; k < n; k++) dst[k] ^= src[k];
+}
+__attribute__((target("avx512f,avx512bw,gfni"))) static void row_axpy_gfni(uint8_t *dst, const uint8_t *src, size_t n, uint8_t beta) {
+  const __m512i a = _mm512_set1_epi64((long long)GF_AFF[beta]);
+  size_t k = 0;
+  for (; k + 64 <= n; k += 64) {
+    const __m512i p = _mm512_gf2p8affine_epi64_epi8(_mm512_loadu_si512((const void *)(src + k)), a, 0);
+    _mm512_storeu_si512((void *)(dst + k), _mm512_xor_si512(_mm512_loadu_si512((const void *)(dst + k)), p));
+  }
+  for (; k < n; k++) dst[k] ^= gf_mul(beta, src[k]);
+}
+__attribute__((target("avx512f,avx512bw,gfni"))) static void row_scal_gfni(uint8_t *dst, size_t n, uint8_t beta) {
+  const __m512i a = _mm512_set1_epi64((long long)GF_AFF[beta]);
+  size_t k = 0;
+  for (; k + 64 <= n; k += 64)
+    _mm512_storeu_si512((void *)(dst + k), _mm512_gf2p8affine_epi64_epi8(_mm512_loadu_si512((const void *)(dst + k)), a, 0));
+  for (; k < n; k++) dst[k] = gf_mul(beta, dst[k]);
+}
+static int have_gfni(void) {
+  return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("gfni");
+}
 #else
 static int have_avx2(void) { return 0; }
+static int have_gfni(void) { return 0; }
 #endif
 
 /* dst ^= beta * src  (oaxpy contract) */
 static void row_axpy(uint8_t *dst, const uint8_t *src, size_t n, uint8_t beta) {
   if (beta == 0) return;
 #if defined(__x86_64__)
+  if (simd_mode == 2 && have_gfni()) {
+    if (beta == 1) row_xor_avx512(dst, src, n); else row_axpy_gfni(dst, src, n, beta);
+    return;
+  }
   if (simd_mode && have_avx2()) {
     if (beta == 1) row_xor_avx2(dst, src, n); else row_axpy_avx2(dst, src, n, beta);
     return;
@@ -246,6 +304,7 @@ static void row_axpy(uint8_t *dst, const uint8_t *src, size_t n, uint8_t beta) {
 static void row_scal(uint8_t *dst, size_t n, uint8_t beta) {
   if (beta == 1) return;
 #if defined(__x86_64__)
+  if (simd_mode == 2 && have_gfni()) { row_scal_gfni(dst, n, beta); return; }
   if (simd_mode && have_avx2()) { row_scal_avx2(dst, n, beta); return; }
 #endif
   row_scal_scalar(dst, n, beta);
@@ -647,8 +706,9 @@ static uint32_t lt_symbol(const orc_params_t *p, const uint8_t *C, size_t ldc, s
 /* ------------------------------------------------------------------------------------------
  * Exported entry points (ctypes)
  * ---------------------------------------------------------------------------------------- */
-void orc_set_simd(int on) { simd_mode = on; }
+void orc_set_simd(int on) { simd_mode = on; } /* 0 scalar, 1 AVX2 split-nibble vpshufb, 2 AVX-512 + GFNI affine (falls back to 1 / 0 without the ISA) */
 int orc_has_avx2(void) { return have_avx2(); }
+int orc_has_gfni(void) { return have_gfni(); }
 
 int orc_params(uint32_t K, uint32_t out[10]) {
   orc_params_t p;

@@ -42,6 +42,16 @@ static void emu_sabotage(PlanCtx &c) {
   }
 }
 #define PL_SABOTAGE_HOOK emu_sabotage(c)
+/* trace of the peel for tools/peel_trace.py: frontier width (rows with one V column) and open columns of every round */
+static std::vector<uint32_t> g_trace;
+static uint32_t g_trace_on = 0;
+extern "C" void emu_plan_trace(uint32_t on) { g_trace_on = on; g_trace.clear(); }
+extern "C" uint32_t emu_plan_trace_read(uint32_t *out, uint32_t cap) {
+  const uint32_t n = (uint32_t)g_trace.size() < cap ? (uint32_t)g_trace.size() : cap;
+  for (uint32_t i = 0; i < n; i++) out[i] = g_trace[i];
+  return (uint32_t)g_trace.size();
+}
+#define PL_TRACE_ROUND(nq, nv) do { if (g_trace_on) { g_trace.push_back(nq); g_trace.push_back(nv); } } while (0)
 
 extern "C" uint32_t emu_plan_arena_bound(uint32_t K, const uint8_t *kc, uint32_t overhead_cap, uint32_t nlost_cap) {
   const nrq_kconst_hdr *kh = reinterpret_cast<const nrq_kconst_hdr *>(kc);

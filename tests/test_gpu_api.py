@@ -592,12 +592,27 @@ def test_bench_one_object_tool_on_one_gpu():
     assert rec["ok"] and rec["devices"] == 2 and rec["blocks"] == 5 and rec["value"] > 0
 
 
+@pytest.fixture
+def book_threads(request):
+    """threads that book a packet batch (nanorq_api.c book_worker: thread t the blocks sbn mod P == t), from the first symbol on"""
+    L = api()
+    L.nanorq_hip_option.restype = C.c_int
+    L.nanorq_hip_option.argtypes = [C.c_size_t, C.c_char_p, C.c_longlong]
+    assert L.nanorq_hip_option(0, b"book_threads", request.param) == 0 and L.nanorq_hip_option(0, b"book_min", 1) == 0
+    yield request.param
+    L.nanorq_hip_option(0, b"book_threads", 0)
+    L.nanorq_hip_option(0, b"book_min", 0)
+
+
+@pytest.mark.parametrize("book_threads", [1, 4], indirect=True)
 @pytest.mark.parametrize("shuffle", [False, True])
-def test_deferred_ingestion_gives_the_same_object(shuffle):
+def test_deferred_ingestion_gives_the_same_object(shuffle, book_threads):
     """nanorq_decoder_add_symbols_async: result codes and counts final on return, the bytes travel afterwards in pieces;
     nanorq_repair_all lets every chunk of blocks wait for its last piece only.  Against the waiting call: same codes, same
     recovered object -- packets in block order and shuffled (then every block's last piece is the last one), in TWO batches,
-    a block completed by per-symbol calls in between, one block left undecodable (flushed as received)."""
+    a block completed by per-symbol calls in between, one block left undecodable (flushed as received).  With the batch booked
+    by one thread and by four (a symbol's code depends on the earlier symbols of its own block only: duplicates, symbols for
+    a block that is complete, repair indices must come out the same)."""
     from capi import SYM_ADDED, pinned_array, pinned_io
     L = api()
     K, T, Z = 900, 1280, 40           # 46 MB of packets: the deferred path moves them in pieces of 48 MB / several batches

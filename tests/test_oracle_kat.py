@@ -86,6 +86,34 @@ def test_simd_rows_equal_scalar(orc):
     orc.set_simd(1)
 
 
+def test_gfni_rows_equal_scalar(orc):
+    """The AVX-512 + GFNI row kernels (vgf2p8affineqb with an 8x8 bit matrix per constant: GFNI's own multiply is fixed to the AES
+    polynomial, RFC 6330's field is 0x11D) against the scalar log/antilog form, every constant; and a whole encode + decode with
+    them gives the bytes of the AVX2 run.  Without the ISA set_simd(2) falls back, and the comparison is trivially true."""
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, 1280 + 37, dtype=np.uint8)
+    for beta in range(256):
+        d0 = rng.integers(0, 256, len(src), dtype=np.uint8)
+        d2 = d0.copy()
+        orc.set_simd(0); orc.row_axpy(d0, src, beta)
+        orc.set_simd(2); orc.row_axpy(d2, src, beta)
+        assert np.array_equal(d0, d2), beta
+        if beta:
+            s0, s2 = src.copy(), src.copy()
+            orc.set_simd(0); orc.row_scal(s0, beta)
+            orc.set_simd(2); orc.row_scal(s2, beta)
+            assert np.array_equal(s0, s2), beta
+    K, T = 300, 192
+    blk = rng.integers(0, 256, (K, T), dtype=np.uint8)
+    esis = np.arange(K, K + 20, dtype=np.uint32)
+    try:
+        orc.set_simd(1); r1, i1, _ = orc.encode_block(blk, K, T, esis, want_inter=True)
+        orc.set_simd(2); r2, i2, _ = orc.encode_block(blk, K, T, esis, want_inter=True)
+    finally:
+        orc.set_simd(1)
+    assert np.array_equal(r1, r2) and np.array_equal(i1, i2)
+
+
 @pytest.mark.parametrize("K,T,p,oh", [(10, 8, 0.3, 0), (100, 1024, 0.06, 0), (100, 1024, 0.06, 2),
                                       (1024, 1280, 0.06, 52), (1024, 1280, 0.05, 0), (1024, 64, 0.5, 3)])
 def test_oracle_roundtrip(orc, K, T, p, oh):
