@@ -106,6 +106,8 @@ def parse():
     ap.add_argument("--patterns", type=int, default=4, choices=(1, 2, 4, 8),
                     help="different reception patterns the steps cycle through (step n loses pattern n mod this): no step's decode "
                          "plan can be a leftover of the step before it; a plan issued ahead is the plan of THAT step's pattern")
+    ap.add_argument("--one-list", action="store_true", help="round 5's launch rule for comparison: one solve launch per batch at the strip width "
+                                                                "EVERY block fits (no second block list)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffers-to-host-buffers leg")
     ap.add_argument("--one-object", choices=("auto", "on", "off"), default="auto",
                     help="ONE object over all N GPUs from rank 0's process (NANORQ_HIP_DEVICES=0..N-1, a host thread per device: "
@@ -317,7 +319,7 @@ def pmc_collect(args):
 
 def pmc_committed(args):
     """the counters of the committed profile (tools/collect_profiles.sh), if it is of this workload"""
-    for name in ("r5_pmc.json", "r4_pmc.json", "r3_pmc.json", "r2_pmc.json", "r1_pmc_hbm.json"):
+    for name in ("r6_pmc.json", "r5_pmc.json", "r4_pmc.json", "r3_pmc.json", "r2_pmc.json", "r1_pmc_hbm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -473,6 +475,8 @@ def main():
     ctxs = [nanorq_amd.Context(local, st.cuda_stream) for st in streams]   # one context per stream, same GPU
     for c_ in ctxs:
         c_.set_threads(threads)
+        if args.one_list:
+            c_.set_option("no_lists", 1)
     ctx = ctxs[0]
 
     K, T, NB = args.K, args.T, args.blocks

@@ -5,7 +5,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r3'
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r4}
+TAG=${1:-r6}
 OUT=$REPO/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
