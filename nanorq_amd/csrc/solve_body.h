@@ -707,8 +707,10 @@ template <int WB, class V> __device__ __forceinline__ void row_apply_at(uint32_t
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   } else if constexpr (WB >= 4) {
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else { /* 2-byte slots: the halfword inside its dword */
-    __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a & ~3u), v << ((a & 2u) * 8u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else { /* 2-byte slots: the halfword inside its dword.  (The shift count is a << 3 as it stands: a is even, so its low five bits --
+            * all the shifter looks at -- are 16 for the upper halfword and 0 for the lower: one instruction, not an AND and a
+            * multiply; tools/microbench/narrow_rows.hip: 57.4 -> clocks per row in profiles/r6_microbench_rows.txt) */
+    __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a & ~3u), v << ((a << 3) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 template <int WB> __device__ __forceinline__ void ph_row_apply(const StripCtx<WB> &, uint32_t op, typename RowVal<WB>::type v) {
