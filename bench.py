@@ -101,8 +101,8 @@ def parse():
     ap.add_argument("--plan-ahead-depth", type=int, default=2, help="planner runs kept in flight ahead of their decode (1 or 2)")
     ap.add_argument("--plan-ahead", choices=("auto", "on", "off"), default="auto",
                     help="issue the decode planner run of the NEXT step while this step's decode is being solved (the symbolic stage "
-                         "needs the reception pattern only): nrq_decode_plan_ahead.  auto = for big blocks (L >= 12000) only; "
-                         "the headline builds the plan inside the decode call")
+                         "needs the reception pattern only): nrq_decode_plan_ahead.  auto = for big blocks (L >= 12000) and small ones "
+                         "(L < 5000); the headline (L = 8416) builds the plan inside the decode call")
     ap.add_argument("--patterns", type=int, default=4, choices=(1, 2, 4, 8),
                     help="different reception patterns the steps cycle through (step n loses pattern n mod this): no step's decode "
                          "plan can be a leftover of the step before it; a plan issued ahead is the plan of THAT step's pattern")
@@ -570,7 +570,9 @@ def main():
     # pattern, see --patterns).  Elsewhere the plan is built inside the decode call, as a receiver does that learns the pattern
     # when it decodes: that is the headline's `value` now (round 5 quoted the run-ahead figure; with a planner of 1.65 ms that
     # owns every CU while it runs the two differ by < 1 % either way: 13.92 against 14.0-14.2 ms per step).
-    plan_ahead = nstreams == 1 and (args.plan_ahead == "on" or (args.plan_ahead == "auto" and replan_early))
+    # Small blocks (L < 5000) keep the run-ahead too: thousands of plan headers come back to the host in the middle of the step and
+    # the solve launch is formed from them with the GPU idle -- K=500: 21.2 -> 20.4 ms per step, K=1000 18.4 -> 18.0 (round 6, same box).
+    plan_ahead = nstreams == 1 and (args.plan_ahead == "on" or (args.plan_ahead == "auto" and (replan_early or L < 5000)))
     ahead_depth = max(1, min(2, args.plan_ahead_depth))
     ahead_out = 0   # planner runs issued ahead and not consumed yet
 
