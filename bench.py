@@ -447,6 +447,9 @@ def main():
             if args.force_device >= 0:
                 env_l["NANORQ_FORCE_DEVICE"] = str(args.force_device)   # (CPU placement: every rank beside that one GPU)
             raise SystemExit(shard.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env_l))
+    if args.force_device >= 0:
+        os.environ.setdefault("NANORQ_FORCE_DEVICE", str(args.force_device))
+    shard.bind_self()   # (a rank of torch.distributed.run: its GPU's cores, like spawn_ranks gives its children; before torch comes up)
     import torch
     import nanorq_amd
     from util import loss_pattern
@@ -780,10 +783,19 @@ def main():
                "--K", str(args.one_object_K), "--T", str(args.one_object_T), "--blocks", str(args.one_object_blocks),
                "--loss", "0.2" if args.one_object_K == 56403 else str(args.loss)]
         env1 = dict(os.environ)
-        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NANORQ_HIP_DEVICE"):
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "NANORQ_HIP_DEVICE", "NANORQ_RANK_CPUS", "OMP_NUM_THREADS"):
             env1.pop(k, None)
+        # (this process is bound to ITS GPU's cores; the one-object run drives every device from one process: all cores again)
+        wide = shard.ORIG_AFFINITY or (set(range(os.cpu_count() or 1)) if os.environ.get("NANORQ_RANK_CPUS") else None)
+
+        def _widen():
+            if wide:
+                try:
+                    os.sched_setaffinity(0, wide)
+                except OSError:
+                    pass
         try:
-            r = subprocess.run(cmd, env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            r = subprocess.run(cmd, env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, preexec_fn=_widen)
             one_object = (json.loads(r.stdout.decode().strip().split("\n")[-1]) if r.returncode == 0 else
                           {"error": "rc %d: %s" % (r.returncode, r.stderr.decode()[-300:])})
         except Exception as e:  # noqa: BLE001 -- the bench line must still come out

@@ -163,6 +163,40 @@ def rank_cpus(n, allowed=None, gpus=None, device_of_rank=None):
     return sets
 
 
+ORIG_AFFINITY = None   # what this process was allowed before bind_self narrowed it (a child that works for ALL devices gets it back)
+
+
+def bind_self(sysfs="/sys"):
+    """A rank started by another launcher (torch.distributed.run: the driver's N-GPU runs) binds ITSELF the way spawn_ranks binds
+    its children: to its slice of the cores of its GPU's NUMA node, before torch (and its thread pools) come up.  Returns the
+    cpu list, or None when nothing was done (already bound by spawn_ranks, NANORQ_NO_BIND=1, no affinity call, one rank)."""
+    if os.environ.get("NANORQ_NO_BIND") == "1" or os.environ.get("NANORQ_RANK_CPUS") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        n = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or "1")
+        r = int(os.environ.get("LOCAL_RANK", "0"))
+    except ValueError:
+        return None
+    if n <= 1 or r >= n:
+        return None
+    vis = visible_devices(os.environ)
+    dev_of = [(vis[k] if vis and k < len(vis) else k) for k in range(n)]
+    if os.environ.get("NANORQ_FORCE_DEVICE", "") != "":
+        dev_of = [int(os.environ["NANORQ_FORCE_DEVICE"])] * n
+    cpus = rank_cpus(n, gpus=gpu_cpu_lists(sysfs), device_of_rank=dev_of)[r]
+    if not cpus:
+        return None
+    global ORIG_AFFINITY
+    try:
+        ORIG_AFFINITY = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(cpus))
+    except OSError:
+        return None
+    os.environ["NANORQ_RANK_CPUS"] = ",".join(str(c) for c in cpus)
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(len(cpus), 16))))
+    return cpus
+
+
 def spawn_ranks(n, argv, env=None, timeout=None, bind=True, sysfs="/sys"):
     """Start `argv` n times on this node, one process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
     torch.distributed.run exports them, rendezvous on 127.0.0.1), and wait for all of them.  Rank 0 inherits stdout (it prints

@@ -171,3 +171,24 @@ def test_a_container_with_some_of_the_nodes_gpus(tmp_path):
     gpus = shard.gpu_cpu_lists(str(tmp_path))
     assert gpus == [(1, list(range(64, 128)))]
     assert shard.rank_cpus(2, allowed=range(128), gpus=gpus, device_of_rank=[0, 0]) == [list(range(64, 96)), list(range(96, 128))]
+
+
+@pytest.mark.timeout(120)
+def test_a_rank_of_another_launcher_binds_itself(tmp_path):
+    """Under torch.distributed.run (the driver's N-GPU runs) nobody binds the ranks: bench.py calls shard.bind_self() before it
+    imports torch -- same slices as spawn_ranks hands out, disjoint over the ranks, NANORQ_RANK_CPUS set; a rank that
+    spawn_ranks has already bound, or NANORQ_NO_BIND=1, is left alone."""
+    if not hasattr(os, "sched_getaffinity") or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("one core")
+    code = ("import os, sys, json; sys.path.insert(0, %r)\n"
+            "from nanorq_amd import shard\n"
+            "got = shard.bind_self(sysfs=%r)\n"
+            "json.dump({'got': got, 'aff': sorted(os.sched_getaffinity(0)), 'env': os.environ.get('NANORQ_RANK_CPUS')}, "
+            "open(os.path.join(%r, 'b' + os.environ['LOCAL_RANK'] + os.environ.get('TAG', '')), 'w'))\n" % (ROOT, str(tmp_path / "nosys"), str(tmp_path)))
+    base = dict(_clean_env(), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2")
+    for r in range(2):
+        subprocess.run([sys.executable, "-c", code], env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), check=True, timeout=60)
+    recs = [json.load(open(tmp_path / ("b%d" % r))) for r in range(2)]
+    assert all(x["got"] == x["aff"] and x["env"] for x in recs) and not set(recs[0]["aff"]) & set(recs[1]["aff"])
+    subprocess.run([sys.executable, "-c", code], env=dict(base, RANK="0", LOCAL_RANK="0", NANORQ_NO_BIND="1", TAG="n"), check=True, timeout=60)
+    assert json.load(open(tmp_path / "b0n"))["got"] is None
