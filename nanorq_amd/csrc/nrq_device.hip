@@ -331,7 +331,12 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       NRQ_STOP(1)
 
       {
-        constexpr uint32_t HNT = NT < NRQ_HDPC_NT_ ? NT : NRQ_HDPC_NT_;
+        /* (the 256-thread variant: NRQ_HDPC_NT_SMALL threads -- every thread of the phase ends in a closing fold of 8 x H masked XORs,
+         * ~800 instructions whatever its chunk holds, and four such workgroups share a CU's issue slots) */
+#ifndef NRQ_HDPC_NT_SMALL
+#define NRQ_HDPC_NT_SMALL 256
+#endif
+        constexpr uint32_t HNT = NT == 256 ? (uint32_t)NRQ_HDPC_NT_SMALL : NT < NRQ_HDPC_NT_ ? NT : NRQ_HDPC_NT_;
         /* (narrow strips: the H sums in registers -- on 16-byte strips that form is slower, 24 k against 17.5 k clocks for the
          * recurrence: 4 x H operations per column instead of four LDS atomics) */
 #ifndef NRQ_HDPC_REGS_MAX_WB
@@ -364,7 +369,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       }
       NRQ_STAMP(4);
       NRQ_STOP(3)
-      ph_dense_fold<WB, G, (NT == 64)>(c, vt, VNT);
+#ifndef NRQ_FOLD_PRE256
+#define NRQ_FOLD_PRE256 0 /* coefficients the 256-thread variant's dense fold asks for at once (0: one per term, a trip to L2 each) */
+#endif
+      ph_dense_fold<WB, G, (NT == 64 ? 8 : NT == 256 ? NRQ_FOLD_PRE256 : 0)>(c, vt, VNT);
       __syncthreads();
       NRQ_MARK(c, 4);
       if (dense_fold_shared(VNT) || G > 1) { /* (then the fold leaves its products in the accumulator copies) */

@@ -1227,20 +1227,20 @@ SB_HD bool dense_fold_shared(uint32_t nt) { return nt >= NRQ_DENSE_SHARED_MIN_NT
  * of a 110 k strip; K=100: free columns 14 k of 140 k).  K=100: dense stage 45 k -> 38 k clocks, solve 7.58 / 7.16 -> 7.24 / 6.84 ms; the 256-thread
  * variant LOSES 2-4 % with it (K=500, 1000, 2000: its fold is bound by the multiplications of four waves per SIMD, and the unrolled
  * form costs it 12 more spills), so it keeps the loop. */
-template <int WB, int G = 1, bool BATCH = false> SB_HD void ph_dense_fold(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
+template <int WB, int G = 1, int BATCH = 0> SB_HD void ph_dense_fold(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const NRQ_GAS uint8_t *mh = c.template arr<uint8_t>(c.h->off_mh);
   const uint32_t H = c.h->H, r2 = c.h->r2, M = c.h->M;
   if (!dense_fold_shared(nt) && G == 1) {
     const uint32_t hq = tid & 15u, part = tid >> 4, nparts = nt >> 4;
     if (hq >= H) return;
     SV<WB> acc = sv_zero<WB>();
-    if constexpr (BATCH) {
-      for (uint32_t p0 = part; p0 < r2; p0 += 8u * nparts) {
-        uint32_t coef[8];
+    if constexpr (BATCH > 0) { /* (BATCH coefficients of the thread's terms in flight together: 8 on a single wave, see above) */
+      for (uint32_t p0 = part; p0 < r2; p0 += (uint32_t)BATCH * nparts) {
+        uint32_t coef[BATCH];
 #pragma unroll
-        for (uint32_t i = 0; i < 8; i++) coef[i] = mh[(size_t)hq * r2 + (p0 + i * nparts < r2 ? p0 + i * nparts : p0)];
+        for (uint32_t i = 0; i < (uint32_t)BATCH; i++) coef[i] = mh[(size_t)hq * r2 + (p0 + i * nparts < r2 ? p0 + i * nparts : p0)];
 #pragma unroll
-        for (uint32_t i = 0; i < 8; i++) {
+        for (uint32_t i = 0; i < (uint32_t)BATCH; i++) {
           const uint32_t p = p0 + i * nparts;
           if (p >= r2 || !coef[i]) continue;
           SV<WB> t = sv_mul<WB>(lds_get<WB, G>(c.slots(), M + p), coef[i]);

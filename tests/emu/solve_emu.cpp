@@ -79,7 +79,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
     for (uint32_t t = 0; t < NT; t++) { uint32_t cb[NRQ_COMBINE_WU]; ph_combine_fetch<WB>(c, w0, t, NT, cb); ph_combine<WB>(c, w0, t, NT, cb); }
   }
   if (c.h->lpr) PHASE(ph_clear_x);
-  for (uint32_t t = 0; t < NT; t++) ph_dense_fold<WB, 1, true>(c, t, NT); /* (the form of the 256-thread workgroup) */
+  for (uint32_t t = 0; t < NT; t++) ph_dense_fold<WB, 1, 8>(c, t, NT); /* (the form of the 256-thread workgroup) */
   if (dense_fold_shared(NT)) PHASE(ph_hdpc_reduce);
   for (uint32_t t = 0; t < NT; t++) ph_dense_free<WB, 1, true>(c, t, NT);
   for (uint32_t t = 0; t < NT; t++) ph_dense_cu<WB, 1, true>(c, t, NT);
