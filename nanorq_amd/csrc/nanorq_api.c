@@ -1346,6 +1346,33 @@ static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, size_t k
  * does the bookkeeping of nanorq_decoder_add_symbol (nanorq.c:478-509) and touches no symbol byte.  Otherwise: the
  * per-symbol call in a loop.  With several devices every device uploads the buffer and keeps the symbols of its own blocks. */
 enum { RIX_NONE = 0xFFFFFFFFu, RIX_SRC = 0xFFFFFFFEu };
+static unsigned book_threads(void);
+#define NRQ_BOOK_THREADS 8u
+struct addr_job { /* destination addresses of the symbols [k0, k1) of a batch that belong to device di (add_all_worker) */
+  nanorq *rq;
+  const uint32_t *tags, *rix;
+  uint64_t *dst;
+  int di;
+  size_t T;
+  uint32_t k0, k1, k_lo, k_hi;
+  uint32_t last_k[NRQ_Z_MAX];
+  bool any;
+};
+static void *addr_worker(void *arg) {
+  struct addr_job *a = arg;
+  for (uint32_t k = a->k0; k < a->k1; k++) {
+    if (a->rix[k] == RIX_NONE) continue;
+    const struct blockst *b = a->rq->blocks[(uint8_t)(a->tags[k] >> 24)];
+    if (b->di != a->di) continue;
+    a->dst[k] = a->rix[k] == RIX_SRC ? (uint64_t)(uintptr_t)((uint8_t *)b->d_src + (size_t)(a->tags[k] & 0x00ffffffu) * a->T)
+                                     : (uint64_t)(uintptr_t)((uint8_t *)b->d_rep + (size_t)a->rix[k] * a->T);
+    if (k < a->k_lo) a->k_lo = k;
+    a->k_hi = k + 1u;
+    a->last_k[(uint8_t)(a->tags[k] >> 24)] = k;
+    a->any = true;
+  }
+  return NULL;
+}
 static void *add_all_worker(void *arg) {
   struct all_job *j = arg;
   nanorq *rq = j->rq;
@@ -1372,18 +1399,34 @@ static void *add_all_worker(void *arg) {
     if (old) olds[nold++] = old; /* (at most one per block) */
   }
   uint32_t k_lo = n, k_hi = 0; /* the stretch of the buffer that holds this device's symbols */
-  if (ok)
-    for (uint32_t k = 0; k < n; k++) {
-      if (j->rix[k] == RIX_NONE) continue;
-      struct blockst *b = rq->blocks[(uint8_t)(j->tags[k] >> 24)];
-      if (b->di != di) continue;
-      dst[k] = j->rix[k] == RIX_SRC ? (uint64_t)(uintptr_t)((uint8_t *)b->d_src + (size_t)(j->tags[k] & 0x00ffffffu) * T)
-                                    : (uint64_t)(uintptr_t)((uint8_t *)b->d_rep + (size_t)j->rix[k] * T);
-      if (k < k_lo) k_lo = k;
-      k_hi = k + 1u;
-      last_k[(uint8_t)(j->tags[k] >> 24)] = k;
-      any = true;
+  if (ok) {
+    /* where every symbol goes: a pure function of the books, so a big batch is cut into stretches for the booking threads
+     * (a million symbols: ~2.5 ms on one thread, in front of everything nanorq_repair_all can start) */
+    struct addr_job aj[NRQ_BOOK_THREADS];
+    pthread_t ath[NRQ_BOOK_THREADS];
+    bool astarted[NRQ_BOOK_THREADS];
+    const unsigned P = n >= g_book_min ? book_threads() : 1u;
+    for (unsigned t = 0; t < P; t++) {
+      aj[t] = (struct addr_job){.rq = rq, .tags = j->tags, .rix = j->rix, .dst = dst, .di = di, .T = T,
+                                .k0 = (uint32_t)((uint64_t)n * t / P), .k1 = (uint32_t)((uint64_t)n * (t + 1u) / P), .k_lo = n, .k_hi = 0, .any = false};
+      memset(aj[t].last_k, 0xFF, sizeof(aj[t].last_k));
+      astarted[t] = false;
     }
+    for (unsigned t = 1; t < P; t++) astarted[t] = pthread_create(&ath[t], NULL, addr_worker, &aj[t]) == 0;
+    addr_worker(&aj[0]);
+    for (unsigned t = 1; t < P; t++) {
+      if (astarted[t]) pthread_join(ath[t], NULL);
+      else addr_worker(&aj[t]);
+    }
+    for (unsigned t = 0; t < P; t++) { /* (stretches in ascending order: a later stretch's last symbol of a block wins) */
+      if (!aj[t].any) continue;
+      any = true;
+      if (aj[t].k_lo < k_lo) k_lo = aj[t].k_lo;
+      if (aj[t].k_hi > k_hi) k_hi = aj[t].k_hi;
+      for (unsigned sbn = 0; sbn < NRQ_Z_MAX; sbn++)
+        if (aj[t].last_k[sbn] != 0xFFFFFFFFu) last_k[sbn] = aj[t].last_k[sbn];
+    }
+  }
   struct upstate *u = &rq->up[di];
   if (j->early_blob) {
     /* The packets have been travelling since the call began (add_symbols_impl): what is left is to tell the GPU where every
@@ -1522,7 +1565,6 @@ static void *add_all_worker(void *arg) {
   return NULL;
 }
 /* bookkeeping of a packet batch (add_symbols_impl), the blocks sbn mod P == t */
-#define NRQ_BOOK_THREADS 8u
 struct book_job {
   nanorq *rq;
   const uint8_t *p;
