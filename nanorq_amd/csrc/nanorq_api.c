@@ -1612,13 +1612,11 @@ static void *book_worker(void *arg) {
       r = j->P > 1 ? NANORQ_SYM_ERR /* (cannot happen: such an object is booked by one thread) */
                    : nanorq_decoder_add_symbol(rq, (void *)(uintptr_t)(j->p + (size_t)k * T), j->tags[k], j->io);
     } else {
-      if (!b->dev) { /* first symbol of the block: it becomes device-resident */
-        nrq_ctx *c = dctx(b->di);
-        gpu_lock(b->di);
-        if (!b->d_src && nrq_dev_alloc(c, (size_t)b->K * T, &b->d_src) != 0) r = NANORQ_SYM_ERR;
-        else if (nrq_memset_on(c, j->early ? 3 : 1, b->d_src, 0, (size_t)b->K * T) != 0) r = NANORQ_SYM_ERR; /* (in front of the sort into rows) */
-        else { b->dev = true; j->newdev[sbn] = 1; }
-        gpu_unlock(b->di);
+      if (!b->dev) { /* first symbol of the block: it becomes device-resident.  Its device rows are allocated and zeroed by the
+                      * calling thread once the books are done (add_symbols_impl): no runtime call from a booking thread -- a
+                      * thread's first one costs it the runtime's per-thread set-up, a millisecond under the device lock */
+        b->dev = true;
+        j->newdev[sbn] = 1;
       }
       if (r == NANORQ_SYM_ADDED && !j->touched[sbn]) { j->touched[sbn] = 1; j->nrep0[sbn] = b->nrep; }
       if (r == NANORQ_SYM_ADDED && esi < b->K) {
@@ -1720,11 +1718,34 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
     else book_worker(&bj[t]); /* (no thread to be had: one after the other) */
   }
   for (unsigned t = 0; t < P; t++) added += bj[t].added;
+  /* the blocks that became device-resident in this batch: their rows, zeroed in front of the sort of the packets into them */
+  bool dev_ok = true;
+  for (unsigned sbn = 0; sbn < NRQ_Z_MAX && dev_ok; sbn++) {
+    struct blockst *b = newdev[sbn] ? rq->blocks[sbn] : NULL;
+    if (!b) continue;
+    nrq_ctx *c = dctx(b->di);
+    gpu_lock(b->di);
+    dev_ok = c && (b->d_src || nrq_dev_alloc(c, (size_t)b->K * T, &b->d_src) == 0) &&
+             nrq_memset_on(c, early_blob ? 3 : 1, b->d_src, 0, (size_t)b->K * T) == 0;
+    gpu_unlock(b->di);
+  }
   struct all_job j;
   memset(&j, 0, sizeof(j));
   j.rq = rq; j.io = io; j.pk = p; j.tags = tags; j.rix = rix; j.n = n; j.nrep0 = nrep0; j.touched = touched; j.deferred = deferred;
   j.early_blob = early_blob; j.early_piece = early_piece; j.early_ev0 = early_ev0;
-  for_devices(add_all_worker, &j, ndev()); /* (also with nothing to put: the memsets of new blocks are waited for) */
+  if (dev_ok) for_devices(add_all_worker, &j, ndev()); /* (also with nothing to put: the memsets of new blocks are waited for) */
+  else {
+    /* (a block's device rows could not be had: the batch is taken back below like one whose bytes did not arrive; what is already
+     * on its way -- the early copies, memsets -- is waited for first) */
+    for (int d = 0; d < ndev(); d++) {
+      nrq_ctx *c = dctx(d);
+      gpu_lock(d);
+      if (c) { nrq_stream_sync(c, 1); nrq_stream_sync(c, 3); }
+      if (d == 0 && early_blob && c) nrq_dev_free(c, early_blob);
+      gpu_unlock(d);
+    }
+    j.ok = false;
+  }
   if (!j.ok) {
     /* The bytes did not reach the device rows: take the batch's bookkeeping back, so that the decoder does not believe in
      * symbols it does not hold (they can be sent again), and say so symbol by symbol. */
