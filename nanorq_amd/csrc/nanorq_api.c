@@ -28,8 +28,10 @@
 #define _GNU_SOURCE
 #include <pthread.h>
 #include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/nanorq.h"
 #include "../../include/nanorq_batch.h"
@@ -1360,17 +1362,22 @@ struct addr_job { /* destination addresses of the symbols [k0, k1) of a batch th
 };
 static void *addr_worker(void *arg) {
   struct addr_job *a = arg;
+  uint32_t k_lo = a->k_lo, k_hi = a->k_hi, last_k[NRQ_Z_MAX]; /* (locals: the jobs lie side by side in memory) */
+  memset(last_k, 0xFF, sizeof(last_k));
+  bool any = false;
   for (uint32_t k = a->k0; k < a->k1; k++) {
     if (a->rix[k] == RIX_NONE) continue;
     const struct blockst *b = a->rq->blocks[(uint8_t)(a->tags[k] >> 24)];
     if (b->di != a->di) continue;
     a->dst[k] = a->rix[k] == RIX_SRC ? (uint64_t)(uintptr_t)((uint8_t *)b->d_src + (size_t)(a->tags[k] & 0x00ffffffu) * a->T)
                                      : (uint64_t)(uintptr_t)((uint8_t *)b->d_rep + (size_t)a->rix[k] * a->T);
-    if (k < a->k_lo) a->k_lo = k;
-    a->k_hi = k + 1u;
-    a->last_k[(uint8_t)(a->tags[k] >> 24)] = k;
-    a->any = true;
+    if (k < k_lo) k_lo = k;
+    k_hi = k + 1u;
+    last_k[(uint8_t)(a->tags[k] >> 24)] = k;
+    any = true;
   }
+  a->k_lo = k_lo; a->k_hi = k_hi; a->any = any;
+  memcpy(a->last_k, last_k, sizeof(last_k));
   return NULL;
 }
 static void *add_all_worker(void *arg) {
@@ -1597,9 +1604,12 @@ static void *book_worker(void *arg) {
   struct book_job *j = arg;
   nanorq *rq = j->rq;
   const size_t T = rq->T;
+  uint8_t owner[NRQ_Z_MAX];
+  for (unsigned s_ = 0; s_ < NRQ_Z_MAX; s_++) owner[s_] = (uint8_t)(j->P > 1 ? s_ % j->P : j->t);
+  size_t added = 0; /* (a local: the jobs lie side by side, and a counter bumped per symbol in each made their cache lines travel) */
   for (uint32_t k = 0; k < j->n; k++) {
     const uint8_t sbn = (uint8_t)(j->tags[k] >> 24);
-    if (j->P > 1 && sbn % j->P != j->t) continue;
+    if (owner[sbn] != j->t) continue; /* (a table, not sbn % P: a division per symbol and thread was the whole gain) */
     const uint32_t esi = j->tags[k] & 0x00ffffffu;
     struct blockst *b = get_block(rq, sbn);
     int r = NANORQ_SYM_ADDED;
@@ -1631,13 +1641,26 @@ static void *book_worker(void *arg) {
       if (r == NANORQ_SYM_ADDED) mask_set(b, esi);
     }
     if (j->results) j->results[k] = r;
-    if (r == NANORQ_SYM_ADDED) j->added++;
+    if (r == NANORQ_SYM_ADDED) added++;
   }
+  j->added = added;
   return NULL;
 }
 
+static double now_us(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+static bool diag_on(void) {
+  static int on = -1;
+  if (on < 0) on = getenv("NANORQ_HIP_DIAG") ? 1 : 0;
+  return on != 0;
+}
 static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tags, uint32_t n, int *results, struct ioctx *io, bool deferred) {
   size_t added = 0;
+  const double t_in = now_us();
+  double t_pin = 0, t_early = 0, t_book = 0, t_rows = 0;
   const uint8_t *p = data;
   const size_t T = rq->T;
   uint8_t *obase;
@@ -1646,6 +1669,7 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
   /* Bookkeeping first, addresses afterwards: a repair symbol is recorded as (block, index in the block's repair rows) while
    * the loop runs; only when the batch's final repair count of every block is known are the blocks' device rows grown and
    * the indices turned into addresses (add_all_worker). */
+  t_pin = now_us();
   uint32_t *rix = dma ? malloc((size_t)n * sizeof(uint32_t)) : NULL; /* per symbol: index of its repair row, or RIX_* */
   if (!rix) {
     for (uint32_t k = 0; k < n; k++) {
@@ -1686,6 +1710,7 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
       gpu_unlock(0);
     }
   }
+  t_early = now_us();
   size_t nrep0[NRQ_Z_MAX];                 /* repair symbols a touched block held before this batch */
   uint8_t touched[NRQ_Z_MAX], newdev[NRQ_Z_MAX];
   memset(touched, 0, sizeof(touched));
@@ -1718,6 +1743,7 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
     else book_worker(&bj[t]); /* (no thread to be had: one after the other) */
   }
   for (unsigned t = 0; t < P; t++) added += bj[t].added;
+  t_book = now_us();
   /* the blocks that became device-resident in this batch: their rows, zeroed in front of the sort of the packets into them */
   bool dev_ok = true;
   for (unsigned sbn = 0; sbn < NRQ_Z_MAX && dev_ok; sbn++) {
@@ -1729,6 +1755,7 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
              nrq_memset_on(c, early_blob ? 3 : 1, b->d_src, 0, (size_t)b->K * T) == 0;
     gpu_unlock(b->di);
   }
+  t_rows = now_us();
   struct all_job j;
   memset(&j, 0, sizeof(j));
   j.rq = rq; j.io = io; j.pk = p; j.tags = tags; j.rix = rix; j.n = n; j.nrep0 = nrep0; j.touched = touched; j.deferred = deferred;
@@ -1773,6 +1800,10 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
       if (rix[k] == RIX_SRC) rq->blocks[(uint8_t)(tags[k] >> 24)]->dirty = true;
   }
   free(rix);
+  if (diag_on())
+    fprintf(stderr, "[NANORQ_HIP_DIAG] add_symbols %u symbols, %u booking threads: page-lock check %.2f ms, early copies %.2f, books %.2f, new blocks' rows %.2f, "
+            "addresses + enqueue %.2f, total %.2f ms\n", n, P, (t_pin - t_in) * 1e-3, (t_early - t_pin) * 1e-3, (t_book - t_early) * 1e-3,
+            (t_rows - t_book) * 1e-3, (now_us() - t_rows) * 1e-3, (now_us() - t_in) * 1e-3);
   return added;
 }
 
