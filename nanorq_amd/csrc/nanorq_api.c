@@ -1831,6 +1831,7 @@ static void *repair_all_worker(void *arg) {
   const int di = j->di;
   nrq_ctx *c = g_dev[di].c;
   const size_t Z = nanorq_blocks(rq), T = rq->T;
+  const double t_call = now_us();
   gpu_lock(di);
   /* Nothing is believed before it is known to have happened: a block's bitmap (and the "output has not seen these rows" flag of
    * a device-resident block) changes only after the copies that carry its rows have been WAITED for successfully.  (The fault
@@ -1918,8 +1919,10 @@ static void *repair_all_worker(void *arg) {
         ev_up_borrowed[ci] = true;
       }
     }
+    const double t_lists = now_us();
     ok = ok && nrq_decode_blocks_vc(c, K, Kp, (uint32_t)T, n, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv, status,
                                     NULL, C, ev_done, ev_up) == 0;
+    const double t_planned = now_us();
     bool any_host = false;
     for (unsigned c0 = 0, ci = 0; c0 < n && ok; c0 += C, ci++) { /* the downloads, each chunk behind its solve */
       const unsigned m = n - c0 < C ? n - c0 : C;
@@ -1959,8 +1962,14 @@ static void *repair_all_worker(void *arg) {
       pthread_mutex_unlock(&rq->io_lock);
     }
     /* (each wait is tried twice: the temporaries below must not be freed under work in flight whatever the first attempt said) */
+    const double t_enq = now_us();
     const bool s0 = nrq_ctx_sync(c) == 0 || nrq_ctx_sync(c) == 0, s1 = nrq_stream_sync(c, 1) == 0 || nrq_stream_sync(c, 1) == 0;
+    const double t_solved = now_us();
     const bool s2 = nrq_stream_sync(c, 2) == 0;
+    if (diag_on())
+      fprintf(stderr, "[NANORQ_HIP_DIAG] repair_all device %d class %u: %u blocks in %u chunks: lists %.2f ms, planner run + solves enqueued %.2f, downloads enqueued %.2f, "
+              "uploads + solves done %.2f, downloads done %.2f ms after the call began\n", di, cls, n, nch, (t_lists - t_call) * 1e-3, (t_planned - t_call) * 1e-3,
+              (t_enq - t_call) * 1e-3, (t_solved - t_call) * 1e-3, (now_us() - t_call) * 1e-3);
     if (ok && s0 && s1 && s2 && dev_done)
       for (unsigned k = 0; k < n; k++) { /* device-resident blocks: recovered, and (with an output context) written */
         if (!dev_done[k]) continue;
