@@ -87,6 +87,12 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
 #define NRQ_HDPC_NT 512 /* threads of the HDPC phase; measured: 256 / 512 / 768 -> 34 k / 28 k / 29 k clocks (the closing fold is per thread) */
 #endif
 #define NRQ_HDPC_NT_ ((uint32_t)NRQ_HDPC_NT)
+#ifndef NRQ_GATHER_WAVES_NARROW
+#define NRQ_GATHER_WAVES_NARROW 2u /* gather waves of the 768-thread workgroup on strips of at most NRQ_GATHER_WAVES_NARROW_WB bytes */
+#endif
+#ifndef NRQ_GATHER_WAVES_NARROW_WB
+#define NRQ_GATHER_WAVES_NARROW_WB 2
+#endif
 #ifndef NRQ_MOVER_WAVES
 #define NRQ_MOVER_WAVES 2u
 #endif
@@ -142,7 +148,11 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
                      /* two gather and two scatter waves in the big workgroup, not three: every mover wave that keeps loads in
                       * flight slows the forward waves' op words down (measured, headline encode: 3+3 -> row pipeline 89 k clocks,
                       * gather done at 70 k; 2+2 -> 79 k / 83 k; 1+1 -> 72 k / 125 k) */
-                     NGW = NMV >= 6u ? NRQ_MOVER_WAVES : NMV >= 3u ? 2u : 1u, NSW = NMV >= 6u ? NRQ_MOVER_WAVES : NMV - NGW;
+                     /* (2-byte strips: the GATHER, not the forward wave, ends the window -- with work slots of 8 strips a row piece is
+                      * 16 bytes of a 128-byte line and the two gather waves are bound by their requests in flight; round 6, NRQ_PROF
+                      * marks at K'=56403: forward wave done 77 k clocks before the window's end, gather at its end) */
+                     NGW = NMV >= 6u ? (WB <= NRQ_GATHER_WAVES_NARROW_WB ? NRQ_GATHER_WAVES_NARROW : NRQ_MOVER_WAVES) : NMV >= 3u ? 2u : 1u,
+                     NSW = NMV >= 6u ? NRQ_MOVER_WAVES : NMV - NGW;
   static_assert(NMV >= 2u || NT == 64, "workgroup too small for the data movers");
   /* op-word ring of the forward wave(s), in rows: what the variant's register budget holds without spilling */
 #ifndef NRQ_PIPE_SMALL
@@ -319,10 +329,14 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       } else if ((wv & 3u) >= NFW) { /* the waves that do not share a SIMD with the forward waves; index among them: */
         const uint32_t mv = (wv >> 2) * (4u - NFW) + (wv & 3u) - NFW;
         if (mv < NGW) {
+#ifndef NRQ_EXPERIMENT_NO_MOVERS /* (measurement only: what the forward window costs with no mover traffic beside it; results are garbage) */
           if (um > u0) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, u0, um, (mv * 64u + (tid & 63u)) / G, (NGW * 64u) / G, subl);
+#endif
           NRQ_MARK_MAX(c, 2);
         } else if (mv < NGW + NSW) {
+#ifndef NRQ_EXPERIMENT_NO_MOVERS
           if (sm > s0) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, s0, sm, ((mv - NGW) * 64u + (tid & 63u)) / G, (NSW * 64u) / G, subl);
+#endif
           NRQ_MARK_MAX(c, 3);
         }
       }

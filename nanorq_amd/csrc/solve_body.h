@@ -752,10 +752,12 @@ template <int WB, int OFF, class V, uint32_t U> __device__ __forceinline__ void 
       row_apply_at<WB, V>(a_dst, v[(k + NS - P) % NS]);
       if constexpr (sizeof(V) == 4 && WB == 2 && OFF == 0) v[k % NS] = *NRQ_LDSP(uint16_t, a_src);
       else v[k % NS] = *NRQ_LDSP(V, a_src);
+#ifndef NRQ_EXPERIMENT_NO_OPLOAD /* (measurement only: the loop on the first ring's words for ever -- no vector memory load in it) */
       if (j % 4u == 3u) { /* the quad's last row has been applied: the rows it holds next (this trip's if still ahead, k < P) */
         const OpQuad w = nxt[(j / 4u + (j < k ? NQ : 0u)) * NRQ_ROW];
         o[j - 3u] = w.x; o[j - 2u] = w.y; o[j - 1u] = w.z; o[j] = w.w;
       }
+#endif
       NRQ_SCHED_FENCE();
     }
   }
