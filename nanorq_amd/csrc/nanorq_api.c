@@ -1349,6 +1349,7 @@ static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, size_t k
  * per-symbol call in a loop.  With several devices every device uploads the buffer and keeps the symbols of its own blocks. */
 enum { RIX_NONE = 0xFFFFFFFFu, RIX_SRC = 0xFFFFFFFEu };
 static unsigned book_threads(void);
+static uint32_t book_min(void);
 #define NRQ_BOOK_THREADS 8u
 struct addr_job { /* destination addresses of the symbols [k0, k1) of a batch that belong to device di (add_all_worker) */
   nanorq *rq;
@@ -1412,7 +1413,7 @@ static void *add_all_worker(void *arg) {
     struct addr_job aj[NRQ_BOOK_THREADS];
     pthread_t ath[NRQ_BOOK_THREADS];
     bool astarted[NRQ_BOOK_THREADS];
-    const unsigned P = n >= g_book_min ? book_threads() : 1u;
+    const unsigned P = n >= book_min() ? book_threads() : 1u;
     for (unsigned t = 0; t < P; t++) {
       aj[t] = (struct addr_job){.rq = rq, .tags = j->tags, .rix = j->rix, .dst = dst, .di = di, .T = T,
                                 .k0 = (uint32_t)((uint64_t)n * t / P), .k1 = (uint32_t)((uint64_t)n * (t + 1u) / P), .k_lo = n, .k_hi = 0, .any = false};
@@ -1586,6 +1587,14 @@ struct book_job {
   unsigned t, P;
   size_t added;
 };
+static uint32_t book_min(void) { /* symbols from which a batch is booked by several threads: "book_min", else NANORQ_HIP_BOOK_MIN, else 65536 */
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("NANORQ_HIP_BOOK_MIN");
+    env = e && *e && atol(e) > 0 ? (int)atol(e) : 0;
+  }
+  return g_book_min != 65536u ? g_book_min : env ? (uint32_t)env : 65536u;
+}
 static unsigned book_threads(void) {
   static int n = -1;
   if (g_book_threads > 0) return (unsigned)g_book_threads;
@@ -1722,7 +1731,7 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
    * output context, which has one cursor. */
   struct book_job bj[NRQ_BOOK_THREADS];
   unsigned P = 1;
-  if (n >= g_book_min) {
+  if (n >= book_min()) {
     P = book_threads();
     for (unsigned sbn = 0; sbn < NRQ_Z_MAX && P > 1; sbn++) {
       const struct blockst *b = rq->blocks[sbn];

@@ -449,7 +449,10 @@ template <int WB, int CB> SB_HD SV<WB> chunk_piece(const SV<CB> &v, int j) {
 }
 template <int WB, int CB, bool PIPELINED> SB_HD void pf_gather_chunks(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0,
                                                                       uint32_t u1, uint32_t p, uint32_t np) {
-  constexpr int NP = CB / WB, LNP = NP == 8 ? 3 : NP == 4 ? 2 : 1, PB = 4;
+#ifndef NRQ_GATHER_CHUNK_PB
+#define NRQ_GATHER_CHUNK_PB 4 /* chunk loads a mover thread has in flight per trip */
+#endif
+  constexpr int NP = CB / WB, LNP = NP == 8 ? 3 : NP == 4 ? 2 : 1, PB = NRQ_GATHER_CHUNK_PB;
   const uint32_t lc = g.lsub - (uint32_t)LNP, cmask = (1u << lc) - 1u; /* chunk unit c = (row c >> lc, chunk c & cmask) */
   const uint32_t c0 = (u0 + NP - 1u) >> LNP, c1 = (u1 + NP - 1u) >> LNP;
   auto fetch = [&](uint32_t cu, uint32_t src) {
