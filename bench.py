@@ -795,7 +795,8 @@ def main():
                 except OSError:
                     pass
         try:
-            r = subprocess.run(cmd, env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, preexec_fn=_widen)
+            # (bounded: the thread-per-device path has never met a node with several GPUs, and the bench line must not wait for it)
+            r = subprocess.run(cmd, env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, preexec_fn=_widen)
             one_object = (json.loads(r.stdout.decode().strip().split("\n")[-1]) if r.returncode == 0 else
                           {"error": "rc %d: %s" % (r.returncode, r.stderr.decode()[-300:])})
         except Exception as e:  # noqa: BLE001 -- the bench line must still come out
@@ -805,7 +806,7 @@ def main():
         payload_step = world * NB * K * T
         value = 8.0 * payload_step * args.steps / elapsed / 1e9
         cpu, balg_enc, balg_dec = (None, None, None)
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:   # (the CPU baseline is a one-GPU-run entry; N > 1 keeps the op counts for the roofline only)
             src_np = src[:args.cpu_sample].cpu().numpy()
             cpu, balg_enc, balg_dec = cpu_baseline(args, src_np, lost, nrep)
         elif args.alg_sample > 0:
