@@ -57,9 +57,11 @@ def main():
                          "lib/tuple.c:21-43): K = K', T = 8, payload = tests/util.py payload(K'*8, seed=477, block=K'); repair ESIs "
                          "K'..K'+3.  Every row was found nonsingular and systematic by tools/gen_kprime_sweep.py.",
            "T": T, "payload_seed": SEED, "repair_per_row": NREP, "rows": out}
-    with open(os.path.join(ROOT, "tests", "golden", "kprime_sweep.json"), "w") as f:
-        json.dump(doc, f, indent=0, separators=(",", ":"))
-        f.write("\n")
+    with open(os.path.join(ROOT, "tests", "golden", "kprime_sweep.json"), "w") as f:   # one table row per line
+        head = {k: v for k, v in doc.items() if k != "rows"}
+        f.write(json.dumps(head, separators=(",", ":"))[:-1] + ',"rows":[\n')
+        f.write(",\n".join(json.dumps(r, separators=(",", ":")) for r in out))
+        f.write("\n]}\n")
     print("wrote %d rows" % len(out))
 
 
