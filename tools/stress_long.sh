@@ -2,10 +2,11 @@
 # Runs ON THE GPU BOX (gpurun): tools/stress_decode.py at length -- ~3 million decodes over the sizes of every planner form
 # (chained peel with the state in LDS, dense stage over the rowstate image, compact state, small workgroups), every block compared
 # with its source.  ~2.5 minutes.
-#   gpurun --timeout 2700 -- 'bash tools/stress_long.sh' > profiles/r5_stress_long.txt
+#   gpurun --timeout 2700 -- 'bash tools/stress_long.sh' > profiles/r6_stress_long.txt
 cd ${GRAFT_REPO_ROOT:-$PWD}
 while read -r args; do
-  echo "== $args: $(timeout 900 python tools/stress_decode.py $args 2>&1 | grep -v amdgpu | tail -1)"
+  out=$(timeout 900 python tools/stress_decode.py $args 2>&1 | grep -v amdgpu)
+  echo "== $args: $(echo "$out" | tail -1); blocks sent to the host planner (capacity or plan check): $(echo "$out" | grep -c "host planner took")"
 done <<'CASES'
 8192 32 256 0.1 200
 8192 32 256 0.45 60
