@@ -123,6 +123,15 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
                           * 151 of them spilled: every phase reloads its pointers from scratch) 370 Gbit/s, 4 / 16 ~385, 3 / 12 419,
                           * 2 / 8 358; K=256 527 / 547 / 569 / 533 */
 #endif
+#ifndef NRQ_W12_FW
+#define NRQ_W12_FW 3 /* forward waves of the 12-byte strip: 3 (a dword each) or 2 (two dwords, one dword) */
+#endif
+#ifndef NRQ_W12_GW
+#define NRQ_W12_GW 2 /* gather / scatter waves beside the three forward waves of the 12-byte strip */
+#endif
+#ifndef NRQ_W12_SW
+#define NRQ_W12_SW 2
+#endif
 #ifndef NRQ_SMALL_WV
 #define NRQ_SMALL_WV 4   /* the 256-thread variant: workgroups per compute unit = waves per SIMD it is built for */
 #endif
@@ -139,11 +148,12 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
   /* NFW waves run the forward passes (two, half the strip width each, when the strip is wide enough and the workgroup
    * big enough to spare a second SIMD); the waves on the other SIMDs move data meanwhile: NGW gather, NSW scatter */
   static_assert(G == 1 || WB == 16, "wide strips are made of 16-byte lanes");
+  static_assert(WB != 12 || NT >= 512, "12-byte strips: the 768-thread workgroup only (blocks whose 16-byte image does not fit the LDS)");
   constexpr uint32_t WBE = (uint32_t)WB * G; /* bytes of a strip */
   constexpr bool ALX = AL && G == 1 && WB >= 4;
   const uint32_t vt = tid / G, subl = tid % G; /* virtual thread, lane inside it */
   constexpr uint32_t VNT = NT / G;
-  constexpr uint32_t SPL = WBE >= 128u ? 1u : 128u / WBE, NFW = (G == 1 && WB >= 8 && NT >= 512) ? 2u : 1u,
+  constexpr uint32_t SPL = nrq_group_strips(WBE), NFW = (G == 1 && WB == 12 && NT >= 512) ? (uint32_t)NRQ_W12_FW : (G == 1 && WB >= 8 && NT >= 512) ? 2u : 1u,
                      NMV = (NT / 64u) / 4u * (4u - NFW) + ((NT / 64u) % 4u > NFW ? (NT / 64u) % 4u - NFW : 0u),
                      /* two gather and two scatter waves in the big workgroup, not three: every mover wave that keeps loads in
                       * flight slows the forward waves' op words down (measured, headline encode: 3+3 -> row pipeline 89 k clocks,
@@ -151,8 +161,11 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
                      /* (2-byte strips: the GATHER, not the forward wave, ends the window -- with work slots of 8 strips a row piece is
                       * 16 bytes of a 128-byte line and the two gather waves are bound by their requests in flight; round 6, NRQ_PROF
                       * marks at K'=56403: forward wave done 77 k clocks before the window's end, gather at its end) */
-                     NGW = NMV >= 6u ? (WB <= NRQ_GATHER_WAVES_NARROW_WB ? NRQ_GATHER_WAVES_NARROW : NRQ_MOVER_WAVES) : NMV >= 3u ? 2u : 1u,
-                     NSW = NMV >= 6u ? NRQ_MOVER_WAVES : NMV - NGW;
+                     /* (12-byte strips: three forward waves leave one SIMD free of them, three waves -- two gathering and one scattering
+                      * ended the forward window at 1.5 x (encode) and 2.7 x (decode) the forward waves' own time at K=10000; so the
+                      * movers are NRQ_W12_GW + NRQ_W12_SW of ALL nine other waves, the free SIMD's first) */
+                     NGW = NFW == 3u ? (uint32_t)NRQ_W12_GW : NMV >= 6u ? (WB <= NRQ_GATHER_WAVES_NARROW_WB ? NRQ_GATHER_WAVES_NARROW : NRQ_MOVER_WAVES) : NMV >= 3u ? 2u : 1u,
+                     NSW = NFW == 3u ? (uint32_t)NRQ_W12_SW : NMV >= 6u ? NRQ_MOVER_WAVES : NMV - NGW;
   static_assert(NMV >= 2u || NT == 64, "workgroup too small for the data movers");
   /* op-word ring of the forward wave(s), in rows: what the variant's register budget holds without spilling */
 #ifndef NRQ_PIPE_SMALL
@@ -259,7 +272,14 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
 #ifndef NRQ_GATHER_LATE_PCT_NARROW
 #define NRQ_GATHER_LATE_PCT_NARROW 15u
 #endif
-      constexpr uint32_t SLATE = WB >= 8 ? NRQ_SCATTER_LATE_PCT : NRQ_SCATTER_LATE_PCT_NARROW, GLATE = WB >= 8 ? NRQ_GATHER_LATE_PCT : NRQ_GATHER_LATE_PCT_NARROW;
+#ifndef NRQ_W12_SLATE
+#define NRQ_W12_SLATE NRQ_SCATTER_LATE_PCT
+#endif
+#ifndef NRQ_W12_GLATE
+#define NRQ_W12_GLATE NRQ_GATHER_LATE_PCT
+#endif
+      constexpr uint32_t SLATE = WB == 12 ? NRQ_W12_SLATE : WB >= 8 ? NRQ_SCATTER_LATE_PCT : NRQ_SCATTER_LATE_PCT_NARROW,
+                         GLATE = WB == 12 ? NRQ_W12_GLATE : WB >= 8 ? NRQ_GATHER_LATE_PCT : NRQ_GATHER_LATE_PCT_NARROW;
       const uint32_t sm = NT > NRQ_HDPC_NT_ ? s1 - (uint32_t)((uint64_t)(s1 - s0) * SLATE / 100u) : s1;
       const uint32_t um = NT > NRQ_HDPC_NT_ ? u1 - (uint32_t)((uint64_t)(u1 - u0) * GLATE / 100u) : u1;
       const uint32_t strip = strip0 + sidx;
@@ -317,6 +337,13 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
         const NRQ_GAS uint32_t *ops_ = c.template arr<uint32_t>(c.h->off_ops);
         if constexpr (G > 1) {
           fwd_rows_wide<G>(ops_, c.h->nrows, tid);
+        } else if constexpr (NFW == 3u) { /* 12-byte strips: a dword of the strip width each */
+          if (wv == 0u) fwd_rows_third<0, RU>(ops_, c.h->nrows, tid);
+          else if (wv == 1u) fwd_rows_third<4, RU>(ops_, c.h->nrows, tid & 63u);
+          else fwd_rows_third<8, RU>(ops_, c.h->nrows, tid & 63u);
+        } else if constexpr (NFW == 2u && WB == 12) { /* 12-byte strips on two waves: dwords 0 and 1, dword 2 */
+          if (wv == 0u) fwd_rows_two_thirds<RU>(ops_, c.h->nrows, tid);
+          else fwd_rows_third<8, RU>(ops_, c.h->nrows, tid & 63u);
         } else if constexpr (NFW == 2u) { /* one half of the strip width each */
           /* (the big workgroup has the registers for the deep ring: 168 per thread) */
           if (wv == 0u) fwd_rows_half<WB, 0, RU>(ops_, c.h->nrows, tid);
@@ -326,15 +353,16 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
         }
         __builtin_amdgcn_s_setprio(0);
         NRQ_MARK(c, 1);
-      } else if ((wv & 3u) >= NFW) { /* the waves that do not share a SIMD with the forward waves; index among them: */
-        const uint32_t mv = (wv >> 2) * (4u - NFW) + (wv & 3u) - NFW;
+      } else if ((wv & 3u) >= NFW || NFW == 3u) { /* the waves that do not share a SIMD with the forward waves; index among them: */
+        const uint32_t mv = NFW == 3u ? ((wv & 3u) == 3u ? (wv >> 2) : (wv >> 2) * 3u + (wv & 3u)) /* (SIMD 3's: 0-2; waves 4-6, 8-10: 3-8) */
+                                      : (wv >> 2) * (4u - NFW) + (wv & 3u) - NFW;
         if (mv < NGW) {
-#ifndef NRQ_EXPERIMENT_NO_MOVERS /* (measurement only: what the forward window costs with no mover traffic beside it; results are garbage) */
+#if !defined(NRQ_EXPERIMENT_NO_MOVERS) && !defined(NRQ_EXPERIMENT_NO_GATHER) /* (measurement only: what the forward window costs with no mover traffic beside it; results are garbage) */
           if (um > u0) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, u0, um, (mv * 64u + (tid & 63u)) / G, (NGW * 64u) / G, subl);
 #endif
           NRQ_MARK_MAX(c, 2);
         } else if (mv < NGW + NSW) {
-#ifndef NRQ_EXPERIMENT_NO_MOVERS
+#if !defined(NRQ_EXPERIMENT_NO_MOVERS) && !defined(NRQ_EXPERIMENT_NO_SCATTER)
           if (sm > s0) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, s0, sm, ((mv - NGW) * 64u + (tid & 63u)) / G, (NSW * 64u) / G, subl);
 #endif
           NRQ_MARK_MAX(c, 3);
@@ -356,7 +384,10 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
 #ifndef NRQ_HDPC_REGS_MAX_WB
 #define NRQ_HDPC_REGS_MAX_WB 4
 #endif
-        if (tid < HNT) { ph_hdpc<WB, G, (NT >= 512 && G == 1 && WB <= NRQ_HDPC_REGS_MAX_WB)>(c, tid / G, HNT / G); }
+#ifndef NRQ_HDPC_REGS_12
+#define NRQ_HDPC_REGS_12 0
+#endif
+        if (tid < HNT) { ph_hdpc<WB, G, (NT >= 512 && G == 1 && (WB <= NRQ_HDPC_REGS_MAX_WB || (WB == 12 && NRQ_HDPC_REGS_12)))>(c, tid / G, HNT / G); }
         else { /* the waves HDPC leaves idle */
           if (u1 > um) pf_gather_impl<WB, G, MPIPE, ALX>(gn, stage_nxt, stage_stride, um, u1, (tid - HNT) / G, (NT - HNT) / G, subl);
           if (s1 > sm) pf_scatter_impl<WB, G, MPIPE, ALX>(gp, ostage_prv, ostage_stride, sm, s1, (tid - HNT) / G, (NT - HNT) / G, subl);
@@ -1015,6 +1046,7 @@ struct Tuning {
   uint32_t small_div = 2;    /* NRQ_SMALL_DIV: LDS images per CU from which the 256-thread variant is used (measured: 2 beats 3) */
   uint64_t solve_grid = 0;   /* NRQ_SOLVE_GRID: persistent workgroups of the solve launch (0 = fill the device) */
   uint32_t max_wb = 16;      /* NRQ_MAX_WB: widest strip considered */
+  bool no_wb12 = false;      /* NRQ_NO_WB12: strip widths 16, 8, 4, 2 only (round 5's set) */
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
   uint32_t encplan_dev_min_l = 12000; /* NRQ_ENCPLAN_DEV_MIN_L: from this many intermediate symbols on, encode plans are built by
                               * the device planner, asynchronously (the host planner takes 25 ms at K=27000, 95 ms at K'=56403) */
@@ -1054,7 +1086,7 @@ struct Tuning {
     wide_g = (uint32_t)num("NRQ_WIDE_G", 0);
     if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
     no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 7); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 7);
-    no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); no_lists = flag("NRQ_NO_LISTS"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
+    no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); no_lists = flag("NRQ_NO_LISTS"); no_wb12 = flag("NRQ_NO_WB12"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
     plan_small_state = !flag("NRQ_PLAN_BIG_STATE"); plan_no_wg128 = flag("NRQ_PLAN_NO_WG128");
   }
@@ -1082,7 +1114,7 @@ struct nrq_ctx {
   nrq_call_stats stats;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   hipEvent_t encplan_uploaded = nullptr;
-  bool attr_set[4] = {false, false, false, false};
+  bool attr_set[5] = {false, false, false, false, false};
   /* optional per-launch timing of the solve kernel (HIP events on the launch stream) */
   bool ktime_on = false;
   bool ktime_outer = false; /* the solve launches in flight are bracketed by their caller's pair of events */
@@ -1546,11 +1578,11 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   const bool split = WB <= 4 && !ctx->tune.no_split;
   const uint32_t res_elems = max_out; /* rows nrq_collect_kernel writes per block at most */
   if (split) max_out = max_slots + max_u;
-  const uint32_t nstrips = (T + WBE - 1) / WBE, spl = WBE >= 128u ? 1u : 128u / WBE;
+  const uint32_t nstrips = (T + WBE - 1) / WBE, spl = nrq_group_strips(WBE);
   const bool by_block = nrq_map_by_block(nblk) && !ctx->tune.map_spread;
   /* workgroup shape: the full-size workgroup when a strip image needs more than half of the CU's LDS, 256-thread ones
    * when two or more fit */
-  const bool small = lds_alloc(lds_bytes) * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg;
+  const bool small = WB != 12 && lds_alloc(lds_bytes) * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg; /* (12-byte strips: big blocks) */
   /* single-wave workgroups when 12 or more images fit a CU (see the kernel; K=256: +26 % over five 256-thread workgroups) */
   const uint32_t tdiv = hdrs.size() > 1u ? ctx->tune.tiny_div_dec : ctx->tune.tiny_div;
   const bool tiny = G == 1 && small && (uint64_t)lds_alloc(lds_bytes) * tdiv <= NRQ_LDS_MAX && !ctx->tune.no_tiny;
@@ -1635,9 +1667,11 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)NRQ_LDS_MAX))
     NRQ_SET_LDS_ATTR(WB, NRQ_WG, 1, 1, false); NRQ_SET_LDS_ATTR(WB, NRQ_WG, 1, 1, true);
+    if constexpr (WB != 12) {
     NRQ_SET_LDS_ATTR(WB, 256, NRQ_SMALL_WV, 1, false);    NRQ_SET_LDS_ATTR(WB, 256, NRQ_SMALL_WV, 1, true);
     NRQ_SET_LDS_ATTR(WB, 256, 5, 1, false);    NRQ_SET_LDS_ATTR(WB, 256, 5, 1, true);
     NRQ_SET_LDS_ATTR(WB, 64, NRQ_TINY_WV, 1, false);     NRQ_SET_LDS_ATTR(WB, 64, NRQ_TINY_WV, 1, true);
+    }
 #undef NRQ_SET_LDS_ATTR
     if constexpr (WB == 16) {
       HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nrq_solve_kernel<16, 256, 4, 2>),
@@ -1676,12 +1710,14 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   else if (WB == 16 && G == 4) { if constexpr (WB == 16) NRQ_LAUNCH_WIDE(4); }
   else if (WB == 16 && G == 2) { if constexpr (WB == 16) NRQ_LAUNCH_WIDE(2); }
   else {
-    const bool al = ctx->io_aligned && G == 1 && WB >= 4 && T % (uint32_t)WB == 0u; /* (the movers' aligned-only form) */
+    /* (the movers' aligned-only form; 12-byte strips: whole dwords, solve_body.h g_get_al12) */
+    const bool al = ctx->io_aligned && G == 1 && WB >= 4 && T % (uint32_t)(WB == 12 ? 4 : WB) == 0u;
 #define NRQ_LAUNCH(NTT, WVV, ALL)                                                                                                        \
   hipLaunchKernelGGL((nrq_solve_kernel<WB, NTT, WVV, 1, ALL>), dim3((uint32_t)grid), dim3(NTT), lds_bytes, ctx->stream, d_jobs, nblk, T, nstrips, \
                      by_block ? 1u : 0u, (uint32_t)nslots, lsub, d_kc, (uint8_t *)ctx->stage.p, stage_stride, ostage_stride, ctx->prof, ybuf,   \
                      ybuf_stride)
-    if (tiny) { if (al) NRQ_LAUNCH(64, NRQ_TINY_WV, true); else NRQ_LAUNCH(64, NRQ_TINY_WV, false); }
+    if constexpr (WB == 12) { if (al) NRQ_LAUNCH(NRQ_WG, 1, true); else NRQ_LAUNCH(NRQ_WG, 1, false); }
+    else if (tiny) { if (al) NRQ_LAUNCH(64, NRQ_TINY_WV, true); else NRQ_LAUNCH(64, NRQ_TINY_WV, false); }
     else if (five) { if (al) NRQ_LAUNCH(256, 5, true); else NRQ_LAUNCH(256, 5, false); }
     else if (small) { if (al) NRQ_LAUNCH(256, NRQ_SMALL_WV, true); else NRQ_LAUNCH(256, NRQ_SMALL_WV, false); }
     else { if (al) NRQ_LAUNCH(NRQ_WG, 1, true); else NRQ_LAUNCH(NRQ_WG, 1, false); }
@@ -1770,6 +1806,7 @@ static int launch_list(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hd
   }
   switch (wb) {
     case 16: return launch_wb<16>(ctx, 0, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr, hdrs);
+    case 12: return launch_wb<12>(ctx, 4, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr, hdrs);
     case 8: return launch_wb<8>(ctx, 1, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr, hdrs);
     case 4: return launch_wb<4>(ctx, 2, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr, hdrs);
     default: return launch_wb<2>(ctx, 3, d_jobs, nblk, T, d_kc, need, max_slots, max_out, max_u, max_wpr, hdrs);
@@ -1777,9 +1814,12 @@ static int launch_list(nrq_ctx *ctx, const std::vector<const nrq_plan_hdr *> &hd
 }
 /* widest width at which the image of h fits the LDS (0: none) and its size there */
 static uint32_t widest_fit(const nrq_ctx *ctx, const nrq_plan_hdr *h, uint32_t *need) {
-  static const uint32_t widths[4] = {16, 8, 4, 2};
-  for (int s = 0; s < 4; s++) {
+  /* (12 bytes: between the 16-byte image's limit, K ~ 8500, and ~12000; below, a block that does not fit 16 bytes is the odd one
+   * of its batch -- a decode plan with many inactive columns -- and goes on the second list at 12 as well) */
+  static const uint32_t widths[5] = {16, 12, 8, 4, 2};
+  for (int s = 0; s < 5; s++) {
     if (widths[s] > ctx->tune.max_wb) continue;
+    if (widths[s] == 12u && ctx->tune.no_wb12) continue;
     const uint32_t t = nrq_lds_plan(h, widths[s]).total;
     if (t <= ctx->tune.lds_max) { *need = t; return widths[s]; }
   }
@@ -2068,6 +2108,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "tiny_div_dec") t.tiny_div_dec = (uint32_t)value;
   else if (n == "no_balance") t.no_balance = value != 0;
   else if (n == "no_lists") t.no_lists = value != 0;
+  else if (n == "no_wb12") t.no_wb12 = value != 0;
   else if (n == "lds_max") t.lds_max = value > 0 && value <= (long long)NRQ_LDS_MAX ? (uint32_t)value : NRQ_LDS_MAX;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
   else if (n == "no_plan_split") t.no_plan_split = value != 0;

@@ -109,6 +109,16 @@ template <int WB> struct SV {
   uint32_t w[ND];
 };
 
+/* a strip element's natural alignment: its width, 4 bytes for the 12-byte strip (three dwords; round 6: K ~ 8500-12000, whose
+ * 16-byte image does not fit the LDS) */
+template <int WB> struct SVAlign { static constexpr uintptr_t mask = (uintptr_t)(WB == 12 ? 3 : WB - 1); };
+struct nrq_u3 { uint32_t x, y, z; };
+/* strips that make a line group (staging buffers per set; the largest work slot): the strips that share a 128-byte line of a
+ * row -- 8 for the 12-byte strip (a power of two: 96 bytes of every row, so a line is shared by the groups either side) */
+#ifndef NRQ_W12_GROUP
+#define NRQ_W12_GROUP 8u
+#endif
+SB_HD constexpr uint32_t nrq_group_strips(uint32_t wbe) { return wbe >= 128u ? 1u : wbe == 12u ? NRQ_W12_GROUP : 128u / wbe; }
 template <int WB> SB_HD SV<WB> sv_zero() {
   SV<WB> r;
 #pragma unroll
@@ -174,6 +184,9 @@ template <int WB, int G = 1> SB_HD SV<WB> lds_get(const uint8_t *lds, uint32_t i
     const uint4 *p = reinterpret_cast<const uint4 *>(lds) + (size_t)idx * G;
     uint4 v = *p;
     r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  } else if constexpr (WB == 12) {
+    const nrq_u3 v = reinterpret_cast<const nrq_u3 *>(lds)[idx];
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z;
   } else if constexpr (WB == 8) {
     const uint2 *p = reinterpret_cast<const uint2 *>(lds) + idx;
     uint2 v = *p;
@@ -190,6 +203,9 @@ template <int WB, int G = 1> SB_HD void lds_put(uint8_t *lds, uint32_t idx, cons
   if constexpr (WB == 16) {
     uint4 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2]; t.w = v.w[3];
     reinterpret_cast<uint4 *>(lds)[(size_t)idx * G] = t;
+  } else if constexpr (WB == 12) {
+    nrq_u3 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2];
+    reinterpret_cast<nrq_u3 *>(lds)[idx] = t;
   } else if constexpr (WB == 8) {
     uint2 t; t.x = v.w[0]; t.y = v.w[1];
     reinterpret_cast<uint2 *>(lds)[idx] = t;
@@ -207,6 +223,9 @@ template <int WB, int G = 1> SB_HD void lds_xor(uint8_t *lds, uint32_t idx, cons
     unsigned long long *p = reinterpret_cast<unsigned long long *>(lds) + 2 * (size_t)idx * G;
     atomicXor(p, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32));
     atomicXor(p + 1, (unsigned long long)v.w[2] | ((unsigned long long)v.w[3] << 32));
+  } else if constexpr (WB == 12) { /* (slots on 4-byte boundaries: three 32-bit atomics) */
+    unsigned int *p = reinterpret_cast<unsigned int *>(lds) + 3 * (size_t)idx;
+    atomicXor(p, v.w[0]); atomicXor(p + 1, v.w[1]); atomicXor(p + 2, v.w[2]);
   } else if constexpr (WB == 8) {
     unsigned long long *p = reinterpret_cast<unsigned long long *>(lds) + idx;
     atomicXor(p, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32));
@@ -225,10 +244,13 @@ template <int WB, int G = 1> SB_HD void lds_xor(uint8_t *lds, uint32_t idx, cons
 /* ---- global strip access: `valid` bytes (<= WB) at p ---- */
 template <int WB> SB_HD SV<WB> g_get(const NRQ_GAS uint8_t *p, uint32_t valid) {
   SV<WB> r = sv_zero<WB>();
-  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
+  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & SVAlign<WB>::mask) == 0) {
     if constexpr (WB == 16) {
       uint4 v = *reinterpret_cast<const NRQ_GAS uint4 *>(p);
       r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    } else if constexpr (WB == 12) {
+      const NRQ_GAS uint32_t *q = reinterpret_cast<const NRQ_GAS uint32_t *>(p);
+      r.w[0] = q[0]; r.w[1] = q[1]; r.w[2] = q[2];
     } else if constexpr (WB == 8) {
       uint2 v = *reinterpret_cast<const NRQ_GAS uint2 *>(p);
       r.w[0] = v.x; r.w[1] = v.y;
@@ -254,6 +276,11 @@ template <int WB> SB_HD SV<WB> g_get_l2(const NRQ_GAS uint8_t *p) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     const u4 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u4 *>(p));
     r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  } else if constexpr (WB == 12) {
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    typedef u3 u3a __attribute__((aligned(4)));
+    const u3 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u3a *>(p));
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z;
   } else if constexpr (WB == 8) {
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
     const u2 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u2 *>(p));
@@ -293,10 +320,13 @@ template <int CB, int AL> SB_HD SV<CB> g_get_chunk(const NRQ_GAS uint8_t *p) {
 #endif
 }
 template <int WB> SB_HD void g_put(NRQ_GAS uint8_t *p, uint32_t valid, const SV<WB> &v) {
-  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
+  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & SVAlign<WB>::mask) == 0) {
     if constexpr (WB == 16) {
       uint4 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2]; t.w = v.w[3];
       *reinterpret_cast<NRQ_GAS uint4 *>(p) = t;
+    } else if constexpr (WB == 12) {
+      NRQ_GAS uint32_t *q = reinterpret_cast<NRQ_GAS uint32_t *>(p);
+      q[0] = v.w[0]; q[1] = v.w[1]; q[2] = v.w[2];
     } else if constexpr (WB == 8) {
       uint2 t; t.x = v.w[0]; t.y = v.w[1];
       *reinterpret_cast<NRQ_GAS uint2 *>(p) = t;
@@ -312,10 +342,33 @@ template <int WB> SB_HD void g_put(NRQ_GAS uint8_t *p, uint32_t valid, const SV<
   }
 }
 
+/* 12-byte strips, the movers' aligned form: T a multiple of 4 and rows on 4-byte boundaries, so a strip element is 1-3 whole
+ * dwords (T = 1280: the 107th strip holds 8 bytes).  Branch-free: a dword beyond `valid` re-reads the first and is dropped. */
+SB_HD SV<12> g_get_al12(const NRQ_GAS uint8_t *p, uint32_t valid) {
+  const NRQ_GAS uint32_t *q = reinterpret_cast<const NRQ_GAS uint32_t *>(p);
+  SV<12> r = sv_zero<12>();
+  const bool h1 = valid > 4u, h2 = valid > 8u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + (h1 ? 1 : 0)), c = __builtin_nontemporal_load(q + (h2 ? 2 : 0));
+#else
+  const uint32_t a = q[0], b = q[h1 ? 1 : 0], c = q[h2 ? 2 : 0];
+#endif
+  r.w[0] = a; r.w[1] = h1 ? b : 0u; r.w[2] = h2 ? c : 0u;
+  return r;
+}
+SB_HD void g_put_al12(NRQ_GAS uint8_t *p, uint32_t valid, const SV<12> &v) {
+  NRQ_GAS uint32_t *q = reinterpret_cast<NRQ_GAS uint32_t *>(p);
+  q[0] = v.w[0];
+  if (valid > 4u) q[1] = v.w[1];
+  if (valid > 8u) q[2] = v.w[2];
+}
 template <int WB> SB_HD void g_put_al(NRQ_GAS uint8_t *p, const SV<WB> &v) { /* a whole, aligned strip element */
   if constexpr (WB == 16) {
     uint4 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2]; t.w = v.w[3];
     *reinterpret_cast<NRQ_GAS uint4 *>(p) = t;
+  } else if constexpr (WB == 12) {
+    NRQ_GAS uint32_t *q = reinterpret_cast<NRQ_GAS uint32_t *>(p);
+    q[0] = v.w[0]; q[1] = v.w[1]; q[2] = v.w[2];
   } else if constexpr (WB == 8) {
     uint2 t; t.x = v.w[0]; t.y = v.w[1];
     *reinterpret_cast<NRQ_GAS uint2 *>(p) = t;
@@ -330,12 +383,17 @@ template <int WB> SB_HD void g_put_al(NRQ_GAS uint8_t *p, const SV<WB> &v) { /* 
  * they do not push the plans -- read over and over by every strip of a block -- out of L2. */
 template <int WB> SB_HD SV<WB> g_get_stream(const NRQ_GAS uint8_t *p, uint32_t valid) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
+  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & SVAlign<WB>::mask) == 0) {
     SV<WB> r = sv_zero<WB>();
     if constexpr (WB == 16) {
       typedef uint32_t u4 __attribute__((ext_vector_type(4)));
       const u4 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u4 *>(p));
       r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    } else if constexpr (WB == 12) {
+      typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+      typedef u3 u3a __attribute__((aligned(4)));
+      const u3 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u3a *>(p));
+      r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z;
     } else if constexpr (WB == 8) {
       typedef uint32_t u2 __attribute__((ext_vector_type(2)));
       const u2 v = __builtin_nontemporal_load(reinterpret_cast<const NRQ_GAS u2 *>(p));
@@ -352,11 +410,16 @@ template <int WB> SB_HD SV<WB> g_get_stream(const NRQ_GAS uint8_t *p, uint32_t v
 }
 template <int WB> SB_HD void g_put_stream(NRQ_GAS uint8_t *p, uint32_t valid, const SV<WB> &v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(WB - 1)) == 0) {
+  if (valid == (uint32_t)WB && (reinterpret_cast<uintptr_t>(p) & SVAlign<WB>::mask) == 0) {
     if constexpr (WB == 16) {
       typedef uint32_t u4 __attribute__((ext_vector_type(4)));
       const u4 t = {v.w[0], v.w[1], v.w[2], v.w[3]};
       __builtin_nontemporal_store(t, reinterpret_cast<NRQ_GAS u4 *>(p));
+    } else if constexpr (WB == 12) {
+      typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+      typedef u3 u3a __attribute__((aligned(4)));
+      const u3 t = {v.w[0], v.w[1], v.w[2]};
+      __builtin_nontemporal_store(t, reinterpret_cast<NRQ_GAS u3a *>(p));
     } else if constexpr (WB == 8) {
       typedef uint32_t u2 __attribute__((ext_vector_type(2)));
       const u2 t = {v.w[0], v.w[1]};
@@ -387,7 +450,7 @@ SB_HD nrq_lds_layout nrq_lds_plan(const nrq_plan_hdr *h, uint32_t WB) {
   l.off_cu = o;    o = nrq_r16(o + (h->u ? h->u : 1u) * WB);
   /* region X: the free-column accumulators Cf during the dense stage, then the 4-bit XOR tables */
   uint32_t cf = NRQ_MAX_FREE * WB;
-  uint32_t t4 = h->wpr * 8u * 16u * WB;
+  uint32_t t4 = h->wpr * 8u * 16u * (WB == 12u ? 16u : WB); /* (12-byte strips: entries on 16-byte boundaries, one LDS read each) */
   l.off_x = o;
   o = nrq_r16(o + (cf > t4 ? cf : t4));
   l.total = o;
@@ -511,11 +574,17 @@ template <int WB, int CB, bool PIPELINED> SB_HD void pf_gather_chunks(const Grou
 #ifndef NRQ_GATHER_CHUNKS
 #define NRQ_GATHER_CHUNKS 1
 #endif
-template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_gather_impl(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
+/* AL: 0 byte-wise, 1 whole aligned elements, 2 (12-byte strips) whole dwords of an element that may end early -- the form of the
+ * one line group that holds a row's last, partial strip (T = 1280: 106 strips and 8 bytes); a request per dword there, one per
+ * element everywhere else (every request of a wave touches 64 lines: the CU's cache looks up a line per clock) */
+template <int WB, int G, bool PIPELINED, int AL> SB_HD void pf_gather_impl(const GroupSrc<WB> &g, NRQ_GAS uint8_t *stage, size_t stage_stride, uint32_t u0, uint32_t u1,
                                        uint32_t p, uint32_t np, uint32_t sub) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u; /* unit u = (row u >> lsub, piece u & pmask) */
+  if constexpr (WB == 12 && AL == 1) {
+    if ((g.strip0 + (1u << lsub)) * 12u > g.T) { pf_gather_impl<WB, G, PIPELINED, 2>(g, stage, stage_stride, u0, u1, p, np, sub); return; }
+  }
 #if NRQ_GATHER_CHUNKS
-  if constexpr (G == 1 && WB < 16) {
+  if constexpr (G == 1 && WB < 16 && WB != 12) {
     const uint32_t span = (uint32_t)WB << lsub, cb = span >= 16u ? 16u : span; /* bytes of a row that a line group holds; of a chunk */
     const bool whole = cb > (uint32_t)WB && g.T % cb == 0u &&
                        ((reinterpret_cast<uintptr_t>(g.src) | reinterpret_cast<uintptr_t>(g.rep)) & (uintptr_t)(WB - 1)) == 0;
@@ -532,7 +601,10 @@ template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_gather_impl(cons
 #ifndef NRQ_GATHER_PB
 #define NRQ_GATHER_PB 4
 #endif
-  constexpr int PB = NRQ_GATHER_PB; /* requests in flight per thread and stage: few -- a deep queue of gather requests in the CU's
+#ifndef NRQ_W12_GATHER_PB
+#define NRQ_W12_GATHER_PB NRQ_GATHER_PB
+#endif
+  constexpr int PB = WB == 12 ? NRQ_W12_GATHER_PB : NRQ_GATHER_PB; /* requests in flight per thread and stage: few -- a deep queue of gather requests in the CU's
                                      * memory pipeline delays the op words wave 0 is waiting for */
   if constexpr (!PIPELINED) { /* the register-lean form (the 256- and 64-thread workgroups: 96-128 registers per thread) */
   for (uint32_t base = u0 + p; base < u1; base += PB * np) {
@@ -549,7 +621,10 @@ template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_gather_impl(cons
         v[q] = sv_zero<WB>();
         if (s[q] != NRQ_ROW_ZERO && strip < g.nstrips) {
           const NRQ_GAS uint8_t *b = (s[q] & NRQ_ROW_REP) ? g.rep + (size_t)(s[q] & 0x7FFFFFFFu) * g.T : g.src + (size_t)s[q] * g.T;
-          if constexpr (AL) {
+          if constexpr (AL == 2) {
+            const uint32_t rem = g.T - strip * WB;
+            v[q] = g_get_al12(b + (size_t)strip * WB, rem < 12u ? rem : 12u);
+          } else if constexpr (AL == 1) {
             v[q] = g_get_l2<WB>(b + (size_t)strip * WB);
           } else if constexpr (G == 1) {
             const uint32_t rem = g.T - strip * WB;
@@ -578,7 +653,10 @@ template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_gather_impl(cons
     SV<WB> v = sv_zero<WB>();
     if (u < u1 && src != NRQ_ROW_ZERO && strip < g.nstrips) {
       const NRQ_GAS uint8_t *b = (src & NRQ_ROW_REP) ? g.rep + (size_t)(src & 0x7FFFFFFFu) * g.T : g.src + (size_t)src * g.T;
-      if constexpr (AL) {
+      if constexpr (AL == 2) {
+        const uint32_t rem = g.T - strip * WB;
+        v = g_get_al12(b + (size_t)strip * WB, rem < 12u ? rem : 12u);
+      } else if constexpr (AL == 1) {
         v = g_get_l2<WB>(b + (size_t)strip * WB);
       } else if constexpr (G == 1) {
         const uint32_t rem = g.T - strip * WB;
@@ -625,7 +703,7 @@ template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_gather(const 
                                        uint32_t p, uint32_t np, uint32_t sub = 0) {
 #ifndef NRQ_NO_AL
   if constexpr (G == 1 && WB >= 4) {
-    const bool al = g.T % (uint32_t)WB == 0u && ((reinterpret_cast<uintptr_t>(g.src) | reinterpret_cast<uintptr_t>(g.rep)) & (uintptr_t)(WB - 1)) == 0;
+    const bool al = g.T % (uint32_t)(WB == 12 ? 4 : WB) == 0u && ((reinterpret_cast<uintptr_t>(g.src) | reinterpret_cast<uintptr_t>(g.rep)) & SVAlign<WB>::mask) == 0;
     if (al) { pf_gather_impl<WB, G, PIPELINED, true>(g, stage, stage_stride, u0, u1, p, np, sub); return; }
   }
 #endif
@@ -678,12 +756,22 @@ template <> struct RowVal<2> { typedef uint32_t type; };
 template <int WB> __device__ __forceinline__ uint32_t row_addr_hi(uint32_t op) { /* (op >> 16) * WB */
   constexpr uint32_t sh = WB == 16 ? 4 : WB == 8 ? 3 : WB == 4 ? 2 : 1;
   uint32_t r, s = sh;
+  if constexpr (WB == 12) { /* (no shift does it: the 24-bit multiply has the same sub-dword operand select) */
+    s = 12u;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(op));
+    return r;
+  }
   asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(op));
   return r;
 }
 template <int WB> __device__ __forceinline__ uint32_t row_addr_lo(uint32_t op) { /* (op & 0xFFFF) * WB */
   constexpr uint32_t sh = WB == 16 ? 4 : WB == 8 ? 3 : WB == 4 ? 2 : 1;
   uint32_t r, s = sh;
+  if constexpr (WB == 12) {
+    s = 12u;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(op));
+    return r;
+  }
   asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(op));
   return r;
 }
@@ -706,6 +794,9 @@ template <int WB, class V> __device__ __forceinline__ void row_apply_at(uint32_t
     const u2 lo = {v.x, v.y}, hi = {v.z, v.w};
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a + 8u), __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else if constexpr (sizeof(V) == 8 && WB == 12) { /* (two dwords of a slot that starts on any dword: no 64-bit atomic there) */
+    __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a), v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_xor(NRQ_LDSP(unsigned int, a + 4u), v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   } else if constexpr (sizeof(V) == 8) {
     __hip_atomic_fetch_xor(NRQ_LDSP(unsigned long long, a), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   } else if constexpr (WB >= 4) {
@@ -754,6 +845,7 @@ template <int WB, int OFF, class V, uint32_t U> __device__ __forceinline__ void 
       NRQ_SCHED_FENCE();
       row_apply_at<WB, V>(a_dst, v[(k + NS - P) % NS]);
       if constexpr (sizeof(V) == 4 && WB == 2 && OFF == 0) v[k % NS] = *NRQ_LDSP(uint16_t, a_src);
+      else if constexpr (sizeof(V) == 8 && WB == 12) { typedef V Va __attribute__((aligned(4))); v[k % NS] = *NRQ_LDSP(Va, a_src); } /* (ds_read2_b32) */
       else v[k % NS] = *NRQ_LDSP(V, a_src);
 #ifndef NRQ_EXPERIMENT_NO_OPLOAD /* (measurement only: the loop on the first ring's words for ever -- no vector memory load in it) */
       if (j % 4u == 3u) { /* the quad's last row has been applied: the rows it holds next (this trip's if still ahead, k < P) */
@@ -777,6 +869,15 @@ template <> struct HalfVal<8> { typedef uint32_t type; };
 template <int WB, int OFF, uint32_t U = NRQ_RING> __device__ __forceinline__ void fwd_rows_half(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
   static_assert(WB == 16 || WB == 8, "half-width pipeline: 16- and 8-byte strips only");
   fwd_rows_impl<WB, OFF, typename HalfVal<WB>::type, U>(ops, nrows, lane);
+}
+/* ... and on a THIRD of the 12-byte strip (bytes [OFF, OFF + 4) of every slot): three waves, a dword each.  A 12-byte slot starts on
+ * any dword, so the 64 lanes' dwords spread over all 64 LDS banks (the 8-byte halves of 16-byte slots reach 32 of them). */
+template <int OFF, uint32_t U = NRQ_RING> __device__ __forceinline__ void fwd_rows_third(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
+  fwd_rows_impl<12, OFF, uint32_t, U>(ops, nrows, lane);
+}
+template <uint32_t U = NRQ_RING> __device__ __forceinline__ void fwd_rows_two_thirds(const NRQ_GAS uint32_t *ops, uint32_t nrows, uint32_t lane) {
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  fwd_rows_impl<12, 0, u2, U>(ops, nrows, lane);
 }
 /* The op stream TRANSPOSED and in reverse: row by row from the last to the first, every op dst ^= src becomes
  * slot(src) ^= slot(dst).  With z = one 16-byte value per slot this computes z <- z * X^-1 for the row vector z (the forward
@@ -892,6 +993,8 @@ template <int WB> SB_HD SV<WB> row_zero() { return sv_zero<WB>(); }
  * their own row loops over ph_row_read / ph_row_apply) */
 template <int WB, uint32_t U = NRQ_RING> SB_HD void fwd_rows(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
 template <int WB, int OFF, uint32_t U = NRQ_RING> SB_HD void fwd_rows_half(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
+template <int OFF, uint32_t U = NRQ_RING> SB_HD void fwd_rows_third(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
+template <uint32_t U = NRQ_RING> SB_HD void fwd_rows_two_thirds(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
 template <int WB> SB_HD void rev_rows(const NRQ_GAS uint32_t *, uint32_t, uint32_t) {}
 #endif
 
@@ -1338,6 +1441,22 @@ template <int WB, int G = 1, bool BATCH = false> SB_HD void ph_dense_cu(const St
   for (uint32_t f = tid; f < c.h->nfree; f += nt) lds_put<WB, G>(c.cu(), (BATCH && f == tid) ? fx0 : (uint32_t)freex[f], lds_get<WB, G>(c.cf(), f));
 }
 
+/* table entry e of the back-substitution tables.  12-byte strips keep them 16 bytes apart: an entry is then ONE 16-byte LDS read at
+ * an aligned address (as three dwords, two read instructions, a lookup cost 7.7 clocks against 5.6 on the 16-byte strip) */
+template <int WB, int G = 1> SB_HD SV<WB> t4_get(const uint8_t *t4, uint32_t e) {
+  if constexpr (WB == 12) {
+    SV<12> r = sv_zero<12>();
+    const uint4 v = reinterpret_cast<const uint4 *>(t4)[e];
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z;
+    return r;
+  } else return lds_get<WB, G>(t4, e);
+}
+template <int WB, int G = 1> SB_HD void t4_put(uint8_t *t4, uint32_t e, const SV<WB> &v) {
+  if constexpr (WB == 12) {
+    uint4 t; t.x = v.w[0]; t.y = v.w[1]; t.z = v.w[2]; t.w = 0u;
+    reinterpret_cast<uint4 *>(t4)[e] = t;
+  } else lds_put<WB, G>(t4, e, v);
+}
 /* phase 5a: 16-entry XOR tables over groups of 4 inactive columns (region X is reused) */
 template <int WB, int G = 1> SB_HD void ph_tables(const StripCtx<WB, G> &c, uint32_t tid, uint32_t nt) {
   const uint32_t ngroups = c.h->wpr * 8u, u = c.h->u;
@@ -1352,7 +1471,7 @@ template <int WB, int G = 1> SB_HD void ph_tables(const StripCtx<WB, G> &c, uint
         sv_xor<WB>(v, t);
       }
     }
-    lds_put<WB, G>(c.t4(), e, v);
+    t4_put<WB, G>(c.t4(), e, v);
   }
 }
 
@@ -1419,11 +1538,31 @@ SB_HD void backsub_one(const StripCtx<WB, G> &c, const uint8_t *t4, uint32_t slo
       NRQ_SCHED_FENCE();
       continue;
     }
+    if constexpr (WB == 12 && G == 1) {
+      /* 12-byte strips: entries 16 bytes apart (t4_get), looked up like the 16-byte strip's */
+      uint32_t odd = bits & 0xF0F0F0F0u, even = (bits << 4) & 0xF0F0F0F0u;
+      asm volatile("" : "+v"(odd), "+v"(even));
+      const uint32_t tbw = (uint32_t)(uintptr_t)t4 + w * 2048u;
+      uint4 d[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) d[q] = *NRQ_LDSP(uint4, t4_addr(tbw, (q & 1u) ? odd : even, q >> 1) + q * 256u);
+      uint32_t pad = 0; /* (the entries' fourth dword, zero: used, so that the read stays a ds_read_b128 -- left to itself the compiler
+                         * narrows it to ds_read_b96, which this LDS serves at half the rate: the phase took 116 k clocks against
+                         * 68 k with three dword reads per entry) */
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q += 2) {
+        acc.w[0] = nrq_xor3(acc.w[0], d[q].x, d[q + 1].x); acc.w[1] = nrq_xor3(acc.w[1], d[q].y, d[q + 1].y);
+        acc.w[2] = nrq_xor3(acc.w[2], d[q].z, d[q + 1].z); pad = nrq_xor3(pad, d[q].w, d[q + 1].w);
+      }
+      asm volatile("" : : "v"(pad));
+      NRQ_SCHED_FENCE();
+      continue;
+    }
 #endif
 #pragma unroll
     for (uint32_t q = 0; q < 8; q++) {
       const uint32_t nib = (bits >> (4u * q)) & 15u;
-      SV<WB> t = lds_get<WB, G>(t4, (w * 8u + q) * 16u + nib);
+      SV<WB> t = t4_get<WB, G>(t4, (w * 8u + q) * 16u + nib);
       sv_xor<WB>(acc, t);
       if (q == 3) NRQ_SCHED_FENCE(); /* 4 lookups in flight are enough; hoisting all NW*8 of them costs ~100 more registers */
     }
@@ -1502,7 +1641,7 @@ template <int WB, int G = 1, bool FAST = true> SB_HD void ph_backsub(const Strip
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
           uint32_t nib = (bits >> (4u * q)) & 15u;
-          SV<WB> t = lds_get<WB, G>(t4, (w * 8u + q) * 16u + nib);
+          SV<WB> t = t4_get<WB, G>(t4, (w * 8u + q) * 16u + nib);
           sv_xor<WB>(acc, t);
         }
       }
@@ -1675,16 +1814,22 @@ template <int WB> struct GroupDst {
   uint32_t lsub;
 };
 /* units [u0, u1) of the scatter, unit = (staged element, piece of the line): whole lines to the symbol rows */
-template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_scatter_impl(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
+template <int WB, int G, bool PIPELINED, int AL> SB_HD void pf_scatter_impl(const GroupDst<WB> &g, const NRQ_GAS uint8_t *ostage, size_t stage_stride, uint32_t u0,
                                         uint32_t u1, uint32_t p, uint32_t np, uint32_t sub) {
   const uint32_t lsub = g.lsub, pmask = (1u << lsub) - 1u;
+  if constexpr (WB == 12 && AL == 1) { /* (the line group with the row's last, partial strip: pf_gather_impl) */
+    if ((g.strip0 + (1u << lsub)) * 12u > g.T) { pf_scatter_impl<WB, G, PIPELINED, 2>(g, ostage, stage_stride, u0, u1, p, np, sub); return; }
+  }
 #ifndef NRQ_SCATTER_PB
 #define NRQ_SCATTER_PB 4
 #endif
 #ifndef NRQ_SCATTER_PUT
 #define NRQ_SCATTER_PUT g_put
 #endif
-  constexpr int PB = NRQ_SCATTER_PB;
+#ifndef NRQ_W12_SCATTER_PB
+#define NRQ_W12_SCATTER_PB NRQ_SCATTER_PB
+#endif
+  constexpr int PB = WB == 12 ? NRQ_W12_SCATTER_PB : NRQ_SCATTER_PB;
   if constexpr (!PIPELINED) {
   for (uint32_t base = u0 + p; base < u1; base += PB * np) {
       SV<WB> v[PB];
@@ -1699,8 +1844,9 @@ template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_scatter_impl(con
       for (int q = 0; q < PB; q++) {
         const uint32_t u = base + (uint32_t)q * np, i = u >> lsub, strip = g.strip0 + (u & pmask);
         if (u >= u1 || strip >= g.nstrips) continue;
-        if constexpr (AL) {
-          g_put_al<WB>((i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB, v[q]);
+        if constexpr (AL != 0) {
+          if constexpr (AL == 2) { const uint32_t rem = g.T - strip * WB; g_put_al12((i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB, rem < 12u ? rem : 12u, v[q]); }
+          else g_put_al<WB>((i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB, v[q]);
         } else if constexpr (G == 1) {
           const uint32_t rem = g.T - strip * WB;
           NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB;
@@ -1737,8 +1883,9 @@ template <int WB, int G, bool PIPELINED, bool AL> SB_HD void pf_scatter_impl(con
     for (int q = 0; q < PB; q++) {
       const uint32_t u = base + (uint32_t)q * np, i = u >> lsub, strip = g.strip0 + (u & pmask);
       if (u >= u1 || strip >= g.nstrips) continue;
-      if constexpr (AL) {
-        g_put_al<WB>((i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB, v[q]);
+      if constexpr (AL != 0) {
+        if constexpr (AL == 2) { const uint32_t rem = g.T - strip * WB; g_put_al12((i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB, rem < 12u ? rem : 12u, v[q]); }
+        else g_put_al<WB>((i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB, v[q]);
       } else if constexpr (G == 1) {
         const uint32_t rem = g.T - strip * WB;
         NRQ_GAS uint8_t *dst = (i < g.ni ? g.inter : g.out) + (size_t)row[q] * g.T + (size_t)strip * WB;
@@ -1760,7 +1907,7 @@ template <int WB, int G = 1, bool PIPELINED = false> SB_HD void pf_scatter(const
                                         uint32_t u1, uint32_t p, uint32_t np, uint32_t sub = 0) {
 #ifndef NRQ_NO_AL
   if constexpr (G == 1 && WB >= 4) {
-    const bool al = g.T % (uint32_t)WB == 0u && ((reinterpret_cast<uintptr_t>(g.inter) | reinterpret_cast<uintptr_t>(g.out)) & (uintptr_t)(WB - 1)) == 0;
+    const bool al = g.T % (uint32_t)(WB == 12 ? 4 : WB) == 0u && ((reinterpret_cast<uintptr_t>(g.inter) | reinterpret_cast<uintptr_t>(g.out)) & SVAlign<WB>::mask) == 0;
     if (al) { pf_scatter_impl<WB, G, PIPELINED, true>(g, ostage, stage_stride, u0, u1, p, np, sub); return; }
   }
 #endif

@@ -59,7 +59,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
 #define PHASE(fn) for (uint32_t t = 0; t < NT; t++) fn<WB>(c, t, NT)
   { /* the way the persistent kernel fills the image: the gathering threads bring the whole line group of this
      * strip into the per-strip staging buffers, then all threads copy this strip's buffer into the image */
-    constexpr uint32_t SPL = 128u / WB;
+    constexpr uint32_t SPL = nrq_group_strips(WB);
     const size_t stride = ((size_t)c.h->M * WB + 255u) & ~(size_t)255u;
     std::vector<uint8_t> stage(stride * SPL + 64, 0x5A);
     GroupSrc<WB> g;
@@ -87,7 +87,7 @@ template <int WB> static int run_strip(const nrq_job &job, uint32_t T, uint32_t 
   PHASE(ph_backsub);
   PHASE(ph_park);
   { /* results: staged per strip, then scattered to the symbol rows a line group at a time */
-    constexpr uint32_t SPL = 128u / WB;
+    constexpr uint32_t SPL = nrq_group_strips(WB);
     const uint32_t nstrips = (T + WB - 1) / WB, ne = out_elems<WB>(c.job, c.h);
     const size_t ostride = ((size_t)ne * WB + 255u) & ~(size_t)255u;
     if (strip % SPL == 0) ostage.assign(ostride * SPL + 64, 0x3C);
@@ -117,6 +117,7 @@ extern "C" int emu_solve(const nrq_job *job, uint32_t T, uint32_t wb, const uint
   for (uint32_t s = 0; s < nstrips && r; s++) {
     switch (wb) {
       case 16: r = run_strip<16>(*job, T, s, kc, ostage); break;
+      case 12: r = run_strip<12>(*job, T, s, kc, ostage); break;
       case 8: r = run_strip<8>(*job, T, s, kc, ostage); break;
       case 4: r = run_strip<4>(*job, T, s, kc, ostage); break;
       case 2: r = run_strip<2>(*job, T, s, kc, ostage); break;

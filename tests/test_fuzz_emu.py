@@ -16,7 +16,7 @@ def test_random_small_cases(orc, seed):
     for trial in range(40):
         K = int(rng.choice([1, 2, 9, 10, 11, 12, 13, 26, 27, 55, 56, 101, 102, 150, 257]))
         T = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 17, 24, 33, 40]))
-        wb = int(rng.choice([2, 4, 8, 16]))
+        wb = int(rng.choice([2, 4, 8, 12, 16]))
         nl = int(rng.integers(1, K + 1)) if K > 1 else 1
         nl = min(nl, max(1, int(K * rng.choice([0.1, 0.3, 0.6, 1.0]))))
         prm = orc.params(K)

@@ -362,11 +362,12 @@ def test_lazy_decode_takes_spare_symbols_only_when_needed(G, orc, planner):
         c.set_planner(True)
 
 
-@pytest.mark.parametrize("wb,split", [(4, True), (2, True), (2, False), (8, False)])
+@pytest.mark.parametrize("wb,split", [(4, True), (2, True), (2, False), (8, False), (12, False)])
 def test_narrow_strip_paths_at_small_sizes(G, orc, wb, split):
-    """The kernels big blocks use -- 8/4/2-byte strips and, for 4 and 2, the split solve (nrq_backsub_kernel +
+    """The kernels big blocks use -- 12/8/4/2-byte strips and, for 4 and 2, the split solve (nrq_backsub_kernel +
     nrq_collect_kernel finishing on full-width rows) -- forced at sizes the oracle checks in no time: intermediate,
-    repair and recovered symbols byte for byte, ragged symbol sizes included (T = 1, 50, 1288)."""
+    repair and recovered symbols byte for byte, ragged symbol sizes included (T = 1, 50, 1288; for the 12-byte strip
+    1288 = 107 strips and 4 bytes, moved by the aligned form, 96 = whole strips, 50 and 1 the byte-wise form)."""
     c = G.ctx()
     c.set_option("max_wb", wb)
     c.set_option("no_split", 0 if split else 1)
@@ -375,6 +376,7 @@ def test_narrow_strip_paths_at_small_sizes(G, orc, wb, split):
             src = np.stack([payload(K * T, seed=K + wb, block=b).reshape(K, T) for b in range(nblk)])
             esis = np.array([K, K + 1, K + 9, K + 500], np.uint32)
             rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+            assert c.stats()["strip_bytes"] == wb
             for b in (0, nblk - 1):
                 r_rep, r_int, _ = orc.encode_block(src[b], K, T, esis, want_inter=True)
                 assert np.array_equal(inter[b], r_int) and np.array_equal(rep[b], r_rep), (K, T, b)
@@ -385,6 +387,33 @@ def test_narrow_strip_paths_at_small_sizes(G, orc, wb, split):
     finally:
         c.set_option("max_wb", 16)
         c.set_option("no_split", 0)
+
+
+@pytest.mark.parametrize("K,T", [(10000, 40), (11500, 28), (9000, 1288)])
+def test_twelve_byte_strips_where_sixteen_do_not_fit(G, orc, K, T):
+    """K between ~8500 and ~12000: the 16-byte strip image exceeds the CU's LDS, the 12-byte one fits (three forward waves, a
+    dword of the strip each; nrq_device.hip widest_fit).  Chosen on its own here, checked against the oracle; with "no_wb12"
+    the launch falls back to 8 bytes and gives the same bytes."""
+    c = G.ctx()
+    nblk = 2
+    src = np.stack([payload(K * T, seed=K + 12, block=b).reshape(K, T) for b in range(nblk)])
+    esis = np.array([K, K + 3, K + 70000], np.uint32)
+    rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
+    assert c.stats()["strip_bytes"] == 12
+    r_rep, r_int, _ = orc.encode_block(src[1], K, T, esis, want_inter=True)
+    assert np.array_equal(inter[1], r_int) and np.array_equal(rep[1], r_rep)
+    st, out, src2 = _roundtrip(G, K, T, 3, 0.06, 2, seed=K + 5)
+    assert c.stats()["strip_bytes"] in (12, 8)   # (a decode plan with many inactive columns may need the narrower image)
+    for b in range(3):
+        assert not st[b] or np.array_equal(out[b], src2[b]), b
+    assert st.sum() >= 2
+    c.set_option("no_wb12", 1)
+    try:
+        rep8, inter8 = G.gpu_encode(src, K, T, esis, want_inter=True)
+        assert c.stats()["strip_bytes"] == 8
+        assert np.array_equal(rep8, rep) and np.array_equal(inter8, inter)
+    finally:
+        c.set_option("no_wb12", 0)
 
 
 def test_device_built_encode_plans(G, orc):
@@ -726,7 +755,8 @@ def test_block_lists_per_launch(G, orc):
     finally:
         c.set_option("lds_max", 0)
     assert thr, "no bound split the batch"
-    assert s["strip_bytes"] == 16 and s["strip_bytes_b"] == 8 and 0 < s["blocks_b"] < nblk, {k: s[k] for k in ("strip_bytes", "strip_bytes_b", "blocks_b", "lds_bytes", "u")}
+    # (the second list runs at the next width down: 12 bytes since round 6)
+    assert s["strip_bytes"] == 16 and s["strip_bytes_b"] == 12 and 0 < s["blocks_b"] < nblk, {k: s[k] for k in ("strip_bytes", "strip_bytes_b", "blocks_b", "lds_bytes", "u")}
     try:
         c.set_option("no_lists", 1)
         c.set_option("lds_max", thr)
@@ -735,9 +765,18 @@ def test_block_lists_per_launch(G, orc):
     finally:
         c.set_option("no_lists", 0)
         c.set_option("lds_max", 0)
-    # (one launch at the width every block fits: 8 bytes -- unless this run's plans, which differ from run to run in who claimed
+    # (one launch at the width every block fits: 12 bytes -- unless this run's plans, which differ from run to run in who claimed
     # which column, all happen to fit the lowered bound)
-    assert s1["strip_bytes"] in (8, 16) and s1["blocks_b"] == 0 and st1.all() and np.array_equal(out1, out)
+    assert s1["strip_bytes"] in (12, 16) and s1["blocks_b"] == 0 and st1.all() and np.array_equal(out1, out)
+    try:   # ... and with the 12-byte strip switched off, the second list at 8 bytes as in round 5: same bytes
+        c.set_option("no_wb12", 1)
+        c.set_option("lds_max", thr)
+        st2, out2, _ = G.gpu_decode(*args)
+        s2 = c.stats()
+    finally:
+        c.set_option("no_wb12", 0)
+        c.set_option("lds_max", 0)
+    assert s2["strip_bytes_b"] in (0, 8) and st2.all() and np.array_equal(out2, out)
     for b in (0, nblk - 1):   # the oracle on the sparsest and the heaviest reception
         keep = np.setdiff1d(np.arange(K, dtype=np.uint32), lost[b])
         ok, ref, _ = orc.decode_block(np.concatenate([keep, esis[:len(lost[b]) + 2]]), np.concatenate([src[b][keep], rep[b][:len(lost[b]) + 2]]), K, T)

@@ -36,7 +36,9 @@ def _encode_case(orc, K, T, wb, nrep=7):
 @pytest.mark.parametrize("K,T,wb", [(10, 8, 16), (10, 8, 4), (10, 24, 16), (100, 64, 16), (100, 36, 8), (100, 10, 4),
                                     (100, 6, 2), (1024, 32, 16), (1024, 20, 8), (8192, 16, 16),
                                     # T a multiple of 16: narrow strips gathered as 16-byte chunks of their line group (pf_gather_chunks)
-                                    (100, 32, 8), (100, 16, 2), (1024, 48, 4), (300, 160, 2)])
+                                    (100, 32, 8), (100, 16, 2), (1024, 48, 4), (300, 160, 2),
+                                    # 12-byte strips: T a multiple of 12, of 4 only (the last strip holds 4 or 8 bytes), of neither
+                                    (10, 24, 12), (100, 36, 12), (100, 64, 12), (100, 104, 12), (1024, 20, 12), (100, 13, 12), (8192, 16, 12)])
 def test_encode_emulated_matches_oracle(orc, K, T, wb):
     _encode_case(orc, K, T, wb)
 
@@ -64,7 +66,8 @@ def test_encoder_plan_by_components(orc, K, monkeypatch):
 
 @pytest.mark.parametrize("K,T,wb,p,oh", [(10, 16, 16, 0.3, 0), (100, 32, 16, 0.06, 0), (100, 32, 8, 0.06, 2),
                                          (100, 8, 2, 0.5, 30), (1024, 16, 16, 0.05, 0), (1024, 16, 4, 0.06, 52),
-                                         (8192, 16, 16, 0.1, 0), (8192, 16, 16, 0.1, 2)])
+                                         (8192, 16, 16, 0.1, 0), (8192, 16, 16, 0.1, 2),
+                                         (100, 32, 12, 0.06, 2), (1024, 28, 12, 0.05, 0), (100, 11, 12, 0.3, 3)])
 def test_decode_emulated_matches_oracle(orc, K, T, wb, p, oh):
     prm = orc.params(K)
     src = payload(K * T, seed=5).reshape(K, T)
