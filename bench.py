@@ -108,6 +108,7 @@ def parse():
                          "plan can be a leftover of the step before it; a plan issued ahead is the plan of THAT step's pattern")
     ap.add_argument("--one-list", action="store_true", help="round 5's launch rule for comparison: one solve launch per batch at the strip width "
                                                                 "EVERY block fits (no second block list)")
+    ap.add_argument("--no-wb12", action="store_true", help="round 5's strip widths for comparison (16, 8, 4, 2 bytes: K ~ 8500-12000 on 8-byte strips)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffers-to-host-buffers leg")
     ap.add_argument("--one-object", choices=("auto", "on", "off"), default="auto",
                     help="ONE object over all N GPUs from rank 0's process (NANORQ_HIP_DEVICES=0..N-1, a host thread per device: "
@@ -271,6 +272,10 @@ def pmc_collect(args):
              "--no-e2e", "--K", str(args.K), "--T", str(args.T), "--blocks", str(args.blocks), "--loss", str(args.loss), "--overhead", str(args.overhead)]
     if args.no_replan:
         inner.append("--no-replan")
+    if args.no_wb12:
+        inner.append("--no-wb12")
+    if args.one_list:
+        inner.append("--one-list")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -480,6 +485,8 @@ def main():
         c_.set_threads(threads)
         if args.one_list:
             c_.set_option("no_lists", 1)
+        if args.no_wb12:
+            c_.set_option("no_wb12", 1)
     ctx = ctxs[0]
 
     K, T, NB = args.K, args.T, args.blocks

@@ -30,7 +30,7 @@ typedef struct nrq_ctx nrq_ctx;
 typedef struct nrq_call_stats {
   double plan_ms;      /* symbolic stage wall time (all blocks) */
   double host_ms;      /* whole host side of the call before the launch returns */
-  uint32_t strip_bytes;/* column-strip width chosen (16/8/4/2) */
+  uint32_t strip_bytes;/* column-strip width chosen (16/12/8/4/2) */
   uint32_t lds_bytes;  /* dynamic LDS per workgroup */
   uint32_t grid;       /* (persistent) workgroups launched */
   uint32_t planner;    /* 0 = host planner, 1 = device planner */

@@ -7,8 +7,9 @@ TAG=${1:-r6}
 OUT=$REPO/gpurun_out/cfg
 mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
-run() { # name K T blocks loss overhead [cpu-sample] [further bench.py arguments]
+run() { # name K T blocks loss overhead [cpu-sample] [further bench.py arguments]      (ONLY=regex in the environment: just the matching lines)
   local name=$1 K=$2 T=$3 B=$4 P=$5 OH=$6 CS=${7:-2}
+  if [ -n "$ONLY" ] && ! [[ "$name" =~ $ONLY ]]; then return 0; fi
   shift 7 2>/dev/null || shift $#
   timeout 900 python $REPO/bench.py --K $K --T $T --blocks $B --loss $P --overhead $OH --steps 5 --warmup 2 --cpu-sample $CS "$@" > "$OUT/${TAG}_bench_$name.json" 2> "$OUT/${TAG}_bench_$name.err"
   set -- $name
@@ -42,6 +43,9 @@ run K1000_T1280         1000  1280 2048 0.06 0
 run K256_T1280           256  1280 8192 0.06 0
 run K500_T1280           500  1280 4096 0.06 0
 run K5000_T1280         5000  1280  512 0.06 0
+run K9000_T1280         9000  1280  256 0.06 0
 run K10000_T1280       10000  1280  256 0.06 0
+run K10000_T1280_8byte 10000  1280  256 0.06 0 0 --no-wb12
+run K11000_T1280       11000  1280  256 0.06 0
 run K20000_T1280       20000  1280   64 0.10 0 1
 run K50000_T1280       50000  1280   16 0.06 0 1

@@ -9,14 +9,16 @@
 #include <vector>
 #include "solve_body.h"
 
-template <int WB, int HALF> __global__ __launch_bounds__(128) void k(const uint32_t *__restrict__ ops, uint32_t nrows, uint32_t nslot, unsigned long long *out) {
+template <int WB, int HALF> __global__ __launch_bounds__(192) void k(const uint32_t *__restrict__ ops, uint32_t nrows, uint32_t nslot, unsigned long long *out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t tid = threadIdx.x, wv = tid >> 6;
-  for (uint32_t i = tid; i < nslot * WB / 4u; i += 128) ((uint32_t *)smem)[i] = i * 2654435761u;
+  for (uint32_t i = tid; i < nslot * WB / 4u; i += blockDim.x) ((uint32_t *)smem)[i] = i * 2654435761u;
   __syncthreads();
   const NRQ_GAS uint32_t *o = gptr<uint32_t>(ops);
   const unsigned long long t0 = clock64();
-  if constexpr (HALF) { // the 16- and 8-byte strips' form: two waves, half the width each
+  if constexpr (WB == 12) { // three waves, a dword each
+    if (wv == 0) fwd_rows_third<0>(o, nrows, tid); else if (wv == 1) fwd_rows_third<4>(o, nrows, tid & 63u); else fwd_rows_third<8>(o, nrows, tid & 63u);
+  } else if constexpr (HALF) { // the 16- and 8-byte strips' form: two waves, half the width each
     if (wv == 0) fwd_rows_half<WB, 0>(o, nrows, tid); else fwd_rows_half<WB, WB / 2>(o, nrows, tid & 63u);
   } else {
     if (wv == 0) fwd_rows<WB>(o, nrows, tid);
@@ -25,7 +27,9 @@ template <int WB, int HALF> __global__ __launch_bounds__(128) void k(const uint3
   if ((tid & 63u) == 0 && wv == 0) out[blockIdx.x] = t1 - t0;
 }
 
-template <int WB, int HALF> static void run(const char *what, uint32_t nslot, uint32_t nrows) {
+// spread: the 64 ops of a row take their targets (and sources) from 64 different residues of the slot number mod 64 -- what a
+// bank-aware placement of a level's ops into rows could reach at best; random otherwise (what the planners produce)
+template <int WB, int HALF> static void run(const char *what, uint32_t nslot, uint32_t nrows, bool spread = false) {
   const uint32_t total = NRQ_STREAM_ROWS(nrows + NRQ_PAD_ROWS);
   std::vector<uint32_t> h((size_t)total * 64, 0u);
   uint32_t x = 12345;
@@ -33,8 +37,9 @@ template <int WB, int HALF> static void run(const char *what, uint32_t nslot, ui
     for (uint32_t lane = 0; lane < 64; lane++) {
       uint32_t w = NRQ_NOP_AT(lane);
       if (row < nrows && lane != 63u) {
-        x = x * 1664525u + 1013904223u; const uint32_t src = (x >> 8) % (nslot - 64u);
-        x = x * 1664525u + 1013904223u; const uint32_t dst = (x >> 8) % (nslot - 64u);
+        x = x * 1664525u + 1013904223u; uint32_t src = (x >> 8) % (nslot - 64u);
+        x = x * 1664525u + 1013904223u; uint32_t dst = (x >> 8) % (nslot - 64u);
+        if (spread) { src = (src & ~63u) | ((lane * 37u + row) & 63u); dst = (dst & ~63u) | ((lane * 29u + 7u * row) & 63u); if (src >= nslot - 64u) src -= 64u; if (dst >= nslot - 64u) dst -= 64u; }
         w = NRQ_OP(dst, src);
       }
       h[NRQ_OP_INDEX(row, lane)] = w;
@@ -44,7 +49,7 @@ template <int WB, int HALF> static void run(const char *what, uint32_t nslot, ui
   hipMemcpy(d_ops, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipFuncSetAttribute((const void *)k<WB, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   for (uint32_t grid : {1u, 256u}) {
-    for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL((k<WB, HALF>), dim3(grid), dim3(128), (nslot + 64u) * WB, 0, d_ops, nrows, nslot, d_out); hipDeviceSynchronize(); }
+    for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL((k<WB, HALF>), dim3(grid), dim3(WB == 12 ? 192 : 128), (nslot + 64u) * WB, 0, d_ops, nrows, nslot, d_out); hipDeviceSynchronize(); }
     std::vector<unsigned long long> o(grid);
     hipMemcpy(o.data(), d_out, o.size() * 8, hipMemcpyDeviceToHost);
     double s = 0; for (auto v : o) s += (double)v;
@@ -59,5 +64,11 @@ int main() {
   run<4, 0>("4-byte strips, K=27000 (27.7 k slots)", 27700u, 3000u);
   run<8, 1>("8-byte strips, two waves x 4 bytes, K=10000", 10500u, 1400u);
   run<16, 1>("16-byte strips, two waves x 8 bytes, K=8192", 8480u, 1400u);
+  run<12, 0>("12-byte strips, three waves x 4 bytes, K=10000", 10500u, 1400u);
+  printf("# the same with every row's 64 targets and 64 sources on 64 different slot residues mod 64 (no two lanes on one LDS bank group)\n");
+  run<4, 0>("4-byte strips, spread", 27700u, 3000u, true);
+  run<8, 1>("8-byte strips, spread", 10500u, 1400u, true);
+  run<12, 0>("12-byte strips, spread", 10500u, 1400u, true);
+  run<16, 1>("16-byte strips, spread", 8480u, 1400u, true);
   return 0;
 }
