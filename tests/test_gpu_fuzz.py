@@ -103,7 +103,9 @@ def test_many_reception_patterns_through_the_device_planner(K, T, nblk, p, iters
 STRESS_CASES = [  # K, T, blocks, loss, iterations -- the sizes every planner form covers (tools/stress_sweep.sh, same table)
     (8192, 64, 256, 0.1, 60), (8192, 64, 256, 0.3, 30), (9400, 32, 256, 0.1, 30), (2000, 32, 1024, 0.2, 40), (5000, 32, 512, 0.06, 40),
     (20000, 16, 64, 0.1, 15), (56403, 8, 8, 0.2, 10), (56403, 8, 8, 0.45, 6), (700, 32, 2048, 0.1, 30), (1000, 32, 2048, 0.5, 20),
-    (100, 32, 8192, 0.2, 20), (10, 32, 8192, 0.3, 20)]
+    (100, 32, 8192, 0.2, 20), (10, 32, 8192, 0.3, 20),
+    # 12-byte strips: T = whole strips / strips + 8 bytes / not a multiple of 4 (byte-wise movers)
+    (11000, 36, 128, 0.2, 15), (10000, 44, 128, 0.06, 20), (9000, 50, 128, 0.1, 15)]
 
 
 @pytest.mark.skipif(__import__("os").environ.get("NANORQ_STRESS") != "1", reason="long sweep: NANORQ_STRESS=1 enables it (~8 GPU-minutes)")

@@ -19,4 +19,7 @@ done <<'CASES'
 1000 32 2048 0.5 20
 100 32 8192 0.2 20
 10 32 8192 0.3 20
+11000 36 128 0.2 15
+10000 44 128 0.06 20
+9000 50 128 0.1 15
 CASES
