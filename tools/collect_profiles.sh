@@ -25,7 +25,7 @@ done
 python $REPO/tools/rocprof_summary.py pmc $(find "$OUT" -path '*pmc*' -name '*.db' | sort) > "$OUT/${TAG}_pmc.txt"
 python $REPO/tools/rocprof_summary.py pmcjson $(find "$OUT" -path '*pmc*' -name '*.db' | sort) > "$OUT/${TAG}_pmc.json"
 # large-K and small-K kernel traces
-for cfg in "cfg5 56403 1280 8 0.2" "cfg4 27000 65504 1 0.1" "cfg1 100 1024 8192 0.06" "K1000 1000 1280 2048 0.06"; do set -- $cfg
+for cfg in "cfg5 56403 1280 8 0.2" "cfg4 27000 65504 1 0.1" "cfg1 100 1024 8192 0.06" "K1000 1000 1280 2048 0.06" "K10000 10000 1280 256 0.06"; do set -- $cfg
   timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/tr_$1" -- python $REPO/bench.py --K $2 --T $3 --blocks $4 --loss $5 --steps 3 --warmup 1 --cpu-sample 0 --pmc off --no-e2e > "$OUT/tr_$1.log" 2>&1
   python $REPO/tools/rocprof_summary.py stats $(find "$OUT/tr_$1" -name '*.db' | head -1) > "$OUT/${TAG}_kernel_stats_$1.txt"
 done
