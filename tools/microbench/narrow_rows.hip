@@ -29,7 +29,7 @@ template <int WB, int HALF> __global__ __launch_bounds__(192) void k(const uint3
 
 // spread: the 64 ops of a row take their targets (and sources) from 64 different residues of the slot number mod 64 -- what a
 // bank-aware placement of a level's ops into rows could reach at best; random otherwise (what the planners produce)
-template <int WB, int HALF> static void run(const char *what, uint32_t nslot, uint32_t nrows, bool spread = false) {
+template <int WB, int HALF> static void run(const char *what, uint32_t nslot, uint32_t nrows, int spread = 0) { /* 1: targets and sources, 2: targets only, 3: sources only */
   const uint32_t total = NRQ_STREAM_ROWS(nrows + NRQ_PAD_ROWS);
   std::vector<uint32_t> h((size_t)total * 64, 0u);
   uint32_t x = 12345;
@@ -39,7 +39,13 @@ template <int WB, int HALF> static void run(const char *what, uint32_t nslot, ui
       if (row < nrows && lane != 63u) {
         x = x * 1664525u + 1013904223u; uint32_t src = (x >> 8) % (nslot - 64u);
         x = x * 1664525u + 1013904223u; uint32_t dst = (x >> 8) % (nslot - 64u);
-        if (spread) { src = (src & ~63u) | ((lane * 37u + row) & 63u); dst = (dst & ~63u) | ((lane * 29u + 7u * row) & 63u); if (src >= nslot - 64u) src -= 64u; if (dst >= nslot - 64u) dst -= 64u; }
+        if (spread == 1 || spread == 3) { src = (src & ~63u) | ((lane * 37u + row) & 63u); if (src >= nslot - 64u) src -= 64u; }
+        if (spread == 1 || spread == 2) { dst = (dst & ~63u) | ((lane * 29u + 7u * row) & 63u); if (dst >= nslot - 64u) dst -= 64u; }
+        if (spread == 4) { /* the planners' rule (plan.h): lane 2d + (r & 1) of a 16-lane block holds a target of class d = slot mod 8; sources random */
+          dst = (dst & ~7u) | ((lane >> 1) & 7u); if (dst >= nslot - 64u) dst -= 64u; }
+        if (spread == 5) { /* ... and the sources two per class and block as well */
+          dst = (dst & ~7u) | ((lane >> 1) & 7u); if (dst >= nslot - 64u) dst -= 64u;
+          src = (src & ~7u) | (((lane >> 1) + 3u) & 7u); if (src >= nslot - 64u) src -= 64u; }
         w = NRQ_OP(dst, src);
       }
       h[NRQ_OP_INDEX(row, lane)] = w;
@@ -66,9 +72,15 @@ int main() {
   run<16, 1>("16-byte strips, two waves x 8 bytes, K=8192", 8480u, 1400u);
   run<12, 0>("12-byte strips, three waves x 4 bytes, K=10000", 10500u, 1400u);
   printf("# the same with every row's 64 targets and 64 sources on 64 different slot residues mod 64 (no two lanes on one LDS bank group)\n");
-  run<4, 0>("4-byte strips, spread", 27700u, 3000u, true);
-  run<8, 1>("8-byte strips, spread", 10500u, 1400u, true);
-  run<12, 0>("12-byte strips, spread", 10500u, 1400u, true);
-  run<16, 1>("16-byte strips, spread", 8480u, 1400u, true);
+  run<4, 0>("4-byte strips, spread", 27700u, 3000u, 1);
+  run<8, 1>("8-byte strips, spread", 10500u, 1400u, 1);
+  run<12, 0>("12-byte strips, spread", 10500u, 1400u, 1);
+  run<16, 1>("16-byte strips, spread", 8480u, 1400u, 1);
+  run<16, 1>("16-byte strips, targets spread only", 8480u, 1400u, 2);
+  run<16, 1>("16-byte strips, sources spread only", 8480u, 1400u, 3);
+  run<16, 1>("16-byte strips, targets by the planners' rule", 8480u, 1400u, 4);
+  run<16, 1>("16-byte strips, targets and sources by that rule", 8480u, 1400u, 5);
+  run<12, 0>("12-byte strips, targets by the planners' rule", 10500u, 1400u, 4);
+  run<8, 1>("8-byte strips, targets by the planners' rule", 10500u, 1400u, 4);
   return 0;
 }
