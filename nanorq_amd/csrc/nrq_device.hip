@@ -123,6 +123,11 @@ __device__ __forceinline__ uint32_t nrq_next_group(uint32_t q, uint32_t nslots, 
                           * 151 of them spilled: every phase reloads its pointers from scratch) 370 Gbit/s, 4 / 16 ~385, 3 / 12 419,
                           * 2 / 8 358; K=256 527 / 547 / 569 / 533 */
 #endif
+#ifndef NRQ_PROF_DONE
+#define NRQ_PROF_DONE 9 /* NRQ_PROF samples this strip (counted from 0) of every 16th workgroup.  It must lie behind the workgroup's FIRST work
+                         * slot to see a scatter at all (the first slot has no results of a slot before it to move): strip 9 is in the second
+                         * slot when slots are 8 strips (16- and 12-byte strips), in the first when they are 16 or more (8 bytes and narrower) */
+#endif
 #ifndef NRQ_W12_FW
 #define NRQ_W12_FW 3 /* forward waves of the 12-byte strip: 3 (a dword each) or 2 (two dwords, one dword) */
 #endif
@@ -302,7 +307,7 @@ void nrq_solve_kernel(const nrq_job *__restrict__ jobs, uint32_t nblk,
       const uint32_t lpr_ = c.h->lpr; /* (fetched here, with the header fields the first phases need: not a trip of its own later) */
       /* NRQ_PROF=1 debugging aid: shader-clock stamps at phase boundaries, the 10th strip of every 16th workgroup */
       unsigned long long *stamp = nullptr;
-      const bool sampled = prof && (blockIdx.x & 15u) == 0 && done == 9u;
+      const bool sampled = prof && (blockIdx.x & 15u) == 0 && done == (uint32_t)NRQ_PROF_DONE;
       if (sampled && tid == 0) stamp = prof + (size_t)(blockIdx.x >> 4) * 16;
 #define NRQ_STAMP(i) do { if (stamp) stamp[i] = (unsigned long long)clock64(); } while (0)
       /* -DNRQ_STOP_AFTER=p (tools/phase_counters.sh): a strip ends behind phase p -- 0 load, 1 forward, 2 HDPC, 3 GF(2) combinations,
