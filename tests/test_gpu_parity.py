@@ -372,11 +372,15 @@ def test_narrow_strip_paths_at_small_sizes(G, orc, wb, split):
     c.set_option("max_wb", wb)
     c.set_option("no_split", 0 if split else 1)
     try:
-        for K, T, nblk, p, oh in [(300, 1288, 3, 0.1, 0), (1024, 50, 9, 0.05, 2), (64, 1, 5, 0.2, 1), (2000, 96, 2, 0.1, 0)]:
+        # (T = 1280, 32 and 16: rows 16-byte aligned -- the movers' aligned forms; for the 12-byte strip with a last strip of 8 / 8 / 4 bytes)
+        for K, T, nblk, p, oh in [(300, 1288, 3, 0.1, 0), (1024, 50, 9, 0.05, 2), (64, 1, 5, 0.2, 1), (2000, 96, 2, 0.1, 0),
+                                  (300, 1280, 3, 0.1, 0), (700, 32, 9, 0.1, 1), (100, 16, 17, 0.2, 0)]:
             src = np.stack([payload(K * T, seed=K + wb, block=b).reshape(K, T) for b in range(nblk)])
             esis = np.array([K, K + 1, K + 9, K + 500], np.uint32)
             rep, inter = G.gpu_encode(src, K, T, esis, want_inter=True)
             assert c.stats()["strip_bytes"] == wb
+            if T % 16 == 0 and wb >= 4:
+                assert c.stats()["movers_aligned"] == 1, (K, T)
             for b in (0, nblk - 1):
                 r_rep, r_int, _ = orc.encode_block(src[b], K, T, esis, want_inter=True)
                 assert np.array_equal(inter[b], r_int) and np.array_equal(rep[b], r_rep), (K, T, b)
