@@ -1052,6 +1052,7 @@ struct Tuning {
   uint64_t solve_grid = 0;   /* NRQ_SOLVE_GRID: persistent workgroups of the solve launch (0 = fill the device) */
   uint32_t max_wb = 16;      /* NRQ_MAX_WB: widest strip considered */
   bool no_wb12 = false;      /* NRQ_NO_WB12: strip widths 16, 8, 4, 2 only (round 5's set) */
+  bool host_plan_auto = true; /* NRQ_HOST_PLAN_AUTO=0: a call of one or two small blocks is planned by the planner kernel like any other */
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
   uint32_t encplan_dev_min_l = 12000; /* NRQ_ENCPLAN_DEV_MIN_L: from this many intermediate symbols on, encode plans are built by
                               * the device planner, asynchronously (the host planner takes 25 ms at K=27000, 95 ms at K'=56403) */
@@ -1091,7 +1092,7 @@ struct Tuning {
     wide_g = (uint32_t)num("NRQ_WIDE_G", 0);
     if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
     no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 7); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 7);
-    no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); no_lists = flag("NRQ_NO_LISTS"); no_wb12 = flag("NRQ_NO_WB12"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
+    no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); no_lists = flag("NRQ_NO_LISTS"); no_wb12 = flag("NRQ_NO_WB12"); host_plan_auto = num("NRQ_HOST_PLAN_AUTO", 1) != 0; reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
     plan_small_state = !flag("NRQ_PLAN_BIG_STATE"); plan_no_wg128 = flag("NRQ_PLAN_NO_WG128");
   }
@@ -2114,6 +2115,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "no_balance") t.no_balance = value != 0;
   else if (n == "no_lists") t.no_lists = value != 0;
   else if (n == "no_wb12") t.no_wb12 = value != 0;
+  else if (n == "host_plan_auto") t.host_plan_auto = value != 0;
   else if (n == "lds_max") t.lds_max = value > 0 && value <= (long long)NRQ_LDS_MAX ? (uint32_t)value : NRQ_LDS_MAX;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
   else if (n == "no_plan_split") t.no_plan_split = value != 0;
@@ -2748,9 +2750,20 @@ int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, ui
   ctx->io_aligned = (ctx->vec_src ? vec_aligned(ctx->vec_src, nblk, T) : rows_aligned(d_src, src_stride, T)) &&
                     (ctx->vec_rep ? vec_aligned(ctx->vec_rep, nblk, T) : rows_aligned(d_rep, rep_stride, T)) &&
                     (!d_inter || rows_aligned(d_inter, inter_stride, T));
-  if (!ctx->planner)
-    return decode_host(ctx, nullptr, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
-                       h_nrep_avail, h_used, rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);
+  /* A call with one or two SMALL blocks (the reference's own harness: one block per call): the planner kernel is a chain of ~120
+   * phases that a lone block cannot fill -- 200 us at K=100, 460 at K=1000, whatever the block count up to one per CU -- while the
+   * host planner, sequential per block, needs ~0.45 us per source symbol on the GPU box's CPU.  Measured with the reference's
+   * benchmark.c (decode column, Gbit/s, device / host planner): K=100 3.5 / 7.5, K=200 5.7 / 12.4, K=500 8.5 / 20.7, K=1000
+   * 16.6 / 19.6, K=1500 20.1 / 21.4, K=2000 21.5 / 19.6, K=3000 25.2 / 20.8.  So the host plans when its estimate is the shorter
+   * one (option "host_plan_auto" / NRQ_HOST_PLAN_AUTO=0: never), unless plans were issued ahead or the call solves in chunks. */
+  const bool host_small = ctx->planner && ctx->tune.host_plan_auto && ctx->ahead.empty() && !ctx->chunk_blocks &&
+                          (uint64_t)50u * nblk * K < (uint64_t)25000u + (uint64_t)35u * K; /* (host ~0.5 us x K per block, kernel ~250 us + 0.35 us x K: K < 1670 for one block, < 385 for two) */
+  if (!ctx->planner || host_small) {
+    const int rc_ = decode_host(ctx, nullptr, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
+                                h_nrep_avail, h_used, rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);
+    if (host_small) ctx->stats.host_planned = 0; /* (a choice, not a fallback: tests read host_planned as "the device planner gave up") */
+    return rc_;
+  }
   std::vector<uint8_t> fallback(nblk, 0);
   int rc = decode_device(ctx, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep, rep_cap, d_rep,
                          rep_stride, d_inter, inter_stride, h_status, &fallback, h_nrep_avail, h_used);

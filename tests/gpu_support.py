@@ -20,6 +20,9 @@ def ctx():
         except ImportError:
             pass
         _CTX = nanorq_amd.Context(0)
+        # the parity tests are about the DEVICE planner at every size and block count; a product context gives calls of one or two small
+        # blocks to the host planner (nrq_decode_blocks_lazy "host_small"), which test_small_calls_take_the_host_planner covers
+        _CTX.set_option("host_plan_auto", 0)
     return _CTX
 
 

@@ -785,3 +785,29 @@ def test_block_lists_per_launch(G, orc):
         keep = np.setdiff1d(np.arange(K, dtype=np.uint32), lost[b])
         ok, ref, _ = orc.decode_block(np.concatenate([keep, esis[:len(lost[b]) + 2]]), np.concatenate([src[b][keep], rep[b][:len(lost[b]) + 2]]), K, T)
         assert ok and np.array_equal(out[b], ref)
+
+
+def test_small_calls_take_the_host_planner(G, orc):
+    """A decode call of one or two small blocks is planned on the host (200-460 us of planner kernel latency against ~0.45 us per
+    source symbol on the CPU: nrq_decode_blocks_lazy; the reference's harness decodes one block per call) -- unless the option is
+    off, the batch is larger, or the blocks are big.  Same bytes either way, and `host_planned` stays 0: it counts blocks the device
+    planner gave up on.  Reference call site: benchmark.c (one nanorq_repair_block per block)."""
+    c = G.ctx()
+
+    def run(K, T, nblk):
+        st, out, src = _roundtrip(G, K, T, nblk, 0.1, 2, seed=K + nblk)
+        s = c.stats()
+        assert st.all() and np.array_equal(out, src), (K, nblk)
+        return s["planner"], s["host_planned"]
+
+    try:
+        c.set_option("host_plan_auto", 1)
+        assert run(100, 64, 1) == (0, 0)
+        assert run(1000, 32, 1) == (0, 0)
+        assert run(300, 32, 2) == (0, 0)
+        assert run(3000, 16, 1) == (1, 0)     # (a big block: the planner kernel is the faster one)
+        assert run(100, 64, 8) == (1, 0)      # (a batch: one workgroup per block, all at once)
+        c.set_option("host_plan_auto", 0)
+        assert run(100, 64, 1) == (1, 0)
+    finally:
+        c.set_option("host_plan_auto", 0)
