@@ -145,3 +145,42 @@ def test_failure_rates_match_rfc6330_design():
     assert 0.002 < r[0]["rate"] < 0.02, r
     assert r[1]["rate"] < 0.001, r
     assert r[2]["rate"] < 0.0001, r
+
+
+def test_single_small_blocks_through_the_host_planner_rule(G, orc):
+    """What an unchanged caller of the reference API does: one block per call.  With the product's default ("host_plan_auto") such
+    calls are planned on the host when the block is small and by the planner kernel otherwise; 80 random calls across the rule's
+    boundary (K = 1 ... 2500, one or two blocks), every block back to its source or -- with too few symbols -- refused and untouched,
+    and the verdict of a few of them against the reference algorithm."""
+    c = G.ctx()
+    rng = np.random.default_rng(90210)
+    took = {0: 0, 1: 0}
+    try:
+        c.set_option("host_plan_auto", 1)
+        for trial in range(80):
+            K = int(rng.choice([1, 2, 10, 11, 55, 100, 101, 256, 500, 777, 1000, 1400, 1660, 1680, 2000, 2500]))
+            T = int(rng.choice([1, 8, 16, 40, 64, 100]))
+            nblk = int(rng.choice([1, 1, 1, 2]))
+            p = float(rng.choice([0.05, 0.2, 0.5]))
+            oh = int(rng.choice([0, 1, 2]))
+            src = np.stack([payload(K * T, seed=trial, block=b).reshape(K, T) for b in range(nblk)])
+            lost = [loss_pattern(K, p, seed=trial * 31, block=b) for b in range(nblk)]
+            nrep = max(len(l) for l in lost) + oh
+            esis = np.arange(K, K + nrep, dtype=np.uint32)
+            rep, _ = G.gpu_encode(src, K, T, esis)
+            work = src.copy()
+            for b in range(nblk):
+                work[b][lost[b]] = 0x11
+            use = [len(l) + (oh if len(l) else 0) for l in lost]
+            st, out, _ = G.gpu_decode(work, K, T, lost, [esis[:n] for n in use], [rep[b][:use[b]] for b in range(nblk)])
+            took[c.stats()["planner"]] += 1
+            for b in range(nblk):
+                assert np.array_equal(out[b], src[b] if st[b] else work[b]), (K, T, nblk, p, oh, b)
+            if trial % 6 == 0:
+                rx = received_set(K, lost[0], oh if len(lost[0]) else 0)
+                syms = np.concatenate([src[0][rx[rx < K]], rep[0][:use[0]]]) if use[0] else src[0][rx[rx < K]]
+                ok, _, _ = orc.decode_block(rx, syms, K, T)
+                assert bool(st[0]) == ok, (K, T, p, oh)
+    finally:
+        c.set_option("host_plan_auto", 0)
+    assert took[0] > 20 and took[1] > 6, took   # both sides of the rule were exercised
