@@ -2319,6 +2319,7 @@ static int decode_host(nrq_ctx *ctx, const uint8_t *select, uint32_t K, uint32_t
     uint32_t nth = ctx->threads > 0 ? (uint32_t)ctx->threads : std::thread::hardware_concurrency();
     if (nth == 0) nth = 1;
     if (nth > nblk) nth = nblk;
+    if ((uint64_t)K * nblk < 920u) nth = 1; /* (a few small blocks: ~0.4 us x K each -- less than starting and joining threads, ~200 us) */
     std::atomic<uint32_t> next(0);
     auto worker = [&]() {
       for (;;) {
@@ -2755,9 +2756,11 @@ int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, ui
    * host planner, sequential per block, needs ~0.45 us per source symbol on the GPU box's CPU.  Measured with the reference's
    * benchmark.c (decode column, Gbit/s, device / host planner): K=100 3.5 / 7.5, K=200 5.7 / 12.4, K=500 8.5 / 20.7, K=1000
    * 16.6 / 19.6, K=1500 20.1 / 21.4, K=2000 21.5 / 19.6, K=3000 25.2 / 20.8.  So the host plans when its estimate is the shorter
-   * one (option "host_plan_auto" / NRQ_HOST_PLAN_AUTO=0: never), unless plans were issued ahead or the call solves in chunks. */
+   * one (option "host_plan_auto" / NRQ_HOST_PLAN_AUTO=0: never), unless plans were issued ahead or the call solves in chunks.
+   * (Several small blocks: decode_host plans them one after the other -- its worker threads cost more to start than such plans take.) */
   const bool host_small = ctx->planner && ctx->tune.host_plan_auto && ctx->ahead.empty() && !ctx->chunk_blocks &&
-                          (uint64_t)50u * nblk * K < (uint64_t)25000u + (uint64_t)35u * K; /* (host ~0.5 us x K per block, kernel ~250 us + 0.35 us x K: K < 1670 for one block, < 385 for two) */
+                          (uint64_t)40u * nblk * K < (uint64_t)19000u + (uint64_t)28u * K; /* (tools/small_calls.py: host call ~80 us + 0.38 us x K per block, planner-kernel call
+                                                                                                      * ~270 us + 0.28 us x K: one block of K < 1580, two of K < 365, four of K < 144) */
   if (!ctx->planner || host_small) {
     const int rc_ = decode_host(ctx, nullptr, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
                                 h_nrep_avail, h_used, rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);
