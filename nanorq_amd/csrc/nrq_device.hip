@@ -2754,13 +2754,13 @@ int nrq_decode_blocks_lazy(nrq_ctx *ctx, uint32_t K, uint32_t Kp, uint32_t T, ui
   /* A call with one or two SMALL blocks (the reference's own harness: one block per call): the planner kernel is a chain of ~120
    * phases that a lone block cannot fill -- 200 us at K=100, 460 at K=1000, whatever the block count up to one per CU -- while the
    * host planner, sequential per block, needs ~0.45 us per source symbol on the GPU box's CPU.  Measured with the reference's
-   * benchmark.c (decode column, Gbit/s, device / host planner): K=100 3.5 / 7.5, K=200 5.7 / 12.4, K=500 8.5 / 20.7, K=1000
-   * 16.6 / 19.6, K=1500 20.1 / 21.4, K=2000 21.5 / 19.6, K=3000 25.2 / 20.8.  So the host plans when its estimate is the shorter
+   * benchmark.c (decode column, Gbit/s, device / host planner): K=100 3.5 / 9.3, K=500 8.6 / 23.8, K=1000 16.7 / 23.2, K=1500
+   * 20.8 / 24.1, K=2000 22.3 / 21.8, K=2500 25.5 / 23.6, K=3000 25.7 / 23.1, K=4000 34.8 / 17.9.  So the host plans when its estimate is the shorter
    * one (option "host_plan_auto" / NRQ_HOST_PLAN_AUTO=0: never), unless plans were issued ahead or the call solves in chunks.
    * (Several small blocks: decode_host plans them one after the other -- its worker threads cost more to start than such plans take.) */
   const bool host_small = ctx->planner && ctx->tune.host_plan_auto && ctx->ahead.empty() && !ctx->chunk_blocks &&
-                          (uint64_t)40u * nblk * K < (uint64_t)19000u + (uint64_t)28u * K; /* (tools/small_calls.py: host call ~80 us + 0.38 us x K per block, planner-kernel call
-                                                                                                      * ~270 us + 0.28 us x K: one block of K < 1580, two of K < 365, four of K < 144) */
+                          (uint64_t)38u * nblk * K < (uint64_t)20000u + (uint64_t)28u * K; /* (tools/small_calls.py: host call ~65 us + 0.3-0.4 us x K per block, planner-kernel
+                                                                                                      * call ~270 us + 0.28 us x K: one block of K < 2000, two of K < 416, four of K < 161) */
   if (!ctx->planner || host_small) {
     const int rc_ = decode_host(ctx, nullptr, K, Kp, T, nblk, d_src, src_stride, h_lost, h_nlost, lost_cap, h_rep_esi, h_nrep,
                                 h_nrep_avail, h_used, rep_cap, d_rep, rep_stride, d_inter, inter_stride, h_status);

@@ -423,7 +423,13 @@ static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis
   /* ---- XOR op stream: pivot pass by level, then the low-row pass ---- */
   std::vector<uint32_t> ops;
   uint32_t n_real_ops = 0;
-  auto pad_rows = [&](uint32_t nrows_) { for (uint32_t k = 0; k < nrows_ * NRQ_ROW; k++) ops.push_back(NRQ_NOP_AT(ops.size())); };
+  /* (whole rows of padding ops; ops.size() is a multiple of NRQ_ROW wherever this is called, so lane l of a row is NRQ_NOP_AT(l).
+   * One resize and a fill: the 246 rows behind the stream were 15.7 k push_backs, a third of a K=100 plan's build time) */
+  auto pad_rows = [&](uint32_t nrows_) {
+    const size_t n0 = ops.size();
+    ops.resize(n0 + (size_t)nrows_ * NRQ_ROW);
+    for (size_t k = n0; k < ops.size(); k++) ops[k] = NRQ_NOP_AT(k);
+  };
   /* place one group (plan.h): `fin` ops that complete rows other groups may read next, then `early` ops whose
    * targets are read later; the last NRQ_PIPE-1 rows of a group hold no finishing op */
   /* Lanes inside a group are chosen for the LDS banks (plan.h "lane placement"): of every 16 consecutive lanes, two per
@@ -655,6 +661,7 @@ static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis
   Arena A;
   nrq_plan_hdr hd;
   memset(&hd, 0, sizeof(hd));
+  A.buf.reserve(ops.size() * 4u + (size_t)wpr * ((npiv + 63u) & ~63u) * 4u + (size_t)L * 16u + (size_t)augt.size() * 4u + 8192u); /* (no regrowth on the way) */
   A.reserve((uint32_t)sizeof(hd));
   hd.magic = NRQ_PLAN_MAGIC; hd.status = status;
   hd.K = K; hd.Kp = p.Kp; hd.J = p.J; hd.S = S; hd.H = H; hd.W = W; hd.L = L; hd.P = p.P; hd.P1 = p.P1; hd.B = p.B;
@@ -666,7 +673,14 @@ static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis
     while ((ops.size() / NRQ_ROW) % 4u) pad_rows(1);
     hd.off_ops = A.reserve((uint32_t)(ops.size() * 4));
     uint32_t *out = A.at<uint32_t>(hd.off_ops);
-    for (size_t i = 0; i < ops.size(); i++) out[NRQ_OP_INDEX(i / NRQ_ROW, i % NRQ_ROW)] = ops[i];
+    const size_t nquads = ops.size() / (4u * NRQ_ROW);
+    for (size_t g = 0; g < nquads; g++) { /* out[NRQ_OP_INDEX(row, lane)] = ops[row * NRQ_ROW + lane], a quad of rows at a time */
+      const uint32_t *r0 = &ops[g * 4u * NRQ_ROW];
+      uint32_t *o = out + g * 4u * NRQ_ROW;
+      for (uint32_t l = 0; l < NRQ_ROW; l++) {
+        o[4u * l] = r0[l]; o[4u * l + 1u] = r0[NRQ_ROW + l]; o[4u * l + 2u] = r0[2u * NRQ_ROW + l]; o[4u * l + 3u] = r0[3u * NRQ_ROW + l];
+      }
+    }
   }
   hd.off_pivslot = A.reserve(npiv * 2);
   memcpy(A.at<uint8_t>(hd.off_pivslot), pivslot.data(), (size_t)npiv * 2);

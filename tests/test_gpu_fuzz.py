@@ -158,7 +158,7 @@ def test_single_small_blocks_through_the_host_planner_rule(G, orc):
     try:
         c.set_option("host_plan_auto", 1)
         for trial in range(80):
-            K = int(rng.choice([1, 2, 10, 11, 55, 100, 101, 256, 500, 777, 1000, 1400, 1660, 1680, 2000, 2500]))
+            K = int(rng.choice([1, 2, 10, 11, 55, 100, 101, 256, 500, 777, 1000, 1400, 1990, 2010, 2300, 2500]))
             T = int(rng.choice([1, 8, 16, 40, 64, 100]))
             nblk = int(rng.choice([1, 1, 1, 2]))
             p = float(rng.choice([0.05, 0.2, 0.5]))

@@ -35,4 +35,4 @@ for K in (100, 300, 600, 1000):
             assert np.asarray(st).all()
         c.set_planner(True)
         c.free(d_src); c.free(d_rep)
-        print("%5d %3d  %8.0f  %8.0f   rule: %s" % (K, nblk, res[0], res[1], "host" if 40 * nblk * K < 19000 + 28 * K else "device"))
+        print("%5d %3d  %8.0f  %8.0f   rule: %s" % (K, nblk, res[0], res[1], "host" if 38 * nblk * K < 20000 + 28 * K else "device"))
