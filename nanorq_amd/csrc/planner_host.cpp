@@ -184,33 +184,30 @@ static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis
   if (M > 65535u) return -3; /* slots are 16-bit */
 
   /* ---- A: binary constraint rows as CSR (HDPC rows stay empty) ---- */
+  /* (the LDPC rows and the LT rows of ISI < K' are the per-K' constants' base rows -- nrq_host_kconst_build made them with the
+   * same generator, in the same order: copied, not generated again; only the repair symbols' rows are generated here.  A tenth of
+   * a decode plan's build time at K=1000.) */
   std::vector<uint32_t> rptr(M + 1, 0);
   std::vector<uint16_t> cidx;
   {
-    std::vector<std::vector<uint16_t>> ldpc(S);
-    for (uint32_t c = 0; c < p.B; c++) {
-      uint32_t blk = c / S;
-      ldpc[c % S].push_back((uint16_t)c);
-      ldpc[(c + blk + 1) % S].push_back((uint16_t)c);
-      ldpc[(c + 2 * (blk + 1)) % S].push_back((uint16_t)c);
-    }
-    for (uint32_t r = 0; r < S; r++) {
-      ldpc[r].push_back((uint16_t)(p.B + r));
-      ldpc[r].push_back((uint16_t)(W + r % p.P));
-      ldpc[r].push_back((uint16_t)(W + (r + 1) % p.P));
-    }
-    cidx.reserve((size_t)nrows * 8 + (size_t)p.B * 3 + 3 * S);
+    const uint32_t *brp = reinterpret_cast<const uint32_t *>(kconst + kh->off_rptr);
+    const uint16_t *bci = reinterpret_cast<const uint16_t *>(kconst + kh->off_cidx);
+    cidx.reserve((size_t)kh->nnz + (size_t)(nrows - p.Kp + 8u) * RQ_MAX_LT_COLS);
     for (uint32_t r = 0; r < S; r++) {
       rptr[r] = (uint32_t)cidx.size();
-      /* LDPC part 2 can name the same column twice when P == 1; XOR semantics */
-      cidx.insert(cidx.end(), ldpc[r].begin(), ldpc[r].end());
+      cidx.insert(cidx.end(), bci + brp[r], bci + brp[r + 1]);
     }
     for (uint32_t r = S; r < S + H; r++) rptr[r] = (uint32_t)cidx.size();
     uint32_t tmp[RQ_MAX_LT_COLS];
     for (uint32_t k = 0; k < nrows; k++) {
       rptr[S + H + k] = (uint32_t)cidx.size();
-      uint32_t n = rq_lt_columns(&p, isis[k], tmp);
-      for (uint32_t q = 0; q < n; q++) cidx.push_back((uint16_t)tmp[q]);
+      if (isis[k] < p.Kp) {
+        const uint32_t br = S + H + isis[k];
+        cidx.insert(cidx.end(), bci + brp[br], bci + brp[br + 1]);
+      } else {
+        uint32_t n = rq_lt_columns(&p, isis[k], tmp);
+        for (uint32_t q = 0; q < n; q++) cidx.push_back((uint16_t)tmp[q]);
+      }
     }
     rptr[M] = (uint32_t)cidx.size();
   }
@@ -422,13 +419,15 @@ static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis
 
   /* ---- XOR op stream: pivot pass by level, then the low-row pass ---- */
   std::vector<uint32_t> ops;
+  ops.reserve(((size_t)cidx.size() / NRQ_ROW + (size_t)(NRQ_PIPE + 1u) * (nlev + 2u) + NRQ_PAD_ROWS + 16u) * NRQ_ROW + (size_t)u * nlow / 2u); /* (no regrowth: ops, level spacers, padding) */
   uint32_t n_real_ops = 0;
   /* (whole rows of padding ops; ops.size() is a multiple of NRQ_ROW wherever this is called, so lane l of a row is NRQ_NOP_AT(l).
    * One resize and a fill: the 246 rows behind the stream were 15.7 k push_backs, a third of a K=100 plan's build time) */
   auto pad_rows = [&](uint32_t nrows_) {
+    static const struct NopRow { uint32_t w[NRQ_ROW]; NopRow() { for (uint32_t l = 0; l < NRQ_ROW; l++) w[l] = NRQ_NOP_AT(l); } } nop_row;
     const size_t n0 = ops.size();
     ops.resize(n0 + (size_t)nrows_ * NRQ_ROW);
-    for (size_t k = n0; k < ops.size(); k++) ops[k] = NRQ_NOP_AT(k);
+    for (size_t k = n0; k < ops.size(); k += NRQ_ROW) memcpy(&ops[k], nop_row.w, sizeof(nop_row.w));
   };
   /* place one group (plan.h): `fin` ops that complete rows other groups may read next, then `early` ops whose
    * targets are read later; the last NRQ_PIPE-1 rows of a group hold no finishing op */
