@@ -60,7 +60,8 @@ void nrq_ctx_last_stats(nrq_ctx *ctx, nrq_call_stats *out);
 int nrq_ctx_set_planner(nrq_ctx *ctx, int device_planner);
 /* Tuning / test knobs of the launch path (the NRQ_* environment variables read at nrq_ctx_create set the same
  * fields): "max_wb" widest column strip considered (16/12/8/4/2), "no_wb12" (round 5's widths: no 12-byte strip), "host_plan_auto" (1: a decode call of one or two small blocks is planned on the host -- faster than the
- * planner kernel's latency for a lone block of K < ~1700; 0: never), "no_split", "no_balance", "no_plan_stream",
+ * planner kernel's latency for a lone block of K < 2000; 0: never), "plan_pack" (1: small blocks' planner workgroups share a CU whatever the batch size;
+ * default: only when the batch has more blocks than the device has compute units), "no_split", "no_balance", "no_plan_stream",
  * "reserve_cus", "solve_grid", "big_wg", "map_spread", "no_tiny", "tiny_div", "wide_g", "small_waves4", "no_plan_split",
  * "plan_split_force", "plan_small_state", "plan_big_wg", "encplan_dev_min_l", "no_lists" (one solve launch per batch at the width every block fits, no second block list), "lds_max" (tests: LDS bytes a strip
  * image may take when the block lists are formed), "plan_ucap" (inactive columns the device

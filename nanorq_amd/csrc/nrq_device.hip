@@ -1052,6 +1052,7 @@ struct Tuning {
   uint64_t solve_grid = 0;   /* NRQ_SOLVE_GRID: persistent workgroups of the solve launch (0 = fill the device) */
   uint32_t max_wb = 16;      /* NRQ_MAX_WB: widest strip considered */
   bool no_wb12 = false;      /* NRQ_NO_WB12: strip widths 16, 8, 4, 2 only (round 5's set) */
+  bool plan_pack = false;     /* NRQ_PLAN_PACK: small blocks' planner workgroups share a CU whatever the block count */
   bool host_plan_auto = true; /* NRQ_HOST_PLAN_AUTO=0: a call of one or two small blocks is planned by the planner kernel like any other */
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
   uint32_t encplan_dev_min_l = 12000; /* NRQ_ENCPLAN_DEV_MIN_L: from this many intermediate symbols on, encode plans are built by
@@ -1092,7 +1093,7 @@ struct Tuning {
     wide_g = (uint32_t)num("NRQ_WIDE_G", 0);
     if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
     no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 7); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 7);
-    no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); no_lists = flag("NRQ_NO_LISTS"); no_wb12 = flag("NRQ_NO_WB12"); host_plan_auto = num("NRQ_HOST_PLAN_AUTO", 1) != 0; reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
+    no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); no_lists = flag("NRQ_NO_LISTS"); no_wb12 = flag("NRQ_NO_WB12"); host_plan_auto = num("NRQ_HOST_PLAN_AUTO", 1) != 0; plan_pack = flag("NRQ_PLAN_PACK"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
     plan_small_state = !flag("NRQ_PLAN_BIG_STATE"); plan_no_wg128 = flag("NRQ_PLAN_NO_WG128");
   }
@@ -1313,7 +1314,12 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
     /* (queues / claim lists / Gauss-Jordan flags: a frontier, a round's claims and the leftover rows are at most the block's rows) */
     const uint32_t q_s = Mcap <= 248u ? 256u : p.L <= 1500u ? 512u : 1024u, low_s = Mcap <= 248u ? 256u : p.L <= 1500u ? 384u : 768u;
     const uint32_t sh_s = ctx->tune.plan_small_state ? pl_shared_bytes(q_s, low_s, PL_NT_MIN) : sh_bytes;
-    if (lds_alloc(fit + sh_s) <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) {
+    /* ... when there are more blocks than compute units.  A batch of at most one block per CU gains nothing from sharing: every block
+     * gets the 1024-thread workgroup and the whole LDS (round 6, planner per batch, 256-thread / 1024-thread workgroups: K=500 x 256
+     * blocks 0.55 / 0.39 ms, K=1000 x 256 0.53 / 0.44, K=2500 x 256 0.95 / 0.69, K=2500 x 64 1.15 / 0.79; one block of K=2500 through
+     * the reference's benchmark.c: decode column 24.1 -> 30.8 Gbit/s).  "plan_pack" = 1 packs regardless (tests of the small forms). */
+    const bool pack = nblk > (uint32_t)ctx->ncu || ctx->tune.plan_pack;
+    if (lds_alloc(fit + sh_s) <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max && pack) {
       dyn_bytes = fit;
       small_wg = !ctx->tune.plan_big_wg;
       if (small_wg && ctx->tune.plan_small_state) { qcap = q_s; lowcap = low_s; sh_bytes = sh_s; }
@@ -2116,6 +2122,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "no_lists") t.no_lists = value != 0;
   else if (n == "no_wb12") t.no_wb12 = value != 0;
   else if (n == "host_plan_auto") t.host_plan_auto = value != 0;
+  else if (n == "plan_pack") t.plan_pack = value != 0;
   else if (n == "lds_max") t.lds_max = value > 0 && value <= (long long)NRQ_LDS_MAX ? (uint32_t)value : NRQ_LDS_MAX;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
   else if (n == "no_plan_split") t.no_plan_split = value != 0;

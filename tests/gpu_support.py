@@ -23,6 +23,9 @@ def ctx():
         # the parity tests are about the DEVICE planner at every size and block count; a product context gives calls of one or two small
         # blocks to the host planner (nrq_decode_blocks_lazy "host_small"), which test_small_calls_take_the_host_planner covers
         _CTX.set_option("host_plan_auto", 0)
+        # ... and about every FORM of it: a product context gives a batch of at most one block per compute unit the 1024-thread planner
+        # workgroup; the 256- and 128-thread forms that batches of thousands of small blocks use are exercised here at a few blocks
+        _CTX.set_option("plan_pack", 1)
     return _CTX
 
 

@@ -811,3 +811,22 @@ def test_small_calls_take_the_host_planner(G, orc):
         assert run(100, 64, 1) == (1, 0)
     finally:
         c.set_option("host_plan_auto", 0)
+
+
+@pytest.mark.parametrize("K,T,nblk", [(300, 64, 5), (1000, 32, 64), (2500, 16, 9)])
+def test_planner_workgroup_by_batch_size(G, orc, K, T, nblk):
+    """A batch of at most one block per compute unit is planned by 1024-thread workgroups with the whole LDS each (nothing to
+    share a CU with; launch_plan_kernel), larger batches of small blocks by 256- or 128-thread ones that share a CU -- "plan_pack"
+    forces the latter, as the fixture does.  Same decoded bytes both ways, one block against the oracle."""
+    c = G.ctx()
+    res = []
+    try:
+        for pack in (0, 1):
+            c.set_option("plan_pack", pack)
+            st, out, src = _roundtrip(G, K, T, nblk, 0.1, 2, seed=K + 3)
+            assert c.stats()["planner"] == 1 and c.stats()["host_planned"] == 0
+            assert st.all() and np.array_equal(out, src)
+            res.append(out)
+    finally:
+        c.set_option("plan_pack", 1)
+    assert np.array_equal(res[0], res[1])
