@@ -574,7 +574,11 @@ static int host_plan_build_with(uint32_t K, uint32_t nrows, const uint32_t *isis
       for (uint32_t q = 0; q < r2; q++) {
         const uint32_t *aug = &Mb[(size_t)red_row[q] * rowlen + wpr];
         uint32_t &j = curj[q];
-        while (j < nlow && !bit(aug, j)) j++;
+        while (j < nlow) { /* next set bit from j on, a word at a time */
+          const uint32_t w = aug[j >> 5] >> (j & 31u);
+          if (w) { j += (uint32_t)__builtin_ctz(w); break; }
+          j = (j | 31u) + 1u;
+        }
         if (j < nlow) {
           g.push_back(NRQ_OP(M + q, lowslot[j]));
           j++; any = true;
