@@ -1319,9 +1319,9 @@ int launch_plan_kernel(nrq_ctx *ctx, hipStream_t ps, const rq_params &p, const u
      * blocks 0.55 / 0.39 ms, K=1000 x 256 0.53 / 0.44, K=2500 x 256 0.95 / 0.69, K=2500 x 64 1.15 / 0.79; one block of K=2500 through
      * the reference's benchmark.c: decode column 24.1 -> 30.8 Gbit/s).  "plan_pack" = 1 packs regardless (tests of the small forms). */
     const bool pack = nblk > (uint32_t)ctx->ncu || ctx->tune.plan_pack;
-    if (lds_alloc(fit + sh_s) <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max && pack) {
-      dyn_bytes = fit;
-      small_wg = !ctx->tune.plan_big_wg;
+    if (lds_alloc(fit + sh_s) <= NRQ_LDS_MAX / 2u && !ctx->tune.plan_lds_max) {
+      dyn_bytes = fit; /* (also for the 1024-thread workgroup of a small batch: it then leaves LDS and wave slots to a solve running beside it) */
+      small_wg = !ctx->tune.plan_big_wg && pack;
       if (small_wg && ctx->tune.plan_small_state) { qcap = q_s; lowcap = low_s; sh_bytes = sh_s; }
       /* The smallest blocks: 128 threads.  A planner phase is one wave's chain of instructions and trips,
        * the other waves of the workgroup mostly wait; the registers of the kernel (~100) let a CU hold 20 waves -- five
