@@ -1052,6 +1052,7 @@ struct Tuning {
   uint64_t solve_grid = 0;   /* NRQ_SOLVE_GRID: persistent workgroups of the solve launch (0 = fill the device) */
   uint32_t max_wb = 16;      /* NRQ_MAX_WB: widest strip considered */
   bool no_wb12 = false;      /* NRQ_NO_WB12: strip widths 16, 8, 4, 2 only (round 5's set) */
+  bool tiny_any = false;      /* "tiny_any" / NRQ_TINY_ANY: single-wave solve workgroups also for launches of a few hundred strips (tests) */
   bool plan_pack = false;     /* NRQ_PLAN_PACK: small blocks' planner workgroups share a CU whatever the block count */
   bool host_plan_auto = true; /* NRQ_HOST_PLAN_AUTO=0: a call of one or two small blocks is planned by the planner kernel like any other */
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
@@ -1093,7 +1094,7 @@ struct Tuning {
     wide_g = (uint32_t)num("NRQ_WIDE_G", 0);
     if (wide_g != 2u && wide_g != 4u && wide_g != 8u) wide_g = 0;
     no_wentry = flag("NRQ_NO_WENTRY"); no_tiny = flag("NRQ_NO_TINY"); tiny_div = (uint32_t)num("NRQ_TINY_DIV", 7); tiny_div_dec = (uint32_t)num("NRQ_TINY_DIV_DEC", 7);
-    no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); no_lists = flag("NRQ_NO_LISTS"); no_wb12 = flag("NRQ_NO_WB12"); host_plan_auto = num("NRQ_HOST_PLAN_AUTO", 1) != 0; plan_pack = flag("NRQ_PLAN_PACK"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
+    no_split = flag("NRQ_NO_SPLIT"); no_balance = flag("NRQ_NO_BALANCE"); no_lists = flag("NRQ_NO_LISTS"); no_wb12 = flag("NRQ_NO_WB12"); host_plan_auto = num("NRQ_HOST_PLAN_AUTO", 1) != 0; plan_pack = flag("NRQ_PLAN_PACK"); tiny_any = flag("NRQ_TINY_ANY"); reserve_cus = (int)num("NRQ_RESERVE_CUS", -1); no_plan_stream = flag("NRQ_NO_PLAN_STREAM");
     no_plan_split = flag("NRQ_NO_PLAN_SPLIT");
     plan_small_state = !flag("NRQ_PLAN_BIG_STATE"); plan_no_wg128 = flag("NRQ_PLAN_NO_WG128");
   }
@@ -1597,7 +1598,11 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   const bool small = WB != 12 && lds_alloc(lds_bytes) * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg; /* (12-byte strips: big blocks) */
   /* single-wave workgroups when 12 or more images fit a CU (see the kernel; K=256: +26 % over five 256-thread workgroups) */
   const uint32_t tdiv = hdrs.size() > 1u ? ctx->tune.tiny_div_dec : ctx->tune.tiny_div;
-  const bool tiny = G == 1 && small && (uint64_t)lds_alloc(lds_bytes) * tdiv <= NRQ_LDS_MAX && !ctx->tune.no_tiny;
+  /* ... and when the launch has the strips to fill them: a lone block's 80 strips each get a 256-thread workgroup and a CU of their own
+   * (the reference's benchmark.c, one block per call, K=500: encode column 81 -> 106 Gbit/s without the single-wave form; from ~1000
+   * strips on -- 16 blocks of K=500 -- the single-wave form is the faster one again: 0.07 against 0.09 ms) */
+  const bool tiny = G == 1 && small && (uint64_t)lds_alloc(lds_bytes) * tdiv <= NRQ_LDS_MAX && !ctx->tune.no_tiny &&
+                    ((uint64_t)nblk * nstrips > 2u * (uint64_t)ctx->ncu || ctx->tune.tiny_any);
   const uint32_t nt = tiny ? 64u : small ? 256u : (uint32_t)NRQ_WG;
   uint32_t occ = NRQ_LDS_MAX / lds_alloc(lds_bytes ? lds_bytes : 1u);
   if (occ > 2048u / nt) occ = 2048u / nt;
@@ -2123,6 +2128,7 @@ int nrq_ctx_set_option(nrq_ctx *ctx, const char *name, long long value) {
   else if (n == "no_wb12") t.no_wb12 = value != 0;
   else if (n == "host_plan_auto") t.host_plan_auto = value != 0;
   else if (n == "plan_pack") t.plan_pack = value != 0;
+  else if (n == "tiny_any") t.tiny_any = value != 0;
   else if (n == "lds_max") t.lds_max = value > 0 && value <= (long long)NRQ_LDS_MAX ? (uint32_t)value : NRQ_LDS_MAX;
   else if (n == "no_plan_stream") t.no_plan_stream = value != 0;
   else if (n == "no_plan_split") t.no_plan_split = value != 0;

@@ -26,6 +26,8 @@ def ctx():
         # ... and about every FORM of it: a product context gives a batch of at most one block per compute unit the 1024-thread planner
         # workgroup; the 256- and 128-thread forms that batches of thousands of small blocks use are exercised here at a few blocks
         _CTX.set_option("plan_pack", 1)
+        # ... and the single-wave solve workgroups, which a product context keeps for launches of more than ~500 strips
+        _CTX.set_option("tiny_any", 1)
     return _CTX
 
 
