@@ -1052,7 +1052,8 @@ struct Tuning {
   uint64_t solve_grid = 0;   /* NRQ_SOLVE_GRID: persistent workgroups of the solve launch (0 = fill the device) */
   uint32_t max_wb = 16;      /* NRQ_MAX_WB: widest strip considered */
   bool no_wb12 = false;      /* NRQ_NO_WB12: strip widths 16, 8, 4, 2 only (round 5's set) */
-  bool tiny_any = false;      /* "tiny_any" / NRQ_TINY_ANY: single-wave solve workgroups also for launches of a few hundred strips (tests) */
+  bool tiny_any = false;      /* "tiny_any" / NRQ_TINY_ANY: the solve's throughput forms whatever the launch size (tests): single-wave workgroups also for a
+                               * few hundred strips, 256-thread ones also for a lone mid-size block */
   bool plan_pack = false;     /* NRQ_PLAN_PACK: small blocks' planner workgroups share a CU whatever the block count */
   bool host_plan_auto = true; /* NRQ_HOST_PLAN_AUTO=0: a call of one or two small blocks is planned by the planner kernel like any other */
   int prof_base = 2;         /* NRQ_PROF_BASE: stamp the free-form marks are measured from */
@@ -1595,7 +1596,10 @@ template <int WB> int launch_wb(nrq_ctx *ctx, int slot, const nrq_job *d_jobs, u
   const bool by_block = nrq_map_by_block(nblk) && !ctx->tune.map_spread;
   /* workgroup shape: the full-size workgroup when a strip image needs more than half of the CU's LDS, 256-thread ones
    * when two or more fit */
-  const bool small = WB != 12 && lds_alloc(lds_bytes) * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg; /* (12-byte strips: big blocks) */
+  /* (a launch whose strips each get a CU of their own -- a lone block of the reference's harness -- takes the full-size workgroup from
+   * K ~ 1200 on: encode column of benchmark.c K=1500 208 -> 225 Gbit/s, K=3000 294 -> 315, K=4000 313 -> 333; below, the same) */
+  const bool lone = (uint64_t)nblk * ((T + WB - 1) / WB) <= (uint64_t)ctx->ncu && max_slots >= 1200u && !ctx->tune.tiny_any;
+  const bool small = WB != 12 && lds_alloc(lds_bytes) * ctx->tune.small_div <= NRQ_LDS_MAX && !ctx->tune.big_wg && !lone; /* (12-byte strips: big blocks) */
   /* single-wave workgroups when 12 or more images fit a CU (see the kernel; K=256: +26 % over five 256-thread workgroups) */
   const uint32_t tdiv = hdrs.size() > 1u ? ctx->tune.tiny_div_dec : ctx->tune.tiny_div;
   /* ... and when the launch has the strips to fill them: a lone block's 80 strips each get a 256-thread workgroup and a CU of their own
