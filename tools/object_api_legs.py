@@ -3,6 +3,8 @@ host buffers in, host buffers out, PCIe both ways, upload / solve / download ove
 (include/nanorq_batch.h).  One object of Z source blocks of K symbols of T bytes; block b loses the source symbols
 lost[b] and receives len(lost[b]) + spare repair symbols instead (the object layer takes gaps + 2 up front and holds the
 rest in reserve, nanorq_api.c rep_upfront)."""
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (the host process's to set before its first HIP call: include/nanorq.h)
 import ctypes as C
 import time
 
