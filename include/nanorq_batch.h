@@ -88,7 +88,7 @@ void nanorq_trim(void);
  * tuning switches and the fault injection the tests use ("fail_after").  Returns what nrq_ctx_set_option returns, -1 without
  * such a device.  Two switches belong to the object layer itself (any `dev`): "book_threads" n -- host threads that book a packet
  * batch of nanorq_decoder_add_symbols(_async), each the blocks sbn mod n (0 = default: NANORQ_HIP_BOOK_THREADS, else half the
- * cores the process may use, at most 8) -- and "book_min" -- symbols from which a batch is booked by more than one thread
+ * cores the process may use, at most 16; up to 32 when set) -- and "book_min" -- symbols from which a batch is booked by more than one thread
  * (0 = default, 65536).  Result codes and bytes do not depend on either. */
 int nanorq_hip_option(size_t dev, const char *name, long long value);
 

@@ -221,6 +221,13 @@ int nrq_ctl_copy(nrq_ctx *ctx, int stream, void *d_dst, const void *h_pinned, si
 /* the same with the destination addresses already on the device (enqueue only: no staging of the list, nothing waited for) */
 int nrq_scatter_symbols_dev(nrq_ctx *ctx, int stream, const void *d_blob, uint32_t n, uint32_t T, const uint64_t *d_dst);
 
+/* Rows by address pair (enqueue only): row k, T bytes, from address d_pairs[2k] to address d_pairs[2k+1] (0 = skip); either side
+ * may be page-locked host memory the device can address.  The receiver's repaired symbols go from their device rows straight to
+ * their places in the caller's page-locked output buffer this way (nanorq_repair_all): no staging, no copy per row. */
+int nrq_move_rows_dev(nrq_ctx *ctx, int stream, const uint64_t *d_pairs, uint32_t n, uint32_t T);
+/* the address at which a kernel reaches page-locked host memory (hipHostMalloc'ed or hipHostRegister'ed); 0 = it cannot */
+uint64_t nrq_host_device_address(const void *p);
+
 /* Per-launch duration of the solve kernel, measured with HIP events recorded on the launch stream
  * immediately around each launch (bench.py's roofline leg).  enable(1) starts collecting; read()
  * synchronises, returns the durations of the launches since the last read/enable in launch order. */

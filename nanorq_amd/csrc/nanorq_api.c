@@ -85,6 +85,9 @@ struct blockst {
   void *d_rep;        /* device: repair symbols in arrival order, capacity d_rep_cap symbols */
   size_t d_rep_cap;
   bool dirty;         /* received source symbols have not reached the output context yet */
+  uint8_t *io_base;   /* page-locked output region the HOST has written every received source symbol of this block into, at ingestion
+                       * (as the reference does: nanorq.c:478-509 writes a source symbol to the output when it arrives); NULL: not so.
+                       * Then only the REPAIRED rows have to come down after the decode (nanorq_repair_all), a tenth of the block */
   uint32_t up_seq;    /* deferred ingestion: 1 + index (in the object's list for the block's device) of the last upload piece that
                        * carries symbols of this block; 0 = none in flight */
   /* decoded ahead of its nanorq_repair_block call, in the device batch of an earlier block's call (repair_ahead below):
@@ -173,11 +176,14 @@ static void gpu_lock(int di) { pthread_mutex_lock(&g_dev[di].lock); }
 static void gpu_unlock(int di) { pthread_mutex_unlock(&g_dev[di].lock); }
 size_t nanorq_devices(void) { return (size_t)ndev(); }
 /* object-layer switches of nanorq_hip_option (not the context's): threads that book a packet batch, and from how many symbols on */
-static int g_book_threads = -1;        /* -1: NANORQ_HIP_BOOK_THREADS, else half the cores this process may use, at most 8 */
+#define NRQ_BOOK_THREADS_MAX 32
+static int g_book_threads = -1;        /* -1: NANORQ_HIP_BOOK_THREADS (up to 32), else half the cores this process may use, at most 16 */
 static uint32_t g_book_min = 65536u;
+static int g_host_rows = -1;          /* -1: NANORQ_HIP_HOST_ROWS (default on), see host_rows_on() */
 int nanorq_hip_option(size_t dev, const char *name, long long value) {
-  if (name && !strcmp(name, "book_threads")) { g_book_threads = value > 0 ? (int)(value > 8 ? 8 : value) : -1; return 0; }
+  if (name && !strcmp(name, "book_threads")) { g_book_threads = value > 0 ? (int)(value > (long long)NRQ_BOOK_THREADS_MAX ? (long long)NRQ_BOOK_THREADS_MAX : value) : -1; return 0; }
   if (name && !strcmp(name, "book_min")) { g_book_min = value > 0 ? (uint32_t)value : 65536u; return 0; }
+  if (name && !strcmp(name, "host_rows")) { g_host_rows = value != 0; return 0; }
   if (dev >= (size_t)ndev()) return -1;
   gpu_lock((int)dev);
   const int rc = nrq_ctx_set_option(g_dev[dev].c, name, value);
@@ -863,6 +869,15 @@ static bool flush_dev_block(nanorq *rq, uint8_t sbn, struct blockst *b, struct i
  * reference's call does: the verdict is the block's own, a rank-deficient block stays retryable (a new symbol clears the
  * cached verdict), a recovered block stays recovered whatever arrives later (the solution is unique).
  * NANORQ_HIP_REPAIR_AHEAD=0 switches it off (one block per call). */
+/* Received source symbols of device-resident blocks are written into a page-locked output region by the HOST at ingestion, and only
+ * the repaired rows come down after the decode ("host_rows" option / NANORQ_HIP_HOST_ROWS=0: whole blocks come down, as in round 5) */
+static bool host_rows_on(void) {
+  if (g_host_rows < 0) {
+    const char *e = getenv("NANORQ_HIP_HOST_ROWS");
+    g_host_rows = !(e && *e == '0');
+  }
+  return g_host_rows != 0;
+}
 static bool repair_ahead_on(void) {
   static int on = -1;
   if (on < 0) {
@@ -1350,7 +1365,7 @@ static bool dev_rep_reserve(nanorq *rq, struct blockst *b, size_t need, size_t k
 enum { RIX_NONE = 0xFFFFFFFFu, RIX_SRC = 0xFFFFFFFEu };
 static unsigned book_threads(void);
 static uint32_t book_min(void);
-#define NRQ_BOOK_THREADS 8u
+#define NRQ_BOOK_THREADS 32u
 struct addr_job { /* destination addresses of the symbols [k0, k1) of a batch that belong to device di (add_all_worker) */
   nanorq *rq;
   const uint32_t *tags, *rix;
@@ -1586,6 +1601,7 @@ struct book_job {
   bool early;
   unsigned t, P;
   size_t added;
+  uint8_t *obase; /* the output context's page-locked region (NULL: none): source symbols of device-resident blocks are written there now */
 };
 static uint32_t book_min(void) { /* symbols from which a batch is booked by several threads: "book_min", else NANORQ_HIP_BOOK_MIN, else 65536 */
   static int env = -1;
@@ -1605,7 +1621,10 @@ static unsigned book_threads(void) {
       cpu_set_t set;
       v = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) / 2 : 1; /* (the cores this process may use: a rank of N has its slice) */
     }
-    n = v < 1 ? 1 : v > (long)NRQ_BOOK_THREADS ? (int)NRQ_BOOK_THREADS : (int)v;
+    /* (default: at most 16 -- the threads also write the batch's source symbols into a page-locked output, 1.2 GB for 128 blocks
+     * of K=8192: receiver pipeline 331 / 394 / 377 Gbit/s with 8 / 16 / 32 threads; NANORQ_HIP_BOOK_THREADS takes up to 32) */
+    const long cap = e && *e && atol(e) > 0 ? (long)NRQ_BOOK_THREADS : 16;
+    n = v < 1 ? 1 : v > cap ? (int)cap : (int)v;
   }
   return (unsigned)n;
 }
@@ -1616,6 +1635,9 @@ static void *book_worker(void *arg) {
   uint8_t owner[NRQ_Z_MAX];
   for (unsigned s_ = 0; s_ < NRQ_Z_MAX; s_++) owner[s_] = (uint8_t)(j->P > 1 ? s_ % j->P : j->t);
   size_t added = 0; /* (a local: the jobs lie side by side, and a counter bumped per symbol in each made their cache lines travel) */
+  size_t xoff[NRQ_Z_MAX], xlen[NRQ_Z_MAX];
+  uint8_t xknown[NRQ_Z_MAX]; /* 0 = not looked at, 1 = extent known, 2 = no extent */
+  memset(xknown, 0, sizeof(xknown));
   for (uint32_t k = 0; k < j->n; k++) {
     const uint8_t sbn = (uint8_t)(j->tags[k] >> 24);
     if (owner[sbn] != j->t) continue; /* (a table, not sbn % P: a division per symbol and thread was the whole gain) */
@@ -1636,10 +1658,19 @@ static void *book_worker(void *arg) {
                       * thread's first one costs it the runtime's per-thread set-up, a millisecond under the device lock */
         b->dev = true;
         j->newdev[sbn] = 1;
+        b->io_base = j->obase; /* (from its first symbol on, or not at all) */
+      } else if (b->io_base != j->obase && !xknown[sbn]) {
+        b->io_base = NULL; /* another output, or none, this time: the block's rows come down whole after the decode, as before */
       }
+      if (!xknown[sbn]) xknown[sbn] = b->io_base && block_extent(rq, sbn, b->K, &xoff[sbn], &xlen[sbn]) ? 1 : 2;
+      if (xknown[sbn] == 2) b->io_base = NULL;
       if (r == NANORQ_SYM_ADDED && !j->touched[sbn]) { j->touched[sbn] = 1; j->nrep0[sbn] = b->nrep; }
       if (r == NANORQ_SYM_ADDED && esi < b->K) {
         j->rix[k] = RIX_SRC;
+        if (b->io_base) { /* the symbol's place in the output, written by this thread while the packets travel to the device */
+          const size_t o = (size_t)esi * T;
+          if (o < xlen[sbn]) memcpy(b->io_base + xoff[sbn] + o, j->p + (size_t)k * T, xlen[sbn] - o < T ? xlen[sbn] - o : T);
+        }
       } else if (r == NANORQ_SYM_ADDED) {
         if (!rep_reserve_host(rq, b)) r = NANORQ_SYM_ERR;
         else {
@@ -1742,7 +1773,7 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
   bool bstarted[NRQ_BOOK_THREADS];
   for (unsigned t = 0; t < P; t++) {
     bj[t] = (struct book_job){.rq = rq, .p = p, .tags = tags, .n = n, .results = results, .io = io, .rix = rix, .nrep0 = nrep0, .touched = touched,
-                              .newdev = newdev, .early = early_blob != NULL, .t = t, .P = P, .added = 0};
+                              .newdev = newdev, .early = early_blob != NULL, .t = t, .P = P, .added = 0, .obase = io && host_rows_on() ? obase : NULL};
     bstarted[t] = false;
   }
   for (unsigned t = 1; t < P; t++) bstarted[t] = pthread_create(&bth[t], NULL, book_worker, &bj[t]) == 0;
@@ -1802,11 +1833,11 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
       struct blockst *b = touched[sbn] ? rq->blocks[sbn] : NULL;
       if (!b) continue;
       b->nrep = nrep0[sbn];
-      if (newdev[sbn]) { b->dev = false; b->dirty = false; } /* (d_src stays allocated for the next attempt) */
+      if (newdev[sbn]) { b->dev = false; b->dirty = false; b->io_base = NULL; } /* (d_src stays allocated for the next attempt) */
     }
   } else {
     for (uint32_t k = 0; k < n; k++)
-      if (rix[k] == RIX_SRC) rq->blocks[(uint8_t)(tags[k] >> 24)]->dirty = true;
+      if (rix[k] == RIX_SRC && !rq->blocks[(uint8_t)(tags[k] >> 24)]->io_base) rq->blocks[(uint8_t)(tags[k] >> 24)]->dirty = true;
   }
   free(rix);
   if (diag_on())
@@ -1928,6 +1959,51 @@ static void *repair_all_worker(void *arg) {
         ev_up_borrowed[ci] = true;
       }
     }
+    /* Device-resident blocks whose received source symbols the host wrote into the output at ingestion (blockst::io_base): only
+     * their REPAIRED rows come down -- by a kernel that writes each from its device row to its place in the page-locked output
+     * (address pairs, built here: the lost lists are known before the decode; one launch per chunk behind its solve). */
+    uint64_t *pairs = NULL, *d_pairs = NULL; /* (src, dst) per lost row, blocks in todo order */
+    uint32_t *pair0 = calloc((size_t)n + 1u, sizeof(uint32_t)); /* first pair of block k; pair0[k + 1] - pair0[k] = its pairs (0: whole block comes down) */
+    bool pairs_pinned = false;
+    size_t pairs_bytes = 0;
+    uint8_t *obase = NULL;
+    size_t olen = 0;
+    ok = ok && pair0 != NULL;
+    if (ok && io && host_rows_on() && ioctx_dma_region(io, &obase, &olen)) {
+      const uint64_t odev = nrq_host_device_address(obase);
+      uint32_t np = 0;
+      for (unsigned k = 0; k < n; k++) {
+        struct blockst *b = rq->blocks[todo[k]];
+        size_t off, len;
+        pair0[k] = np;
+        if (odev && b->dev && b->io_base == obase && !b->dirty && block_extent(rq, (uint8_t)todo[k], b->K, &off, &len) && len == (size_t)b->K * T &&
+            off + len <= olen)
+          np += nlost[k];
+      }
+      pair0[n] = np;
+      pairs_bytes = (((size_t)np * 16u) + 15u) & ~(size_t)15u;
+      if (np) {
+        pairs = host_alloc(pairs_bytes >= PIN_MIN ? pairs_bytes : PIN_MIN, &pairs_pinned);
+        void *dp = NULL;
+        if (pairs && pairs_pinned && nrq_dev_alloc(c, pairs_bytes, &dp) == 0) {
+          d_pairs = dp;
+          for (unsigned k = 0; k < n; k++) {
+            if (pair0[k + 1] == pair0[k]) continue;
+            struct blockst *b = rq->blocks[todo[k]];
+            size_t off, len;
+            block_extent(rq, (uint8_t)todo[k], b->K, &off, &len);
+            for (uint32_t q = 0; q < nlost[k]; q++) {
+              const uint32_t e = lost[(size_t)k * lost_cap + q];
+              pairs[2u * (pair0[k] + q)] = (uint64_t)(uintptr_t)b->d_src + (uint64_t)e * T;
+              pairs[2u * (pair0[k] + q) + 1u] = odev + off + (uint64_t)e * T;
+            }
+          }
+          ok = nrq_ctl_copy(c, 2, d_pairs, pairs, pairs_bytes) == 0; /* (download stream: in front of the launches that read it) */
+        } else { /* no list to be had: every block comes down whole */
+          for (unsigned k = 0; k <= n; k++) pair0[k] = 0;
+        }
+      }
+    }
     const double t_lists = now_us();
     ok = ok && nrq_decode_blocks_vc(c, K, Kp, (uint32_t)T, n, sv, lost, nlost, (uint32_t)lost_cap, resi, nuse, navail, (uint32_t)rep_cap, rv, status,
                                     NULL, C, ev_done, ev_up) == 0;
@@ -1944,7 +2020,9 @@ static void *repair_all_worker(void *arg) {
           continue;
         }
         if (b->dev) {
-          if (io) ok = flush_dev_block(rq, sbn, b, io, true);
+          if (io && d_pairs && pair0[k + 1] > pair0[k]) /* (the received rows are in the output since they arrived: the repaired ones follow) */
+            ok = nrq_move_rows_dev(c, 2, d_pairs + 2u * (size_t)pair0[k], pair0[k + 1] - pair0[k], (uint32_t)T) == 0;
+          else if (io) ok = flush_dev_block(rq, sbn, b, io, true);
           if (ok) wrote[sbn] = 1; /* (bitmap and flag: behind the sync at the end) */
           dev_done[k] = ok;
         } else {
@@ -1988,6 +2066,9 @@ static void *repair_all_worker(void *arg) {
     else
       for (unsigned k = 0; k < n; k++) wrote[todo[k]] = 0;
     for (unsigned i = 0; i < ntmp; i++) nrq_dev_free(c, tmp_rep[i]);
+    if (d_pairs) nrq_dev_free(c, d_pairs);
+    if (pairs) host_free(pairs, pairs_pinned);
+    free(pair0);
     for (unsigned ci = 0; ci < nch; ci++) {
       if (ev_done) nrq_event_free(ev_done[ci]);
       if (ev_up && !(ev_up_borrowed && ev_up_borrowed[ci])) nrq_event_free(ev_up[ci]);

@@ -944,6 +944,22 @@ __global__ __launch_bounds__(128) void nrq_scatter_kernel(const uint8_t *__restr
   }
 }
 
+/* Rows by address pair: row k (T bytes) from src[k] to dst[k]; either may be page-locked HOST memory (the receiver's repaired
+ * symbols leave for their places in the caller's output buffer: no staging buffer, no copy per row).  pairs = src0, dst0, src1, ... */
+__global__ __launch_bounds__(128) void nrq_move_rows_kernel(const uint64_t *__restrict__ pairs, uint32_t T, uint32_t n) {
+  const uint32_t k = blockIdx.x;
+  if (k >= n) return;
+  const uint8_t *s = reinterpret_cast<const uint8_t *>(pairs[2u * k]);
+  uint8_t *d = reinterpret_cast<uint8_t *>(pairs[2u * k + 1u]);
+  if (!s || !d) return;
+  if ((T & 15u) == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
+    for (uint32_t off = threadIdx.x * 16u; off < T; off += 128u * 16u)
+      *reinterpret_cast<uint4 *>(d + off) = *reinterpret_cast<const uint4 *>(s + off);
+  } else {
+    for (uint32_t off = threadIdx.x; off < T; off += 128u) d[off] = s[off];
+  }
+}
+
 /* One workgroup per (symbol, block): out = XOR of the LT neighbours of `isi` among the L
  * intermediate symbols in HBM (coalesced 16-byte lanes along the symbol). */
 __global__ __launch_bounds__(NRQ_GEN_WG) void nrq_gen_kernel(rq_params p, uint32_t T, const uint8_t *__restrict__ inter,
@@ -2965,6 +2981,14 @@ int nrq_host_range_is_pinned(const void *p, size_t bytes) {
   return 1;
 }
 
+/* the address a kernel reaches page-locked host memory at (hipHostMalloc'ed or hipHostRegister'ed); 0 = it cannot */
+uint64_t nrq_host_device_address(const void *p) {
+  if (!p || !nrq_host_is_pinned(p)) return 0;
+  void *d = nullptr;
+  if (hipHostGetDevicePointer(&d, const_cast<void *>(p), 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return (uint64_t)(uintptr_t)d;
+}
+
 /* streams and events of the object layer's copy pipeline; stream selector: 0 = the context's stream, 1 = upload
  * stream, 2 = download stream */
 static hipStream_t sel_stream(nrq_ctx *ctx, int which) {
@@ -3054,6 +3078,15 @@ int nrq_scatter_symbols_dev(nrq_ctx *ctx, int stream, const void *d_blob, uint32
   if (n == 0) return 0;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipLaunchKernelGGL(nrq_scatter_kernel, dim3(n), dim3(128), 0, sel_stream(ctx, stream), (const uint8_t *)d_blob, T, d_dst, n);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+int nrq_move_rows_dev(nrq_ctx *ctx, int stream, const uint64_t *d_pairs, uint32_t n, uint32_t T) {
+  if (!ctx || !d_pairs || T == 0) return -1;
+  if (n == 0) return 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(nrq_move_rows_kernel, dim3(n), dim3(128), 0, sel_stream(ctx, stream), d_pairs, T, n);
   HIPCHK(ctx, hipGetLastError());
   return 0;
 }

@@ -365,8 +365,8 @@ def test_fault_injection_is_a_test_facility_only():
     import sys
     code = ("import os, sys, ctypes as C\n"
             "sys.path[:0] = [%r, %r]\n"
-            "import nanorq_amd\n"
-            "L = nanorq_amd.lib()\n"
+            "L = C.CDLL(os.path.join(sys.path[0], 'nanorq_amd', 'libnanorq_hip.so'))\n"   # (the library alone: the python package, a host, sets the variable itself)
+
             "L.nanorq_hip_option.restype = C.c_int\n"
             "L.nanorq_hip_option.argtypes = [C.c_size_t, C.c_char_p, C.c_longlong]\n"
             "L.nanorq_devices.restype = C.c_size_t\n"
