@@ -86,10 +86,14 @@ size_t nanorq_devices(void); /* contexts in use (0: no GPU could be opened -- ev
 void nanorq_trim(void);
 /* nrq_ctx_set_option (include/nanorq_hip.h) on the context of device number `dev` of the process (0 .. nanorq_devices() - 1):
  * tuning switches and the fault injection the tests use ("fail_after").  Returns what nrq_ctx_set_option returns, -1 without
- * such a device.  Two switches belong to the object layer itself (any `dev`): "book_threads" n -- host threads that book a packet
+ * such a device.  Three switches belong to the object layer itself (any `dev`): "host_rows" 0 / 1 -- with a page-locked output
+ * context given to nanorq_decoder_add_symbols(_async), the received SOURCE symbols of device-resident blocks are written to
+ * their places in the output by the host as they arrive (what the reference does per symbol, nanorq.c:478-509) and
+ * nanorq_repair_all brings down the repaired rows only (default 1; NANORQ_HIP_HOST_ROWS=0: whole blocks come down) --,
+ * "book_threads" n -- host threads that book a packet
  * batch of nanorq_decoder_add_symbols(_async), each the blocks sbn mod n (0 = default: NANORQ_HIP_BOOK_THREADS, else half the
  * cores the process may use, at most 16; up to 32 when set) -- and "book_min" -- symbols from which a batch is booked by more than one thread
- * (0 = default, 65536).  Result codes and bytes do not depend on either. */
+ * (0 = default, 65536).  Result codes and bytes do not depend on any of them. */
 int nanorq_hip_option(size_t dev, const char *name, long long value);
 
 #ifdef __cplusplus
