@@ -109,6 +109,8 @@ def parse():
     ap.add_argument("--one-list", action="store_true", help="round 5's launch rule for comparison: one solve launch per batch at the strip width "
                                                                 "EVERY block fits (no second block list)")
     ap.add_argument("--no-wb12", action="store_true", help="round 5's strip widths for comparison (16, 8, 4, 2 bytes: K ~ 8500-12000 on 8-byte strips)")
+    ap.add_argument("--replan-late", action="store_true", help="rebuild the next step's encode plan behind the decode launch (where it was until late in "
+                                                               "round 6) instead of behind the encode launch: for comparison")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffers-to-host-buffers leg")
     ap.add_argument("--one-object", choices=("auto", "on", "off"), default="auto",
                     help="ONE object over all N GPUs from rank 0's process (NANORQ_HIP_DEVICES=0..N-1, a host thread per device: "
@@ -571,6 +573,11 @@ def main():
     groups = [(bounds[g_], bounds[g_ + 1]) for g_ in range(nstreams)]
 
     replan_early = L >= 12000   # (the library's threshold for device-built encode plans, NRQ_ENCPLAN_DEV_MIN_L)
+    # host-built encode plans: rebuilt behind the encode launch while the build is shorter than the encode solve it runs beside
+    # (K=8192: ~5 ms against 6.1 -- behind the decode launch it had the decode solve's 5.9 ms and nothing to spare: 17.8 ms steps on
+    # a slower host core), behind the decode launch from L = 9000 on, where the build is the longer one and would hold the decode
+    # call back (K=10000: 22.1 / 21.4 ms per step behind the encode / the decode launch)
+    replan_behind_encode = L < 9000 and not args.replan_late
     # auto = always.  Big blocks: the planner's latency leaves the critical path (two steps' runs side by side).  Many small
     # blocks (the planner stays on the solve stream): what goes is the host's wait for the planner in the MIDDLE of the step and
     # its work behind it (2048 plan headers, the solve launch) with the GPU idle -- K=1000: 18.5 -> 18.1 ms on a quiet host,
@@ -625,9 +632,13 @@ def main():
             c_.encode_blocks(K, T, n_, src[lo].data_ptr(), K * T, rep[lo].data_ptr(), nrep * T, esis, inter[lo].data_ptr(),
                              L * T)
             enc_stats = enc_stats or c_.stats()
-        if not args.no_replan and replan_early:
-            # big K': the NEXT step's encode plan is built by the device planner, asynchronously on a stream of its own
-            # (nrq_precalculate only enqueues it) -- issued before the decode so that it runs beside this step's work
+        if not args.no_replan and (replan_early or replan_behind_encode):
+            # one encode plan per step (= per 256-block object, like nanorq_precalculate): the plan for the NEXT step's encode is
+            # rebuilt here, right behind this step's encode launch.  Big K': by the device planner, asynchronously on a stream of
+            # its own (nrq_precalculate only enqueues it), beside this step's work.  Smaller K': on the host (4-6 ms at K=8192),
+            # while the GPU runs this step's encode solve -- it used to sit behind the decode launch, where it had the decode solve
+            # (5.9 ms) to hide in and nothing to spare: with the decode plan built inside the decode call a slower host core turned
+            # every step from 14.0 into 17.8 ms (seen in two of three full default runs late in round 6)
             for c_ in ctxs:
                 c_.clear_plan_cache()
                 c_.precalculate(K)
@@ -663,9 +674,7 @@ def main():
                     ahead_out += 1
         if ph_rep and nstreams == 1:
             digests.append((ph, digest_of(ph, work_rows)))
-        if not args.no_replan and not replan_early:
-            # one encode plan per step (= per 256-block object, like nanorq_precalculate): the plan for the NEXT step's
-            # encode is rebuilt on the host here (once per context), while the GPU runs this step's solve
+        if not args.no_replan and not replan_early and not replan_behind_encode:   # (behind the decode launch: K' ~ 9000-12000, and --replan-late)
             for c_ in ctxs:
                 c_.clear_plan_cache()
                 c_.precalculate(K)
