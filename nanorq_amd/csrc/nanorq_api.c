@@ -1764,7 +1764,7 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
   unsigned P = 1;
   /* (... or when the threads have bytes to move: with a page-locked output they write the batch's source symbols to their places,
    * a copy of the whole batch -- 64 blocks of K=1000, 82 MB: 7.2 ms on one thread) */
-  if (n >= book_min() || (io && host_rows_on() && (size_t)n * T >= ((size_t)8 << 20))) {
+  if (n >= book_min() || (io && host_rows_on() && g_ndev == 1 && (size_t)n * T >= ((size_t)8 << 20))) {
     P = book_threads();
     for (unsigned sbn = 0; sbn < NRQ_Z_MAX && P > 1; sbn++) {
       const struct blockst *b = rq->blocks[sbn];
@@ -1775,7 +1775,8 @@ static size_t add_symbols_impl(nanorq *rq, const void *data, const uint32_t *tag
   bool bstarted[NRQ_BOOK_THREADS];
   for (unsigned t = 0; t < P; t++) {
     bj[t] = (struct book_job){.rq = rq, .p = p, .tags = tags, .n = n, .results = results, .io = io, .rix = rix, .nrep0 = nrep0, .touched = touched,
-                              .newdev = newdev, .early = early_blob != NULL, .t = t, .P = P, .added = 0, .obase = io && host_rows_on() ? obase : NULL};
+                              .newdev = newdev, .early = early_blob != NULL, .t = t, .P = P, .added = 0, .obase = io && host_rows_on() && g_ndev == 1 ? obase : NULL}; /* (one device: a kernel of device 0 writes the
+                               * repaired rows into the page-locked output; with several devices every decoded block comes down whole, as it did) */
     bstarted[t] = false;
   }
   for (unsigned t = 1; t < P; t++) bstarted[t] = pthread_create(&bth[t], NULL, book_worker, &bj[t]) == 0;
