@@ -830,3 +830,56 @@ def test_planner_workgroup_by_batch_size(G, orc, K, T, nblk):
     finally:
         c.set_option("plan_pack", 1)
     assert np.array_equal(res[0], res[1])
+
+
+def test_rows_by_address_pair(G):
+    """nrq_move_rows_dev: row k, T bytes, from address pairs[2k] to address pairs[2k+1], either side device memory or page-locked host
+    memory -- the receiver's repaired symbols leave for their places in the caller's output this way (nanorq_repair_all).  Rows of a
+    device buffer to scattered places of a page-locked host buffer and back, a zero pair skipped, T a multiple of 16 and not."""
+    import ctypes as C
+    c = G.ctx()
+    L = nanorq_amd.lib()
+    L.nrq_move_rows_dev.restype = C.c_int
+    L.nrq_move_rows_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.nrq_host_device_address.restype = C.c_uint64
+    L.nrq_host_device_address.argtypes = [C.c_void_p]
+    L.nanorq_pinned_alloc.restype = C.c_void_p
+    L.nanorq_pinned_alloc.argtypes = [C.c_size_t]
+    L.nanorq_pinned_free.argtypes = [C.c_void_p]
+    for T in (1280, 52):
+        n, slots = 37, 64
+        rows = np.frombuffer(payload(n * T, seed=T), np.uint8).reshape(n, T).copy()
+        d_rows = c.alloc(n * T)
+        c.upload(d_rows, rows)
+        hp = L.nanorq_pinned_alloc(slots * T)
+        host = np.ctypeslib.as_array((C.c_uint8 * (slots * T)).from_address(hp)).reshape(slots, T)
+        host[:] = 0xA5
+        hdev = L.nrq_host_device_address(C.c_void_p(hp))
+        assert hdev != 0 and L.nrq_host_device_address(C.c_void_p(rows.ctypes.data)) == 0   # (pageable memory: no)
+        place = np.random.default_rng(T).permutation(slots)[:n]
+        pairs = np.zeros(2 * n, np.uint64)
+        pairs[0::2] = d_rows + np.arange(n, dtype=np.uint64) * T
+        pairs[1::2] = hdev + place.astype(np.uint64) * T
+        pairs[2 * 5] = 0                                    # (skipped)
+        d_pairs = c.alloc(pairs.nbytes)
+        c.upload(d_pairs, pairs.view(np.uint8))
+        assert L.nrq_move_rows_dev(c._h, 0, C.c_void_p(d_pairs), n, T) == 0
+        c.sync()
+        for k in range(n):
+            assert np.array_equal(host[place[k]], rows[k] if k != 5 else np.full(T, 0xA5, np.uint8)), (T, k)
+        untouched = np.setdiff1d(np.arange(slots), place)
+        assert (host[untouched] == 0xA5).all()
+        # and back: host rows to a second device buffer
+        d_back = c.alloc(n * T)
+        c.memset(d_back, 0, n * T)
+        pairs[0::2] = hdev + place.astype(np.uint64) * T
+        pairs[1::2] = d_back + np.arange(n, dtype=np.uint64) * T
+        c.upload(d_pairs, pairs.view(np.uint8))
+        assert L.nrq_move_rows_dev(c._h, 0, C.c_void_p(d_pairs), n, T) == 0
+        c.sync()
+        back = c.download(d_back, n * T).reshape(n, T)
+        rows[5] = 0xA5
+        assert np.array_equal(back, rows)
+        for d in (d_rows, d_pairs, d_back):
+            c.free(d)
+        L.nanorq_pinned_free(C.c_void_p(hp))
